@@ -1,0 +1,144 @@
+"""Device plumbing: one HIP context per process, fields as torch CUDA(HIP) tensors.
+
+PyTorch is used for device memory, the stream and ``torch.distributed`` only; all arithmetic
+goes through ``libbeat_hip.so``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+
+
+class Context:
+    """Wraps ``beat_ctx``: device ordinal + the torch current stream of that device."""
+
+    _default = None
+
+    def __init__(self, device: int | None = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise _hip.BeatHipError(
+                "no MI355X/HIP device visible to PyTorch; the beat HIP backend has no CPU fallback"
+            )
+        self.torch = torch
+        self.lib = _hip.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        handle = C.c_void_p()
+        _hip.check(self.lib.beat_ctx_create(self.device_index, C.c_void_p(self.stream.cuda_stream), C.byref(handle)))
+        self.handle = handle
+
+    @classmethod
+    def default(cls) -> "Context":
+        if cls._default is None:
+            cls._default = cls()
+        return cls._default
+
+    def synchronize(self):
+        _hip.check(self.lib.beat_ctx_synchronize(self.handle))
+
+    # ------------------------------------------------------------------ allocation
+    def zeros(self, n: int, dtype=None):
+        torch = self.torch
+        return torch.zeros(int(n), dtype=dtype or torch.float64, device=self.device)
+
+    def from_numpy(self, a: np.ndarray):
+        torch = self.torch
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def field(self, n: int, plane: int) -> "Field":
+        return Field(self, n, plane)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.lib.beat_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Field:
+    """An N-vector with one ghost xy-plane on either side (see include/beat_hip.h)."""
+
+    def __init__(self, ctx: Context, n: int, plane: int, buf=None, offset: int | None = None):
+        self.ctx = ctx
+        self.n = int(n)
+        self.plane = int(plane)
+        if buf is None:
+            buf = ctx.zeros(self.n + 2 * self.plane)
+            offset = self.plane
+        self.buf = buf
+        self.offset = int(offset)
+        self.data = buf[self.offset : self.offset + self.n]  # interior view (torch)
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.data.data_ptr())
+
+    @property
+    def ghost_lo(self):
+        return self.buf[self.offset - self.plane : self.offset]
+
+    @property
+    def ghost_hi(self):
+        return self.buf[self.offset + self.n : self.offset + self.n + self.plane]
+
+    def numpy(self) -> np.ndarray:
+        return self.data.cpu().numpy()
+
+    def set(self, values) -> None:
+        torch = self.ctx.torch
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (self.n,)))
+        self.data.copy_(torch.from_numpy(arr))
+
+    def copy_from(self, other: "Field") -> None:
+        _hip.check(self.ctx.lib.beat_copy(self.ctx.handle, self.ptr, other.ptr, self.n))
+
+    def fill(self, value: float) -> None:
+        _hip.check(self.ctx.lib.beat_fill(self.ctx.handle, self.ptr, float(value), self.n))
+
+    def minmax(self) -> tuple[float, float]:
+        lo, hi = C.c_double(), C.c_double()
+        _hip.check(self.ctx.lib.beat_field_minmax(self.ctx.handle, self.ptr, self.n, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+
+class StateArray:
+    """(S, N) state-major array; every row is a Field-compatible N-vector (ghost planes on
+    both sides) so that any row can be handed to the PDE kernels without a copy."""
+
+    def __init__(self, ctx: Context, num_states: int, n: int, plane: int = 0):
+        self.ctx = ctx
+        self.S = int(num_states)
+        self.n = int(n)
+        self.plane = int(plane)
+        ld = self.n + 2 * self.plane
+        self.ld = (ld + 31) // 32 * 32  # 256-byte aligned rows
+        self.buf = ctx.zeros(self.S * self.ld + 32)
+        # make row starts (after the leading ghost plane) 16-byte aligned whenever plane is even
+        self.base = self.plane
+        self.rows = self.buf[self.base : self.base + self.S * self.ld].view(self.S, self.ld)[:, : self.n]
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.buf.data_ptr() + 8 * self.base)
+
+    def row_field(self, k: int) -> Field:
+        return Field(self.ctx, self.n, self.plane, buf=self.buf, offset=self.base + k * self.ld)
+
+    def numpy(self) -> np.ndarray:
+        return self.rows.cpu().numpy()
+
+    def set(self, values: np.ndarray) -> None:
+        torch = self.ctx.torch
+        values = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+        assert values.shape == (self.S, self.n), (values.shape, (self.S, self.n))
+        self.rows.copy_(torch.from_numpy(values))

@@ -1,0 +1,116 @@
+"""ctypes binding of ``libbeat_hip.so`` (C ABI declared in ``include/beat_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing or a call fails the
+product path raises.  Loading the library does not need a GPU (tests check the exported
+symbols on CPU-only machines); creating a context does.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = Path(os.environ.get("BEAT_HIP_LIBRARY", _HERE / "lib" / "libbeat_hip.so"))
+
+MODEL_SIMPLE_ODE = 0
+MODEL_FHN_DEMO = 1
+MODEL_FHN_README = 2
+MODEL_TP06_GRL1 = 3
+MAX_STIM = 8
+
+# slots of the PCG scalar state (see include/beat_hip.h)
+ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON = range(11)
+ST_SIZE = 16
+
+
+class BeatHipError(RuntimeError):
+    pass
+
+
+class KspInfo(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("converged_reason", C.c_int32),
+        ("residual_norm", C.c_double),
+        ("rhs_norm", C.c_double),
+    ]
+
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_dbl = C.c_double
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol declared in include/beat_hip.h
+SIGNATURES = {
+    "beat_abi_version": (_int, []),
+    "beat_last_error": (C.c_char_p, []),
+    "beat_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "beat_ctx_destroy": (_int, [_vp]),
+    "beat_ctx_set_stream": (_int, [_vp, _vp]),
+    "beat_ctx_synchronize": (_int, [_vp]),
+    "beat_malloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "beat_free": (_int, [_vp, _vp]),
+    "beat_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "beat_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "beat_ode_model_info": (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
+    "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
+    "beat_copy": (_int, [_vp, _vp, _vp, _i64]),
+    "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),
+    "beat_gather": (_int, [_vp, _vp, _vp, _vp, _i64]),
+    "beat_scatter": (_int, [_vp, _vp, _vp, _vp, _i64]),
+    "beat_pde_create": (_int, [_vp, C.POINTER(_i64), _int, _int, _vp, _vp, C.POINTER(_vp)]),
+    "beat_pde_destroy": (_int, [_vp]),
+    "beat_stencil_offsets": (C.POINTER(_int), []),
+    "beat_pde_set_timestep": (_int, [_vp, _dbl, _dbl, _dbl]),
+    "beat_pde_apply": (_int, [_vp, _int, _vp, _vp]),
+    "beat_pde_rhs": (_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _vp, _vp]),
+    "beat_pde_cg_begin": (_int, [_vp, _vp, _dbl, _dbl, _int]),
+    "beat_pde_spmv_dot": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_cg_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "beat_pde_cg_next": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_solve": (
+        _int,
+        [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],
+    ),
+    "beat_field_probe": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
+    "beat_field_minmax": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
+}
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libbeat_hip.so and declare every prototype.  Raises BeatHipError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.is_file():
+        raise BeatHipError(
+            f"HIP extension not built: {_LIB_PATH} is missing. Run `python -c 'import __graft_entry__ "
+            "as g; g.build()'` (or `make -C fenicsx-beat_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().beat_last_error().decode(errors="replace")
+        raise BeatHipError(f"libbeat_hip error {rc}: {msg}")
+
+
+def stencil_offsets() -> list[tuple[int, int, int]]:
+    p = load().beat_stencil_offsets()
+    return [(p[3 * k], p[3 * k + 1], p[3 * k + 2]) for k in range(15)]

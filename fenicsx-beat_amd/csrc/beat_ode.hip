@@ -1,0 +1,105 @@
+// Ionic (reaction) step kernels: one node per thread, state-major SoA rows, fp64.
+// Replaces  states[:] = fun(states=, t=, parameters=, dt=)  (src/beat/odesolver.py:67-79).
+//
+// HBM traffic per node-update: 16*NS bytes (each state row read once, written once) plus 8 bytes
+// when the transmembrane potential is mirrored into the PDE vector (dev_v_copy).
+#include "beat_common.h"
+#include "ionic_models.h"
+
+template <int NP>
+struct ParamPack {
+  double p[NP];
+};
+
+template <class Model, bool PER_NODE>
+__global__ __launch_bounds__(BEAT_BLOCK) void ode_step_kernel(
+    double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
+    typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
+    int v_index, double* __restrict__ v_copy) {
+  const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double y[Model::NS];
+#pragma unroll
+  for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];
+  if (PER_NODE) {
+    double pl[Model::NP];
+#pragma unroll
+    for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+    Model::step(y, pl, drv, t, dt);
+  } else {
+    Model::step(y, prm.p, drv, t, dt);
+  }
+#pragma unroll
+  for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
+  if (v_copy != nullptr) {
+#pragma unroll
+    for (int k = 0; k < Model::NS; ++k)
+      if (k == v_index) v_copy[i] = y[k];
+  }
+}
+
+template <class Model>
+static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
+                      int num_params, const double* ppn, int64_t pld, double t, double dt,
+                      int v_index, double* v_copy) {
+  BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
+               "model expects %d parameters, got %d", Model::NP, num_params);
+  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range",
+               v_index);
+  ParamPack<Model::NP> prm;
+  for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
+  typename Model::Derived drv = Model::derive(prm.p);
+  const unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  if (ppn != nullptr) {
+    BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
+    hipLaunchKernelGGL((ode_step_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
+                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy);
+  } else {
+    hipLaunchKernelGGL((ode_step_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
+                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy);
+  }
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_params) {
+  int ns, np;
+  switch (model_id) {
+    case BEAT_MODEL_SIMPLE_ODE: ns = SimpleOde::NS; np = SimpleOde::NP; break;
+    case BEAT_MODEL_FHN_DEMO: ns = FhnDemo::NS; np = FhnDemo::NP; break;
+    case BEAT_MODEL_FHN_README: ns = FhnReadme::NS; np = FhnReadme::NP; break;
+    case BEAT_MODEL_TP06_GRL1: ns = Tp06Grl1::NS; np = Tp06Grl1::NP; break;
+    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+  }
+  if (num_states) *num_states = ns;
+  if (num_params) *num_params = np;
+  return BEAT_OK;
+}
+
+extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                             const double* host_params, int num_params,
+                             const double* dev_params_per_node, int64_t params_ld, double t, double dt,
+                             int v_index, double* dev_v_copy) {
+  BEAT_REQUIRE(ctx != nullptr, "null context");
+  BEAT_REQUIRE(dev_states != nullptr, "null states");
+  BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
+  BEAT_REQUIRE((n + BEAT_BLOCK - 1) / BEAT_BLOCK < (int64_t)0x7fffffff, "n too large");
+  if (n == 0) return BEAT_OK;
+  switch (model_id) {
+    case BEAT_MODEL_SIMPLE_ODE:
+      return launch_ode<SimpleOde>(ctx, dev_states, n, ld, host_params, num_params,
+                                   dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
+    case BEAT_MODEL_FHN_DEMO:
+      return launch_ode<FhnDemo>(ctx, dev_states, n, ld, host_params, num_params,
+                                 dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
+    case BEAT_MODEL_FHN_README:
+      return launch_ode<FhnReadme>(ctx, dev_states, n, ld, host_params, num_params,
+                                   dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
+    case BEAT_MODEL_TP06_GRL1:
+      return launch_ode<Tp06Grl1>(ctx, dev_states, n, ld, host_params, num_params,
+                                  dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
+    default:
+      beat_set_error("unknown model id %d", model_id);
+      return BEAT_EINVAL;
+  }
+}

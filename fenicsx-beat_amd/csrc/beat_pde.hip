@@ -1,0 +1,615 @@
+// Diffusion step on a structured z-slab: matrix-free P1 operators as a 15-point stencil,
+// right-hand-side build and Jacobi-PCG.  Replaces dolfinx assemble_vector + PETSc KSP.solve of
+// src/beat/base_model.py:196-236 (forms: src/beat/monodomain_model.py:68-98).
+//
+// Data layout: a field is nx*ny*nz_local doubles, x fastest, with one ghost xy-plane addressable
+// on either side.  The 27x15 coefficient tables (one row per boundary type of a node) come from
+// the caller, derived by element assembly; the interior row (type 13) is passed by value so it
+// lives in SGPRs, the 26 boundary rows are looked up from a small device table by the few lanes
+// that need them.
+//
+// Stencil kernel structure (gfx950): a 256-thread workgroup owns a 64(x) x 16(y) tile and marches
+// along z through a chunk of planes.  Three (TY+2)x(TX+2) planes live in a ring of LDS slots; the
+// next plane is prefetched into registers while the current one is computed (global loads are
+// row-contiguous, 8 B/lane).  Every output needs 15 LDS reads (ds_read_b64, conflict-free: lanes
+// read consecutive doubles); a thread computes 4 rows so the compiler shares the in-plane reads.
+// Algorithmic HBM traffic: 8 B read + 8 B written per node per operator application; the tile
+// halo (+16%) and the chunk's two extra planes are re-reads that the XCD-local L2 mostly absorbs
+// (tiles are dealt to XCDs in contiguous runs, see tile_of_block()).
+#include "beat_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int TX = 64, TY = 16;
+constexpr int PITCH = TX + 2;
+constexpr int SLOT = (TY + 2) * PITCH;                      // 1188 doubles per staged plane
+constexpr int NLOAD = (SLOT + BEAT_BLOCK - 1) / BEAT_BLOCK;  // 5 staged values per thread
+constexpr int ROWS_PER_THREAD = TY / (BEAT_BLOCK / TX);      // 4
+constexpr int TARGET_BLOCKS = 1024;
+constexpr int TABW = 16;  // padded row width of the device coefficient tables
+
+// slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
+enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT };
+
+const int kOffsets[45] = {0, 0, 0,  1, 0, 0,  -1, 0, 0,  0, 1, 0,  0, -1, 0,  0, 0, 1,  0, 0, -1,
+                          1, 1, 0,  -1, -1, 0,  0, 1, 1,  0, -1, -1,  1, 0, 1,  -1, 0, -1,
+                          1, 1, 1,  -1, -1, -1};
+
+struct Coef15 {
+  double c[15];
+};
+
+struct Geom {
+  int nx, ny, nz;
+  int64_t plane;
+  int tiles_x, tiles_y, nchunks, zc, total;
+  int z_lo_phys, z_hi_phys;
+};
+
+struct StencilArgs {
+  const double* x;
+  double* y;    // APPLY: y | SPMV: q | RHS: r
+  double* y2;   // RHS: p
+  double* y3;   // RHS: x (copy of v_) or nullptr
+  const double* tab;   // APPLY/SPMV: operator table | RHS: mass table
+  const double* tab2;  // RHS: stiffness table
+  const double* dinv;  // RHS: 1/diag(A) per type
+  Coef15 ci, ci2;
+  double dinv_i;
+  double cm, omt_dt, dt;
+  const double* w[BEAT_MAX_STIM];
+  double amp[BEAT_MAX_STIM];
+  int nstim;
+  double* partials;
+  const double* st;
+};
+
+enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2 };
+
+__device__ __forceinline__ int axis_type(int i, int n, int lo_phys, int hi_phys) {
+  if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
+  if (i == 0 && lo_phys) return 0;
+  if (i == n - 1 && hi_phys) return 2;
+  return 1;
+}
+
+// Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so that
+// tiles sharing a halo share an L2.  Pure performance heuristic (placement is not relied upon).
+__device__ __forceinline__ int tile_of_block(int b, int total) {
+  const int per = (total + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ void stage_load(double (&reg)[NLOAD], const double* __restrict__ x,
+                                           const Geom& g, int x0, int y0, int gz) {
+  const bool zvalid = (gz >= 0 || !g.z_lo_phys) && (gz < g.nz || !g.z_hi_phys);
+  const double* __restrict__ base = x + (int64_t)gz * g.plane;
+#pragma unroll
+  for (int l = 0; l < NLOAD; ++l) {
+    const int idx = threadIdx.x + l * BEAT_BLOCK;
+    const int row = idx / PITCH, col = idx - row * PITCH;
+    const int gx = x0 + col - 1, gy = y0 + row - 1;
+    const bool ok = zvalid && idx < SLOT && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;
+    reg[l] = ok ? base[(int64_t)gy * g.nx + gx] : 0.0;
+  }
+}
+
+__device__ __forceinline__ void stage_store(const double (&reg)[NLOAD], double* __restrict__ slot) {
+#pragma unroll
+  for (int l = 0; l < NLOAD; ++l) {
+    const int idx = threadIdx.x + l * BEAT_BLOCK;
+    if (idx < SLOT) slot[idx] = reg[l];
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs a) {
+  __shared__ double lds[3 * SLOT];
+  __shared__ double red[4];
+  if (MODE == MODE_SPMV_DOT) {
+    if (a.st[STOP] != 0.0) return;  // convergence latch: nothing left to do in this solve
+  }
+  const int t = tile_of_block(blockIdx.x, g.total);
+  if (t >= g.total) return;
+  const int tile_x = t % g.tiles_x;
+  const int tile_y = (t / g.tiles_x) % g.tiles_y;
+  const int chunk = t / (g.tiles_x * g.tiles_y);
+  const int x0 = tile_x * TX, y0 = tile_y * TY;
+  const int z_begin = chunk * g.zc;
+  const int z_end = min(z_begin + g.zc, g.nz);
+
+  const int lx = threadIdx.x & (TX - 1);
+  const int wave = threadIdx.x >> 6;
+  const int gx = x0 + lx;
+  const int tx = axis_type(gx, g.nx, 1, 1);
+
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;  // block partial sums (mode dependent)
+
+  double reg[NLOAD];
+  stage_load(reg, a.x, g, x0, y0, z_begin - 1);
+  stage_store(reg, lds + ((z_begin - 1 + 3) % 3) * SLOT);
+  stage_load(reg, a.x, g, x0, y0, z_begin);
+  stage_store(reg, lds + (z_begin % 3) * SLOT);
+  stage_load(reg, a.x, g, x0, y0, z_begin + 1);
+
+  for (int z = z_begin; z < z_end; ++z) {
+    stage_store(reg, lds + ((z + 1) % 3) * SLOT);
+    if (z + 1 < z_end) stage_load(reg, a.x, g, x0, y0, z + 2);  // in flight during the compute
+    __syncthreads();
+    const double* __restrict__ Pm = lds + ((z + 2) % 3) * SLOT;  // plane z-1
+    const double* __restrict__ P0 = lds + (z % 3) * SLOT;
+    const double* __restrict__ Pp = lds + ((z + 1) % 3) * SLOT;
+    const int tz = axis_type(z, g.nz, g.z_lo_phys, g.z_hi_phys);
+#pragma unroll
+    for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
+      const int ly = wave * ROWS_PER_THREAD + rr;
+      const int gy = y0 + ly;
+      const int c = (ly + 1) * PITCH + (lx + 1);
+      double v[15];
+      v[0] = P0[c];
+      v[1] = P0[c + 1];
+      v[2] = P0[c - 1];
+      v[3] = P0[c + PITCH];
+      v[4] = P0[c - PITCH];
+      v[5] = Pp[c];
+      v[6] = Pm[c];
+      v[7] = P0[c + PITCH + 1];
+      v[8] = P0[c - PITCH - 1];
+      v[9] = Pp[c + PITCH];
+      v[10] = Pm[c - PITCH];
+      v[11] = Pp[c + 1];
+      v[12] = Pm[c - 1];
+      v[13] = Pp[c + PITCH + 1];
+      v[14] = Pm[c - PITCH - 1];
+      if (gx < g.nx && gy < g.ny) {
+        const int ty = axis_type(gy, g.ny, 1, 1);
+        const int type = tx + 3 * ty + 9 * tz;
+        const int64_t gi = (int64_t)z * g.plane + (int64_t)gy * g.nx + gx;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
+        if (MODE == MODE_RHS) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+          double di = a.dinv_i;
+          if (type != 13) {
+            s = 0.0;
+            s2 = 0.0;
+            const double* __restrict__ r1 = a.tab + type * TABW;
+            const double* __restrict__ r2 = a.tab2 + type * TABW;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+              s = fma(r1[k], v[k], s);
+              s2 = fma(r2[k], v[k], s2);
+            }
+            di = a.dinv[type];
+          }
+          // s = (Mass v)_i, s2 = (K v)_i
+          double stim = 0.0;
+          for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
+          const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
+          const double r = a.dt * (stim - s2);
+          const double zz = di * r;
+          a.y[gi] = r;
+          a.y2[gi] = zz;
+          if (a.y3 != nullptr) a.y3[gi] = v[0];
+          acc0 = fma(b, b, acc0);
+          acc1 = fma(r, zz, acc1);
+          acc2 = fma(r, r, acc2);
+        } else {
+          if (type != 13) {
+            s = 0.0;
+            const double* __restrict__ r1 = a.tab + type * TABW;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s = fma(r1[k], v[k], s);
+          }
+          a.y[gi] = s;
+          if (MODE == MODE_SPMV_DOT) acc0 = fma(v[0], s, acc0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (MODE == MODE_SPMV_DOT) {
+    const double s0 = beat_block_sum(acc0, red);
+    if (threadIdx.x == 0) a.partials[t] = s0;
+  } else if (MODE == MODE_RHS) {
+    const double s0 = beat_block_sum(acc0, red);
+    const double s1 = beat_block_sum(acc1, red);
+    const double s2 = beat_block_sum(acc2, red);
+    if (threadIdx.x == 0) {
+      a.partials[t] = s0;
+      a.partials[BEAT_MAX_PARTIALS + t] = s1;
+      a.partials[2 * BEAT_MAX_PARTIALS + t] = s2;
+    }
+  }
+}
+
+// Sum `count` block partials of `nsum` quantities in a fixed order and store them at out[0..nsum).
+__global__ __launch_bounds__(BEAT_BLOCK) void reduce_partials_kernel(const double* __restrict__ partials,
+                                                                     int count, int nsum,
+                                                                     double* __restrict__ out,
+                                                                     const double* __restrict__ st) {
+  __shared__ double red[4];
+  if (st != nullptr && st[STOP] != 0.0) return;
+  for (int k = 0; k < nsum; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += BEAT_BLOCK) s += partials[(int64_t)k * BEAT_MAX_PARTIALS + i];
+    s = beat_block_sum(s, red);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+__global__ void pcg_begin_kernel(double* st, double rtol, double atol, double max_it) {
+  const double bb = st[BB], rr = st[RR];
+  const double tr = rtol * rtol * bb, ta = atol * atol;
+  const double tol2 = tr > ta ? tr : ta;
+  st[TOL2] = tol2;
+  st[ITERS] = 0.0;
+  st[RTOL] = rtol;
+  st[ATOL] = atol;
+  st[MAXIT] = max_it;
+  st[BETA] = 0.0;
+  const bool done = rr <= tol2;
+  st[STOP] = done ? 1.0 : 0.0;
+  st[REASON] = done ? (rr <= tr ? 2.0 : 3.0) : 0.0;
+}
+
+__global__ void pcg_next_kernel(double* st) {
+  if (st[STOP] != 0.0) return;
+  st[BETA] = st[RZN] / st[RZ];
+  st[RZ] = st[RZN];
+  st[RR] = st[RRN];
+  st[ITERS] += 1.0;
+  const double tr = st[RTOL] * st[RTOL] * st[BB];
+  if (st[RR] <= st[TOL2]) {
+    st[STOP] = 1.0;
+    st[REASON] = st[RR] <= tr ? 2.0 : 3.0;
+  } else if (st[ITERS] >= st[MAXIT]) {
+    st[STOP] = 1.0;
+    st[REASON] = -3.0;
+  }
+}
+
+// x += alpha p ; r -= alpha q ; partial sums of r.z (z = D^-1 r) and r.r.  Row-per-wave so the node
+// type (hence 1/diag) needs no integer division per element.
+__global__ __launch_bounds__(BEAT_BLOCK) void cg_update_kernel(Geom g, const double* __restrict__ st,
+                                                               double* __restrict__ x,
+                                                               double* __restrict__ r,
+                                                               const double* __restrict__ p,
+                                                               const double* __restrict__ q,
+                                                               const double* __restrict__ dinv,
+                                                               double dinv_i, double* __restrict__ partials) {
+  __shared__ double red[4];
+  if (st[STOP] != 0.0) return;
+  const double alpha = st[RZ] / st[PQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = g.ny * g.nz;
+  double s_rz = 0.0, s_rr = 0.0;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int iz = row / g.ny, iy = row - iz * g.ny;
+    const int tyz = 3 * axis_type(iy, g.ny, 1, 1) + 9 * axis_type(iz, g.nz, g.z_lo_phys, g.z_hi_phys);
+    const int64_t base = (int64_t)row * g.nx;
+    for (int ix = lane; ix < g.nx; ix += 64) {
+      const int type = axis_type(ix, g.nx, 1, 1) + tyz;
+      const double di = (type == 13) ? dinv_i : dinv[type];
+      const int64_t i = base + ix;
+      const double pi = p[i], qi = q[i];
+      const double xi = fma(alpha, pi, x[i]);
+      const double ri = fma(-alpha, qi, r[i]);
+      x[i] = xi;
+      r[i] = ri;
+      s_rz = fma(ri * di, ri, s_rz);
+      s_rr = fma(ri, ri, s_rr);
+    }
+  }
+  const double a0 = beat_block_sum(s_rz, red);
+  const double a1 = beat_block_sum(s_rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = a0;
+    partials[BEAT_MAX_PARTIALS + blockIdx.x] = a1;
+  }
+}
+
+// p = D^-1 r + beta p
+__global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const double* __restrict__ st,
+                                                                const double* __restrict__ r,
+                                                                double* __restrict__ p,
+                                                                const double* __restrict__ dinv,
+                                                                double dinv_i) {
+  if (st[STOP] != 0.0) return;
+  const double beta = st[BETA];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = g.ny * g.nz;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int iz = row / g.ny, iy = row - iz * g.ny;
+    const int tyz = 3 * axis_type(iy, g.ny, 1, 1) + 9 * axis_type(iz, g.nz, g.z_lo_phys, g.z_hi_phys);
+    const int64_t base = (int64_t)row * g.nx;
+    for (int ix = lane; ix < g.nx; ix += 64) {
+      const int type = axis_type(ix, g.nx, 1, 1) + tyz;
+      const double di = (type == 13) ? dinv_i : dinv[type];
+      const int64_t i = base + ix;
+      p[i] = fma(beta, p[i], di * r[i]);
+    }
+  }
+}
+
+}  // namespace
+
+struct beat_pde {
+  beat_ctx* ctx = nullptr;
+  Geom g{};
+  int64_t n = 0;
+  double h_mass[27 * 15], h_stiff[27 * 15];
+  double h_A[27 * 15], h_B[27 * 15], h_dinv[27];
+  bool have_dt = false;
+  double C_m = 1.0, theta = 0.5, dt = 0.0;
+  // device: 4 padded tables (A, B, Mass, K), then dinv[32]
+  double* d_tabs = nullptr;
+  double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
+  int last_iters = -1;
+  unsigned vec_grid = 1;
+  const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
+  const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * TABW; }
+};
+
+static Coef15 interior(const double* tab) {
+  Coef15 c;
+  for (int k = 0; k < 15; ++k) c.c[k] = tab[13 * 15 + k];
+  return c;
+}
+
+static int upload_tables(beat_pde* pde);
+
+extern "C" const int* beat_stencil_offsets(void) { return kOffsets; }
+
+extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
+                               const double* host_mass_tab, const double* host_stiff_tab,
+                               beat_pde** out) {
+  BEAT_REQUIRE(ctx != nullptr && n != nullptr && host_mass_tab && host_stiff_tab && out, "null argument");
+  BEAT_REQUIRE(n[0] >= 1 && n[1] >= 1 && n[2] >= 1, "node counts must be >= 1");
+  BEAT_REQUIRE(n[0] * n[1] * n[2] < ((int64_t)1 << 40) && n[0] < (1 << 30) && n[1] * n[2] < (1LL << 31),
+               "grid too large");
+  beat_pde* p = new beat_pde();
+  p->ctx = ctx;
+  Geom& g = p->g;
+  g.nx = (int)n[0];
+  g.ny = (int)n[1];
+  g.nz = (int)n[2];
+  g.plane = n[0] * n[1];
+  g.z_lo_phys = z_lo_phys ? 1 : 0;
+  g.z_hi_phys = z_hi_phys ? 1 : 0;
+  g.tiles_x = (g.nx + TX - 1) / TX;
+  g.tiles_y = (g.ny + TY - 1) / TY;
+  const int tiles = g.tiles_x * g.tiles_y;
+  int nchunks = std::max(1, (TARGET_BLOCKS + tiles - 1) / tiles);
+  nchunks = std::min(nchunks, g.nz);
+  g.zc = (g.nz + nchunks - 1) / nchunks;
+  g.nchunks = (g.nz + g.zc - 1) / g.zc;
+  const int64_t total = (int64_t)tiles * g.nchunks;
+  if (total > BEAT_MAX_PARTIALS) {
+    // fall back to fewer, longer chunks
+    g.nchunks = std::max(1, (int)(BEAT_MAX_PARTIALS / tiles));
+    g.zc = (g.nz + g.nchunks - 1) / g.nchunks;
+    g.nchunks = (g.nz + g.zc - 1) / g.zc;
+  }
+  BEAT_REQUIRE((int64_t)tiles * g.nchunks <= BEAT_MAX_PARTIALS, "xy plane too large: %d tiles", tiles);
+  g.total = tiles * g.nchunks;
+  p->n = n[0] * n[1] * n[2];
+  const int64_t rows = (int64_t)g.ny * g.nz;
+  p->vec_grid = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (rows + 3) / 4));
+  std::memcpy(p->h_mass, host_mass_tab, sizeof(p->h_mass));
+  std::memcpy(p->h_stiff, host_stiff_tab, sizeof(p->h_stiff));
+  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
+  BEAT_HIP_CHECK(hipMalloc(&p->d_tabs, sizeof(double) * (4 * 27 * TABW + 32)));
+  BEAT_HIP_CHECK(hipMalloc(&p->d_st, sizeof(double) * 16));
+  BEAT_HIP_CHECK(hipMemsetAsync(p->d_st, 0, sizeof(double) * 16, ctx->stream));
+  const int rc = upload_tables(p);  // Mass / K usable before the first set_timestep
+  if (rc) return rc;
+  *out = p;
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_destroy(beat_pde* pde) {
+  if (pde == nullptr) return BEAT_OK;
+  (void)hipFree(pde->d_tabs);
+  (void)hipFree(pde->d_st);
+  delete pde;
+  return BEAT_OK;
+}
+
+static int upload_tables(beat_pde* pde) {
+  const double C_m = pde->C_m, theta = pde->theta, dt = pde->dt;
+  std::vector<double> h(4 * 27 * TABW + 32, 0.0);
+  for (int t = 0; t < 27; ++t) {
+    for (int k = 0; k < 15; ++k) {
+      const double m = pde->h_mass[t * 15 + k], s = pde->h_stiff[t * 15 + k];
+      pde->h_A[t * 15 + k] = C_m * m + theta * dt * s;
+      pde->h_B[t * 15 + k] = C_m * m - (1.0 - theta) * dt * s;
+      h[(0 * 27 + t) * TABW + k] = pde->h_A[t * 15 + k];
+      h[(1 * 27 + t) * TABW + k] = pde->h_B[t * 15 + k];
+      h[(2 * 27 + t) * TABW + k] = m;
+      h[(3 * 27 + t) * TABW + k] = s;
+    }
+    const double diag = pde->h_A[t * 15];
+    pde->h_dinv[t] = diag != 0.0 ? 1.0 / diag : 0.0;
+    h[4 * 27 * TABW + t] = pde->h_dinv[t];
+  }
+  // stream-ordered: later kernels on ctx->stream see the new tables
+  BEAT_HIP_CHECK(hipMemcpyAsync(pde->d_tabs, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice,
+                                pde->ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(pde->ctx->stream));  // h goes out of scope
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, double dt) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  pde->C_m = C_m;
+  pde->theta = theta;
+  pde->dt = dt;
+  pde->have_dt = true;
+  pde->last_iters = -1;
+  return upload_tables(pde);
+}
+
+static inline unsigned stencil_grid(const Geom& g) { return (unsigned)(((g.total + 7) / 8) * 8); }
+
+extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y) {
+  BEAT_REQUIRE(pde != nullptr && dev_x && dev_y, "null argument");
+  BEAT_REQUIRE(which >= 0 && which < 4, "which must be 0..3");
+  BEAT_REQUIRE(which >= 2 || pde->have_dt, "beat_pde_set_timestep has not been called");
+  BEAT_REQUIRE(dev_x != dev_y, "in-place apply is not supported");
+  const double* host_tab = which == 0 ? pde->h_A : which == 1 ? pde->h_B : which == 2 ? pde->h_mass : pde->h_stiff;
+  StencilArgs a{};
+  a.x = dev_x;
+  a.y = dev_y;
+  a.tab = pde->d_tab(which);
+  a.ci = interior(host_tab);
+  hipLaunchKernelGGL((stencil_kernel<MODE_APPLY>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
+                     pde->ctx->stream, pde->g, a);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+static int launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+                     (const double*)pde->ctx->d_partials, count, nsum, out, st);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                            const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r,
+                            double* dev_p, double* dev_red) {
+  BEAT_REQUIRE(pde != nullptr && dev_v_prev && dev_x && dev_r && dev_p && dev_red, "null argument");
+  BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+  BEAT_REQUIRE(dev_r != dev_v_prev && dev_p != dev_v_prev && dev_r != dev_p, "r, p must be distinct work fields");
+  StencilArgs a{};
+  a.x = dev_v_prev;
+  a.y = dev_r;
+  a.y2 = dev_p;
+  a.y3 = (dev_x == dev_v_prev) ? nullptr : dev_x;
+  a.tab = pde->d_tab(2);
+  a.tab2 = pde->d_tab(3);
+  a.dinv = pde->d_dinv();
+  a.ci = interior(pde->h_mass);
+  a.ci2 = interior(pde->h_stiff);
+  a.dinv_i = pde->h_dinv[13];
+  a.cm = pde->C_m;
+  a.omt_dt = (1.0 - pde->theta) * pde->dt;
+  a.dt = pde->dt;
+  a.nstim = 0;
+  for (int k = 0; k < n_stim; ++k) {
+    if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
+    a.w[a.nstim] = host_dev_stim_w[k];
+    a.amp[a.nstim] = host_stim_amp[k];
+    ++a.nstim;
+  }
+  a.partials = pde->ctx->d_partials;
+  hipLaunchKernelGGL((stencil_kernel<MODE_RHS>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
+                     pde->ctx->stream, pde->g, a);
+  BEAT_LAUNCH_CHECK();
+  return launch_reduce(pde, pde->g.total, 3, dev_red, nullptr);
+}
+
+extern "C" int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, double atol, int max_it) {
+  BEAT_REQUIRE(pde != nullptr && dev_st, "null argument");
+  hipLaunchKernelGGL(pcg_begin_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st, rtol, atol,
+                     (double)max_it);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
+  BEAT_REQUIRE(pde != nullptr && dev_p && dev_q && dev_st, "null argument");
+  BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  StencilArgs a{};
+  a.x = dev_p;
+  a.y = dev_q;
+  a.tab = pde->d_tab(0);
+  a.ci = interior(pde->h_A);
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  hipLaunchKernelGGL((stencil_kernel<MODE_SPMV_DOT>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
+                     pde->ctx->stream, pde->g, a);
+  BEAT_LAUNCH_CHECK();
+  return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
+}
+
+extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,
+                                  const double* dev_p, const double* dev_q) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_r && dev_p && dev_q, "null argument");
+  hipLaunchKernelGGL(cg_update_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_x, dev_r, dev_p, dev_q, pde->d_dinv(), pde->h_dinv[13],
+                     pde->ctx->d_partials);
+  BEAT_LAUNCH_CHECK();
+  return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
+}
+
+extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p, "null argument");
+  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cg_pupdate_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_p, pde->d_dinv(), pde->h_dinv[13]);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
+                              const double* const* host_dev_stim_w, const double* host_stim_amp,
+                              int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
+                              int max_it, beat_ksp_info* info) {
+  BEAT_REQUIRE(pde != nullptr && dev_work != nullptr, "null argument");
+  BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "beat_pde_solve is the single-slab path");
+  BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
+  const int64_t fld = pde->n + 2 * pde->g.plane;
+  double* r = dev_work + pde->g.plane;
+  double* p = r + fld;
+  double* q = p + fld;
+  double* st = pde->d_st;
+  int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, p, st);
+  if (rc) return rc;
+  if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
+  beat_ctx* ctx = pde->ctx;
+  double* h = ctx->h_pinned;
+  int launched = 0;
+  int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  while (true) {
+    chunk = std::min(chunk, max_it - launched);
+    for (int it = 0; it < chunk; ++it) {
+      if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
+      if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
+      if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
+    }
+    launched += chunk;
+    BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (h[STOP] != 0.0 || launched >= max_it) break;
+    chunk = 2;
+  }
+  const int iters = (int)h[ITERS];
+  pde->last_iters = iters;
+  int reason = (int)h[REASON];
+  if (h[STOP] == 0.0) reason = -3;  // max_it == launched without the latch (max_it = 0)
+  if (info) {
+    info->iterations = iters;
+    info->converged_reason = reason;
+    info->residual_norm = std::sqrt(h[RR]);
+    info->rhs_norm = std::sqrt(h[BB]);
+  }
+  if (reason < 0) {
+    beat_set_error("PCG did not converge in %d iterations (||r|| = %.3e, ||b|| = %.3e)", iters,
+                   std::sqrt(h[RR]), std::sqrt(h[BB]));
+    return BEAT_ENOTCONV;
+  }
+  return BEAT_OK;
+}

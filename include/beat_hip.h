@@ -1,0 +1,182 @@
+/*
+ * beat_hip.h -- C ABI of libbeat_hip.so, the MI355X (gfx950) device library behind the
+ * operator-split monodomain hot path of fenicsx-beat.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below replaces the
+ * arithmetic that one reference call site delegates to NumPy / DOLFINx / PETSc, cited as
+ * file:line into the reference tree (src/beat/...).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative BEAT_E* code otherwise; no exception
+ *    crosses the ABI; beat_last_error() returns the text of the most recent failure
+ *    (thread-local).
+ *  - all `double*` named dev_* are DEVICE pointers owned by the caller (the Python layer
+ *    allocates them as torch tensors / hipMalloc blocks); host pointers are named host_* and
+ *    are only read during the call.
+ *  - calls enqueue work on the context's HIP stream and return immediately unless the
+ *    description says "synchronises".
+ *  - an N-vector ("field") is the nodal array of one slab of a structured grid, x fastest:
+ *    id = ix + nx*(iy + ny*iz_local).  Every field passed to a PDE function must be
+ *    addressable one xy-plane (nx*ny doubles) BEFORE its first and AFTER its last element:
+ *    those are the ghost planes of the z-slab decomposition (filled by the halo exchange on
+ *    interior slab faces, ignored on physical boundaries, but they must hold finite numbers).
+ *  - one host thread drives one context; contexts are not thread-safe.
+ */
+#ifndef BEAT_HIP_H
+#define BEAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEAT_OK 0
+#define BEAT_EINVAL -1      /* bad argument (shape, null pointer, unknown model) */
+#define BEAT_EHIP -2        /* a HIP runtime call failed */
+#define BEAT_ENOTCONV -3    /* PCG hit max_it without meeting the tolerance */
+#define BEAT_ENOMEM -4
+
+#define BEAT_ABI_VERSION 1
+
+/* cell-model ids (ionic step kernels) */
+#define BEAT_MODEL_SIMPLE_ODE 0 /* v' = -a s, s' = b v, forward Euler; tests/test_odesolver.py:11-17 */
+#define BEAT_MODEL_FHN_DEMO 1   /* demos/fitzhughnagumo.py:45-80,224-225 (10 params, states [s,V]) */
+#define BEAT_MODEL_FHN_README 2 /* README.md:58-89 (11 params, states [s,v]) */
+#define BEAT_MODEL_TP06_GRL1 3  /* odes/tentusscher_panfilov_2006 (.ode) + gotranx GRL1 (demos/niederer_benchmark.py:82-99) */
+
+#define BEAT_STENCIL_POINTS 15
+#define BEAT_NODE_TYPES 27
+#define BEAT_MAX_STIM 8
+
+typedef struct beat_ctx beat_ctx;
+typedef struct beat_pde beat_pde;
+
+/* KSP-like result of one linear solve; mirrors what telemetry.py:67-76 reads from PETSc
+ * (getIterationNumber / getResidualNorm / getConvergedReason). */
+typedef struct beat_ksp_info {
+  int32_t iterations;
+  int32_t converged_reason; /* >0 converged (2 = rtol, 3 = atol), 0 still iterating, -3 = max_it */
+  double residual_norm;     /* ||r||_2 (global, unpreconditioned) */
+  double rhs_norm;          /* ||b||_2 (global) */
+} beat_ksp_info;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int beat_abi_version(void);
+const char* beat_last_error(void);
+/* device: HIP device ordinal.  hip_stream: an existing hipStream_t (e.g. torch's current
+ * stream) or NULL to use the null stream. */
+int beat_ctx_create(int device, void* hip_stream, beat_ctx** out);
+int beat_ctx_destroy(beat_ctx* ctx);
+int beat_ctx_set_stream(beat_ctx* ctx, void* hip_stream);
+int beat_ctx_synchronize(beat_ctx* ctx); /* synchronises */
+
+/* plain device-memory helpers so the library is usable from bare ctypes (no torch) */
+int beat_malloc(beat_ctx* ctx, size_t bytes, void** dev_out); /* zero-filled */
+int beat_free(beat_ctx* ctx, void* dev_ptr);
+int beat_memcpy_h2d(beat_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes); /* synchronises */
+int beat_memcpy_d2h(beat_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes); /* synchronises */
+
+/* ---- ionic (reaction) step: replaces  states[:] = fun(states, t, parameters, dt)
+ *      src/beat/odesolver.py:67-79 ----------------------------------------------------------- */
+/* Static description of a built-in cell model. */
+int beat_ode_model_info(int model_id, int* num_states, int* num_params);
+/* One explicit / GRL1 update of all num_states states at n nodes.
+ *  dev_states : (num_states, ld) row-major ("state-major" SoA as odesolver.py:149-153), updated
+ *               in place.
+ *  host_params: (num_params) uniform parameters, or NULL when dev_params_per_node is given.
+ *  dev_params_per_node : optional (num_params, params_ld) per-node parameters
+ *               (demos/pace_train.py:133-137), else NULL.
+ *  dev_v_copy : optional field; when non-NULL the updated row `v_index` is also written there
+ *               (fuses ode.to_dolfin + ode_to_pde + pde.assign_previous,
+ *               monodomain_solver.py:70-79). */
+int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                  const double* host_params, int num_params, const double* dev_params_per_node,
+                  int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy);
+
+/* row/field transfers: v_ode.x.array[:] = values[v_index] etc. (odesolver.py:164-170,
+ * utils.py:52-54, monodomain_model.py:59-60) */
+int beat_copy(beat_ctx* ctx, double* dev_dst, const double* dev_src, int64_t n);
+int beat_fill(beat_ctx* ctx, double* dev_dst, double value, int64_t n);
+/* dst[i] = src[idx[i]] (gather) / dst[idx[i]] = src[i] (scatter): marker-wise state transfer of
+ * DolfinMultiODESolver (odesolver.py:280-292). */
+int beat_gather(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, int64_t n);
+int beat_scatter(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, int64_t n);
+
+/* ---- diffusion (PDE) step: replaces LinearProblem assembly + KSP solve
+ *      src/beat/base_model.py:114-124,188-245 ---------------------------------------------- */
+/* Structured-grid operator of one z-slab.
+ *  n[3]        : local node counts (nx, ny, nz_local); unused axes = 1.
+ *  z_lo_phys / z_hi_phys : 1 if the slab's low / high z face is a physical (Neumann)
+ *               boundary, 0 if another slab continues there (ghost plane is then live).
+ *  host_mass_tab / host_stiff_tab : (27, 15) coefficient tables of the P1 consistent mass
+ *               matrix and of K = int M grad phi_j . grad phi_i for the 27 node types
+ *               (type = tx + 3 ty + 9 tz, t = 0 low face, 1 interior, 2 high face); column k
+ *               multiplies the node at offset beat_stencil_offsets()[k].  They are derived by
+ *               literal element assembly on DOLFINx's 6-tet (2-triangle) subdivision
+ *               (monodomain_model.py:68-98). */
+int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
+                    const double* host_mass_tab, const double* host_stiff_tab, beat_pde** out);
+int beat_pde_destroy(beat_pde* pde);
+/* (dx,dy,dz) of the 15 stencil points, 45 ints. */
+const int* beat_stencil_offsets(void);
+/* A = C_m*Mass + theta*dt*K ; B = C_m*Mass - (1-theta)*dt*K  (base_model.py:188-194, called
+ * when dt changes, :225-230). */
+int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, double dt);
+/* y = A x  /  y = B x  /  y = Mass x  /  y = K x   (which = 0,1,2,3); ghost planes of x must be
+ * current.  Returns nothing else; used by tests and by the distributed PCG. */
+int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y);
+
+/* --- Jacobi-PCG, expressed as stage functions so that the same kernels serve the single-slab
+ * solve (beat_pde_solve) and the slab-decomposed solve, where the caller all-reduces the marked
+ * slots of `dev_st` across ranks (RCCL) and exchanges ghost planes between the stages.
+ *
+ * dev_st: caller-owned device array of >= 16 doubles, the scalar state of one solve:
+ *   [0] b.b  [1] r.z  [2] r.r  [3] p.q  [4] r.z (new)  [5] r.r (new)  [6] tol^2  [7] beta
+ *   [8] stop latch (0/1)  [9] iterations  [10] converged reason  [11] rtol  [12] atol  [13] max_it
+ * Once the latch [8] is set every stage function becomes a no-op, so a caller may enqueue more
+ * iterations than needed without synchronising and read [8..10] back later.
+ *
+ * Right-hand side build (base_model.py:196-206 + _G_stim :247-248), in residual form with
+ * initial guess x0 = v_:
+ *     b  = B v_ + dt * sum_k amp[k] * w_k          (never stored; only b.b is reduced)
+ *     r  = b - A v_ = dt * ( -K v_ + sum_k amp[k] w_k )
+ *     x  = v_ (skipped when dev_x == dev_v_prev),  p = z = D^-1 r
+ * dev_stim_w[k] are the nodal weight fields int_{dz_k} phi_i (NULL entries / amp 0 skipped).
+ * Writes the LOCAL sums b.b, r.z, r.r to dev_st[0..2]  -> all-reduce dev_st[0:3]. */
+int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r,
+                 double* dev_p, double* dev_st);
+/* tol^2 = max(rtol^2 b.b, atol^2); latch if r.r <= tol^2 (PETSc-style ||r|| <= max(rtol ||b||, atol)). */
+int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, double atol, int max_it);
+/* q = A p (ghost planes of p must be current); LOCAL p.q -> dev_st[3]  -> all-reduce dev_st[3:4]. */
+int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
+/* alpha = st[1]/st[3]; x += alpha p; r -= alpha q; LOCAL r.D^-1 r, r.r -> dev_st[4..5]
+ * -> all-reduce dev_st[4:6]. */
+int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,
+                       const double* dev_p, const double* dev_q);
+/* beta = st[4]/st[1]; roll the scalars, count the iteration, set the latch on convergence or
+ * max_it; then p = D^-1 r + beta p   -> exchange ghost planes of p. */
+int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p);
+
+/* Whole single-slab step: rhs build + Jacobi-PCG to ||r|| <= max(rtol*||b||, atol), with all
+ * scalars kept on the device (one host synchronisation at the end to fill `info`).
+ * Replaces _update_rhs + KSP.solve of base_model.py:232-236 when the grid is not decomposed.
+ * dev_work: 3 fields (r, p, q) laid out back to back, each with its own ghost planes:
+ * size 3*(n_local + 2*nx*ny) doubles. Synchronises. */
+int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                   const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
+                   double rtol, double atol, int max_it, beat_ksp_info* info);
+
+/* P1 point evaluation: out[k] = sum_j w[k,j] * field[idx[k,j]], j < 4
+ * (scifem.evaluate_function stand-in, demos/niederer_benchmark.py:285).  Synchronises. */
+int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
+                     const double* host_w, int npts, double* host_out);
+/* min / max of a field (demos read v.max(), v.min() every step; avoids a full D2H).  Synchronises. */
+int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t n, double* host_min, double* host_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAT_HIP_H */

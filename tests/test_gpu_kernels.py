@@ -1,0 +1,365 @@
+"""GPU parity tests proper: every HIP kernel called through the C-ABI (ctypes) and compared
+with the CPU oracle on the same seeded inputs.  Floating-point tolerances are stated per test
+(all arithmetic is fp64; exp/log come from different libms on the two sides)."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr_array(ptrs):
+    arr = (C.c_void_p * max(1, len(ptrs)))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def _dbl_array(vals):
+    arr = (C.c_double * max(1, len(vals)))()
+    for i, v in enumerate(vals):
+        arr[i] = v
+    return arr
+
+
+def _ode_step(ctx, model_id, states, params, t, dt, v_index=0, v_copy=None, ppn=None):
+    from beat import _hip
+    from beat._device import StateArray
+
+    S, n = states.shape
+    sa = StateArray(ctx, S, n)
+    sa.set(states)
+    hp = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    npar = 0 if hp is None else len(hp)
+    ppn_t = None
+    if ppn is not None:
+        ppn_t = ctx.from_numpy(np.ascontiguousarray(ppn, dtype=np.float64))
+        npar = ppn.shape[0]
+    _hip.check(
+        ctx.lib.beat_ode_step(
+            ctx.handle, model_id, sa.ptr, n, sa.ld,
+            None if hp is None or ppn is not None else hp.ctypes.data_as(C.c_void_p), npar,
+            None if ppn_t is None else C.c_void_p(ppn_t.data_ptr()), 0 if ppn is None else ppn.shape[1],
+            float(t), float(dt), v_index, None if v_copy is None else v_copy.ptr,
+        )
+    )
+    ctx.synchronize()
+    return sa.numpy()
+
+
+def _random_tp06_states(n, seed):
+    from oracle import ionic
+
+    rng = np.random.default_rng(seed)
+    S = np.repeat(ionic.tp06_init_state_values()[:, None], n, axis=1)
+    idx = ionic.tp06_state_index
+    S[idx("V")] = rng.uniform(-95, 50, n)
+    for g in ["Xr1", "Xr2", "Xs", "m", "h", "j", "d", "f", "f2", "fCass", "s", "r", "R_prime"]:
+        S[idx(g)] = rng.uniform(0, 1, n)
+    S[idx("Ca_i")] = 10 ** rng.uniform(-4.2, -2.8, n)
+    S[idx("Ca_ss")] = 10 ** rng.uniform(-4, -2, n)
+    S[idx("Ca_SR")] = rng.uniform(1, 4.5, n)
+    S[idx("Na_i")] = rng.uniform(6, 12, n)
+    S[idx("K_i")] = rng.uniform(125, 145, n)
+    return S
+
+
+def test_simple_ode_and_fhn_match_oracle(hip_ctx):
+    from beat import _hip
+    from oracle import ionic
+
+    rng = np.random.default_rng(1)
+    n = 10007
+    st = rng.standard_normal((2, n))
+    out = _ode_step(hip_ctx, _hip.MODEL_SIMPLE_ODE, st, np.array([1.5, 0.5]), 0.0, 0.1)
+    ref = ionic.simple_ode_forward_euler(st, 0.0, 0.1, np.array([1.5, 0.5]))
+    np.testing.assert_allclose(out, ref, rtol=1e-15, atol=1e-15)
+    out = _ode_step(hip_ctx, _hip.MODEL_SIMPLE_ODE, st, None, 0.0, 0.1)
+    np.testing.assert_allclose(out, ionic.simple_ode_forward_euler(st, 0.0, 0.1), rtol=1e-15, atol=1e-15)
+
+    st = np.stack([rng.uniform(-0.5, 2, n), rng.uniform(-90, 45, n)])
+    p_demo = np.array([40.0, -85.0, 0.13, 0.013, 0.26, 0.1, 1.0, 100.0, 1.0, 0.0])
+    for t in (0.5, 3.0):
+        out = _ode_step(hip_ctx, _hip.MODEL_FHN_DEMO, st, p_demo, t, 0.01)
+        np.testing.assert_allclose(out, ionic.fhn_demo_forward_euler(st, t, 0.01, p_demo), rtol=1e-14, atol=1e-14)
+    p_readme = np.array([0.26, 0.1, 1.0, 0.13, 0.013, 125.0, -85.0, 40.0, 100.0, 1.0, 0.0])
+    for t in (0.5, 1.0, 3.0):
+        out = _ode_step(hip_ctx, _hip.MODEL_FHN_README, st, p_readme, t, 0.01)
+        np.testing.assert_allclose(out, ionic.fhn_readme_forward_euler(st, t, 0.01, p_readme), rtol=1e-14, atol=1e-14)
+
+
+def test_tp06_grl1_one_step_matches_oracle(hip_ctx):
+    """One GRL1 step on 20k random physiological states: |HIP - oracle| <= 1e-11 relative to the
+    state scale (different exp/log implementations; the update multiplies rounding by <= dt*|J|)."""
+    from beat import _hip
+    from oracle import ionic
+
+    n = 20011
+    S = _random_tp06_states(n, 11)
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    for dt in (0.05, 0.01):
+        out = _ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, P, 1.0, dt)
+        ref = ionic.tp06_generalized_rush_larsen(S, 1.0, dt, P)
+        scale = np.maximum(np.abs(ref), 1e-3)
+        err = np.abs(out - ref) / scale
+        assert np.isfinite(out).all()
+        assert err.max() < 1e-11, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_tp06_many_steps_and_stimulus_window(hip_ctx):
+    """2000 steps (20 ms at dt = 0.01) through an upstroke triggered by the model's own i_Stim:
+    trajectories agree to 1e-7 relative (error growth through the stiff upstroke)."""
+    from beat import _hip
+    from beat._device import StateArray
+    from oracle import ionic
+
+    n = 257
+    S0 = np.repeat(ionic.tp06_init_state_values()[:, None], n, axis=1)
+    S0[ionic.tp06_state_index("V")] += np.linspace(0, 5, n)
+    P = ionic.tp06_init_parameter_values(stim_start=1.0)
+    sa = StateArray(hip_ctx, 19, n)
+    sa.set(S0)
+    ref = S0.copy()
+    dt = 0.01
+    t = 0.0
+    for _ in range(2000):
+        _hip.check(hip_ctx.lib.beat_ode_step(hip_ctx.handle, _hip.MODEL_TP06_GRL1, sa.ptr, n, sa.ld,
+                                              P.ctypes.data_as(C.c_void_p), 53, None, 0, t, dt, 17, None))
+        ref = ionic.tp06_generalized_rush_larsen(ref, t, dt, P)
+        t += dt
+    out = sa.numpy()
+    assert ref[17].max() > 0.0  # the cells fired
+    err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-7, err.max()
+
+
+def test_tp06_per_node_parameters_and_v_copy(hip_ctx):
+    from beat import _hip
+    from beat._device import Field
+    from oracle import ionic
+
+    n = 1000
+    S = _random_tp06_states(n, 5)
+    P = np.repeat(ionic.tp06_init_parameter_values(stim_amplitude=0.0)[:, None], n, axis=1)
+    rng = np.random.default_rng(2)
+    P[ionic.tp06_parameter_index("g_Ks")] *= rng.uniform(0.5, 2.0, n)
+    P[ionic.tp06_parameter_index("g_to")] *= rng.uniform(0.5, 2.0, n)
+    vcopy = Field(hip_ctx, n, 0)
+    out = _ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, None, 0.0, 0.02, v_index=17, v_copy=vcopy, ppn=P)
+    ref = ionic.tp06_generalized_rush_larsen(S, 0.0, 0.02, P)
+    err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-11
+    np.testing.assert_array_equal(vcopy.numpy(), out[17])
+
+
+GRIDS = [
+    # (cells per axis, box lengths, conductivity)
+    ((70, 37, 9), (7.0, 3.7, 0.9), "aniso3"),
+    ((40, 14, 6), (20.0, 7.0, 3.0), "niederer"),
+    ((4, 1, 2), (2.0, 0.5, 1.0), "aniso3"),
+    ((130, 33), (1.0, 1.0), "aniso2"),
+    ((10,), (1.0,), 1.0),
+]
+
+
+def _conductivity(kind, dim):
+    if kind == "aniso3":
+        f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
+        return 9.5e-4 * np.outer(f0, f0) + 1.25e-4 * (np.eye(3) - np.outer(f0, f0))
+    if kind == "niederer":
+        return np.diag([9.5301e-4, 1.2576e-4, 1.2576e-4])
+    if kind == "aniso2":
+        return np.array([[2.0, 0.3], [0.3, 1.0]])
+    return kind
+
+
+def _make_pde(ctx, cells, L, Mk, z_lo_phys=1, z_hi_phys=1):
+    from beat import _hip, _stencil
+
+    dim = len(cells)
+    h = tuple(l / c for l, c in zip(L, cells))
+    mt, kt = _stencil.stencil_tables(dim, h, _conductivity(Mk, dim))
+    nn = [c + 1 for c in cells] + [1] * (3 - dim)
+    n3 = (C.c_int64 * 3)(*nn)
+    handle = C.c_void_p()
+    mt = np.ascontiguousarray(mt)
+    kt = np.ascontiguousarray(kt)
+    _hip.check(ctx.lib.beat_pde_create(ctx.handle, n3, z_lo_phys, z_hi_phys, mt.ctypes.data_as(C.c_void_p),
+                                       kt.ctypes.data_as(C.c_void_p), C.byref(handle)))
+    return handle, nn, mt, kt
+
+
+@pytest.mark.parametrize("cells,L,Mk", GRIDS)
+def test_stencil_operators_match_assembled_matrices(hip_ctx, cells, L, Mk):
+    """y = Mass x, K x, A x, B x from the LDS-tiled stencil vs the oracle's literally assembled
+    sparse matrices: <= 1e-13 relative to ||row||_1 * max|x| (15-term fp64 sums)."""
+    from beat import _hip
+    from beat._device import Field
+    from oracle import fem
+
+    ctx = hip_ctx
+    dim = len(cells)
+    mesh = fem.BoxMesh(cells, L)
+    handle, nn, _, _ = _make_pde(ctx, cells, L, Mk)
+    Mass = fem.assemble_mass(mesh)
+    K = fem.assemble_stiffness(mesh, _conductivity(Mk, dim))
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    _hip.check(ctx.lib.beat_pde_set_timestep(handle, C_m, theta, dt))
+    mats = {0: C_m * Mass + theta * dt * K, 1: C_m * Mass - (1 - theta) * dt * K, 2: Mass, 3: K}
+    n = mesh.num_nodes
+    plane = nn[0] * nn[1]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n)
+    fx, fy = Field(ctx, n, plane), Field(ctx, n, plane)
+    fx.set(x)
+    # poison the ghost planes: physical faces must ignore them
+    fx.ghost_lo.fill_(float("nan"))
+    fx.ghost_hi.fill_(float("nan"))
+    for which, mat in mats.items():
+        _hip.check(ctx.lib.beat_pde_apply(handle, which, fx.ptr, fy.ptr))
+        ctx.synchronize()
+        ref = mat @ x
+        scale = (abs(mat) @ np.ones(n)).max() * np.abs(x).max()
+        assert np.abs(fy.numpy() - ref).max() <= 1e-13 * scale, which
+    _hip.check(ctx.lib.beat_pde_destroy(handle))
+
+
+def test_stencil_slab_ghost_planes(hip_ctx):
+    """A z-slab with live ghost planes reproduces the rows of the undivided operator."""
+    from beat import _hip
+    from beat._device import Field
+    from oracle import fem
+
+    ctx = hip_ctx
+    cells, L = (20, 9, 11), (2.0, 0.9, 1.1)
+    mesh = fem.BoxMesh(cells, L)
+    A = fem.assemble_mass(mesh) + 0.3 * fem.assemble_stiffness(mesh, _conductivity("aniso3", 3))
+    nx, ny, nz = (c + 1 for c in cells)
+    plane = nx * ny
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(mesh.num_nodes)
+    ref = (A @ x).reshape(nz, plane)
+    X = x.reshape(nz, plane)
+    for z0, z1 in ((0, 4), (4, 9), (9, 12)):
+        from beat import _stencil
+
+        h = tuple(l / c for l, c in zip(L, cells))
+        mt, kt = _stencil.stencil_tables(3, h, _conductivity("aniso3", 3))
+        n3 = (C.c_int64 * 3)(nx, ny, z1 - z0)
+        handle = C.c_void_p()
+        _hip.check(ctx.lib.beat_pde_create(ctx.handle, n3, int(z0 == 0), int(z1 == nz),
+                                           mt.ctypes.data_as(C.c_void_p), kt.ctypes.data_as(C.c_void_p),
+                                           C.byref(handle)))
+        _hip.check(ctx.lib.beat_pde_set_timestep(handle, 1.0, 1.0, 0.3))
+        nloc = (z1 - z0) * plane
+        fx, fy = Field(ctx, nloc, plane), Field(ctx, nloc, plane)
+        fx.set(X[z0:z1].ravel())
+        if z0 > 0:
+            fx.ghost_lo.copy_(ctx.from_numpy(X[z0 - 1]))
+        if z1 < nz:
+            fx.ghost_hi.copy_(ctx.from_numpy(X[z1]))
+        _hip.check(ctx.lib.beat_pde_apply(handle, 0, fx.ptr, fy.ptr))
+        ctx.synchronize()
+        np.testing.assert_allclose(fy.numpy().reshape(-1, plane), ref[z0:z1], rtol=0, atol=1e-12)
+        _hip.check(ctx.lib.beat_pde_destroy(handle))
+
+
+@pytest.mark.parametrize("cells,L,Mk", GRIDS[:2] + GRIDS[3:])
+def test_pde_solve_matches_direct_solve(hip_ctx, cells, L, Mk):
+    """One theta-step: rhs build + Jacobi-PCG (rtol 1e-12) vs the oracle's sparse-LU solve of
+    (C_m Mass + theta dt K) v = (C_m Mass - (1-theta) dt K) v_ + dt b_stim: <= 1e-9 * max|v|."""
+    from beat import _hip
+    from beat._device import Field
+    from oracle import fem
+
+    ctx = hip_ctx
+    dim = len(cells)
+    mesh = fem.BoxMesh(cells, L)
+    Mten = _conductivity(Mk, dim)
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    if Mk == "aniso2" or Mk == 1.0:
+        C_m, dt = 1.0, 1e-3
+    handle, nn, _, _ = _make_pde(ctx, cells, L, Mk)
+    _hip.check(ctx.lib.beat_pde_set_timestep(handle, C_m, theta, dt))
+    n = mesh.num_nodes
+    plane = nn[0] * nn[1]
+    rng = np.random.default_rng(8)
+    v_prev = -85.0 + 100.0 * np.exp(-((mesh.x - 0.3 * np.array(L)) ** 2).sum(axis=1) / (0.05 * max(L) ** 2))
+    v_prev += 0.01 * rng.standard_normal(n)
+    cellsel = mesh.locate_cells(lambda x: x[0] <= 0.25 * L[0] + 1e-10)
+    w = fem.stimulus_weights(mesh, cellsel)
+    amp = 0.357
+    model = fem.OracleMonodomainModel(mesh, Mten, [fem.OracleStimulus(lambda t: amp, w)], C_m=C_m, theta=theta,
+                                      default_timestep=dt)
+    model.state[:] = v_prev
+    model.assign_previous()
+    model.step((0.0, dt))
+    fv, fx, fw = Field(ctx, n, plane), Field(ctx, n, plane), Field(ctx, n, plane)
+    fv.set(v_prev)
+    fw.set(w)
+    work = ctx.zeros(3 * (n + 2 * plane))
+    info = _hip.KspInfo()
+    _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([fw.ptr.value]), _dbl_array([amp]), 1, fx.ptr,
+                                      C.c_void_p(work.data_ptr()), 1e-12, 1e-50, 500, C.byref(info)))
+    out = fx.numpy()
+    assert info.converged_reason > 0 and 0 < info.iterations < 200
+    assert np.abs(out - model.state).max() <= 1e-9 * np.abs(model.state).max()
+    # the same iteration count as the oracle's restatement of the PCG (same algorithm, same x0)
+    A = (C_m * fem.assemble_mass(mesh) + theta * dt * fem.assemble_stiffness(mesh, Mten)).tocsr()
+    _, its, _ = fem.pcg_jacobi(A, model.rhs(theta * dt, dt), v_prev, rtol=1e-12)
+    assert abs(its - info.iterations) <= 1
+    _hip.check(ctx.lib.beat_pde_destroy(handle))
+
+
+def test_pde_solve_zero_rhs_and_latch(hip_ctx):
+    """b = 0 (M = 0, no stimulus, v_ = 0) converges in 0 iterations with reason > 0."""
+    from beat import _hip
+    from beat._device import Field
+
+    ctx = hip_ctx
+    handle, nn, _, _ = _make_pde(ctx, (10,), (1.0,), 0.0)
+    _hip.check(ctx.lib.beat_pde_set_timestep(handle, 1.0, 0.5, 0.4))
+    n, plane = 11, 11
+    fv, fx = Field(ctx, n, plane), Field(ctx, n, plane)
+    work = ctx.zeros(3 * (n + 2 * plane))
+    info = _hip.KspInfo()
+    _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([]), _dbl_array([]), 0, fx.ptr,
+                                      C.c_void_p(work.data_ptr()), 1e-10, 1e-50, 100, C.byref(info)))
+    assert info.iterations == 0 and info.converged_reason > 0
+    assert np.all(fx.numpy() == 0.0)
+
+
+def test_field_utilities(hip_ctx):
+    from beat import _hip
+    from beat._device import Field
+
+    ctx = hip_ctx
+    rng = np.random.default_rng(0)
+    n = 100003
+    a, b = Field(ctx, n, 0), Field(ctx, n, 0)
+    x = rng.standard_normal(n)
+    a.set(x)
+    b.copy_from(a)
+    np.testing.assert_array_equal(b.numpy(), x)
+    lo, hi = a.minmax()
+    assert lo == x.min() and hi == x.max()
+    b.fill(2.5)
+    assert np.all(b.numpy() == 2.5)
+    idx = rng.permutation(n)[: n // 3].astype(np.int64)
+    didx = ctx.from_numpy(idx)
+    g = Field(ctx, len(idx), 0)
+    _hip.check(ctx.lib.beat_gather(ctx.handle, g.ptr, a.ptr, C.c_void_p(didx.data_ptr()), len(idx)))
+    np.testing.assert_array_equal(g.numpy(), x[idx])
+    _hip.check(ctx.lib.beat_scatter(ctx.handle, b.ptr, g.ptr, C.c_void_p(didx.data_ptr()), len(idx)))
+    ref = np.full(n, 2.5)
+    ref[idx] = x[idx]
+    np.testing.assert_array_equal(b.numpy(), ref)
+    # P1 point evaluation
+    pidx = np.array([[0, 1, 2, 3], [5, 5, 5, 5]], dtype=np.int64)
+    w = np.array([[0.1, 0.2, 0.3, 0.4], [1.0, 0.0, 0.0, 0.0]])
+    out = np.zeros(2)
+    _hip.check(ctx.lib.beat_field_probe(ctx.handle, a.ptr, pidx.ctypes.data_as(C.c_void_p),
+                                        w.ctypes.data_as(C.c_void_p), 2, out.ctypes.data_as(C.c_void_p)))
+    np.testing.assert_allclose(out, [w[0] @ x[:4], x[5]], rtol=1e-15)
