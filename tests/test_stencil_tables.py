@@ -49,4 +49,8 @@ def test_interior_row_sums():
     mt, kt = _stencil.stencil_tables(3, (0.5, 0.5, 0.5), _aniso(3))
     assert abs(mt[13].sum() - 0.125) < 1e-15
     assert np.abs(kt.sum(axis=1)).max() < 1e-18
-    assert abs(mt[0].sum() - 0.125 / 8) < 1e-15  # corner node
+    # the corner on the shared v0-v7 diagonal belongs to all 6 tetrahedra of its only cell
+    assert abs(mt[0].sum() - 0.125 / 4) < 1e-15
+    assert abs(mt[26].sum() - 0.125 / 4) < 1e-15
+    # the corner (hi, lo, lo) = v1 belongs to 2 of the 6
+    assert abs(mt[2].sum() - 2 * 0.125 / 24) < 1e-15
