@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Headline benchmark: operator-split monodomain step (TP06 GRL1 ionic step + theta-rule
+diffusion solve) on a 512^3 anisotropic-fibre slab, dt = 0.01 ms  (BASELINE.json configs[3]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; the grid is cut into z-slabs (strong scaling: the 512^3 grid is fixed, the
+slabs shrink as N grows).  A "step" is one call of the hot path of
+``MonodomainSplittingSolver.step`` (src/beat/monodomain_solver.py:53-116, theta_split = 1,
+theta_pde = 0.5): ionic step on every node, then right-hand-side build + Jacobi-PCG to
+``--rtol`` relative to ||b||.  Inputs are synthetic and already resident in HBM when the timed
+region starts.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "fenicsx-beat_amd"))
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0  # measured streaming-copy ceiling, same guide
+
+S_L, S_T = 9.5301e-4, 1.2576e-4  # uA/mV, Niederer harmonic-mean conductivities / chi (mm mesh)
+C_M = 0.01  # uF/mm^2
+THETA = 0.5
+DT = 0.01
+H = 0.1  # mm
+
+
+def conductivity():
+    f0 = np.array([np.cos(np.pi / 6.0), np.sin(np.pi / 6.0), 0.0])
+    return S_L * np.outer(f0, f0) + S_T * (np.eye(3) - np.outer(f0, f0))
+
+
+def tp06_defaults():
+    from beat.models import tp06
+
+    ic = tp06.init_state_values(
+        V=-85.23, Xr1=0.00621, Xr2=0.4712, Xs=0.0095, m=0.00172, h=0.7444, j=0.7045, d=3.373e-05, f=0.7888,
+        f2=0.9755, fCass=0.9953, s=0.999998, r=2.42e-08, Ca_i=0.000126, R_prime=0.9073, Ca_SR=3.64,
+        Ca_ss=0.00036, Na_i=8.604, K_i=136.89,
+    )  # demos/niederer_benchmark.py:44-67
+    return ic, tp06.init_parameter_values(stim_amplitude=0.0), tp06.state_index("V")
+
+
+def init_states(ctx, states, ic, v_index, n_glob, slab, seed):
+    """TP06 resting state everywhere, V raised by a 60 mV Gaussian bump (sigma 2 mm) at the box
+    centre so that a depolarisation front travels through the timed steps, every other state
+    multiplied by (1 + 0.01 u), u ~ U(-1, 1) (seeded per rank)."""
+    torch = ctx.torch
+    nx = ny = n_glob
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(seed + slab.rank)
+    plane = nx * ny
+    zc = torch.arange(slab.z0, slab.z1, device=ctx.device, dtype=torch.float64) * H
+    yc = torch.arange(ny, device=ctx.device, dtype=torch.float64) * H
+    xc = torch.arange(nx, device=ctx.device, dtype=torch.float64) * H
+    c = 0.5 * (n_glob - 1) * H
+    for k in range(states.S):
+        row = states.rows[k]
+        if k == v_index:
+            for iz in range(slab.nz):
+                r2 = (zc[iz] - c) ** 2 + (yc[:, None] - c) ** 2 + (xc[None, :] - c) ** 2
+                row[iz * plane : (iz + 1) * plane] = (float(ic[k]) + 60.0 * torch.exp(-r2 / (2.0 * 2.0**2))).reshape(-1)
+        else:
+            u = torch.rand(row.shape[0], generator=gen, device=ctx.device, dtype=torch.float64) * 2.0 - 1.0
+            row.copy_(float(ic[k]) * (1.0 + 0.01 * u))
+            del u
+
+
+def cpu_baseline(n_side: int, steps: int, rtol: float):
+    """The oracle (CPU restatement: NumPy ionic step + SciPy-assembled P1 operators + Jacobi-PCG)
+    timed on this host, single thread, on an n_side^3 sample of the same workload."""
+    from oracle import fem, ionic
+
+    mesh = fem.BoxMesh((n_side - 1,) * 3, ((n_side - 1) * H,) * 3)
+    model = fem.OracleMonodomainModel(mesh, conductivity(), [], C_m=C_M, theta=THETA, default_timestep=DT,
+                                      solver="pcg", rtol=rtol)
+    ic = ionic.tp06_init_state_values()
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    vi = ionic.tp06_state_index("V")
+    S = np.repeat(ic[:, None], mesh.num_nodes, axis=1)
+    c = 0.5 * (n_side - 1) * H
+    r2 = ((mesh.x - c) ** 2).sum(axis=1)
+    S[vi] += 60.0 * np.exp(-r2 / (2.0 * (0.4 * c) ** 2 + 1e-300))
+    t = 0.0
+    tic = time.perf_counter()
+    its = 0
+    for _ in range(steps):
+        S = ionic.tp06_generalized_rush_larsen(S, t, DT, P)
+        model.state[:] = S[vi]
+        model.assign_previous()
+        model.step((t, t + DT))
+        S[vi] = model.state
+        its += model.last_its
+        t += DT
+    wall = time.perf_counter() - tic
+    return {
+        "value": mesh.num_nodes * steps / wall,
+        "unit": "node-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_side}^3 nodes x {steps} steps, TP06 GRL1 + P1 theta-rule PCG (avg {its / steps:.1f} its), "
+                  f"NumPy/SciPy oracle, {wall:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=512, help="nodes per axis of the cubic slab")
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="side of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=40)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from beat import _hip, _stencil
+    from beat._device import Context, StateArray
+    from beat._engine import DiffusionSolver, HipOps, Slab
+
+    ctx = Context(local_rank)
+    lib = ctx.lib
+    n = args.n
+    slab = Slab(n, rank, world)
+    plane = n * n
+    n_local = plane * slab.nz
+    mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
+    ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+    ops.set_timestep(C_M, THETA, DT)
+    solver = DiffusionSolver(ops, slab)
+
+    ic, params, v_index = tp06_defaults()
+    states = StateArray(ctx, len(ic), n_local, plane)
+    init_states(ctx, states, ic, v_index, n, slab, 1234)
+    v_field = states.row_field(v_index)  # PDE unknown lives in the V row: no ODE<->PDE copies
+    import ctypes as C
+
+    p_host = np.ascontiguousarray(params)
+    p_ptr = p_host.ctypes.data_as(C.c_void_p)
+
+    ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    iters = []
+
+    def step(t, i=None):
+        if i is not None:
+            ev_ode[i][0].record()
+        _hip.check(lib.beat_ode_step(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
+                                     len(p_host), None, 0, t, DT, v_index, None))
+        if i is not None:
+            ev_ode[i][1].record()
+        res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500)
+        if i is not None:
+            ev_pde_end[i].record()
+            iters.append(res.iterations)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t = 0.0
+    for _ in range(args.warmup):
+        step(t)
+        t += DT
+    barrier()
+    tic = time.perf_counter()
+    for i in range(args.steps):
+        step(t, i)
+        t += DT
+    barrier()
+    wall = time.perf_counter() - tic
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+
+    ode_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ode]))
+    pde_ms = float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(args.steps)]))
+    vmin, vmax = v_field.minmax()
+    finite = bool(np.isfinite(vmin) and np.isfinite(vmax))
+
+    if rank == 0:
+        n_total = n**3
+        k_avg = float(np.mean(iters)) if iters else 0.0
+        S = len(ic)
+        ode_bytes = 16.0 * S * n_local  # every state row read once + written once
+        achieved = ode_bytes / (ode_ms * 1e-3) / 1e9
+        step_bytes = (16.0 * S + 16.0 + 88.0 * k_avg) * n_total
+        out = {
+            "metric": "node_updates_per_sec",
+            "value": n_total * args.steps / wall,
+            "unit": "node-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n}^3-node anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy), TP06 GRL1 ionic step, "
+                            f"P1 consistent-mass theta=0.5 diffusion, Godunov splitting, dt=0.01 ms, "
+                            f"Jacobi-PCG rtol={args.rtol:g} (x0 = previous v)",
+                "nodes": n_total,
+                "states_per_node": S,
+                "parallelism": f"z-slabs x{world}",
+                "pcg_iterations_per_step": k_avg,
+                "ode_ms": ode_ms,
+                "pde_ms": pde_ms,
+                "v_min": vmin,
+                "v_max": vmax,
+                "finite": finite,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "ode_step_kernel<Tp06Grl1>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_node": 16.0 * S,
+                "whole_step": {
+                    "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,
+                    "achieved": step_bytes * args.steps / wall / 1e9 / world,
+                    "frac_of_8TBs_per_gpu": step_bytes * args.steps / wall / 1e9 / world / HBM_PEAK_GBS,
+                    "frac_of_6.29TBs_per_gpu": step_bytes * args.steps / wall / 1e9 / world / HBM_COPY_GBS,
+                },
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, args.rtol)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not finite:
+        raise SystemExit("non-finite membrane potential after the timed steps")
+
+
+if __name__ == "__main__":
+    main()

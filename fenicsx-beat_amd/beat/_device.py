@@ -122,9 +122,8 @@ class StateArray:
         self.plane = int(plane)
         ld = self.n + 2 * self.plane
         self.ld = (ld + 31) // 32 * 32  # 256-byte aligned rows
-        self.buf = ctx.zeros(self.S * self.ld + 32)
-        # make row starts (after the leading ghost plane) 16-byte aligned whenever plane is even
-        self.base = self.plane
+        self.base = self.plane  # leading ghost plane of row 0
+        self.buf = ctx.zeros(self.base + self.S * self.ld + 32)
         self.rows = self.buf[self.base : self.base + self.S * self.ld].view(self.S, self.ld)[:, : self.n]
 
     @property

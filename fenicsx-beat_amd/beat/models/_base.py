@@ -1,0 +1,104 @@
+"""Built-in cell models: handles the HIP backend recognises.
+
+A :class:`DeviceModel` is what the reference calls ``fun`` (src/beat/odesolver.py:70-76): it is
+still callable by keyword on NumPy arrays, ``fun(states=, t=, parameters=, dt=)`` returning the new
+``(S, N)`` array -- the call stages the arrays through the GPU and runs the same HIP kernel as the
+solver (there is no CPU implementation in the product) -- and it exposes the helper functions a
+gotranx-generated module has (``init_state_values``, ``init_parameter_values``, ``state_index``,
+``parameter_index``; demos/niederer_benchmark.py:66,99,212).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+class DeviceModel:
+    def __init__(self, name, model_id, states: dict, parameters: dict, v_name=None):
+        self.name = name
+        self.model_id = int(model_id)
+        self.state_names = tuple(states)
+        self.state_defaults = dict(states)
+        self.parameter_names = tuple(parameters)
+        self.parameter_defaults = dict(parameters)
+        self.v_name = v_name
+        self.__name__ = name
+
+    # ---- gotranx-module-like helpers -----------------------------------------------------
+    @property
+    def num_states(self) -> int:
+        return len(self.state_names)
+
+    @property
+    def num_parameters(self) -> int:
+        return len(self.parameter_names)
+
+    def state_index(self, name: str) -> int:
+        try:
+            return self.state_names.index(name)
+        except ValueError:
+            raise KeyError(f"Unknown state {name}") from None
+
+    def parameter_index(self, name: str) -> int:
+        try:
+            return self.parameter_names.index(name)
+        except ValueError:
+            raise KeyError(f"Unknown parameter {name}") from None
+
+    def init_state_values(self, **values) -> np.ndarray:
+        d = dict(self.state_defaults)
+        for k, v in values.items():
+            if k not in d:
+                raise KeyError(f"Unknown state {k}")
+            d[k] = v
+        return np.array([d[k] for k in self.state_names], dtype=np.float64)
+
+    def init_parameter_values(self, **values) -> np.ndarray:
+        d = dict(self.parameter_defaults)
+        for k, v in values.items():
+            if k not in d:
+                raise KeyError(f"Unknown parameter {k}")
+            d[k] = v
+        return np.array([d[k] for k in self.parameter_names], dtype=np.float64)
+
+    # ---- the reference's `fun` calling convention ---------------------------------------------
+    def __call__(self, states=None, t=0.0, parameters=None, dt=None, **kwargs):
+        """Advance ``states`` ((S,) or (S, N) NumPy) by one step on the GPU; returns a new array."""
+        from .. import _hip
+        from .._device import Context, StateArray
+
+        if dt is None:
+            raise TypeError("dt is required")
+        ctx = Context.default()
+        arr = np.asarray(states, dtype=np.float64)
+        one_d = arr.ndim == 1
+        a2 = arr.reshape(arr.shape[0], -1)
+        S, n = a2.shape
+        if S != self.num_states:
+            raise ValueError(f"{self.name} has {self.num_states} states, got {S}")
+        sa = StateArray(ctx, S, n)
+        sa.set(a2)
+        hp, ppn, pld = host_and_device_parameters(ctx, parameters, self.num_parameters, n)
+        _hip.check(
+            ctx.lib.beat_ode_step(ctx.handle, self.model_id, sa.ptr, n, sa.ld,
+                                  None if hp is None else hp.ctypes.data_as(C.c_void_p), self.num_parameters if (hp is not None or ppn is not None) else 0,
+                                  None if ppn is None else C.c_void_p(ppn.data_ptr()), pld, float(t), float(dt), 0, None)
+        )
+        out = sa.numpy()
+        return out[:, 0].copy() if one_d else out
+
+
+def host_and_device_parameters(ctx, parameters, num_parameters, n):
+    """Split ``parameters`` into (host (P,) array | None, device (P, N) tensor | None, ld)."""
+    if parameters is None:
+        return None, None, 0
+    p = np.asarray(parameters, dtype=np.float64)
+    if p.ndim == 1:
+        if p.shape[0] != num_parameters:
+            raise ValueError(f"expected {num_parameters} parameters, got {p.shape[0]}")
+        return np.ascontiguousarray(p), None, 0
+    if p.shape != (num_parameters, n):
+        raise ValueError(f"per-node parameters must have shape ({num_parameters}, {n}), got {p.shape}")
+    return None, ctx.from_numpy(np.ascontiguousarray(p)), n
