@@ -1,0 +1,34 @@
+"""beat (MI355X) -- HIP-native operator-split monodomain solver with the fenicsx-beat API surface.
+
+``beat.MonodomainModel``, ``beat.odesolver.DolfinODESolver`` and ``beat.MonodomainSplittingSolver``
+keep the reference's constructor signatures, methods and step semantics; meshes are structured
+boxes (``beat.grid`` provides the handful of dolfinx/ufl names the callers use) and all arithmetic
+runs in ``libbeat_hip.so``.  There is no CPU fallback."""
+
+from . import (  # noqa: F401
+    base_model,
+    conductivities,
+    geometry,
+    grid,
+    models,
+    monodomain_model,
+    monodomain_solver,
+    odesolver,
+    stimulation,
+    telemetry,
+    units,
+    utils,
+)
+from .monodomain_model import MonodomainModel
+from .monodomain_solver import MonodomainSplittingSolver
+from .stimulation import Stimulus
+from .telemetry import BaseMonitor, NullMonitor, PerformanceMonitor
+
+__version__ = "0.1.0"
+__program_name__ = "fenicsx-beat-amd"
+
+__all__ = [
+    "monodomain_model", "odesolver", "base_model", "MonodomainModel", "monodomain_solver",
+    "MonodomainSplittingSolver", "utils", "conductivities", "stimulation", "geometry", "grid", "models",
+    "Stimulus", "telemetry", "BaseMonitor", "NullMonitor", "PerformanceMonitor", "units",
+]

@@ -1,0 +1,812 @@
+"""Structured-grid stand-ins for the few dolfinx / ufl / scifem names the hot-path callers touch
+(demos/fitzhughnagumo.py, demos/niederer_benchmark.py, README.md, tests/test_monodomain*.py,
+tests/test_stimulation.py, tests/test_odesolver.py).
+
+The reference discretises on DOLFINx meshes of boxes (src/beat/geometry.py:78-139).  Here a box
+mesh *is* a structured grid with the same simplicial subdivision (see beat/_stencil.py), nodes
+numbered x-fastest, optionally cut into z-slabs (one per rank).  Nothing here computes on the hot
+path: functions hold their values in HBM (``Field``) and expose them through a lazy ``x.array``.
+"""
+
+from __future__ import annotations
+
+import math
+import operator
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _stencil
+
+default_scalar_type = np.float64
+
+
+# ------------------------------------------------------------------------------------------------
+# communicator stand-in
+# ------------------------------------------------------------------------------------------------
+class Comm:
+    """Minimal ``MPI.Intracomm`` look-alike over torch.distributed (rank/size/allreduce/Barrier)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    @staticmethod
+    def _dist():
+        try:
+            import torch.distributed as dist
+
+            return dist if dist.is_available() and dist.is_initialized() else None
+        except Exception:  # pragma: no cover
+            return None
+
+    @property
+    def rank(self) -> int:
+        d = self._dist()
+        return d.get_rank(self.group) if d else 0
+
+    @property
+    def size(self) -> int:
+        d = self._dist()
+        return d.get_world_size(self.group) if d else 1
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def Barrier(self):
+        d = self._dist()
+        if d:
+            d.barrier(self.group)
+
+    def allreduce(self, value, op=None):
+        d = self._dist()
+        if not d:
+            return value
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if d.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        d.all_reduce(t, group=self.group)
+        return float(t.item())
+
+
+COMM_WORLD = Comm()
+
+
+# ------------------------------------------------------------------------------------------------
+# tiny expression language (the subset of UFL used to describe stimuli and exact solutions)
+# ------------------------------------------------------------------------------------------------
+class Expr:
+    """Scalar expression of the spatial coordinate and of mutable ``Constant`` objects (time)."""
+
+    def evaluate(self, x=None):
+        raise NotImplementedError
+
+    def depends_on_x(self) -> bool:
+        return False
+
+    def depends_on_constants(self) -> bool:
+        return False
+
+    # arithmetic ---------------------------------------------------------------------------------
+    def __add__(self, o):
+        return BinOp(operator.add, self, as_expr(o))
+
+    def __radd__(self, o):
+        return BinOp(operator.add, as_expr(o), self)
+
+    def __sub__(self, o):
+        return BinOp(operator.sub, self, as_expr(o))
+
+    def __rsub__(self, o):
+        return BinOp(operator.sub, as_expr(o), self)
+
+    def __mul__(self, o):
+        return BinOp(operator.mul, self, as_expr(o))
+
+    def __rmul__(self, o):
+        return BinOp(operator.mul, as_expr(o), self)
+
+    def __truediv__(self, o):
+        return BinOp(operator.truediv, self, as_expr(o))
+
+    def __rtruediv__(self, o):
+        return BinOp(operator.truediv, as_expr(o), self)
+
+    def __pow__(self, o):
+        return BinOp(operator.pow, self, as_expr(o))
+
+    def __rpow__(self, o):
+        return BinOp(operator.pow, as_expr(o), self)
+
+    def __neg__(self):
+        return BinOp(operator.mul, Literal(-1.0), self)
+
+
+class Literal(Expr):
+    def __init__(self, value):
+        self.value = float(value)
+
+    def evaluate(self, x=None):
+        return self.value
+
+
+def as_expr(v) -> Expr:
+    if isinstance(v, Expr):
+        return v
+    return Literal(v)
+
+
+class BinOp(Expr):
+    def __init__(self, op, a: Expr, b: Expr):
+        self.op, self.a, self.b = op, a, b
+
+    def evaluate(self, x=None):
+        return self.op(self.a.evaluate(x), self.b.evaluate(x))
+
+    def depends_on_x(self):
+        return self.a.depends_on_x() or self.b.depends_on_x()
+
+    def depends_on_constants(self):
+        return self.a.depends_on_constants() or self.b.depends_on_constants()
+
+
+class Func(Expr):
+    def __init__(self, fn, a: Expr):
+        self.fn, self.a = fn, a
+
+    def evaluate(self, x=None):
+        return self.fn(self.a.evaluate(x))
+
+    def depends_on_x(self):
+        return self.a.depends_on_x()
+
+    def depends_on_constants(self):
+        return self.a.depends_on_constants()
+
+
+class Coordinate(Expr):
+    def __init__(self, axis: int):
+        self.axis = axis
+
+    def evaluate(self, x=None):
+        if x is None:
+            raise ValueError("expression depends on the spatial coordinate")
+        return x[self.axis]
+
+    def depends_on_x(self):
+        return True
+
+
+class SpatialCoordinate:
+    """``ufl.SpatialCoordinate(mesh)``: indexable, ``x[0]``, ``x[1]``, ..."""
+
+    def __init__(self, mesh=None):
+        self.mesh = mesh
+
+    def __getitem__(self, i: int) -> Coordinate:
+        return Coordinate(int(i))
+
+
+class Condition(Expr):
+    def __init__(self, op, a, b):
+        self.op, self.a, self.b = op, as_expr(a), as_expr(b)
+
+    def evaluate(self, x=None):
+        return self.op(self.a.evaluate(x), self.b.evaluate(x))
+
+    def depends_on_x(self):
+        return self.a.depends_on_x() or self.b.depends_on_x()
+
+    def depends_on_constants(self):
+        return self.a.depends_on_constants() or self.b.depends_on_constants()
+
+
+class Conditional(Expr):
+    def __init__(self, cond, a, b):
+        self.cond, self.a, self.b = cond, as_expr(a), as_expr(b)
+
+    def evaluate(self, x=None):
+        return np.where(self.cond.evaluate(x), self.a.evaluate(x), self.b.evaluate(x))
+
+    def depends_on_x(self):
+        return self.cond.depends_on_x() or self.a.depends_on_x() or self.b.depends_on_x()
+
+    def depends_on_constants(self):
+        return self.cond.depends_on_constants() or self.a.depends_on_constants() or self.b.depends_on_constants()
+
+
+pi = math.pi
+
+
+def cos(a):
+    return Func(np.cos, as_expr(a))
+
+
+def sin(a):
+    return Func(np.sin, as_expr(a))
+
+
+def exp(a):
+    return Func(np.exp, as_expr(a))
+
+
+def sqrt(a):
+    return Func(np.sqrt, as_expr(a))
+
+
+def ge(a, b):
+    return Condition(operator.ge, a, b)
+
+
+def le(a, b):
+    return Condition(operator.le, a, b)
+
+
+def gt(a, b):
+    return Condition(operator.gt, a, b)
+
+
+def lt(a, b):
+    return Condition(operator.lt, a, b)
+
+
+def And(a, b):
+    return Condition(np.logical_and, a, b)
+
+
+def Or(a, b):
+    return Condition(np.logical_or, a, b)
+
+
+def conditional(cond, a, b):
+    return Conditional(cond, a, b)
+
+
+def variable(e):
+    return e
+
+
+def zero():
+    return Literal(0.0)
+
+
+def product_factors(e: Expr) -> list[Expr]:
+    if isinstance(e, BinOp) and e.op is operator.mul:
+        return product_factors(e.a) + product_factors(e.b)
+    return [e]
+
+
+def separate(e: Expr):
+    """Split ``e`` into (spatial Expr | None, temporal Expr | None) with e = spatial * temporal, or
+    return None when some factor mixes the coordinate and a mutable Constant."""
+    spatial, temporal = [], []
+    for f in product_factors(as_expr(e)):
+        dx, dc = f.depends_on_x(), f.depends_on_constants()
+        if dx and dc:
+            return None
+        (spatial if dx else temporal).append(f)
+
+    def prod(fs):
+        out = None
+        for f in fs:
+            out = f if out is None else BinOp(operator.mul, out, f)
+        return out
+
+    return prod(spatial), prod(temporal)
+
+
+# ------------------------------------------------------------------------------------------------
+# mesh
+# ------------------------------------------------------------------------------------------------
+class CellType:
+    interval = "interval"
+    triangle = "triangle"
+    tetrahedron = "tetrahedron"
+
+
+class _Topology:
+    def __init__(self, dim):
+        self.dim = dim
+
+
+class _Geometry:
+    def __init__(self, mesh):
+        self._mesh = mesh
+
+    @property
+    def x(self) -> np.ndarray:
+        """(num_local_nodes, 3) coordinates, x fastest."""
+        return self._mesh.node_coordinates(pad3=True)
+
+    @property
+    def dim(self):
+        return self._mesh.dim
+
+
+class Mesh:
+    """Uniform box mesh with the reference's simplicial subdivision, optionally z-slab decomposed."""
+
+    def __init__(self, cells, lower, upper, comm: Comm | None = None):
+        self.n = tuple(int(c) for c in cells)
+        self.dim = len(self.n)
+        if self.dim not in (1, 2, 3) or min(self.n) < 1:
+            raise ValueError(f"invalid cell counts {cells}")
+        self.lower = tuple(float(v) for v in lower)
+        self.upper = tuple(float(v) for v in upper)
+        self.h = tuple((u - l) / c for l, u, c in zip(self.lower, self.upper, self.n))
+        self.comm = comm or COMM_WORLD
+        self.topology = _Topology(self.dim)
+        self.geometry = _Geometry(self)
+        nodes = [c + 1 for c in self.n] + [1] * (3 - self.dim)
+        self.shape_global = tuple(nodes)  # (nx, ny, nz)
+        from ._engine import Slab
+
+        world = self.comm.size
+        if world > 1 and self.dim < 3:
+            raise NotImplementedError("slab decomposition is implemented for 3-D boxes only")
+        self.slab = Slab(nodes[2], self.comm.rank, world)
+        self.shape_local = (nodes[0], nodes[1], self.slab.nz)
+        self.plane = nodes[0] * nodes[1]
+        self.num_nodes = self.plane * self.slab.nz
+        self.num_nodes_global = self.plane * nodes[2]
+        self.simplices_per_cell = {1: 1, 2: 2, 3: 6}[self.dim]
+        self.num_cells_global = int(np.prod(self.n)) * self.simplices_per_cell
+
+    def basix_cell(self):
+        return {1: CellType.interval, 2: CellType.triangle, 3: CellType.tetrahedron}[self.dim]
+
+    # ---- geometry ------------------------------------------------------------------------------
+    def axis_coordinates(self, axis: int, local: bool = True) -> np.ndarray:
+        if axis >= self.dim:
+            return np.zeros(1)
+        c = self.lower[axis] + self.h[axis] * np.arange(self.n[axis] + 1)
+        if axis == 2 and local:
+            c = c[self.slab.z0 : self.slab.z1]
+        return c
+
+    def node_coordinates(self, pad3=False, local=True) -> np.ndarray:
+        ax = [self.axis_coordinates(a, local) for a in range(3)]
+        Z, Y, X = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+        cols = [X.ravel(), Y.ravel(), Z.ravel()]
+        return np.stack(cols if pad3 else cols[: self.dim], axis=1)
+
+    # ---- cells ---------------------------------------------------------------------------------
+    def _cell_vertex_mask(self, node_ok: np.ndarray) -> np.ndarray:
+        """node_ok: bool (nz, ny, nx) on the GLOBAL grid -> bool (num_cells_global,) 'all vertices ok',
+        cell id = box_cell_id * simplices_per_cell + k, box cells numbered x fastest."""
+        d = self.dim
+        cx = self.n[0]
+        cy = self.n[1] if d >= 2 else 1
+        cz = self.n[2] if d == 3 else 1
+        out = np.zeros((cz, cy, cx, self.simplices_per_cell), dtype=bool)
+        simp = _stencil._SIMPLICES[d]
+        for k, s in enumerate(simp):
+            ok = np.ones((cz, cy, cx), dtype=bool)
+            for corner in s:
+                ox, oy, oz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
+                ok &= node_ok[oz : oz + cz, oy : oy + cy, ox : ox + cx]
+            out[..., k] = ok
+        return out.reshape(-1)
+
+    def cell_vertices(self, cell_ids: np.ndarray) -> np.ndarray:
+        """(len, dim+1) GLOBAL node ids of the given cells."""
+        cell_ids = np.asarray(cell_ids, dtype=np.int64)
+        d = self.dim
+        spc = self.simplices_per_cell
+        box, k = np.divmod(cell_ids, spc)
+        cx = self.n[0]
+        cy = self.n[1] if d >= 2 else 1
+        ix = box % cx
+        iy = (box // cx) % cy
+        iz = box // (cx * cy)
+        nx, ny = self.shape_global[0], self.shape_global[1]
+        simp = np.array(_stencil._SIMPLICES[d], dtype=np.int64)[k]  # (len, d+1) corner ids
+        ox, oy, oz = simp & 1, (simp >> 1) & 1, (simp >> 2) & 1
+        return (ix[:, None] + ox) + nx * ((iy[:, None] + oy) + ny * (iz[:, None] + oz))
+
+    def all_cells(self) -> np.ndarray:
+        return np.arange(self.num_cells_global, dtype=np.int64)
+
+
+def _mesh(comm, lower, upper, n):
+    return Mesh(n, lower, upper, comm if isinstance(comm, Comm) else COMM_WORLD)
+
+
+def create_unit_interval(comm, nx, **kw):
+    return _mesh(comm, (0.0,), (1.0,), (nx,))
+
+
+def create_interval(comm, nx, points, **kw):
+    return _mesh(comm, (points[0],), (points[1],), (nx,))
+
+
+def create_unit_square(comm, nx, ny, cell_type=CellType.triangle, **kw):
+    _require_simplex(cell_type, CellType.triangle)
+    return _mesh(comm, (0.0, 0.0), (1.0, 1.0), (nx, ny))
+
+
+def create_rectangle(comm, points, n, cell_type=CellType.triangle, **kw):
+    _require_simplex(cell_type, CellType.triangle)
+    return _mesh(comm, tuple(points[0]), tuple(points[1]), tuple(n))
+
+
+def create_unit_cube(comm, nx, ny, nz, cell_type=CellType.tetrahedron, **kw):
+    _require_simplex(cell_type, CellType.tetrahedron)
+    return _mesh(comm, (0.0,) * 3, (1.0,) * 3, (nx, ny, nz))
+
+
+def create_box(comm, points, n, cell_type=CellType.tetrahedron, **kw):
+    _require_simplex(cell_type, CellType.tetrahedron)
+    return _mesh(comm, tuple(points[0]), tuple(points[1]), tuple(n))
+
+
+def _require_simplex(cell_type, expected):
+    name = getattr(cell_type, "name", cell_type)
+    if name != expected:
+        raise NotImplementedError(f"only {expected} cells are implemented (got {cell_type})")
+
+
+def locate_entities(mesh: Mesh, dim: int, marker) -> np.ndarray:
+    """Cells (``dim == mesh.topology.dim``) whose vertices ALL satisfy ``marker(x)``, x of shape
+    (3, num_points) -- dolfinx.mesh.locate_entities semantics."""
+    if dim != mesh.topology.dim:
+        raise NotImplementedError("only cell entities (dim == topological dimension) are implemented")
+    x = mesh.node_coordinates(pad3=True, local=False).T
+    ok = np.asarray(marker(x), dtype=bool)
+    if ok.shape == ():
+        ok = np.full(x.shape[1], bool(ok))
+    nx, ny, nz = mesh.shape_global
+    return np.nonzero(mesh._cell_vertex_mask(ok.reshape(nz, ny, nx)))[0].astype(np.int32)
+
+
+@dataclass
+class MeshTags:
+    mesh: Mesh
+    dim: int
+    indices: np.ndarray
+    values: np.ndarray
+
+    def find(self, value) -> np.ndarray:
+        return self.indices[self.values == value]
+
+
+def meshtags(mesh: Mesh, dim: int, entities, values) -> MeshTags:
+    entities = np.asarray(entities, dtype=np.int64)
+    values = np.broadcast_to(np.asarray(values), entities.shape).copy()
+    order = np.argsort(entities, kind="stable")
+    return MeshTags(mesh, int(dim), entities[order], values[order])
+
+
+class Measure:
+    """``ufl.Measure("dx", domain=mesh, subdomain_data=tags)``; calling it with a marker restricts
+    the integration domain to the cells carrying that tag."""
+
+    def __init__(self, integral_type="dx", domain=None, subdomain_data=None, subdomain_id=None, metadata=None):
+        if integral_type != "dx":
+            raise NotImplementedError("only cell measures ('dx') are implemented")
+        self.integral_type = integral_type
+        self.domain = domain
+        self.subdomain_data = subdomain_data
+        self.subdomain_id = subdomain_id
+        self.metadata = metadata
+
+    def __call__(self, subdomain_id=None, domain=None, metadata=None, **kw):
+        return Measure(self.integral_type, domain or self.domain, self.subdomain_data, subdomain_id,
+                       metadata or self.metadata)
+
+    def cells(self):
+        """Cell ids to integrate over, or None for the whole mesh."""
+        if self.subdomain_id is None:
+            return None
+        if self.subdomain_data is None:
+            raise ValueError("measure has a subdomain id but no subdomain_data")
+        return self.subdomain_data.find(self.subdomain_id)
+
+
+def dx(domain=None, **kw):
+    return Measure("dx", domain=domain, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# constants, spaces, functions
+# ------------------------------------------------------------------------------------------------
+class Constant(Expr):
+    """``dolfinx.fem.Constant(mesh, value)``: mutable scalar (or small vector) parameter."""
+
+    def __init__(self, mesh, value):
+        self.mesh = mesh
+        self._value = np.array(value, dtype=np.float64)
+
+    @property
+    def value(self):
+        return self._value if self._value.ndim else float(self._value)
+
+    @value.setter
+    def value(self, v):
+        self._value = np.array(v, dtype=np.float64)
+
+    def __float__(self):
+        return float(self._value)
+
+    def __len__(self):
+        return len(self._value)
+
+    def evaluate(self, x=None):
+        return float(self._value)
+
+    def depends_on_constants(self):
+        return True
+
+
+class _Element:
+    def __init__(self, family, degree):
+        self.family_name = family
+        self._degree = degree
+
+    def degree(self):
+        return self._degree
+
+
+class FunctionSpace:
+    def __init__(self, mesh: Mesh, family="Lagrange", degree=1):
+        fam = {"P": "Lagrange", "CG": "Lagrange", "Lagrange": "Lagrange"}.get(family)
+        if fam is None or degree != 1:
+            raise NotImplementedError(
+                f"only continuous P1 spaces are implemented on the HIP backend (got {family} {degree})"
+            )
+        self.mesh = mesh
+        self.family = fam
+        self.degree = degree
+        self._element = _Element(fam, degree)
+
+    def ufl_element(self):
+        return self._element
+
+    @property
+    def num_dofs(self):
+        return self.mesh.num_nodes
+
+    def tabulate_dof_coordinates(self):
+        return self.mesh.node_coordinates(pad3=True)
+
+
+def functionspace(mesh: Mesh, element, **kw) -> FunctionSpace:
+    if isinstance(element, _Element):
+        return FunctionSpace(mesh, element.family_name, element.degree())
+    family, degree = element[0], element[1]
+    return FunctionSpace(mesh, family, degree)
+
+
+class LazyArray:
+    """``Function.x.array``: values live in HBM; the host copy is fetched on first use and cached
+    until the device data changes.  Supports the idioms the reference's callers use
+    (``arr[:] = ...``, ``arr[i]``, ``arr.max()``, ``np.asarray(arr)``, ``arr.size``)."""
+
+    __array_priority__ = 100
+
+    def __init__(self, function: "Function"):
+        self._f = function
+
+    # numpy protocol ------------------------------------------------------------------------------
+    def __array__(self, dtype=None, copy=None):
+        a = self._f._host()
+        return a.astype(dtype) if dtype is not None and dtype != a.dtype else a
+
+    def __len__(self):
+        return self._f.field.n
+
+    @property
+    def size(self):
+        return self._f.field.n
+
+    @property
+    def shape(self):
+        return (self._f.field.n,)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    @property
+    def ndim(self):
+        return 1
+
+    def copy(self):
+        return self._f._host().copy()
+
+    def max(self):
+        return self._f.field.minmax()[1] if self.size else -np.inf
+
+    def min(self):
+        return self._f.field.minmax()[0] if self.size else np.inf
+
+    def __getitem__(self, key):
+        return self._f._host()[key]
+
+    def __setitem__(self, key, value):
+        f = self._f
+        if isinstance(value, LazyArray):
+            if isinstance(key, slice) and key == slice(None):
+                src = value._f.field
+                dst = f.writable_field()
+                if dst is not src:
+                    dst.copy_from(src)  # device-to-device, no host round trip
+                f._touch()
+                return
+            value = np.asarray(value)
+        if isinstance(key, slice) and key == slice(None):
+            f.writable_field().set(value)
+            f._touch()
+            return
+        host = f._host().copy()
+        host[key] = value
+        f.writable_field().set(host)
+        f._touch()
+
+    # arithmetic falls back to the host copy
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(np.asarray(i) if isinstance(i, LazyArray) else i for i in inputs)
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __add__(self, o):
+        return np.asarray(self) + o
+
+    def __sub__(self, o):
+        return np.asarray(self) - o
+
+    def __mul__(self, o):
+        return np.asarray(self) * o
+
+    def __repr__(self):
+        return f"LazyArray({np.asarray(self)!r})"
+
+
+class _Vector:
+    def __init__(self, function):
+        self.array = LazyArray(function)
+        self._f = function
+
+    def scatter_forward(self):
+        pass
+
+
+class Function:
+    """``dolfinx.fem.Function(V)``: nodal values of a P1 function held on the device.
+
+    A function either owns its storage or is a read-only *alias* of another field (the fused split
+    step leaves ``pde.state``, ``pde.v_`` and ``ode.v_ode`` aliased to the V row of the state array
+    instead of copying it three times; the alias is materialised into the function's own storage
+    the moment the two would diverge)."""
+
+    def __init__(self, V: FunctionSpace, name: str = "f", field=None):
+        from ._device import Context
+
+        self.function_space = V
+        self.name = name
+        mesh = V.mesh
+        self._ctx = Context.default()
+        self._own = field if field is not None else self._ctx.field(mesh.num_nodes, mesh.plane)
+        self._alias = None
+        self._version = 0
+        self._cache = None
+        self._x = _Vector(self)
+
+    @property
+    def x(self):
+        return self._x
+
+    def ufl_element(self):
+        return self.function_space.ufl_element()
+
+    # ---- storage ---------------------------------------------------------------------------
+    @property
+    def field(self):
+        """Field to READ the current values from."""
+        return self._alias if self._alias is not None else self._own
+
+    def writable_field(self, overwrite_all: bool = True):
+        """Field to WRITE into; ends an alias (copying the aliased values first unless everything is
+        about to be overwritten).  Call ``_touch()`` after the write."""
+        if self._alias is not None:
+            if not overwrite_all:
+                self._own.copy_from(self._alias)
+            self._alias = None
+        return self._own
+
+    def alias_to(self, field) -> None:
+        self._alias = field
+        self._touch()
+
+    def materialize(self) -> None:
+        if self._alias is not None:
+            self._own.copy_from(self._alias)
+            self._alias = None
+
+    def _touch(self):
+        """Call after any device-side modification of the values."""
+        self._version += 1
+
+    def _host(self) -> np.ndarray:
+        if self._cache is None or self._cache[0] != self._version:
+            arr = self.field.numpy()
+            arr.setflags(write=False)
+            self._cache = (self._version, arr)
+        return self._cache[1]
+
+    def interpolate(self, f) -> None:
+        x = self.function_space.mesh.node_coordinates(pad3=True).T
+        if isinstance(f, Expr):
+            vals = f.evaluate(x)
+        elif isinstance(f, Function):
+            vals = np.asarray(f.x.array)
+        else:
+            vals = f(x)
+        fld = self.writable_field()
+        fld.set(np.broadcast_to(np.asarray(vals, dtype=np.float64), (fld.n,)))
+        self._touch()
+
+    def copy(self):
+        g = Function(self.function_space, self.name)
+        g._own.copy_from(self.field)
+        g._touch()
+        return g
+
+
+def evaluate_function(f: Function, points) -> np.ndarray:
+    """``scifem.evaluate_function(f, points)`` for P1 functions on the box mesh (single rank)."""
+    import ctypes as C
+
+    from . import _hip
+
+    mesh = f.function_space.mesh
+    if mesh.comm.size > 1:
+        raise NotImplementedError("point evaluation on a decomposed mesh")
+    pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
+    d = mesh.dim
+    idx = np.zeros((len(pts), 4), dtype=np.int64)
+    wts = np.zeros((len(pts), 4), dtype=np.float64)
+    lower, h, n = np.array(mesh.lower), np.array(mesh.h), np.array(mesh.n)
+    for k, p in enumerate(pts):
+        rel = (p[:d] - lower) / h
+        c = np.clip(np.floor(rel).astype(np.int64), 0, n - 1)
+        box = c[0] + (n[0] * (c[1] + (n[1] * c[2] if d == 3 else 0)) if d >= 2 else 0)
+        best = None
+        for s in range(mesh.simplices_per_cell):
+            verts = mesh.cell_vertices(np.array([box * mesh.simplices_per_cell + s]))[0]
+            X = _node_xyz(mesh, verts)[:, :d]
+            A = np.hstack([np.ones((d + 1, 1)), X])
+            lam = np.linalg.solve(A.T, np.concatenate([[1.0], p[:d]]))
+            if best is None or lam.min() > best[0]:
+                best = (lam.min(), lam, verts)
+        idx[k, : d + 1] = best[2]
+        wts[k, : d + 1] = best[1]
+    out = np.zeros(len(pts))
+    ctx = f._ctx
+    _hip.check(ctx.lib.beat_field_probe(ctx.handle, f.field.ptr, idx.ctypes.data_as(C.c_void_p),
+                                        wts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p)))
+    return out.reshape(-1, 1)
+
+
+def _node_xyz(mesh: Mesh, ids: np.ndarray) -> np.ndarray:
+    nx, ny, _ = mesh.shape_global
+    ix, iy, iz = ids % nx, (ids // nx) % ny, ids // (nx * ny)
+    lo = list(mesh.lower) + [0.0] * (3 - mesh.dim)
+    hh = list(mesh.h) + [0.0] * (3 - mesh.dim)
+    return np.stack([lo[0] + hh[0] * ix, lo[1] + hh[1] * iy, lo[2] + hh[2] * iz], axis=1)
+
+
+class VTXWriter:
+    """No-op stand-in for dolfinx.io.VTXWriter (output is not part of the hot path)."""
+
+    def __init__(self, *a, **kw):
+        pass
+
+    def write(self, t):
+        pass
+
+    def close(self):
+        pass

@@ -1,0 +1,71 @@
+"""``MonodomainModel`` -- interface of src/beat/monodomain_model.py:18-98.
+
+Solves  C_m dv/dt = div(M grad v) + I_stim  with the theta-rule weak form of :68-98 on P1
+elements.  ``M`` is a scalar, a ``Constant`` or a constant (dim, dim) tensor (see
+beat.conductivities.define_conductivity_tensor)."""
+
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from . import _stencil, grid
+from ._engine import DiffusionSolver, HipOps
+from .base_model import BaseModel
+
+logger = logging.getLogger(__name__)
+
+
+class MonodomainModel(BaseModel):
+    def __init__(self, time, mesh, M, I_s=None, params=None, C_m: float = 1.0, dx=None, **kwargs) -> None:
+        self._M = M
+        self.C_m = grid.Constant(mesh, C_m)
+        super().__init__(mesh=mesh, time=time, params=params, I_s=I_s, dx=dx, **kwargs)
+
+    def _setup_state_space(self) -> None:
+        k = self.parameters["degree"]
+        family = self.parameters["family"]
+        self.V = grid.FunctionSpace(self._mesh, family, k)
+        self.v_ = grid.Function(self.V, name="v_")
+        self._state = grid.Function(self.V, name="v")
+
+    def _conductivity(self) -> np.ndarray:
+        M = self._M
+        if isinstance(M, grid.Function):
+            raise NotImplementedError("spatially varying conductivity is not implemented yet")
+        if isinstance(M, grid.Constant):
+            M = M.value
+        return _stencil.conductivity_matrix(M, self._mesh.dim)
+
+    def _setup_operators(self) -> None:
+        mesh = self._mesh
+        mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, self._conductivity())
+        slab = mesh.slab
+        self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+        self._diffusion = DiffusionSolver(self._ops, slab, group=mesh.comm.group)
+
+    @property
+    def state(self) -> grid.Function:
+        return self._state
+
+    def assign_previous(self):
+        self.v_.x.array[:] = self.state.x.array
+
+    @staticmethod
+    def default_parameters():
+        params = super(MonodomainModel, MonodomainModel).default_parameters()
+        params["use_custom_preconditioner"] = True
+        return params
+
+    def _solve_linear(self, stim_w, stim_amp) -> None:
+        rtol, atol, max_it = self._solver_tolerances()
+        x = self._state.writable_field()
+        self.ksp = self._diffusion.solve(self.v_.field, stim_w, stim_amp, x, rtol=rtol, atol=atol, max_it=max_it)
+        self._state._touch()
+
+    def solve_in_place(self, field, stim_w, stim_amp):
+        """Fused-step entry: v_ and the unknown share ``field`` (the V row of the ODE state array)."""
+        rtol, atol, max_it = self._solver_tolerances()
+        self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it)
+        return self.ksp

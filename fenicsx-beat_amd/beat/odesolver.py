@@ -1,0 +1,406 @@
+"""ODE (reaction) solvers -- interface of src/beat/odesolver.py:24-354.
+
+``fun`` follows the reference's convention, ``fun(states=, t=, parameters=, dt=) -> new states``.
+When ``fun`` is one of the built-in device models (``beat.models``) the ``(S, N)`` state array
+lives in HBM and a step is one kernel launch; any other callable is the caller's own NumPy code and
+is run exactly as the reference runs it (host arrays, the transmembrane potential staged to and
+from the device field)."""
+
+from __future__ import annotations
+
+import abc
+import ctypes as C
+import logging
+from dataclasses import dataclass, field
+from typing import Any, Callable, NamedTuple
+
+import numpy as np
+
+from . import _hip, grid
+from .models._base import DeviceModel, host_and_device_parameters
+from .telemetry import BaseMonitor, NullMonitor
+from .utils import local_project
+
+EPS = 1e-12
+logger = logging.getLogger(__name__)
+
+
+class ODEResults(NamedTuple):
+    y: np.ndarray
+    t: np.ndarray
+
+
+def solve(fun, t_bound: float, states, V, V_index: int, dt: float, parameters, t0: float = 0.0, extra=None):
+    """Free-running multi-point loop of odesolver.py:24-43 (``states`` is advanced in place)."""
+    if extra is None:
+        extra = {}
+    i = 0
+    t = t0
+    while t + dt < t_bound:
+        new = fun(states=states, t=t, parameters=parameters, dt=dt, **extra)
+        if new is not None and new is not states:
+            states[:] = new
+        V[i, :] = states[V_index, :]
+        i += 1
+        t += dt
+
+
+@dataclass
+class ODESystemSolver:
+    fun: Callable
+    states: np.ndarray
+    parameters: np.ndarray
+    missing_variables: np.ndarray | None = None
+    _kwargs: dict = field(default_factory=dict)
+    monitor: BaseMonitor = field(default_factory=NullMonitor)
+
+    def __post_init__(self):
+        if self.missing_variables is not None:
+            self._kwargs["missing_variables"] = self.missing_variables
+
+    @property
+    def num_points(self) -> int:
+        return self.states.shape[1]
+
+    @property
+    def num_states(self) -> int:
+        return self.states.shape[0]
+
+    def step(self, t0: float, dt: float) -> None:
+        with self.monitor.track_time("ode_total_step"):
+            with self.monitor.track_time("ode_function_call"):
+                updated_states = self.fun(states=self.states, t=t0, parameters=self.parameters, dt=dt, **self._kwargs)
+            with self.monitor.track_time("ode_state_update"):
+                self.states[:] = updated_states
+
+
+class _DeviceODE:
+    """(S, N) state array in HBM advanced by a built-in model kernel."""
+
+    def __init__(self, ctx, model: DeviceModel, num_states, n, plane, parameters, monitor):
+        from ._device import StateArray
+
+        if num_states != model.num_states:
+            raise ValueError(f"{model.name} has {model.num_states} states, num_states={num_states}")
+        self.ctx = ctx
+        self.model = model
+        self.n = n
+        self.states = StateArray(ctx, num_states, n, plane)
+        self.parameters = parameters
+        self.monitor = monitor
+        self._ppn = None
+        self._ppn_src = None
+
+    def _param_args(self):
+        p = self.parameters
+        if p is None:
+            return None, 0, None, 0
+        p = np.asarray(p, dtype=np.float64)
+        if p.ndim == 1:
+            hp = np.ascontiguousarray(p)
+            self._keep = hp
+            return hp.ctypes.data_as(C.c_void_p), len(hp), None, 0
+        # per-node parameters: re-upload when the caller's array changed (cheap checksum)
+        chk = (p.shape, float(p.sum()), float(np.abs(p).sum()))
+        if self._ppn is None or self._ppn_src != chk:
+            _, self._ppn, _ = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
+            self._ppn_src = chk
+        return None, p.shape[0], C.c_void_p(self._ppn.data_ptr()), self.n
+
+    def step(self, t0, dt, v_index=0, v_copy=None):
+        hp, npar, ppn, pld = self._param_args()
+        with self.monitor.track_time("ode_total_step"):
+            with self.monitor.track_time("ode_function_call"):
+                _hip.check(
+                    self.ctx.lib.beat_ode_step(self.ctx.handle, self.model.model_id, self.states.ptr, self.n,
+                                               self.states.ld, hp, npar, ppn, pld, float(t0), float(dt), int(v_index),
+                                               None if v_copy is None else v_copy.ptr)
+                )
+            with self.monitor.track_time("ode_state_update"):
+                pass  # updated in place by the kernel
+
+
+class BaseDolfinODESolver(abc.ABC):
+    v_ode: grid.Function
+    v_pde: grid.Function
+    _metadata: dict[str, Any] | None = None
+
+    def _initialize_metadata(self):
+        if self.v_ode.ufl_element().family_name == "Quadrature":
+            self._metadata = {"quadrature_degree": self.v_ode.ufl_element().degree()}
+        else:
+            self._metadata = None
+
+    @abc.abstractmethod
+    def to_dolfin(self) -> None: ...
+
+    @abc.abstractmethod
+    def from_dolfin(self) -> None: ...
+
+    def ode_to_pde(self) -> None:
+        local_project(self.v_ode, self.v_pde.function_space, self.v_pde)
+
+    def pde_to_ode(self) -> None:
+        local_project(self.v_pde, self.v_ode.function_space, self.v_ode)
+
+    @abc.abstractmethod
+    def step(self, t0: float, dt: float) -> None: ...
+
+    @property
+    @abc.abstractmethod
+    def full_values(self): ...
+
+
+@dataclass
+class DolfinODESolver(BaseDolfinODESolver):
+    v_ode: grid.Function
+    v_pde: grid.Function
+    init_states: np.ndarray
+    parameters: np.ndarray
+    fun: Callable
+    num_states: int
+    v_index: int = 0
+    missing_variables: np.ndarray | None = None
+    num_missing_variables: int = 0
+    monitor: BaseMonitor = field(default_factory=NullMonitor)
+
+    def __post_init__(self):
+        if np.shape(self.init_states) == self.shape:
+            values = np.copy(self.init_states)
+        else:
+            values = np.zeros(self.shape)
+            values.T[:] = self.init_states
+        self._aliases: list[grid.Function] = []
+        self.on_device = isinstance(self.fun, DeviceModel)
+        if self.on_device:
+            mesh = self.v_ode.function_space.mesh
+            self._dev = _DeviceODE(self.v_ode._ctx, self.fun, self.num_states, self.num_points, mesh.plane,
+                                   self.parameters, self.monitor)
+            self._dev.states.set(values)
+            self._v_row = self._dev.states.row_field(self.v_index)
+            self._ode = self._dev
+        else:
+            self._values = values
+            self._ode = ODESystemSolver(fun=self.fun, states=self._values, parameters=self.parameters,
+                                        missing_variables=self.missing_variables, monitor=self.monitor)
+        self._initialize_metadata()
+
+    # ---- alias bookkeeping (see grid.Function) ------------------------------------------------
+    def _release_aliases(self):
+        """The V row is about to change outside the fused step: give every function that merely
+        aliases it its own copy of the current values first."""
+        for f in self._aliases:
+            if f._alias is self._v_row:
+                f.materialize()
+        self._aliases = []
+
+    # ---- reference interface --------------------------------------------------------------------
+    def to_dolfin(self) -> None:
+        """values[v_index] -> v_ode  (odesolver.py:164-166)"""
+        if self.on_device:
+            if self.v_ode._alias is self._v_row:
+                return
+            self.v_ode.writable_field().copy_from(self._v_row)
+            self.v_ode._touch()
+        else:
+            self.v_ode.x.array[:] = self._values[self.v_index, :]
+
+    def from_dolfin(self) -> None:
+        """v_ode -> values[v_index]  (odesolver.py:168-170)"""
+        if self.on_device:
+            if self.v_ode._alias is self._v_row:
+                return
+            self._release_aliases()
+            self._v_row.copy_from(self.v_ode.field)
+        else:
+            self._values[self.v_index, :] = np.asarray(self.v_ode.x.array)
+
+    @property
+    def values(self):
+        return self._dev.states.numpy() if self.on_device else self._values
+
+    @property
+    def num_parameters(self) -> int:
+        return len(self.parameters)
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (self.num_states, self.num_points)
+
+    @property
+    def shape_missing_values(self) -> tuple[int, int]:
+        return (self.num_missing_variables, self.num_points)
+
+    @property
+    def num_points(self) -> int:
+        return self.v_ode.x.array.size
+
+    def step(self, t0: float, dt: float):
+        if self.on_device:
+            self._release_aliases()
+            self._dev.parameters = self.parameters
+            self._dev.step(t0, dt)
+        else:
+            self._ode.step(t0=t0, dt=dt)
+
+    @property
+    def full_values(self):
+        return self.values
+
+    def set_values(self, values) -> None:
+        """Overwrite the whole (S, N) state array (e.g. with a pre-paced steady state)."""
+        values = np.asarray(values, dtype=np.float64)
+        if self.on_device:
+            self._release_aliases()
+            self._dev.states.set(np.broadcast_to(values.reshape(self.num_states, -1), self.shape))
+        else:
+            self._values[:] = values.reshape(self.num_states, -1)
+
+    def assign_all_states(self, functions: list[grid.Function]) -> None:
+        vals = self.values
+        assert len(functions) == vals.shape[0], "Number of functions must match number of states"
+        for index, f in enumerate(functions):
+            f.x.array[:] = vals[index, :]
+
+    def states_to_dolfin(self, names: list[str] | None = None) -> list[grid.Function]:
+        V = self.v_ode.function_space
+        num_states = self.num_states
+        if names is not None:
+            msg = f"Number of names must match number of states, got {len(names)} names, but number of states is {num_states}"
+            assert len(names) == num_states, msg
+        else:
+            names = [f"state_{i}" for i in range(num_states)]
+        functions = [grid.Function(V, name=name) for name in names]
+        self.assign_all_states(functions)
+        return functions
+
+
+@dataclass
+class DolfinMultiODESolver(BaseDolfinODESolver):
+    """One cell model / parameter set per marker value (odesolver.py:228-354)."""
+
+    v_ode: grid.Function
+    v_pde: grid.Function
+    markers: grid.Function
+    init_states: dict
+    parameters: dict
+    fun: dict
+    num_states: dict
+    v_index: dict
+    monitor: BaseMonitor = field(default_factory=NullMonitor)
+
+    def __post_init__(self):
+        if self.v_ode.x.array.size != self.markers.x.array.size:
+            raise RuntimeError("Marker and voltage need to be in the same function space")
+        self._marker_values = tuple(self.init_states.keys())
+        marker_arr = np.asarray(self.markers.x.array)
+        self._num_points, self._inds, self._idx_dev, self._odes, self._values = {}, {}, {}, {}, {}
+        ctx = self.v_ode._ctx
+        self._ctx = ctx
+        self.on_device = all(isinstance(f, DeviceModel) for f in self.fun.values())
+        self._initialize_full_values()
+        for marker in self._marker_values:
+            where = marker_arr == marker
+            n_m = int(where.sum())
+            self._num_points[marker] = n_m
+            self._inds[marker] = where
+            if np.shape(self.init_states[marker]) == self.shape(marker):
+                values = np.copy(self.init_states[marker])
+            else:
+                values = np.zeros(self.shape(marker))
+                values.T[:] = self.init_states[marker]
+            if self.on_device:
+                dev = _DeviceODE(ctx, self.fun[marker], self.num_states[marker], n_m, 0, self.parameters[marker],
+                                 self.monitor)
+                dev.states.set(values)
+                self._odes[marker] = dev
+                self._idx_dev[marker] = ctx.from_numpy(np.nonzero(where)[0].astype(np.int64))
+            else:
+                self._values[marker] = values
+                self._odes[marker] = ODESystemSolver(fun=self.fun[marker], states=values,
+                                                     parameters=self.parameters[marker], monitor=self.monitor)
+        self._initialize_metadata()
+
+    def _initialize_full_values(self):
+        ns = tuple(self.num_states.values())
+        self._all_states_equal_size = bool((np.array(ns) == ns[0]).all())
+        if self._all_states_equal_size:
+            self._full_values = np.zeros((ns[0], self.markers.x.array.size))
+
+    def to_dolfin(self) -> None:
+        if self.on_device:
+            dst = self.v_ode.writable_field(overwrite_all=False)
+            for marker in self._marker_values:
+                row = self._odes[marker].states.row_field(self.v_index[marker])
+                _hip.check(self._ctx.lib.beat_scatter(self._ctx.handle, dst.ptr, row.ptr,
+                                                      C.c_void_p(self._idx_dev[marker].data_ptr()), row.n))
+            self.v_ode._touch()
+        else:
+            arr = np.asarray(self.v_ode.x.array).copy()
+            for marker in self._marker_values:
+                arr[self._inds[marker]] = self._values[marker][self.v_index[marker], :]
+            self.v_ode.x.array[:] = arr
+
+    def from_dolfin(self) -> None:
+        if self.on_device:
+            src = self.v_ode.field
+            for marker in self._marker_values:
+                row = self._odes[marker].states.row_field(self.v_index[marker])
+                _hip.check(self._ctx.lib.beat_gather(self._ctx.handle, row.ptr, src.ptr,
+                                                     C.c_void_p(self._idx_dev[marker].data_ptr()), row.n))
+        else:
+            arr = np.asarray(self.v_ode.x.array)
+            for marker in self._marker_values:
+                self._values[marker][self.v_index[marker], :] = arr[self._inds[marker]]
+
+    def values(self, marker: int):
+        return self._odes[marker].states.numpy() if self.on_device else self._values[marker]
+
+    def num_parameters(self, marker: int) -> int:
+        return len(self.parameters[marker])
+
+    def shape(self, marker: int) -> tuple[int, int]:
+        return (self.num_states[marker], self._num_points[marker])
+
+    def num_points(self, marker: int) -> int:
+        return self._num_points[marker]
+
+    def step(self, t0: float, dt: float):
+        with self.monitor.track_time("total_ode_step"):
+            for marker, ode in self._odes.items():
+                with self.monitor.track_time(f"marker_{marker}_ode_step"):
+                    if self.on_device:
+                        ode.parameters = self.parameters[marker]
+                        ode.step(t0, dt)
+                    else:
+                        ode.step(t0=t0, dt=dt)
+
+    def assign_all_states(self, functions: list[grid.Function]) -> None:
+        num_states = self.num_states[self._marker_values[0]]
+        assert len(functions) == num_states, "Number of functions must match number of states"
+        for index, f in enumerate(functions):
+            arr = np.asarray(f.x.array).copy()
+            for marker in self._marker_values:
+                arr[self._inds[marker]] = self.values(marker)[index, :]
+            f.x.array[:] = arr
+
+    def states_to_dolfin(self, names: list[str] | None = None) -> list[grid.Function]:
+        V = self.v_ode.function_space
+        num_states = self.num_states[self._marker_values[0]]
+        if names is not None:
+            assert len(names) == num_states, "Number of names must match number of states"
+        else:
+            names = [f"state_{i}" for i in range(num_states)]
+        functions = [grid.Function(V, name=name) for name in names]
+        self.assign_all_states(functions)
+        return functions
+
+    @property
+    def full_values(self):
+        if not self._all_states_equal_size:
+            msg = ("Cannot get full values size states are not of equal size. "
+                   f"Have {self.num_states=}, use .values(marker) instead")
+            raise RuntimeError(msg)
+        for marker in self._marker_values:
+            self._full_values[:, self._inds[marker]] = self.values(marker)
+        return self._full_values

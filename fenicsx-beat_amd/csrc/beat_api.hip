@@ -171,21 +171,41 @@ extern "C" int beat_scatter(beat_ctx* ctx, double* dev_dst, const double* dev_sr
 }
 
 // ---- point evaluation and min/max -------------------------------------------------------------
+struct ProbeBatch {
+  int64_t idx[64];
+  double w[64];
+  int n;  // points in this batch (<= 16)
+};
+
+__global__ void probe_kernel(const double* __restrict__ field, ProbeBatch b, double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= b.n) return;
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double w = b.w[4 * k + j];
+    if (w != 0.0) s = fma(w, field[b.idx[4 * k + j]], s);
+  }
+  out[k] = s;
+}
+
 extern "C" int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
                                 const double* host_w, int npts, double* host_out) {
   BEAT_REQUIRE(ctx != nullptr && dev_field && host_idx && host_w && host_out && npts >= 0, "bad argument");
-  // a handful of points (9 in the Niederer demo): gather the <=4 vertex values with small D2H copies
-  std::vector<double> vals((size_t)npts * 4, 0.0);
-  for (int k = 0; k < npts * 4; ++k) {
-    if (host_w[k] == 0.0) continue;
-    BEAT_HIP_CHECK(hipMemcpyAsync(&vals[k], dev_field + host_idx[k], sizeof(double),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-  }
-  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < npts; ++k) {
-    double s = 0.0;
-    for (int j = 0; j < 4; ++j) s += host_w[4 * k + j] * vals[4 * k + j];
-    host_out[k] = s;
+  // a handful of points (9 in the Niederer demo): one tiny kernel + one D2H copy per 16 points
+  for (int base = 0; base < npts; base += 16) {
+    ProbeBatch b;
+    b.n = npts - base < 16 ? npts - base : 16;
+    for (int k = 0; k < 4 * b.n; ++k) {
+      b.idx[k] = host_idx[4 * base + k];
+      b.w[k] = host_w[4 * base + k];
+    }
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, ctx->d_small);
+    BEAT_LAUNCH_CHECK();
+    BEAT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * b.n, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < b.n; ++k) host_out[base + k] = ctx->h_pinned[k];
   }
   return BEAT_OK;
 }

@@ -1,0 +1,414 @@
+"""GPU tests of the reference-shaped Python API.  They restate the reference's own tests
+(tests/test_monodomain.py, tests/test_stimulation.py, tests/test_odesolver.py,
+tests/test_monodomain_solver.py) and the Niederer table (demos/niederer_benchmark.py:315-319)
+against the HIP backend, with the reference's thresholds."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _ctx(hip_ctx):
+    return hip_ctx
+
+
+def _l2_error(mesh, vh, exact):
+    from oracle import fem
+
+    om = fem.BoxMesh(mesh.n, tuple(u - l for l, u in zip(mesh.lower, mesh.upper)), origin=mesh.lower)
+    return fem.l2_error(om, np.asarray(vh), exact)
+
+
+# ---- tests/test_monodomain.py:11-64 ---------------------------------------------------------------
+@pytest.mark.parametrize(
+    "M, amp, err",
+    [
+        (0.0, lambda g, t: g.cos(t), 1e-4),
+        (1.0, lambda g, t: g.cos(t) + 8 * g.pi**2 * g.sin(t), 2e-4),
+        (2.0, lambda g, t: g.cos(t) + 16 * g.pi**2 * g.sin(t), 2e-4),
+    ],
+)
+def test_monodomain_analytic(M, amp, err):
+    import beat
+    from beat import grid as g
+
+    N, theta, dt = 15, 0.5, 0.001
+    T = 10 * dt
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N, g.CellType.triangle)
+    time = g.Constant(mesh, g.default_scalar_type(0.0))
+    x = g.SpatialCoordinate(mesh)
+    t_var = g.variable(time)
+    I_s = g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * amp(g, t_var)
+    model = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, params=dict(theta=theta, linear_solver_type="direct"))
+    res = model.solve((0, T), dt=dt)
+    e = _l2_error(mesh, res.state.x.array, lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(T))
+    assert e < err
+
+
+# ---- tests/test_monodomain.py:67-104 --------------------------------------------------------------
+def test_monodomain_spatial_convergence():
+    import beat
+    from beat import grid as g
+
+    errors = []
+    dt = 0.001
+    T = 10 * dt
+    for N in (4, 8, 16, 32):
+        mesh = g.create_unit_square(g.COMM_WORLD, N, N)
+        time = g.Constant(mesh, 0.0)
+        x = g.SpatialCoordinate(mesh)
+        I_s = g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * (g.cos(time) + 8 * g.pi**2 * g.sin(time))
+        model = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=I_s, params=dict(theta=0.5))
+        res = model.solve((0, T), dt=dt)
+        errors.append(_l2_error(mesh, res.state.x.array,
+                                lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(T)))
+    rates = [np.log(e1 / e2) / np.log(2) for e1, e2 in zip(errors[:-1], errors[1:])]
+    assert all(rate >= 2.0 for rate in rates), rates
+
+
+# ---- tests/test_monodomain.py:107-147 (coarser N to keep it quick; same criterion) ------------------
+def test_monodomain_temporal_convergence():
+    import beat
+    from beat import grid as g
+
+    T, N = 1.0, 100
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N)
+    x = g.SpatialCoordinate(mesh)
+    errors = []
+    for dt in (1.0, 0.5, 0.25, 0.125):
+        time = g.Constant(mesh, 0.0)
+        I_s = g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * (g.cos(time) + 8 * g.pi**2 * g.sin(time))
+        model = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=I_s, params=dict(theta=0.5))
+        res = model.solve((0, T), dt=dt)
+        errors.append(_l2_error(mesh, res.state.x.array,
+                                lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(T)))
+    rates = [np.log(e1 / e2) / np.log(2) for e1, e2 in zip(errors[:-1], errors[1:])]
+    assert all(rate >= 2.0 for rate in rates), rates
+
+
+# ---- tests/test_stimulation.py:12-48 ---------------------------------------------------------------
+def test_single_stimulation():
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_unit_interval(g.COMM_WORLD, 10)
+    value, end, start, dt = 2.0, 1.0, 0.5, 0.01
+    time = g.Constant(mesh, 0.0)
+    expr = g.conditional(g.And(g.ge(time, start), g.le(time, end)), value, 0.0)
+    I_s = beat.stimulation.Stimulus(dZ=g.dx(domain=mesh), expr=expr)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=g.Constant(mesh, 0.0), I_s=I_s)
+    pde.step((0.0, 0.4))
+    assert np.allclose(pde.state.x.array, 0.0)
+    t0 = 0.9
+    pde.solve((0.4, t0), dt=dt)
+    assert np.allclose(pde.state.x.array, value * (t0 - start))
+    pde.solve((t0, end + dt), dt=dt)
+    # solve() does not assign_previous() after its final step: hence the "- dt"
+    assert np.allclose(pde.state.x.array, (end - start - dt) * value)
+    pde.solve((end + dt, 2 * end), dt=dt)
+    assert np.allclose(pde.state.x.array, (end - start - dt) * value)
+
+
+# ---- tests/test_stimulation.py:51-107 --------------------------------------------------------------
+def test_double_stimulation():
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_unit_interval(g.COMM_WORLD, 10)
+    dt, value1, value2 = 0.01, 2.0, 3.0
+    start1, end1, start2, end2 = 0.5, 1.0, 0.9, 1.5
+    time = g.Constant(mesh, 0.0)
+    expr1 = g.conditional(g.And(g.ge(time, start1), g.le(time, end1)), value1, 0.0)
+    expr2 = g.conditional(g.And(g.ge(time, start2), g.le(time, end2)), value2, 0.0)
+    dx = g.dx(domain=mesh)
+    I_s = [beat.stimulation.Stimulus(dZ=dx, expr=expr1), beat.stimulation.Stimulus(dZ=dx, expr=expr2)]
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=g.Constant(mesh, 0.0), I_s=I_s)
+    pde.step((0.0, 0.4))
+    assert np.allclose(pde.state.x.array, 0.0)
+    t0 = 0.9
+    pde.solve((0.4, t0), dt=dt)
+    assert np.allclose(pde.state.x.array, value1 * (t0 - start1))
+    pde.solve((t0, end1 + dt), dt=dt)
+    assert np.allclose(pde.state.x.array, (end1 - start1 - dt) * value1 + (end1 + dt - start2) * value2)
+    pde.solve((end1 + dt, end2 + dt), dt=dt)
+    assert np.allclose(pde.state.x.array, (end1 - start1 - dt) * value1 + (end2 - start2 - dt) * value2)
+    pde.solve((end2 + dt, 2 * end2), dt=dt)
+    assert np.allclose(pde.state.x.array, (end1 - start1 - dt) * value1 + (end2 - start2 - dt) * value2)
+
+
+# ---- tests/test_stimulation.py:253-304: integral of define_stimulus over the marked region -----------
+def test_define_stimulus_integral():
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_unit_cube(g.COMM_WORLD, 4, 4, 4)
+    time = g.Constant(mesh, 0.0)
+    cells = g.locate_entities(mesh, 3, lambda x: x[0] <= 0.5 + 1e-12)
+    tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+    chi, amplitude = 1400.0, 50000.0
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=chi * beat.units.ureg("cm**-1"), time=time,
+                                           subdomain_data=tags, marker=1, mesh_unit="mm", amplitude=amplitude,
+                                           duration=2.0, start=1.0)
+    expected = (amplitude * beat.units.ureg("uA/cm**3") / (chi * beat.units.ureg("cm**-1"))).to("uA/mm**2").magnitude
+    w = beat.stimulation.assemble_weights(mesh, I_s.dz.cells(), None)
+    for t, on in ((0.5, False), (1.0, True), (2.0, True), (3.0, True), (3.1, False)):
+        time.value = t
+        assert np.isclose(float(I_s.expr.evaluate()) * w.sum(), (expected * 0.5) if on else 0.0)
+
+
+# ---- tests/test_odesolver.py:52-117 ----------------------------------------------------------------
+def _simple_ode_forward_euler(states, t, dt, parameters):
+    v, s = states
+    a, b = parameters
+    values = np.zeros_like(states)
+    values[0] = v - a * s * dt
+    values[1] = s + b * v * dt
+    return values
+
+
+@pytest.mark.parametrize("device_model", [False, True])
+def test_DolfinODESolver_data_movement(device_model):
+    import beat
+    from beat import grid as g
+    from beat.odesolver import DolfinODESolver
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 5, 5)
+    v_pde = g.Function(g.functionspace(mesh, ("P", 1)))
+    v_ode = g.Function(g.functionspace(mesh, ("P", 1)))
+    N_ode = 36
+    v0, s0 = 1.0, 2.0
+    fun = beat.models.simple.forward_euler if device_model else _simple_ode_forward_euler
+    ode = DolfinODESolver(v_ode=v_ode, v_pde=v_pde, init_states=np.array([v0, s0]), parameters=np.array([1, 1]),
+                          fun=fun, num_states=2, v_index=0)
+    assert ode.on_device == device_model
+    assert ode.full_values.shape == (2, N_ode) and ode.values.shape == (2, N_ode)
+    assert np.allclose(ode.values[0, :], v0) and np.allclose(ode.values[1, :], s0)
+    dt = 0.1
+    ode.step(0.0, dt)
+    assert np.allclose(ode.values[0, :], v0 - s0 * dt)
+    assert np.allclose(ode.values[1, :], s0 + v0 * dt)
+    assert np.allclose(v_ode.x.array, 0.0)
+    ode.to_dolfin()
+    assert np.allclose(v_ode.x.array, v0 - s0 * dt)
+    assert np.allclose(v_pde.x.array, 0.0)
+    ode.ode_to_pde()
+    assert np.allclose(v_pde.x.array, v0 - s0 * dt)
+    v_pde.x.array[:] = 1.0
+    ode.pde_to_ode()
+    assert np.allclose(v_ode.x.array, 1.0)
+    ode.from_dolfin()
+    assert np.allclose(ode.values[0, :], 1.0)
+    assert np.allclose(ode.values[1, :], s0 + v0 * dt)
+    states = ode.states_to_dolfin()
+    assert len(states) == 2
+    assert np.allclose(states[0].x.array, 1.0)
+    assert np.allclose(states[1].x.array, s0 + v0 * dt)
+
+
+# ---- tests/test_odesolver.py:120-215 (two markers, per-marker parameters) ---------------------------
+@pytest.mark.parametrize("device_model", [False, True])
+def test_DolfinMultiODESolver(device_model):
+    import beat
+    from beat import grid as g
+    from beat.odesolver import DolfinMultiODESolver
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 5, 5)
+    V = g.functionspace(mesh, ("P", 1))
+    v_pde, v_ode, markers = g.Function(V), g.Function(V), g.Function(V)
+    marr = np.zeros(36)
+    marr[:10] = 1
+    markers.x.array[:] = marr
+    fun = beat.models.simple.forward_euler if device_model else _simple_ode_forward_euler
+    init = {0: np.array([1.0, 2.0]), 1: np.array([3.0, 4.0])}
+    par = {0: np.array([1.0, 1.0]), 1: np.array([2.0, 0.5])}
+    ode = DolfinMultiODESolver(v_ode=v_ode, v_pde=v_pde, markers=markers, init_states=init, parameters=par,
+                               fun={0: fun, 1: fun}, num_states={0: 2, 1: 2}, v_index={0: 0, 1: 0})
+    assert ode.values(0).shape == (2, 26) and ode.values(1).shape == (2, 10)
+    dt = 0.1
+    ode.step(0.0, dt)
+    assert np.allclose(ode.values(0)[0], 1.0 - 1.0 * 2.0 * dt) and np.allclose(ode.values(0)[1], 2.0 + 1.0 * 1.0 * dt)
+    assert np.allclose(ode.values(1)[0], 3.0 - 2.0 * 4.0 * dt) and np.allclose(ode.values(1)[1], 4.0 + 0.5 * 3.0 * dt)
+    assert np.allclose(v_ode.x.array, 0.0)
+    ode.to_dolfin()
+    expect = np.where(marr == 1, 3.0 - 2.0 * 4.0 * dt, 1.0 - 2.0 * dt)
+    assert np.allclose(v_ode.x.array, expect)
+    ode.ode_to_pde()
+    assert np.allclose(v_pde.x.array, expect)
+    v_pde.x.array[:] = np.arange(36.0)
+    ode.pde_to_ode()
+    ode.from_dolfin()
+    assert np.allclose(ode.values(1)[0], np.arange(10.0)) and np.allclose(ode.values(0)[0], np.arange(10.0, 36.0))
+    fv = ode.full_values
+    assert fv.shape == (2, 36) and np.allclose(fv[0], np.arange(36.0))
+
+
+# ---- tests/test_monodomain_solver.py:33-87 (P1 ODE space) -------------------------------------------
+@pytest.mark.parametrize("mode", ["device_fused", "device_unfused", "host_callable"])
+def test_monodomain_splitting_analytic(mode):
+    import beat
+    from beat import grid as g
+
+    N, M, dt, T, t0 = 50, 1.0, 0.01, 1.0, 0.0
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N)
+    time = g.Constant(mesh, 0.0)
+    x = g.SpatialCoordinate(mesh)
+    I_s = 8 * g.pi**2 * g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * g.sin(time)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s)
+    V_ode = beat.utils.space_from_string("P_1", mesh, dim=1)
+    v_ode = g.Function(V_ode)
+    s = g.Function(V_ode)
+    s.interpolate(lambda p: -np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.cos(0.0))
+    init_states = np.zeros((2, s.x.array.size))
+    init_states[1, :] = np.asarray(s.x.array)
+
+    def simple(states, t, dt, parameters):
+        v, s_ = states
+        values = np.zeros_like(states)
+        values[0] = v - s_ * dt
+        values[1] = s_ + v * dt
+        return values
+
+    fun = simple if mode == "host_callable" else beat.models.simple.forward_euler
+    ode = beat.odesolver.DolfinODESolver(v_ode=v_ode, v_pde=pde.state, fun=fun, init_states=init_states,
+                                         parameters=None, num_states=2, v_index=0)
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, fused=(mode != "device_unfused"))
+    solver.solve((t0, T), dt=dt)
+    E = _l2_error(mesh, pde.state.x.array,
+                  lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(float(time)))
+    assert E < 0.002
+    # every N-vector the reference keeps in sync is in sync
+    assert np.array_equal(np.asarray(pde.v_.x.array), np.asarray(pde.state.x.array))
+    assert np.array_equal(np.asarray(ode.v_ode.x.array), np.asarray(pde.state.x.array))
+    assert np.array_equal(ode.values[0], np.asarray(pde.state.x.array))
+
+
+def _tp06_slab(fused, theta=1.0, nsteps=40, stim=True):
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=4.0, Ly=2.0, Lz=1.0, dx=0.25)
+    mesh = geo.mesh
+    time = g.Constant(mesh, 0.0)
+    cond = beat.conductivities.default_conductivities("Niederer")
+    cells = g.locate_entities(mesh, 3, lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+    tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                           mesh_unit="mm", amplitude=50_000.0 if stim else 0.0)
+    M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+    C_m = (1.0 * beat.units.ureg("uF/cm**2")).to("uF/mm**2").magnitude
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, dx=I_s.dZ)
+    ode = beat.odesolver.DolfinODESolver(
+        v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+        init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+        num_states=19, v_index=tp06.state_index("V"))
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta, fused=fused)
+    dt = 0.05
+    for i in range(nsteps):
+        solver.step((i * dt, (i + 1) * dt))
+    return solver
+
+
+def test_fused_step_equals_reference_sequence():
+    """The fused route (in-place solve on the V row, aliased functions) gives the same numbers as
+    the literal 8-stage reference sequence."""
+    a, b = _tp06_slab(True), _tp06_slab(False)
+    va, vb = np.asarray(a.pde.state.x.array), np.asarray(b.pde.state.x.array)
+    assert va.max() > 0.0  # the stimulated corner fired
+    np.testing.assert_allclose(va, vb, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a.ode.values, b.ode.values, rtol=1e-12, atol=1e-14)
+    for s in (a, b):
+        assert np.array_equal(np.asarray(s.pde.v_.x.array), np.asarray(s.pde.state.x.array))
+        assert np.array_equal(s.ode.values[17], np.asarray(s.pde.state.x.array))
+
+
+def test_fused_aliases_materialise_when_values_diverge():
+    s = _tp06_slab(True, nsteps=3)
+    before = np.asarray(s.pde.state.x.array).copy()
+    s.ode.step(0.15, 0.05)  # manual sub-step: the V row changes, pde.state must not
+    assert np.array_equal(np.asarray(s.pde.state.x.array), before)
+    assert not np.array_equal(s.ode.values[17], before)
+    s.pde.state.x.array[:] = 1.0  # writing one function must not leak into the others
+    assert np.array_equal(np.asarray(s.pde.v_.x.array), before)
+
+
+def test_strang_splitting_against_oracle():
+    """theta = 0.5 (corrective ODE half-step, monodomain_solver.py:98-113) against the oracle."""
+    from oracle import fem, ionic
+
+    s = _tp06_slab(False, theta=0.5, nsteps=10)
+    mesh = fem.BoxMesh((16, 8, 4), (4.0, 2.0, 1.0))
+    M = np.diag([0.0009529837251356239, 0.00012575841147269718, 0.00012575841147269718])
+    cells = mesh.locate_cells(lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+    w = fem.stimulus_weights(mesh, cells)
+    amp = 50000.0 / 1400.0 / 100.0
+    model = fem.OracleMonodomainModel(mesh, M, [fem.OracleStimulus(fem.window(0.0, 2.0, amp), w)], C_m=0.01, theta=0.5)
+    S = np.repeat(ionic.tp06_init_state_values()[:, None], mesh.num_nodes, axis=1)
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    dt = 0.05
+    for i in range(10):
+        t0 = i * dt
+        S = ionic.tp06_generalized_rush_larsen(S, t0, 0.5 * dt, P)
+        model.state[:] = S[17]
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        S[17] = model.state
+        S = ionic.tp06_generalized_rush_larsen(S, t0 + 0.5 * dt, 0.5 * dt, P)
+    out = s.ode.values
+    err = np.abs(out - S) / np.maximum(np.abs(S), 1e-3)
+    assert err.max() < 1e-8, err.max()
+
+
+NIEDERER = {  # demos/niederer_benchmark.py:317-318, dx = 0.5
+    0.05: dict(P1=1.25, P2=51.1, P3=34.9, P4=58.9, P5=14.1, P6=49.5, P7=34.0, P8=56.65, P9=26.05),
+    0.01: dict(P1=1.22, P2=50.85, P3=33.96, P4=58.05, P5=13.98, P6=49.36, P7=33.07, P8=55.91, P9=25.64),
+}
+
+
+@pytest.mark.parametrize("dt", [0.05, 0.01])
+def test_niederer_activation_times(dt):
+    """Niederer 2011 benchmark, dx = 0.5 mm: activation times (first t with v > 0) at P1..P9 within
+    +-2 dt of the table committed in the reference demo."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    Lx, Ly, Lz, dx = 20.0, 7.0, 3.0, 0.5
+    geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=Lx, Ly=Ly, Lz=Lz, dx=dx)
+    mesh = geo.mesh
+    cond = beat.conductivities.default_conductivities("Niederer")
+    C_m = 1.0 * beat.units.ureg("uF/cm**2")
+    time = g.Constant(mesh, 0.0)
+    L, tol = 1.5, 1.0e-10
+    cells = g.locate_entities(mesh, 3, lambda x: np.logical_and(np.logical_and(x[0] <= L + tol, x[1] <= L + tol), x[2] <= L + tol))
+    tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                           mesh_unit="mm", amplitude=50_000.0)
+    M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s,
+                               params={"petsc_options": {"ksp_type": "cg", "pc_type": "hypre"}},
+                               C_m=C_m.to("uF/mm**2").magnitude, dx=I_s.dZ)
+    ic = tp06.init_state_values(V=-85.23, Xr1=0.00621, Xr2=0.4712, Xs=0.0095, m=0.00172, h=0.7444, j=0.7045,
+                                d=3.373e-05, f=0.7888, f2=0.9755, fCass=0.9953, s=0.999998, r=2.42e-08,
+                                Ca_i=0.000126, R_prime=0.9073, Ca_SR=3.64, Ca_ss=0.00036, Na_i=8.604, K_i=136.89)
+    ode = beat.odesolver.DolfinODESolver(
+        v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+        init_states=ic, parameters=tp06.init_parameter_values(stim_amplitude=0.0), num_states=len(ic),
+        v_index=tp06.state_index("V"))
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    points = {"P1": (0, 0, 0), "P2": (0.0, Ly, 0.0), "P3": (Lx, 0.0, 0.0), "P4": (Lx, Ly, 0.0), "P5": (0.0, 0.0, Lz),
+              "P6": (0.0, Ly, Lz), "P7": (Lx, 0.0, Lz), "P8": (Lx, Ly, Lz), "P9": (Lx / 2, Ly / 2, Lz / 2)}
+    plist = np.array(list(points.values()), dtype=float)
+    at = {p: -1.0 for p in points}
+    t, T = 0.0, 70.0
+    while t < T + 1e-12 and any(a < 0.0 for a in at.values()):
+        solver.step((t, t + dt))
+        vals = g.evaluate_function(solver.pde.state, plist).ravel()
+        for p, value in zip(points, vals):
+            if value > 0.0 and at[p] < 0.0:
+                at[p] = t
+        t += dt
+    for p, ref in NIEDERER[dt].items():
+        assert abs(at[p] - ref) <= 2 * dt + 1e-9, (p, at[p], ref, at)
