@@ -25,7 +25,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void ode_step_kernel(
     double pl[Model::NP];
 #pragma unroll
     for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
-    Model::step(y, pl, drv, t, dt);
+    const typename Model::Derived dl = Model::derive(pl);
+    Model::step(y, pl, dl, t, dt);
   } else {
     Model::step(y, prm.p, drv, t, dt);
   }

@@ -12,17 +12,23 @@ NumPy restatement of the pointwise ionic steps (``fun(states=, t=, parameters=, 
   (demos/niederer_benchmark.py:82-99).
 
 gotranx is an un-vendored, un-pinned dependency (pyproject.toml:57-64); its GRL1 scheme is
-restated from its published algorithm: for every state y_i with RHS f_i, take the derivative
-``J_i = d f_i / d y_i`` of the *state-derivative expression as written* (intermediate
-expressions held fixed); if it is identically zero the state is advanced by forward Euler,
-``y_i += dt f_i``; otherwise ``y_i += f_i (exp(J_i dt) - 1) / J_i`` where ``|J_i| > 1e-8`` and
-``dt f_i`` elsewhere.  All f_i, J_i are evaluated at the old state.
+restated from its published algorithm: for every state y_i with RHS f_i(y) (all intermediate
+expressions resolved), take the self-derivative ``J_i = d f_i / d y_i``; if it is identically
+zero the state is advanced by forward Euler, ``y_i += dt f_i``; otherwise
+``y_i += f_i (exp(J_i dt) - 1) / J_i`` where ``|J_i| > 1e-8`` and ``dt f_i`` elsewhere.  All f_i,
+J_i are evaluated at the old state.  For TP06 every J_i is non-zero.
 
-PARITY UNPINNED for per-step GRL1 values: the reference holds no numerical output of a
+Which derivative gotranx takes is not stated in the reference; it is PINNED HERE BY THE
+REFERENCE'S NIEDERER TABLE (demos/niederer_benchmark.py:315-319): with the total self-derivative
+(this file) the nine activation times at dx = 0.5 mm land within one dt of the committed rows,
+whereas differentiating only the explicit occurrence of y_i in the written expression (which would
+leave V, Ca_i, Ca_SR, Ca_ss, Na_i, K_i on forward Euler) is 8-13 dt early at dt = 0.05
+(tests/test_oracle_pins.py::test_niederer_table_pins_the_grl1_variant).
+
+PARITY UNPINNED for individual per-step GRL1 values: the reference holds no numerical output of a
 gotranx-generated step.  What *is* pinned: (i) the RHS f and the J_i of this file against an
-independent evaluation of the reference's ``.ode`` text (tests/golden/tp06_rhs.npz, generated
-by tests/golden/make_golden.py), (ii) the end-to-end Niederer activation times
-(demos/niederer_benchmark.py:315-319).
+independent evaluation of the reference's ``.ode`` text (tests/golden/tp06_spec.npz, generated
+by tests/golden/make_golden.py), (ii) the end-to-end Niederer activation times.
 """
 
 from __future__ import annotations
@@ -133,9 +139,58 @@ def tp06_init_parameter_values(**values) -> np.ndarray:
     return np.array([d[k] for k in TP06_PARAMETERS], dtype=np.float64)
 
 
-def tp06_rhs_and_linearized(states, t, parameters):
-    """Returns (f, J): f[i] = dy_i/dt, J[i] = explicit d f_i / d y_i (None where identically 0)."""
-    exp, log, sqrt = np.exp, np.log, np.sqrt
+class _NumpyNS:
+    exp = staticmethod(np.exp)
+    log = staticmethod(np.log)
+    sqrt = staticmethod(np.sqrt)
+    floor = staticmethod(np.floor)
+
+    @staticmethod
+    def where(c, a, b):
+        return np.where(c, a, b)
+
+    @staticmethod
+    def lt(a, b):
+        return a < b
+
+    @staticmethod
+    def ge(a, b):
+        return a >= b
+
+    @staticmethod
+    def le(a, b):
+        return a <= b
+
+    @staticmethod
+    def land(a, b):
+        return np.logical_and(a, b)
+
+
+def _sympy_ns():
+    import sympy
+
+    class NS:
+        exp = staticmethod(sympy.exp)
+        log = staticmethod(sympy.log)
+        sqrt = staticmethod(sympy.sqrt)
+        floor = staticmethod(sympy.floor)
+
+        @staticmethod
+        def where(c, a, b):
+            return sympy.Piecewise((a, c), (b, True))
+
+        lt = staticmethod(sympy.Lt)
+        ge = staticmethod(sympy.Ge)
+        le = staticmethod(sympy.Le)
+        land = staticmethod(sympy.And)
+
+    return NS
+
+
+def tp06_rhs(states, t, parameters, ns=_NumpyNS):
+    """dy/dt of the 19 states, written once for NumPy arrays and for SymPy symbols (``ns`` supplies
+    exp/log/sqrt/where/...)."""
+    exp, log, sqrt = ns.exp, ns.log, ns.sqrt
     (Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i) = states
     (P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,
      alpha, gamma, Km_Ca, Km_Nai, g_pCa, K_pCa, g_pK, Ca_o, k1_prime, k2_prime, k3, k4, EC, max_sr,
@@ -186,28 +241,27 @@ def tp06_rhs_and_linearized(states, t, parameters):
     tau_m = 1 * alpha_m * beta_m
     dm_dt = (m_inf - m) / tau_m
     h_inf = 1 / (1 + exp((V + 71.55) / 7.43)) ** 2
-    lt = V < -40
-    with np.errstate(over="ignore", invalid="ignore"):
-        alpha_h = np.where(lt, 0.057 * exp(-(V + 80) / 6.8), 0)
-        beta_h = np.where(
-            lt,
-            2.7 * exp(0.079 * V) + 310000 * exp(0.3485 * V),
-            0.77 / (0.13 * (1 + exp((V + 10.66) / -11.1))),
-        )
-        tau_h = 1 / (alpha_h + beta_h)
-        dh_dt = (h_inf - h) / tau_h
-        j_inf = 1 / (1 + exp((V + 71.55) / 7.43)) ** 2
-        alpha_j = np.where(
-            lt,
-            (-25428 * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) / 1
-            / (1 + exp(0.311 * (V + 79.23))),
-            0,
-        )
-        beta_j = np.where(
-            lt,
-            0.02424 * exp(-0.01052 * V) / (1 + exp(-0.1378 * (V + 40.14))),
-            0.6 * exp(0.057 * V) / (1 + exp(-0.1 * (V + 32))),
-        )
+    lt = ns.lt(V, -40)
+    alpha_h = ns.where(lt, 0.057 * exp(-(V + 80) / 6.8), 0)
+    beta_h = ns.where(
+        lt,
+        2.7 * exp(0.079 * V) + 310000 * exp(0.3485 * V),
+        0.77 / (0.13 * (1 + exp((V + 10.66) / -11.1))),
+    )
+    tau_h = 1 / (alpha_h + beta_h)
+    dh_dt = (h_inf - h) / tau_h
+    j_inf = 1 / (1 + exp((V + 71.55) / 7.43)) ** 2
+    alpha_j = ns.where(
+        lt,
+        (-25428 * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) / 1
+        / (1 + exp(0.311 * (V + 79.23))),
+        0,
+    )
+    beta_j = ns.where(
+        lt,
+        0.02424 * exp(-0.01052 * V) / (1 + exp(-0.1378 * (V + 40.14))),
+        0.6 * exp(0.057 * V) / (1 + exp(-0.1 * (V + 32))),
+    )
     tau_j = 1 / (alpha_j + beta_j)
     dj_dt = (j_inf - j) / tau_j
 
@@ -288,20 +342,48 @@ def tp06_rhs_and_linearized(states, t, parameters):
 
     # Sodium, membrane, potassium (.ode:318-322)
     dNa_i_dt = -(i_Na + i_b_Na + 3 * i_NaK + 3 * i_NaCa) / (V_c * F) * Cm
-    tmod = t - np.floor(t / stim_period) * stim_period
-    i_Stim = np.where(
-        np.logical_and(tmod >= stim_start, tmod <= stim_start + stim_duration), stim_amplitude, 0
-    )
+    tmod = t - ns.floor(t / stim_period) * stim_period
+    i_Stim = ns.where(ns.land(ns.ge(tmod, stim_start), ns.le(tmod, stim_start + stim_duration)), stim_amplitude, 0)
     dV_dt = -(i_K1 + i_to + i_Kr + i_Ks + i_CaL + i_NaK + i_Na + i_b_Na + i_NaCa + i_b_Ca + i_p_K
               + i_p_Ca + i_Stim)
     dK_i_dt = -(i_K1 + i_to + i_Kr + i_Ks + i_p_K + i_Stim - 2 * i_NaK) / (V_c * F) * Cm
 
-    fvals = [dXr1_dt, dXr2_dt, dXs_dt, dm_dt, dh_dt, dj_dt, dd_dt, df_dt, df2_dt, dfCass_dt, ds_dt,
-             dr_dt, dR_prime_dt, dCa_i_dt, dCa_SR_dt, dCa_ss_dt, dNa_i_dt, dV_dt, dK_i_dt]
-    # explicit self-derivatives of the expressions as written
-    J = [-1 / tau_xr1, -1 / tau_xr2, -1 / tau_xs, -1 / tau_m, -1 / tau_h, -1 / tau_j, -1 / tau_d,
-         -1 / tau_f, -1 / tau_f2, -1 / tau_fCass, -1 / tau_s, -1 / tau_r, -Ca_ss * k2 - k4,
-         None, None, None, None, None, None]
+    return [dXr1_dt, dXr2_dt, dXs_dt, dm_dt, dh_dt, dj_dt, dd_dt, df_dt, df2_dt, dfCass_dt, ds_dt,
+            dr_dt, dR_prime_dt, dCa_i_dt, dCa_SR_dt, dCa_ss_dt, dNa_i_dt, dV_dt, dK_i_dt]
+
+
+_TP06_JAC = None
+
+
+def _tp06_linearized_function():
+    """J_i = d f_i / d y_i with every intermediate expression resolved (total self-derivative),
+    derived symbolically once and compiled with lambdify(cse=True)."""
+    global _TP06_JAC
+    if _TP06_JAC is None:
+        import sympy
+
+        ys = sympy.symbols(" ".join(TP06_STATES), real=True)
+        ps = sympy.symbols(" ".join("p_" + n for n in TP06_PARAMETERS), real=True)
+        tt = sympy.Symbol("t", real=True)
+        fs = tp06_rhs(ys, tt, ps, ns=_sympy_ns())
+        J = [sympy.diff(fi, yi) for fi, yi in zip(fs, ys)]
+        nonzero = [not (Ji == 0) for Ji in J]
+        fn = sympy.lambdify([*ys, tt, *ps], J, modules="numpy", cse=True)
+        _TP06_JAC = (fn, nonzero)
+    return _TP06_JAC
+
+
+def tp06_rhs_and_linearized(states, t, parameters):
+    """Returns (f, J): f[i] = dy_i/dt, J[i] = total d f_i / d y_i (None where identically 0)."""
+    states = np.asarray(states, dtype=np.float64)
+    parameters = np.asarray(parameters, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        fvals = tp06_rhs(states, t, parameters)
+        fn, nonzero = _tp06_linearized_function()
+        Jraw = fn(*states, t, *parameters)
+    shape = np.broadcast(*fvals).shape
+    fvals = [np.broadcast_to(np.asarray(v, dtype=np.float64), shape) for v in fvals]
+    J = [np.broadcast_to(np.asarray(v, dtype=np.float64), shape) if nz else None for v, nz in zip(Jraw, nonzero)]
     return fvals, J
 
 
@@ -313,14 +395,15 @@ def tp06_generalized_rush_larsen(states, t, dt, parameters, delta=1e-8):
         if Ji is None:
             values[i] = y + fi * dt
         else:
-            with np.errstate(divide="ignore", invalid="ignore"):
+            with np.errstate(all="ignore"):
                 values[i] = y + np.where(np.abs(Ji) > delta, fi * (np.exp(Ji * dt) - 1) / Ji, fi * dt)
     return values
 
 
 def tp06_forward_euler(states, t, dt, parameters):
     states = np.asarray(states, dtype=np.float64)
-    fvals, _ = tp06_rhs_and_linearized(states, t, parameters)
+    with np.errstate(all="ignore"):
+        fvals = tp06_rhs(states, t, np.asarray(parameters, dtype=np.float64))
     return states + dt * np.array(np.broadcast_arrays(*fvals))
 
 

@@ -76,8 +76,10 @@ class OdeSpec:
         return out
 
     # ---------------------------------------------------------------- symbolic
-    def linearized(self) -> dict[str, sympy.Expr]:
-        """d(dX_dt)/dX of each state-derivative expression *as written* (intermediates opaque)."""
+    def linearized(self, total: bool = True) -> dict[str, sympy.Expr]:
+        """d(dX_dt)/dX of each state derivative.  ``total=True``: every intermediate expression is
+        resolved first (total self-derivative, the variant the Niederer table pins); ``total=False``:
+        intermediates are held as opaque symbols (derivative of the expression as written)."""
         sym = {n: sympy.Symbol(n) for n in list(self.states) + list(self.parameters)}
         ns = {
             "exp": sympy.exp, "log": sympy.log, "sqrt": sympy.sqrt, "floor": sympy.floor,
@@ -90,18 +92,19 @@ class OdeSpec:
         out = {}
         for name, node in self.assignments:
             expr = eval(compile(ast.Expression(node), str(self.path), "eval"), {"__builtins__": {}}, ns)
-            ns[name] = sympy.Symbol(name)
+            ns[name] = sympy.sympify(expr) if total else sympy.Symbol(name)
             if name.startswith("d") and name.endswith("_dt") and name[1:-3] in self.states:
                 out[name[1:-3]] = sympy.diff(sympy.sympify(expr), sym[name[1:-3]])
         return out
 
-    def grl1(self, states: dict, parameters: dict, t: float, dt: float, delta: float = 1e-8):
+    def grl1(self, states: dict, parameters: dict, t: float, dt: float, delta: float = 1e-8, total: bool = True):
         """Returns (rhs, lin, new_states) dicts keyed by state name."""
         vals = self.evaluate(states, parameters, t)
-        lin = self.linearized()
+        lin = self.linearized(total)
         env = dict(parameters)
         env.update(states)
         env.update(vals)
+        env["time"] = t
         rhs, J, new = {}, {}, {}
         for s in self.state_names:
             f = np.asarray(vals[f"d{s}_dt"], dtype=float) + 0.0 * np.asarray(states[s])
@@ -112,7 +115,7 @@ class OdeSpec:
                 new[s] = states[s] + f * dt
                 continue
             syms = sorted(e.free_symbols, key=lambda x: x.name)
-            fn = sympy.lambdify(syms, e, "numpy")
+            fn = sympy.lambdify(syms, e, "numpy", cse=True)
             with np.errstate(all="ignore"):
                 Jv = np.asarray(fn(*[env[x.name] for x in syms]), dtype=float) + 0.0 * f
                 J[s] = Jv

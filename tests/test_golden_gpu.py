@@ -1,0 +1,154 @@
+"""GPU: the HIP path against the committed golden fixtures (tests/golden/, generated from the
+reference's own modules and model specification by tests/golden/make_golden.py)."""
+
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(autouse=True)
+def _ctx(hip_ctx):
+    return hip_ctx
+
+
+def test_tp06_kernel_matches_the_ode_spec_golden(hip_ctx):
+    """One GRL1 step of the HIP kernel vs the reference's .ode specification evaluated independently
+    (SymPy total self-derivatives): 1e-11 relative to the state scale."""
+    from beat.models import tp06
+
+    g = np.load(GOLD / "tp06_spec.npz")
+    assert tuple(g["state_names"]) == tp06.generalized_rush_larsen.state_names
+    assert tuple(g["parameter_names"]) == tp06.generalized_rush_larsen.parameter_names
+    np.testing.assert_array_equal(g["state_defaults"], tp06.init_state_values())
+    np.testing.assert_array_equal(g["parameter_defaults"], tp06.init_parameter_values())
+    out = tp06.generalized_rush_larsen(states=g["states"], t=float(g["t"]), parameters=tp06.init_parameter_values(),
+                                       dt=float(g["dt"]))
+    ref = g["grl1_total"]
+    err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-11, err.max()
+    # and a 1-D state vector (single cell), as single_cell-style callers pass it
+    one = tp06.generalized_rush_larsen(states=g["states"][:, 0], t=float(g["t"]), parameters=tp06.init_parameter_values(),
+                                       dt=float(g["dt"]))
+    assert one.shape == (19,) and np.allclose(one, ref[:, 0], rtol=1e-11)
+
+
+def test_dolfin_ode_solver_matches_reference_golden():
+    import beat
+    from beat import grid as g
+
+    gold = np.load(GOLD / "splitting_reference.npz")
+    mesh = g.create_unit_interval(g.COMM_WORLD, 6)  # 7 nodes
+    V = g.functionspace(mesh, ("P", 1))
+    v_ode, v_pde = g.Function(V), g.Function(V)
+    ode = beat.odesolver.DolfinODESolver(v_ode=v_ode, v_pde=v_pde, init_states=np.array([1.0, 2.0]),
+                                         parameters=np.array([1.5, 0.5]), fun=beat.models.simple.forward_euler,
+                                         num_states=2, v_index=0)
+    np.testing.assert_array_equal(ode.values, gold["dolfin_values_init"])
+    ode.step(0.0, 0.1)
+    np.testing.assert_allclose(ode.values, gold["dolfin_values_after_step"], rtol=1e-15)
+    np.testing.assert_array_equal(np.asarray(v_ode.x.array), gold["dolfin_v_ode_before_to_dolfin"])
+    ode.to_dolfin()
+    np.testing.assert_allclose(np.asarray(v_ode.x.array), gold["dolfin_v_ode_after_to_dolfin"], rtol=1e-15)
+    ode.ode_to_pde()
+    np.testing.assert_allclose(np.asarray(v_pde.x.array), gold["dolfin_v_pde_after_ode_to_pde"], rtol=1e-15)
+    v_pde.x.array[:] = np.linspace(-1.0, 1.0, 7)
+    ode.pde_to_ode()
+    ode.from_dolfin()
+    np.testing.assert_allclose(ode.values, gold["dolfin_values_after_from_dolfin"], rtol=1e-15)
+
+
+def test_multi_ode_solver_matches_reference_golden():
+    import beat
+    from beat import grid as g
+
+    gold = np.load(GOLD / "splitting_reference.npz")
+    mesh = g.create_unit_interval(g.COMM_WORLD, 9)
+    V = g.functionspace(mesh, ("P", 1))
+    v_ode, v_pde, markers = g.Function(V), g.Function(V), g.Function(V)
+    markers.x.array[:] = gold["multi_markers"]
+    fe = beat.models.simple.forward_euler
+    multi = beat.odesolver.DolfinMultiODESolver(
+        v_ode=v_ode, v_pde=v_pde, markers=markers,
+        init_states={0: np.array([1.0, 2.0]), 1: np.array([3.0, 4.0]), 2: np.array([5.0, 6.0])},
+        parameters={0: np.array([1.0, 1.0]), 1: np.array([2.0, 0.5]), 2: np.array([0.25, 4.0])},
+        fun={0: fe, 1: fe, 2: fe}, num_states={0: 2, 1: 2, 2: 2}, v_index={0: 0, 1: 0, 2: 0})
+    multi.step(0.0, 0.1)
+    multi.to_dolfin()
+    np.testing.assert_allclose(np.asarray(v_ode.x.array), gold["multi_v_ode_after_to_dolfin"], rtol=1e-15)
+    np.testing.assert_allclose(multi.full_values, gold["multi_full_values_after_step"], rtol=1e-15)
+    v_ode.x.array[:] = np.arange(10.0)
+    multi.from_dolfin()
+    np.testing.assert_allclose(multi.full_values, gold["multi_full_values_after_from_dolfin"], rtol=1e-15)
+    for mk in (0, 1, 2):
+        np.testing.assert_allclose(multi.values(mk), gold[f"multi_values_marker{mk}"], rtol=1e-15)
+
+
+class _RecordingPDE:
+    """Same affine fake diffusion step as the fixture generator: state <- 0.5 v_ + 1."""
+
+    def __init__(self, state, log):
+        self.state, self.log = state, log
+        self.v_ = np.zeros(state.x.array.size)
+
+    def assign_previous(self):
+        self.log.append("pde.assign_previous")
+        self.v_[:] = np.asarray(self.state.x.array)
+
+    def step(self, interval):
+        self.log.append(f"pde.step({interval[0]:.6f},{interval[1]:.6f})")
+        self.state.x.array[:] = 0.5 * self.v_ + 1.0
+
+
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_splitting_solver_call_order_and_values_match_reference_golden(theta):
+    import beat
+    from beat import grid as g
+
+    gold = np.load(GOLD / "splitting_reference.npz")
+    meta = json.loads((GOLD / "splitting_reference.json").read_text())
+    tag = f"split_theta{theta:g}".replace(".", "p")
+    mesh = g.create_unit_interval(g.COMM_WORLD, 4)
+    V = g.functionspace(mesh, ("P", 1))
+    log = []
+    pde = _RecordingPDE(g.Function(V), log)
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, init_states=gold[f"{tag}_init_states"],
+                                         parameters=np.array([1.0, 1.0]), fun=beat.models.simple.forward_euler,
+                                         num_states=2, v_index=0)
+    real_step = ode.step
+
+    def logged_step(t0, dt):
+        log.append(f"ode.fun(t={t0:.6f},dt={dt:.6f})")
+        real_step(t0, dt)
+
+    ode.step = logged_step
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta)
+    assert log == meta[f"{tag}_calls_init"]
+    del log[:]
+    solver.step((0.0, 0.1))
+    assert log == meta[f"{tag}_calls_step"]
+    np.testing.assert_allclose(ode.values, gold[f"{tag}_values_after_step"], rtol=1e-15)
+    np.testing.assert_allclose(np.asarray(pde.state.x.array), gold[f"{tag}_pde_state_after_step"], rtol=1e-15)
+    np.testing.assert_allclose(pde.v_, gold[f"{tag}_pde_prev_after_step"], rtol=1e-15)
+    del log[:]
+    solver.solve((0.1, 0.4), dt=0.1)
+    assert log == meta[f"{tag}_calls_solve"]
+    np.testing.assert_allclose(ode.values, gold[f"{tag}_values_after_solve"], rtol=1e-15)
+
+
+def test_free_running_ode_solve_matches_reference_golden():
+    import beat
+
+    gold = np.load(GOLD / "splitting_reference.npz")
+    states = np.zeros((2, 3))
+    states.T[:] = [1.0, 0.0]
+    trace = np.zeros((12, 3))
+    beat.odesolver.solve(fun=beat.models.simple.forward_euler, t_bound=1.0, states=states, V=trace, V_index=0, dt=0.1,
+                         parameters=np.array([1.0, 1.0]))
+    np.testing.assert_allclose(trace, gold["solve_trace"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(states, gold["solve_final_states"], rtol=1e-14)
