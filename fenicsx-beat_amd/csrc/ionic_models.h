@@ -111,7 +111,7 @@ struct Tp06Grl1 {
   };
 
   struct Derived {
-    double RTF, FRT, halfRTF, sqrtKo, gK1s, gKrs, KoPk, cCaL, eCaL0, NaK_B, Nao3, A2c, kNaCaQ, gm1,
+    double RTF, FRT, halfRTF, sqrtKo, gK1s, gKrs, KoPk, cCaL, NaK_B, Nao3, A2c, kNaCaQ, gm1,
         cVF, c1, c2, c3, c4, c5, Kup2, BKc, BKsr, BKss, dsr;
   };
   __host__ __device__ static Derived derive(const double* p) {
@@ -124,7 +124,6 @@ struct Tp06Grl1 {
     q.gKrs = p[g_Kr] * q.sqrtKo;
     q.KoPk = p[K_o] + p[P_kna] * p[Na_o];
     q.cCaL = p[g_CaL] * 4.0 * (p[F] * p[F]) / (p[R] * p[T]);
-    q.eCaL0 = exp(-30.0 * q.FRT);
     q.NaK_B = p[P_NaK] * p[K_o] / (p[K_o] + p[K_mk]);
     q.Nao3 = p[Na_o] * p[Na_o] * p[Na_o];
     q.A2c = q.Nao3 * p[alpha];
@@ -271,7 +270,9 @@ struct Tp06Grl1 {
     const double e6 = e5_8 * e5_2;                                // exp(-V F/RT)
     const double eg = exp(p[gamma] * vF);
     const double eg1 = eg * e6;                                   // exp((gamma - 1) V F/RT)
-    const double eCaL = q.eCaL0 * rcp(e6 * e6);                   // exp(2 (V - 15) F/RT)
+    // exp(2 (V - 15) F/RT): kept as its own exp() -- i_CaL divides by (eCaL - 1), which cancels
+    // near V = 15 mV and would amplify the few-ulp error of a value derived from e6
+    const double eCaL = exp(2.0 * (v - 15.0) * q.FRT);
 
     // ---- L-type calcium (.ode:240-268) ------------------------------------------------------------------
     const double gates_CaL = q.cCaL * vd * vf * vf2 * vfCass;

@@ -92,7 +92,9 @@ def test_simple_ode_and_fhn_match_oracle(hip_ctx):
 
 def test_tp06_grl1_one_step_matches_oracle(hip_ctx):
     """One GRL1 step on 20k random physiological states: |HIP - oracle| <= 1e-11 relative to the
-    state scale (different exp/log implementations; the update multiplies rounding by <= dt*|J|)."""
+    state scale (different exp/log implementations; the update multiplies rounding by <= dt*|J|).
+    i_CaL = ... / (exp(2 (V-15) F/RT) - 1) has a removable singularity at V = 15 mV where the
+    reference's own formula loses digits; nodes within 0.05 mV of it get 1e-8."""
     from beat import _hip
     from oracle import ionic
 
@@ -105,7 +107,9 @@ def test_tp06_grl1_one_step_matches_oracle(hip_ctx):
         scale = np.maximum(np.abs(ref), 1e-3)
         err = np.abs(out - ref) / scale
         assert np.isfinite(out).all()
-        assert err.max() < 1e-11, (err.max(), np.unravel_index(err.argmax(), err.shape))
+        near = np.abs(S[17] - 15.0) < 0.05
+        assert err[:, ~near].max() < 1e-11, (err[:, ~near].max(), np.unravel_index(err.argmax(), err.shape))
+        assert err[:, near].max() < 1e-8
 
 
 def test_tp06_many_steps_and_stimulus_window(hip_ctx):
