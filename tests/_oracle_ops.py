@@ -1,0 +1,141 @@
+"""Test-only compute backend for beat._engine.DiffusionSolver: the same stage interface as
+``HipOps`` but every stage is the CPU oracle (NumPy) on CPU torch tensors, so that the product's
+slab decomposition / halo exchange / all-reduce orchestration can run under gloo without a GPU."""
+
+import numpy as np
+import torch
+
+from oracle import fem
+
+ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON, ST_RTOL, ST_ATOL, ST_MAXIT = range(14)
+
+
+class CpuField:
+    def __init__(self, n, plane):
+        self.n, self.plane = n, plane
+        self.buf = torch.zeros(n + 2 * plane, dtype=torch.float64)
+        self.data = self.buf[plane : plane + n]
+
+    @property
+    def ghost_lo(self):
+        return self.buf[: self.plane]
+
+    @property
+    def ghost_hi(self):
+        return self.buf[self.plane + self.n :]
+
+    def numpy(self):
+        return self.data.numpy()
+
+
+class OracleOps:
+    def __init__(self, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab):
+        self.shape = tuple(int(v) for v in shape_local)
+        nx, ny, nz = self.shape
+        self.plane, self.n = nx * ny, nx * ny * nz
+        self.lo_phys, self.hi_phys = bool(lo_phys), bool(hi_phys)
+        self.mass_tab, self.stiff_tab = np.asarray(mass_tab), np.asarray(stiff_tab)
+        self.r, self.p, self.q = (CpuField(self.n, self.plane) for _ in range(3))
+        self.st = torch.zeros(16, dtype=torch.float64)
+        # node types of the slab: z type decided by the PHYSICAL position of the plane
+        def t(n, lo, hi):
+            a = np.ones(n, dtype=np.int64)
+            if n == 1 and lo and hi:
+                return a
+            if lo:
+                a[0] = 0
+            if hi:
+                a[-1] = 2
+            return a
+        tx, ty, tz = t(nx, True, True), t(ny, True, True), t(nz, self.lo_phys, self.hi_phys)
+        self.typ = (tx[None, None, :] + 3 * ty[None, :, None] + 9 * tz[:, None, None])
+
+    def new_field(self):
+        return CpuField(self.n, self.plane)
+
+    def read_state(self):
+        return self.st.numpy().copy()
+
+    def set_timestep(self, C_m, theta, dt):
+        self.C_m, self.theta, self.dt = C_m, theta, dt
+        self.A = C_m * self.mass_tab + theta * dt * self.stiff_tab
+        self.dinv = (1.0 / self.A[:, 0])[self.typ].ravel()
+
+    def _apply(self, tab, f: CpuField):
+        nx, ny, nz = self.shape
+        X = np.zeros((nz + 2, ny + 2, nx + 2))
+        X[1:-1, 1:-1, 1:-1] = f.data.numpy().reshape(nz, ny, nx)
+        if not self.lo_phys:
+            X[0, 1:-1, 1:-1] = f.ghost_lo.numpy().reshape(ny, nx)
+        if not self.hi_phys:
+            X[-1, 1:-1, 1:-1] = f.ghost_hi.numpy().reshape(ny, nx)
+        y = np.zeros((nz, ny, nx))
+        for k, (ox, oy, oz) in enumerate(fem.STENCIL_OFFSETS):
+            y += tab[:, k][self.typ] * X[1 + oz : 1 + oz + nz, 1 + oy : 1 + oy + ny, 1 + ox : 1 + ox + nx]
+        return y.ravel()
+
+    def rhs(self, v_prev, stim_w, stim_amp, x):
+        Mv, Kv = self._apply(self.mass_tab, v_prev), self._apply(self.stiff_tab, v_prev)
+        stim = np.zeros(self.n)
+        for w, a in zip(stim_w, stim_amp):
+            stim += a * w.data.numpy()
+        b = self.C_m * Mv - (1 - self.theta) * self.dt * Kv + self.dt * stim
+        r = self.dt * (stim - Kv)
+        z = self.dinv * r
+        if x is not v_prev:
+            x.data.copy_(v_prev.data)
+        self.r.data.copy_(torch.from_numpy(r))
+        self.p.data.copy_(torch.from_numpy(z))
+        self.st[ST_BB], self.st[ST_RZ], self.st[ST_RR] = float(b @ b), float(r @ z), float(r @ r)
+
+    def cg_begin(self, rtol, atol, max_it):
+        st = self.st
+        tr, ta = rtol * rtol * float(st[ST_BB]), atol * atol
+        st[ST_TOL2] = max(tr, ta)
+        st[ST_ITERS], st[ST_RTOL], st[ST_ATOL], st[ST_MAXIT], st[ST_BETA] = 0.0, rtol, atol, float(max_it), 0.0
+        done = float(st[ST_RR]) <= float(st[ST_TOL2])
+        st[ST_STOP] = 1.0 if done else 0.0
+        st[ST_REASON] = (2.0 if float(st[ST_RR]) <= tr else 3.0) if done else 0.0
+
+    def spmv_dot(self):
+        if self.st[ST_STOP] != 0:
+            return
+        q = self._apply(self.A, self.p)
+        self.q.data.copy_(torch.from_numpy(q))
+        self.st[ST_PQ] = float(self.p.data.numpy() @ q)
+
+    def cg_update(self, x):
+        if self.st[ST_STOP] != 0:
+            return
+        alpha = float(self.st[ST_RZ]) / float(self.st[ST_PQ])
+        x.data.add_(self.p.data, alpha=alpha)
+        self.r.data.add_(self.q.data, alpha=-alpha)
+        r = self.r.data.numpy()
+        self.st[ST_RZN], self.st[ST_RRN] = float(r @ (self.dinv * r)), float(r @ r)
+
+    def cg_next(self):
+        st = self.st
+        if st[ST_STOP] != 0:
+            return
+        st[ST_BETA] = float(st[ST_RZN]) / float(st[ST_RZ])
+        st[ST_RZ], st[ST_RR] = float(st[ST_RZN]), float(st[ST_RRN])
+        st[ST_ITERS] += 1.0
+        tr = float(st[ST_RTOL]) ** 2 * float(st[ST_BB])
+        if float(st[ST_RR]) <= float(st[ST_TOL2]):
+            st[ST_STOP], st[ST_REASON] = 1.0, (2.0 if float(st[ST_RR]) <= tr else 3.0)
+        elif float(st[ST_ITERS]) >= float(st[ST_MAXIT]):
+            st[ST_STOP], st[ST_REASON] = 1.0, -3.0
+        z = torch.from_numpy(self.dinv) * self.r.data
+        self.p.data.mul_(float(st[ST_BETA])).add_(z)
+
+    def solve_single(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it):
+        from beat._engine import KspResult
+
+        self.rhs(v_prev, stim_w, stim_amp, x)
+        self.cg_begin(rtol, atol, max_it)
+        while self.st[ST_STOP] == 0:
+            self.spmv_dot()
+            self.cg_update(x)
+            self.cg_next()
+        st = self.st.numpy()
+        return KspResult(int(st[ST_ITERS]), float(np.sqrt(st[ST_RR])), int(st[ST_REASON]), float(np.sqrt(st[ST_BB])))
