@@ -11,31 +11,33 @@ struct ParamPack {
   double p[NP];
 };
 
+// Minimum resident waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__): the TP06 step has ~50 independent exp() chains that the scheduler would
+// otherwise hoist until one wave owns the whole register file.
+#ifndef BEAT_ODE_WAVES
+#define BEAT_ODE_WAVES 2
+#endif
+
 template <class Model, bool PER_NODE>
-__global__ __launch_bounds__(BEAT_BLOCK) void ode_step_kernel(
+__global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
     int v_index, double* __restrict__ v_copy) {
+  __shared__ double etab[64];
+  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  __syncthreads();
+  const FastMath fm{etab};
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;
-  double y[Model::NS];
-#pragma unroll
-  for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];
+  const NodeIO io{states, ld, i, v_copy, v_index};
   if (PER_NODE) {
     double pl[Model::NP];
 #pragma unroll
     for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
     const typename Model::Derived dl = Model::derive(pl);
-    Model::step(y, pl, dl, t, dt);
+    Model::step(io, pl, dl, fm, t, dt);
   } else {
-    Model::step(y, prm.p, drv, t, dt);
-  }
-#pragma unroll
-  for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
-  if (v_copy != nullptr) {
-#pragma unroll
-    for (int k = 0; k < Model::NS; ++k)
-      if (k == v_index) v_copy[i] = y[k];
+    Model::step(io, prm.p, drv, fm, t, dt);
   }
 }
 

@@ -20,16 +20,24 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace {
 
-constexpr int TX = 64, TY = 16;
-constexpr int PITCH = TX + 2;
-constexpr int SLOT = (TY + 2) * PITCH;                      // 1188 doubles per staged plane
-constexpr int NLOAD = (SLOT + BEAT_BLOCK - 1) / BEAT_BLOCK;  // 5 staged values per thread
-constexpr int ROWS_PER_THREAD = TY / (BEAT_BLOCK / TX);      // 4
+// Tile shape of the stencil kernels: TX x TY nodes per workgroup and plane (TX*TY = 1024, four
+// rows per thread).  Wider tiles read longer contiguous row segments (DRAM page locality) at the
+// price of more y-halo rows (served by L2).
+template <int TX_, int TY_>
+struct Tile {
+  static constexpr int TX = TX_, TY = TY_;
+  static constexpr int PITCH = TX + 2;
+  static constexpr int SLOT = (TY + 2) * PITCH;                       // doubles per staged plane
+  static constexpr int NLOAD = (SLOT + BEAT_BLOCK - 1) / BEAT_BLOCK;  // staged values per thread
+  static constexpr int ROWS_PER_THREAD = TY / (BEAT_BLOCK / TX);      // 4
+  static_assert(TX * TY == 1024 && ROWS_PER_THREAD == 4, "tile must hold 1024 nodes");
+};
 constexpr int TARGET_BLOCKS = 1024;
 constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
@@ -49,16 +57,18 @@ struct Geom {
   int64_t plane;
   int tiles_x, tiles_y, nchunks, zc, total;
   int z_lo_phys, z_hi_phys;
+  int tile_tx;  // 64, 128 or 256: which Tile<> instantiation the grid was sized for
 };
 
 struct StencilArgs {
-  const double* x;
-  double* y;    // APPLY: y | SPMV: q | RHS: r
-  double* y2;   // RHS: p
-  double* y3;   // RHS: x (copy of v_) or nullptr
-  const double* tab;   // APPLY/SPMV: operator table | RHS: mass table
+  const double* x;     // input field (FUSED: previous search direction p_old)
+  const double* x2;    // FUSED: residual r
+  double* y;           // APPLY: y | SPMV*: q | RHS: r
+  double* y2;          // RHS: p | FUSED: new search direction p_new
+  double* y3;          // RHS: x (copy of v_) or nullptr
+  const double* tab;   // APPLY/SPMV*: operator table | RHS: mass table
   const double* tab2;  // RHS: stiffness table
-  const double* dinv;  // RHS: 1/diag(A) per type
+  const double* dinv;  // RHS/FUSED: 1/diag(A) per type
   Coef15 ci, ci2;
   double dinv_i;
   double cm, omt_dt, dt;
@@ -69,7 +79,10 @@ struct StencilArgs {
   const double* st;
 };
 
-enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2 };
+// APPLY: y = T x.  SPMV_DOT: q = A p, partial p.q.  RHS: see beat_pde_rhs.
+// SPMV_FUSED: p_new = D^-1 r + beta p_old formed while staging (written once by the owning tile),
+//             q = A p_new, partial p_new.q  -- replaces a separate p-update pass.
+enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_SPMV_FUSED = 3 };
 
 __device__ __forceinline__ int axis_type(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -85,21 +98,59 @@ __device__ __forceinline__ int tile_of_block(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
-__device__ __forceinline__ void stage_load(double (&reg)[NLOAD], const double* __restrict__ x,
-                                           const Geom& g, int x0, int y0, int gz) {
-  const bool zvalid = (gz >= 0 || !g.z_lo_phys) && (gz < g.nz || !g.z_hi_phys);
-  const double* __restrict__ base = x + (int64_t)gz * g.plane;
+// Per-thread staging descriptors, computed once per tile: which elements of the (TY+2)x(TX+2)
+// staged plane this thread moves, their offset inside an xy-plane (-1: outside the box or idle),
+// and for the fused mode the xy part of the node type and whether the tile owns the element.
+template <class T>
+struct StageDesc {
+  int off[T::NLOAD];
+  int txy[T::NLOAD];  // tx + 3 ty (+64 when the element is halo, i.e. not owned by this tile), or -1
+};
+
+template <class T>
+__device__ __forceinline__ void stage_setup(StageDesc<T>& d, const Geom& g, int x0, int y0) {
+  constexpr int NLOAD = T::NLOAD, PITCH = T::PITCH, SLOT = T::SLOT, TX = T::TX, TY = T::TY;
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) {
     const int idx = threadIdx.x + l * BEAT_BLOCK;
     const int row = idx / PITCH, col = idx - row * PITCH;
     const int gx = x0 + col - 1, gy = y0 + row - 1;
-    const bool ok = zvalid && idx < SLOT && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;
-    reg[l] = ok ? base[(int64_t)gy * g.nx + gx] : 0.0;
+    const bool ok = idx < SLOT && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;
+    d.off[l] = ok ? gy * g.nx + gx : -1;
+    const bool owned = ok && col >= 1 && col <= TX && row >= 1 && row <= TY;
+    d.txy[l] = ok ? (axis_type(gx, g.nx, 1, 1) + 3 * axis_type(gy, g.ny, 1, 1)) | (owned ? 0 : 64) : -1;
   }
 }
 
-__device__ __forceinline__ void stage_store(const double (&reg)[NLOAD], double* __restrict__ slot) {
+template <int MODE, class T>
+__device__ __forceinline__ void stage_load(double (&reg)[T::NLOAD], const StageDesc<T>& d, const StencilArgs& a,
+                                           const Geom& g, int gz, bool plane_owned, double beta) {
+  constexpr int NLOAD = T::NLOAD;
+  const bool zvalid = (gz >= 0 || !g.z_lo_phys) && (gz < g.nz || !g.z_hi_phys);
+  const int64_t zoff = (int64_t)gz * g.plane;
+  const int tz9 = 9 * axis_type(gz, g.nz, g.z_lo_phys, g.z_hi_phys);
+#pragma unroll
+  for (int l = 0; l < NLOAD; ++l) {
+    const bool ok = zvalid && d.off[l] >= 0;
+    if (MODE == MODE_SPMV_FUSED) {
+      double v = 0.0;
+      if (ok) {
+        const int64_t i = zoff + d.off[l];
+        const int type = (d.txy[l] & 63) + tz9;
+        const double di = (type == 13) ? a.dinv_i : a.dinv[type];
+        v = fma(beta, a.x[i], di * a.x2[i]);
+        if (plane_owned && !(d.txy[l] & 64)) a.y2[i] = v;
+      }
+      reg[l] = v;
+    } else {
+      reg[l] = ok ? a.x[zoff + d.off[l]] : 0.0;
+    }
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void stage_store(const double (&reg)[T::NLOAD], double* __restrict__ slot) {
+  constexpr int NLOAD = T::NLOAD, SLOT = T::SLOT;
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) {
     const int idx = threadIdx.x + l * BEAT_BLOCK;
@@ -107,12 +158,97 @@ __device__ __forceinline__ void stage_store(const double (&reg)[NLOAD], double* 
   }
 }
 
-template <int MODE>
+// One output plane of the tile from the three staged planes.
+template <int MODE, class T>
+__device__ __forceinline__ void compute_plane(const Geom& g, const StencilArgs& a, const double* __restrict__ lds,
+                                              int z, int x0, int y0, int lx, int wave, int tx, double& acc0,
+                                              double& acc1, double& acc2) {
+  constexpr int PITCH = T::PITCH, SLOT = T::SLOT, ROWS_PER_THREAD = T::ROWS_PER_THREAD;
+  const double* __restrict__ Pm = lds + ((z + 2) % 3) * SLOT;  // plane z-1
+  const double* __restrict__ P0 = lds + (z % 3) * SLOT;
+  const double* __restrict__ Pp = lds + ((z + 1) % 3) * SLOT;
+  const int tz = axis_type(z, g.nz, g.z_lo_phys, g.z_hi_phys);
+  const int gx = x0 + lx;
+#pragma unroll
+  for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
+    const int ly = wave * ROWS_PER_THREAD + rr;
+    const int gy = y0 + ly;
+    const int c = (ly + 1) * PITCH + (lx + 1);
+    double v[15];
+    v[0] = P0[c];
+    v[1] = P0[c + 1];
+    v[2] = P0[c - 1];
+    v[3] = P0[c + PITCH];
+    v[4] = P0[c - PITCH];
+    v[5] = Pp[c];
+    v[6] = Pm[c];
+    v[7] = P0[c + PITCH + 1];
+    v[8] = P0[c - PITCH - 1];
+    v[9] = Pp[c + PITCH];
+    v[10] = Pm[c - PITCH];
+    v[11] = Pp[c + 1];
+    v[12] = Pm[c - 1];
+    v[13] = Pp[c + PITCH + 1];
+    v[14] = Pm[c - PITCH - 1];
+    if (gx < g.nx && gy < g.ny) {
+      const int ty = axis_type(gy, g.ny, 1, 1);
+      const int type = tx + 3 * ty + 9 * tz;
+      const int64_t gi = (int64_t)z * g.plane + (int64_t)gy * g.nx + gx;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
+      if (MODE == MODE_RHS) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+        double di = a.dinv_i;
+        if (type != 13) {
+          s = 0.0;
+          s2 = 0.0;
+          const double* __restrict__ r1 = a.tab + type * TABW;
+          const double* __restrict__ r2 = a.tab2 + type * TABW;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) {
+            s = fma(r1[k], v[k], s);
+            s2 = fma(r2[k], v[k], s2);
+          }
+          di = a.dinv[type];
+        }
+        // s = (Mass v)_i, s2 = (K v)_i
+        double stim = 0.0;
+        for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
+        const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
+        const double r = a.dt * (stim - s2);
+        const double zz = di * r;
+        a.y[gi] = r;
+        a.y2[gi] = zz;
+        if (a.y3 != nullptr) a.y3[gi] = v[0];
+        acc0 = fma(b, b, acc0);
+        acc1 = fma(r, zz, acc1);
+        acc2 = fma(r, r, acc2);
+      } else {
+        if (type != 13) {
+          s = 0.0;
+          const double* __restrict__ r1 = a.tab + type * TABW;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) s = fma(r1[k], v[k], s);
+        }
+        a.y[gi] = s;
+        if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) acc0 = fma(v[0], s, acc0);
+      }
+    }
+  }
+}
+
+template <int MODE, class T>
 __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs a) {
+  constexpr int NLOAD = T::NLOAD, SLOT = T::SLOT, TX = T::TX, TY = T::TY;
   __shared__ double lds[3 * SLOT];
   __shared__ double red[4];
-  if (MODE == MODE_SPMV_DOT) {
+  double beta = 0.0;
+  if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) {
     if (a.st[STOP] != 0.0) return;  // convergence latch: nothing left to do in this solve
+    if (MODE == MODE_SPMV_FUSED) beta = a.st[BETA];
   }
   const int t = tile_of_block(blockIdx.x, g.total);
   if (t >= g.total) return;
@@ -124,100 +260,38 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   const int z_end = min(z_begin + g.zc, g.nz);
 
   const int lx = threadIdx.x & (TX - 1);
-  const int wave = threadIdx.x >> 6;
-  const int gx = x0 + lx;
-  const int tx = axis_type(gx, g.nx, 1, 1);
+  const int wave = threadIdx.x / TX;  // thread row group: rows 4*group .. 4*group+3 of the tile
+  const int tx = axis_type(x0 + lx, g.nx, 1, 1);
 
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;  // block partial sums (mode dependent)
 
-  double reg[NLOAD];
-  stage_load(reg, a.x, g, x0, y0, z_begin - 1);
-  stage_store(reg, lds + ((z_begin - 1 + 3) % 3) * SLOT);
-  stage_load(reg, a.x, g, x0, y0, z_begin);
-  stage_store(reg, lds + (z_begin % 3) * SLOT);
-  stage_load(reg, a.x, g, x0, y0, z_begin + 1);
+  StageDesc<T> d;
+  stage_setup<T>(d, g, x0, y0);
+  // planes z_begin-1 and z_begin go straight to LDS; the next two are held in registers so that
+  // two planes of global loads are always in flight behind the plane being computed
+  double ra[NLOAD], rb[NLOAD];
+  stage_load<MODE, T>(ra, d, a, g, z_begin - 1, false, beta);
+  stage_load<MODE, T>(rb, d, a, g, z_begin, true, beta);
+  stage_store<T>(ra, lds + ((z_begin + 2) % 3) * SLOT);
+  stage_store<T>(rb, lds + (z_begin % 3) * SLOT);
+  stage_load<MODE, T>(ra, d, a, g, z_begin + 1, z_begin + 1 < z_end, beta);
+  if (z_begin + 2 <= z_end) stage_load<MODE, T>(rb, d, a, g, z_begin + 2, z_begin + 2 < z_end, beta);
 
-  for (int z = z_begin; z < z_end; ++z) {
-    stage_store(reg, lds + ((z + 1) % 3) * SLOT);
-    if (z + 1 < z_end) stage_load(reg, a.x, g, x0, y0, z + 2);  // in flight during the compute
+  for (int z = z_begin; z < z_end; z += 2) {
+    stage_store<T>(ra, lds + ((z + 1) % 3) * SLOT);
+    if (z + 3 <= z_end) stage_load<MODE, T>(ra, d, a, g, z + 3, z + 3 < z_end, beta);
     __syncthreads();
-    const double* __restrict__ Pm = lds + ((z + 2) % 3) * SLOT;  // plane z-1
-    const double* __restrict__ P0 = lds + (z % 3) * SLOT;
-    const double* __restrict__ Pp = lds + ((z + 1) % 3) * SLOT;
-    const int tz = axis_type(z, g.nz, g.z_lo_phys, g.z_hi_phys);
-#pragma unroll
-    for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
-      const int ly = wave * ROWS_PER_THREAD + rr;
-      const int gy = y0 + ly;
-      const int c = (ly + 1) * PITCH + (lx + 1);
-      double v[15];
-      v[0] = P0[c];
-      v[1] = P0[c + 1];
-      v[2] = P0[c - 1];
-      v[3] = P0[c + PITCH];
-      v[4] = P0[c - PITCH];
-      v[5] = Pp[c];
-      v[6] = Pm[c];
-      v[7] = P0[c + PITCH + 1];
-      v[8] = P0[c - PITCH - 1];
-      v[9] = Pp[c + PITCH];
-      v[10] = Pm[c - PITCH];
-      v[11] = Pp[c + 1];
-      v[12] = Pm[c - 1];
-      v[13] = Pp[c + PITCH + 1];
-      v[14] = Pm[c - PITCH - 1];
-      if (gx < g.nx && gy < g.ny) {
-        const int ty = axis_type(gy, g.ny, 1, 1);
-        const int type = tx + 3 * ty + 9 * tz;
-        const int64_t gi = (int64_t)z * g.plane + (int64_t)gy * g.nx + gx;
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
-        if (MODE == MODE_RHS) {
-          double s2 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
-          double di = a.dinv_i;
-          if (type != 13) {
-            s = 0.0;
-            s2 = 0.0;
-            const double* __restrict__ r1 = a.tab + type * TABW;
-            const double* __restrict__ r2 = a.tab2 + type * TABW;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) {
-              s = fma(r1[k], v[k], s);
-              s2 = fma(r2[k], v[k], s2);
-            }
-            di = a.dinv[type];
-          }
-          // s = (Mass v)_i, s2 = (K v)_i
-          double stim = 0.0;
-          for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
-          const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
-          const double r = a.dt * (stim - s2);
-          const double zz = di * r;
-          a.y[gi] = r;
-          a.y2[gi] = zz;
-          if (a.y3 != nullptr) a.y3[gi] = v[0];
-          acc0 = fma(b, b, acc0);
-          acc1 = fma(r, zz, acc1);
-          acc2 = fma(r, r, acc2);
-        } else {
-          if (type != 13) {
-            s = 0.0;
-            const double* __restrict__ r1 = a.tab + type * TABW;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) s = fma(r1[k], v[k], s);
-          }
-          a.y[gi] = s;
-          if (MODE == MODE_SPMV_DOT) acc0 = fma(v[0], s, acc0);
-        }
-      }
-    }
+    compute_plane<MODE, T>(g, a, lds, z, x0, y0, lx, wave, tx, acc0, acc1, acc2);
+    __syncthreads();
+    if (z + 1 >= z_end) break;
+    stage_store<T>(rb, lds + ((z + 2) % 3) * SLOT);
+    if (z + 4 <= z_end) stage_load<MODE, T>(rb, d, a, g, z + 4, z + 4 < z_end, beta);
+    __syncthreads();
+    compute_plane<MODE, T>(g, a, lds, z + 1, x0, y0, lx, wave, tx, acc0, acc1, acc2);
     __syncthreads();
   }
 
-  if (MODE == MODE_SPMV_DOT) {
+  if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) {
     const double s0 = beat_block_sum(acc0, red);
     if (threadIdx.x == 0) a.partials[t] = s0;
   } else if (MODE == MODE_RHS) {
@@ -386,6 +460,14 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   g.plane = n[0] * n[1];
   g.z_lo_phys = z_lo_phys ? 1 : 0;
   g.z_hi_phys = z_hi_phys ? 1 : 0;
+  // tile width: as wide as the rows allow (long contiguous reads), overridable for experiments
+  int tile_tx = g.nx >= 256 ? 256 : g.nx >= 128 ? 128 : 64;
+  if (const char* e = std::getenv("BEAT_TILE_TX")) {
+    const int v = std::atoi(e);
+    if (v == 64 || v == 128 || v == 256) tile_tx = v;
+  }
+  g.tile_tx = tile_tx;
+  const int TX = tile_tx, TY = 1024 / tile_tx;
   g.tiles_x = (g.nx + TX - 1) / TX;
   g.tiles_y = (g.ny + TY - 1) / TY;
   const int tiles = g.tiles_x * g.tiles_y;
@@ -461,6 +543,18 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
 
 static inline unsigned stencil_grid(const Geom& g) { return (unsigned)(((g.total + 7) / 8) * 8); }
 
+template <int MODE>
+static void launch_stencil(const beat_pde* pde, const StencilArgs& a) {
+  const Geom& g = pde->g;
+  const dim3 grid(stencil_grid(g)), block(BEAT_BLOCK);
+  hipStream_t s = pde->ctx->stream;
+  switch (g.tile_tx) {
+    case 256: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<256, 4>>), grid, block, 0, s, g, a); break;
+    case 128: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<128, 8>>), grid, block, 0, s, g, a); break;
+    default: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<64, 16>>), grid, block, 0, s, g, a); break;
+  }
+}
+
 extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y) {
   BEAT_REQUIRE(pde != nullptr && dev_x && dev_y, "null argument");
   BEAT_REQUIRE(which >= 0 && which < 4, "which must be 0..3");
@@ -472,8 +566,7 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   a.y = dev_y;
   a.tab = pde->d_tab(which);
   a.ci = interior(host_tab);
-  hipLaunchKernelGGL((stencil_kernel<MODE_APPLY>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
-                     pde->ctx->stream, pde->g, a);
+  launch_stencil<MODE_APPLY>(pde, a);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -514,8 +607,7 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
     ++a.nstim;
   }
   a.partials = pde->ctx->d_partials;
-  hipLaunchKernelGGL((stencil_kernel<MODE_RHS>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
-                     pde->ctx->stream, pde->g, a);
+  launch_stencil<MODE_RHS>(pde, a);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, pde->g.total, 3, dev_red, nullptr);
 }
@@ -538,8 +630,7 @@ extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev
   a.ci = interior(pde->h_A);
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
-  hipLaunchKernelGGL((stencil_kernel<MODE_SPMV_DOT>), dim3(stencil_grid(pde->g)), dim3(BEAT_BLOCK), 0,
-                     pde->ctx->stream, pde->g, a);
+  launch_stencil<MODE_SPMV_DOT>(pde, a);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
 }
@@ -552,6 +643,31 @@ extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, 
                      pde->ctx->d_partials);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
+}
+
+// q = A p_new with p_new = D^-1 r + beta p_old formed on the fly (single-slab solve only).
+static int launch_spmv_fused(beat_pde* pde, const double* r, const double* p_old, double* p_new, double* q,
+                             double* dev_st) {
+  StencilArgs a{};
+  a.x = p_old;
+  a.x2 = r;
+  a.y = q;
+  a.y2 = p_new;
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.dinv_i = pde->h_dinv[13];
+  a.ci = interior(pde->h_A);
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  launch_stencil<MODE_SPMV_FUSED>(pde, a);
+  BEAT_LAUNCH_CHECK();
+  return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
+}
+
+static int launch_next_scalars(beat_pde* pde, double* dev_st) {
+  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
 }
 
 extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p) {
@@ -575,6 +691,7 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   double* r = dev_work + pde->g.plane;
   double* p = r + fld;
   double* q = p + fld;
+  double* p_alt = q + fld;  // the fused SpMV writes the new search direction out of place
   double* st = pde->d_st;
   int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, p, st);
   if (rc) return rc;
@@ -583,12 +700,19 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   double* h = ctx->h_pinned;
   int launched = 0;
   int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  bool first = true;
   while (true) {
     chunk = std::min(chunk, max_it - launched);
     for (int it = 0; it < chunk; ++it) {
-      if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
+      if (first) {
+        if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;  // p = D^-1 r from the rhs kernel
+        first = false;
+      } else {
+        if ((rc = launch_spmv_fused(pde, r, p, p_alt, q, st))) return rc;
+        std::swap(p, p_alt);
+      }
       if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
-      if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
+      if ((rc = launch_next_scalars(pde, st))) return rc;  // beta for the next fused SpMV, latch
     }
     launched += chunk;
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
