@@ -91,7 +91,7 @@ class HipOps:
                                      kt.ctypes.data_as(C.c_void_p), C.byref(handle))
         )
         self.handle = handle
-        self.work = ctx.zeros(4 * (self.n + 2 * self.plane))  # r, p, q, p' (see beat_pde_solve)
+        self.work = ctx.zeros(3 * (self.n + 2 * self.plane))  # r, p, q (see beat_pde_solve)
         fld = self.n + 2 * self.plane
         from ._device import Field
 

@@ -61,14 +61,13 @@ struct Geom {
 };
 
 struct StencilArgs {
-  const double* x;     // input field (FUSED: previous search direction p_old)
-  const double* x2;    // FUSED: residual r
-  double* y;           // APPLY: y | SPMV*: q | RHS: r
-  double* y2;          // RHS: p | FUSED: new search direction p_new
+  const double* x;     // input field
+  double* y;           // APPLY: y | SPMV: q | RHS: r
+  double* y2;          // RHS: p
   double* y3;          // RHS: x (copy of v_) or nullptr
-  const double* tab;   // APPLY/SPMV*: operator table | RHS: mass table
+  const double* tab;   // APPLY/SPMV: operator table | RHS: mass table
   const double* tab2;  // RHS: stiffness table
-  const double* dinv;  // RHS/FUSED: 1/diag(A) per type
+  const double* dinv;  // RHS: 1/diag(A) per type
   Coef15 ci, ci2;
   double dinv_i;
   double cm, omt_dt, dt;
@@ -80,9 +79,9 @@ struct StencilArgs {
 };
 
 // APPLY: y = T x.  SPMV_DOT: q = A p, partial p.q.  RHS: see beat_pde_rhs.
-// SPMV_FUSED: p_new = D^-1 r + beta p_old formed while staging (written once by the owning tile),
-//             q = A p_new, partial p_new.q  -- replaces a separate p-update pass.
-enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_SPMV_FUSED = 3 };
+// (Forming p = D^-1 r + beta p_old while staging was tried and rejected: the halo makes it re-read two
+//  fields 1.5x, 1.8 ms against 0.58 + 0.66 ms for SpMV + a streaming p-update at 512^3.)
+enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2 };
 
 __device__ __forceinline__ int axis_type(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -100,16 +99,14 @@ __device__ __forceinline__ int tile_of_block(int b, int total) {
 
 // Per-thread staging descriptors, computed once per tile: which elements of the (TY+2)x(TX+2)
 // staged plane this thread moves, their offset inside an xy-plane (-1: outside the box or idle),
-// and for the fused mode the xy part of the node type and whether the tile owns the element.
 template <class T>
 struct StageDesc {
   int off[T::NLOAD];
-  int txy[T::NLOAD];  // tx + 3 ty (+64 when the element is halo, i.e. not owned by this tile), or -1
 };
 
 template <class T>
 __device__ __forceinline__ void stage_setup(StageDesc<T>& d, const Geom& g, int x0, int y0) {
-  constexpr int NLOAD = T::NLOAD, PITCH = T::PITCH, SLOT = T::SLOT, TX = T::TX, TY = T::TY;
+  constexpr int NLOAD = T::NLOAD, PITCH = T::PITCH, SLOT = T::SLOT;
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) {
     const int idx = threadIdx.x + l * BEAT_BLOCK;
@@ -117,35 +114,17 @@ __device__ __forceinline__ void stage_setup(StageDesc<T>& d, const Geom& g, int 
     const int gx = x0 + col - 1, gy = y0 + row - 1;
     const bool ok = idx < SLOT && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;
     d.off[l] = ok ? gy * g.nx + gx : -1;
-    const bool owned = ok && col >= 1 && col <= TX && row >= 1 && row <= TY;
-    d.txy[l] = ok ? (axis_type(gx, g.nx, 1, 1) + 3 * axis_type(gy, g.ny, 1, 1)) | (owned ? 0 : 64) : -1;
   }
 }
 
-template <int MODE, class T>
+template <class T>
 __device__ __forceinline__ void stage_load(double (&reg)[T::NLOAD], const StageDesc<T>& d, const StencilArgs& a,
-                                           const Geom& g, int gz, bool plane_owned, double beta) {
+                                           const Geom& g, int gz) {
   constexpr int NLOAD = T::NLOAD;
   const bool zvalid = (gz >= 0 || !g.z_lo_phys) && (gz < g.nz || !g.z_hi_phys);
-  const int64_t zoff = (int64_t)gz * g.plane;
-  const int tz9 = 9 * axis_type(gz, g.nz, g.z_lo_phys, g.z_hi_phys);
+  const double* __restrict__ base = a.x + (int64_t)gz * g.plane;
 #pragma unroll
-  for (int l = 0; l < NLOAD; ++l) {
-    const bool ok = zvalid && d.off[l] >= 0;
-    if (MODE == MODE_SPMV_FUSED) {
-      double v = 0.0;
-      if (ok) {
-        const int64_t i = zoff + d.off[l];
-        const int type = (d.txy[l] & 63) + tz9;
-        const double di = (type == 13) ? a.dinv_i : a.dinv[type];
-        v = fma(beta, a.x[i], di * a.x2[i]);
-        if (plane_owned && !(d.txy[l] & 64)) a.y2[i] = v;
-      }
-      reg[l] = v;
-    } else {
-      reg[l] = ok ? a.x[zoff + d.off[l]] : 0.0;
-    }
-  }
+  for (int l = 0; l < NLOAD; ++l) reg[l] = (zvalid && d.off[l] >= 0) ? base[d.off[l]] : 0.0;
 }
 
 template <class T>
@@ -234,7 +213,7 @@ __device__ __forceinline__ void compute_plane(const Geom& g, const StencilArgs& 
           for (int k = 0; k < 15; ++k) s = fma(r1[k], v[k], s);
         }
         a.y[gi] = s;
-        if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) acc0 = fma(v[0], s, acc0);
+        if (MODE == MODE_SPMV_DOT) acc0 = fma(v[0], s, acc0);
       }
     }
   }
@@ -245,10 +224,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   constexpr int NLOAD = T::NLOAD, SLOT = T::SLOT, TX = T::TX, TY = T::TY;
   __shared__ double lds[3 * SLOT];
   __shared__ double red[4];
-  double beta = 0.0;
-  if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) {
+  if (MODE == MODE_SPMV_DOT) {
     if (a.st[STOP] != 0.0) return;  // convergence latch: nothing left to do in this solve
-    if (MODE == MODE_SPMV_FUSED) beta = a.st[BETA];
   }
   const int t = tile_of_block(blockIdx.x, g.total);
   if (t >= g.total) return;
@@ -270,28 +247,28 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   // planes z_begin-1 and z_begin go straight to LDS; the next two are held in registers so that
   // two planes of global loads are always in flight behind the plane being computed
   double ra[NLOAD], rb[NLOAD];
-  stage_load<MODE, T>(ra, d, a, g, z_begin - 1, false, beta);
-  stage_load<MODE, T>(rb, d, a, g, z_begin, true, beta);
+  stage_load<T>(ra, d, a, g, z_begin - 1);
+  stage_load<T>(rb, d, a, g, z_begin);
   stage_store<T>(ra, lds + ((z_begin + 2) % 3) * SLOT);
   stage_store<T>(rb, lds + (z_begin % 3) * SLOT);
-  stage_load<MODE, T>(ra, d, a, g, z_begin + 1, z_begin + 1 < z_end, beta);
-  if (z_begin + 2 <= z_end) stage_load<MODE, T>(rb, d, a, g, z_begin + 2, z_begin + 2 < z_end, beta);
+  stage_load<T>(ra, d, a, g, z_begin + 1);
+  if (z_begin + 2 <= z_end) stage_load<T>(rb, d, a, g, z_begin + 2);
 
   for (int z = z_begin; z < z_end; z += 2) {
     stage_store<T>(ra, lds + ((z + 1) % 3) * SLOT);
-    if (z + 3 <= z_end) stage_load<MODE, T>(ra, d, a, g, z + 3, z + 3 < z_end, beta);
+    if (z + 3 <= z_end) stage_load<T>(ra, d, a, g, z + 3);
     __syncthreads();
     compute_plane<MODE, T>(g, a, lds, z, x0, y0, lx, wave, tx, acc0, acc1, acc2);
     __syncthreads();
     if (z + 1 >= z_end) break;
     stage_store<T>(rb, lds + ((z + 2) % 3) * SLOT);
-    if (z + 4 <= z_end) stage_load<MODE, T>(rb, d, a, g, z + 4, z + 4 < z_end, beta);
+    if (z + 4 <= z_end) stage_load<T>(rb, d, a, g, z + 4);
     __syncthreads();
     compute_plane<MODE, T>(g, a, lds, z + 1, x0, y0, lx, wave, tx, acc0, acc1, acc2);
     __syncthreads();
   }
 
-  if (MODE == MODE_SPMV_DOT || MODE == MODE_SPMV_FUSED) {
+  if (MODE == MODE_SPMV_DOT) {
     const double s0 = beat_block_sum(acc0, red);
     if (threadIdx.x == 0) a.partials[t] = s0;
   } else if (MODE == MODE_RHS) {
@@ -645,31 +622,6 @@ extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, 
   return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
 }
 
-// q = A p_new with p_new = D^-1 r + beta p_old formed on the fly (single-slab solve only).
-static int launch_spmv_fused(beat_pde* pde, const double* r, const double* p_old, double* p_new, double* q,
-                             double* dev_st) {
-  StencilArgs a{};
-  a.x = p_old;
-  a.x2 = r;
-  a.y = q;
-  a.y2 = p_new;
-  a.tab = pde->d_tab(0);
-  a.dinv = pde->d_dinv();
-  a.dinv_i = pde->h_dinv[13];
-  a.ci = interior(pde->h_A);
-  a.partials = pde->ctx->d_partials;
-  a.st = dev_st;
-  launch_stencil<MODE_SPMV_FUSED>(pde, a);
-  BEAT_LAUNCH_CHECK();
-  return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
-}
-
-static int launch_next_scalars(beat_pde* pde, double* dev_st) {
-  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
-  BEAT_LAUNCH_CHECK();
-  return BEAT_OK;
-}
-
 extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p, "null argument");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
@@ -691,7 +643,6 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   double* r = dev_work + pde->g.plane;
   double* p = r + fld;
   double* q = p + fld;
-  double* p_alt = q + fld;  // the fused SpMV writes the new search direction out of place
   double* st = pde->d_st;
   int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, p, st);
   if (rc) return rc;
@@ -700,19 +651,12 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   double* h = ctx->h_pinned;
   int launched = 0;
   int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
-  bool first = true;
   while (true) {
     chunk = std::min(chunk, max_it - launched);
     for (int it = 0; it < chunk; ++it) {
-      if (first) {
-        if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;  // p = D^-1 r from the rhs kernel
-        first = false;
-      } else {
-        if ((rc = launch_spmv_fused(pde, r, p, p_alt, q, st))) return rc;
-        std::swap(p, p_alt);
-      }
+      if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
       if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
-      if ((rc = launch_next_scalars(pde, st))) return rc;  // beta for the next fused SpMV, latch
+      if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
     }
     launched += chunk;
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -163,9 +163,8 @@ int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double*
 /* Whole single-slab step: rhs build + Jacobi-PCG to ||r|| <= max(rtol*||b||, atol), with all
  * scalars kept on the device (one host synchronisation at the end to fill `info`).
  * Replaces _update_rhs + KSP.solve of base_model.py:232-236 when the grid is not decomposed.
- * dev_work: 4 fields (r, p, q, p') laid out back to back, each with its own ghost planes:
- * size 4*(n_local + 2*nx*ny) doubles (the p-update is fused into the SpMV and writes the new
- * search direction out of place). Synchronises. */
+ * dev_work: 3 fields (r, p, q) laid out back to back, each with its own ghost planes:
+ * size 3*(n_local + 2*nx*ny) doubles. Synchronises. */
 int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
                    double rtol, double atol, int max_it, beat_ksp_info* info);
