@@ -133,6 +133,14 @@ class HipOps:
     def spmv_dot(self):
         _hip.check(self.lib.beat_pde_spmv_dot(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr())))
 
+    def spmv_interior(self):
+        """q = A p on the planes that need no ghost data (runs while the halo exchange is in flight)."""
+        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 0))
+
+    def spmv_boundary(self):
+        """q = A p on the slab-boundary planes, then the local p.q."""
+        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 1))
+
     def cg_update(self, x):
         _hip.check(self.lib.beat_pde_cg_update(self.handle, C.c_void_p(self.st.data_ptr()), x.ptr, self.r.ptr,
                                                self.p.ptr, self.q.ptr))
@@ -154,12 +162,12 @@ class HipOps:
 class DiffusionSolver:
     """theta-rule diffusion step on one slab of a (possibly) decomposed grid."""
 
-    def __init__(self, ops, slab: Slab, group=None):
+    def __init__(self, ops, slab: Slab, group=None, force_distributed: bool = False):
         self.ops = ops
         self.slab = slab
         self.group = group
         self._last_its = 8
-        if slab.world > 1:
+        if slab.world > 1 or force_distributed:  # force_distributed: run the collective path on 1 rank (tests)
             import torch.distributed as dist
 
             self.dist = dist
@@ -169,8 +177,17 @@ class DiffusionSolver:
     # -- communication ------------------------------------------------------------------------
     def exchange_halo(self, field) -> None:
         """Send the first/last owned plane to the z-neighbours, receive into the ghost planes."""
-        if self.dist is None:
-            return
+        self.finish_halo(self.start_halo(field))
+
+    def finish_halo(self, reqs) -> None:
+        for req in reqs:
+            req.wait()
+
+    def start_halo(self, field):
+        """Enqueue the ghost-plane exchange (RCCL send/recv on the communication stream); returns the
+        requests to wait on before anything reads the ghost planes."""
+        if self.dist is None or self.slab.world == 1:
+            return []
         dist, slab, plane = self.dist, self.slab, field.plane
         ops = []
         first = field.data[:plane]
@@ -181,8 +198,7 @@ class DiffusionSolver:
         if not slab.hi_phys:
             ops.append(dist.P2POp(dist.isend, last, self._peer(slab.rank + 1), self.group))
             ops.append(dist.P2POp(dist.irecv, field.ghost_hi, self._peer(slab.rank + 1), self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def _peer(self, group_rank: int) -> int:
         if self.group is None:
@@ -207,8 +223,10 @@ class DiffusionSolver:
         while True:
             chunk = min(chunk, max_it - launched)
             for _ in range(chunk):
-                self.exchange_halo(ops.p)
-                ops.spmv_dot()
+                reqs = self.start_halo(ops.p)  # ghost planes of p travel ...
+                ops.spmv_interior()            # ... while the interior planes are computed
+                self.finish_halo(reqs)
+                ops.spmv_boundary()
                 self._allreduce(ops.st[3:4])
                 ops.cg_update(x)
                 self._allreduce(ops.st[4:6])

@@ -69,6 +69,7 @@ SIGNATURES = {
     "beat_pde_rhs": (_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _vp, _vp]),
     "beat_pde_cg_begin": (_int, [_vp, _vp, _dbl, _dbl, _int]),
     "beat_pde_spmv_dot": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_spmv_dot_part": (_int, [_vp, _vp, _vp, _vp, _int]),
     "beat_pde_cg_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "beat_pde_cg_next": (_int, [_vp, _vp, _vp, _vp]),
     "beat_pde_solve": (

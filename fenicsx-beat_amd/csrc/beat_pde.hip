@@ -58,6 +58,8 @@ struct Geom {
   int tiles_x, tiles_y, nchunks, zc, total;
   int z_lo_phys, z_hi_phys;
   int tile_tx;  // 64, 128 or 256: which Tile<> instantiation the grid was sized for
+  int z_lo, z_hi;    // planes [z_lo, z_hi) computed by this launch (whole slab: 0, nz)
+  int part_off;      // first block-partial slot this launch writes
 };
 
 struct StencilArgs {
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   const int tile_y = (t / g.tiles_x) % g.tiles_y;
   const int chunk = t / (g.tiles_x * g.tiles_y);
   const int x0 = tile_x * TX, y0 = tile_y * TY;
-  const int z_begin = chunk * g.zc;
-  const int z_end = min(z_begin + g.zc, g.nz);
+  const int z_begin = g.z_lo + chunk * g.zc;
+  const int z_end = min(z_begin + g.zc, g.z_hi);
 
   const int lx = threadIdx.x & (TX - 1);
   const int wave = threadIdx.x / TX;  // thread row group: rows 4*group .. 4*group+3 of the tile
@@ -270,15 +272,15 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
 
   if (MODE == MODE_SPMV_DOT) {
     const double s0 = beat_block_sum(acc0, red);
-    if (threadIdx.x == 0) a.partials[t] = s0;
+    if (threadIdx.x == 0) a.partials[g.part_off + t] = s0;
   } else if (MODE == MODE_RHS) {
     const double s0 = beat_block_sum(acc0, red);
     const double s1 = beat_block_sum(acc1, red);
     const double s2 = beat_block_sum(acc2, red);
     if (threadIdx.x == 0) {
-      a.partials[t] = s0;
-      a.partials[BEAT_MAX_PARTIALS + t] = s1;
-      a.partials[2 * BEAT_MAX_PARTIALS + t] = s2;
+      a.partials[g.part_off + t] = s0;
+      a.partials[BEAT_MAX_PARTIALS + g.part_off + t] = s1;
+      a.partials[2 * BEAT_MAX_PARTIALS + g.part_off + t] = s2;
     }
   }
 }
@@ -461,6 +463,9 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   }
   BEAT_REQUIRE((int64_t)tiles * g.nchunks <= BEAT_MAX_PARTIALS, "xy plane too large: %d tiles", tiles);
   g.total = tiles * g.nchunks;
+  g.z_lo = 0;
+  g.z_hi = g.nz;
+  g.part_off = 0;
   p->n = n[0] * n[1] * n[2];
   const int64_t rows = (int64_t)g.ny * g.nz;
   p->vec_grid = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (rows + 3) / 4));
@@ -520,9 +525,27 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
 
 static inline unsigned stencil_grid(const Geom& g) { return (unsigned)(((g.total + 7) / 8) * 8); }
 
+// Geometry of a launch restricted to planes [z_lo, z_hi) of the slab, writing block partials from
+// slot part_off on (used to overlap the interior SpMV with the halo exchange).
+static Geom range_geom(const Geom& full, int z_lo, int z_hi, int part_off) {
+  Geom g = full;
+  g.z_lo = z_lo;
+  g.z_hi = z_hi;
+  const int tiles = g.tiles_x * g.tiles_y;
+  const int nzr = std::max(0, z_hi - z_lo);
+  int nchunks = std::max(1, (TARGET_BLOCKS + tiles - 1) / tiles);
+  nchunks = std::max(1, std::min(nchunks, nzr));
+  g.zc = std::max(1, (nzr + nchunks - 1) / nchunks);
+  g.nchunks = (nzr + g.zc - 1) / g.zc;
+  g.total = tiles * g.nchunks;
+  g.part_off = part_off;
+  return g;
+}
+
 template <int MODE>
-static void launch_stencil(const beat_pde* pde, const StencilArgs& a) {
-  const Geom& g = pde->g;
+static void launch_stencil(const beat_pde* pde, const StencilArgs& a, const Geom* range = nullptr) {
+  const Geom& g = range ? *range : pde->g;
+  if (g.total <= 0) return;
   const dim3 grid(stencil_grid(g)), block(BEAT_BLOCK);
   hipStream_t s = pde->ctx->stream;
   switch (g.tile_tx) {
@@ -610,6 +633,41 @@ extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev
   launch_stencil<MODE_SPMV_DOT>(pde, a);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
+}
+
+extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part) {
+  BEAT_REQUIRE(pde != nullptr && dev_p && dev_q && dev_st, "null argument");
+  BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  BEAT_REQUIRE(part == 0 || part == 1, "part must be 0 (interior) or 1 (boundary planes + reduce)");
+  const Geom& f = pde->g;
+  const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);  // planes that need no ghost data
+  StencilArgs a{};
+  a.x = dev_p;
+  a.y = dev_q;
+  a.tab = pde->d_tab(0);
+  a.ci = interior(pde->h_A);
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  const Geom gi = range_geom(f, lo, std::max(lo, hi), 0);
+  if (part == 0) {
+    launch_stencil<MODE_SPMV_DOT>(pde, a, &gi);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
+  int off = gi.total;
+  if (!f.z_lo_phys) {
+    const Geom gb = range_geom(f, 0, 1, off);
+    launch_stencil<MODE_SPMV_DOT>(pde, a, &gb);
+    off += gb.total;
+  }
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) {
+    const Geom gb = range_geom(f, f.nz - 1, f.nz, off);
+    launch_stencil<MODE_SPMV_DOT>(pde, a, &gb);
+    off += gb.total;
+  }
+  BEAT_LAUNCH_CHECK();
+  BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+  return launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
 }
 
 extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,

@@ -152,6 +152,10 @@ int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
 int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, double atol, int max_it);
 /* q = A p (ghost planes of p must be current); LOCAL p.q -> dev_st[3]  -> all-reduce dev_st[3:4]. */
 int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
+/* The same SpMV in two parts, to overlap the halo exchange of p with compute on a decomposed grid:
+ * part 0 computes the planes that need no ghost data (enqueue it while the ghost planes travel),
+ * part 1 the one or two slab-boundary planes, then reduces LOCAL p.q -> dev_st[3]. */
+int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 /* alpha = st[1]/st[3]; x += alpha p; r -= alpha q; LOCAL r.D^-1 r, r.r -> dev_st[4..5]
  * -> all-reduce dev_st[4:6]. */
 int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,

@@ -367,3 +367,44 @@ def test_field_utilities(hip_ctx):
     _hip.check(ctx.lib.beat_field_probe(ctx.handle, a.ptr, pidx.ctypes.data_as(C.c_void_p),
                                         w.ctypes.data_as(C.c_void_p), 2, out.ctypes.data_as(C.c_void_p)))
     np.testing.assert_allclose(out, [w[0] @ x[:4], x[5]], rtol=1e-15)
+
+
+@pytest.mark.parametrize("lo_phys,hi_phys,nzl", [(0, 0, 5), (1, 0, 4), (0, 1, 3), (0, 0, 1), (0, 0, 2), (1, 1, 4)])
+def test_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl):
+    """beat_pde_spmv_dot_part: interior planes (part 0, ghost planes POISONED while it runs) + boundary
+    planes (part 1) give the same q and p.q as the one-shot SpMV."""
+    from beat import _hip, _stencil
+    from beat._device import Field
+
+    ctx = hip_ctx
+    nx, ny = 70, 21
+    plane, n = nx * ny, nx * ny * nzl
+    mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), _conductivity("aniso3", 3))
+    n3 = (C.c_int64 * 3)(nx, ny, nzl)
+    handle = C.c_void_p()
+    _hip.check(ctx.lib.beat_pde_create(ctx.handle, n3, lo_phys, hi_phys, mt.ctypes.data_as(C.c_void_p),
+                                       kt.ctypes.data_as(C.c_void_p), C.byref(handle)))
+    _hip.check(ctx.lib.beat_pde_set_timestep(handle, 0.01, 0.5, 0.05))
+    rng = np.random.default_rng(12)
+    p, q1, q2 = Field(ctx, n, plane), Field(ctx, n, plane), Field(ctx, n, plane)
+    p.set(rng.standard_normal(n))
+    glo, ghi = rng.standard_normal(plane), rng.standard_normal(plane)
+    p.ghost_lo.copy_(ctx.from_numpy(glo))
+    p.ghost_hi.copy_(ctx.from_numpy(ghi))
+    st = ctx.zeros(16)
+    stp = C.c_void_p(st.data_ptr())
+    _hip.check(ctx.lib.beat_pde_spmv_dot(handle, p.ptr, q1.ptr, stp))
+    ctx.synchronize()
+    pq_whole = float(st[3])
+    q2.fill(float("nan"))
+    p.ghost_lo.fill_(float("nan"))
+    p.ghost_hi.fill_(float("nan"))
+    _hip.check(ctx.lib.beat_pde_spmv_dot_part(handle, p.ptr, q2.ptr, stp, 0))
+    ctx.synchronize()
+    p.ghost_lo.copy_(ctx.from_numpy(glo))
+    p.ghost_hi.copy_(ctx.from_numpy(ghi))
+    _hip.check(ctx.lib.beat_pde_spmv_dot_part(handle, p.ptr, q2.ptr, stp, 1))
+    ctx.synchronize()
+    np.testing.assert_array_equal(q2.numpy(), q1.numpy())
+    assert np.isclose(float(st[3]), pq_whole, rtol=1e-13)
+    _hip.check(ctx.lib.beat_pde_destroy(handle))
