@@ -135,10 +135,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BEAT_FORCE_DISTRIBUTED=1 rehearses the collective code path (RCCL all-reduces, stage kernels driven
+    # from Python) on a single rank; the reported numbers are then NOT the single-GPU headline.
+    force_dist = os.environ.get("BEAT_FORCE_DISTRIBUTED", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from beat import _hip, _stencil
@@ -154,7 +160,7 @@ def main():
     mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
     ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
     ops.set_timestep(C_M, THETA, DT)
-    solver = DiffusionSolver(ops, slab)
+    solver = DiffusionSolver(ops, slab, force_distributed=force_dist)
 
     ic, params, v_index = tp06_defaults()
     states = StateArray(ctx, len(ic), n_local, plane)
@@ -234,7 +240,7 @@ def main():
                             f"Jacobi-PCG rtol={args.rtol:g} (x0 = previous v)",
                 "nodes": n_total,
                 "states_per_node": S,
-                "parallelism": f"z-slabs x{world}",
+                "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else ""),
                 "pcg_iterations_per_step": k_avg,
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
@@ -264,7 +270,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not finite:

@@ -97,6 +97,8 @@ class Field:
     def set(self, values) -> None:
         torch = self.ctx.torch
         arr = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (self.n,)))
+        if not arr.flags.writeable:  # torch.from_numpy wants a writable buffer
+            arr = arr.copy()
         self.data.copy_(torch.from_numpy(arr))
 
     def copy_from(self, other: "Field") -> None:
