@@ -38,7 +38,12 @@ DT = 0.01
 H = 0.1  # mm
 
 
+ISOTROPIC = False  # --iso: M = s_l * I (BASELINE.json configs[2]); default: fibre at 30 degrees in the xy plane
+
+
 def conductivity():
+    if ISOTROPIC:
+        return S_L * np.eye(3)
     f0 = np.array([np.cos(np.pi / 6.0), np.sin(np.pi / 6.0), 0.0])
     return S_L * np.outer(f0, f0) + S_T * (np.eye(3) - np.outer(f0, f0))
 
@@ -125,7 +130,12 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--cpu-sample", type=int, default=64, help="side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--pc-degree", type=int, default=int(os.environ.get("BEAT_PC_DEGREE", "1")),
+                    help="1 = Jacobi-PCG, m >= 2 = Chebyshev polynomial preconditioner with m terms")
+    ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
     args = ap.parse_args()
+    global ISOTROPIC
+    ISOTROPIC = args.iso
 
     import torch
 
@@ -159,6 +169,7 @@ def main():
     n_local = plane * slab.nz
     mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
     ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+    ops.set_preconditioner(args.pc_degree)
     ops.set_timestep(C_M, THETA, DT)
     solver = DiffusionSolver(ops, slab, force_distributed=force_dist)
 
@@ -235,9 +246,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n}^3-node anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy), TP06 GRL1 ionic step, "
+                "workload": f"{n}^3-node " + ("isotropic slab (h=0.1 mm)" if ISOTROPIC else "anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy)") + ", TP06 GRL1 ionic step, "
                             f"P1 consistent-mass theta=0.5 diffusion, Godunov splitting, dt=0.01 ms, "
-                            f"Jacobi-PCG rtol={args.rtol:g} (x0 = previous v)",
+                            f"PCG rtol={args.rtol:g} (x0 = previous v), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
                 "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else ""),

@@ -72,6 +72,43 @@ class KspResult:
         return self.converged_reason
 
 
+def chebyshev_coefficients(m: int, lmin: float, lmax: float) -> np.ndarray:
+    """Coefficients c_0..c_{m-1} of the polynomial preconditioner z = sum_k c_k B^k rhat (B = D^-1 A,
+    rhat = D^-1 r) given by m steps of the Chebyshev iteration for B z = rhat on [lmin, lmax] started
+    from zero.  m = 1 is Jacobi (scaled by 2/(lmin+lmax), irrelevant for CG).  The polynomial is positive
+    on (0, lmax], so the preconditioner stays SPD as long as lmax bounds the spectrum from above."""
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    sigma = theta / delta
+    rho = 1.0 / sigma
+
+    def pad(a, n):
+        return np.pad(a, (0, n - len(a)))
+
+    def add(a, b):
+        n = max(len(a), len(b))
+        return pad(a, n) + pad(b, n)
+
+    d = np.array([1.0 / theta])
+    z = d.copy()
+    res = add(np.array([1.0]), -np.concatenate([[0.0], z]))
+    for _ in range(1, m):
+        rho_new = 1.0 / (2.0 * sigma - rho)
+        d = add(rho_new * rho * d, (2.0 * rho_new / delta) * res)
+        z = add(z, d)
+        res = add(np.array([1.0]), -np.concatenate([[0.0], z]))
+        rho = rho_new
+    return pad(z, m)
+
+
+def spectrum_bounds(A_tab: np.ndarray, ratio: float = 5.0) -> tuple[float, float]:
+    """(lmin, lmax) estimates for D^-1 A from the 27x15 coefficient table: lmax = largest Gershgorin
+    row bound sum|a_k|/a_0 (a true upper bound); lmin = lmax/ratio (kappa(D^-1 Mass) <= 5 for P1
+    tetrahedra, and the stiffness part only adds to the top of the spectrum)."""
+    rows = A_tab[np.abs(A_tab[:, 0]) > 0]
+    lmax = float((np.abs(rows).sum(axis=1) / rows[:, 0]).max())
+    return lmax / ratio, lmax
+
+
 class HipOps:
     """The product compute backend: every method is one C-ABI call into libbeat_hip.so."""
 
@@ -91,14 +128,18 @@ class HipOps:
                                      kt.ctypes.data_as(C.c_void_p), C.byref(handle))
         )
         self.handle = handle
-        self.work = ctx.zeros(3 * (self.n + 2 * self.plane))  # r, p, q (see beat_pde_solve)
+        self.mass_tab, self.stiff_tab = mt, kt
+        self.work = ctx.zeros(4 * (self.n + 2 * self.plane))  # r, p, q, z (see beat_pde_solve)
         fld = self.n + 2 * self.plane
         from ._device import Field
 
         self.r = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane)
         self.p = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + fld)
         self.q = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + 2 * fld)
+        self.z = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + 3 * fld)
         self.st = ctx.zeros(_hip.ST_SIZE)
+        self.pc_degree = 1
+        self._coeffs = (1.0, 0.5, 0.0)
 
     # -- field helpers ----------------------------------------------------------------------
     def new_field(self):
@@ -111,6 +152,47 @@ class HipOps:
     # -- stages -----------------------------------------------------------------------------
     def set_timestep(self, C_m, theta, dt):
         _hip.check(self.lib.beat_pde_set_timestep(self.handle, float(C_m), float(theta), float(dt)))
+        self._coeffs = (float(C_m), float(theta), float(dt))
+        self._update_preconditioner()
+
+    def set_preconditioner(self, degree: int):
+        """degree 1: Jacobi; m >= 2: Chebyshev polynomial preconditioner with m terms (m-1 stencil passes)."""
+        if not 1 <= int(degree) <= 8:
+            raise ValueError("preconditioner degree must be in 1..8")
+        self.pc_degree = int(degree)
+        self._update_preconditioner()
+
+    def _update_preconditioner(self):
+        m = self.pc_degree
+        if m <= 1:
+            _hip.check(self.lib.beat_pde_set_preconditioner(self.handle, 1, None))
+            return
+        C_m, theta, dt = self._coeffs
+        lmin, lmax = spectrum_bounds(C_m * self.mass_tab + theta * dt * self.stiff_tab)
+        coef = np.ascontiguousarray(chebyshev_coefficients(m, lmin, lmax))
+        _hip.check(self.lib.beat_pde_set_preconditioner(self.handle, m, coef.ctypes.data_as(C.c_void_p)))
+
+    # polynomial preconditioner stages (see include/beat_hip.h)
+    @property
+    def pc_num_passes(self) -> int:
+        return self.pc_degree - 1
+
+    def pc_io(self, j):
+        """(input field, output field) of Horner pass j: outputs alternate q / z and end in z."""
+        n = self.pc_num_passes
+        out = lambda jj: self.z if (n - 1 - jj) % 2 == 0 else self.q  # noqa: E731
+        return (self.r if j == 0 else out(j - 1)), out(j)
+
+    def pc_pass(self, j, slot):
+        stp = self.st.data_ptr()
+        _hip.check(self.lib.beat_pde_pc_pass(self.handle, j, self.r.ptr, self.z.ptr, self.q.ptr, C.c_void_p(stp),
+                                             C.c_void_p(stp + 8 * slot)))
+
+    def cg_first_z(self):
+        _hip.check(self.lib.beat_pde_cg_first_z(self.handle, C.c_void_p(self.st.data_ptr()), self.z.ptr, self.p.ptr))
+
+    def cg_next_z(self):
+        _hip.check(self.lib.beat_pde_cg_next_z(self.handle, C.c_void_p(self.st.data_ptr()), self.z.ptr, self.p.ptr))
 
     @staticmethod
     def _stim_args(stim_w, stim_amp):
@@ -208,6 +290,12 @@ class DiffusionSolver:
     def _allreduce(self, t) -> None:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def _precondition(self, slot: int) -> None:
+        ops = self.ops
+        for j in range(ops.pc_num_passes):
+            self.exchange_halo(ops.pc_io(j)[0])
+            ops.pc_pass(j, slot)
+
     # -- solve ----------------------------------------------------------------------------------
     def solve(self, v_prev, stim_w, stim_amp, x, rtol=1e-8, atol=1e-50, max_it=1000) -> KspResult:
         """x <- solution of A x = B v_prev + dt*sum amp_k w_k, started from x0 = v_prev."""
@@ -218,6 +306,11 @@ class DiffusionSolver:
         ops.rhs(v_prev, stim_w, stim_amp, x)
         self._allreduce(ops.st[0:3])
         ops.cg_begin(rtol, atol, max_it)
+        npass = ops.pc_num_passes
+        if npass:  # z = M^-1 r by the polynomial preconditioner, p = z
+            self._precondition(_hip.ST_RZ)
+            self._allreduce(ops.st[1:2])
+            ops.cg_first_z()
         launched = 0
         chunk = max(1, self._last_its)
         while True:
@@ -229,8 +322,13 @@ class DiffusionSolver:
                 ops.spmv_boundary()
                 self._allreduce(ops.st[3:4])
                 ops.cg_update(x)
+                if npass:
+                    self._precondition(_hip.ST_RZN)  # replaces the Jacobi r.z written by cg_update
                 self._allreduce(ops.st[4:6])
-                ops.cg_next()
+                if npass:
+                    ops.cg_next_z()
+                else:
+                    ops.cg_next()
             launched += chunk
             st = ops.read_state()
             if st[_hip.ST_STOP] != 0.0 or launched >= max_it:

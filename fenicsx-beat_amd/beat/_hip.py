@@ -72,6 +72,11 @@ SIGNATURES = {
     "beat_pde_spmv_dot_part": (_int, [_vp, _vp, _vp, _vp, _int]),
     "beat_pde_cg_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "beat_pde_cg_next": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_set_preconditioner": (_int, [_vp, _int, _vp]),
+    "beat_pde_pc_num_passes": (_int, [_vp]),
+    "beat_pde_pc_pass": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "beat_pde_cg_first_z": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_cg_next_z": (_int, [_vp, _vp, _vp, _vp]),
     "beat_pde_solve": (
         _int,
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],

@@ -64,7 +64,8 @@ struct Geom {
 
 struct StencilArgs {
   const double* x;     // input field
-  double* y;           // APPLY: y | SPMV: q | RHS: r
+  const double* x2;    // PC: residual r (centre values)
+  double* y;           // APPLY: y | SPMV: q | RHS: r | PC: output of the pass
   double* y2;          // RHS: p
   double* y3;          // RHS: x (copy of v_) or nullptr
   const double* tab;   // APPLY/SPMV: operator table | RHS: mass table
@@ -78,12 +79,17 @@ struct StencilArgs {
   int nstim;
   double* partials;
   const double* st;
+  double c_in, c_r;    // PC: staged input is scaled by c_in * D^-1 (first pass only); weight of the D^-1 r term
+  int pc_first, pc_last;
 };
 
 // APPLY: y = T x.  SPMV_DOT: q = A p, partial p.q.  RHS: see beat_pde_rhs.
 // (Forming p = D^-1 r + beta p_old while staging was tried and rejected: the halo makes it re-read two
 //  fields 1.5x, 1.8 ms against 0.58 + 0.66 ms for SpMV + a streaming p-update at 512^3.)
-enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2 };
+// PC: one Horner pass of the polynomial preconditioner z = sum_j c_j (D^-1 A)^j D^-1 r:
+//     out = c_r D^-1 r + D^-1 A in,   in = c_in D^-1 r on the first pass, the previous output afterwards;
+//     the last pass also reduces r.z.
+enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_PC = 3 };
 
 __device__ __forceinline__ int axis_type(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -104,6 +110,7 @@ __device__ __forceinline__ int tile_of_block(int b, int total) {
 template <class T>
 struct StageDesc {
   int off[T::NLOAD];
+  int txy[T::NLOAD];  // tx + 3 ty of the staged element (only read by the PC mode)
 };
 
 template <class T>
@@ -116,10 +123,11 @@ __device__ __forceinline__ void stage_setup(StageDesc<T>& d, const Geom& g, int 
     const int gx = x0 + col - 1, gy = y0 + row - 1;
     const bool ok = idx < SLOT && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;
     d.off[l] = ok ? gy * g.nx + gx : -1;
+    d.txy[l] = axis_type(gx, g.nx, 1, 1) + 3 * axis_type(gy, g.ny, 1, 1);
   }
 }
 
-template <class T>
+template <int MODE, class T>
 __device__ __forceinline__ void stage_load(double (&reg)[T::NLOAD], const StageDesc<T>& d, const StencilArgs& a,
                                            const Geom& g, int gz) {
   constexpr int NLOAD = T::NLOAD;
@@ -127,6 +135,16 @@ __device__ __forceinline__ void stage_load(double (&reg)[T::NLOAD], const StageD
   const double* __restrict__ base = a.x + (int64_t)gz * g.plane;
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) reg[l] = (zvalid && d.off[l] >= 0) ? base[d.off[l]] : 0.0;
+  if (MODE == MODE_PC) {
+    if (a.pc_first) {  // stage c_in * D^-1 r instead of r
+      const int tz9 = 9 * axis_type(gz, g.nz, g.z_lo_phys, g.z_hi_phys);
+#pragma unroll
+      for (int l = 0; l < NLOAD; ++l) {
+        const int type = d.txy[l] + tz9;
+        reg[l] *= a.c_in * ((type == 13) ? a.dinv_i : a.dinv[type]);
+      }
+    }
+  }
 }
 
 template <class T>
@@ -208,14 +226,23 @@ __device__ __forceinline__ void compute_plane(const Geom& g, const StencilArgs& 
         acc1 = fma(r, zz, acc1);
         acc2 = fma(r, r, acc2);
       } else {
+        double di = a.dinv_i;
         if (type != 13) {
           s = 0.0;
           const double* __restrict__ r1 = a.tab + type * TABW;
 #pragma unroll
           for (int k = 0; k < 15; ++k) s = fma(r1[k], v[k], s);
+          if (MODE == MODE_PC) di = a.dinv[type];
         }
-        a.y[gi] = s;
-        if (MODE == MODE_SPMV_DOT) acc0 = fma(v[0], s, acc0);
+        if (MODE == MODE_PC) {
+          const double ri = a.x2[gi];
+          const double out = di * fma(a.c_r, ri, s);
+          a.y[gi] = out;
+          if (a.pc_last) acc0 = fma(ri, out, acc0);
+        } else {
+          a.y[gi] = s;
+          if (MODE == MODE_SPMV_DOT) acc0 = fma(v[0], s, acc0);
+        }
       }
     }
   }
@@ -226,7 +253,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   constexpr int NLOAD = T::NLOAD, SLOT = T::SLOT, TX = T::TX, TY = T::TY;
   __shared__ double lds[3 * SLOT];
   __shared__ double red[4];
-  if (MODE == MODE_SPMV_DOT) {
+  if (MODE == MODE_SPMV_DOT || MODE == MODE_PC) {
     if (a.st[STOP] != 0.0) return;  // convergence latch: nothing left to do in this solve
   }
   const int t = tile_of_block(blockIdx.x, g.total);
@@ -249,28 +276,28 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
   // planes z_begin-1 and z_begin go straight to LDS; the next two are held in registers so that
   // two planes of global loads are always in flight behind the plane being computed
   double ra[NLOAD], rb[NLOAD];
-  stage_load<T>(ra, d, a, g, z_begin - 1);
-  stage_load<T>(rb, d, a, g, z_begin);
+  stage_load<MODE, T>(ra, d, a, g, z_begin - 1);
+  stage_load<MODE, T>(rb, d, a, g, z_begin);
   stage_store<T>(ra, lds + ((z_begin + 2) % 3) * SLOT);
   stage_store<T>(rb, lds + (z_begin % 3) * SLOT);
-  stage_load<T>(ra, d, a, g, z_begin + 1);
-  if (z_begin + 2 <= z_end) stage_load<T>(rb, d, a, g, z_begin + 2);
+  stage_load<MODE, T>(ra, d, a, g, z_begin + 1);
+  if (z_begin + 2 <= z_end) stage_load<MODE, T>(rb, d, a, g, z_begin + 2);
 
   for (int z = z_begin; z < z_end; z += 2) {
     stage_store<T>(ra, lds + ((z + 1) % 3) * SLOT);
-    if (z + 3 <= z_end) stage_load<T>(ra, d, a, g, z + 3);
+    if (z + 3 <= z_end) stage_load<MODE, T>(ra, d, a, g, z + 3);
     __syncthreads();
     compute_plane<MODE, T>(g, a, lds, z, x0, y0, lx, wave, tx, acc0, acc1, acc2);
     __syncthreads();
     if (z + 1 >= z_end) break;
     stage_store<T>(rb, lds + ((z + 2) % 3) * SLOT);
-    if (z + 4 <= z_end) stage_load<T>(rb, d, a, g, z + 4);
+    if (z + 4 <= z_end) stage_load<MODE, T>(rb, d, a, g, z + 4);
     __syncthreads();
     compute_plane<MODE, T>(g, a, lds, z + 1, x0, y0, lx, wave, tx, acc0, acc1, acc2);
     __syncthreads();
   }
 
-  if (MODE == MODE_SPMV_DOT) {
+  if (MODE == MODE_SPMV_DOT || MODE == MODE_PC) {
     const double s0 = beat_block_sum(acc0, red);
     if (threadIdx.x == 0) a.partials[g.part_off + t] = s0;
   } else if (MODE == MODE_RHS) {
@@ -394,6 +421,20 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const do
   }
 }
 
+// p = z + beta p  (z = M^-1 r already formed by the polynomial preconditioner)
+__global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_z_kernel(int64_t n, const double* __restrict__ st,
+                                                                  const double* __restrict__ z,
+                                                                  double* __restrict__ p) {
+  if (st[STOP] != 0.0) return;
+  const double beta = st[BETA];
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  if (beta == 0.0) {  // first direction: p may hold anything
+    for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) p[i] = z[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) p[i] = fma(beta, p[i], z[i]);
+  }
+}
+
 }  // namespace
 
 struct beat_pde {
@@ -409,6 +450,8 @@ struct beat_pde {
   double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
   int last_iters = -1;
   unsigned vec_grid = 1;
+  int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
+  double pc_coef[8] = {1.0};
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
   const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * TABW; }
 };
@@ -680,6 +723,71 @@ extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, 
   return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
 }
 
+extern "C" int beat_pde_set_preconditioner(beat_pde* pde, int ncoef, const double* host_coef) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(ncoef >= 1 && ncoef <= 8, "polynomial preconditioner needs 1..8 coefficients, got %d", ncoef);
+  BEAT_REQUIRE(ncoef == 1 || host_coef != nullptr, "null coefficients");
+  pde->pc_ncoef = ncoef;
+  for (int k = 0; k < ncoef; ++k) pde->pc_coef[k] = host_coef ? host_coef[k] : 1.0;
+  pde->last_iters = -1;
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_pc_num_passes(beat_pde* pde) { return pde ? pde->pc_ncoef - 1 : BEAT_EINVAL; }
+
+// Horner pass j (0 .. ncoef-2) of z = sum_k c_k (D^-1 A)^k D^-1 r.  Pass j reads r (first pass) or the
+// previous output and writes q or z alternately such that the LAST pass writes z; the last pass also
+// reduces the local r.z into *dev_red.
+extern "C" int beat_pde_pc_pass(beat_pde* pde, int j, const double* dev_r, double* dev_z, double* dev_q,
+                                double* dev_st, double* dev_red) {
+  BEAT_REQUIRE(pde != nullptr && dev_r && dev_z && dev_q && dev_st && dev_red, "null argument");
+  const int npass = pde->pc_ncoef - 1;
+  BEAT_REQUIRE(j >= 0 && j < npass, "pass %d out of range (have %d)", j, npass);
+  BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  // outputs alternate and end in z: pass j writes z if (npass - 1 - j) is even, else q
+  auto out_of = [&](int jj) { return ((npass - 1 - jj) % 2 == 0) ? dev_z : dev_q; };
+  StencilArgs a{};
+  a.x = (j == 0) ? dev_r : out_of(j - 1);
+  a.x2 = dev_r;
+  a.y = out_of(j);
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.dinv_i = pde->h_dinv[13];
+  a.ci = interior(pde->h_A);
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  a.pc_first = (j == 0);
+  a.pc_last = (j == npass - 1);
+  a.c_in = pde->pc_coef[npass];          // highest coefficient scales the first staged input
+  a.c_r = pde->pc_coef[npass - 1 - j];   // Horner: s_k = c_k D^-1 r + (D^-1 A) s_{k+1}
+  launch_stencil<MODE_PC>(pde, a);
+  BEAT_LAUNCH_CHECK();
+  if (a.pc_last) return launch_reduce(pde, pde->g.total, 1, dev_red, dev_st);
+  return BEAT_OK;
+}
+
+// p = z + beta p after the scalar roll (polynomial-preconditioned variant of beat_pde_cg_next)
+extern "C" int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_z && dev_p, "null argument");
+  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_LAUNCH_CHECK();
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
+                     (const double*)dev_st, dev_z, dev_p);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+// p = z (first search direction) without touching the scalars
+extern "C" int beat_pde_cg_first_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_z && dev_p, "null argument");
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
+                     (const double*)dev_st, dev_z, dev_p);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p, "null argument");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
@@ -701,10 +809,17 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   double* r = dev_work + pde->g.plane;
   double* p = r + fld;
   double* q = p + fld;
+  double* z = q + fld;  // only touched by the polynomial preconditioner
   double* st = pde->d_st;
+  const int npass = pde->pc_ncoef - 1;
   int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, p, st);
   if (rc) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
+  if (npass > 0) {  // z = M^-1 r, r.z -> st[RZ], p = z
+    for (int j = 0; j < npass; ++j)
+      if ((rc = beat_pde_pc_pass(pde, j, r, z, q, st, st + RZ))) return rc;
+    if ((rc = beat_pde_cg_first_z(pde, st, z, p))) return rc;
+  }
   beat_ctx* ctx = pde->ctx;
   double* h = ctx->h_pinned;
   int launched = 0;
@@ -714,7 +829,13 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
     for (int it = 0; it < chunk; ++it) {
       if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
       if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
-      if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
+      if (npass > 0) {
+        for (int j = 0; j < npass; ++j)
+          if ((rc = beat_pde_pc_pass(pde, j, r, z, q, st, st + RZN))) return rc;
+        if ((rc = beat_pde_cg_next_z(pde, st, z, p))) return rc;
+      } else {
+        if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
+      }
     }
     launched += chunk;
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));

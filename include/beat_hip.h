@@ -164,11 +164,30 @@ int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev
  * max_it; then p = D^-1 r + beta p   -> exchange ghost planes of p. */
 int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p);
 
+/* Optional polynomial (Chebyshev-Jacobi) preconditioner  z = sum_k c_k (D^-1 A)^k D^-1 r,
+ * k < ncoef <= 8.  ncoef = 1 is plain Jacobi (the default).  On this bandwidth-bound path a PCG
+ * iteration moves 72 B/node in vector updates but only 16-24 B/node per stencil pass, so trading
+ * iterations for a few extra stencil passes lowers the bytes per solve.  The coefficients come from
+ * the caller (beat/_engine.py derives them from Gershgorin bounds on D^-1 A). */
+int beat_pde_set_preconditioner(beat_pde* pde, int ncoef, const double* host_coef);
+int beat_pde_pc_num_passes(beat_pde* pde); /* ncoef - 1 */
+/* Horner pass j of the preconditioner: reads r (j = 0, ghost planes of r current) or the previous
+ * output (ghost planes of that field current) and writes dev_q / dev_z alternately such that the
+ * last pass writes dev_z; the last pass also stores the LOCAL r.z in *dev_red (dev_st+1 for the
+ * initial residual, dev_st+4 inside the iteration, where it replaces the Jacobi value written by
+ * beat_pde_cg_update). */
+int beat_pde_pc_pass(beat_pde* pde, int j, const double* dev_r, double* dev_z, double* dev_q,
+                     double* dev_st, double* dev_red);
+/* p = z (first search direction, beta = 0 after beat_pde_cg_begin). */
+int beat_pde_cg_first_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p);
+/* as beat_pde_cg_next with p = z + beta p. */
+int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p);
+
 /* Whole single-slab step: rhs build + Jacobi-PCG to ||r|| <= max(rtol*||b||, atol), with all
  * scalars kept on the device (one host synchronisation at the end to fill `info`).
  * Replaces _update_rhs + KSP.solve of base_model.py:232-236 when the grid is not decomposed.
- * dev_work: 3 fields (r, p, q) laid out back to back, each with its own ghost planes:
- * size 3*(n_local + 2*nx*ny) doubles. Synchronises. */
+ * dev_work: 4 fields (r, p, q, z) laid out back to back, each with its own ghost planes:
+ * size 4*(n_local + 2*nx*ny) doubles (z is only used by the polynomial preconditioner). Synchronises. */
 int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
                    double rtol, double atol, int max_it, beat_ksp_info* info);

@@ -395,6 +395,59 @@ def pcg_jacobi(A, b, x0, rtol=1e-10, atol=1e-50, maxit=10000):
     return x, its, rnorm
 
 
+def chebyshev_coefficients(m, lmin, lmax):
+    """Polynomial preconditioner coefficients: m steps of the Chebyshev iteration for B z = rhat on
+    [lmin, lmax] from a zero start, expanded in powers of B (Saad, Iterative Methods, Alg. 12.1)."""
+    import numpy.polynomial.polynomial as P
+
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    sigma = theta / delta
+    rho = 1.0 / sigma
+    d = np.array([1.0 / theta])
+    z = d.copy()
+    res = P.polysub([1.0], P.polymulx(z))
+    for _ in range(1, m):
+        rho_new = 1.0 / (2.0 * sigma - rho)
+        d = P.polyadd(rho_new * rho * d, (2.0 * rho_new / delta) * res)
+        z = P.polyadd(z, d)
+        res = P.polysub([1.0], P.polymulx(z))
+        rho = rho_new
+    out = np.zeros(m)
+    out[: len(z)] = z
+    return out
+
+
+def pcg_polynomial(A, b, x0, coef, rtol=1e-10, atol=1e-50, maxit=10000):
+    """PCG with the preconditioner z = sum_k coef[k] (D^-1 A)^k D^-1 r (coef of length 1 = Jacobi)."""
+    dinv = 1.0 / A.diagonal()
+
+    def precond(r):
+        rh = dinv * r
+        s = coef[-1] * rh
+        for c in coef[-2::-1]:
+            s = c * rh + dinv * (A @ s)
+        return s
+
+    x = x0.copy()
+    r = b - A @ x
+    tol = max(rtol * np.linalg.norm(b), atol)
+    z = precond(r)
+    p = z.copy()
+    rz = r @ z
+    its = 0
+    while np.linalg.norm(r) > tol and its < maxit:
+        q = A @ p
+        alpha = rz / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        z = precond(r)
+        rz_new = r @ z
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        its += 1
+    return x, its, np.linalg.norm(r)
+
+
 class OracleStimulus:
     """I_k(t) * int_{dz_k} f_k(x) phi_i.  ``amp(t)`` scalar function of time, ``weights`` (N,)."""
 

@@ -35,7 +35,8 @@ class OracleOps:
         self.plane, self.n = nx * ny, nx * ny * nz
         self.lo_phys, self.hi_phys = bool(lo_phys), bool(hi_phys)
         self.mass_tab, self.stiff_tab = np.asarray(mass_tab), np.asarray(stiff_tab)
-        self.r, self.p, self.q = (CpuField(self.n, self.plane) for _ in range(3))
+        self.r, self.p, self.q, self.z = (CpuField(self.n, self.plane) for _ in range(4))
+        self.pc_degree, self.pc_coef = 1, np.array([1.0])
         self.st = torch.zeros(16, dtype=torch.float64)
         # node types of the slab: z type decided by the PHYSICAL position of the plane
         def t(n, lo, hi):
@@ -60,6 +61,75 @@ class OracleOps:
         self.C_m, self.theta, self.dt = C_m, theta, dt
         self.A = C_m * self.mass_tab + theta * dt * self.stiff_tab
         self.dinv = (1.0 / self.A[:, 0])[self.typ].ravel()
+        self._update_pc()
+
+    # ---- polynomial preconditioner (same stage interface as HipOps) -------------------------------
+    @property
+    def pc_num_passes(self):
+        return self.pc_degree - 1
+
+    def set_preconditioner(self, degree):
+        self.pc_degree = int(degree)
+        if hasattr(self, "A"):
+            self._update_pc()
+
+    def _update_pc(self):
+        from beat._engine import chebyshev_coefficients, spectrum_bounds
+
+        if self.pc_degree > 1:
+            self.pc_coef = chebyshev_coefficients(self.pc_degree, *spectrum_bounds(self.A))
+
+    def pc_io(self, j):
+        n = self.pc_num_passes
+        out = lambda jj: self.z if (n - 1 - jj) % 2 == 0 else self.q  # noqa: E731
+        return (self.r if j == 0 else out(j - 1)), out(j)
+
+    def pc_pass(self, j, slot):
+        if self.st[ST_STOP] != 0:
+            return
+        n = self.pc_num_passes
+        fin, fout = self.pc_io(j)
+        if j == 0:  # stage c_in * D^-1 r, ghost planes included
+            tmp = CpuField(self.n, self.plane)
+            tmp.buf.copy_(fin.buf)
+            tmp.data.mul_(torch.from_numpy(self.pc_coef[n] * self.dinv))
+            nx, ny, nz = self.shape
+            dl = (1.0 / self.A[:, 0])[self._ghost_types(lo=True)].ravel()
+            dh = (1.0 / self.A[:, 0])[self._ghost_types(lo=False)].ravel()
+            tmp.ghost_lo.mul_(torch.from_numpy(self.pc_coef[n] * dl))
+            tmp.ghost_hi.mul_(torch.from_numpy(self.pc_coef[n] * dh))
+            fin = tmp
+        s = self._apply(self.A, fin)
+        r = self.r.data.numpy()
+        out = self.dinv * (self.pc_coef[n - 1 - j] * r + s)
+        fout.data.copy_(torch.from_numpy(out))
+        if j == n - 1:
+            self.st[slot] = float(r @ out)
+
+    def _ghost_types(self, lo):
+        """node types of the neighbouring slab's plane adjacent to this slab (interior in z there unless
+        that neighbour plane is itself a physical face, which cannot happen for a ghost plane)."""
+        nx, ny, _ = self.shape
+        def t(n):
+            a = np.ones(n, dtype=np.int64)
+            if n > 1:
+                a[0], a[-1] = 0, 2
+            return a
+        return t(nx)[None, :] + 3 * t(ny)[:, None] + 9
+
+    def cg_first_z(self):
+        if self.st[ST_STOP] != 0:
+            return
+        self.p.data.copy_(self.z.data)
+
+    def cg_next_z(self):
+        st = self.st
+        if st[ST_STOP] != 0:
+            return
+        self._roll_scalars()
+        if st[ST_STOP] != 0:
+            return
+        self.p.data.mul_(float(st[ST_BETA])).add_(self.z.data)
 
     def _apply(self, tab, f: CpuField, poison_ghosts=False):
         nx, ny, nz = self.shape
@@ -141,6 +211,12 @@ class OracleOps:
         st = self.st
         if st[ST_STOP] != 0:
             return
+        self._roll_scalars()
+        z = torch.from_numpy(self.dinv) * self.r.data
+        self.p.data.mul_(float(st[ST_BETA])).add_(z)
+
+    def _roll_scalars(self):
+        st = self.st
         st[ST_BETA] = float(st[ST_RZN]) / float(st[ST_RZ])
         st[ST_RZ], st[ST_RR] = float(st[ST_RZN]), float(st[ST_RRN])
         st[ST_ITERS] += 1.0
@@ -149,17 +225,25 @@ class OracleOps:
             st[ST_STOP], st[ST_REASON] = 1.0, (2.0 if float(st[ST_RR]) <= tr else 3.0)
         elif float(st[ST_ITERS]) >= float(st[ST_MAXIT]):
             st[ST_STOP], st[ST_REASON] = 1.0, -3.0
-        z = torch.from_numpy(self.dinv) * self.r.data
-        self.p.data.mul_(float(st[ST_BETA])).add_(z)
 
     def solve_single(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it):
         from beat._engine import KspResult
 
         self.rhs(v_prev, stim_w, stim_amp, x)
         self.cg_begin(rtol, atol, max_it)
+        npass = self.pc_num_passes
+        if npass:
+            for j in range(npass):
+                self.pc_pass(j, ST_RZ)
+            self.cg_first_z()
         while self.st[ST_STOP] == 0:
             self.spmv_dot()
             self.cg_update(x)
-            self.cg_next()
+            if npass:
+                for j in range(npass):
+                    self.pc_pass(j, ST_RZN)
+                self.cg_next_z()
+            else:
+                self.cg_next()
         st = self.st.numpy()
         return KspResult(int(st[ST_ITERS]), float(np.sqrt(st[ST_RR])), int(st[ST_REASON]), float(np.sqrt(st[ST_BB])))

@@ -418,3 +418,52 @@ def test_niederer_activation_times(dt):
         t += dt
     for p, ref in NIEDERER[dt].items():
         assert abs(at[p] - ref) <= max(2 * dt, 1e-3 * ref) + 1e-9, (p, at[p], ref, at)
+
+
+def test_readme_fitzhugh_nagumo_32x32_matches_oracle():
+    """BASELINE config 1: the README script (README.md:40-199; 32x32 unit square, FHN forward Euler with
+    11 parameters, M = 0.001, stimulus 600 on [0, 0.5]^2 for t in [0, 0.5], dt = 0.01) for 1000 steps:
+    HIP path vs CPU oracle, max-abs difference <= 1e-10 (all-fp64, no transcendental functions)."""
+    import beat
+    from beat import grid as g
+    from oracle import fem, ionic
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 32, 32, g.CellType.triangle)
+    time = g.Constant(mesh, g.default_scalar_type(0.0))
+    a, b, c1, c2, c3, v_peak, v_rest = 0.13, 0.013, 0.26, 0.1, 1.0, 40.0, -85.0
+    parameters = np.array([c1, c2, c3, a, b, v_peak - v_rest, v_rest, v_peak, 100.0, 1, 0.0], dtype=np.float64)
+    init_states = np.array([0.0, -85], dtype=np.float64)
+    parameters[-3] = 0.0
+    stim_expr = g.conditional(g.And(g.ge(time, 0.0), g.le(time, 0.5)), 600.0, 0.0)
+    cells = g.locate_entities(mesh, mesh.topology.dim, lambda x: np.logical_and(x[0] <= 0.5, x[1] <= 0.5))
+    tags = g.meshtags(mesh, mesh.topology.dim, cells, np.full(len(cells), 1, dtype=np.int32))
+    dx = g.Measure("dx", domain=mesh, subdomain_data=tags)
+    I_s = beat.Stimulus(expr=stim_expr, dZ=dx, marker=1)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=0.001, I_s=I_s, dx=dx,
+                               params={"petsc_options": {"ksp_rtol": 1e-13}})
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(g.functionspace(mesh, ("P", 1))), v_pde=pde.state,
+                                         fun=beat.models.fhn.forward_euler_readme, init_states=init_states,
+                                         parameters=parameters, num_states=2, v_index=1)
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+
+    om = fem.BoxMesh((32, 32), (1.0, 1.0))
+    w = fem.stimulus_weights(om, om.locate_cells(lambda x: np.logical_and(x[0] <= 0.5, x[1] <= 0.5)))
+    model = fem.OracleMonodomainModel(om, 0.001, [fem.OracleStimulus(fem.window(0.0, 0.5, 600.0), w)], theta=0.5)
+    S = np.zeros((2, om.num_nodes))
+    S.T[:] = init_states
+    t, dt = 0.0, 0.01
+    vmin, vmax = [], []
+    for i in range(1000):
+        solver.step((t, t + dt))
+        S = ionic.fhn_readme_forward_euler(S, t, dt, parameters)
+        model.state[:] = S[1]
+        model.assign_previous()
+        model.step((t, t + dt))
+        S[1] = model.state
+        t += dt
+        if i % 100 == 0:
+            v = solver.pde.state.x.array
+            vmin.append(v.min())
+            vmax.append(v.max())
+    assert np.isfinite(vmin).all() and np.isfinite(vmax).all() and max(vmax) > -80.0
+    assert np.abs(ode.values - S).max() <= 1e-10

@@ -38,7 +38,7 @@ def _problem():
     return mesh, M, v_prev, w
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, degree):
     for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -55,6 +55,7 @@ def _worker(rank, world, port, out_dir):
         slab = Slab(nz, rank, world)
         mt, kt = _stencil.stencil_tables(3, tuple(l / c for l, c in zip(L, CELLS)), M)
         ops = OracleOps((nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, mt, kt)
+        ops.set_preconditioner(degree)
         ops.set_timestep(C_M, THETA, DT)
         solver = DiffusionSolver(ops, slab)
         sl = slice(slab.z0 * plane, slab.z1 * plane)
@@ -71,12 +72,12 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_decomposed_pcg_matches_undivided_solve(world, tmp_path):
+@pytest.mark.parametrize("world,degree", [(2, 1), (3, 1), (2, 3)])
+def test_slab_decomposed_pcg_matches_undivided_solve(world, degree, tmp_path):
     from oracle import fem
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), degree), nprocs=world, join=True)
     mesh, M, v_prev, w = _problem()
     model = fem.OracleMonodomainModel(mesh, M, [fem.OracleStimulus(lambda t: AMP, w)], C_m=C_M, theta=THETA,
                                       default_timestep=DT)
@@ -94,7 +95,15 @@ def test_slab_decomposed_pcg_matches_undivided_solve(world, tmp_path):
     # same iteration count and norms as the undivided PCG
     A = (C_M * fem.assemble_mass(mesh) + THETA * DT * fem.assemble_stiffness(mesh, M)).tocsr()
     b = model.rhs(THETA * DT, DT)
-    _, its_ref, rn = fem.pcg_jacobi(A, b, v_prev, rtol=1e-12)
+    if degree == 1:
+        _, its_ref, rn = fem.pcg_jacobi(A, b, v_prev, rtol=1e-12)
+    else:
+        from beat import _stencil
+        from beat._engine import chebyshev_coefficients, spectrum_bounds
+
+        mt, kt = _stencil.stencil_tables(3, tuple(l / c for l, c in zip(L, CELLS)), M)
+        coef = chebyshev_coefficients(degree, *spectrum_bounds(C_M * mt + THETA * DT * kt))
+        _, its_ref, rn = fem.pcg_polynomial(A, b, v_prev, coef, rtol=1e-12)
     assert abs(its.pop() - its_ref) <= 1
     assert np.isclose(float(parts[0]["bnorm"]), np.linalg.norm(b), rtol=1e-12)
 

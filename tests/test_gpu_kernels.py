@@ -303,7 +303,7 @@ def test_pde_solve_matches_direct_solve(hip_ctx, cells, L, Mk):
     fv, fx, fw = Field(ctx, n, plane), Field(ctx, n, plane), Field(ctx, n, plane)
     fv.set(v_prev)
     fw.set(w)
-    work = ctx.zeros(3 * (n + 2 * plane))
+    work = ctx.zeros(4 * (n + 2 * plane))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([fw.ptr.value]), _dbl_array([amp]), 1, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-12, 1e-50, 500, C.byref(info)))
@@ -327,7 +327,7 @@ def test_pde_solve_zero_rhs_and_latch(hip_ctx):
     _hip.check(ctx.lib.beat_pde_set_timestep(handle, 1.0, 0.5, 0.4))
     n, plane = 11, 11
     fv, fx = Field(ctx, n, plane), Field(ctx, n, plane)
-    work = ctx.zeros(3 * (n + 2 * plane))
+    work = ctx.zeros(4 * (n + 2 * plane))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([]), _dbl_array([]), 0, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-10, 1e-50, 100, C.byref(info)))
@@ -408,3 +408,50 @@ def test_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl):
     np.testing.assert_array_equal(q2.numpy(), q1.numpy())
     assert np.isclose(float(st[3]), pq_whole, rtol=1e-13)
     _hip.check(ctx.lib.beat_pde_destroy(handle))
+
+
+@pytest.mark.parametrize("degree", [2, 3, 4])
+def test_polynomial_preconditioned_pcg(hip_ctx, degree):
+    """Chebyshev-polynomial preconditioned PCG: same solution as the sparse-LU solve (1e-9), fewer
+    iterations than Jacobi, and the iteration count of the oracle's restatement with the same coefficients."""
+    from beat import _stencil
+    from beat._engine import DiffusionSolver, HipOps, Slab, chebyshev_coefficients, spectrum_bounds
+    from oracle import fem
+
+    ctx = hip_ctx
+    cells, L = (40, 21, 12), (4.0, 2.1, 1.2)
+    mesh = fem.BoxMesh(cells, L)
+    Mten = _conductivity("aniso3", 3)
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    nn = tuple(c + 1 for c in cells)
+    mt, kt = _stencil.stencil_tables(3, tuple(l / c for l, c in zip(L, cells)), Mten)
+    rng = np.random.default_rng(8)
+    v_prev = -85.0 + 100.0 / (1.0 + np.exp((np.linalg.norm(mesh.x - 1.0, axis=1) - 0.8) / 0.05))
+    v_prev += 0.01 * rng.standard_normal(mesh.num_nodes)
+    w = fem.stimulus_weights(mesh, mesh.locate_cells(lambda x: x[0] <= 1.0 + 1e-10))
+    amp = 0.357
+    model = fem.OracleMonodomainModel(mesh, Mten, [fem.OracleStimulus(lambda t: amp, w)], C_m=C_m, theta=theta,
+                                      default_timestep=dt)
+    model.state[:] = v_prev
+    model.assign_previous()
+    model.step((0.0, dt))
+    its = {}
+    for deg in (1, degree):
+        ops = HipOps(ctx, nn, True, True, mt, kt)
+        ops.set_preconditioner(deg)
+        ops.set_timestep(C_m, theta, dt)
+        solver = DiffusionSolver(ops, Slab(nn[2]))
+        fv, fx, fw = ops.new_field(), ops.new_field(), ops.new_field()
+        fv.set(v_prev)
+        fw.set(w)
+        res = solver.solve(fv, [fw], [amp], fx, rtol=1e-11, atol=1e-50, max_it=300)
+        assert res.converged_reason > 0
+        assert np.abs(fx.numpy() - model.state).max() <= 1e-9 * np.abs(model.state).max()
+        its[deg] = res.iterations
+    assert its[degree] < its[1]
+    A = (C_m * fem.assemble_mass(mesh) + theta * dt * fem.assemble_stiffness(mesh, Mten)).tocsr()
+    lmin, lmax = spectrum_bounds(C_m * mt + theta * dt * kt)
+    coef = chebyshev_coefficients(degree, lmin, lmax)
+    np.testing.assert_allclose(coef, fem.chebyshev_coefficients(degree, lmin, lmax), rtol=1e-13)
+    _, its_ref, _ = fem.pcg_polynomial(A, model.rhs(theta * dt, dt), v_prev, coef, rtol=1e-11)
+    assert abs(its_ref - its[degree]) <= 1, (its_ref, its)
