@@ -227,6 +227,14 @@ def main():
 
     if rank == 0:
         n_total = n**3
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (only quoted when this
+        # run has the configuration the counters were collected on)
+        traffic = None
+        tfile = ROOT / "profiles" / "r01_final_512_traffic.json"
+        if tfile.is_file():
+            tj = json.loads(tfile.read_text())
+            if tj.get("n") == n and tj.get("n_gpus") == world:
+                traffic = tj.get("hbm_bytes_per_launch")
         k_avg = float(np.mean(iters)) if iters else 0.0
         S = len(ic)
         ode_bytes = 16.0 * S * n_local  # every state row read once + written once
@@ -266,7 +274,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": ode_bytes,
                 "bytes_per_node": 16.0 * S,
                 "whole_step": {
                     "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,
