@@ -129,7 +129,8 @@ class HipOps:
         )
         self.handle = handle
         self.mass_tab, self.stiff_tab = mt, kt
-        self.work = ctx.zeros(4 * (self.n + 2 * self.plane))  # r, p, q, z (see beat_pde_solve)
+        nfields = max(4, int(self.lib.beat_pde_work_fields(handle)))  # see beat_pde_solve
+        self.work = ctx.zeros(nfields * (self.n + 2 * self.plane))
         fld = self.n + 2 * self.plane
         from ._device import Field
 

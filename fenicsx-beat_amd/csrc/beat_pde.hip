@@ -42,7 +42,8 @@ constexpr int TARGET_BLOCKS = 1024;
 constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
 // slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
-enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT };
+enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD };
+constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
 
 const int kOffsets[45] = {0, 0, 0,  1, 0, 0,  -1, 0, 0,  0, 1, 0,  0, -1, 0,  0, 0, 1,  0, 0, -1,
                           1, 1, 0,  -1, -1, 0,  0, 1, 1,  0, -1, -1,  1, 0, 1,  -1, 0, -1,
@@ -316,9 +317,11 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
 __global__ __launch_bounds__(BEAT_BLOCK) void reduce_partials_kernel(const double* __restrict__ partials,
                                                                      int count, int nsum,
                                                                      double* __restrict__ out,
-                                                                     const double* __restrict__ st) {
+                                                                     const double* __restrict__ st,
+                                                                     double* __restrict__ counter) {
   __shared__ double red[4];
   if (st != nullptr && st[STOP] != 0.0) return;
+  if (counter != nullptr && threadIdx.x == 0) counter[0] += 1.0;  // one more executed residual update
   for (int k = 0; k < nsum; ++k) {
     double s = 0.0;
     for (int i = threadIdx.x; i < count; i += BEAT_BLOCK) s += partials[(int64_t)k * BEAT_MAX_PARTIALS + i];
@@ -333,6 +336,7 @@ __global__ void pcg_begin_kernel(double* st, double rtol, double atol, double ma
   const double tol2 = tr > ta ? tr : ta;
   st[TOL2] = tol2;
   st[ITERS] = 0.0;
+  st[NUPD] = 0.0;
   st[RTOL] = rtol;
   st[ATOL] = atol;
   st[MAXIT] = max_it;
@@ -421,6 +425,95 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const do
   }
 }
 
+// ---- deferred-x PCG (single-slab solve) -----------------------------------------------------------
+// x only matters when the solve ends, so the per-iteration x += alpha p (24 B/node) is replaced by
+// keeping the search directions in a ring (the p-update writes out of place at the same traffic) and
+// adding sum_i alpha_i p_i to x once the ring is full or the solve is over (8 (k+2) B/node in total).
+
+// r -= alpha q ; alpha = rz/pq is also stored in alphas[slot]; partial sums of r.D^-1 r and r.r.
+__global__ __launch_bounds__(BEAT_BLOCK) void cg_update_r_kernel(Geom g, const double* __restrict__ st,
+                                                                 double* __restrict__ r,
+                                                                 const double* __restrict__ q,
+                                                                 const double* __restrict__ dinv, double dinv_i,
+                                                                 double* __restrict__ partials,
+                                                                 double* __restrict__ alphas, int slot) {
+  __shared__ double red[4];
+  if (st[STOP] != 0.0) return;
+  const double alpha = st[RZ] / st[PQ];
+  if (blockIdx.x == 0 && threadIdx.x == 0) alphas[slot] = alpha;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = g.ny * g.nz;
+  double s_rz = 0.0, s_rr = 0.0;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int iz = row / g.ny, iy = row - iz * g.ny;
+    const int tyz = 3 * axis_type(iy, g.ny, 1, 1) + 9 * axis_type(iz, g.nz, g.z_lo_phys, g.z_hi_phys);
+    const int64_t base = (int64_t)row * g.nx;
+    for (int ix = lane; ix < g.nx; ix += 64) {
+      const int type = axis_type(ix, g.nx, 1, 1) + tyz;
+      const double di = (type == 13) ? dinv_i : dinv[type];
+      const int64_t i = base + ix;
+      const double ri = fma(-alpha, q[i], r[i]);
+      r[i] = ri;
+      s_rz = fma(ri * di, ri, s_rz);
+      s_rr = fma(ri, ri, s_rr);
+    }
+  }
+  const double a0 = beat_block_sum(s_rz, red);
+  const double a1 = beat_block_sum(s_rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = a0;
+    partials[BEAT_MAX_PARTIALS + blockIdx.x] = a1;
+  }
+}
+
+// p_new = D^-1 r + beta p_old (out of place)
+__global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_oop_kernel(Geom g, const double* __restrict__ st,
+                                                                    const double* __restrict__ r,
+                                                                    const double* __restrict__ p_old,
+                                                                    double* __restrict__ p_new,
+                                                                    const double* __restrict__ dinv, double dinv_i) {
+  if (st[STOP] != 0.0) return;
+  const double beta = st[BETA];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = g.ny * g.nz;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int iz = row / g.ny, iy = row - iz * g.ny;
+    const int tyz = 3 * axis_type(iy, g.ny, 1, 1) + 9 * axis_type(iz, g.nz, g.z_lo_phys, g.z_hi_phys);
+    const int64_t base = (int64_t)row * g.nx;
+    for (int ix = lane; ix < g.nx; ix += 64) {
+      const int type = axis_type(ix, g.nx, 1, 1) + tyz;
+      const double di = (type == 13) ? dinv_i : dinv[type];
+      const int64_t i = base + ix;
+      p_new[i] = fma(beta, p_old[i], di * r[i]);
+    }
+  }
+}
+
+// x += sum_{j < nvalid} alphas[j] * P_j, nvalid = clamp(executed updates - ring_base, 0, PRING).
+// Runs regardless of the latch: it is what brings x up to date after convergence.
+__global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const double* __restrict__ st,
+                                                             double* __restrict__ x,
+                                                             const double* __restrict__ ring, int64_t fld,
+                                                             const double* __restrict__ alphas, int ring_base,
+                                                             int only_if_full) {
+  int nvalid = (int)st[NUPD] - ring_base;
+  nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
+  // in-loop flushes are enqueued ahead of time: they must do nothing unless their ring cycle really
+  // filled up (a partially filled last cycle is flushed once, after the host has seen the latch)
+  if (nvalid == 0 || (only_if_full && nvalid < PRING)) return;
+  double a[PRING];
+#pragma unroll
+  for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
+    double xi = x[i];
+#pragma unroll
+    for (int j = 0; j < PRING; ++j)
+      if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
+    x[i] = xi;
+  }
+}
+
 // p = z + beta p  (z = M^-1 r already formed by the polynomial preconditioner)
 __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_z_kernel(int64_t n, const double* __restrict__ st,
                                                                   const double* __restrict__ z,
@@ -450,6 +543,7 @@ struct beat_pde {
   double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
   int last_iters = -1;
   unsigned vec_grid = 1;
+  double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
@@ -517,6 +611,7 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   BEAT_HIP_CHECK(hipSetDevice(ctx->device));
   BEAT_HIP_CHECK(hipMalloc(&p->d_tabs, sizeof(double) * (4 * 27 * TABW + 32)));
   BEAT_HIP_CHECK(hipMalloc(&p->d_st, sizeof(double) * 16));
+  BEAT_HIP_CHECK(hipMalloc(&p->d_alphas, sizeof(double) * PRING));
   BEAT_HIP_CHECK(hipMemsetAsync(p->d_st, 0, sizeof(double) * 16, ctx->stream));
   const int rc = upload_tables(p);  // Mass / K usable before the first set_timestep
   if (rc) return rc;
@@ -528,6 +623,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   if (pde == nullptr) return BEAT_OK;
   (void)hipFree(pde->d_tabs);
   (void)hipFree(pde->d_st);
+  (void)hipFree(pde->d_alphas);
   delete pde;
   return BEAT_OK;
 }
@@ -614,9 +710,10 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   return BEAT_OK;
 }
 
-static int launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st) {
+static int launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st,
+                         double* counter = nullptr) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                     (const double*)pde->ctx->d_partials, count, nsum, out, st);
+                     (const double*)pde->ctx->d_partials, count, nsum, out, st, counter);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -798,6 +895,19 @@ extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev
   return BEAT_OK;
 }
 
+extern "C" int beat_pde_work_fields(beat_pde* pde) {
+  return pde ? 3 + PRING : BEAT_EINVAL;  // r, q, z + the ring of search directions
+}
+
+static int launch_flush(beat_pde* pde, double* x, const double* ring, int64_t fld, int ring_base,
+                        int only_if_full) {
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
+                     (const double*)pde->d_st, x, ring, fld, (const double*)pde->d_alphas, ring_base, only_if_full);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
                               const double* const* host_dev_stim_w, const double* host_stim_amp,
                               int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
@@ -807,41 +917,73 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
   const int64_t fld = pde->n + 2 * pde->g.plane;
   double* r = dev_work + pde->g.plane;
-  double* p = r + fld;
-  double* q = p + fld;
-  double* z = q + fld;  // only touched by the polynomial preconditioner
+  double* q = r + fld;
+  double* z = q + fld;     // only touched by the polynomial preconditioner
+  double* ring = z + fld;  // PRING search directions, ring[j] = ring + j*fld
   double* st = pde->d_st;
+  beat_ctx* ctx = pde->ctx;
+  double* h = ctx->h_pinned;
   const int npass = pde->pc_ncoef - 1;
-  int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, p, st);
+  int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   if (rc) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
-  if (npass > 0) {  // z = M^-1 r, r.z -> st[RZ], p = z
+  int launched = 0;
+  int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  if (npass > 0) {
+    // polynomial preconditioner: classic in-place recurrences with p = ring[0]
+    double* p = ring;
     for (int j = 0; j < npass; ++j)
       if ((rc = beat_pde_pc_pass(pde, j, r, z, q, st, st + RZ))) return rc;
     if ((rc = beat_pde_cg_first_z(pde, st, z, p))) return rc;
-  }
-  beat_ctx* ctx = pde->ctx;
-  double* h = ctx->h_pinned;
-  int launched = 0;
-  int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
-  while (true) {
-    chunk = std::min(chunk, max_it - launched);
-    for (int it = 0; it < chunk; ++it) {
-      if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
-      if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
-      if (npass > 0) {
+    while (true) {
+      chunk = std::min(chunk, max_it - launched);
+      for (int it = 0; it < chunk; ++it) {
+        if ((rc = beat_pde_spmv_dot(pde, p, q, st))) return rc;
+        if ((rc = beat_pde_cg_update(pde, st, dev_x, r, p, q))) return rc;
         for (int j = 0; j < npass; ++j)
           if ((rc = beat_pde_pc_pass(pde, j, r, z, q, st, st + RZN))) return rc;
         if ((rc = beat_pde_cg_next_z(pde, st, z, p))) return rc;
-      } else {
-        if ((rc = beat_pde_cg_next(pde, st, r, p))) return rc;
       }
+      launched += chunk;
+      BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+      BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (h[STOP] != 0.0 || launched >= max_it) break;
+      chunk = 2;
     }
-    launched += chunk;
-    BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
-    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (h[STOP] != 0.0 || launched >= max_it) break;
-    chunk = 2;
+  } else {
+    // Jacobi, deferred x: iteration i uses p_i = ring[i % PRING]
+    while (true) {
+      chunk = std::min(chunk, max_it - launched);
+      for (int it = 0; it < chunk; ++it) {
+        const int i = launched + it, slot = i % PRING;
+        double* p_cur = ring + (int64_t)slot * fld;
+        double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
+        if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
+        hipLaunchKernelGGL(cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
+                           (const double*)st, r, (const double*)q, pde->d_dinv(), pde->h_dinv[13],
+                           ctx->d_partials, pde->d_alphas, slot);
+        BEAT_LAUNCH_CHECK();
+        if ((rc = launch_reduce(pde, (int)pde->vec_grid, 2, st + RZN, st, st + NUPD))) return rc;
+        if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
+          if ((rc = launch_flush(pde, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+        }
+        hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, ctx->stream, st);
+        BEAT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
+                           (const double*)st, (const double*)r, (const double*)p_cur, p_next, pde->d_dinv(),
+                           pde->h_dinv[13]);
+        BEAT_LAUNCH_CHECK();
+      }
+      launched += chunk;
+      BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+      BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (h[STOP] != 0.0 || launched >= max_it) break;
+      chunk = 2;
+    }
+    // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x)
+    const int nupd = (int)h[NUPD];
+    if (nupd % PRING != 0)
+      if ((rc = launch_flush(pde, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) return rc;
   }
   const int iters = (int)h[ITERS];
   pde->last_iters = iters;

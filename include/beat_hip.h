@@ -186,8 +186,12 @@ int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, doubl
 /* Whole single-slab step: rhs build + Jacobi-PCG to ||r|| <= max(rtol*||b||, atol), with all
  * scalars kept on the device (one host synchronisation at the end to fill `info`).
  * Replaces _update_rhs + KSP.solve of base_model.py:232-236 when the grid is not decomposed.
- * dev_work: 4 fields (r, p, q, z) laid out back to back, each with its own ghost planes:
- * size 4*(n_local + 2*nx*ny) doubles (z is only used by the polynomial preconditioner). Synchronises. */
+ * The Jacobi path defers the update of x: search directions are kept in a ring of 6 fields (the
+ * p-update writes out of place) and x += sum_i alpha_i p_i is applied once per solve, which removes
+ * 24 B/node of traffic per iteration.
+ * dev_work: beat_pde_work_fields() fields (r, q, z, ring[6]) laid out back to back, each with its own
+ * ghost planes: size fields*(n_local + 2*nx*ny) doubles. Synchronises. */
+int beat_pde_work_fields(beat_pde* pde);
 int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
                    double rtol, double atol, int max_it, beat_ksp_info* info);

@@ -303,7 +303,7 @@ def test_pde_solve_matches_direct_solve(hip_ctx, cells, L, Mk):
     fv, fx, fw = Field(ctx, n, plane), Field(ctx, n, plane), Field(ctx, n, plane)
     fv.set(v_prev)
     fw.set(w)
-    work = ctx.zeros(4 * (n + 2 * plane))
+    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * (n + 2 * plane))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([fw.ptr.value]), _dbl_array([amp]), 1, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-12, 1e-50, 500, C.byref(info)))
@@ -327,7 +327,7 @@ def test_pde_solve_zero_rhs_and_latch(hip_ctx):
     _hip.check(ctx.lib.beat_pde_set_timestep(handle, 1.0, 0.5, 0.4))
     n, plane = 11, 11
     fv, fx = Field(ctx, n, plane), Field(ctx, n, plane)
-    work = ctx.zeros(4 * (n + 2 * plane))
+    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * (n + 2 * plane))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([]), _dbl_array([]), 0, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-10, 1e-50, 100, C.byref(info)))
@@ -455,3 +455,44 @@ def test_polynomial_preconditioned_pcg(hip_ctx, degree):
     np.testing.assert_allclose(coef, fem.chebyshev_coefficients(degree, lmin, lmax), rtol=1e-13)
     _, its_ref, _ = fem.pcg_polynomial(A, model.rhs(theta * dt, dt), v_prev, coef, rtol=1e-11)
     assert abs(its_ref - its[degree]) <= 1, (its_ref, its)
+
+
+def test_deferred_x_ring_wrap_and_over_enqueue(hip_ctx):
+    """Deferred-x PCG bookkeeping: (a) more iterations than the ring holds (wraps, in-loop flush),
+    (b) a solve that converges long before the iterations enqueued ahead of time have run (the
+    pre-enqueued flushes must stay no-ops): both give exactly what a fresh solver gives."""
+    from beat import _stencil
+    from beat._engine import DiffusionSolver, HipOps, Slab
+
+    ctx = hip_ctx
+    nn = (50, 23, 11)
+    mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), _conductivity("aniso3", 3))
+    rng = np.random.default_rng(21)
+    v_hard = rng.standard_normal(nn[0] * nn[1] * nn[2]) * 50.0
+    v_easy = -85.0 + 1e-3 * rng.standard_normal(v_hard.size)
+
+    def make():
+        ops = HipOps(ctx, nn, True, True, mt, kt)
+        ops.set_timestep(0.01, 0.5, 0.5)  # large dt: stiffness matters, many iterations
+        return ops, DiffusionSolver(ops, Slab(nn[2]))
+
+    def solve(solver, ops, v, rtol):
+        fv, fx = ops.new_field(), ops.new_field()
+        fv.set(v)
+        res = solver.solve(fv, [], [], fx, rtol=rtol, atol=1e-50, max_it=500)
+        return fx.numpy(), res
+
+    ops, solver = make()
+    x_hard, r_hard = solve(solver, ops, v_hard, 1e-12)
+    assert r_hard.iterations > 13  # wrapped the 6-deep ring at least twice
+    x_easy, r_easy = solve(solver, ops, v_easy, 1e-6)  # same handle: r_hard.iterations get enqueued
+    assert r_easy.iterations < 6
+    ops2, solver2 = make()
+    x_ref, r_ref = solve(solver2, ops2, v_easy, 1e-6)
+    assert r_ref.iterations == r_easy.iterations
+    np.testing.assert_array_equal(x_easy, x_ref)
+    # and the hard one against the distributed-style classic recurrences (x updated every iteration)
+    ops3 = HipOps(ctx, nn, True, True, mt, kt)
+    ops3.set_timestep(0.01, 0.5, 0.5)
+    x_cls, r_cls = solve(DiffusionSolver(ops3, Slab(nn[2]), force_distributed=False), ops3, v_hard, 1e-12)
+    np.testing.assert_array_equal(x_cls, x_hard)
