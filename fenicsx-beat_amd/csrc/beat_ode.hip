@@ -24,9 +24,11 @@ __global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_step_kernel(
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
     int v_index, double* __restrict__ v_copy) {
   __shared__ double etab[64];
+  __shared__ LogEntry ltab[128];
   if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
-  const FastMath fm{etab};
+  const FastMath fm{etab, ltab};
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;
   const NodeIO io{states, ld, i, v_copy, v_index};

@@ -45,8 +45,161 @@ __device__ const double kExp2Tab[64] = {
     1.9152065613971472939, 1.9360617934922944506, 1.9571441241754002690, 1.9784560263879509683,
 };
 
+// log(): x = 2^e * m, m in [1, 2); the top 7 mantissa bits pick c_j = 1 + (j + 0.5)/128 from a table of
+// (1/c_j, log c_j) pairs (2 KB in LDS, one ds_read_b128); r = m/c_j - 1, |r| <= 2^-8, and
+// log x = e ln2 + log c_j + (r - r^2/2 + ... - r^6/6), truncation < 2e-18.  Arguments here are
+// concentration ratios (positive, normal, far from 1), so no special cases.
+struct LogEntry {
+  double inv, logc;
+};
+__device__ const LogEntry kLogTab[128] = {
+    {0.9961089494163424, 0.0038986404156573091361},
+    {0.9884169884169884, 0.011650617219975250717},
+    {0.9808429118773946, 0.019342962843130986244},
+    {0.973384030418251, 0.026976587698202081386},
+    {0.9660377358490566, 0.034552381506659725601},
+    {0.9588014981273408, 0.042071213920687043533},
+    {0.9516728624535316, 0.04953393512227667772},
+    {0.9446494464944649, 0.056941376400138453816},
+    {0.9377289377289377, 0.064294350705397258084},
+    {0.9309090909090909, 0.071593653187008818793},
+    {0.924187725631769, 0.07884006170777598897},
+    {0.9175627240143369, 0.086034337341803154249},
+    {0.9110320284697508, 0.093177224854183340943},
+    {0.9045936395759717, 0.10026945316367516232},
+    {0.8982456140350877, 0.10731173578908803202},
+    {0.89198606271777, 0.1143047712800586345},
+    {0.8858131487889274, 0.1212492436328696548},
+    {0.8797250859106529, 0.12814582269193005726},
+    {0.8737201365187713, 0.13499516453750482063},
+    {0.8677966101694915, 0.14179791186025737894},
+    {0.8619528619528619, 0.14855469432313718671},
+    {0.8561872909698997, 0.1552661289111239693},
+    {0.8504983388704319, 0.16193282026931322982},
+    {0.8448844884488449, 0.1685553610298066548},
+    {0.839344262295082, 0.17513433212784914888},
+    {0.8338762214983714, 0.18167030310763463359},
+    {0.8284789644012945, 0.18816383241818293955},
+    {0.8231511254019293, 0.19461546769967167013},
+    {0.8178913738019169, 0.20102574606059078297},
+    {0.8126984126984127, 0.20739519434607058803},
+    {0.807570977917981, 0.21372432939771816965},
+    {0.8025078369905956, 0.22001365830528213494},
+    {0.7975077881619937, 0.22626367865045341755},
+    {0.7925696594427245, 0.23247487874309400507},
+    {0.7876923076923077, 0.23864773785017501078},
+    {0.7828746177370031, 0.24478272641769090819},
+    {0.7781155015197568, 0.25088030628580942049},
+    {0.7734138972809668, 0.25694093089750042631},
+    {0.7687687687687688, 0.26296504550088136049},
+    {0.764179104477612, 0.26895308734550394896},
+    {0.7596439169139466, 0.27490548587279921274},
+    {0.7551622418879056, 0.28082266290088779852},
+    {0.750733137829912, 0.28670503280395431552},
+    {0.7463556851311953, 0.29255300268637745602},
+    {0.7420289855072464, 0.29836697255179726932},
+    {0.7377521613832853, 0.3041473354672967825},
+    {0.7335243553008596, 0.30989447772286471865},
+    {0.7293447293447294, 0.31560877898630328503},
+    {0.7252124645892352, 0.32129061245373424479},
+    {0.7211267605633803, 0.32694034499585326725},
+    {0.7170868347338936, 0.33255833730007659317},
+    {0.713091922005571, 0.33814494400871639467},
+    {0.7091412742382271, 0.34370051385331844251},
+    {0.7052341597796143, 0.34922538978528827643},
+    {0.7013698630136986, 0.35471990910292902055},
+    {0.6975476839237057, 0.36018440357500783228},
+    {0.6937669376693767, 0.36561919956096471219},
+    {0.6900269541778976, 0.37102461812787261014},
+    {0.6863270777479893, 0.37640097516425304692},
+    {0.6826666666666666, 0.38174858149084837325},
+    {0.6790450928381963, 0.38706774296844833951},
+    {0.6754617414248021, 0.39235876060286390804},
+    {0.6719160104986877, 0.39762193064713850298},
+    {0.6684073107049608, 0.40285754470108350164},
+    {0.6649350649350649, 0.4080658898082217493},
+    {0.661498708010336, 0.41324724855021928886},
+    {0.6580976863753213, 0.41840189913888388994},
+    {0.6547314578005116, 0.42353011550580321375},
+    {0.6513994910941476, 0.42863216738969868561},
+    {0.6481012658227848, 0.43370832042155937479},
+    {0.6448362720403022, 0.43875883620762796463},
+    {0.6416040100250626, 0.44378397241030103668},
+    {0.6384039900249376, 0.44878398282700673567},
+    {0.6352357320099256, 0.45375911746712050751},
+    {0.6320987654320988, 0.45870962262697668523},
+    {0.628992628992629, 0.46363574096303253781},
+    {0.6259168704156479, 0.46853771156323927471},
+    {0.6228710462287105, 0.47341577001667210492},
+    {0.6198547215496368, 0.47827014848147023268},
+    {0.6168674698795181, 0.4831010757511357347},
+    {0.6139088729016786, 0.48790877731923904177},
+    {0.6109785202863962, 0.49269347544257520972},
+    {0.6080760095011877, 0.49745538920281889802},
+    {0.6052009456264775, 0.50219473456671551856},
+    {0.6023529411764705, 0.50691172444485444172},
+    {0.5995316159250585, 0.51160656874906207939},
+    {0.5967365967365967, 0.51627947444845449704},
+    {0.5939675174013921, 0.52093064562418535404},
+    {0.5912240184757506, 0.52556028352292738743},
+    {0.5885057471264368, 0.53016858660912163172},
+    {0.585812356979405, 0.53475575061602767331},
+    {0.5831435079726651, 0.53932196859560892193},
+    {0.5804988662131519, 0.54386743096728349121},
+    {0.5778781038374717, 0.54839232556557324645},
+    {0.5752808988764045, 0.55289683768667764954},
+    {0.5727069351230425, 0.55738115013400637873},
+    {0.5701559020044543, 0.56184544326269186172},
+    {0.5676274944567627, 0.56628989502311587346},
+    {0.565121412803532, 0.57071468100347154572},
+    {0.5626373626373626, 0.57511997447138794129},
+    {0.5601750547045952, 0.57950594641464226028},
+    {0.5577342047930284, 0.58387276558098258239},
+    {0.5553145336225597, 0.58822059851708601311},
+    {0.5529157667386609, 0.59254960960667153759},
+    {0.5505376344086022, 0.59685996110779383745},
+    {0.5481798715203426, 0.60115181318933478025},
+    {0.5458422174840085, 0.60542532396671690852},
+    {0.5435244161358811, 0.60968064953685529126},
+    {0.5412262156448203, 0.61391794401237045013},
+    {0.5389473684210526, 0.61813735955507875642},
+    {0.5366876310272537, 0.62233904640877868782},
+    {0.534446764091858, 0.62652315293135285953},
+    {0.5322245322245323, 0.63068982562619864957},
+    {0.5300207039337475, 0.63483920917301013998},
+    {0.5278350515463918, 0.63897144645792069839},
+    {0.5256673511293635, 0.6430866786030272781},
+    {0.523517382413088, 0.64718504499530945601},
+    {0.5213849287169042, 0.65126668331495819751},
+    {0.5192697768762677, 0.65533172956312764597},
+    {0.5171717171717172, 0.65938031808912782698},
+    {0.5150905432595574, 0.66341258161706616696},
+    {0.5130260521042084, 0.66742865127195627278},
+    {0.5109780439121756, 0.67142865660530240745},
+    {0.5089463220675944, 0.67541272562017683386},
+    {0.5069306930693069, 0.679380984795797338},
+    {0.504930966469428, 0.68333355911162063829},
+    {0.5029469548133595, 0.68727057207096033905},
+    {0.5009784735812133, 0.69119214572414201437},
+};
+
 struct FastMath {
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
+  const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab
+  __device__ __forceinline__ double log(double x) const {
+    const int hi = __double2hiint(x);
+    const int e = ((hi >> 20) & 0x7ff) - 1023;
+    const LogEntry t = ltab[(hi >> 13) & 127];
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x));  // mantissa in [1, 2)
+    const double r = fma(m, t.inv, -1.0);
+    double p = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r * r, p, r);
+    const double ed = (double)e;
+    return fma(ed, 0.693147180559663, t.logc + fma(ed, 2.8235290563031577e-13, p));
+  }
   __device__ __forceinline__ double exp(double x) const {
     const double k = __builtin_rint(x * 92.33248261689366);             // 64 / ln 2
     double r = fma(k, -0.01083042469326756, x);                         // ln2/64, high part (exact product)
@@ -203,16 +356,47 @@ struct Tp06Grl1 {
     return q;
   }
 
-  // 1/x: hardware estimate + two Newton steps
+  // 1/x: hardware estimate (~26 bits) + one third-order step r (1 + e + e^2), e = 1 - x r
   __device__ static __forceinline__ double rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+  }
+  // Reciprocals of 2-4 independent values from ONE v_rcp_f64 (Montgomery's trick): 1/(ab) b = 1/a ...
+  // Every group here is a set of finite, normal, same-sign-insensitive denominators whose product
+  // stays far inside the double range; each result carries ~2 extra roundings.
+  __device__ static __forceinline__ void rcp2(double a, double b, double& ia, double& ib) {
+    const double r = rcp(a * b);
+    ia = r * b;
+    ib = r * a;
+  }
+  __device__ static __forceinline__ void rcp3(double a, double b, double c, double& ia, double& ib, double& ic) {
+    const double ab = a * b;
+    const double r = rcp(ab * c);
+    ic = r * ab;
+    const double t = r * c;
+    ia = t * b;
+    ib = t * a;
+  }
+  __device__ static __forceinline__ void rcp4(double a, double b, double c, double d, double& ia, double& ib,
+                                              double& ic, double& id) {
+    const double ab = a * b, cd = c * d;
+    const double r = rcp(ab * cd);
+    const double rab = r * cd, rcd = r * ab;
+    ia = rab * b;
+    ib = rab * a;
+    ic = rcd * d;
+    id = rcd * c;
   }
   __device__ static __forceinline__ double grl1(const FastMath& fm, double y, double fy, double J, double dt) {
     return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(J * dt) - 1.0) * rcp(J) : fy * dt);
   }
+  // same with 1/J supplied by the caller (batched); rJ is only used where |J| > 1e-8
+  __device__ static __forceinline__ double grl1r(const FastMath& fm, double y, double fy, double J, double rJ,
+                                                 double dt) {
+    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(J * dt) - 1.0) * rJ : fy * dt);
+  }
+  __device__ static __forceinline__ double guard(double J) { return (fabs(J) > 1e-8) ? J : 1.0; }
   // gate with f = (inf - y)/tau, J = -1/tau
   __device__ static __forceinline__ double gate(const FastMath& fm, double y, double inf, double rtau, double dt) {
     return y + (inf - y) * (1.0 - fm.exp(-dt * rtau));
@@ -258,95 +442,94 @@ struct Tp06Grl1 {
     const double gates_CaL = q.cCaL * od * of * of2 * ofCass;
 
     // ---- shared exponentials of V ----------------------------------------------------------------------
-    const double E20 = fm.exp(0.05 * v), I20 = rcp(E20);
+    const double E20 = fm.exp(0.05 * v), E7 = fm.exp(v * (1.0 / 7.0));
+    double I20, I7;
+    rcp2(E20, E7, I20, I7);
     const double E10 = E20 * E20, I10 = I20 * I20;
     const double E5 = E10 * E10, I5 = I10 * I10;
-    const double E7 = fm.exp(v * (1.0 / 7.0)), I7 = rcp(E7);
     const double I6 = fm.exp(v * (-1.0 / 6.0));
     BEAT_FENCE();
 
     // ---- gates: y += (inf - y)(1 - exp(-dt/tau)); time constants as single quotients ------------------------
-    {  // Xr1 (.ode:189-194): tau = 450/(1+ea) * 6/(1+eb)
-      const double inf = rcp(1.0 + EXP_M26_7 * I7);                          // exp((-26 - V)/7)
-      const double rtau = (1.0 + EXP_M4P5 * I10) * (1.0 + fm.exp((v + 30.0) * (1.0 / 11.5))) * (1.0 / 2700.0);
-      io.store(Xr1, gate(fm, oXr1, inf, rtau, dt));
-    }
-    {  // Xr2 (.ode:196-201): tau = 3/(1+ea) * 1.12/(1+eb)
-      const double inf = rcp(1.0 + fm.exp((v + 88.0) * (1.0 / 24.0)));
-      const double rtau = (1.0 + EXP_M3 * I20) * (1.0 + EXP_M3 * E20) * (1.0 / 3.36);
-      io.store(Xr2, gate(fm, oXr2, inf, rtau, dt));
+    {  // Xr1 (.ode:189-194): tau = 450/(1+ea) * 6/(1+eb);  Xr2 (.ode:196-201): tau = 3/(1+ea) * 1.12/(1+eb)
+      double inf1, inf2;
+      rcp2(1.0 + EXP_M26_7 * I7, 1.0 + fm.exp((v + 88.0) * (1.0 / 24.0)), inf1, inf2);  // exp((-26 - V)/7)
+      const double rtau1 = (1.0 + EXP_M4P5 * I10) * (1.0 + fm.exp((v + 30.0) * (1.0 / 11.5))) * (1.0 / 2700.0);
+      io.store(Xr1, gate(fm, oXr1, inf1, rtau1, dt));
+      const double rtau2 = (1.0 + EXP_M3 * I20) * (1.0 + EXP_M3 * E20) * (1.0 / 3.36);
+      io.store(Xr2, gate(fm, oXr2, inf2, rtau2, dt));
     }
     BEAT_FENCE();
     {  // Xs (.ode:206-211): tau = 1400/sqrt(1+ea) * 1/(1+eb) + 80 = (1400 + 80 D)/D
-      const double inf = rcp(1.0 + fm.exp((-5.0 - v) * (1.0 / 14.0)));
       const double D = sqrt(1.0 + EXP_5_6 * I6) * (1.0 + fm.exp((v - 35.0) * (1.0 / 15.0)));  // exp((5 - V)/6)
-      const double rtau = D * rcp(1400.0 + 80.0 * D);
-      io.store(Xs, gate(fm, oXs, inf, rtau, dt));
+      double inf, rnum;
+      rcp2(1.0 + fm.exp((-5.0 - v) * (1.0 / 14.0)), 1400.0 + 80.0 * D, inf, rnum);
+      io.store(Xs, gate(fm, oXs, inf, D * rnum, dt));
     }
     BEAT_FENCE();
     {  // m (.ode:216-221): tau = 1/(1+ea) * (0.1/(1+eb) + 0.1/(1+ec))
-      const double rm = rcp(1.0 + fm.exp((-56.86 - v) * (1.0 / 9.03)));
       const double da = 1.0 + EXP_M12 * I5;                                   // exp((-60 - V)/5)
       const double db = 1.0 + EXP_7 * E5;                                     // exp((V + 35)/5)
       const double dc = 1.0 + fm.exp((v - 50.0) * (1.0 / 200.0));
-      const double rtau = da * db * dc * 10.0 * rcp(db + dc);
-      io.store(m, gate(fm, om, rm * rm, rtau, dt));
+      double rm, rsum;
+      rcp2(1.0 + fm.exp((-56.86 - v) * (1.0 / 9.03)), db + dc, rm, rsum);
+      io.store(m, gate(fm, om, rm * rm, da * db * dc * 10.0 * rsum, dt));
     }
     BEAT_FENCE();
     {  // h, j (.ode:223-235): tau = 1/(alpha + beta), shared steady state
-      const double rh = rcp(1.0 + fm.exp((v + 71.55) * (1.0 / 7.43)));
-      const double h_inf = rh * rh;
-      double ah_bh, aj_bj;
+      const double dh = 1.0 + fm.exp((v + 71.55) * (1.0 / 7.43));
+      double rh, ah_bh, aj_bj;
       if (v < -40.0) {
         ah_bh = 0.057 * fm.exp(-(v + 80.0) * (1.0 / 6.8)) + 2.7 * fm.exp(0.079 * v) + 310000.0 * fm.exp(0.3485 * v);
         const double da = 1.0 + fm.exp(0.311 * (v + 79.23)), db = 1.0 + fm.exp(-0.1378 * (v + 40.14));
         const double na = (-25428.0 * fm.exp(0.2444 * v) - 6.948e-6 * fm.exp(-0.04391 * v)) * (v + 37.78);
         const double nb = 0.02424 * fm.exp(-0.01052 * v);
-        aj_bj = (na * db + nb * da) * rcp(da * db);
+        double rab;
+        rcp2(dh, da * db, rh, rab);
+        aj_bj = (na * db + nb * da) * rab;
       } else {
-        ah_bh = 0.77 * rcp(0.13 * (1.0 + fm.exp((v + 10.66) * (-1.0 / 11.1))));
-        aj_bj = 0.6 * fm.exp(0.057 * v) * rcp(1.0 + EXP_M3P2 * I10);         // exp(-0.1 (V + 32))
+        double rbh, rbj;
+        rcp3(dh, 0.13 * (1.0 + fm.exp((v + 10.66) * (-1.0 / 11.1))), 1.0 + EXP_M3P2 * I10, rh, rbh, rbj);
+        ah_bh = 0.77 * rbh;
+        aj_bj = 0.6 * fm.exp(0.057 * v) * rbj;                               // exp(-0.1 (V + 32))
       }
+      const double h_inf = rh * rh;
       io.store(h, gate(fm, oh, h_inf, ah_bh, dt));
       io.store(j, gate(fm, oj, h_inf, aj_bj, dt));
     }
     BEAT_FENCE();
     {  // d (.ode:243-249): tau = (1.4/(1+ea) + 0.25) * 1.4/(1+eb) + 1/(1+ec)
-      const double inf = rcp(1.0 + fm.exp((-8.0 - v) * (1.0 / 7.5)));
       const double da = 1.0 + fm.exp((-35.0 - v) * (1.0 / 13.0));
       const double db = 1.0 + EXP_1 * E5;                                     // exp((V + 5)/5)
       const double dc = 1.0 + EXP_2P5 * I20;                                  // exp((50 - V)/20)
       const double num = (1.4 + 0.25 * da) * 1.4 * dc + da * db;
-      const double rtau = da * db * dc * rcp(num);
-      io.store(d, gate(fm, od, inf, rtau, dt));
+      double inf, rnum;
+      rcp2(1.0 + fm.exp((-8.0 - v) * (1.0 / 7.5)), num, inf, rnum);
+      io.store(d, gate(fm, od, inf, da * db * dc * rnum, dt));
     }
     BEAT_FENCE();
     {  // f, f2 (.ode:251-259): tau = c G + A/(1+ea) + B/(1+eb) [+ 20]
       const double v27sq = (v + 27.0) * (v + 27.0);
       const double db = 1.0 + EXP_3 * E10;                                    // exp((V + 30)/10)
-      {
-        const double inf = rcp(1.0 + EXP_20_7 * E7);                          // exp((V + 20)/7)
-        const double da = 1.0 + EXP_1P3 * I10;                                // exp((13 - V)/10)
-        const double dab = da * db;
-        const double num = (1102.5 * fm.exp(v27sq * (-1.0 / 225.0)) + 20.0) * dab + 200.0 * db + 180.0 * da;
-        io.store(f, gate(fm, of, inf, dab * rcp(num), dt));
-      }
-      {
-        const double inf = 0.67 * rcp(1.0 + EXP_5 * E7) + 0.33;               // exp((V + 35)/7)
-        const double da = 1.0 + EXP_2P5 * I10;                                // exp((25 - V)/10)
-        const double dab = da * db;
-        const double num = 562.0 * fm.exp(v27sq * (-1.0 / 240.0)) * dab + 31.0 * db + 80.0 * da;
-        io.store(f2, gate(fm, of2, inf, dab * rcp(num), dt));
-      }
+      const double da1 = 1.0 + EXP_1P3 * I10;                                 // exp((13 - V)/10)
+      const double dab1 = da1 * db;
+      const double num1 = (1102.5 * fm.exp(v27sq * (-1.0 / 225.0)) + 20.0) * dab1 + 200.0 * db + 180.0 * da1;
+      const double da2 = 1.0 + EXP_2P5 * I10;                                 // exp((25 - V)/10)
+      const double dab2 = da2 * db;
+      const double num2 = 562.0 * fm.exp(v27sq * (-1.0 / 240.0)) * dab2 + 31.0 * db + 80.0 * da2;
+      double inf1, rnum1, rinf2, rnum2;
+      rcp4(1.0 + EXP_20_7 * E7, num1, 1.0 + EXP_5 * E7, num2, inf1, rnum1, rinf2, rnum2);  // exp((V+20)/7), exp((V+35)/7)
+      io.store(f, gate(fm, of, inf1, dab1 * rnum1, dt));
+      io.store(f2, gate(fm, of2, 0.67 * rinf2 + 0.33, dab2 * rnum2, dt));
     }
     BEAT_FENCE();
     {  // s, r (.ode:276-284)
       const double ds_ = 1.0 + EXP_M4 * E5;                                   // exp((V - 20)/5)
-      const double s_inf = rcp(1.0 + EXP_4 * E5);                             // exp((V + 20)/5)
       const double num = (85.0 * fm.exp((v + 45.0) * (v + 45.0) * (-1.0 / 320.0)) + 3.0) * ds_ + 5.0;
-      io.store(s, gate(fm, os, s_inf, ds_ * rcp(num), dt));
-      const double r_inf = rcp(1.0 + EXP_20_6 * I6);                          // exp((20 - V)/6)
-      const double rtau_r = rcp(9.5 * fm.exp((v + 40.0) * (v + 40.0) * (-1.0 / 1800.0)) + 0.8);
+      double s_inf, rnum, r_inf, rtau_r;
+      rcp4(1.0 + EXP_4 * E5, num, 1.0 + EXP_20_6 * I6,                        // exp((V + 20)/5), exp((20 - V)/6)
+           9.5 * fm.exp((v + 40.0) * (v + 40.0) * (-1.0 / 1800.0)) + 0.8, s_inf, rnum, r_inf, rtau_r);
+      io.store(s, gate(fm, os, s_inf, ds_ * rnum, dt));
       io.store(r, gate(fm, orr, r_inf, rtau_r, dt));
     }
     BEAT_FENCE();
@@ -355,17 +538,18 @@ struct Tp06Grl1 {
                  vKi = io.load(K_i), vR = io.load(R_prime);
     {  // fCass (.ode:261-264): depends on Ca_ss only
       const double c2 = 1.0 + (vCass * 20.0) * (vCass * 20.0);                // 1 + (Ca_ss/0.05)^2
-      const double rc2 = rcp(c2);
-      io.store(fCass, gate(fm, ofCass, 0.6 * rc2 + 0.4, c2 * rcp(80.0 + 2.0 * c2), dt));
+      double rc2, rt;
+      rcp2(c2, 80.0 + 2.0 * c2, rc2, rt);
+      io.store(fCass, gate(fm, ofCass, 0.6 * rc2 + 0.4, c2 * rt, dt));
     }
 
     // ---- reversal potentials ------------------------------------------------------------------------
-    const double rNai = rcp(vNai), rKi = rcp(vKi), rCai = rcp(vCai);
-    const double rKs = rcp(vKi + p[P_kna] * vNai);
-    const double E_Na = q.RTF * log(p[Na_o] * rNai);
-    const double E_K = q.RTF * log(p[K_o] * rKi);
-    const double E_Ks = q.RTF * log(q.KoPk * rKs);
-    const double E_Ca = q.halfRTF * log(p[Ca_o] * rCai);
+    double rNai, rKi, rCai, rKs;
+    rcp4(vNai, vKi, vCai, vKi + p[P_kna] * vNai, rNai, rKi, rCai, rKs);
+    const double E_Na = q.RTF * fm.log(p[Na_o] * rNai);
+    const double E_K = q.RTF * fm.log(p[K_o] * rKi);
+    const double E_Ks = q.RTF * fm.log(q.KoPk * rKs);
+    const double E_Ca = q.halfRTF * fm.log(p[Ca_o] * rCai);
     const double u = v - E_K;
     BEAT_FENCE();
 
@@ -377,19 +561,19 @@ struct Tp06Grl1 {
       const double e1 = EXP_M12 * (G2 * G);                  // exp(0.06 (u - 200))
       const double e2 = EXP_P02 * fm.exp(0.0002 * u);        // exp(0.0002 (u + 100))
       const double e3 = EXP_M1 * G5;                         // exp(0.1 (u - 10))
-      const double e4 = rcp(G25);                            // exp(-0.5 u)
-      const double r1 = rcp(1.0 + e1);
+      double e4, r1, rG1;                                    // exp(-0.5 u) = 1/G25, 1/(1 + e1), 1/(G25 + 1)
+      rcp3(G25, 1.0 + e1, G25 + 1.0, e4, r1, rG1);
       const double aK1 = 0.1 * r1;
       const double daK1 = -0.06 * aK1 * e1 * r1;
-      const double rD = rcp(1.0 + e4);
+      const double rD = G25 * rG1;                           // 1/(1 + e4)
       const double bK1 = (3.0 * e2 + e3) * rD;
       const double dbK1 = (0.0006 * e2 + 0.1 * e3 + 0.5 * e4 * bK1) * rD;
-      const double rab = rcp(aK1 + bK1);
+      const double epK = fm.exp((25.0 - v) * (1.0 / 5.98));  // plateau K current (.ode:296)
+      double rab, rpK;
+      rcp2(aK1 + bK1, 1.0 + epK, rab, rpK);
       const double xK1 = aK1 * rab;
       const double dxK1 = (daK1 * bK1 - aK1 * dbK1) * rab * rab;
       const double i_K1 = q.gK1s * xK1 * u;
-      const double epK = fm.exp((25.0 - v) * (1.0 / 5.98));  // plateau K current (.ode:296)
-      const double rpK = rcp(1.0 + epK);
       const double i_p_K = p[g_pK] * u * rpK;
       I_K = i_K1 + gto * u + gKr * u + i_p_K;
       sum_du = q.gK1s * (dxK1 * u + xK1) + gto + gKr + p[g_pK] * rpK;  // d/du of the u-driven currents
@@ -406,13 +590,12 @@ struct Tp06Grl1 {
     const double e6 = e5_8 * e5_2;                                // exp(-V F/RT)
     const double eg = fm.exp(p[gamma] * vF);
     const double eg1 = eg * e6;                                   // exp((gamma - 1) V F/RT)
-    const double rNaK = rcp(1.0 + 0.1245 * e5 + 0.0353 * e6);
-    const double rNaKm = rcp(vNai + p[K_mNa]);
+    double rNaK, rNaKm, rS;
+    rcp3(1.0 + 0.1245 * e5 + 0.0353 * e6, vNai + p[K_mNa], 1.0 + p[K_sat] * eg1, rNaK, rNaKm, rS);
     const double i_NaK = q.NaK_B * vNai * rNaKm * rNaK;
     const double di_NaK_dNai = q.NaK_B * p[K_mNa] * rNaKm * rNaKm * rNaK;
     dI_dV += i_NaK * q.FRT * (0.01245 * e5 + 0.0353 * e6) * rNaK;
     const double A1 = (vNai * vNai * vNai) * p[Ca_o], A2 = q.A2c * vCai;
-    const double rS = rcp(1.0 + p[K_sat] * eg1);
     const double NNaCa = eg * A1 - eg1 * A2;
     const double kS = q.kNaCaQ * rS;
     const double i_NaCa = kS * NNaCa;
@@ -430,12 +613,12 @@ struct Tp06Grl1 {
     // V = 15 mV and would amplify the few-ulp error of a value derived from e6
     const double eCaL = fm.exp(2.0 * (v - 15.0) * q.FRT);
     const double w15 = v - 15.0;
-    const double rDc = rcp(eCaL - 1.0);
+    double rDc, rpCa;
+    rcp2(eCaL - 1.0, vCai + p[K_pCa], rDc, rpCa);
     const double NCaL = 0.25 * vCass * eCaL - p[Ca_o];
     const double i_CaL = gates_CaL * w15 * NCaL * rDc;
     dI_dV += gates_CaL * (NCaL * rDc + w15 * (2.0 * q.FRT) * eCaL * (p[Ca_o] - 0.25 * vCass) * rDc * rDc);
     const double di_CaL_dCass = gates_CaL * w15 * 0.25 * eCaL * rDc;
-    const double rpCa = rcp(vCai + p[K_pCa]);
     const double i_p_Ca = p[g_pCa] * vCai * rpCa;
     const double di_pCa_dCai = p[g_pCa] * p[K_pCa] * rpCa * rpCa;
     I_tot += i_CaL + i_p_Ca;
@@ -445,17 +628,28 @@ struct Tp06Grl1 {
     const double tmod = t - floor(t / p[stim_period]) * p[stim_period];
     const double i_Stim =
         (tmod >= p[stim_start] && tmod <= p[stim_start] + p[stim_duration]) ? p[stim_amplitude] : 0.0;
-    io.store(V, grl1(fm, v, -(I_tot + i_Stim), -dI_dV, dt));
-    // dE_K/dK_i = -RTF/K_i, dE_Ks/dK_i = -RTF/(K_i + P_kna Na_i); currents depend on K_i only through them
-    io.store(K_i, grl1(fm, vKi, -(I_K + i_Stim - 2.0 * i_NaK) * q.cVF,
-                       -(sum_du * q.RTF * rKi + gKs * q.RTF * rKs) * q.cVF, dt));
-    io.store(Na_i, grl1(fm, vNai, -(i_Na_tot + 3.0 * i_NaK + 3.0 * i_NaCa) * q.cVF,
-                        -((gNa + p[g_bna]) * q.RTF * rNai + 3.0 * di_NaK_dNai + 3.0 * di_NaCa_dNai) * q.cVF, dt));
+    {
+      const double J_V = -dI_dV;
+      // dE_K/dK_i = -RTF/K_i, dE_Ks/dK_i = -RTF/(K_i + P_kna Na_i); currents depend on K_i only through them
+      const double J_Ki = -(sum_du * q.RTF * rKi + gKs * q.RTF * rKs) * q.cVF;
+      const double J_Nai = -((gNa + p[g_bna]) * q.RTF * rNai + 3.0 * di_NaK_dNai + 3.0 * di_NaCa_dNai) * q.cVF;
+      double rJV, rJK, rJN;
+      rcp3(guard(J_V), guard(J_Ki), guard(J_Nai), rJV, rJK, rJN);
+      io.store(V, grl1r(fm, v, -(I_tot + i_Stim), J_V, rJV, dt));
+      io.store(K_i, grl1r(fm, vKi, -(I_K + i_Stim - 2.0 * i_NaK) * q.cVF, J_Ki, rJK, dt));
+      io.store(Na_i, grl1r(fm, vNai, -(i_Na_tot + 3.0 * i_NaK + 3.0 * i_NaCa) * q.cVF, J_Nai, rJN, dt));
+    }
     BEAT_FENCE();
 
     // ---- calcium dynamics (.ode:298-316) -----------------------------------------------------------------------------
     const double qup = q.Kup2 * rCai * rCai;
-    const double rup = rcp(1.0 + qup);
+    double rup, rbc, rCaSR, rbsr, rbss;
+    rcp3(1.0 + qup, vCai + p[K_buf_c], vCaSR, rup, rbc, rCaSR);
+    rcp2(vCaSR + p[K_buf_sr], vCass + p[K_buf_ss], rbsr, rbss);
+    const double zsr = (p[EC] * rCaSR) * (p[EC] * rCaSR);
+    const double gci = q.BKc * rbc * rbc, gsr = q.BKsr * rbsr * rbsr, gss = q.BKss * rbss * rbss;
+    double rz, Fr_i, Fr_sr, Fr_ss;
+    rcp4(1.0 + zsr, 1.0 + gci, 1.0 + gsr, 1.0 + gss, rz, Fr_i, Fr_sr, Fr_ss);
     const double i_up = p[Vmax_up] * rup;
     const double di_up_dCai = i_up * 2.0 * qup * rCai * rup;
     const double i_leak = p[V_leak] * (vCaSR - vCai);
@@ -464,15 +658,9 @@ struct Tp06Grl1 {
       const double T_i = -(i_b_Ca + i_p_Ca - 2.0 * i_NaCa) * q.c1 + (i_leak - i_up) * q.c2 + i_xfer;
       const double dT_i = -(p[g_bca] * q.halfRTF * rCai + di_pCa_dCai - 2.0 * di_NaCa_dCai) * q.c1 +
                           (-p[V_leak] - di_up_dCai) * q.c2 - p[V_xfer];
-      const double rbc = rcp(vCai + p[K_buf_c]);
-      const double gci = q.BKc * rbc * rbc;
-      const double Fr_i = rcp(1.0 + gci);
       io.store(Ca_i, grl1(fm, vCai, T_i * Fr_i, dT_i * Fr_i + T_i * (Fr_i * Fr_i * 2.0 * gci * rbc), dt));
     }
     BEAT_FENCE();
-    const double rCaSR = rcp(vCaSR);
-    const double zsr = (p[EC] * rCaSR) * (p[EC] * rCaSR);
-    const double rz = rcp(1.0 + zsr);
     const double kcasr = p[max_sr] - q.dsr * rz;
     const double dkcasr = -2.0 * q.dsr * zsr * rCaSR * rz * rz;
     const double rkc = rcp(kcasr);
@@ -490,18 +678,12 @@ struct Tp06Grl1 {
     {  // Ca_SR
       const double T_sr = i_up - (i_rel + i_leak);
       const double dT_sr = -(p[V_rel] * (dO_dk1 * dk1 * dsrss + O) + p[V_leak]);
-      const double rbsr = rcp(vCaSR + p[K_buf_sr]);
-      const double gsr = q.BKsr * rbsr * rbsr;
-      const double Fr_sr = rcp(1.0 + gsr);
       io.store(Ca_SR, grl1(fm, vCaSR, T_sr * Fr_sr, dT_sr * Fr_sr + T_sr * (Fr_sr * Fr_sr * 2.0 * gsr * rbsr), dt));
     }
     BEAT_FENCE();
     {  // Ca_ss
       const double T_ss = -i_CaL * q.c3 + i_rel * q.c4 - i_xfer * q.c5;
       const double dT_ss = -di_CaL_dCass * q.c3 + p[V_rel] * (dO_dCass * dsrss - O) * q.c4 - p[V_xfer] * q.c5;
-      const double rbss = rcp(vCass + p[K_buf_ss]);
-      const double gss = q.BKss * rbss * rbss;
-      const double Fr_ss = rcp(1.0 + gss);
       io.store(Ca_ss, grl1(fm, vCass, T_ss * Fr_ss, dT_ss * Fr_ss + T_ss * (Fr_ss * Fr_ss * 2.0 * gss * rbss), dt));
     }
   }
