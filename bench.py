@@ -172,8 +172,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=512, help="nodes per axis of the cubic slab")
     ap.add_argument("--rtol", type=float, default=1e-8)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="side of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=160, help="side of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--pc-degree", type=int, default=int(os.environ.get("BEAT_PC_DEGREE", "1")),
                     help="1 = Jacobi-PCG, m >= 2 = Chebyshev polynomial preconditioner with m terms")
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")

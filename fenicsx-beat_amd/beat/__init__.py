@@ -14,6 +14,7 @@ from . import (  # noqa: F401
     monodomain_model,
     monodomain_solver,
     odesolver,
+    single_cell,
     stimulation,
     telemetry,
     units,
@@ -29,6 +30,6 @@ __program_name__ = "fenicsx-beat-amd"
 
 __all__ = [
     "monodomain_model", "odesolver", "base_model", "MonodomainModel", "monodomain_solver",
-    "MonodomainSplittingSolver", "utils", "conductivities", "stimulation", "geometry", "grid", "models",
+    "MonodomainSplittingSolver", "utils", "single_cell", "conductivities", "stimulation", "geometry", "grid", "models",
     "Stimulus", "telemetry", "BaseMonitor", "NullMonitor", "PerformanceMonitor", "units",
 ]

@@ -57,6 +57,7 @@ SIGNATURES = {
     "beat_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "beat_ode_model_info": (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
     "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
+    "beat_ode_run": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _i64, _int, _int, _vp, _int, _vp]),
     "beat_copy": (_int, [_vp, _vp, _vp, _i64]),
     "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),
     "beat_gather": (_int, [_vp, _vp, _vp, _vp, _i64]),

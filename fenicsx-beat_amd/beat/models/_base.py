@@ -90,6 +90,48 @@ class DeviceModel:
         return out[:, 0].copy() if one_d else out
 
 
+    # ---- many steps in one launch ---------------------------------------------------------------------
+    def run(self, states, parameters, dt, nsteps, nbeats=1, t0=0.0, track_indices=None, save_freq=1):
+        """Advance ``states`` ((S,) or (S, N)) by nbeats x nsteps steps inside one kernel launch (t restarts at
+        t0 each beat, t = t0 + j*dt within it).  Returns (new_states, track) where track has shape
+        (rows, len(track_indices)[, N]) or is None."""
+        from .. import _hip
+        from .._device import Context, StateArray
+
+        ctx = Context.default()
+        arr = np.asarray(states, dtype=np.float64)
+        one_d = arr.ndim == 1
+        a2 = arr.reshape(arr.shape[0], -1)
+        S, n = a2.shape
+        if S != self.num_states:
+            raise ValueError(f"{self.name} has {self.num_states} states, got {S}")
+        sa = StateArray(ctx, S, n)
+        sa.set(a2)
+        hp, ppn, pld = host_and_device_parameters(ctx, parameters, self.num_parameters, n)
+        ntrack = 0 if track_indices is None else len(track_indices)
+        trace, tidx = None, None
+        rows = 0
+        if ntrack:
+            rows = int(nbeats) * int(-(-int(nsteps) // int(save_freq)))
+            trace = ctx.zeros(rows * ntrack * n)
+            tidx = (C.c_int * ntrack)(*[int(i) for i in track_indices])
+        _hip.check(
+            ctx.lib.beat_ode_run(ctx.handle, self.model_id, sa.ptr, n, sa.ld,
+                                 None if hp is None else hp.ctypes.data_as(C.c_void_p),
+                                 self.num_parameters if (hp is not None or ppn is not None) else 0,
+                                 None if ppn is None else C.c_void_p(ppn.data_ptr()), pld, float(t0), float(dt), int(nsteps),
+                                 int(nbeats), int(save_freq), tidx, ntrack,
+                                 None if trace is None else C.c_void_p(trace.data_ptr()))
+        )
+        out = sa.numpy()
+        tr = None
+        if ntrack:
+            tr = trace.cpu().numpy().reshape(rows, ntrack, n)
+            if one_d:
+                tr = tr[:, :, 0]
+        return (out[:, 0].copy() if one_d else out), tr
+
+
 def host_and_device_parameters(ctx, parameters, num_parameters, n):
     """Split ``parameters`` into (host (P,) array | None, device (P, N) tensor | None, ld)."""
     if parameters is None:

@@ -43,6 +43,112 @@ __global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_step_kernel(
   }
 }
 
+// Many steps inside one launch (single-cell pre-pacing, free-running ODE solves): the node's states stay
+// in registers; t restarts at 0 for every beat and advances as j*dt within it (numpy.arange semantics of
+// src/beat/single_cell.py:42-65).  Optionally records `ntrack` states every `save_freq` steps.
+struct TrackSpec {
+  int idx[8];
+  int n;
+};
+
+template <class Model, bool PER_NODE>
+__global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_run_kernel(
+    double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
+    const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
+    TrackSpec track, double* __restrict__ trace) {
+  __shared__ double etab[64];
+  __shared__ LogEntry ltab[128];
+  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
+  __syncthreads();
+  const FastMath fm{etab, ltab};
+  const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double y[Model::NS];
+#pragma unroll
+  for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];
+  double pl[PER_NODE ? Model::NP : 1];
+  typename Model::Derived dl = drv;
+  if (PER_NODE) {
+#pragma unroll
+    for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+    dl = Model::derive(pl);
+  }
+  const RegIO io{y};
+  int64_t row = 0;
+  for (int beat = 0; beat < nbeats; ++beat) {
+    for (int64_t j = 0; j < nsteps; ++j) {
+      if (track.n > 0 && j % save_freq == 0) {
+        for (int a = 0; a < track.n; ++a) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < Model::NS; ++k)
+            if (k == track.idx[a]) v = y[k];
+          trace[(row * track.n + a) * n + i] = v;
+        }
+        ++row;
+      }
+      const double t = t0 + (double)j * dt;
+      if (PER_NODE)
+        Model::step(io, pl, dl, fm, t, dt);
+      else
+        Model::step(io, prm.p, dl, fm, t, dt);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
+}
+
+template <class Model>
+static int launch_ode_run(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
+                          int num_params, const double* ppn, int64_t pld, double t0, double dt, int64_t nsteps,
+                          int nbeats, int save_freq, const int* track_idx, int ntrack, double* trace) {
+  BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
+               "model expects %d parameters, got %d", Model::NP, num_params);
+  BEAT_REQUIRE(ntrack >= 0 && ntrack <= 8, "at most 8 tracked states");
+  BEAT_REQUIRE(ntrack == 0 || (trace != nullptr && save_freq >= 1), "tracking needs a trace buffer and save_freq >= 1");
+  ParamPack<Model::NP> prm;
+  for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
+  typename Model::Derived drv = Model::derive(prm.p);
+  TrackSpec tr{};
+  tr.n = ntrack;
+  for (int a = 0; a < ntrack; ++a) {
+    BEAT_REQUIRE(track_idx[a] >= 0 && track_idx[a] < Model::NS, "tracked state %d out of range", track_idx[a]);
+    tr.idx[a] = track_idx[a];
+  }
+  const unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  if (ppn != nullptr) {
+    BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
+    hipLaunchKernelGGL((ode_run_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld, prm,
+                       drv, ppn, pld, t0, dt, nsteps, nbeats, save_freq, tr, trace);
+  } else {
+    hipLaunchKernelGGL((ode_run_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld,
+                       prm, drv, ppn, pld, t0, dt, nsteps, nbeats, save_freq, tr, trace);
+  }
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                            const double* host_params, int num_params, const double* dev_params_per_node,
+                            int64_t params_ld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
+                            const int* host_track_idx, int ntrack, double* dev_trace) {
+  BEAT_REQUIRE(ctx != nullptr && dev_states != nullptr, "null argument");
+  BEAT_REQUIRE(n >= 0 && ld >= n && nsteps >= 0 && nbeats >= 0, "bad shape");
+  if (n == 0 || nsteps == 0 || nbeats == 0) return BEAT_OK;
+#define BEAT_RUN(M)                                                                                          \
+  return launch_ode_run<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, \
+                           t0, dt, nsteps, nbeats, save_freq, host_track_idx, ntrack, dev_trace)
+  switch (model_id) {
+    case BEAT_MODEL_SIMPLE_ODE: BEAT_RUN(SimpleOde);
+    case BEAT_MODEL_FHN_DEMO: BEAT_RUN(FhnDemo);
+    case BEAT_MODEL_FHN_README: BEAT_RUN(FhnReadme);
+    case BEAT_MODEL_TP06_GRL1: BEAT_RUN(Tp06Grl1);
+    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+  }
+#undef BEAT_RUN
+}
+
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,

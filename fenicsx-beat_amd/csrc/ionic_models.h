@@ -227,6 +227,14 @@ struct NodeIO {
   }
 };
 
+// The same interface on a register-resident copy of the node's states (in-kernel time loops).  Every
+// model loads a state before it stores it and never reloads it afterwards, so one array suffices.
+struct RegIO {
+  double* y;
+  __device__ __forceinline__ double load(int k) const { return y[k]; }
+  __device__ __forceinline__ void store(int k, double v) const { y[k] = v; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // v' = -a s, s' = b v, forward Euler  (tests/test_odesolver.py:11-17)
 // ------------------------------------------------------------------------------------------------
@@ -234,7 +242,8 @@ struct SimpleOde {
   static constexpr int NS = 2, NP = 2;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
-  __device__ static __forceinline__ void step(const NodeIO& io, const double* p, const Derived&, const FastMath&,
+  template <class IO>
+  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived&, const FastMath&,
                                               double, double dt) {
     const double v = io.load(0), s = io.load(1);
     io.store(0, v - p[0] * s * dt);
@@ -250,7 +259,8 @@ struct FhnDemo {
   static constexpr int NS = 2, NP = 10;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
-  __device__ static __forceinline__ void step(const NodeIO& io, const double* p, const Derived&, const FastMath&,
+  template <class IO>
+  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived&, const FastMath&,
                                               double t, double dt) {
     const double s = io.load(0), V = io.load(1);
     const double V_peak = p[0], V_rest = p[1], a = p[2], b = p[3], c_1 = p[4], c_2 = p[5],
@@ -275,7 +285,8 @@ struct FhnReadme {
   static constexpr int NS = 2, NP = 11;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
-  __device__ static __forceinline__ void step(const NodeIO& io, const double* p, const Derived&, const FastMath&,
+  template <class IO>
+  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived&, const FastMath&,
                                               double t, double dt) {
     const double s = io.load(0), v = io.load(1);
     const double c_1 = p[0], c_2 = p[1], c_3 = p[2], a = p[3], b = p[4], v_amp = p[5],
@@ -408,7 +419,8 @@ struct Tp06Grl1 {
   // 3-4 resident waves per SIMD need.
 #define BEAT_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-  __device__ static __forceinline__ void step(const NodeIO& io, const double* p, const Derived& q, const FastMath& fm,
+  template <class IO>
+  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived& q, const FastMath& fm,
                                               double t, double dt) {
     const double v = io.load(V);
     // exp(c) constants, c written out in the comment

@@ -95,6 +95,15 @@ int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, in
                   const double* host_params, int num_params, const double* dev_params_per_node,
                   int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy);
 
+/* nbeats x nsteps updates in ONE launch with the node's states held in registers: replaces the Python
+ * loops of src/beat/single_cell.py:42-65 (solve_with_save / solve_without_save; t restarts at t0 for every
+ * beat and is t0 + j*dt within it) and of src/beat/odesolver.py:24-43.  Optionally records `ntrack` (<= 8)
+ * states every `save_freq` steps into dev_trace, shape (rows, ntrack, n), rows = nbeats*ceil(nsteps/save_freq). */
+int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                 const double* host_params, int num_params, const double* dev_params_per_node,
+                 int64_t params_ld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
+                 const int* host_track_idx, int ntrack, double* dev_trace);
+
 /* row/field transfers: v_ode.x.array[:] = values[v_index] etc. (odesolver.py:164-170,
  * utils.py:52-54, monodomain_model.py:59-60) */
 int beat_copy(beat_ctx* ctx, double* dev_dst, const double* dev_src, int64_t n);

@@ -152,3 +152,31 @@ def test_free_running_ode_solve_matches_reference_golden():
                          parameters=np.array([1.0, 1.0]))
     np.testing.assert_allclose(trace, gold["solve_trace"], rtol=1e-14, atol=1e-16)
     np.testing.assert_allclose(states, gold["solve_final_states"], rtol=1e-14)
+
+
+def test_single_cell_steady_state_device_loop(tmp_path):
+    """beat.single_cell.get_steady_state (src/beat/single_cell.py:86-156): the in-kernel nbeats x arange(0, BCL, dt)
+    loop gives what stepping the oracle one call at a time gives, and the tracked trace has the reference's
+    shape (ceil(len(times)/save_freq)*nbeats, len(track_indices))."""
+    import beat
+    from beat.models import tp06
+    from oracle import ionic
+
+    P = tp06.init_parameter_values(stim_start=1.0)
+    y0 = tp06.init_state_values()
+    dt, BCL, nbeats = 0.05, 40, 2
+    y = beat.single_cell.get_steady_state(tp06.generalized_rush_larsen, y0, P, tmp_path, nbeats=nbeats, BCL=BCL, dt=dt,
+                                          track_indices=[tp06.state_index("V"), tp06.state_index("Ca_i")])
+    ref = y0[:, None].copy()
+    times = np.arange(0.0, BCL, dt)
+    for _ in range(nbeats):
+        for t in times:
+            ref = ionic.tp06_generalized_rush_larsen(ref, t, dt, P)
+    assert np.abs(y - ref[:, 0]).max() / np.abs(ref).max() < 1e-7 and ref[17, 0] > -60.0  # mid action potential
+    tracked = np.load(next(tmp_path.glob("tracked_values_*.npy")))
+    assert tracked.shape == (int(np.ceil(len(times) / 20) * nbeats), 2)
+    assert tracked[0, 0] == y0[17] and tracked[:, 0].max() > 0.0
+    # cached on the second call
+    y2 = beat.single_cell.get_steady_state(tp06.generalized_rush_larsen, y0, P, tmp_path, nbeats=nbeats, BCL=BCL, dt=dt,
+                                           track_indices=[17, 13])
+    np.testing.assert_array_equal(y, y2)
