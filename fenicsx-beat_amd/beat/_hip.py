@@ -18,6 +18,7 @@ MODEL_SIMPLE_ODE = 0
 MODEL_FHN_DEMO = 1
 MODEL_FHN_README = 2
 MODEL_TP06_GRL1 = 3
+MODEL_TORORD_DYNCL_GRL1 = 4
 MAX_STIM = 8
 
 # slots of the PCG scalar state (see include/beat_hip.h)

@@ -5,6 +5,7 @@
 // when the transmembrane potential is mirrored into the PDE vector (dev_v_copy).
 #include "beat_common.h"
 #include "ionic_models.h"
+#include "generated/torord_dyncl.h"
 
 template <int NP>
 struct ParamPack {
@@ -144,6 +145,7 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
     case BEAT_MODEL_FHN_DEMO: BEAT_RUN(FhnDemo);
     case BEAT_MODEL_FHN_README: BEAT_RUN(FhnReadme);
     case BEAT_MODEL_TP06_GRL1: BEAT_RUN(Tp06Grl1);
+    case BEAT_MODEL_TORORD_DYNCL_GRL1: BEAT_RUN(TorordDynClGrl1);
     default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
 #undef BEAT_RUN
@@ -180,6 +182,7 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
     case BEAT_MODEL_FHN_DEMO: ns = FhnDemo::NS; np = FhnDemo::NP; break;
     case BEAT_MODEL_FHN_README: ns = FhnReadme::NS; np = FhnReadme::NP; break;
     case BEAT_MODEL_TP06_GRL1: ns = Tp06Grl1::NS; np = Tp06Grl1::NP; break;
+    case BEAT_MODEL_TORORD_DYNCL_GRL1: ns = TorordDynClGrl1::NS; np = TorordDynClGrl1::NP; break;
     default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
   if (num_states) *num_states = ns;
@@ -209,6 +212,9 @@ extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, in
     case BEAT_MODEL_TP06_GRL1:
       return launch_ode<Tp06Grl1>(ctx, dev_states, n, ld, host_params, num_params,
                                   dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
+    case BEAT_MODEL_TORORD_DYNCL_GRL1:
+      return launch_ode<TorordDynClGrl1>(ctx, dev_states, n, ld, host_params, num_params,
+                                         dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
     default:
       beat_set_error("unknown model id %d", model_id);
       return BEAT_EINVAL;

@@ -46,6 +46,8 @@ extern "C" {
 #define BEAT_MODEL_FHN_README 2 /* README.md:58-89 (11 params, states [s,v]) */
 #define BEAT_MODEL_TP06_GRL1 3  /* odes/tentusscher_panfilov_2006 (.ode) + gotranx GRL1 (demos/niederer_benchmark.py:82-99) */
 
+#define BEAT_MODEL_TORORD_DYNCL_GRL1 4 /* odes/torord/ToRORd_dynCl_endo.ode + gotranx GRL1 (demos/biv_endocardial.py:124); 45 states, 112 parameters */
+
 #define BEAT_STENCIL_POINTS 15
 #define BEAT_NODE_TYPES 27
 #define BEAT_MAX_STIM 8

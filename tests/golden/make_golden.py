@@ -3,7 +3,7 @@
 
 Two sources, both the reference itself:
 
-1. ``tp06_spec.npz`` -- the reference's TP06 ``.ode`` specification
+1. ``tp06_spec.npz`` / ``torord_spec.npz`` -- the reference's TP06 / ToR-ORd-dynCl ``.ode`` specifications
    (odes/tentusscher_panfilov_2006/tentusscher_panfilov_2006_epi_cell.ode) evaluated by the
    independent evaluator in ``ode_spec.py``: right-hand sides, total self-derivatives and one
    GRL1 step at seeded random states.
@@ -72,6 +72,35 @@ def make_tp06_spec():
         grl1_explicit=np.array([new_explicit[k] for k in names]),
     )
     print("tp06_spec.npz:", n, "points,", len(names), "states")
+
+
+def make_torord_spec():
+    """ToR-ORd-dynCl (odes/torord/ToRORd_dynCl_endo.ode): RHS, total self-derivatives and one GRL1 step at
+    seeded states around the file's initial state, for the three cell types."""
+    from ode_spec import OdeSpec
+
+    spec = OdeSpec(REF / "odes/torord/ToRORd_dynCl_endo.ode")
+    rng = np.random.default_rng(20261004)
+    n = 48
+    names = spec.state_names
+    st = {k: spec.states[k] * (1.0 + 0.05 * rng.uniform(-1, 1, n)) for k in names}
+    st["v"] = rng.uniform(-90.0, 40.0, n)
+    for k in names:
+        st[k][0] = spec.states[k]
+    t, dt = 0.3, 0.05
+    out = dict(state_names=np.array(names), parameter_names=np.array(spec.parameter_names),
+               state_defaults=np.array([spec.states[k] for k in names]),
+               parameter_defaults=np.array([spec.parameters[k] for k in spec.parameter_names]),
+               states=np.array([st[k] for k in names]), t=t, dt=dt)
+    for celltype in (0, 1, 2):
+        par = dict(spec.parameters)
+        par["celltype"] = float(celltype)
+        rhs, J, new = spec.grl1(st, par, t, dt, total=True)
+        out[f"rhs_celltype{celltype}"] = np.array([rhs[k] for k in names])
+        out[f"jac_celltype{celltype}"] = np.array([J[k] for k in names])
+        out[f"grl1_celltype{celltype}"] = np.array([new[k] for k in names])
+    np.savez_compressed(HERE / "torord_spec.npz", **out)
+    print("torord_spec.npz:", n, "points,", len(names), "states, 3 cell types")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -274,4 +303,5 @@ if __name__ == "__main__":
     if not REF.is_dir():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
     make_tp06_spec()
+    make_torord_spec()
     make_splitting_reference()

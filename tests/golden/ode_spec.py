@@ -53,6 +53,30 @@ class OdeSpec:
                 self.assignments.append((name, node))
         self.state_names = list(self.states)
         self.parameter_names = list(self.parameters)
+        self.assignments = self._dependency_order(self.assignments)
+
+    @staticmethod
+    def _dependency_order(assignments):
+        """gotran files may use an intermediate before the line that defines it: order by dependencies
+        (stable: a line keeps its place unless it has to wait for a later definition)."""
+        defined_here = {name for name, _ in assignments}
+        deps = {name: {n.id for n in ast.walk(node) if isinstance(n, ast.Name)} & defined_here - {name}
+                for name, node in assignments}
+        out, done, pending = [], set(), list(assignments)
+        while pending:
+            progressed = False
+            rest = []
+            for name, node in pending:
+                if deps[name] <= done:
+                    out.append((name, node))
+                    done.add(name)
+                    progressed = True
+                else:
+                    rest.append((name, node))
+            if not progressed:
+                raise ValueError(f"cyclic definitions: {[n for n, _ in rest]}")
+            pending = rest
+        return out
 
     # ---------------------------------------------------------------- numeric
     def evaluate(self, states: dict, parameters: dict, t: float) -> dict:

@@ -180,3 +180,38 @@ def test_single_cell_steady_state_device_loop(tmp_path):
     y2 = beat.single_cell.get_steady_state(tp06.generalized_rush_larsen, y0, P, tmp_path, nbeats=nbeats, BCL=BCL, dt=dt,
                                            track_indices=[17, 13])
     np.testing.assert_array_equal(y, y2)
+
+
+@pytest.mark.parametrize("celltype", [0, 1, 2])
+def test_torord_kernel_matches_the_ode_spec_golden(celltype):
+    """ToR-ORd-dynCl (45 states): one GRL1 step of the generated HIP kernel vs the reference's .ode
+    specification evaluated independently (NumPy RHS, SymPy total self-derivatives of the fully resolved
+    expressions), endo / epi / mid: 1e-10 relative to the state scale."""
+    from beat.models import torord
+
+    g = np.load(GOLD / "torord_spec.npz")
+    assert tuple(g["state_names"]) == torord.generalized_rush_larsen.state_names
+    assert tuple(g["parameter_names"]) == torord.generalized_rush_larsen.parameter_names
+    np.testing.assert_array_equal(g["state_defaults"], torord.init_state_values())
+    np.testing.assert_array_equal(g["parameter_defaults"], torord.init_parameter_values())
+    P = torord.init_parameter_values(celltype=float(celltype))
+    out = torord.generalized_rush_larsen(states=g["states"], t=float(g["t"]), parameters=P, dt=float(g["dt"]))
+    ref = g[f"grl1_celltype{celltype}"]
+    assert np.isfinite(out).all()
+    scale = np.maximum(np.abs(ref), 1e-6 * np.abs(g["state_defaults"])[:, None] + 1e-12)
+    err = np.abs(out - ref) / scale
+    assert err.max() < 1e-10, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_torord_action_potential():
+    """Pacing one ToR-ORd cell for one beat with the in-kernel loop: physiological upstroke and repolarisation."""
+    from beat.models import torord
+
+    y0 = torord.init_state_values()
+    P = torord.init_parameter_values()
+    vi = torord.state_index("v")
+    y, tr = torord.generalized_rush_larsen.run(y0, P, dt=0.02, nsteps=25000, nbeats=1, track_indices=[vi], save_freq=50)
+    v = tr[:, 0]
+    assert np.isfinite(y).all() and 20.0 < v.max() < 60.0 and v[-1] < -80.0
+    apd90 = (np.nonzero(v > v.min() + 0.1 * (v.max() - v.min()))[0][-1] - np.nonzero(v > 0)[0][0]) * 1.0
+    assert 200.0 < apd90 < 400.0, apd90

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Cell-model kernel generator (development tool, run in the build container).
+
+Reads a gotran ``.ode`` model specification (the reference keeps them under odes/), and emits
+
+  * a C++ header with a model struct for csrc/beat_ode.hip: one generalized-Rush-Larsen (GRL1) step per
+    node with the total self-derivatives d f_i / d y_i obtained by forward-mode differentiation through
+    the model's own intermediate expressions (chain rule per state; no expression is expanded), and
+  * a Python data module with the state / parameter names and defaults.
+
+usage: gen_cell_model.py <model.ode> <StructName> <out_header> <out_py>
+
+The generated files are ordinary source (committed); the tool only has to be re-run when a model is added.
+"""
+
+from __future__ import annotations
+
+import ast
+import sys
+from pathlib import Path
+
+import sympy
+from sympy.printing.c import C99CodePrinter
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests" / "golden"))
+from ode_spec import OdeSpec  # noqa: E402  (ast walker + dependency ordering of the assignments)
+
+
+class Printer(C99CodePrinter):
+    def _print_Float(self, e):
+        return repr(float(e))
+
+    def _print_Integer(self, e):
+        return f"{int(e)}.0"
+
+    def _print_Rational(self, e):
+        return f"({int(e.p)}.0 / {int(e.q)}.0)"
+
+    def _print_Pow(self, e):
+        b, x = e.base, e.exp
+        if x.is_Float and float(x) == int(float(x)):
+            x = sympy.Integer(int(float(x)))
+        if x.is_Float and float(2 * x) == int(float(2 * x)):
+            x = sympy.Rational(int(float(2 * x)), 2)
+        if x.is_Rational and not x.is_Integer and x.q == 2 and abs(x.p) in (3, 5):
+            bs = self.parenthesize(b, 1000)
+            body = f"({bs} * sqrt({self._print(b)}))" if abs(x.p) == 3 else f"({bs} * {bs} * sqrt({self._print(b)}))"
+            return body if x.p > 0 else f"(1.0 / {body})"
+        if x.is_Integer:
+            n = int(x)
+            bs = self.parenthesize(b, 1000)
+            if n == -1:
+                return f"(1.0 / {bs})"
+            if 1 < abs(n) <= 4:
+                prod = " * ".join([bs] * abs(n))
+                return f"({prod})" if n > 0 else f"(1.0 / ({prod}))"
+        if x == sympy.Rational(1, 2):
+            return f"sqrt({self._print(b)})"
+        if x == -sympy.Rational(1, 2):
+            return f"(1.0 / sqrt({self._print(b)}))"
+        return f"pow({self._print(b)}, {self._print(x)})"
+
+    def _print_exp(self, e):
+        return f"fm.exp({self._print(e.args[0])})"
+
+    def _print_log(self, e):
+        return f"fm.log({self._print(e.args[0])})"
+
+    def _print_Abs(self, e):
+        return f"fabs({self._print(e.args[0])})"
+
+    def _print_floor(self, e):
+        return f"floor({self._print(e.args[0])})"
+
+    def _print_Piecewise(self, e):
+        out = None
+        for val, cond in reversed(e.args):
+            v = self._print(val)
+            out = v if out is None and cond == True else f"(({self._print(cond)}) ? {v} : {out if out is not None else '0.0'})"  # noqa: E712
+        return out
+
+    def _print_Relational(self, e):
+        op = {"==": "==", "!=": "!=", "<": "<", "<=": "<=", ">": ">", ">=": ">="}[e.rel_op]
+        return f"{self._print(e.lhs)} {op} {self._print(e.rhs)}"
+
+    def _print_And(self, e):
+        return " && ".join(f"({self._print(a)})" for a in e.args)
+
+    def _print_Or(self, e):
+        return " || ".join(f"({self._print(a)})" for a in e.args)
+
+    def _print_Symbol(self, e):
+        return SYMBOL_NAMES.get(e.name, e.name)
+
+
+SYMBOL_NAMES: dict[str, str] = {}
+
+
+def build(spec: OdeSpec):
+    states, params = spec.state_names, spec.parameter_names
+    sym = {n: sympy.Symbol(n, real=True) for n in states + params}
+    ns = {
+        "exp": sympy.exp, "log": sympy.log, "sqrt": sympy.sqrt, "floor": sympy.floor, "abs": sympy.Abs,
+        "Conditional": lambda c, a, b: sympy.Piecewise((a, c), (b, True)),
+        "Lt": sympy.Lt, "Le": sympy.Le, "Gt": sympy.Gt, "Ge": sympy.Ge, "Eq": sympy.Eq, "And": sympy.And,
+        "Or": sympy.Or, "time": sympy.Symbol("t", real=True), "pi": sympy.pi,
+    }
+    ns.update(sym)
+    exprs: dict[str, sympy.Expr] = {}
+    order: list[str] = []
+    for name, node in spec.assignments:
+        e = sympy.sympify(eval(compile(ast.Expression(node), "<ode>", "eval"), {"__builtins__": {}}, ns))
+        exprs[name] = e
+        order.append(name)
+        ns[name] = sympy.Symbol(name, real=True)
+    # transitive state dependencies of every intermediate
+    dep: dict[str, set[str]] = {}
+    for name in order:
+        d = set()
+        for s in exprs[name].free_symbols:
+            if s.name in states:
+                d.add(s.name)
+            elif s.name in dep:
+                d |= dep[s.name]
+        dep[name] = d
+    return exprs, order, dep
+
+
+def derivative_statements(exprs, order, dep, states):
+    """Forward-mode chain rule: for each state y, statements d<u>_d<y> for the intermediates u between y and
+    d<y>_dt, ending with J_<y>."""
+    stmts: list[tuple[str, sympy.Expr]] = []
+    jac: dict[str, sympy.Expr | None] = {}
+    for y in states:
+        target = f"d{y}_dt"
+        ysym = sympy.Symbol(y, real=True)
+        # intermediates the target depends on (transitively)
+        needed, stack = set(), [target]
+        while stack:
+            u = stack.pop()
+            if u in needed:
+                continue
+            needed.add(u)
+            stack += [s.name for s in exprs[u].free_symbols if s.name in exprs]
+        dsym: dict[str, sympy.Expr] = {}
+        for u in order:
+            if u not in needed or y not in dep[u]:
+                continue
+            e = exprs[u]
+            total = sympy.diff(e, ysym)
+            for w in e.free_symbols:
+                if w.name in dsym:
+                    total += sympy.diff(e, w) * dsym[w.name]
+            if u == target:
+                jac[y] = total
+            else:
+                name = f"d{u}_d{y}"
+                if total == 0:
+                    continue
+                stmts.append((name, total))
+                dsym[u] = sympy.Symbol(name, real=True)
+        jac.setdefault(y, None)
+        if jac[y] is not None and jac[y] == 0:
+            jac[y] = None
+    return stmts, jac
+
+
+def needed_intermediates(exprs, order, roots):
+    need, stack = set(), list(roots)
+    while stack:
+        u = stack.pop()
+        if u in need or u not in exprs:
+            continue
+        need.add(u)
+        stack += [s.name for s in exprs[u].free_symbols if s.name in exprs]
+    return [u for u in order if u in need]
+
+
+def main():
+    ode, struct, out_h, out_py = sys.argv[1:5]
+    spec = OdeSpec(ode)
+    states, params = spec.state_names, spec.parameter_names
+    exprs, order, dep = build(spec)
+    dstmts, jac = derivative_statements(exprs, order, dep, states)
+    dnames = {n for n, _ in dstmts}
+    roots = [f"d{y}_dt" for y in states]
+    for _, e in dstmts:
+        roots += [s.name for s in e.free_symbols if s.name in exprs]
+    for y, j in jac.items():
+        if j is not None:
+            roots += [s.name for s in j.free_symbols if s.name in exprs]
+    live = needed_intermediates(exprs, order, roots)
+
+    for i, p in enumerate(params):
+        SYMBOL_NAMES[p] = f"p[{i}]"
+    pr = Printer()
+    lines = []
+    w = lines.append
+    w(f"// GENERATED by tools/gen_cell_model.py from the model specification {Path(ode).name} -- do not edit.")
+    w("// One generalized Rush-Larsen step per node; J_i = total d f_i / d y_i by forward-mode differentiation")
+    w("// through the model's intermediate expressions (see oracle/ionic.py for the scheme and its pin).")
+    w("#pragma once")
+    w('#include "../ionic_models.h"')
+    w("")
+    w(f"struct {struct} {{")
+    w(f"  static constexpr int NS = {len(states)}, NP = {len(params)};")
+    w("  struct Derived {};")
+    w("  __host__ __device__ static Derived derive(const double*) { return {}; }")
+    w("  template <class IO>")
+    w("  __device__ static void step(const IO& io, const double* p, const Derived&, const FastMath& fm, double t,")
+    w("                              double dt) {")
+    for i, s in enumerate(states):
+        w(f"    const double {s} = io.load({i});")
+    # interleave: intermediates in order; derivative statements placed after all (they reference intermediates)
+    for u in live:
+        if u.startswith("d") and u.endswith("_dt") and u[1:-3] in states:
+            continue
+        w(f"    const double {u} = {pr.doprint(exprs[u])};")
+    for y in states:
+        w(f"    const double d{y}_dt = {pr.doprint(exprs[f'd{y}_dt'])};")
+    for name, e in dstmts:
+        w(f"    const double {name} = {pr.doprint(e)};")
+    for i, y in enumerate(states):
+        if jac[y] is None:
+            w(f"    io.store({i}, {y} + dt * d{y}_dt);")
+        else:
+            w(f"    {{ const double J = {pr.doprint(jac[y])};")
+            w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? d{y}_dt * (fm.exp(J * dt) - 1.0) / J : d{y}_dt * dt)); }}")
+    w("  }")
+    w("};")
+    Path(out_h).parent.mkdir(parents=True, exist_ok=True)
+    Path(out_h).write_text("\n".join(lines) + "\n")
+
+    py = [f'"""GENERATED by tools/gen_cell_model.py from {Path(ode).name}: state / parameter names and defaults',
+          '(order of appearance in the model specification)."""', "", "STATES = {"]
+    py += [f"    {s!r}: {spec.states[s]!r}," for s in states] + ["}", "", "PARAMETERS = {"]
+    py += [f"    {p!r}: {spec.parameters[p]!r}," for p in params] + ["}", ""]
+    Path(out_py).write_text("\n".join(py))
+    nz = sum(1 for y in states if jac[y] is not None)
+    print(f"{struct}: {len(states)} states ({nz} Rush-Larsen, {len(states) - nz} forward Euler), {len(params)} parameters, "
+          f"{len(live)} intermediates, {len(dstmts)} derivative statements ({len(dnames)} names)")
+
+
+if __name__ == "__main__":
+    main()
