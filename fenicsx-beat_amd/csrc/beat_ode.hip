@@ -75,7 +75,12 @@ __global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_run_kernel(
     for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
     dl = Model::derive(pl);
   }
-  const RegIO io{y};
+  // Hand-written models keep the states in registers across steps (RegIO).  The generated ToR-ORd step
+  // (heavy register spilling) produced wrong values through RegIO with ROCm 7.2 while the identical step
+  // is correct through global memory, so generated models round-trip their states through HBM/L2 each
+  // step (tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards both variants).
+  const RegIO rio{y};
+  const NodeIO gio{states, ld, i, nullptr, 0};
   int64_t row = 0;
   for (int beat = 0; beat < nbeats; ++beat) {
     for (int64_t j = 0; j < nsteps; ++j) {
@@ -90,14 +95,25 @@ __global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_run_kernel(
         ++row;
       }
       const double t = t0 + (double)j * dt;
-      if (PER_NODE)
-        Model::step(io, pl, dl, fm, t, dt);
-      else
-        Model::step(io, prm.p, dl, fm, t, dt);
+      if (Model::REGISTER_LOOP) {
+        if (PER_NODE)
+          Model::step(rio, pl, dl, fm, t, dt);
+        else
+          Model::step(rio, prm.p, dl, fm, t, dt);
+      } else {
+        if (PER_NODE)
+          Model::step(gio, pl, dl, fm, t, dt);
+        else
+          Model::step(gio, prm.p, dl, fm, t, dt);
+#pragma unroll
+        for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];  // for the tracking above
+      }
     }
   }
+  if (Model::REGISTER_LOOP) {
 #pragma unroll
-  for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
+    for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
+  }
 }
 
 template <class Model>

@@ -240,6 +240,7 @@ struct RegIO {
 // ------------------------------------------------------------------------------------------------
 struct SimpleOde {
   static constexpr int NS = 2, NP = 2;
+  static constexpr bool REGISTER_LOOP = true;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -257,6 +258,7 @@ struct SimpleOde {
 // ------------------------------------------------------------------------------------------------
 struct FhnDemo {
   static constexpr int NS = 2, NP = 10;
+  static constexpr bool REGISTER_LOOP = true;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -283,6 +285,7 @@ struct FhnDemo {
 // ------------------------------------------------------------------------------------------------
 struct FhnReadme {
   static constexpr int NS = 2, NP = 11;
+  static constexpr bool REGISTER_LOOP = true;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -325,6 +328,7 @@ struct FhnReadme {
 // ------------------------------------------------------------------------------------------------
 struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53;
+  static constexpr bool REGISTER_LOOP = true;
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
     P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,

@@ -99,8 +99,48 @@ def make_torord_spec():
         out[f"rhs_celltype{celltype}"] = np.array([rhs[k] for k in names])
         out[f"jac_celltype{celltype}"] = np.array([J[k] for k in names])
         out[f"grl1_celltype{celltype}"] = np.array([new[k] for k in names])
+    # states along one paced action potential (endo, dt = 0.02 ms): covers the upstroke, plateau and
+    # repolarisation regimes that the perturbed resting states above do not reach
+    import sympy
+
+    lin = spec.linearized(total=True)
+    fns = {}
+    for s in names:
+        syms = sorted(lin[s].free_symbols, key=lambda x: x.name)
+        fns[s] = (syms, sympy.lambdify(syms, lin[s], "numpy", cse=True))
+    par = dict(spec.parameters)
+    cur = {k: np.array([v]) for k, v in spec.states.items()}
+    hdt, tt = 0.02, 0.0
+    keep_at = sorted(set(list(range(0, 150, 5)) + list(range(150, 15000, 500))))
+    traj, traj_t = [], []
+    for i in range(15000):
+        if i in keep_at:
+            traj.append(np.array([cur[k][0] for k in names]))
+            traj_t.append(tt)
+        vals = spec.evaluate(cur, par, tt)
+        env = dict(par)
+        env.update(cur)
+        env["time"] = tt
+        new = {}
+        for s in names:
+            f = np.asarray(vals[f"d{s}_dt"], dtype=float)
+            syms, fn = fns[s]
+            Jv = np.asarray(fn(*[env[x.name] for x in syms]), dtype=float)
+            with np.errstate(all="ignore"):
+                new[s] = cur[s] + np.where(np.abs(Jv) > 1e-8, f * (np.exp(Jv * hdt) - 1) / Jv, f * hdt)
+        cur, tt = new, tt + hdt
+    traj = np.array(traj).T  # (45, npts)
+    out["traj_states"] = traj
+    out["traj_times"] = np.array(traj_t)
+    out["traj_dt"] = hdt
+    # one GRL1 step from every trajectory state, all evaluated at the SAME time t (stimulus off)
+    stt = {k: traj[i] for i, k in enumerate(names)}
+    _, _, new = spec.grl1(stt, par, 5.0, hdt, total=True)
+    out["traj_grl1"] = np.array([new[k] for k in names])
+    out["traj_step_t"] = 5.0
     np.savez_compressed(HERE / "torord_spec.npz", **out)
-    print("torord_spec.npz:", n, "points,", len(names), "states, 3 cell types")
+    print("torord_spec.npz:", n, "points,", len(names), "states, 3 cell types;", traj.shape[1], "trajectory states, V range",
+          traj[names.index("v")].min(), traj[names.index("v")].max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -302,6 +342,10 @@ def make_splitting_reference():
 if __name__ == "__main__":
     if not REF.is_dir():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
-    make_tp06_spec()
-    make_torord_spec()
-    make_splitting_reference()
+    which = sys.argv[1:] or ["tp06", "torord", "splitting"]
+    if "tp06" in which:
+        make_tp06_spec()
+    if "torord" in which:
+        make_torord_spec()
+    if "splitting" in which:
+        make_splitting_reference()

@@ -216,3 +216,39 @@ def test_torord_action_potential():
     assert np.isfinite(y).all() and 5.0 < v.max() < 60.0 and v[-1] < -80.0
     apd90 = (np.nonzero(v > v.min() + 0.1 * (v.max() - v.min()))[0][-1] - np.nonzero(v > 0)[0][0]) * 1.0
     assert 200.0 < apd90 < 400.0, apd90
+
+
+def test_torord_kernel_along_an_action_potential():
+    """One GRL1 step from 60 states sampled along a paced action potential of the reference specification
+    (upstroke, plateau, repolarisation): 1e-9 relative to the state scale."""
+    from beat.models import torord
+
+    g = np.load(GOLD / "torord_spec.npz")
+    P = torord.init_parameter_values()
+    out = torord.generalized_rush_larsen(states=g["traj_states"], t=float(g["traj_step_t"]), parameters=P,
+                                         dt=float(g["traj_dt"]))
+    ref = g["traj_grl1"]
+    scale = np.maximum(np.abs(ref), 1e-6 * np.abs(g["state_defaults"])[:, None] + 1e-12)
+    err = np.abs(out - ref) / scale
+    bad = np.argwhere(err > 1e-9)
+    assert len(bad) == 0, [(g["state_names"][i], float(g["traj_times"][j]), float(err[i, j])) for i, j in bad[:12]]
+
+
+@pytest.mark.parametrize("model", ["tp06", "torord", "fhn"])
+def test_run_kernel_equals_repeated_steps(model):
+    """beat_ode_run (in-kernel time loop) gives bit-for-bit what repeated beat_ode_step launches give."""
+    from beat.models import fhn, torord, tp06
+
+    m = {"tp06": tp06.generalized_rush_larsen, "torord": torord.generalized_rush_larsen,
+         "fhn": fhn.forward_euler_readme}[model]
+    rng = np.random.default_rng(4)
+    y0 = np.repeat(m.init_state_values()[:, None], 70, axis=1)
+    y0[m.state_index(m.v_name)] += rng.uniform(0, 20, 70)
+    P = m.init_parameter_values()
+    ys = y0.copy()
+    for j in range(25):
+        ys = m(states=ys, t=j * 0.02, parameters=P, dt=0.02)
+    yr, tr = m.run(y0, P, dt=0.02, nsteps=25, track_indices=[m.state_index(m.v_name)], save_freq=5)
+    np.testing.assert_array_equal(yr, ys)
+    assert tr.shape == (5, 1, 70)
+    np.testing.assert_array_equal(tr[0, 0], y0[m.state_index(m.v_name)])

@@ -204,10 +204,11 @@ def main():
     w("")
     w(f"struct {struct} {{")
     w(f"  static constexpr int NS = {len(states)}, NP = {len(params)};")
+    w("  static constexpr bool REGISTER_LOOP = false;  // see ode_run_kernel")
     w("  struct Derived {};")
     w("  __host__ __device__ static Derived derive(const double*) { return {}; }")
     w("  template <class IO>")
-    w("  __device__ static void step(const IO& io, const double* p, const Derived&, const FastMath& fm, double t,")
+    w("  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived&, const FastMath& fm, double t,")
     w("                              double dt) {")
     for i, s in enumerate(states):
         w(f"    const double {s} = io.load({i});")
