@@ -212,21 +212,47 @@ def main():
     w("                              double dt) {")
     for i, s in enumerate(states):
         w(f"    const double {s} = io.load({i});")
-    # interleave: intermediates in order; derivative statements placed after all (they reference intermediates)
-    for u in live:
-        if u.startswith("d") and u.endswith("_dt") and u[1:-3] in states:
-            continue
-        w(f"    const double {u} = {pr.doprint(exprs[u])};")
+    # Emission order: states sorted by how many intermediates their update needs (the V-only gates first, the
+    # membrane potential and the ion concentrations last); before each state's block only the intermediates
+    # not emitted yet are computed, so few values are live at any point.  Each block ends with the store and
+    # a scheduling fence.
+    def closure(names):
+        need, stack = set(), list(names)
+        while stack:
+            u = stack.pop()
+            if u in need or u not in exprs:
+                continue
+            need.add(u)
+            stack += [sy.name for sy in exprs[u].free_symbols if sy.name in exprs]
+        return need
+
+    per_state = {}
     for y in states:
-        w(f"    const double d{y}_dt = {pr.doprint(exprs[f'd{y}_dt'])};")
-    for name, e in dstmts:
-        w(f"    const double {name} = {pr.doprint(e)};")
-    for i, y in enumerate(states):
+        roots_y = [f"d{y}_dt"]
+        for name, e in dstmts:
+            if name.endswith(f"_d{y}"):
+                roots_y += [sy.name for sy in e.free_symbols if sy.name in exprs]
+        if jac[y] is not None:
+            roots_y += [sy.name for sy in jac[y].free_symbols if sy.name in exprs]
+        per_state[y] = closure(roots_y)
+    emitted = set()
+    for y in sorted(states, key=lambda q: len(per_state[q])):
+        i = states.index(y)
+        for u in order:
+            if u in per_state[y] and u not in emitted:
+                w(f"    const double {u} = {pr.doprint(exprs[u])};")
+                emitted.add(u)
+        w("    {")
+        for name, e in dstmts:
+            if name.endswith(f"_d{y}"):
+                w(f"      const double {name} = {pr.doprint(e)};")
         if jac[y] is None:
-            w(f"    io.store({i}, {y} + dt * d{y}_dt);")
+            w(f"      io.store({i}, {y} + dt * d{y}_dt);")
         else:
-            w(f"    {{ const double J = {pr.doprint(jac[y])};")
-            w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? d{y}_dt * (fm.exp(J * dt) - 1.0) / J : d{y}_dt * dt)); }}")
+            w(f"      const double J = {pr.doprint(jac[y])};")
+            w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? d{y}_dt * (fm.exp(J * dt) - 1.0) / J : d{y}_dt * dt));")
+        w("    }")
+        w("    __builtin_amdgcn_sched_barrier(0);")
     w("  }")
     w("};")
     Path(out_h).parent.mkdir(parents=True, exist_ok=True)
