@@ -134,10 +134,14 @@ class HipOps:
         fld = self.n + 2 * self.plane
         from ._device import Field
 
+        # same layout as beat_pde_solve: r, q, z, ring[...]; p is ring[0] for the in-place recurrences
+        self.fld = fld
         self.r = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane)
-        self.p = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + fld)
-        self.q = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + 2 * fld)
-        self.z = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + 3 * fld)
+        self.q = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + fld)
+        self.z = Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + 2 * fld)
+        self.ring = [Field(ctx, self.n, self.plane, buf=self.work, offset=self.plane + (3 + j) * fld)
+                     for j in range(nfields - 3)]
+        self.p = self.ring[0]
         self.st = ctx.zeros(_hip.ST_SIZE)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
@@ -216,13 +220,27 @@ class HipOps:
     def spmv_dot(self):
         _hip.check(self.lib.beat_pde_spmv_dot(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr())))
 
-    def spmv_interior(self):
+    def spmv_interior(self, p=None):
         """q = A p on the planes that need no ghost data (runs while the halo exchange is in flight)."""
-        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 0))
+        p = p or self.p
+        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 0))
 
-    def spmv_boundary(self):
+    def spmv_boundary(self, p=None):
         """q = A p on the slab-boundary planes, then the local p.q."""
-        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, self.p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 1))
+        p = p or self.p
+        _hip.check(self.lib.beat_pde_spmv_dot_part(self.handle, p.ptr, self.q.ptr, C.c_void_p(self.st.data_ptr()), 1))
+
+    # deferred-x stages (see include/beat_hip.h)
+    def cg_update_r(self, slot):
+        _hip.check(self.lib.beat_pde_cg_update_r(self.handle, C.c_void_p(self.st.data_ptr()), self.r.ptr, self.q.ptr, slot))
+
+    def cg_next_oop(self, p_cur, p_next):
+        _hip.check(self.lib.beat_pde_cg_next_oop(self.handle, C.c_void_p(self.st.data_ptr()), self.r.ptr, p_cur.ptr,
+                                                 p_next.ptr))
+
+    def x_flush(self, x, ring_base, only_if_full):
+        _hip.check(self.lib.beat_pde_x_flush(self.handle, C.c_void_p(self.st.data_ptr()), x.ptr, self.ring[0].ptr,
+                                             self.fld, int(ring_base), int(only_if_full)))
 
     def cg_update(self, x):
         _hip.check(self.lib.beat_pde_cg_update(self.handle, C.c_void_p(self.st.data_ptr()), x.ptr, self.r.ptr,
@@ -314,27 +332,38 @@ class DiffusionSolver:
             ops.cg_first_z()
         launched = 0
         chunk = max(1, self._last_its)
+        ring = ops.ring
+        K = len(ring)
         while True:
             chunk = min(chunk, max_it - launched)
-            for _ in range(chunk):
-                reqs = self.start_halo(ops.p)  # ghost planes of p travel ...
-                ops.spmv_interior()            # ... while the interior planes are computed
+            for it in range(chunk):
+                i = launched + it
+                p_cur = ops.p if npass else ring[i % K]
+                reqs = self.start_halo(p_cur)   # ghost planes of p travel ...
+                ops.spmv_interior(p_cur)        # ... while the interior planes are computed
                 self.finish_halo(reqs)
-                ops.spmv_boundary()
+                ops.spmv_boundary(p_cur)
                 self._allreduce(ops.st[3:4])
-                ops.cg_update(x)
                 if npass:
+                    ops.cg_update(x)
                     self._precondition(_hip.ST_RZN)  # replaces the Jacobi r.z written by cg_update
-                self._allreduce(ops.st[4:6])
-                if npass:
+                    self._allreduce(ops.st[4:6])
                     ops.cg_next_z()
-                else:
-                    ops.cg_next()
+                else:  # Jacobi with deferred x (see beat_pde_solve)
+                    ops.cg_update_r(i % K)
+                    self._allreduce(ops.st[4:6])
+                    if i % K == K - 1:
+                        ops.x_flush(x, i + 1 - K, True)
+                    ops.cg_next_oop(p_cur, ring[(i + 1) % K])
             launched += chunk
             st = ops.read_state()
             if st[_hip.ST_STOP] != 0.0 or launched >= max_it:
                 break
             chunk = 2
+        if not npass:
+            nupd = int(st[_hip.ST_NUPD])
+            if nupd % K:
+                ops.x_flush(x, (nupd // K) * K, False)
         its = int(st[_hip.ST_ITERS])
         self._last_its = max(its, 1)
         reason = int(st[_hip.ST_REASON]) if st[_hip.ST_STOP] != 0.0 else -3

@@ -23,6 +23,7 @@ MAX_STIM = 8
 
 # slots of the PCG scalar state (see include/beat_hip.h)
 ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON = range(11)
+ST_NUPD = 14
 ST_SIZE = 16
 
 
@@ -74,6 +75,10 @@ SIGNATURES = {
     "beat_pde_spmv_dot_part": (_int, [_vp, _vp, _vp, _vp, _int]),
     "beat_pde_cg_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "beat_pde_cg_next": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_ring_size": (_int, []),
+    "beat_pde_cg_update_r": (_int, [_vp, _vp, _vp, _vp, _int]),
+    "beat_pde_cg_next_oop": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "beat_pde_x_flush": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int]),
     "beat_pde_set_preconditioner": (_int, [_vp, _int, _vp]),
     "beat_pde_pc_num_passes": (_int, [_vp]),
     "beat_pde_pc_pass": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -908,6 +908,46 @@ static int launch_flush(beat_pde* pde, double* x, const double* ring, int64_t fl
   return BEAT_OK;
 }
 
+// ---- deferred-x stages for callers that drive the iteration themselves (slab-decomposed solve) ----------
+extern "C" int beat_pde_ring_size(void) { return PRING; }
+
+// r -= alpha q, alpha = st[1]/st[3] (also kept for the later x update, slot = iteration % ring size);
+// LOCAL r.D^-1 r, r.r -> dev_st[4..5]; counts the executed update in dev_st[14].
+extern "C" int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_q, "null argument");
+  BEAT_REQUIRE(slot >= 0 && slot < PRING, "slot %d out of range", slot);
+  hipLaunchKernelGGL(cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_q, pde->d_dinv(), pde->h_dinv[13], pde->ctx->d_partials,
+                     pde->d_alphas, slot);
+  BEAT_LAUNCH_CHECK();
+  return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
+}
+
+// scalar roll (beta, latch, iteration count) then p_next = D^-1 r + beta p_cur
+extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur,
+                                    double* dev_p_next) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p_cur && dev_p_next, "null argument");
+  BEAT_REQUIRE(dev_p_cur != dev_p_next, "the p-update is out of place");
+  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_p_cur, dev_p_next, pde->d_dinv(), pde->h_dinv[13]);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+// x += sum_j alpha_j ring_j over the valid directions of the ring cycle starting at iteration ring_base
+// (ring_j = dev_ring0 + j*field_stride); with only_if_full it acts only when that cycle filled up.
+extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
+                                int64_t field_stride, int ring_base, int only_if_full) {
+  BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_ring0, "null argument");
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
+                     dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
                               const double* const* host_dev_stim_w, const double* host_stim_amp,
                               int n_stim, double* dev_x, double* dev_work, double rtol, double atol,

@@ -175,6 +175,21 @@ int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev
  * max_it; then p = D^-1 r + beta p   -> exchange ghost planes of p. */
 int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p);
 
+/* Deferred-x variant of the update stages (what beat_pde_solve uses internally, exposed for the
+ * slab-decomposed solve): search directions live in a ring of beat_pde_ring_size() fields, iteration i
+ * uses p_i = ring[i % size]; x is brought up to date by beat_pde_x_flush when the ring is full
+ * (only_if_full = 1, enqueue it right after the update of iteration i with i % size == size-1, before
+ * that slot is overwritten) and once more after the solve for the partially filled last cycle. */
+int beat_pde_ring_size(void);
+/* alpha = st[1]/st[3] (remembered for slot); r -= alpha q; LOCAL r.D^-1 r, r.r -> dev_st[4..5]
+ * -> all-reduce dev_st[4:6].  dev_st[14] counts the executed updates. */
+int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);
+/* scalar roll as beat_pde_cg_next, then p_next = D^-1 r + beta p_cur (out of place). */
+int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur,
+                         double* dev_p_next);
+int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
+                     int64_t field_stride, int ring_base, int only_if_full);
+
 /* Optional polynomial (Chebyshev-Jacobi) preconditioner  z = sum_k c_k (D^-1 A)^k D^-1 r,
  * k < ncoef <= 8.  ncoef = 1 is plain Jacobi (the default).  On this bandwidth-bound path a PCG
  * iteration moves 72 B/node in vector updates but only 16-24 B/node per stencil pass, so trading

@@ -7,7 +7,7 @@ import torch
 
 from oracle import fem
 
-ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON, ST_RTOL, ST_ATOL, ST_MAXIT = range(14)
+ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON, ST_RTOL, ST_ATOL, ST_MAXIT, ST_NUPD = range(15)
 
 
 class CpuField:
@@ -35,7 +35,10 @@ class OracleOps:
         self.plane, self.n = nx * ny, nx * ny * nz
         self.lo_phys, self.hi_phys = bool(lo_phys), bool(hi_phys)
         self.mass_tab, self.stiff_tab = np.asarray(mass_tab), np.asarray(stiff_tab)
-        self.r, self.p, self.q, self.z = (CpuField(self.n, self.plane) for _ in range(4))
+        self.r, self.q, self.z = (CpuField(self.n, self.plane) for _ in range(3))
+        self.ring = [CpuField(self.n, self.plane) for _ in range(6)]
+        self.p = self.ring[0]
+        self.alphas = np.zeros(6)
         self.pc_degree, self.pc_coef = 1, np.array([1.0])
         self.st = torch.zeros(16, dtype=torch.float64)
         # node types of the slab: z type decided by the PHYSICAL position of the plane
@@ -162,7 +165,7 @@ class OracleOps:
         st = self.st
         tr, ta = rtol * rtol * float(st[ST_BB]), atol * atol
         st[ST_TOL2] = max(tr, ta)
-        st[ST_ITERS], st[ST_RTOL], st[ST_ATOL], st[ST_MAXIT], st[ST_BETA] = 0.0, rtol, atol, float(max_it), 0.0
+        st[ST_ITERS], st[ST_RTOL], st[ST_ATOL], st[ST_MAXIT], st[ST_BETA], st[ST_NUPD] = 0.0, rtol, atol, float(max_it), 0.0, 0.0
         done = float(st[ST_RR]) <= float(st[ST_TOL2])
         st[ST_STOP] = 1.0 if done else 0.0
         st[ST_REASON] = (2.0 if float(st[ST_RR]) <= tr else 3.0) if done else 0.0
@@ -174,29 +177,57 @@ class OracleOps:
         self.q.data.copy_(torch.from_numpy(q))
         self.st[ST_PQ] = float(self.p.data.numpy() @ q)
 
-    def spmv_interior(self):
+    # ---- deferred-x stages ------------------------------------------------------------------------------
+    def cg_update_r(self, slot):
+        if self.st[ST_STOP] != 0:
+            return
+        alpha = float(self.st[ST_RZ]) / float(self.st[ST_PQ])
+        self.alphas[slot] = alpha
+        self.r.data.add_(self.q.data, alpha=-alpha)
+        r = self.r.data.numpy()
+        self.st[ST_RZN], self.st[ST_RRN] = float(r @ (self.dinv * r)), float(r @ r)
+        self.st[ST_NUPD] += 1.0
+
+    def cg_next_oop(self, p_cur, p_next):
+        if self.st[ST_STOP] != 0:
+            return
+        self._roll_scalars()
+        if self.st[ST_STOP] != 0:
+            return
+        p_next.data.copy_(torch.from_numpy(self.dinv) * self.r.data + float(self.st[ST_BETA]) * p_cur.data)
+
+    def x_flush(self, x, ring_base, only_if_full):
+        nvalid = int(min(6, max(0, int(self.st[ST_NUPD]) - ring_base)))
+        if nvalid == 0 or (only_if_full and nvalid < 6):
+            return
+        for j in range(nvalid):
+            x.data.add_(self.ring[j].data, alpha=float(self.alphas[j]))
+
+    def spmv_interior(self, p=None):
         """Planes that need no ghost data, computed with the ghost planes POISONED to prove it."""
+        p = p or self.p
         if self.st[ST_STOP] != 0:
             return
         nx, ny, nz = self.shape
         lo, hi = (0 if self.lo_phys else 1), nz - (0 if self.hi_phys else 1)
         # the real ghost planes may be mid-receive here: they are neither read nor written
-        q = self._apply(self.A, self.p, poison_ghosts=True).reshape(nz, ny * nx)
+        q = self._apply(self.A, p, poison_ghosts=True).reshape(nz, ny * nx)
         if hi > lo:
             assert np.isfinite(q[lo:hi]).all()
             self.q.data.view(nz, ny * nx)[lo:hi] = torch.from_numpy(q[lo:hi].copy())
 
-    def spmv_boundary(self):
+    def spmv_boundary(self, p=None):
+        p = p or self.p
         if self.st[ST_STOP] != 0:
             return
         nx, ny, nz = self.shape
-        q = self._apply(self.A, self.p).reshape(nz, ny * nx)
+        q = self._apply(self.A, p).reshape(nz, ny * nx)
         qv = self.q.data.view(nz, ny * nx)
         if not self.lo_phys:
             qv[0] = torch.from_numpy(q[0].copy())
         if not self.hi_phys:
             qv[nz - 1] = torch.from_numpy(q[nz - 1].copy())
-        self.st[ST_PQ] = float(self.p.data.numpy() @ self.q.data.numpy())
+        self.st[ST_PQ] = float(p.data.numpy() @ self.q.data.numpy())
 
     def cg_update(self, x):
         if self.st[ST_STOP] != 0:
