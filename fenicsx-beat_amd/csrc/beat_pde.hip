@@ -169,7 +169,10 @@ __device__ __forceinline__ void compute_plane(const Geom& g, const StencilArgs& 
   const double* __restrict__ Pp = lds + ((z + 1) % 3) * SLOT;
   const int tz = axis_type(z, g.nz, g.z_lo_phys, g.z_hi_phys);
   const int gx = x0 + lx;
-#pragma unroll
+#ifndef BEAT_ROW_UNROLL
+#define BEAT_ROW_UNROLL 2  // 4 costs the RHS kernel half its occupancy (173 vs 128 VGPRs) for no gain
+#endif
+#pragma unroll BEAT_ROW_UNROLL
   for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
     const int ly = wave * ROWS_PER_THREAD + rr;
     const int gy = y0 + ly;
