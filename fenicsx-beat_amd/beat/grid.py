@@ -767,6 +767,12 @@ def evaluate_function(f: Function, points) -> np.ndarray:
         raise NotImplementedError("point evaluation on a decomposed mesh")
     pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
     d = mesh.dim
+    # callers evaluate the same probe points every time step: locate them once per mesh
+    cache = mesh.__dict__.setdefault("_probe_cache", {})
+    key = pts.tobytes()
+    if key in cache:
+        idx, wts = cache[key]
+        return _probe(f, idx, wts)
     idx = np.zeros((len(pts), 4), dtype=np.int64)
     wts = np.zeros((len(pts), 4), dtype=np.float64)
     lower, h, n = np.array(mesh.lower), np.array(mesh.h), np.array(mesh.n)
@@ -784,10 +790,20 @@ def evaluate_function(f: Function, points) -> np.ndarray:
                 best = (lam.min(), lam, verts)
         idx[k, : d + 1] = best[2]
         wts[k, : d + 1] = best[1]
-    out = np.zeros(len(pts))
+    if len(cache) < 64:
+        cache[key] = (idx, wts)
+    return _probe(f, idx, wts)
+
+
+def _probe(f: "Function", idx: np.ndarray, wts: np.ndarray) -> np.ndarray:
+    import ctypes as C
+
+    from . import _hip
+
+    out = np.zeros(len(idx))
     ctx = f._ctx
     _hip.check(ctx.lib.beat_field_probe(ctx.handle, f.field.ptr, idx.ctypes.data_as(C.c_void_p),
-                                        wts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p)))
+                                        wts.ctypes.data_as(C.c_void_p), len(idx), out.ctypes.data_as(C.c_void_p)))
     return out.reshape(-1, 1)
 
 
