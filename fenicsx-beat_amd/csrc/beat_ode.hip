@@ -12,15 +12,8 @@ struct ParamPack {
   double p[NP];
 };
 
-// Minimum resident waves per SIMD the register allocator must leave room for (2nd argument of
-// __launch_bounds__): the TP06 step has ~50 independent exp() chains that the scheduler would
-// otherwise hoist until one wave owns the whole register file.
-#ifndef BEAT_ODE_WAVES
-#define BEAT_ODE_WAVES 2
-#endif
-
 template <class Model, bool PER_NODE>
-__global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_step_kernel(
+__global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
     int v_index, double* __restrict__ v_copy) {
@@ -53,7 +46,7 @@ struct TrackSpec {
 };
 
 template <class Model, bool PER_NODE>
-__global__ __launch_bounds__(BEAT_BLOCK, BEAT_ODE_WAVES) void ode_run_kernel(
+__global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
     const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
     TrackSpec track, double* __restrict__ trace) {

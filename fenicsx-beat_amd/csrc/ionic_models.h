@@ -183,6 +183,20 @@ __device__ const LogEntry kLogTab[128] = {
     {0.5009784735812133, 0.69119214572414201437},
 };
 
+// Minimum resident waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__, Model::WAVES): the TP06 step has ~50 independent exp() chains that the scheduler would
+// otherwise hoist until one wave owns the whole register file.
+#ifndef BEAT_ODE_WAVES
+#define BEAT_ODE_WAVES 2
+#endif
+
+// 1/x: hardware estimate (~26 bits) + one third-order step r (1 + e + e^2), e = 1 - x r
+__device__ __forceinline__ double beat_rcp(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, fma(e, e, e), r);
+}
+
 struct FastMath {
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
   const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab
@@ -241,6 +255,7 @@ struct RegIO {
 struct SimpleOde {
   static constexpr int NS = 2, NP = 2;
   static constexpr bool REGISTER_LOOP = true;
+  static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -259,6 +274,7 @@ struct SimpleOde {
 struct FhnDemo {
   static constexpr int NS = 2, NP = 10;
   static constexpr bool REGISTER_LOOP = true;
+  static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -286,6 +302,7 @@ struct FhnDemo {
 struct FhnReadme {
   static constexpr int NS = 2, NP = 11;
   static constexpr bool REGISTER_LOOP = true;
+  static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -329,6 +346,7 @@ struct FhnReadme {
 struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53;
   static constexpr bool REGISTER_LOOP = true;
+  static constexpr int WAVES = BEAT_ODE_WAVES;
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
     P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,
@@ -371,12 +389,7 @@ struct Tp06Grl1 {
     return q;
   }
 
-  // 1/x: hardware estimate (~26 bits) + one third-order step r (1 + e + e^2), e = 1 - x r
-  __device__ static __forceinline__ double rcp(double x) {
-    const double r = __builtin_amdgcn_rcp(x);
-    const double e = fma(-x, r, 1.0);
-    return fma(r, fma(e, e, e), r);
-  }
+  __device__ static __forceinline__ double rcp(double x) { return beat_rcp(x); }
   // Reciprocals of 2-4 independent values from ONE v_rcp_f64 (Montgomery's trick): 1/(ab) b = 1/a ...
   // Every group here is a set of finite, normal, same-sign-insensitive denominators whose product
   // stays far inside the double range; each result carries ~2 extra roundings.

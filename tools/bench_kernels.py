@@ -88,6 +88,23 @@ def main():
                                      None, 0, 0.0, 0.01, 17, None))
 
     timeit("ode_step tp06", ode, 304, reps=6)
+    del sa, snap
+
+    from beat.models import torord
+
+    ic = torord.init_state_values()
+    P2 = np.ascontiguousarray(torord.init_parameter_values())
+    vi = torord.state_index("v")
+    sb = StateArray(ctx, len(ic), N, plane)
+    for k in range(len(ic)):
+        sb.rows[k].fill_(float(ic[k]))
+    sb.rows[vi].add_(torch.rand(N, dtype=torch.float64, device=ctx.device) * 100.0)
+
+    def ode2():
+        _hip.check(lib.beat_ode_step(ctx.handle, _hip.MODEL_TORORD_DYNCL_GRL1, sb.ptr, N, sb.ld, P2.ctypes.data_as(C.c_void_p),
+                                     len(P2), None, 0, 0.0, 0.01, vi, None))
+
+    timeit("ode_step torord", ode2, 16 * len(ic), reps=4)
 
 
 if __name__ == "__main__":

@@ -45,20 +45,47 @@ class Printer(C99CodePrinter):
         if x.is_Rational and not x.is_Integer and x.q == 2 and abs(x.p) in (3, 5):
             bs = self.parenthesize(b, 1000)
             body = f"({bs} * sqrt({self._print(b)}))" if abs(x.p) == 3 else f"({bs} * {bs} * sqrt({self._print(b)}))"
-            return body if x.p > 0 else f"(1.0 / {body})"
+            return body if x.p > 0 else f"beat_rcp({body})"
         if x.is_Integer:
             n = int(x)
             bs = self.parenthesize(b, 1000)
             if n == -1:
-                return f"(1.0 / {bs})"
+                return f"beat_rcp({self._print(b)})"
             if 1 < abs(n) <= 4:
                 prod = " * ".join([bs] * abs(n))
-                return f"({prod})" if n > 0 else f"(1.0 / ({prod}))"
+                return f"({prod})" if n > 0 else f"beat_rcp({prod})"
         if x == sympy.Rational(1, 2):
             return f"sqrt({self._print(b)})"
         if x == -sympy.Rational(1, 2):
-            return f"(1.0 / sqrt({self._print(b)}))"
+            return f"beat_rcp(sqrt({self._print(b)}))"
         return f"pow({self._print(b)}, {self._print(x)})"
+
+    def _print_Mul(self, e):
+        # a / b is emitted as a * beat_rcp(b) (v_rcp_f64 + one cubic Newton step, <= 1 ulp) instead of the
+        # ~12-instruction IEEE division sequence; equal denominators are merged by the compiler's CSE
+        num, den = [], []
+        for a in e.args:
+            if a.is_Pow and a.exp.is_Number and a.exp.is_negative:
+                den.append(sympy.Pow(a.base, -a.exp))
+            else:
+                num.append(a)
+        if not den:
+            return super()._print_Mul(e)
+        sign = ""
+        if num and num[0].is_Number and num[0].is_negative:
+            sign = "-"
+            num[0] = -num[0]
+            if num[0] == 1:
+                num = num[1:]
+        d = sympy.Mul(*den)
+        r = f"beat_rcp({self._print(d)})"
+        if not num:
+            return f"{sign}{r}"
+        n = sympy.Mul(*num)
+        ns = self._print(n)
+        if n.is_Add:
+            ns = f"({ns})"
+        return f"{sign}{ns}*{r}"
 
     def _print_exp(self, e):
         return f"fm.exp({self._print(e.args[0])})"
@@ -94,6 +121,7 @@ class Printer(C99CodePrinter):
 
 
 SYMBOL_NAMES: dict[str, str] = {}
+WAVES = 1
 
 
 def build(spec: OdeSpec):
@@ -205,6 +233,7 @@ def main():
     w(f"struct {struct} {{")
     w(f"  static constexpr int NS = {len(states)}, NP = {len(params)};")
     w("  static constexpr bool REGISTER_LOOP = false;  // see ode_run_kernel")
+    w(f"  static constexpr int WAVES = {WAVES};           // waves per SIMD the kernels are compiled for")
     w("  struct Derived {};")
     w("  __host__ __device__ static Derived derive(const double*) { return {}; }")
     w("  template <class IO>")
@@ -250,7 +279,14 @@ def main():
             w(f"      io.store({i}, {y} + dt * d{y}_dt);")
         else:
             w(f"      const double J = {pr.doprint(jac[y])};")
-            w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? d{y}_dt * (fm.exp(J * dt) - 1.0) / J : d{y}_dt * dt));")
+            # f / J in closed form where that is simpler than f (gates: (inf - y)/tau over -1/tau = y - inf)
+            f_e = exprs[f"d{y}_dt"]
+            ratio = sympy.cancel(f_e / jac[y]) if sympy.count_ops(jac[y]) <= 6 else None
+            if ratio is not None and sympy.count_ops(ratio) < sympy.count_ops(f_e):
+                quot = f"({pr.doprint(ratio)})"
+            else:
+                quot = f"d{y}_dt * beat_rcp(J)"
+            w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? {quot} * (fm.exp(J * dt) - 1.0) : d{y}_dt * dt));")
         w("    }")
         w("    __builtin_amdgcn_sched_barrier(0);")
     w("  }")
