@@ -122,6 +122,11 @@ class Printer(C99CodePrinter):
 
 SYMBOL_NAMES: dict[str, str] = {}
 WAVES = 1
+# scheduling fences: after every block whose closure has more than LIGHT_CLOSURE intermediates, and after every
+# FENCE_GROUP-th light block (light gate blocks may overlap each other's exp/table-lookup latencies)
+import os  # noqa: E402
+FENCE_GROUP = int(os.environ.get("GEN_FENCE_GROUP", "1"))
+LIGHT_CLOSURE = int(os.environ.get("GEN_LIGHT_CLOSURE", "12"))
 
 
 def build(spec: OdeSpec):
@@ -265,6 +270,7 @@ def main():
             roots_y += [sy.name for sy in jac[y].free_symbols if sy.name in exprs]
         per_state[y] = closure(roots_y)
     emitted = set()
+    nblock = 0
     for y in sorted(states, key=lambda q: len(per_state[q])):
         i = states.index(y)
         for u in order:
@@ -288,7 +294,9 @@ def main():
                 quot = f"d{y}_dt * beat_rcp(J)"
             w(f"      io.store({i}, {y} + ((fabs(J) > 1e-8) ? {quot} * (fm.exp(J * dt) - 1.0) : d{y}_dt * dt));")
         w("    }")
-        w("    __builtin_amdgcn_sched_barrier(0);")
+        nblock += 1
+        if len(per_state[y]) > LIGHT_CLOSURE or nblock % FENCE_GROUP == 0:
+            w("    __builtin_amdgcn_sched_barrier(0);")
     w("  }")
     w("};")
     Path(out_h).parent.mkdir(parents=True, exist_ok=True)
