@@ -112,7 +112,9 @@ def spectrum_bounds(A_tab: np.ndarray, ratio: float = 5.0) -> tuple[float, float
 class HipOps:
     """The product compute backend: every method is one C-ABI call into libbeat_hip.so."""
 
-    def __init__(self, ctx, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab):
+    def __init__(self, ctx, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab, per_node: bool = False):
+        """mass_tab / stiff_tab: the (27, 15) tables of _stencil.stencil_tables, or with ``per_node`` the
+        (15, n) rows of _stencil.stencil_fields (voxel masks, spatially varying conductivity)."""
         self.ctx = ctx
         self.lib = ctx.lib
         nx, ny, nz = (int(v) for v in shape_local)
@@ -123,10 +125,23 @@ class HipOps:
         mt = np.ascontiguousarray(mass_tab, dtype=np.float64)
         kt = np.ascontiguousarray(stiff_tab, dtype=np.float64)
         handle = C.c_void_p()
-        _hip.check(
-            self.lib.beat_pde_create(ctx.handle, n3, int(lo_phys), int(hi_phys), mt.ctypes.data_as(C.c_void_p),
-                                     kt.ctypes.data_as(C.c_void_p), C.byref(handle))
-        )
+        self.per_node = bool(per_node)
+        if self.per_node:
+            if mt.shape != (15, self.n) or kt.shape != (15, self.n):
+                raise ValueError(f"per-node rows must have shape (15, {self.n}), got {mt.shape} / {kt.shape}")
+            # device copies stay alive with this object: the handle borrows them
+            self._mass_dev, self._stiff_dev = ctx.from_numpy(mt), ctx.from_numpy(kt)
+            _hip.check(
+                self.lib.beat_pde_create_var(ctx.handle, n3, int(lo_phys), int(hi_phys),
+                                             C.c_void_p(self._mass_dev.data_ptr()),
+                                             C.c_void_p(self._stiff_dev.data_ptr()), self.n, C.byref(handle))
+            )
+            mt = kt = None  # the host copies are not needed any more
+        else:
+            _hip.check(
+                self.lib.beat_pde_create(ctx.handle, n3, int(lo_phys), int(hi_phys), mt.ctypes.data_as(C.c_void_p),
+                                         kt.ctypes.data_as(C.c_void_p), C.byref(handle))
+            )
         self.handle = handle
         self.mass_tab, self.stiff_tab = mt, kt
         nfields = max(4, int(self.lib.beat_pde_work_fields(handle)))  # see beat_pde_solve
@@ -164,6 +179,8 @@ class HipOps:
         """degree 1: Jacobi; m >= 2: Chebyshev polynomial preconditioner with m terms (m-1 stencil passes)."""
         if not 1 <= int(degree) <= 8:
             raise ValueError("preconditioner degree must be in 1..8")
+        if self.per_node and int(degree) > 1:
+            raise ValueError("the polynomial preconditioner is not available with per-node coefficients")
         self.pc_degree = int(degree)
         self._update_preconditioner()
 

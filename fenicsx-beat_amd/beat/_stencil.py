@@ -101,3 +101,85 @@ def stencil_tables(dim: int, h, M) -> tuple[np.ndarray, np.ndarray]:
                 mass_tab[typ, k] += mass[local, other]
                 stiff_tab[typ, k] += stiff[local, other]
     return mass_tab, stiff_tab
+
+
+def stencil_fields(dim: int, cells: tuple[int, ...], h, M, active=None, z_range=None) -> tuple[np.ndarray, np.ndarray]:
+    """Per-node rows of the same operators for voxel-masked domains and spatially varying conductivity:
+    returns (mass, stiff), each (15, n_local) with n_local = nx*ny*(z1-z0) nodes, x fastest.
+
+    cells   : box cells per axis (length dim)
+    M       : scalar, (dim, dim), per box cell (nbox, dim, dim) or per simplex (nbox*spc, dim, dim)
+    active  : None, bool per box cell (nbox,) or per simplex (nbox*spc,); box cells numbered x fastest,
+              simplex id = box*spc + k as in grid.Mesh
+    z_range : (z0, z1) node planes owned by this rank (3-D only); default: all
+
+    Element matrices are those of cell_matrices(); every (simplex, corner pair) contributes to one stencil
+    slot of one node per cell, so the accumulation is 96 shifted array additions (no scatter)."""
+    h = tuple(float(v) for v in np.atleast_1d(h))[:dim]
+    d = dim
+    c = [int(v) for v in cells] + [1] * (3 - d)           # box cells per axis (1 for unused axes)
+    nn = [c[a] + 1 if a < d else 1 for a in range(3)]     # nodes per axis
+    simp = _SIMPLICES[d]
+    spc = len(simp)
+    nbox = c[0] * c[1] * c[2]
+    z0, z1 = (0, nn[2]) if z_range is None else (int(z_range[0]), int(z_range[1]))
+    # cell layers touching the owned planes, node planes they cover
+    if d == 3:
+        cz_lo, cz_hi = max(z0 - 1, 0), min(z1, c[2])
+    else:
+        cz_lo, cz_hi = 0, 1
+    ncz = cz_hi - cz_lo
+    pz = ncz + 1 if d == 3 else 1  # node planes covered by those layers
+    mass = np.zeros((15, pz, nn[1], nn[0]))
+    stiff = np.zeros((15, pz, nn[1], nn[0]))
+
+    def per_cell(arr, tail):
+        """-> array (ncz, cy, cx, spc) + tail, restricted to the needed cell layers"""
+        arr = np.asarray(arr)
+        if arr.shape[0] == nbox:
+            arr = arr.reshape((c[2], c[1], c[0]) + tail)[cz_lo:cz_hi]
+            return np.broadcast_to(arr[:, :, :, None], arr.shape[:3] + (spc,) + tail)
+        if arr.shape[0] == nbox * spc:
+            return arr.reshape((c[2], c[1], c[0], spc) + tail)[cz_lo:cz_hi]
+        raise ValueError(f"per-cell data has leading size {arr.shape[0]}, expected {nbox} or {nbox * spc}")
+
+    act = None if active is None else per_cell(np.asarray(active, dtype=bool), ())
+    Marr = np.asarray(M, dtype=np.float64)
+    Mc = None
+    if Marr.ndim == 3:
+        Mc = per_cell(Marr, (d, d))
+    else:
+        Mconst = conductivity_matrix(Marr, d)
+    _, _, per_simplex = cell_matrices(h, np.eye(d))
+    corners = np.array([[(k >> a) & 1 for a in range(d)] for k in range(2**d)], dtype=np.float64) * np.asarray(h)
+    fact = float(np.prod(np.arange(1, d + 1)))
+    for k, s in enumerate(simp):
+        X = corners[list(s)]
+        A = np.hstack([np.ones((d + 1, 1)), X])
+        vol = abs(np.linalg.det(A)) / fact
+        G = np.linalg.inv(A)[1:, :].T  # (d+1, d)
+        me = per_simplex[k][1]
+        if Mc is None:
+            ke = vol * G @ Mconst @ G.T  # (d+1, d+1)
+        else:
+            ke = vol * np.einsum("ai,zyxij,bj->zyxab", G, Mc[:, :, :, k], G)
+        a_k = None if act is None else act[:, :, :, k]
+        for ia, ca in enumerate(s):
+            oa = (ca & 1, (ca >> 1) & 1, (ca >> 2) & 1)
+            sl = (slice(oa[2], oa[2] + ncz) if d == 3 else slice(0, 1), slice(oa[1], oa[1] + c[1]) if d >= 2 else slice(0, 1),
+                  slice(oa[0], oa[0] + c[0]))
+            for ib, cb in enumerate(s):
+                ob = (cb & 1, (cb >> 1) & 1, (cb >> 2) & 1)
+                slot = _OFFSET_INDEX[(ob[0] - oa[0], ob[1] - oa[1], ob[2] - oa[2])]
+                kv = ke[..., ia, ib] if Mc is not None else ke[ia, ib]
+                mv = me[ia, ib]
+                if a_k is not None:
+                    kv = kv * a_k
+                    mv = mv * a_k
+                mass[(slot,) + sl] += mv
+                stiff[(slot,) + sl] += kv
+    if d == 3:
+        lo = z0 - cz_lo
+        mass = mass[:, lo : lo + (z1 - z0)]
+        stiff = stiff[:, lo : lo + (z1 - z0)]
+    return (np.ascontiguousarray(mass.reshape(15, -1)), np.ascontiguousarray(stiff.reshape(15, -1)))

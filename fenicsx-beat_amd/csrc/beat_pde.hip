@@ -367,6 +367,7 @@ __global__ void pcg_next_kernel(double* st) {
 
 // x += alpha p ; r -= alpha q ; partial sums of r.z (z = D^-1 r) and r.r.  Row-per-wave so the node
 // type (hence 1/diag) needs no integer division per element.
+template <bool VAR>
 __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_kernel(Geom g, const double* __restrict__ st,
                                                                double* __restrict__ x,
                                                                double* __restrict__ r,
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_kernel(Geom g, const dou
     const int64_t base = (int64_t)row * g.nx;
     for (int ix = lane; ix < g.nx; ix += 64) {
       const int type = axis_type(ix, g.nx, 1, 1) + tyz;
-      const double di = (type == 13) ? dinv_i : dinv[type];
       const int64_t i = base + ix;
+      const double di = VAR ? dinv[i] : (type == 13) ? dinv_i : dinv[type];
       const double pi = p[i], qi = q[i];
       const double xi = fma(alpha, pi, x[i]);
       const double ri = fma(-alpha, qi, r[i]);
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_kernel(Geom g, const dou
 }
 
 // p = D^-1 r + beta p
+template <bool VAR>
 __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const double* __restrict__ st,
                                                                 const double* __restrict__ r,
                                                                 double* __restrict__ p,
@@ -421,8 +423,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const do
     const int64_t base = (int64_t)row * g.nx;
     for (int ix = lane; ix < g.nx; ix += 64) {
       const int type = axis_type(ix, g.nx, 1, 1) + tyz;
-      const double di = (type == 13) ? dinv_i : dinv[type];
       const int64_t i = base + ix;
+      const double di = VAR ? dinv[i] : (type == 13) ? dinv_i : dinv[type];
       p[i] = fma(beta, p[i], di * r[i]);
     }
   }
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_kernel(Geom g, const do
 // adding sum_i alpha_i p_i to x once the ring is full or the solve is over (8 (k+2) B/node in total).
 
 // r -= alpha q ; alpha = rz/pq is also stored in alphas[slot]; partial sums of r.D^-1 r and r.r.
+template <bool VAR>
 __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_r_kernel(Geom g, const double* __restrict__ st,
                                                                  double* __restrict__ r,
                                                                  const double* __restrict__ q,
@@ -453,8 +456,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_r_kernel(Geom g, const d
     const int64_t base = (int64_t)row * g.nx;
     for (int ix = lane; ix < g.nx; ix += 64) {
       const int type = axis_type(ix, g.nx, 1, 1) + tyz;
-      const double di = (type == 13) ? dinv_i : dinv[type];
       const int64_t i = base + ix;
+      const double di = VAR ? dinv[i] : (type == 13) ? dinv_i : dinv[type];
       const double ri = fma(-alpha, q[i], r[i]);
       r[i] = ri;
       s_rz = fma(ri * di, ri, s_rz);
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_update_r_kernel(Geom g, const d
 }
 
 // p_new = D^-1 r + beta p_old (out of place)
+template <bool VAR>
 __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_oop_kernel(Geom g, const double* __restrict__ st,
                                                                     const double* __restrict__ r,
                                                                     const double* __restrict__ p_old,
@@ -485,8 +489,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_oop_kernel(Geom g, cons
     const int64_t base = (int64_t)row * g.nx;
     for (int ix = lane; ix < g.nx; ix += 64) {
       const int type = axis_type(ix, g.nx, 1, 1) + tyz;
-      const double di = (type == 13) ? dinv_i : dinv[type];
       const int64_t i = base + ix;
+      const double di = VAR ? dinv[i] : (type == 13) ? dinv_i : dinv[type];
       p_new[i] = fma(beta, p_old[i], di * r[i]);
     }
   }
@@ -531,6 +535,110 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_z_kernel(int64_t n, con
   }
 }
 
+
+// ---- variable-coefficient operators (beat_pde_create_var) -----------------------------------------------
+// Voxel-masked domains and spatially varying conductivity: every node carries its own 15 coefficients per
+// operator, stored coefficient-major ((15, ld) arrays, so a wave reads 15 contiguous 512 B segments).  The
+// coefficient streams are 120 of the 136 B/node an application moves, so the neighbour values are simply
+// gathered through L1/L2 (rows of x are contiguous across the wave) instead of being staged through LDS.
+// A neighbour is only read where its coefficient is non-zero: rows never reach outside the box (or into an
+// inactive voxel), so no out-of-range address is formed and stale ghost planes cannot leak NaNs.
+struct VarArgs {
+  const double* T1;  // (15, ld) coefficients
+  const double* T2;  // second operator (RHS: stiffness; APPLY: optional) or nullptr
+  double c1, c2;     // APPLY: y = (c1 T1 + c2 T2) x
+  int64_t ld;
+  const double* x;
+  double* y;         // APPLY: y | SPMV: q | RHS: r
+  double* y2;        // RHS: p
+  double* y3;        // RHS: x (copy of v_) or nullptr
+  const double* dinv;
+  double dt;
+  const double* w[BEAT_MAX_STIM];
+  double amp[BEAT_MAX_STIM];
+  int nstim;
+  double* partials;
+  int part_off;
+  const double* st;
+  int64_t i_lo, i_hi;  // node range of this launch
+  int doff[15];        // linear offsets of the 15 stencil points
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
+  __shared__ double red[4];
+  if (MODE == MODE_SPMV_DOT) {
+    if (a.st[STOP] != 0.0) return;
+  }
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = a.i_lo + (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < a.i_hi; i += stride) {
+    double s1 = 0.0, s2 = 0.0;
+    double xc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      const double c1 = a.T1[(int64_t)k * a.ld + i];
+      double c2 = 0.0;
+      if (MODE == MODE_RHS || (MODE == MODE_APPLY && a.T2 != nullptr)) c2 = a.T2[(int64_t)k * a.ld + i];
+      const bool need = (k == 0) || c1 != 0.0 || c2 != 0.0;
+      const double xv = need ? a.x[i + a.doff[k]] : 0.0;
+      if (k == 0) xc = xv;
+      s1 = fma(c1, xv, s1);
+      s2 = fma(c2, xv, s2);
+    }
+    if (MODE == MODE_APPLY) {
+      a.y[i] = a.c1 * s1 + a.c2 * s2;
+    } else if (MODE == MODE_SPMV_DOT) {
+      a.y[i] = s1;
+      acc0 = fma(xc, s1, acc0);
+    } else {  // RHS: T1 = A, T2 = K; b = A v + r, r = dt (stim - K v)
+      double stim = 0.0;
+      for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
+      const double r = a.dt * (stim - s2);
+      const double b = s1 + r;
+      const double zz = a.dinv[i] * r;
+      a.y[i] = r;
+      a.y2[i] = zz;
+      if (a.y3 != nullptr) a.y3[i] = xc;
+      acc0 = fma(b, b, acc0);
+      acc1 = fma(r, zz, acc1);
+      acc2 = fma(r, r, acc2);
+    }
+  }
+  if (MODE == MODE_SPMV_DOT) {
+    const double s0 = beat_block_sum(acc0, red);
+    if (threadIdx.x == 0) a.partials[a.part_off + blockIdx.x] = s0;
+  } else if (MODE == MODE_RHS) {
+    const double s0 = beat_block_sum(acc0, red);
+    const double s1 = beat_block_sum(acc1, red);
+    const double s2 = beat_block_sum(acc2, red);
+    if (threadIdx.x == 0) {
+      a.partials[a.part_off + blockIdx.x] = s0;
+      a.partials[BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s1;
+      a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
+    }
+  }
+}
+
+// A = C_m Mass + theta dt K per node, 1/diag(A); rows without any element (inactive voxels) become identity
+__global__ __launch_bounds__(BEAT_BLOCK) void var_form_A_kernel(int64_t n, int64_t ld, const double* __restrict__ M,
+                                                                const double* __restrict__ K, double cm, double tdt,
+                                                                double* __restrict__ A, double* __restrict__ dinv) {
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
+    double d = cm * M[i] + tdt * K[i];
+    const bool inactive = (M[i] == 0.0);
+    if (inactive) d = 1.0;
+    A[i] = d;
+    dinv[i] = 1.0 / d;
+#pragma unroll
+    for (int k = 1; k < 15; ++k) {
+      const int64_t j = (int64_t)k * ld + i;
+      A[j] = inactive ? 0.0 : cm * M[j] + tdt * K[j];
+    }
+  }
+}
+
 }  // namespace
 
 struct beat_pde {
@@ -549,9 +657,26 @@ struct beat_pde {
   double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
+  // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
+  bool var = false;
+  const double* v_mass = nullptr;
+  const double* v_stiff = nullptr;
+  double* v_A = nullptr;
+  double* v_dinv = nullptr;
+  int64_t v_ld = 0;
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
   const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * TABW; }
+  const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }
 };
+
+// vector kernels are compiled for both the typed (27 node types) and the per-node 1/diag
+#define BEAT_LAUNCH_VEC(pde, kernel, ...)                                   \
+  do {                                                                      \
+    if ((pde)->var)                                                         \
+      hipLaunchKernelGGL((kernel<true>), __VA_ARGS__);                      \
+    else                                                                    \
+      hipLaunchKernelGGL((kernel<false>), __VA_ARGS__);                     \
+  } while (0)
 
 static Coef15 interior(const double* tab) {
   Coef15 c;
@@ -560,6 +685,7 @@ static Coef15 interior(const double* tab) {
 }
 
 static int upload_tables(beat_pde* pde);
+extern "C" int beat_pde_destroy(beat_pde* pde);
 
 extern "C" const int* beat_stencil_offsets(void) { return kOffsets; }
 
@@ -622,11 +748,66 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   return BEAT_OK;
 }
 
+
+// ---- variable-coefficient mode ------------------------------------------------------------------------
+static void var_offsets(const beat_pde* pde, VarArgs& a) {
+  const Geom& g = pde->g;
+  for (int k = 0; k < 15; ++k)
+    a.doff[k] = kOffsets[3 * k] + g.nx * kOffsets[3 * k + 1] + (int)g.plane * kOffsets[3 * k + 2];
+  a.ld = pde->v_ld;
+}
+
+// launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on
+template <int MODE>
+static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int part_off) {
+  if (z_hi <= z_lo) return 0;
+  a.i_lo = (int64_t)z_lo * pde->g.plane;
+  a.i_hi = (int64_t)z_hi * pde->g.plane;
+  a.part_off = part_off;
+  const int64_t nodes = a.i_hi - a.i_lo;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, (nodes + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+  return (int)grid;
+}
+
+static int var_form_A(beat_pde* pde) {
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
+                     pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, pde->v_A, pde->v_dinv);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
+                                   const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out) {
+  BEAT_REQUIRE(ctx != nullptr && n != nullptr && dev_mass && dev_stiff && out, "null argument");
+  BEAT_REQUIRE(ld >= n[0] * n[1] * n[2], "leading dimension %lld smaller than the node count", (long long)ld);
+  BEAT_REQUIRE(n[0] * n[1] * (n[2] + 2) < ((int64_t)1 << 31), "slab too large for 32-bit stencil offsets");
+  std::vector<double> zeros(27 * 15, 0.0);
+  beat_pde* p = nullptr;
+  int rc = beat_pde_create(ctx, n, z_lo_phys, z_hi_phys, zeros.data(), zeros.data(), &p);
+  if (rc) return rc;
+  p->var = true;
+  p->v_mass = dev_mass;
+  p->v_stiff = dev_stiff;
+  p->v_ld = ld;
+  if (hipMalloc(&p->v_A, sizeof(double) * 15 * (size_t)ld) != hipSuccess ||
+      hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess) {
+    beat_pde_destroy(p);
+    beat_set_error("out of device memory for the %lld-node coefficient rows", (long long)ld);
+    return BEAT_EHIP;
+  }
+  *out = p;
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_destroy(beat_pde* pde) {
   if (pde == nullptr) return BEAT_OK;
   (void)hipFree(pde->d_tabs);
   (void)hipFree(pde->d_st);
   (void)hipFree(pde->d_alphas);
+  (void)hipFree(pde->v_A);
+  (void)hipFree(pde->v_dinv);
   delete pde;
   return BEAT_OK;
 }
@@ -662,6 +843,7 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
   pde->dt = dt;
   pde->have_dt = true;
   pde->last_iters = -1;
+  if (pde->var) return var_form_A(pde);
   return upload_tables(pde);
 }
 
@@ -702,6 +884,27 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   BEAT_REQUIRE(which >= 0 && which < 4, "which must be 0..3");
   BEAT_REQUIRE(which >= 2 || pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(dev_x != dev_y, "in-place apply is not supported");
+  if (pde->var) {
+    VarArgs a{};
+    var_offsets(pde, a);
+    a.x = dev_x;
+    a.y = dev_y;
+    a.c1 = 1.0;
+    a.c2 = 0.0;
+    if (which == 0) {
+      a.T1 = pde->v_A;
+    } else if (which == 1) {  // B = C_m Mass - (1 - theta) dt K
+      a.T1 = pde->v_mass;
+      a.c1 = pde->C_m;
+      a.T2 = pde->v_stiff;
+      a.c2 = -(1.0 - pde->theta) * pde->dt;
+    } else {
+      a.T1 = which == 2 ? pde->v_mass : pde->v_stiff;
+    }
+    launch_var<MODE_APPLY>(pde, a, 0, pde->g.nz, 0);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
   const double* host_tab = which == 0 ? pde->h_A : which == 1 ? pde->h_B : which == 2 ? pde->h_mass : pde->h_stiff;
   StencilArgs a{};
   a.x = dev_x;
@@ -728,6 +931,28 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
   BEAT_REQUIRE(dev_r != dev_v_prev && dev_p != dev_v_prev && dev_r != dev_p, "r, p must be distinct work fields");
+  if (pde->var) {
+    VarArgs a{};
+    var_offsets(pde, a);
+    a.T1 = pde->v_A;
+    a.T2 = pde->v_stiff;
+    a.x = dev_v_prev;
+    a.y = dev_r;
+    a.y2 = dev_p;
+    a.y3 = (dev_x == dev_v_prev) ? nullptr : dev_x;
+    a.dinv = pde->v_dinv;
+    a.dt = pde->dt;
+    for (int k = 0; k < n_stim; ++k) {
+      if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
+      a.w[a.nstim] = host_dev_stim_w[k];
+      a.amp[a.nstim] = host_stim_amp[k];
+      ++a.nstim;
+    }
+    a.partials = pde->ctx->d_partials;
+    const int nb = launch_var<MODE_RHS>(pde, a, 0, pde->g.nz, 0);
+    BEAT_LAUNCH_CHECK();
+    return launch_reduce(pde, nb, 3, dev_red, nullptr);
+  }
   StencilArgs a{};
   a.x = dev_v_prev;
   a.y = dev_r;
@@ -766,6 +991,18 @@ extern "C" int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, dou
 extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
   BEAT_REQUIRE(pde != nullptr && dev_p && dev_q && dev_st, "null argument");
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  if (pde->var) {
+    VarArgs a{};
+    var_offsets(pde, a);
+    a.T1 = pde->v_A;
+    a.x = dev_p;
+    a.y = dev_q;
+    a.partials = pde->ctx->d_partials;
+    a.st = dev_st;
+    const int nb = launch_var<MODE_SPMV_DOT>(pde, a, 0, pde->g.nz, 0);
+    BEAT_LAUNCH_CHECK();
+    return launch_reduce(pde, nb, 1, dev_st + PQ, dev_st);
+  }
   StencilArgs a{};
   a.x = dev_p;
   a.y = dev_q;
@@ -784,6 +1021,28 @@ extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double
   BEAT_REQUIRE(part == 0 || part == 1, "part must be 0 (interior) or 1 (boundary planes + reduce)");
   const Geom& f = pde->g;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);  // planes that need no ghost data
+  if (pde->var) {
+    VarArgs a{};
+    var_offsets(pde, a);
+    a.T1 = pde->v_A;
+    a.x = dev_p;
+    a.y = dev_q;
+    a.partials = pde->ctx->d_partials;
+    a.st = dev_st;
+    // block-partial slots: the interior launch owns [0, 4096), the boundary planes follow
+    if (part == 0) {
+      launch_var<MODE_SPMV_DOT>(pde, a, lo, std::max(lo, hi), 0);
+      BEAT_LAUNCH_CHECK();
+      return BEAT_OK;
+    }
+    const int64_t inner = (int64_t)std::max(0, std::max(lo, hi) - lo) * f.plane;
+    int off = (int)std::min<int64_t>(4096, (inner + BEAT_BLOCK - 1) / BEAT_BLOCK);
+    if (!f.z_lo_phys) off += launch_var<MODE_SPMV_DOT>(pde, a, 0, 1, off);
+    if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch_var<MODE_SPMV_DOT>(pde, a, f.nz - 1, f.nz, off);
+    BEAT_LAUNCH_CHECK();
+    BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+    return launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
+  }
   StencilArgs a{};
   a.x = dev_p;
   a.y = dev_q;
@@ -816,8 +1075,8 @@ extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double
 extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,
                                   const double* dev_p, const double* dev_q) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_r && dev_p && dev_q, "null argument");
-  hipLaunchKernelGGL(cg_update_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
-                     (const double*)dev_st, dev_x, dev_r, dev_p, dev_q, pde->d_dinv(), pde->h_dinv[13],
+  BEAT_LAUNCH_VEC(pde, cg_update_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_x, dev_r, dev_p, dev_q, pde->dinv_arg(), pde->h_dinv[13],
                      pde->ctx->d_partials);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
@@ -827,6 +1086,7 @@ extern "C" int beat_pde_set_preconditioner(beat_pde* pde, int ncoef, const doubl
   BEAT_REQUIRE(pde != nullptr, "null pde");
   BEAT_REQUIRE(ncoef >= 1 && ncoef <= 8, "polynomial preconditioner needs 1..8 coefficients, got %d", ncoef);
   BEAT_REQUIRE(ncoef == 1 || host_coef != nullptr, "null coefficients");
+  BEAT_REQUIRE(ncoef == 1 || !pde->var, "the polynomial preconditioner is not available with per-node coefficients");
   pde->pc_ncoef = ncoef;
   for (int k = 0; k < ncoef; ++k) pde->pc_coef[k] = host_coef ? host_coef[k] : 1.0;
   pde->last_iters = -1;
@@ -892,8 +1152,8 @@ extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p, "null argument");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_pupdate_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
-                     (const double*)dev_st, dev_r, dev_p, pde->d_dinv(), pde->h_dinv[13]);
+  BEAT_LAUNCH_VEC(pde, cg_pupdate_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_p, pde->dinv_arg(), pde->h_dinv[13]);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -919,8 +1179,8 @@ extern "C" int beat_pde_ring_size(void) { return PRING; }
 extern "C" int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_q, "null argument");
   BEAT_REQUIRE(slot >= 0 && slot < PRING, "slot %d out of range", slot);
-  hipLaunchKernelGGL(cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
-                     (const double*)dev_st, dev_r, dev_q, pde->d_dinv(), pde->h_dinv[13], pde->ctx->d_partials,
+  BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_q, pde->dinv_arg(), pde->h_dinv[13], pde->ctx->d_partials,
                      pde->d_alphas, slot);
   BEAT_LAUNCH_CHECK();
   return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
@@ -933,8 +1193,8 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
   BEAT_REQUIRE(dev_p_cur != dev_p_next, "the p-update is out of place");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
-                     (const double*)dev_st, dev_r, dev_p_cur, dev_p_next, pde->d_dinv(), pde->h_dinv[13]);
+  BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
+                     (const double*)dev_st, dev_r, dev_p_cur, dev_p_next, pde->dinv_arg(), pde->h_dinv[13]);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -1002,8 +1262,8 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
         double* p_cur = ring + (int64_t)slot * fld;
         double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
         if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
-        hipLaunchKernelGGL(cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
-                           (const double*)st, r, (const double*)q, pde->d_dinv(), pde->h_dinv[13],
+        BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
+                           (const double*)st, r, (const double*)q, pde->dinv_arg(), pde->h_dinv[13],
                            ctx->d_partials, pde->d_alphas, slot);
         BEAT_LAUNCH_CHECK();
         if ((rc = launch_reduce(pde, (int)pde->vec_grid, 2, st + RZN, st, st + NUPD))) return rc;
@@ -1012,8 +1272,8 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
         }
         hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, ctx->stream, st);
         BEAT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
-                           (const double*)st, (const double*)r, (const double*)p_cur, p_next, pde->d_dinv(),
+        BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
+                           (const double*)st, (const double*)r, (const double*)p_cur, p_next, pde->dinv_arg(),
                            pde->h_dinv[13]);
         BEAT_LAUNCH_CHECK();
       }

@@ -129,6 +129,17 @@ int beat_scatter(beat_ctx* ctx, double* dev_dst, const double* dev_src, const in
  *               (monodomain_model.py:68-98). */
 int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
                     const double* host_mass_tab, const double* host_stiff_tab, beat_pde** out);
+/* Same operators with per-node coefficients: voxel-masked domains (the reference's ventricular meshes,
+ * demos/biv_endocardial.py, voxelised onto the structured grid) and spatially varying conductivity
+ * M(x) = s_l f0 f0^T + ... from a fibre field (conductivities.py:107-118, monodomain_model.py:68-98).
+ *  dev_mass / dev_stiff : DEVICE arrays (15, ld), coefficient-major: entry [k*ld + i] multiplies the node
+ *               at offset beat_stencil_offsets()[k] in row i.  Borrowed for the lifetime of the handle.
+ *               Rows must not couple to nodes outside the box; a row whose mass diagonal is 0 (node not
+ *               touched by any active element) is treated as an identity row by every operator.
+ * All other beat_pde_* entry points work unchanged on such a handle (the polynomial preconditioner is
+ * Jacobi-only there). */
+int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
+                        const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out);
 int beat_pde_destroy(beat_pde* pde);
 /* (dx,dy,dz) of the 15 stencil points, 45 ints. */
 const int* beat_stencil_offsets(void);
