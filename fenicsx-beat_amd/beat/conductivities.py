@@ -1,5 +1,6 @@
 """Conductivity helpers (interface of src/beat/conductivities.py:29-118).  With a constant fibre
-direction the tensor ``M = s_l f(x)f + s_t (I - f(x)f)`` is a plain (dim, dim) NumPy matrix."""
+direction the tensor ``M = s_l f(x)f + s_t (I - f(x)f)`` is a plain (dim, dim) NumPy matrix; with a
+fibre field given per cell (grid.CellField) it is a CellField of (dim, dim) tensors."""
 
 from __future__ import annotations
 
@@ -48,10 +49,15 @@ def get_harmonic_mean_conductivity(chi, g_il=0.17, g_it=0.019, g_el=0.62, g_et=0
 
 
 def conductivity_tensor(s_l: float, s_t: float, f0) -> np.ndarray:
-    from .grid import Constant, Function
+    from .grid import CellField, Constant, Function
 
     if isinstance(f0, Function):
-        raise NotImplementedError("spatially varying fibre fields are not implemented yet (constant f0 only)")
+        raise NotImplementedError("nodal fibre fields are not implemented: pass the fibres per cell (grid.CellField)")
+    if isinstance(f0, CellField):
+        f = f0.values
+        dim = f.shape[1]
+        ff = f[:, :, None] * f[:, None, :]
+        return CellField(f0.mesh, s_t * np.eye(dim)[None] + (s_l - s_t) * ff)
     f = np.asarray(f0.value if isinstance(f0, Constant) else f0, dtype=np.float64)
     dim = len(f)
     return s_l * np.outer(f, f) + s_t * (np.eye(dim) - np.outer(f, f))

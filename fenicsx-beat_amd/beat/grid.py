@@ -328,9 +328,11 @@ class _Geometry:
 
 
 class Mesh:
-    """Uniform box mesh with the reference's simplicial subdivision, optionally z-slab decomposed."""
+    """Uniform box mesh with the reference's simplicial subdivision, optionally z-slab decomposed and
+    optionally restricted to a subset of ACTIVE cells (a voxelised geometry: the domain is the union of the
+    active simplices; nodes that touch no active cell carry identity rows in every operator)."""
 
-    def __init__(self, cells, lower, upper, comm: Comm | None = None):
+    def __init__(self, cells, lower, upper, comm: Comm | None = None, active=None):
         self.n = tuple(int(c) for c in cells)
         self.dim = len(self.n)
         if self.dim not in (1, 2, 3) or min(self.n) < 1:
@@ -354,7 +356,17 @@ class Mesh:
         self.num_nodes = self.plane * self.slab.nz
         self.num_nodes_global = self.plane * nodes[2]
         self.simplices_per_cell = {1: 1, 2: 2, 3: 6}[self.dim]
-        self.num_cells_global = int(np.prod(self.n)) * self.simplices_per_cell
+        self.num_box_cells = int(np.prod(self.n))
+        self.active = None  # bool per simplex (global numbering) or None = every cell
+        if active is not None:
+            active = np.asarray(active, dtype=bool).ravel()
+            if active.size == self.num_box_cells:
+                active = np.repeat(active, self.simplices_per_cell)
+            if active.size != self.num_box_cells * self.simplices_per_cell:
+                raise ValueError(f"active mask has {active.size} entries for {self.num_box_cells} box cells")
+            self.active = active
+        self.num_cells_global = (int(self.active.sum()) if self.active is not None
+                                 else self.num_box_cells * self.simplices_per_cell)
 
     def basix_cell(self):
         return {1: CellType.interval, 2: CellType.triangle, 3: CellType.tetrahedron}[self.dim]
@@ -409,11 +421,61 @@ class Mesh:
         return (ix[:, None] + ox) + nx * ((iy[:, None] + oy) + ny * (iz[:, None] + oz))
 
     def all_cells(self) -> np.ndarray:
+        if self.active is not None:
+            return np.nonzero(self.active)[0].astype(np.int64)
         return np.arange(self.num_cells_global, dtype=np.int64)
+
+    def node_active(self, local: bool = True) -> np.ndarray:
+        """bool per node: touched by at least one active cell (all True without a mask)."""
+        nx, ny, nz = self.shape_global
+        if self.active is None:
+            ok = np.ones(nx * ny * nz, dtype=bool)
+        else:
+            ok = np.zeros(nx * ny * nz, dtype=bool)
+            ids = np.nonzero(self.active)[0]
+            for s in range(0, len(ids), 1 << 20):
+                ok[self.cell_vertices(ids[s : s + (1 << 20)]).ravel()] = True
+        if local:
+            ok = ok[self.slab.z0 * self.plane : self.slab.z1 * self.plane]
+        return ok
 
 
 def _mesh(comm, lower, upper, n):
     return Mesh(n, lower, upper, comm if isinstance(comm, Comm) else COMM_WORLD)
+
+
+def create_voxel_mesh(comm, mask, h, origin=None):
+    """Voxelised geometry: ``mask`` is a bool array of shape (cz, cy, cx) (or (cy, cx) / (cx,)), True for
+    voxels inside the tissue; every active voxel is split into simplices exactly like a box-mesh cell
+    (src/beat/geometry.py:121-139), so a fully active mask reproduces ``create_box``."""
+    mask = np.asarray(mask, dtype=bool)
+    d = mask.ndim
+    n = tuple(reversed(mask.shape))
+    h = (float(h),) * d if np.ndim(h) == 0 else tuple(float(v) for v in h)
+    origin = (0.0,) * d if origin is None else tuple(float(v) for v in origin)
+    upper = tuple(o + c * hh for o, c, hh in zip(origin, n, h))
+    return Mesh(n, origin, upper, comm if isinstance(comm, Comm) else COMM_WORLD, active=mask.ravel())
+
+
+def cell_centers(mesh: "Mesh") -> np.ndarray:
+    """(num_box_cells, dim) centres of the box cells, x fastest."""
+    ax = [mesh.lower[a] + mesh.h[a] * (np.arange(mesh.n[a]) + 0.5) for a in range(mesh.dim)]
+    grids = np.meshgrid(*reversed(ax), indexing="ij")
+    return np.stack([g.ravel() for g in reversed(grids)], axis=1)
+
+
+class CellField:
+    """Piecewise-constant data per box cell (voxel) or per simplex: fibre directions (ncells, dim) or
+    tensors (ncells, dim, dim); the stand-in for the DG0 functions the reference's geometries carry."""
+
+    def __init__(self, mesh: "Mesh", values):
+        values = np.asarray(values, dtype=np.float64)
+        if values.shape[0] not in (mesh.num_box_cells, mesh.num_box_cells * mesh.simplices_per_cell):
+            raise ValueError(f"cell data has leading size {values.shape[0]}; expected one entry per box cell "
+                             f"({mesh.num_box_cells}) or per simplex")
+        self.mesh = mesh
+        self.values = values
+
 
 
 def create_unit_interval(comm, nx, **kw):
@@ -460,7 +522,10 @@ def locate_entities(mesh: Mesh, dim: int, marker) -> np.ndarray:
     if ok.shape == ():
         ok = np.full(x.shape[1], bool(ok))
     nx, ny, nz = mesh.shape_global
-    return np.nonzero(mesh._cell_vertex_mask(ok.reshape(nz, ny, nx)))[0].astype(np.int32)
+    sel = mesh._cell_vertex_mask(ok.reshape(nz, ny, nx))
+    if mesh.active is not None:
+        sel &= mesh.active
+    return np.nonzero(sel)[0].astype(np.int32)
 
 
 @dataclass

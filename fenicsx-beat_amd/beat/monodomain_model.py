@@ -1,8 +1,10 @@
 """``MonodomainModel`` -- interface of src/beat/monodomain_model.py:18-98.
 
 Solves  C_m dv/dt = div(M grad v) + I_stim  with the theta-rule weak form of :68-98 on P1
-elements.  ``M`` is a scalar, a ``Constant`` or a constant (dim, dim) tensor (see
-beat.conductivities.define_conductivity_tensor)."""
+elements.  ``M`` is a scalar, a ``Constant``, a constant (dim, dim) tensor or a per-cell tensor field
+(``grid.CellField`` / array of shape (ncells, dim, dim), see beat.conductivities.define_conductivity_tensor).
+Constant tensors on an unmasked box use the 27-type stencil tables; per-cell tensors and voxel-masked
+meshes use per-node stencil rows."""
 
 from __future__ import annotations
 
@@ -31,18 +33,33 @@ class MonodomainModel(BaseModel):
         self._state = grid.Function(self.V, name="v")
 
     def _conductivity(self) -> np.ndarray:
+        """(dim, dim) for a constant tensor, (ncells, dim, dim) for a per-cell field."""
         M = self._M
         if isinstance(M, grid.Function):
-            raise NotImplementedError("spatially varying conductivity is not implemented yet")
+            raise NotImplementedError("nodal conductivity fields are not implemented: pass the tensor per cell")
+        if isinstance(M, grid.CellField):
+            M = M.values
         if isinstance(M, grid.Constant):
             M = M.value
+        M = np.asarray(M, dtype=np.float64)
+        if M.ndim == 3:
+            d = self._mesh.dim
+            if M.shape[1:] != (d, d):
+                raise ValueError(f"per-cell conductivity has shape {M.shape}, expected (ncells, {d}, {d})")
+            return M
         return _stencil.conductivity_matrix(M, self._mesh.dim)
 
     def _setup_operators(self) -> None:
         mesh = self._mesh
-        mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, self._conductivity())
+        M = self._conductivity()
         slab = mesh.slab
-        self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+        if M.ndim == 3 or mesh.active is not None:
+            z_range = (slab.z0, slab.z1) if mesh.dim == 3 else None
+            mass, stiff = _stencil.stencil_fields(mesh.dim, mesh.n, mesh.h, M, mesh.active, z_range=z_range)
+            self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass, stiff, per_node=True)
+        else:
+            mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, M)
+            self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
         self._diffusion = DiffusionSolver(self._ops, slab, group=mesh.comm.group)
 
     @property

@@ -467,12 +467,24 @@ class OracleMonodomainModel:
     reference's default ``preonly+lu`` path, or Jacobi-PCG (``solver='pcg'``)."""
 
     def __init__(self, mesh: BoxMesh, M, stimuli=(), C_m=1.0, theta=0.5, default_timestep=1.0,
-                 solver="lu", rtol=1e-10):
+                 solver="lu", rtol=1e-10, active_cells=None):
+        """``active_cells``: bool per simplex -- the domain is the union of those cells (what the reference
+        gets from a mesh of the tissue only); nodes outside it get identity rows and keep their values."""
         self.mesh = mesh
         self.C_m = float(C_m)
         self.theta = float(theta)
-        self.Mass = assemble_mass(mesh)
-        self.K = assemble_stiffness(mesh, M)
+        if active_cells is None:
+            self.Mass = assemble_mass(mesh)
+            self.K = assemble_stiffness(mesh, M)
+            self.outside = None
+        else:
+            act = np.asarray(active_cells, dtype=bool)
+            Mc = np.asarray(M, dtype=float)
+            if Mc.ndim != 3:
+                Mc = np.broadcast_to(_as_tensor(Mc, mesh.dim), (len(act), mesh.dim, mesh.dim))
+            self.Mass = assemble_mass(mesh, np.nonzero(act)[0])
+            self.K = assemble_stiffness(mesh, Mc * act[:, None, None])
+            self.outside = sp.diags(np.where(self.Mass.diagonal() > 0, 0.0, 1.0))
         self.stimuli = list(stimuli)
         self.state = np.zeros(mesh.num_nodes)
         self.v_ = np.zeros(mesh.num_nodes)
@@ -487,6 +499,9 @@ class OracleMonodomainModel:
         self._dt = dt
         self.A = (self.C_m * self.Mass + self.theta * dt * self.K).tocsc()
         self.B = (self.C_m * self.Mass - (1.0 - self.theta) * dt * self.K).tocsr()
+        if self.outside is not None:
+            self.A = (self.A + self.outside).tocsc()
+            self.B = (self.B + self.outside).tocsr()
         self._lu = spla.splu(self.A) if self.solver == "lu" else None
 
     def assign_previous(self):  # monodomain_model.py:59-60

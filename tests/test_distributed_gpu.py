@@ -16,7 +16,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx):
+@pytest.mark.parametrize("per_node", [False, True])
+def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node):
     import torch
     import torch.distributed as dist
 
@@ -33,12 +34,17 @@ def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx):
         nx, ny, nz = 40, 33, 17
         f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
         M = 9.5e-4 * np.outer(f0, f0) + 1.25e-4 * (np.eye(3) - np.outer(f0, f0))
-        mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
+        if per_node:  # masked grid + per-node rows (beat_pde_create_var)
+            cc = np.stack(np.meshgrid(np.arange(nz - 1), np.arange(ny - 1), np.arange(nx - 1), indexing="ij"), -1).reshape(-1, 3)
+            active = ((cc - np.array([8, 16, 20])) ** 2).sum(axis=1) < 14**2
+            mt, kt = _stencil.stencil_fields(3, (nx - 1, ny - 1, nz - 1), (0.1, 0.1, 0.1), M, active)
+        else:
+            mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
         rng = np.random.default_rng(3)
         v = -85.0 + 30.0 * rng.random(nx * ny * nz)
         results = []
         for force in (False, True):
-            ops = HipOps(ctx, (nx, ny, nz), True, True, mt, kt)
+            ops = HipOps(ctx, (nx, ny, nz), True, True, mt, kt, per_node=per_node)
             ops.set_timestep(0.01, 0.5, 0.05)
             solver = DiffusionSolver(ops, Slab(nz), force_distributed=force)
             fv, fx = ops.new_field(), ops.new_field()

@@ -54,3 +54,76 @@ def test_interior_row_sums():
     assert abs(mt[26].sum() - 0.125 / 4) < 1e-15
     # the corner (hi, lo, lo) = v1 belongs to 2 of the 6
     assert abs(mt[2].sum() - 2 * 0.125 / 24) < 1e-15
+
+
+def _apply_rows(rows, nn, x):
+    """y_i = sum_k rows[k, i] x[i + offset_k] with zero padding (NumPy restatement of the per-node kernels)."""
+    from beat import _stencil
+
+    X = np.zeros((nn[2] + 2, nn[1] + 2, nn[0] + 2))
+    X[1:-1, 1:-1, 1:-1] = x.reshape(nn[2], nn[1], nn[0])
+    y = np.zeros((nn[2], nn[1], nn[0]))
+    for k, (ox, oy, oz) in enumerate(_stencil.OFFSETS):
+        y += rows[k].reshape(nn[2], nn[1], nn[0]) * X[1 + oz : 1 + oz + nn[2], 1 + oy : 1 + oy + nn[1], 1 + ox : 1 + ox + nn[0]]
+    return y.ravel()
+
+
+@pytest.mark.parametrize("cells,h", [((5, 4, 6), (0.1, 0.2, 0.15)), ((7, 5), (0.1, 0.3)), ((6,), (0.2,))])
+def test_per_node_rows_equal_assembled_operator_on_masked_cells(cells, h):
+    """stencil_fields (voxel mask + per-cell tensors; per box cell and per simplex) vs the oracle's assembly
+    over the active cells; a z-range returns exactly the rows of those planes."""
+    from beat import _stencil
+
+    dim = len(cells)
+    rng = np.random.default_rng(1)
+    nbox = int(np.prod(cells))
+    spc = {1: 1, 2: 2, 3: 6}[dim]
+    mesh = fem.BoxMesh(cells, tuple(c * hh for c, hh in zip(cells, h)))
+    nn = [c + 1 for c in cells] + [1] * (3 - dim)
+    x = rng.standard_normal(mesh.num_nodes)
+    for per_simplex in (False, True):
+        ncell = nbox * spc if per_simplex else nbox
+        B = rng.standard_normal((ncell, dim, dim))
+        Mc = B @ B.transpose(0, 2, 1) + np.eye(dim)
+        act = rng.random(ncell) > 0.3
+        Ms = Mc if per_simplex else np.repeat(Mc, spc, axis=0)
+        acts = act if per_simplex else np.repeat(act, spc)
+        K = fem.assemble_stiffness(mesh, Ms * acts[:, None, None])
+        Mass = fem.assemble_mass(mesh, np.nonzero(acts)[0])
+        mf, kf = _stencil.stencil_fields(dim, cells, h, Mc, act)
+        assert np.abs(_apply_rows(mf, nn, x) - Mass @ x).max() < 1e-14
+        assert np.abs(_apply_rows(kf, nn, x) - K @ x).max() < 1e-12 * np.abs(K @ x).max()
+        if dim == 3:
+            pl = nn[0] * nn[1]
+            m2, k2 = _stencil.stencil_fields(dim, cells, h, Mc, act, z_range=(2, 5))
+            np.testing.assert_array_equal(m2, mf[:, 2 * pl : 5 * pl])
+            np.testing.assert_array_equal(k2, kf[:, 2 * pl : 5 * pl])
+    # constant tensor, no mask: the rows are the 27-type tables spread over the nodes
+    mt, kt = _stencil.stencil_tables(dim, h, _aniso(dim))
+    mf, kf = _stencil.stencil_fields(dim, cells, h, _aniso(dim))
+    typ = fem.node_types(tuple(c + 1 for c in cells)).ravel()
+    np.testing.assert_allclose(mf.T, mt[typ], rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(kf.T, kt[typ], rtol=1e-12, atol=1e-16)
+
+
+def test_voxel_mesh_cells_and_nodes():
+    """create_voxel_mesh: cell ids, locate_entities, node activity and stimulus weights respect the mask."""
+    from beat import grid as g
+    from beat.stimulation import assemble_weights
+
+    mask = np.ones((3, 4, 5), dtype=bool)
+    mask[:, :, 0] = False
+    mask[1, 2, 3] = False
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, 0.1)
+    assert mesh.n == (5, 4, 3) and mesh.num_cells_global == 6 * int(mask.sum())
+    assert np.array_equal(mesh.all_cells(), np.nonzero(np.repeat(mask.ravel(), 6))[0])
+    act = mesh.node_active().reshape(4, 5, 6)
+    assert not act[:, :, 0].any() and act[:, :, 1:].all()
+    cells = g.locate_entities(mesh, 3, lambda x: x[0] <= 0.3 + 1e-12)
+    assert len(cells) == 6 * int(mask[:, :, 1:3].sum())
+    w = assemble_weights(mesh, None, None)
+    omesh = fem.BoxMesh((5, 4, 3), (0.5, 0.4, 0.3))
+    np.testing.assert_allclose(w, fem.stimulus_weights(omesh, mesh.all_cells()), rtol=1e-13, atol=1e-18)
+    assert np.isclose(w.sum(), mask.sum() * 1e-3)
+    centres = g.cell_centers(mesh)
+    assert centres.shape == (60, 3) and np.allclose(centres[0], 0.05) and np.allclose(centres[1], [0.15, 0.05, 0.05])

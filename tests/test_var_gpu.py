@@ -232,3 +232,167 @@ def test_per_node_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl)
     ctx.synchronize()
     np.testing.assert_array_equal(ops.q.numpy(), q1)
     assert np.isclose(float(ops.st[3]), pq, rtol=1e-13)
+
+
+# ---- API level: voxelised shell, per-cell fibres, transmural cell types (BASELINE configs[4] in small) ---------
+def _shell_geometry(n=(26, 22, 18), h=0.5):
+    """Truncated ellipsoidal shell voxelised on a box: active voxels, transmural depth in [0, 1] per voxel
+    centre (0 = endocardium) and a fibre field rotating from +60 deg (endo) to -60 deg (epi) about the
+    radial direction -- synthetic stand-in for demos/biv_endocardial.py's geometry."""
+    cx, cy, cz = n
+    ax = [(np.arange(c) + 0.5) * h for c in n]
+    Z, Y, X = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    c = np.array([cx, cy, cz]) * h / 2.0
+    semi_o = 0.48 * np.array(n) * h
+    semi_i = 0.62 * semi_o
+    P = np.stack([X - c[0], Y - c[1], Z - c[2]], axis=-1)
+    ro = np.sqrt(((P / semi_o) ** 2).sum(-1))
+    ri = np.sqrt(((P / semi_i) ** 2).sum(-1))
+    mask = (ro < 1.0) & (ri > 1.0) & (Z < 0.8 * cz * h)
+    depth = np.clip((ri - 1.0) / np.maximum(ri - ro, 1e-12) * 1.0, 0.0, 1.0)  # 0 at the inner, 1 at the outer surface
+    rad = P / np.maximum(np.linalg.norm(P, axis=-1, keepdims=True), 1e-12)
+    ez = np.array([0.0, 0.0, 1.0])
+    circ = np.cross(ez, rad)
+    circ /= np.maximum(np.linalg.norm(circ, axis=-1, keepdims=True), 1e-12)
+    longi = np.cross(rad, circ)
+    ang = np.deg2rad(60.0 - 120.0 * depth)[..., None]
+    f0 = np.cos(ang) * circ + np.sin(ang) * longi
+    return mask, depth.reshape(-1), f0.reshape(-1, 3)
+
+
+def _tp06_variants():
+    from beat.models import tp06
+
+    base = dict(stim_amplitude=0.0)
+    return {1: tp06.init_parameter_values(**base),                                     # endo-like
+            0: tp06.init_parameter_values(g_Ks=0.098, **base),                         # mid
+            2: tp06.init_parameter_values(g_to=0.073, g_Ks=0.392 * 1.2, **base)}       # epi-like
+
+
+def test_voxel_shell_multi_celltype_split_step_matches_oracle():
+    """Voxelised shell + per-voxel fibre field + three transmural cell types (DolfinMultiODESolver) + endocardial
+    layer stimulus, 24 Godunov steps at dt = 0.05 ms: every state of every tissue node against the oracle
+    (assembled FEM on the active cells with sparse-LU solves, NumPy TP06 GRL1 per marker) to 1e-7 relative (as
+    test_strang_splitting_against_oracle: the stimulated layer is in its upstroke)."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+    from oracle import fem, ionic, splitting
+
+    n, h = (26, 22, 18), 0.5
+    mask, depth, f0 = _shell_geometry(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    assert mesh.active is not None and 0.1 < mask.mean() < 0.6
+    cond = beat.conductivities.default_conductivities("Bishop")
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    assert isinstance(M, g.CellField) and M.values.shape == (mesh.num_box_cells, 3, 3)
+    time = g.Constant(mesh, 0.0)
+    # stimulus: active voxels of the innermost 25 % of the wall in the lower half (volume tags)
+    vox_sel = mask.ravel() & (depth < 0.25) & (g.cell_centers(mesh)[:, 2] < 0.45 * n[2] * h)
+    stim_cells = np.nonzero(np.repeat(vox_sel, 6))[0]
+    tags = g.meshtags(mesh, 3, stim_cells, np.full(len(stim_cells), 7, dtype=np.int32))
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=7,
+                                           mesh_unit="mm", amplitude=50_000.0, start=0.0, duration=1.0)
+    C_m = 0.01
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, dx=I_s.dZ,
+                               params={"petsc_options": {"ksp_rtol": 1e-13}})
+    # nodal transmural markers: 1 endo / 0 mid / 2 epi from the mean depth of the active voxels around a node;
+    # -1 outside the tissue (no cell model there)
+    V = g.functionspace(mesh, ("P", 1))
+    nx, ny, nz = mesh.shape_global
+    dsum, cnt = np.zeros((nz, ny, nx)), np.zeros((nz, ny, nx))
+    D, A = depth.reshape(n[2], n[1], n[0]), mask
+    for oz in (0, 1):
+        for oy in (0, 1):
+            for ox in (0, 1):
+                dsum[oz : oz + n[2], oy : oy + n[1], ox : ox + n[0]] += D * A
+                cnt[oz : oz + n[2], oy : oy + n[1], ox : ox + n[0]] += A
+    node_depth = np.where(cnt > 0, dsum / np.maximum(cnt, 1), -1.0).ravel()
+    marker_arr = np.where(node_depth < 0, -1, np.where(node_depth < 0.3, 1, np.where(node_depth < 0.7, 0, 2))).astype(float)
+    assert np.array_equal(marker_arr >= 0, mesh.node_active())
+    markers = g.Function(V)
+    markers.x.array[:] = marker_arr
+    params = _tp06_variants()
+    ic = tp06.init_state_values()
+    keys = (1, 0, 2)
+    ode = beat.odesolver.DolfinMultiODESolver(
+        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
+        fun={k: tp06.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
+        parameters={k: params[k] for k in keys}, v_index={k: tp06.state_index("V") for k in keys})
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    dt, nsteps = 0.05, 24
+    for i in range(nsteps):
+        solver.step((i * dt, (i + 1) * dt))
+    assert pde.ksp.iterations > 0
+
+    # ---- oracle
+    omesh = fem.BoxMesh(n, tuple(c * h for c in n))
+    act_s = np.repeat(mask.ravel(), 6)
+    w = fem.stimulus_weights(omesh, stim_cells)
+    amp = 50000.0 / 1400.0 / 100.0  # uA/cm^3 / cm^-1 -> uA/cm^2 -> uA/mm^2
+    model = fem.OracleMonodomainModel(omesh, np.repeat(M.values, 6, axis=0), [fem.OracleStimulus(fem.window(0.0, 1.0, amp), w)],
+                                      C_m=C_m, theta=0.5, active_cells=act_s)
+    oode = splitting.OracleMultiODE(marker_arr, {k: ionic.tp06_init_state_values() for k in keys},
+                                    {k: np.asarray(params[k]) for k in keys},
+                                    {k: ionic.tp06_generalized_rush_larsen for k in keys}, {k: 19 for k in keys},
+                                    {k: 17 for k in keys})
+    for i in range(nsteps):
+        t0 = i * dt
+        oode.step(t0, dt)
+        oode.to_dolfin()
+        model.state[:] = oode.v_ode
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        oode.v_ode[:] = model.state
+        oode.from_dolfin()
+    for k in keys:
+        out, ref = ode.values(k), oode.values[k]
+        err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert err.max() < 1e-7, (k, err.max())
+    # the wave has started: stimulated layer depolarised, far tissue still at rest, outside untouched
+    v = np.asarray(pde.state.x.array)
+    assert v[marker_arr >= 0].max() > -40.0 and v[marker_arr >= 0].min() < -80.0
+    assert np.all(v[marker_arr < 0] == 0.0)
+
+
+def test_voxel_shell_torord_celltypes_runs():
+    """Same geometry with ToR-ORd (45 states) endo / mid / epi through the generated kernel: 40 steps stay finite,
+    the stimulated endocardial layer fires and the three cell types keep their own parameter sets."""
+    import beat
+    from beat import grid as g
+    from beat.models import torord
+
+    n, h = (20, 18, 14), 0.5
+    mask, depth, f0 = _shell_geometry(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    cond = beat.conductivities.default_conductivities("Bishop")
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    time = g.Constant(mesh, 0.0)
+    vox_sel = mask.ravel() & (depth < 0.3)
+    stim_cells = np.nonzero(np.repeat(vox_sel, 6))[0]
+    tags = g.meshtags(mesh, 3, stim_cells, np.full(len(stim_cells), 1, dtype=np.int32))
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                           mesh_unit="mm", amplitude=50_000.0, start=0.0, duration=1.0)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01, dx=I_s.dZ)
+    V = g.functionspace(mesh, ("P", 1))
+    active = mesh.node_active()
+    z = mesh.node_coordinates(pad3=True)[:, 2]
+    marker_arr = np.where(~active, -1.0, np.where(z < 2.5, 0.0, np.where(z < 4.5, 1.0, 2.0)))
+    markers = g.Function(V)
+    markers.x.array[:] = marker_arr
+    keys = (0, 1, 2)
+    ic = torord.init_state_values()
+    ode = beat.odesolver.DolfinMultiODESolver(
+        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
+        fun={k: torord.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
+        parameters={k: torord.init_parameter_values(i_Stim_Amplitude=0.0, celltype=k) for k in keys},
+        v_index={k: torord.state_index("v") for k in keys})
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    dt = 0.05
+    for i in range(40):
+        solver.step((i * dt, (i + 1) * dt))
+    v = np.asarray(pde.state.x.array)
+    assert np.isfinite(v).all()
+    assert v[active].max() > 0.0 and v[active].min() < -80.0 and np.all(v[~active] == 0.0)
+    for k in keys:
+        assert np.isfinite(ode.values(k)).all()
