@@ -122,15 +122,19 @@ class HipOps:
         self.plane = nx * ny
         self.n = nx * ny * nz
         n3 = (C.c_int64 * 3)(nx, ny, nz)
-        mt = np.ascontiguousarray(mass_tab, dtype=np.float64)
-        kt = np.ascontiguousarray(stiff_tab, dtype=np.float64)
+        host = isinstance(mass_tab, np.ndarray) or not per_node
+        mt = np.ascontiguousarray(mass_tab, dtype=np.float64) if host else None
+        kt = np.ascontiguousarray(stiff_tab, dtype=np.float64) if host else None
         handle = C.c_void_p()
         self.per_node = bool(per_node)
         if self.per_node:
-            if mt.shape != (15, self.n) or kt.shape != (15, self.n):
-                raise ValueError(f"per-node rows must have shape (15, {self.n}), got {mt.shape} / {kt.shape}")
+            if tuple(mass_tab.shape) != (15, self.n) or tuple(stiff_tab.shape) != (15, self.n):
+                raise ValueError(f"per-node rows must have shape (15, {self.n}), got {mass_tab.shape} / {stiff_tab.shape}")
             # device copies stay alive with this object: the handle borrows them
-            self._mass_dev, self._stiff_dev = ctx.from_numpy(mt), ctx.from_numpy(kt)
+            if isinstance(mass_tab, np.ndarray):
+                self._mass_dev, self._stiff_dev = ctx.from_numpy(mt), ctx.from_numpy(kt)
+            else:  # already on the device (from_voxels)
+                self._mass_dev, self._stiff_dev = mass_tab, stiff_tab
             _hip.check(
                 self.lib.beat_pde_create_var(ctx.handle, n3, int(lo_phys), int(hi_phys),
                                              C.c_void_p(self._mass_dev.data_ptr()),
@@ -160,6 +164,44 @@ class HipOps:
         self.st = ctx.zeros(_hip.ST_SIZE)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
+
+    @classmethod
+    def from_voxels(cls, ctx, dim, cells, h, M, active, shape_local, z0, lo_phys, hi_phys):
+        """Per-node operators assembled ON THE DEVICE from per-voxel data (beat_pde_assemble_rows).
+        cells: global voxels per axis (length dim); M: (dim, dim) or (nvoxels, dim, dim); active: bool
+        (nvoxels,) or None; shape_local / z0: this rank's slab of nodes."""
+        from . import _stencil
+
+        nvox = int(np.prod(cells))
+        c3 = [int(v) for v in cells] + [1] * (3 - dim)
+        T, Me = _stencil.voxel_element_tensors(dim, h)
+        M = np.asarray(M, dtype=np.float64)
+        m_dev, m_const = None, None
+        if M.ndim == 3:
+            if M.shape != (nvox, dim, dim):
+                raise ValueError(f"per-voxel conductivity has shape {M.shape}, expected ({nvox}, {dim}, {dim})")
+            M9 = np.zeros((nvox, 3, 3))
+            M9[:, :dim, :dim] = M
+            m_dev = ctx.from_numpy(M9.reshape(nvox, 9))
+        else:
+            m_const = np.zeros((3, 3))
+            m_const[:dim, :dim] = _stencil.conductivity_matrix(M, dim)
+        a_dev = None
+        if active is not None:
+            active = np.asarray(active, dtype=bool).ravel()
+            if active.size != nvox:
+                raise ValueError(f"active mask has {active.size} entries for {nvox} voxels")
+            a_dev = ctx.from_numpy(active.astype(np.uint8))
+        nx, ny, nz = (int(v) for v in shape_local)
+        n = nx * ny * nz
+        mass = ctx.torch.empty((15, n), dtype=ctx.torch.float64, device=ctx.device)
+        stiff = ctx.torch.empty((15, n), dtype=ctx.torch.float64, device=ctx.device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        _hip.check(ctx.lib.beat_pde_assemble_rows(
+            ctx.handle, (C.c_int64 * 3)(nx, ny, nz), (C.c_int64 * 3)(*c3), int(z0),
+            T.ctypes.data_as(C.c_void_p), Me.ctypes.data_as(C.c_void_p), ptr(m_dev),
+            None if m_const is None else m_const.ctypes.data_as(C.c_void_p), ptr(a_dev), ptr(mass), ptr(stiff), n))
+        return cls(ctx, shape_local, lo_phys, hi_phys, mass, stiff, per_node=True)
 
     # -- field helpers ----------------------------------------------------------------------
     def new_field(self):

@@ -183,3 +183,28 @@ def stencil_fields(dim: int, cells: tuple[int, ...], h, M, active=None, z_range=
         mass = mass[:, lo : lo + (z1 - z0)]
         stiff = stiff[:, lo : lo + (z1 - z0)]
     return (np.ascontiguousarray(mass.reshape(15, -1)), np.ascontiguousarray(stiff.reshape(15, -1)))
+
+
+def voxel_element_tensors(dim: int, h) -> tuple[np.ndarray, np.ndarray]:
+    """(T, Me) for the device-side row assembly (beat_pde_assemble_rows): T[a, b, 3*i + j] such that a voxel's
+    element stiffness matrix is K_e[a, b] = sum_ij T[a, b, 3i+j] M_ij, and the voxel's element mass matrix Me;
+    corners beyond 2^dim and tensor components beyond dim are zero-padded."""
+    h = tuple(float(v) for v in np.atleast_1d(h))[:dim]
+    d = dim
+    T = np.zeros((8, 8, 9))
+    Me = np.zeros((8, 8))
+    corners = np.array([[(k >> a) & 1 for a in range(d)] for k in range(2**d)], dtype=np.float64) * np.asarray(h)
+    fact = float(np.prod(np.arange(1, d + 1)))
+    for s in _SIMPLICES[d]:
+        X = corners[list(s)]
+        A = np.hstack([np.ones((d + 1, 1)), X])
+        vol = abs(np.linalg.det(A)) / fact
+        G = np.linalg.inv(A)[1:, :].T  # (d+1, d)
+        me = vol / ((d + 1) * (d + 2)) * (np.ones((d + 1, d + 1)) + np.eye(d + 1))
+        for ia, ca in enumerate(s):
+            for ib, cb in enumerate(s):
+                Me[ca, cb] += me[ia, ib]
+                for i in range(d):
+                    for j in range(d):
+                        T[ca, cb, 3 * i + j] += vol * G[ia, i] * G[ib, j]
+    return T, Me

@@ -358,9 +358,11 @@ class Mesh:
         self.simplices_per_cell = {1: 1, 2: 2, 3: 6}[self.dim]
         self.num_box_cells = int(np.prod(self.n))
         self.active = None  # bool per simplex (global numbering) or None = every cell
+        self.active_box = None  # the same per box cell when the mask was given per box cell (voxels)
         if active is not None:
             active = np.asarray(active, dtype=bool).ravel()
             if active.size == self.num_box_cells:
+                self.active_box = active
                 active = np.repeat(active, self.simplices_per_cell)
             if active.size != self.num_box_cells * self.simplices_per_cell:
                 raise ValueError(f"active mask has {active.size} entries for {self.num_box_cells} box cells")

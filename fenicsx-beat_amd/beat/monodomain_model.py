@@ -53,7 +53,13 @@ class MonodomainModel(BaseModel):
         mesh = self._mesh
         M = self._conductivity()
         slab = mesh.slab
-        if M.ndim == 3 or mesh.active is not None:
+        per_voxel = (M.ndim == 2 or M.shape[0] == mesh.num_box_cells) and (mesh.active is None or mesh.active_box is not None)
+        if (M.ndim == 3 or mesh.active is not None) and per_voxel:
+            # data per box cell (voxel): rows assembled on the device
+            self._ops = HipOps.from_voxels(self._ctx, mesh.dim, mesh.n, mesh.h, M, mesh.active_box, mesh.shape_local,
+                                           slab.z0, slab.lo_phys, slab.hi_phys)
+        elif M.ndim == 3 or mesh.active is not None:
+            # data per simplex: rows assembled on the host (NumPy), then uploaded
             z_range = (slab.z0, slab.z1) if mesh.dim == 3 else None
             mass, stiff = _stencil.stencil_fields(mesh.dim, mesh.n, mesh.h, M, mesh.active, z_range=z_range)
             self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass, stiff, per_node=True)

@@ -639,6 +639,76 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_form_A_kernel(int64_t n, int64
   }
 }
 
+
+// Assembly of the per-node rows on the device from per-voxel data (replaces dolfinx assemble_matrix of
+// base_model.py:114-124 for voxelised geometries).  A voxel's 8x8 element stiffness matrix is linear in its
+// conductivity tensor, K_e[a][b] = sum_ij T[a][b][i][j] M_ij with T fixed by the cell size and the 6-tet
+// subdivision; node i gathers, from the <= 8 active voxels around it, the entries K_e[a][b] (a = its corner in
+// that voxel) into the stencil slot of corner b - corner a.  One thread per node, coalesced row writes.
+struct AsmArgs {
+  int nx, ny, nz;       // local nodes
+  int cx, cy, cz;       // global voxels per axis (1 for unused axes)
+  int z0;               // global plane index of local plane 0
+  const double* T;      // device, [8][8][9]
+  const double* Me;     // device, [8][8] element mass
+  const double* M;      // device (nvox, 9) or nullptr
+  double Mc[9];         // constant tensor when M == nullptr
+  const unsigned char* active;  // device (nvox) or nullptr
+  int64_t ld;
+  double* mass;
+  double* stiff;
+  signed char slot[64];  // stencil slot of (a, b), -1 if corner b - corner a is not a stencil offset
+};
+
+__global__ __launch_bounds__(BEAT_BLOCK) void assemble_rows_kernel(AsmArgs a) {
+  __shared__ double sT[8 * 8 * 9];
+  __shared__ double sMe[64];
+  for (int k = threadIdx.x; k < 8 * 8 * 9; k += BEAT_BLOCK) sT[k] = a.T[k];
+  if (threadIdx.x < 64) sMe[threadIdx.x] = a.Me[threadIdx.x];
+  __syncthreads();
+  const int64_t n = (int64_t)a.nx * a.ny * a.nz;
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
+    const int ix = (int)(i % a.nx);
+    const int iy = (int)((i / a.nx) % a.ny);
+    const int iz = (int)(i / ((int64_t)a.nx * a.ny)) + a.z0;
+    double km[15], kk[15];
+#pragma unroll
+    for (int s = 0; s < 15; ++s) km[s] = kk[s] = 0.0;
+    for (int c = 0; c < 8; ++c) {
+      // voxel whose corner `c` is this node
+      const int vx = ix - (c & 1), vy = iy - ((c >> 1) & 1), vz = iz - ((c >> 2) & 1);
+      if (vx < 0 || vx >= a.cx || vy < 0 || vy >= a.cy || vz < 0 || vz >= a.cz) continue;
+      const int64_t v = vx + (int64_t)a.cx * (vy + (int64_t)a.cy * vz);
+      if (a.active != nullptr && a.active[v] == 0) continue;
+      double m[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) m[q] = a.M != nullptr ? a.M[v * 9 + q] : a.Mc[q];
+      for (int b = 0; b < 8; ++b) {
+        const int s = a.slot[c * 8 + b];
+        if (s < 0) continue;
+        const double* t = sT + (c * 8 + b) * 9;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc = fma(t[q], m[q], acc);
+        // runtime slot index: select into the register arrays without dynamic indexing
+#pragma unroll
+        for (int u = 0; u < 15; ++u) {
+          if (u == s) {
+            kk[u] += acc;
+            km[u] += sMe[c * 8 + b];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 15; ++s) {
+      a.mass[(int64_t)s * a.ld + i] = km[s];
+      a.stiff[(int64_t)s * a.ld + i] = kk[s];
+    }
+  }
+}
+
 }  // namespace
 
 struct beat_pde {
@@ -798,6 +868,61 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     return BEAT_EHIP;
   }
   *out = p;
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_assemble_rows(beat_ctx* ctx, const int64_t n[3], const int64_t cells[3], int64_t z0,
+                                      const double* host_T, const double* host_Me, const double* dev_M,
+                                      const double* host_M_const, const unsigned char* dev_active,
+                                      double* dev_mass, double* dev_stiff, int64_t ld) {
+  BEAT_REQUIRE(ctx && n && cells && host_T && host_Me && dev_mass && dev_stiff, "null argument");
+  BEAT_REQUIRE(dev_M != nullptr || host_M_const != nullptr, "no conductivity given");
+  BEAT_REQUIRE(n[0] >= 1 && n[1] >= 1 && n[2] >= 1 && ld >= n[0] * n[1] * n[2], "bad sizes");
+  BEAT_REQUIRE(n[0] * n[1] * n[2] < ((int64_t)1 << 40) && cells[0] * cells[1] * cells[2] < ((int64_t)1 << 40),
+               "grid too large");
+  AsmArgs a{};
+  a.nx = (int)n[0];
+  a.ny = (int)n[1];
+  a.nz = (int)n[2];
+  a.cx = (int)cells[0];
+  a.cy = (int)cells[1];
+  a.cz = (int)cells[2];
+  a.z0 = (int)z0;
+  a.M = dev_M;
+  if (host_M_const)
+    for (int q = 0; q < 9; ++q) a.Mc[q] = host_M_const[q];
+  a.active = dev_active;
+  a.ld = ld;
+  a.mass = dev_mass;
+  a.stiff = dev_stiff;
+  for (int ca = 0; ca < 8; ++ca)
+    for (int cb = 0; cb < 8; ++cb) {
+      const int d[3] = {(cb & 1) - (ca & 1), ((cb >> 1) & 1) - ((ca >> 1) & 1), ((cb >> 2) & 1) - ((ca >> 2) & 1)};
+      int slot = -1;
+      for (int k = 0; k < 15; ++k)
+        if (kOffsets[3 * k] == d[0] && kOffsets[3 * k + 1] == d[1] && kOffsets[3 * k + 2] == d[2]) slot = k;
+      a.slot[ca * 8 + cb] = (signed char)slot;
+    }
+  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
+  double* d_t = nullptr;
+  BEAT_HIP_CHECK(hipMalloc(&d_t, sizeof(double) * (8 * 8 * 9 + 64)));
+  hipError_t e = hipMemcpyAsync(d_t, host_T, sizeof(double) * 8 * 8 * 9, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_t + 8 * 8 * 9, host_Me, sizeof(double) * 64, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    a.T = d_t;
+    a.Me = d_t + 8 * 8 * 9;
+    const int64_t nn = n[0] * n[1] * n[2];
+    const unsigned grid = (unsigned)std::min<int64_t>(8192, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, a);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host tensors and d_t go out of scope
+  }
+  (void)hipFree(d_t);
+  if (e != hipSuccess) {
+    beat_set_error("beat_pde_assemble_rows: %s", hipGetErrorString(e));
+    return BEAT_EHIP;
+  }
   return BEAT_OK;
 }
 

@@ -138,6 +138,19 @@ int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_p
  *               touched by any active element) is treated as an identity row by every operator.
  * All other beat_pde_* entry points work unchanged on such a handle (the polynomial preconditioner is
  * Jacobi-only there). */
+/* Device-side assembly of such rows from per-voxel data: every voxel (box cell) is split into simplices as in
+ * geometry.py:121-139 and carries a conductivity tensor and an in/out flag.
+ *  n[3]     : local nodes of the slab;  cells[3]: GLOBAL voxels per axis (1 for unused axes);
+ *  z0       : global plane index of the slab's first plane
+ *  host_T   : [8][8][9] element tensor, K_e[a][b] = sum_ij T[a][b][3i+j] M_ij (corner k at offsets
+ *             (k&1, (k>>1)&1, (k>>2)&1));  host_Me: [8][8] element mass matrix of one voxel
+ *  dev_M    : DEVICE (nvoxels, 9) row-major tensors, or NULL to use the constant host_M_const[9]
+ *  dev_active : DEVICE (nvoxels) bytes, 0 = outside the tissue, or NULL (all inside)
+ *  dev_mass / dev_stiff : DEVICE (15, ld) outputs.  Synchronises. */
+int beat_pde_assemble_rows(beat_ctx* ctx, const int64_t n[3], const int64_t cells[3], int64_t z0,
+                           const double* host_T, const double* host_Me, const double* dev_M,
+                           const double* host_M_const, const unsigned char* dev_active,
+                           double* dev_mass, double* dev_stiff, int64_t ld);
 int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
                         const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out);
 int beat_pde_destroy(beat_pde* pde);

@@ -396,3 +396,34 @@ def test_voxel_shell_torord_celltypes_runs():
     assert v[active].max() > 0.0 and v[active].min() < -80.0 and np.all(v[~active] == 0.0)
     for k in keys:
         assert np.isfinite(ode.values(k)).all()
+
+
+@pytest.mark.parametrize("cells,h", [((22, 17, 13), (0.1, 0.12, 0.09)), ((40, 31), (0.05, 0.04)), ((15,), (0.1,))])
+def test_device_row_assembly_equals_host_assembly(hip_ctx, cells, h):
+    """beat_pde_assemble_rows (per-voxel tensors + mask, on the device) vs _stencil.stencil_fields (NumPy, itself
+    checked against the oracle's assembly in test_stencil_tables.py): identical up to summation order; also for a
+    z-slab of the grid and for a constant tensor without mask."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    ctx = hip_ctx
+    dim = len(cells)
+    L = tuple(c * hh for c, hh in zip(cells, h))
+    active, M = _shell_case(cells, L, 7)
+    nn = [c + 1 for c in cells] + [1] * (3 - dim)
+    mf, kf = _stencil.stencil_fields(dim, cells, h, M, active)
+    ops = HipOps.from_voxels(ctx, dim, cells, h, M, active, nn, 0, True, True)
+    scale_k = np.abs(kf).max()
+    np.testing.assert_allclose(ops._mass_dev.cpu().numpy(), mf, rtol=0, atol=1e-15 * np.abs(mf).max())
+    np.testing.assert_allclose(ops._stiff_dev.cpu().numpy(), kf, rtol=0, atol=1e-14 * scale_k)
+    if dim == 3:
+        z0, z1 = 4, 9
+        ops = HipOps.from_voxels(ctx, dim, cells, h, M, active, (nn[0], nn[1], z1 - z0), z0, False, False)
+        pl = nn[0] * nn[1]
+        np.testing.assert_allclose(ops._stiff_dev.cpu().numpy(), kf[:, z0 * pl : z1 * pl], rtol=0, atol=1e-14 * scale_k)
+        np.testing.assert_allclose(ops._mass_dev.cpu().numpy(), mf[:, z0 * pl : z1 * pl], rtol=0, atol=1e-15 * np.abs(mf).max())
+    Mc = M[len(M) // 2]
+    mf, kf = _stencil.stencil_fields(dim, cells, h, Mc)
+    ops = HipOps.from_voxels(ctx, dim, cells, h, Mc, None, nn, 0, True, True)
+    np.testing.assert_allclose(ops._stiff_dev.cpu().numpy(), kf, rtol=0, atol=1e-14 * np.abs(kf).max())
+    np.testing.assert_allclose(ops._mass_dev.cpu().numpy(), mf, rtol=0, atol=1e-15 * np.abs(mf).max())
