@@ -562,6 +562,9 @@ struct VarArgs {
   const double* st;
   int64_t i_lo, i_hi;  // node range of this launch
   int doff[15];        // linear offsets of the 15 stencil points
+  const int* seg;      // active 256-node segments covering [i_lo, i_hi) (nullptr: every node of the range)
+  int nseg;
+  const double* mdiag; // RHS: mass diagonal (0 = node outside the tissue)
 };
 
 template <int MODE>
@@ -571,8 +574,12 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
     if (a.st[STOP] != 0.0) return;
   }
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
-  for (int64_t i = a.i_lo + (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < a.i_hi; i += stride) {
+  // Work items: the 256-node segments that hold at least one tissue node (list built at create time); segments
+  // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
+  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const int64_t i = (a.seg ? (int64_t)a.seg[w] * BEAT_BLOCK : a.i_lo + w * BEAT_BLOCK) + threadIdx.x;
+    if (i < a.i_lo || i >= a.i_hi) continue;
     double s1 = 0.0, s2 = 0.0;
     double xc = 0.0;
 #pragma unroll
@@ -595,11 +602,10 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       double stim = 0.0;
       for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
       const double r = a.dt * (stim - s2);
-      const double b = s1 + r;
+      const double b = a.mdiag[i] != 0.0 ? s1 + r : 0.0;  // nodes outside the tissue are not part of the system
       const double zz = a.dinv[i] * r;
       a.y[i] = r;
       a.y2[i] = zz;
-      if (a.y3 != nullptr) a.y3[i] = xc;
       acc0 = fma(b, b, acc0);
       acc1 = fma(r, zz, acc1);
       acc2 = fma(r, r, acc2);
@@ -617,6 +623,87 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       a.partials[BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s1;
       a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
     }
+  }
+}
+
+// PCG vector updates over the active segments (per-node 1/diag)
+__global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+                                                                  const double* __restrict__ st,
+                                                                  double* __restrict__ r, const double* __restrict__ q,
+                                                                  const double* __restrict__ dinv,
+                                                                  double* __restrict__ partials,
+                                                                  double* __restrict__ alphas, int slot) {
+  __shared__ double red[4];
+  if (st[STOP] != 0.0) return;
+  const double alpha = st[RZ] / st[PQ];
+  if (blockIdx.x == 0 && threadIdx.x == 0) alphas[slot] = alpha;
+  double s_rz = 0.0, s_rr = 0.0;
+  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
+    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+    if (i >= n) continue;
+    const double ri = fma(-alpha, q[i], r[i]);
+    r[i] = ri;
+    s_rz = fma(ri * dinv[i], ri, s_rz);
+    s_rr = fma(ri, ri, s_rr);
+  }
+  const double a0 = beat_block_sum(s_rz, red);
+  const double a1 = beat_block_sum(s_rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = a0;
+    partials[BEAT_MAX_PARTIALS + blockIdx.x] = a1;
+  }
+}
+
+__global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+                                                                     const double* __restrict__ st,
+                                                                     const double* __restrict__ r,
+                                                                     const double* __restrict__ p_old,
+                                                                     double* __restrict__ p_new,
+                                                                     const double* __restrict__ dinv) {
+  if (st[STOP] != 0.0) return;
+  const double beta = st[BETA];
+  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
+    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+    if (i >= n) continue;
+    p_new[i] = fma(beta, p_old[i], dinv[i] * r[i]);
+  }
+}
+
+__global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+                                                               const double* __restrict__ st, double* __restrict__ x,
+                                                               const double* __restrict__ ring, int64_t fld,
+                                                               const double* __restrict__ alphas, int ring_base,
+                                                               int only_if_full) {
+  int nvalid = (int)st[NUPD] - ring_base;
+  nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
+  if (nvalid == 0 || (only_if_full && nvalid < PRING)) return;
+  double a[PRING];
+#pragma unroll
+  for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
+  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
+    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+    if (i >= n) continue;
+    double xi = x[i];
+#pragma unroll
+    for (int j = 0; j < PRING; ++j)
+      if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
+    x[i] = xi;
+  }
+}
+
+// flags[s] = 1 if segment s holds a node touched by an element (mass diagonal > 0)
+__global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n, const double* __restrict__ mass_diag,
+                                                                       unsigned char* __restrict__ flags) {
+  __shared__ int any;
+  const int64_t nsegs = (n + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  for (int64_t s = blockIdx.x; s < nsegs; s += gridDim.x) {
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const int64_t i = s * BEAT_BLOCK + threadIdx.x;
+    if (i < n && mass_diag[i] != 0.0) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[s] = (unsigned char)any;
+    __syncthreads();
   }
 }
 
@@ -734,6 +821,8 @@ struct beat_pde {
   double* v_A = nullptr;
   double* v_dinv = nullptr;
   int64_t v_ld = 0;
+  int* v_seg = nullptr;        // device: indices of the 256-node segments that hold tissue nodes (ascending)
+  std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
   const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * TABW; }
   const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }
@@ -827,17 +916,47 @@ static void var_offsets(const beat_pde* pde, VarArgs& a) {
   a.ld = pde->v_ld;
 }
 
-// launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on
+// Work of a launch over planes [z_lo, z_hi): the sub-list of active segments intersecting the range and the grid
+// (= number of block partials the launch writes).
+struct VarRange {
+  const int* seg;
+  int nseg;
+  unsigned grid;
+};
+static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
+  VarRange r{nullptr, 0, 0};
+  if (z_hi <= z_lo) return r;
+  const int64_t i_lo = (int64_t)z_lo * pde->g.plane, i_hi = (int64_t)z_hi * pde->g.plane;
+  int64_t nwork = (i_hi - i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  if (!dense) {
+    const int s_lo = (int)(i_lo / BEAT_BLOCK), s_hi = (int)((i_hi + BEAT_BLOCK - 1) / BEAT_BLOCK);
+    const auto lo = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_lo);
+    const auto hi = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_hi);
+    r.seg = pde->v_seg + (lo - pde->h_seg.begin());
+    r.nseg = (int)(hi - lo);
+    nwork = r.nseg;
+  }
+  r.grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, nwork));
+  return r;
+}
+
+// launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on.
+// `dense` ignores the segment list (APPLY must write every node of y).
 template <int MODE>
-static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int part_off) {
+static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int part_off, bool dense = false) {
   if (z_hi <= z_lo) return 0;
+  const VarRange r = var_range(pde, z_lo, z_hi, dense);
   a.i_lo = (int64_t)z_lo * pde->g.plane;
   a.i_hi = (int64_t)z_hi * pde->g.plane;
   a.part_off = part_off;
-  const int64_t nodes = a.i_hi - a.i_lo;
-  const unsigned grid = (unsigned)std::min<int64_t>(4096, (nodes + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
-  return (int)grid;
+  a.seg = r.seg;
+  a.nseg = r.nseg;
+  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(r.grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+  return (int)r.grid;
+}
+
+static unsigned var_vec_grid(const beat_pde* pde) {
+  return (unsigned)std::min<size_t>(4096, std::max<size_t>(1, pde->h_seg.size()));
 }
 
 static int var_form_A(beat_pde* pde) {
@@ -865,6 +984,31 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
       hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess) {
     beat_pde_destroy(p);
     beat_set_error("out of device memory for the %lld-node coefficient rows", (long long)ld);
+    return BEAT_EHIP;
+  }
+  // list of the 256-node segments that hold tissue nodes
+  const int64_t nsegs = (p->n + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  unsigned char* d_flags = nullptr;
+  std::vector<unsigned char> flags((size_t)nsegs);
+  hipError_t e = hipMalloc(&d_flags, (size_t)nsegs);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, nsegs)), dim3(BEAT_BLOCK), 0,
+                       ctx->stream, p->n, dev_mass, d_flags);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, (size_t)nsegs, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_flags);
+  if (e == hipSuccess) {
+    for (int64_t sidx = 0; sidx < nsegs; ++sidx)
+      if (flags[(size_t)sidx]) p->h_seg.push_back((int)sidx);
+    e = hipMalloc(&p->v_seg, sizeof(int) * std::max<size_t>(1, p->h_seg.size()));
+  }
+  if (e == hipSuccess && !p->h_seg.empty())
+    e = hipMemcpy(p->v_seg, p->h_seg.data(), sizeof(int) * p->h_seg.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    beat_pde_destroy(p);
+    beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
     return BEAT_EHIP;
   }
   *out = p;
@@ -933,6 +1077,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->d_alphas);
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
+  (void)hipFree(pde->v_seg);
   delete pde;
   return BEAT_OK;
 }
@@ -1026,7 +1171,7 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
     } else {
       a.T1 = which == 2 ? pde->v_mass : pde->v_stiff;
     }
-    launch_var<MODE_APPLY>(pde, a, 0, pde->g.nz, 0);
+    launch_var<MODE_APPLY>(pde, a, 0, pde->g.nz, 0, /*dense=*/true);
     BEAT_LAUNCH_CHECK();
     return BEAT_OK;
   }
@@ -1064,8 +1209,12 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
     a.x = dev_v_prev;
     a.y = dev_r;
     a.y2 = dev_p;
-    a.y3 = (dev_x == dev_v_prev) ? nullptr : dev_x;
+    a.y3 = nullptr;
+    if (dev_x != dev_v_prev)  // nodes outside the tissue keep their value: copy everything first
+      BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice,
+                                    pde->ctx->stream));
     a.dinv = pde->v_dinv;
+    a.mdiag = pde->v_mass;
     a.dt = pde->dt;
     for (int k = 0; k < n_stim; ++k) {
       if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
@@ -1160,8 +1309,7 @@ extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double
       BEAT_LAUNCH_CHECK();
       return BEAT_OK;
     }
-    const int64_t inner = (int64_t)std::max(0, std::max(lo, hi) - lo) * f.plane;
-    int off = (int)std::min<int64_t>(4096, (inner + BEAT_BLOCK - 1) / BEAT_BLOCK);
+    int off = (int)var_range(pde, lo, std::max(lo, hi), false).grid;  // partial slots of the interior launch (part 0)
     if (!f.z_lo_phys) off += launch_var<MODE_SPMV_DOT>(pde, a, 0, 1, off);
     if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch_var<MODE_SPMV_DOT>(pde, a, f.nz - 1, f.nz, off);
     BEAT_LAUNCH_CHECK();
@@ -1287,15 +1435,6 @@ extern "C" int beat_pde_work_fields(beat_pde* pde) {
   return pde ? 3 + PRING : BEAT_EINVAL;  // r, q, z + the ring of search directions
 }
 
-static int launch_flush(beat_pde* pde, double* x, const double* ring, int64_t fld, int ring_base,
-                        int only_if_full) {
-  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
-                     (const double*)pde->d_st, x, ring, fld, (const double*)pde->d_alphas, ring_base, only_if_full);
-  BEAT_LAUNCH_CHECK();
-  return BEAT_OK;
-}
-
 // ---- deferred-x stages for callers that drive the iteration themselves (slab-decomposed solve) ----------
 extern "C" int beat_pde_ring_size(void) { return PRING; }
 
@@ -1304,6 +1443,14 @@ extern "C" int beat_pde_ring_size(void) { return PRING; }
 extern "C" int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_q, "null argument");
   BEAT_REQUIRE(slot >= 0 && slot < PRING, "slot %d out of range", slot);
+  if (pde->var) {
+    const unsigned grid = var_vec_grid(pde);
+    hipLaunchKernelGGL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg,
+                       (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_q, (const double*)pde->v_dinv,
+                       pde->ctx->d_partials, pde->d_alphas, slot);
+    BEAT_LAUNCH_CHECK();
+    return launch_reduce(pde, (int)grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
+  }
   BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_q, pde->dinv_arg(), pde->h_dinv[13], pde->ctx->d_partials,
                      pde->d_alphas, slot);
@@ -1318,6 +1465,13 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
   BEAT_REQUIRE(dev_p_cur != dev_p_next, "the p-update is out of place");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
+  if (pde->var) {
+    hipLaunchKernelGGL(var_pupdate_oop_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+                       (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_p_cur,
+                       dev_p_next, (const double*)pde->v_dinv);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
   BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_p_cur, dev_p_next, pde->dinv_arg(), pde->h_dinv[13]);
   BEAT_LAUNCH_CHECK();
@@ -1329,6 +1483,13 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
 extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
                                 int64_t field_stride, int ring_base, int only_if_full) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_ring0, "null argument");
+  if (pde->var) {
+    hipLaunchKernelGGL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+                       (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
+                       (const double*)pde->d_alphas, ring_base, only_if_full);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
                      dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full);
@@ -1387,20 +1548,11 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
         double* p_cur = ring + (int64_t)slot * fld;
         double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
         if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
-        BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
-                           (const double*)st, r, (const double*)q, pde->dinv_arg(), pde->h_dinv[13],
-                           ctx->d_partials, pde->d_alphas, slot);
-        BEAT_LAUNCH_CHECK();
-        if ((rc = launch_reduce(pde, (int)pde->vec_grid, 2, st + RZN, st, st + NUPD))) return rc;
+        if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
         if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
-          if ((rc = launch_flush(pde, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
         }
-        hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, ctx->stream, st);
-        BEAT_LAUNCH_CHECK();
-        BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, ctx->stream, pde->g,
-                           (const double*)st, (const double*)r, (const double*)p_cur, p_next, pde->dinv_arg(),
-                           pde->h_dinv[13]);
-        BEAT_LAUNCH_CHECK();
+        if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
       }
       launched += chunk;
       BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1411,7 +1563,7 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
     // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x)
     const int nupd = (int)h[NUPD];
     if (nupd % PRING != 0)
-      if ((rc = launch_flush(pde, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) return rc;
+      if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) return rc;
   }
   const int iters = (int)h[ITERS];
   pde->last_iters = iters;

@@ -49,7 +49,13 @@ def main():
     rng = torch.Generator(device=ctx.device)
     rng.manual_seed(1)
     v = ops.new_field()
-    v.data.copy_(-85.0 + 100.0 * torch.rand(N, generator=rng, device=ctx.device, dtype=torch.float64))
+    # smooth depolarised region + 1 % noise on the tissue nodes, 0 outside (as the split step leaves it)
+    idx = torch.arange(N, device=ctx.device, dtype=torch.float64)
+    xs, zs = (idx % nn) / nn, torch.div(idx, nn * nn, rounding_mode="floor") / nn
+    bump = 100.0 * torch.exp(-((xs - 0.2) ** 2 + (zs - 0.4) ** 2) / 0.02)
+    noise = 0.01 * torch.rand(N, generator=rng, device=ctx.device, dtype=torch.float64)
+    v.data.copy_(torch.where(ops._mass_dev[0] > 0, -85.0 + bump + noise, torch.zeros_like(idx)))
+    del idx, xs, zs, bump, noise
     ops.p.data.copy_(v.data)
     y = ops.new_field()
 
