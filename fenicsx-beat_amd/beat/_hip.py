@@ -66,6 +66,7 @@ SIGNATURES = {
     "beat_scatter": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "beat_pde_create": (_int, [_vp, C.POINTER(_i64), _int, _int, _vp, _vp, C.POINTER(_vp)]),
     "beat_pde_assemble_rows": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "beat_rows_apply_dirichlet": (_int, [_vp, C.POINTER(_i64), _vp, _i64, _vp, _vp, _vp]),
     "beat_pde_create_var": (_int, [_vp, C.POINTER(_i64), _int, _int, _vp, _vp, _i64, C.POINTER(_vp)]),
     "beat_pde_destroy": (_int, [_vp]),
     "beat_stencil_offsets": (C.POINTER(_int), []),

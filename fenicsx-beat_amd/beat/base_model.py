@@ -12,7 +12,7 @@ from typing import Any, Literal, NamedTuple, Sequence
 import numpy as np
 
 from . import grid
-from .stimulation import Stimulus, assemble_weights
+from .stimulation import Stimulus, assemble_facet_weights, assemble_weights
 from .telemetry import BaseMonitor, NullMonitor
 
 logger = logging.getLogger(__name__)
@@ -46,13 +46,22 @@ class _CompiledStimulus:
         self.stim = stim
         mesh = model._mesh
         expr = grid.as_expr(stim.expr)
-        self.cells = stim.dz.cells()
+        measure = stim.dz
+        self.facets = measure.facets() if measure.integral_type == "ds" else None
+        self.cells = None if self.facets is not None else measure.cells()
         self.zero = isinstance(expr, grid.Literal) and expr.value == 0.0
         sep = grid.separate(expr)
         self.field = None
         self.general = None
         if self.zero:
             self.amplitude = lambda: 0.0
+        elif self.facets is not None:
+            if sep is None or sep[0] is not None:
+                raise NotImplementedError("coordinate-dependent surface stimuli are not implemented")
+            temporal = sep[1]
+            self.field = model._ctx.field(mesh.num_nodes, mesh.plane)
+            self.field.set(assemble_facet_weights(mesh, self.facets))
+            self.amplitude = (lambda: 1.0) if temporal is None else (lambda: float(temporal.evaluate()))
         elif sep is not None:
             spatial, temporal = sep
             self.field = model._ctx.field(mesh.num_nodes, mesh.plane)

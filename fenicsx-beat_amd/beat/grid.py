@@ -427,6 +427,71 @@ class Mesh:
             return np.nonzero(self.active)[0].astype(np.int64)
         return np.arange(self.num_cells_global, dtype=np.int64)
 
+    # ---- facets (faces of box cells; only the exterior ones are ever needed) ------------------------
+    # facet id = box_cell * 2*dim + 2*axis + side: the face of that box cell normal to `axis` on its low
+    # (side 0) or high (side 1) end.  On the simplicial mesh such a face is 1 edge (2-D) or 2 triangles
+    # (3-D) split along the diagonal from its lowest to its highest corner (geometry.py:121-139).
+    def _box_active(self) -> np.ndarray:
+        d = self.dim
+        shape = tuple(reversed(self.n))
+        if self.active is None:
+            return np.ones(shape, dtype=bool)
+        if self.active_box is not None:
+            return self.active_box.reshape(shape)
+        per = self.active.reshape(shape + (self.simplices_per_cell,))
+        if not (per.all(axis=-1) | ~per.any(axis=-1)).all():
+            raise NotImplementedError("facets of a mesh whose mask cuts through box cells")
+        return per.all(axis=-1)
+
+    def exterior_facets(self) -> np.ndarray:
+        """ids of the faces of active box cells whose other side is outside the (active) domain."""
+        d = self.dim
+        act = self._box_active()
+        pad = np.pad(act, 1, constant_values=False)
+        ids = []
+        box = np.arange(self.num_box_cells, dtype=np.int64).reshape(act.shape)
+        for axis in range(d):
+            npax = d - 1 - axis  # numpy axis of the array (z, y, x order)
+            for side in (0, 1):
+                sl = [slice(1, -1)] * d
+                sl[npax] = slice(0, -2) if side == 0 else slice(2, None)
+                ext = act & ~pad[tuple(sl)]
+                ids.append(box[ext] * (2 * d) + 2 * axis + side)
+        return np.sort(np.concatenate(ids))
+
+    def facet_vertices(self, facet_ids: np.ndarray) -> np.ndarray:
+        """(len, 2^(dim-1)) GLOBAL node ids of the facets' corners, lowest corner id first."""
+        facet_ids = np.asarray(facet_ids, dtype=np.int64)
+        d = self.dim
+        box, f = np.divmod(facet_ids, 2 * d)
+        axis, side = np.divmod(f, 2)
+        cx = self.n[0]
+        cy = self.n[1] if d >= 2 else 1
+        ix, iy, iz = box % cx, (box // cx) % cy, box // (cx * cy)
+        nx, ny = self.shape_global[0], self.shape_global[1]
+        out = np.zeros((len(facet_ids), 2 ** (d - 1)), dtype=np.int64)
+        for a in range(d):
+            sel = axis == a
+            if not sel.any():
+                continue
+            corners = [c for c in range(2**d)]
+            for s in (0, 1):
+                m = sel & (side == s)
+                if not m.any():
+                    continue
+                cs = [c for c in corners if ((c >> a) & 1) == s]
+                for j, c in enumerate(cs):
+                    ox, oy, oz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+                    out[m, j] = (ix[m] + ox) + nx * ((iy[m] + oy) + ny * (iz[m] + oz))
+        return out
+
+    def facet_area(self, facet_ids: np.ndarray) -> np.ndarray:
+        d = self.dim
+        axis = (np.asarray(facet_ids, dtype=np.int64) % (2 * d)) // 2
+        h = np.array(self.h)
+        full = float(np.prod(h))
+        return full / h[axis]
+
     def node_active(self, local: bool = True) -> np.ndarray:
         """bool per node: touched by at least one active cell (all True without a mask)."""
         nx, ny, nz = self.shape_global
@@ -517,8 +582,10 @@ def _require_simplex(cell_type, expected):
 def locate_entities(mesh: Mesh, dim: int, marker) -> np.ndarray:
     """Cells (``dim == mesh.topology.dim``) whose vertices ALL satisfy ``marker(x)``, x of shape
     (3, num_points) -- dolfinx.mesh.locate_entities semantics."""
+    if dim == mesh.topology.dim - 1:
+        return locate_entities_boundary(mesh, dim, marker)
     if dim != mesh.topology.dim:
-        raise NotImplementedError("only cell entities (dim == topological dimension) are implemented")
+        raise NotImplementedError("only cells and exterior facets are implemented")
     x = mesh.node_coordinates(pad3=True, local=False).T
     ok = np.asarray(marker(x), dtype=bool)
     if ok.shape == ():
@@ -528,6 +595,19 @@ def locate_entities(mesh: Mesh, dim: int, marker) -> np.ndarray:
     if mesh.active is not None:
         sel &= mesh.active
     return np.nonzero(sel)[0].astype(np.int32)
+
+
+def locate_entities_boundary(mesh: Mesh, dim: int, marker) -> np.ndarray:
+    """Exterior facets (``dim == mesh.topology.dim - 1``) whose vertices ALL satisfy ``marker(x)`` --
+    dolfinx.mesh.locate_entities_boundary semantics; ids as in Mesh.exterior_facets."""
+    if dim != mesh.topology.dim - 1:
+        raise NotImplementedError("only exterior facets (dim == topological dimension - 1) are implemented")
+    x = mesh.node_coordinates(pad3=True, local=False).T
+    ok = np.asarray(marker(x), dtype=bool)
+    if ok.shape == ():
+        ok = np.full(x.shape[1], bool(ok))
+    facets = mesh.exterior_facets()
+    return facets[ok[mesh.facet_vertices(facets)].all(axis=1)]
 
 
 @dataclass
@@ -553,8 +633,8 @@ class Measure:
     the integration domain to the cells carrying that tag."""
 
     def __init__(self, integral_type="dx", domain=None, subdomain_data=None, subdomain_id=None, metadata=None):
-        if integral_type != "dx":
-            raise NotImplementedError("only cell measures ('dx') are implemented")
+        if integral_type not in ("dx", "ds"):
+            raise NotImplementedError("only cell ('dx') and exterior-facet ('ds') measures are implemented")
         self.integral_type = integral_type
         self.domain = domain
         self.subdomain_data = subdomain_data
@@ -565,8 +645,20 @@ class Measure:
         return Measure(self.integral_type, domain or self.domain, self.subdomain_data, subdomain_id,
                        metadata or self.metadata)
 
+    def facets(self):
+        """Exterior facet ids to integrate over (``ds``)."""
+        if self.integral_type != "ds":
+            raise ValueError("not a facet measure")
+        if self.subdomain_id is None:
+            return self.domain.exterior_facets()
+        if self.subdomain_data is None:
+            raise ValueError("measure has a subdomain id but no subdomain_data")
+        return self.subdomain_data.find(self.subdomain_id)
+
     def cells(self):
         """Cell ids to integrate over, or None for the whole mesh."""
+        if self.integral_type != "dx":
+            raise ValueError("not a cell measure")
         if self.subdomain_id is None:
             return None
         if self.subdomain_data is None:
@@ -576,6 +668,10 @@ class Measure:
 
 def dx(domain=None, **kw):
     return Measure("dx", domain=domain, **kw)
+
+
+def ds(domain=None, **kw):
+    return Measure("ds", domain=domain, **kw)
 
 
 # ------------------------------------------------------------------------------------------------

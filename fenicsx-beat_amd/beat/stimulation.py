@@ -47,7 +47,7 @@ def get_dZ(mesh, subdomain_data) -> grid.Measure:
     if dim == mesh.topology.dim - 1:
         if mesh.topology.dim <= 1:
             raise ValueError("Invalid mesh topology dimension")
-        raise NotImplementedError("facet (surface) stimuli are not implemented on the HIP backend")
+        return grid.Measure("ds", domain=mesh, subdomain_data=subdomain_data)
     elif dim == mesh.topology.dim:
         return grid.Measure("dx", domain=mesh, subdomain_data=subdomain_data)
     raise ValueError("Invalid subdomain data dimension")
@@ -115,6 +115,28 @@ def _gauss_simplex(d: int, m: int = 5):
         lam = np.stack([1 - l1 - l2 - l3, l1, l2, l3], axis=-1).reshape(-1, 4)
         w = (wa * wb * wc * (1 - a) ** 2 * (1 - b)).ravel()
     return lam, w / w.sum()
+
+
+def assemble_facet_weights(mesh, facets) -> np.ndarray:
+    """Nodal weights  w_i = int_{facets} phi_i dS  on the LOCAL slab for exterior facets (stimulation.py:63-111,
+    the ``ds`` branch): an edge gives L/2 to both ends; a box-cell face is two triangles split along the diagonal
+    from its lowest to its highest corner, which therefore get A/3 each and the other two corners A/6."""
+    facets = np.asarray(facets, dtype=np.int64)
+    verts = mesh.facet_vertices(facets)
+    area = mesh.facet_area(facets)
+    if mesh.dim == 2:
+        share = np.array([0.5, 0.5])
+    elif mesh.dim == 3:
+        share = np.array([1.0 / 3.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 3.0])
+    else:
+        raise ValueError("facet integrals need a 2-D or 3-D mesh")
+    w = np.zeros(mesh.num_nodes)
+    lo, hi = mesh.slab.z0 * mesh.plane, mesh.slab.z1 * mesh.plane
+    v = verts.ravel()
+    c = (area[:, None] * share[None, :]).ravel()
+    sel = (v >= lo) & (v < hi)
+    np.add.at(w, v[sel] - lo, c[sel])
+    return w
 
 
 def assemble_weights(mesh, cells, spatial: grid.Expr | None, chunk: int = 1 << 18) -> np.ndarray:

@@ -796,6 +796,37 @@ __global__ __launch_bounds__(BEAT_BLOCK) void assemble_rows_kernel(AsmArgs a) {
   }
 }
 
+
+// Dirichlet conditions on per-node rows (symmetric elimination): flagged rows become identity, the couplings of
+// free rows to flagged nodes move to the right-hand side f.
+__global__ __launch_bounds__(BEAT_BLOCK) void rows_dirichlet_kernel(int64_t n, int64_t ld, double* __restrict__ rows,
+                                                                    const unsigned char* __restrict__ flag,
+                                                                    const double* __restrict__ g,
+                                                                    double* __restrict__ f, VarArgs offs) {
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
+    if (flag[i]) {
+      f[i] = g[i];
+      rows[i] = 1.0;
+#pragma unroll
+      for (int k = 1; k < 15; ++k) rows[(int64_t)k * ld + i] = 0.0;
+      continue;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 1; k < 15; ++k) {
+      const double c = rows[(int64_t)k * ld + i];
+      if (c == 0.0) continue;  // rows never couple outside the box, so i + doff is a valid node here
+      const int64_t j = i + offs.doff[k];
+      if (flag[j]) {
+        acc = fma(-c, g[j], acc);
+        rows[(int64_t)k * ld + i] = 0.0;
+      }
+    }
+    f[i] = acc;
+  }
+}
+
 }  // namespace
 
 struct beat_pde {
@@ -1012,6 +1043,21 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     return BEAT_EHIP;
   }
   *out = p;
+  return BEAT_OK;
+}
+
+extern "C" int beat_rows_apply_dirichlet(beat_ctx* ctx, const int64_t n[3], double* dev_rows, int64_t ld,
+                                         const unsigned char* dev_flag, const double* dev_g, double* dev_f) {
+  BEAT_REQUIRE(ctx && n && dev_rows && dev_flag && dev_g && dev_f, "null argument");
+  const int64_t nn = n[0] * n[1] * n[2];
+  BEAT_REQUIRE(nn >= 1 && ld >= nn && nn < ((int64_t)1 << 31), "bad sizes");
+  VarArgs offs{};
+  for (int k = 0; k < 15; ++k)
+    offs.doff[k] = kOffsets[3 * k] + (int)n[0] * kOffsets[3 * k + 1] + (int)(n[0] * n[1]) * kOffsets[3 * k + 2];
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(rows_dirichlet_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, nn, ld, dev_rows, dev_flag,
+                     dev_g, dev_f, offs);
+  BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
 

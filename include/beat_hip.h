@@ -151,6 +151,13 @@ int beat_pde_assemble_rows(beat_ctx* ctx, const int64_t n[3], const int64_t cell
                            const double* host_T, const double* host_Me, const double* dev_M,
                            const double* host_M_const, const unsigned char* dev_active,
                            double* dev_mass, double* dev_stiff, int64_t ld);
+/* Dirichlet conditions on per-node rows by symmetric elimination (dolfinx.fem.dirichletbc in the Laplace
+ * problems of utils.py:115-355, expand_layer / expand_layer_biv): rows of flagged nodes become identity rows,
+ * couplings of the other rows to flagged nodes are zeroed and moved to the right-hand side
+ *   dev_f[i] = dev_g[i] (flagged)  |  -sum_{j flagged} K_ij dev_g[j] (free).
+ * dev_rows (15, ld) is modified in place; dev_flag holds one byte per node.  Single slab (no ghost planes). */
+int beat_rows_apply_dirichlet(beat_ctx* ctx, const int64_t n[3], double* dev_rows, int64_t ld,
+                              const unsigned char* dev_flag, const double* dev_g, double* dev_f);
 int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
                         const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out);
 int beat_pde_destroy(beat_pde* pde);

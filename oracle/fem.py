@@ -193,6 +193,30 @@ def stimulus_weights(mesh: BoxMesh, cells: np.ndarray | None = None) -> np.ndarr
     return w
 
 
+def exterior_facet_weights(mesh: BoxMesh, active_cells=None, node_ok=None, facet_filter=None) -> np.ndarray:
+    """w_i = int_{exterior facets} phi_i dS (the ``ds`` measure of stimulation.py:63-111) from the simplicial
+    mesh itself: the facets of the (active) simplices that belong to exactly one of them; ``node_ok`` (bool per
+    node) keeps the facets whose vertices ALL satisfy it (dolfinx locate_entities_boundary)."""
+    d = mesh.dim
+    cells = mesh.cells if active_cells is None else mesh.cells[np.asarray(active_cells, dtype=bool)]
+    faces = np.concatenate([np.delete(cells, k, axis=1) for k in range(d + 1)], axis=0)
+    faces = np.sort(faces, axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    ext = uniq[counts == 1]
+    if node_ok is not None:
+        ext = ext[np.asarray(node_ok, dtype=bool)[ext].all(axis=1)]
+    if facet_filter is not None:  # callable on the facets' vertex coordinates (nf, d, dim) -> bool (nf,)
+        ext = ext[np.asarray(facet_filter(mesh.x[ext]), dtype=bool)]
+    X = mesh.x[ext]
+    if d == 2:
+        meas = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+    else:
+        meas = 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+    w = np.zeros(mesh.num_nodes)
+    np.add.at(w, ext.ravel(), np.repeat(meas / d, d))
+    return w
+
+
 # Degree-precision quadrature used only to integrate smooth manufactured sources and
 # L2 errors (the reference lets UFL pick a degree / uses quadrature_degree=8).
 def _simplex_quadrature(d: int, m: int = 6):

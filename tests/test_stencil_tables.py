@@ -127,3 +127,30 @@ def test_voxel_mesh_cells_and_nodes():
     assert np.isclose(w.sum(), mask.sum() * 1e-3)
     centres = g.cell_centers(mesh)
     assert centres.shape == (60, 3) and np.allclose(centres[0], 0.05) and np.allclose(centres[1], [0.15, 0.05, 0.05])
+
+
+def test_exterior_facet_weights_match_the_simplicial_mesh():
+    """ds weights from box-cell faces (two triangles along the lowest-to-highest-corner diagonal) equal the weights
+    computed from the exterior triangles / edges of the oracle's simplicial mesh: full box, voxel mask, and a
+    vertex predicate (locate_entities_boundary)."""
+    from beat import grid as g
+    from beat.stimulation import assemble_facet_weights
+
+    rng = np.random.default_rng(3)
+    for cells, h in (((4, 3, 5), (0.5, 0.25, 0.2)), ((6, 5), (0.3, 0.2))):
+        d = len(cells)
+        mask = rng.random(tuple(reversed(cells))) > 0.35
+        L = tuple(c * hh for c, hh in zip(cells, h))
+        omesh = fem.BoxMesh(cells, L)
+        spc = {2: 2, 3: 6}[d]
+        for m in (None, mask):
+            mesh = g.Mesh(cells, (0.0,) * d, L, active=None if m is None else m.ravel())
+            act = None if m is None else np.repeat(m.ravel(), spc)
+            w = assemble_facet_weights(mesh, mesh.exterior_facets())
+            np.testing.assert_allclose(w, fem.exterior_facet_weights(omesh, act), rtol=1e-13, atol=1e-16)
+            pred = lambda x: x[0] <= 0.6 * L[0]  # noqa: E731
+            facets = g.locate_entities_boundary(mesh, d - 1, pred)
+            xp = np.zeros((3, omesh.num_nodes))
+            xp[:d] = omesh.x.T
+            np.testing.assert_allclose(assemble_facet_weights(mesh, facets),
+                                       fem.exterior_facet_weights(omesh, act, pred(xp)), rtol=1e-13, atol=1e-16)

@@ -427,3 +427,98 @@ def test_device_row_assembly_equals_host_assembly(hip_ctx, cells, h):
     ops = HipOps.from_voxels(ctx, dim, cells, h, Mc, None, nn, 0, True, True)
     np.testing.assert_allclose(ops._stiff_dev.cpu().numpy(), kf, rtol=0, atol=1e-14 * np.abs(kf).max())
     np.testing.assert_allclose(ops._mass_dev.cpu().numpy(), mf, rtol=0, atol=1e-15 * np.abs(mf).max())
+
+
+def _shell_facet_tags(mesh, n, h):
+    """Tag the exterior facets of the voxel shell: 10 = endocardial (inner) surface, 20 = epicardial (outer), base
+    plane untagged.  Classified by the facet centre."""
+    from beat import grid as g
+
+    facets = mesh.exterior_facets()
+    xyz = g._node_xyz(mesh, mesh.facet_vertices(facets).ravel()).reshape(len(facets), -1, 3)
+    c = xyz.mean(axis=1)
+    ctr = np.array(n) * h / 2.0
+    semi_o = 0.48 * np.array(n) * h
+    semi_i = 0.62 * semi_o
+    ro = np.sqrt((((c - ctr) / semi_o) ** 2).sum(axis=1))
+    ri = np.sqrt((((c - ctr) / semi_i) ** 2).sum(axis=1))
+    base = np.ptp(xyz[:, :, 2], axis=1) < 1e-12
+    base &= np.abs(xyz[:, 0, 2] - np.floor(0.8 * n[2]) * h) < 0.51 * h
+    base &= (ri > 1.0) & (ro < 1.0)
+    values = np.where(base, 0, np.where(np.abs(ri - 1.0) < np.abs(ro - 1.0) * (1.0 / 0.62), 10, 20)).astype(np.int32)
+    keep = values > 0
+    return g.meshtags(mesh, 2, facets[keep], values[keep])
+
+
+def test_expand_layer_and_surface_stimulus_on_voxel_shell():
+    """utils.expand_layer on the voxel shell (Laplace solve with Dirichlet data on tagged surface facets, on the
+    device) against a sparse direct solve of the same P1 problem; a surface (ds) stimulus on the endocardial facets
+    assembles the same nodal weights as the oracle's exterior-triangle integration and depolarises that surface."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+    from oracle import fem
+
+    n, h = (26, 22, 18), 0.5
+    mask, depth, f0 = _shell_geometry(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    ft = _shell_facet_tags(mesh, n, h)
+    assert len(ft.find(10)) > 100 and len(ft.find(20)) > 100
+    V = g.functionspace(mesh, ("P", 1))
+    u = beat.utils.laplace_dirichlet(V, [(ft.find(10), 0.0), (ft.find(20), 1.0)])
+    # oracle: same problem by sparse LU on the free tissue nodes
+    omesh = fem.BoxMesh(n, tuple(c * h for c in n))
+    act_s = np.repeat(mask.ravel(), 6)
+    K = fem.assemble_stiffness(omesh, np.eye(3)[None] * act_s[:, None, None]).tocsr()
+    tissue = mesh.node_active()
+    gvals = np.full(omesh.num_nodes, np.nan)
+    gvals[np.unique(mesh.facet_vertices(ft.find(10)))] = 0.0
+    gvals[np.unique(mesh.facet_vertices(ft.find(20)))] = 1.0
+    dirichlet = ~np.isnan(gvals)
+    free = tissue & ~dirichlet
+    ref = np.zeros(omesh.num_nodes)
+    ref[dirichlet] = gvals[dirichlet]
+    rhs = -(K[free][:, dirichlet] @ gvals[dirichlet])
+    ref[free] = spla.spsolve(K[free][:, free].tocsc(), rhs)
+    out = np.asarray(u.x.array)
+    assert np.abs(out - ref)[tissue].max() < 1e-7
+    assert 0.0 <= out[tissue].min() and out[tissue].max() <= 1.0 + 1e-12
+    layers = beat.utils.expand_layer(V, ft, 10, 20, endo_size=0.3, epi_size=0.3)
+    lay = np.asarray(layers.x.array)
+    sure = tissue & (np.abs(ref - 0.3) > 1e-6) & (np.abs(ref - 0.7) > 1e-6)
+    expect = np.where(ref <= 0.3, 1, np.where(ref >= 0.7, 2, 0))
+    assert np.array_equal(lay[sure], expect[sure])
+    assert all((lay[tissue] == k).sum() > 50 for k in (0, 1, 2))
+
+    # surface stimulus on the endocardium (demos/biv_endocardial.py:246-258): effective dimension 2
+    cond = beat.conductivities.default_conductivities("Bishop")
+    time = g.Constant(mesh, 0.0)
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=ft, marker=10,
+                                           mesh_unit="mm", amplitude=2000.0, start=0.0, duration=1.0)
+    assert I_s.dZ.integral_type == "ds"
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01)
+    xp = np.zeros((3, omesh.num_nodes))
+    xp[:] = omesh.x.T
+    endo_nodes = np.zeros(omesh.num_nodes, dtype=bool)
+    endo_nodes[np.unique(mesh.facet_vertices(ft.find(10)))] = True
+    zb = np.floor(0.8 * n[2]) * h  # triangles lying in the (untagged) base plane are not part of the endocardium
+    w_ref = fem.exterior_facet_weights(omesh, act_s, endo_nodes,
+                                       facet_filter=lambda X: ~(np.abs(X[:, :, 2] - zb) < 1e-9).all(axis=1))
+    w = pde._stimuli[0].field.numpy()
+    np.testing.assert_allclose(w, w_ref, rtol=1e-12, atol=1e-15)
+    time.value = 0.5
+    amp = pde._stimuli[0].amplitude()
+    assert np.isclose(amp, 2000.0 / 1400.0 / 10.0)  # uA/cm^2 / cm^-1 = uA/cm -> uA/mm (stimulation.py:153-183)
+    ic = tp06.init_state_values()
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+                                         init_states=ic, parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+                                         num_states=len(ic), v_index=tp06.state_index("V"))
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    for i in range(30):
+        solver.step((i * 0.05, (i + 1) * 0.05))
+    v = np.asarray(pde.state.x.array)
+    assert v[endo_nodes].mean() > v[tissue & ~endo_nodes].mean() + 5.0 and np.isfinite(v).all()
