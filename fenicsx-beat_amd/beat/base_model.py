@@ -33,7 +33,7 @@ def _transform_I_s(I_s, dZ: grid.Measure) -> list[Stimulus]:
         return [Stimulus(expr=grid.zero(), dZ=dZ)]
     if isinstance(I_s, Stimulus):
         return [I_s]
-    if isinstance(I_s, grid.Expr):
+    if isinstance(I_s, (grid.Expr, grid.CellFunction)):
         return [Stimulus(expr=I_s, dZ=dZ)]
     return list(I_s)
 
@@ -45,6 +45,18 @@ class _CompiledStimulus:
         self.model = model
         self.stim = stim
         mesh = model._mesh
+        if isinstance(stim.expr, grid.CellFunction):
+            # piecewise-constant current updated by the caller (demos/ukb_atlas.py:340-356): nodal weights are
+            # rebuilt from the non-zero cells whenever the values change
+            self.cellfun = stim.expr
+            self.cells = stim.dz.cells()
+            self.facets = None
+            self.zero = False
+            self.general = None
+            self.field = model._ctx.field(mesh.num_nodes, mesh.plane)
+            self._seen = -1
+            self.amplitude = self._refresh_cells
+            return
         expr = grid.as_expr(stim.expr)
         measure = stim.dz
         self.facets = measure.facets() if measure.integral_type == "ds" else None
@@ -72,6 +84,33 @@ class _CompiledStimulus:
             self.general = expr
             self.field = model._ctx.field(mesh.num_nodes, mesh.plane)
             self.amplitude = self._refresh
+
+    def _refresh_cells(self) -> float:
+        f = self.cellfun
+        if f._version != self._seen:
+            mesh = self.model._mesh
+            vals = np.asarray(f.x.array)
+            if self.cells is not None:
+                sel = np.zeros(vals.shape, dtype=bool)
+                sel[self.cells] = True
+                vals = np.where(sel, vals, 0.0)
+            ids = np.flatnonzero(vals)
+            if mesh.active is not None:
+                ids = ids[mesh.active[ids]]
+            d = mesh.dim
+            vol = float(np.prod(mesh.h)) / {1: 1, 2: 2, 3: 6}[d]
+            w = np.zeros(mesh.num_nodes)
+            lo, hi = mesh.slab.z0 * mesh.plane, mesh.slab.z1 * mesh.plane
+            if len(ids):
+                verts = mesh.cell_vertices(ids)
+                contrib = np.repeat(vals[ids] * vol / (d + 1), d + 1)
+                v = verts.ravel()
+                keep = (v >= lo) & (v < hi)
+                np.add.at(w, v[keep] - lo, contrib[keep])
+            self.field.set(w)
+            self._nonzero = bool(len(ids))
+            self._seen = f._version
+        return 1.0 if self._nonzero else 0.0
 
     def _refresh(self) -> float:
         self.field.set(assemble_weights(self.model._mesh, self.cells, self.general))

@@ -717,9 +717,11 @@ class _Element:
 class FunctionSpace:
     def __init__(self, mesh: Mesh, family="Lagrange", degree=1):
         fam = {"P": "Lagrange", "CG": "Lagrange", "Lagrange": "Lagrange"}.get(family)
-        if fam is None or degree != 1:
+        if family in ("DG", "Discontinuous Lagrange") and degree == 0:
+            fam = "DG"  # piecewise constants: host-side data only (stimulus fields, see CellFunction)
+        elif fam is None or degree != 1:
             raise NotImplementedError(
-                f"only continuous P1 spaces are implemented on the HIP backend (got {family} {degree})"
+                f"only continuous P1 (and DG0 data) spaces are implemented on the HIP backend (got {family} {degree})"
             )
         self.mesh = mesh
         self.family = fam
@@ -731,9 +733,13 @@ class FunctionSpace:
 
     @property
     def num_dofs(self):
+        if self.family == "DG":
+            return self.mesh.num_box_cells * self.mesh.simplices_per_cell
         return self.mesh.num_nodes
 
     def tabulate_dof_coordinates(self):
+        if self.family == "DG":
+            return cell_midpoints(self.mesh, np.arange(self.num_dofs, dtype=np.int64))
         return self.mesh.node_coordinates(pad3=True)
 
 
@@ -742,6 +748,66 @@ def functionspace(mesh: Mesh, element, **kw) -> FunctionSpace:
         return FunctionSpace(mesh, element.family_name, element.degree())
     family, degree = element[0], element[1]
     return FunctionSpace(mesh, family, degree)
+
+
+def cell_midpoints(mesh: Mesh, cell_ids: np.ndarray) -> np.ndarray:
+    """(len, 3) centroids of the given simplices."""
+    verts = mesh.cell_vertices(cell_ids)
+    return _node_xyz(mesh, verts.ravel()).reshape(verts.shape + (3,)).mean(axis=1)
+
+
+class _TrackedArray(np.ndarray):
+    """ndarray whose item assignments bump the owner's version (so device copies can be refreshed lazily)."""
+
+    _owner = None
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if self._owner is not None:
+            self._owner._version += 1
+
+
+class _CellVector:
+    def __init__(self, array):
+        self.array = array
+
+    def scatter_forward(self):
+        pass
+
+
+class CellFunction:
+    """``dolfinx.fem.Function`` on a DG0 space: one value per simplex, kept on the host.  Used as a stimulus
+    current ``I_s`` that the caller re-interpolates every step (demos/ukb_atlas.py:340-356, 440-445)."""
+
+    def __init__(self, V: "FunctionSpace", name: str = "f"):
+        self.function_space = V
+        self.name = name
+        arr = np.zeros(V.num_dofs).view(_TrackedArray)
+        arr._owner = self
+        self._version = 0
+        self.x = _CellVector(arr)
+
+    def interpolate(self, expr) -> None:
+        mesh = self.function_space.mesh
+        e = expr.expr if isinstance(expr, Expression) else expr
+        if hasattr(e, "evaluate_cells"):
+            vals = e.evaluate_cells(mesh)  # fast path for sums of local windows
+        elif isinstance(e, Expr):
+            ids = mesh.all_cells()
+            vals = np.zeros(self.x.array.shape)
+            vals[ids] = np.broadcast_to(e.evaluate(cell_midpoints(mesh, ids).T), ids.shape)
+        else:
+            ids = mesh.all_cells()
+            vals = np.zeros(self.x.array.shape)
+            vals[ids] = e(cell_midpoints(mesh, ids).T)
+        self.x.array[:] = vals
+
+
+class Expression:
+    """``dolfinx.fem.Expression(expr, points)``: here just the expression (points are implied by the space)."""
+
+    def __init__(self, expr, points=None, **kw):
+        self.expr = expr
 
 
 class LazyArray:
@@ -844,6 +910,11 @@ class Function:
     step leaves ``pde.state``, ``pde.v_`` and ``ode.v_ode`` aliased to the V row of the state array
     instead of copying it three times; the alias is materialised into the function's own storage
     the moment the two would diverge)."""
+
+    def __new__(cls, V: FunctionSpace = None, *a, **kw):
+        if V is not None and getattr(V, "family", None) == "DG":
+            return CellFunction(V, *a, **kw)
+        return super().__new__(cls)
 
     def __init__(self, V: FunctionSpace, name: str = "f", field=None):
         from ._device import Context

@@ -166,3 +166,76 @@ def assemble_weights(mesh, cells, spatial: grid.Expr | None, chunk: int = 1 << 1
         sel = (v >= lo) & (v < hi)
         np.add.at(w_global_slab, v[sel] - lo, c[sel])
     return w_global_slab
+
+
+# ---- spatio-temporal activation patterns (stimulation.py:275-363) -----------------------------------------------
+def near(a, b, tol: float = 1e-12):
+    return grid.And(grid.ge(a, b - tol), grid.le(a, b + tol))
+
+
+class LocalActivation(grid.Expr):
+    """sum_i amplitude * [ |x - p_i|_inf <= tol ] * [ start + delay_i <= t <= start + duration + delay_i ]:
+    the expression generate_random_activation builds from conditionals (stimulation.py:331-349), kept in closed
+    form so that it can be evaluated on the cells near the currently active points only."""
+
+    def __init__(self, mesh, time, points, delays, stim_start, stim_duration, stim_amplitude, tol):
+        pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
+        self.points = np.zeros((len(pts), 3))
+        self.points[:, : pts.shape[1]] = pts[:, :3]
+        self.delays = np.asarray(delays, dtype=np.float64)
+        self.time, self.start, self.duration = time, float(stim_start), float(stim_duration)
+        self.amplitude, self.tol, self.mesh = float(stim_amplitude), float(tol), mesh
+
+    def depends_on_x(self):
+        return True
+
+    def depends_on_constants(self):
+        return True
+
+    def active_points(self) -> np.ndarray:
+        t = float(self.time)
+        return np.nonzero((t >= self.start + self.delays) & (t <= self.start + self.duration + self.delays))[0]
+
+    def evaluate(self, x=None):
+        x = np.asarray(x, dtype=np.float64)
+        out = np.zeros(x.shape[1:])
+        d = self.mesh.dim
+        for i in self.active_points():
+            hit = np.ones(x.shape[1:], dtype=bool)
+            for a in range(d):
+                hit &= np.abs(x[a] - self.points[i, a]) <= self.tol
+            out += self.amplitude * hit
+        return out
+
+    def evaluate_cells(self, mesh) -> np.ndarray:
+        """Values at the centroids of all simplices (0 on cells away from the active points and outside the
+        tissue); only box cells within ``tol`` of an active point are visited."""
+        spc = mesh.simplices_per_cell
+        out = np.zeros(mesh.num_box_cells * spc)
+        d = mesh.dim
+        lower, h, n = np.array(mesh.lower), np.array(mesh.h), np.array(mesh.n)
+        for i in self.active_points():
+            p = self.points[i, :d]
+            lo = np.clip(np.floor((p - self.tol - lower) / h).astype(np.int64), 0, n - 1)
+            hi = np.clip(np.floor((p + self.tol - lower) / h).astype(np.int64), 0, n - 1)
+            rng = [np.arange(lo[a], hi[a] + 1) for a in range(d)]
+            gridc = np.meshgrid(*reversed(rng), indexing="ij")
+            idx = [g.ravel() for g in reversed(gridc)]  # ix, iy, iz
+            box = idx[0] + (n[0] * (idx[1] + (n[1] * idx[2] if d == 3 else 0)) if d >= 2 else 0)
+            cells = (box[:, None] * spc + np.arange(spc)[None, :]).ravel()
+            if mesh.active is not None:
+                cells = cells[mesh.active[cells]]
+            mid = grid.cell_midpoints(mesh, cells)
+            hit = (np.abs(mid[:, :d] - p[None, :]) <= self.tol).all(axis=1)
+            np.add.at(out, cells[hit], self.amplitude)
+        return out
+
+
+def generate_random_activation(mesh, time, points, delays, stim_start: float = 0.0, stim_duration: float = 2.0,
+                               stim_amplitude: float = 1.0, tol: float = 1e-12) -> grid.Expr:
+    """Spatio-temporal activation pattern: every point fires ``stim_amplitude`` inside the cube of half-width
+    ``tol`` around it for ``stim_duration`` after ``stim_start + delay`` (stimulation.py:279-363)."""
+    assert len(points) == len(delays), "Points and delays must have the same length"
+    if len(points) == 0:
+        return grid.zero()
+    return LocalActivation(mesh, time, points, delays, stim_start, stim_duration, stim_amplitude, tol)

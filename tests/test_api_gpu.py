@@ -469,3 +469,54 @@ def test_readme_fitzhugh_nagumo_32x32_matches_oracle():
             vmax.append(v.max())
     assert np.isfinite(vmin).all() and np.isfinite(vmax).all() and max(vmax) > -80.0
     assert np.abs(ode.values - S).max() <= 1e-10 * 125.0
+
+
+def test_dg0_stimulus_function_updated_by_the_caller():
+    """I_s given as a DG0 function that the caller re-interpolates from generate_random_activation every step
+    (demos/ukb_atlas.py:327-356, 440-445): the PDE steps equal the oracle's with the same per-cell current,
+    rhs_i = dt * sum_cells s_c |T|/(d+1) (sparse LU), to 1e-9."""
+    import beat
+    from beat import grid as g
+    from oracle import fem
+
+    cells, L = (12, 10, 8), (3.0, 2.5, 2.0)
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array(L)], list(cells))
+    time = g.Constant(mesh, 0.0)
+    pts = np.array([[0.5, 0.5, 0.5], [2.5, 2.0, 1.5], [1.5, 1.25, 1.0]])
+    delays = np.array([0.0, 0.1, 0.25])
+    e = beat.stimulation.generate_random_activation(mesh, time, pts, delays, stim_start=0.0, stim_duration=0.2,
+                                                    stim_amplitude=3.0, tol=0.4)
+    stim = g.Function(g.functionspace(mesh, ("DG", 0)))
+    M = np.diag([1e-3, 5e-4, 2e-4])
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=stim, C_m=0.01, params={"petsc_options": {"ksp_rtol": 1e-13}})
+    omesh = fem.BoxMesh(cells, L)
+    vol, _ = fem._cell_geometry(omesh)
+
+    class CellStim:  # oracle stimulus with per-cell values re-evaluated at the model's time
+        def __init__(self):
+            self.weights = np.zeros(omesh.num_nodes)
+
+        def amp(self, t):
+            time.value = t
+            vals = e.evaluate(g.cell_midpoints(mesh, mesh.all_cells()).T)
+            w = np.zeros(omesh.num_nodes)
+            np.add.at(w, omesh.cells.ravel(), np.repeat(vals * vol / 4.0, 4))
+            self.weights = w
+            return 1.0 if vals.any() else 0.0
+
+    model = fem.OracleMonodomainModel(omesh, M, [CellStim()], C_m=0.01, theta=0.5)
+    pde.state.x.array[:] = -80.0
+    model.state[:] = -80.0
+    dt = 0.05
+    fired = 0
+    for i in range(10):
+        t0 = i * dt
+        time.value = t0 + 0.5 * dt  # the caller evaluates the current at the time the PDE step uses
+        stim.interpolate(e)
+        fired += int(stim.x.array.any())
+        pde.assign_previous()
+        pde.step((t0, t0 + dt))
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        assert np.abs(np.asarray(pde.state.x.array) - model.state).max() < 1e-9 * 80.0
+    assert fired >= 6 and np.asarray(pde.state.x.array).max() > -79.0

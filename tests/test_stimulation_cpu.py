@@ -1,0 +1,63 @@
+"""CPU: host-side stimulus logic that needs no device -- generate_random_activation on DG0 data (mirror of the
+reference's tests/test_stimulation.py:305-385) and the unit conversions of define_stimulus."""
+
+import numpy as np
+import pytest
+
+
+def test_generate_random_activation():
+    import beat
+    from beat import grid as g
+
+    domain = g.create_unit_cube(g.COMM_WORLD, 4, 4, 4)
+    t = g.Constant(domain, 0.0)
+    points = np.array([[0.5, 0.5, 0.5], [1.0, 1.0, 1.0]])
+    delays = np.array([1.0, 3.0])
+    stim_amplitude = 5.0
+    stim_expr = beat.stimulation.generate_random_activation(mesh=domain, time=t, points=points, delays=delays,
+                                                            stim_start=0.0, stim_duration=1.0,
+                                                            stim_amplitude=stim_amplitude, tol=0.2)
+    V = g.functionspace(domain, ("DG", 0))
+    expr = g.Expression(stim_expr, beat.utils.interpolation_points(V))
+    stim_func = g.Function(V)
+    ids = domain.all_cells()
+    mid = g.cell_midpoints(domain, ids).T
+    for tv, expected_max in [(0.5, 0.0), (1.5, stim_amplitude), (2.5, 0.0), (3.5, stim_amplitude), (4.5, 0.0)]:
+        t.value = tv
+        stim_func.interpolate(expr)
+        assert np.max(stim_func.x.array) == pytest.approx(expected_max)
+        assert np.min(stim_func.x.array) == pytest.approx(0.0)
+        # the cell-local fast path equals the plain evaluation of the expression at every centroid
+        np.testing.assert_array_equal(stim_func.x.array, stim_expr.evaluate(mid))
+    # first point: the cells whose centroid lies in the cube of half-width 0.2 around (0.5, 0.5, 0.5)
+    t.value = 1.5
+    stim_func.interpolate(expr)
+    inside = (np.abs(mid - 0.5) <= 0.2).all(axis=0)
+    np.testing.assert_array_equal(stim_func.x.array != 0.0, inside)
+
+
+def test_generate_random_activation_assertion():
+    import beat
+    from beat import grid as g
+
+    domain = g.create_unit_cube(g.COMM_WORLD, 1, 1, 1)
+    t = g.Constant(domain, 0.0)
+    with pytest.raises(AssertionError, match="Points and delays must have the same length"):
+        beat.stimulation.generate_random_activation(mesh=domain, time=t, points=np.zeros((2, 3)), delays=np.zeros(3))
+
+
+def test_generate_random_activation_respects_voxel_mask():
+    import beat
+    from beat import grid as g
+
+    mask = np.ones((4, 4, 4), dtype=bool)
+    mask[:, :, :2] = False
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, 0.25)
+    t = g.Constant(mesh, 0.5)
+    e = beat.stimulation.generate_random_activation(mesh, t, np.array([[0.5, 0.5, 0.5]]), np.array([0.0]),
+                                                    stim_duration=1.0, stim_amplitude=2.0, tol=0.3)
+    f = g.Function(g.functionspace(mesh, ("DG", 0)))
+    f.interpolate(e)
+    nz = np.flatnonzero(f.x.array)
+    assert len(nz) > 0 and mesh.active[nz].all()
+    assert (g.cell_midpoints(mesh, nz)[:, 0] > 0.5).all()
