@@ -8,6 +8,7 @@ runs in ``libbeat_hip.so``.  There is no CPU fallback."""
 from . import (  # noqa: F401
     base_model,
     conductivities,
+    ecg,
     geometry,
     grid,
     models,
@@ -20,6 +21,7 @@ from . import (  # noqa: F401
     units,
     utils,
 )
+from .ecg import ECGRecovery
 from .monodomain_model import MonodomainModel
 from .monodomain_solver import MonodomainSplittingSolver
 from .stimulation import Stimulus
@@ -31,5 +33,5 @@ __program_name__ = "fenicsx-beat-amd"
 __all__ = [
     "monodomain_model", "odesolver", "base_model", "MonodomainModel", "monodomain_solver",
     "MonodomainSplittingSolver", "utils", "single_cell", "conductivities", "stimulation", "geometry", "grid", "models",
-    "Stimulus", "telemetry", "BaseMonitor", "NullMonitor", "PerformanceMonitor", "units",
+    "Stimulus", "ecg", "ECGRecovery", "telemetry", "BaseMonitor", "NullMonitor", "PerformanceMonitor", "units",
 ]

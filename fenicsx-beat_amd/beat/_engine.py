@@ -319,6 +319,44 @@ class HipOps:
         _hip.check(self.lib.beat_pde_apply(self.handle, which, x.ptr, y.ptr))
 
 
+def conductivity_array(M, mesh) -> np.ndarray:
+    """(dim, dim) for a constant tensor, (ncells, dim, dim) for a per-cell field (grid.CellField or array)."""
+    from . import _stencil, grid
+
+    if isinstance(M, grid.Function):
+        raise NotImplementedError("nodal conductivity fields are not implemented: pass the tensor per cell")
+    if isinstance(M, grid.CellField):
+        M = M.values
+    if isinstance(M, grid.Constant):
+        M = M.value
+    M = np.asarray(M, dtype=np.float64)
+    if M.ndim == 3:
+        d = mesh.dim
+        if M.shape[1:] != (d, d):
+            raise ValueError(f"per-cell conductivity has shape {M.shape}, expected (ncells, {d}, {d})")
+        return M
+    return _stencil.conductivity_matrix(M, mesh.dim)
+
+
+def build_ops(ctx, mesh, M: np.ndarray) -> "HipOps":
+    """Mass / stiffness operators of ``mesh`` with conductivity ``M`` (see conductivity_array): the 27-type
+    stencil tables for a constant tensor on an unmasked box, per-node rows otherwise (assembled on the device
+    when the data are per box cell, on the host when they are per simplex)."""
+    from . import _stencil
+
+    slab = mesh.slab
+    if M.ndim == 2 and mesh.active is None:
+        mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, M)
+        return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+    per_voxel = (M.ndim == 2 or M.shape[0] == mesh.num_box_cells) and (mesh.active is None or mesh.active_box is not None)
+    if per_voxel:
+        return HipOps.from_voxels(ctx, mesh.dim, mesh.n, mesh.h, M, mesh.active_box, mesh.shape_local, slab.z0,
+                                  slab.lo_phys, slab.hi_phys)
+    z_range = (slab.z0, slab.z1) if mesh.dim == 3 else None
+    mass, stiff = _stencil.stencil_fields(mesh.dim, mesh.n, mesh.h, M, mesh.active, z_range=z_range)
+    return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass, stiff, per_node=True)
+
+
 class DiffusionSolver:
     """theta-rule diffusion step on one slab of a (possibly) decomposed grid."""
 

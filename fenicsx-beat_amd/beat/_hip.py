@@ -93,6 +93,7 @@ SIGNATURES = {
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],
     ),
     "beat_field_probe": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
+    "beat_field_dot": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_dbl)]),
     "beat_field_minmax": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }
 

@@ -973,6 +973,8 @@ class Function:
 
     def interpolate(self, f) -> None:
         x = self.function_space.mesh.node_coordinates(pad3=True).T
+        if isinstance(f, Expression):
+            f = f.expr
         if isinstance(f, Expr):
             vals = f.evaluate(x)
         elif isinstance(f, Function):

@@ -12,8 +12,8 @@ import logging
 
 import numpy as np
 
-from . import _stencil, grid
-from ._engine import DiffusionSolver, HipOps
+from . import grid
+from ._engine import DiffusionSolver, build_ops, conductivity_array
 from .base_model import BaseModel
 
 logger = logging.getLogger(__name__)
@@ -32,41 +32,10 @@ class MonodomainModel(BaseModel):
         self.v_ = grid.Function(self.V, name="v_")
         self._state = grid.Function(self.V, name="v")
 
-    def _conductivity(self) -> np.ndarray:
-        """(dim, dim) for a constant tensor, (ncells, dim, dim) for a per-cell field."""
-        M = self._M
-        if isinstance(M, grid.Function):
-            raise NotImplementedError("nodal conductivity fields are not implemented: pass the tensor per cell")
-        if isinstance(M, grid.CellField):
-            M = M.values
-        if isinstance(M, grid.Constant):
-            M = M.value
-        M = np.asarray(M, dtype=np.float64)
-        if M.ndim == 3:
-            d = self._mesh.dim
-            if M.shape[1:] != (d, d):
-                raise ValueError(f"per-cell conductivity has shape {M.shape}, expected (ncells, {d}, {d})")
-            return M
-        return _stencil.conductivity_matrix(M, self._mesh.dim)
-
     def _setup_operators(self) -> None:
         mesh = self._mesh
-        M = self._conductivity()
-        slab = mesh.slab
-        per_voxel = (M.ndim == 2 or M.shape[0] == mesh.num_box_cells) and (mesh.active is None or mesh.active_box is not None)
-        if (M.ndim == 3 or mesh.active is not None) and per_voxel:
-            # data per box cell (voxel): rows assembled on the device
-            self._ops = HipOps.from_voxels(self._ctx, mesh.dim, mesh.n, mesh.h, M, mesh.active_box, mesh.shape_local,
-                                           slab.z0, slab.lo_phys, slab.hi_phys)
-        elif M.ndim == 3 or mesh.active is not None:
-            # data per simplex: rows assembled on the host (NumPy), then uploaded
-            z_range = (slab.z0, slab.z1) if mesh.dim == 3 else None
-            mass, stiff = _stencil.stencil_fields(mesh.dim, mesh.n, mesh.h, M, mesh.active, z_range=z_range)
-            self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass, stiff, per_node=True)
-        else:
-            mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, M)
-            self._ops = HipOps(self._ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
-        self._diffusion = DiffusionSolver(self._ops, slab, group=mesh.comm.group)
+        self._ops = build_ops(self._ctx, mesh, conductivity_array(self._M, mesh))
+        self._diffusion = DiffusionSolver(self._ops, mesh.slab, group=mesh.comm.group)
 
     @property
     def state(self) -> grid.Function:

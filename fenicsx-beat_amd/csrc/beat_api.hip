@@ -234,6 +234,34 @@ __global__ __launch_bounds__(BEAT_BLOCK) void minmax_partial_kernel(const double
   }
 }
 
+namespace {
+__global__ __launch_bounds__(BEAT_BLOCK) void dot_partial_kernel(const double* __restrict__ x,
+                                                                 const double* __restrict__ y, int64_t n,
+                                                                 double* __restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) s = fma(x[i], y[i], s);
+  s = beat_block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int beat_field_dot(beat_ctx* ctx, const double* dev_x, const double* dev_y, int64_t n, double* host_out) {
+  BEAT_REQUIRE(ctx != nullptr && dev_x && dev_y && host_out && n > 0, "bad argument");
+  const unsigned grid = stream_grid(n) > 1024 ? 1024 : stream_grid(n);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, dev_x, dev_y, n,
+                     ctx->d_partials);
+  BEAT_LAUNCH_CHECK();
+  std::vector<double> h(grid);
+  BEAT_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->d_partials, sizeof(double) * grid, hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (unsigned b = 0; b < grid; ++b) s += h[b];  // fixed order: deterministic
+  *host_out = s;
+  return BEAT_OK;
+}
+
 extern "C" int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t n, double* host_min,
                                  double* host_max) {
   BEAT_REQUIRE(ctx != nullptr && dev_field && host_min && host_max && n > 0, "bad argument");

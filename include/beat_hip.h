@@ -257,6 +257,9 @@ int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const*
  * (scifem.evaluate_function stand-in, demos/niederer_benchmark.py:285).  Synchronises. */
 int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
                      const double* host_w, int npts, double* host_out);
+/* sum_i x_i y_i on the local slab: lead integrals of the ECG recovery, ecg.py:295-298 (assemble_scalar of
+ * (1/(4 pi sigma_b)) Im / |x - p| dx = weights . Im with precomputed nodal weights).  Synchronises. */
+int beat_field_dot(beat_ctx* ctx, const double* dev_x, const double* dev_y, int64_t n, double* host_out);
 /* min / max of a field (demos read v.max(), v.min() every step; avoids a full D2H).  Synchronises. */
 int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t n, double* host_min, double* host_max);
 

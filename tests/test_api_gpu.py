@@ -520,3 +520,50 @@ def test_dg0_stimulus_function_updated_by_the_caller():
         model.step((t0, t0 + dt))
         assert np.abs(np.asarray(pde.state.x.array) - model.state).max() < 1e-9 * 80.0
     assert fired >= 6 and np.asarray(pde.state.x.array).max() > -79.0
+
+
+def test_ecg_recovery():
+    """beat.ECGRecovery: the reference's own test (tests/test_ecg.py:13-49: zero field -> zero lead, symmetry about
+    x = 0.5, decay with distance) plus the numbers against the oracle: Im = -(1/C_m) Mass^-1 K v by sparse LU and
+    the lead integral by quadrature of Im_h / (4 pi sigma_b |x - p|), to 1e-7 relative (PCG at 1e-8/1e-8... the
+    recovery is run at rtol 1e-12 for this comparison)."""
+    import scipy.sparse.linalg as spla
+
+    import beat
+    from beat import grid as g
+    from oracle import fem
+
+    N = 5
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N, g.CellType.triangle)
+    V = g.functionspace(mesh, ("P", 1))
+    v = g.Function(V)
+    X = g.SpatialCoordinate(mesh)
+    v_expr = (X[0] - 0.5) ** 2
+    ecg = beat.ECGRecovery(v=v, M=1.0, C_m=1.0, sigma_b=1.0)
+    p1, p2, p3 = (1.5, 0.5), (10.0, 0.5), (-0.5, 0.5)
+    f1, f2, f3 = ecg.eval(p1), ecg.eval(p2), ecg.eval(p3)
+    ecg.solve()
+    assert np.isclose(beat.ecg.assemble_scalar(f1), 0.0)
+    v.interpolate(g.Expression(v_expr, beat.utils.interpolation_points(V)))
+    ecg.solve()
+    v1, v2, v3 = (beat.ecg.assemble_scalar(f) for f in (f1, f2, f3))
+    assert np.isclose(v1, v3) and abs(v2) < abs(v1) and abs(v1) > 1e-6
+
+    # numbers: anisotropic tensor, C_m != 1, 3-D
+    cells, L = (8, 6, 5), (2.0, 1.5, 1.0)
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array(L)], list(cells))
+    V = g.functionspace(mesh, ("P", 1))
+    v = g.Function(V)
+    v.interpolate(lambda x: -80.0 + 100.0 * np.exp(-((x[0] - 0.6) ** 2 + (x[1] - 0.5) ** 2 + (x[2] - 0.4) ** 2) / 0.2))
+    M = np.array([[2.0e-3, 3.0e-4, 0.0], [3.0e-4, 1.0e-3, 0.0], [0.0, 0.0, 5.0e-4]])
+    ecg = beat.ECGRecovery(v=v, M=M, C_m=0.01, sigma_b=2.0, petsc_options={"ksp_rtol": 1e-12, "ksp_atol": 1e-30})
+    leads = {"a": (3.0, 0.5, 0.5), "b": (-1.0, 2.0, 1.5)}
+    forms = {k: ecg.eval(p) for k, p in leads.items()}
+    ecg.solve()
+    omesh = fem.BoxMesh(cells, L)
+    Mass, K = fem.assemble_mass(omesh), fem.assemble_stiffness(omesh, M)
+    Im = spla.spsolve((-0.01 * Mass).tocsc(), K @ np.asarray(v.x.array))
+    np.testing.assert_allclose(np.asarray(ecg.sol.x.array), Im, rtol=0, atol=1e-9 * np.abs(Im).max())
+    for k, p in leads.items():
+        w = fem.load_vector(omesh, lambda x, p=p: 1.0 / (4 * np.pi * 2.0) / np.sqrt(sum((x[a] - p[a]) ** 2 for a in range(3))))
+        assert np.isclose(beat.ecg.assemble_scalar(forms[k]), w @ Im, rtol=1e-7)

@@ -61,3 +61,34 @@ def test_generate_random_activation_respects_voxel_mask():
     nz = np.flatnonzero(f.x.array)
     assert len(nz) > 0 and mesh.active[nz].all()
     assert (g.cell_midpoints(mesh, nz)[:, 0] > 0.5).all()
+
+
+def test_12_leads_ecg():
+    """tests/test_ecg.py:52-80 of the reference."""
+    import beat
+
+    x = np.ones(10)
+    la, ra, ll = 1.2, 4.5, 3.6
+    vs = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+    Vw = np.mean([la, ra, ll])
+    ecg = beat.ecg.Leads12(LA=la * x, RA=ra * x, LL=ll * x, **{f"V{i}": v * x for i, v in enumerate(vs, start=1)})
+    for i, vi in enumerate(vs, start=1):
+        assert np.allclose(getattr(ecg, f"V{i}_"), vi - Vw)
+    assert np.allclose(ecg.I, la - ra) and np.allclose(ecg.II, ll - ra) and np.allclose(ecg.III, ll - la)
+    assert np.allclose(ecg.aVR, 1.5 * (ra - Vw)) and np.allclose(ecg.aVL, 1.5 * (la - Vw)) and np.allclose(ecg.aVF, 1.5 * (ll - Vw))
+    with pytest.raises(AttributeError):
+        beat.ecg.Leads12(LA=x, RA=x, LL=x).V1_
+
+
+def test_qt_interval():
+    """tests/test_ecg.py:83-113 of the reference."""
+    import beat
+
+    qrs_peak_time, t_peak_offset_ms, t_width_ms = 200, 200, 60
+    t, y = beat.ecg.example(sampling_rate_hz=1000, duration_s=1, noise_amplitude=0.0, wander_amplitude=0.0,
+                            heart_rate_bpm=60, q_offset_ms=40, s_offset_ms=40, t_peak_offset_ms=t_peak_offset_ms,
+                            r_width_ms=20, q_width_ms=20, s_width_ms=30, t_width_ms=t_width_ms, qrs_peak_time=qrs_peak_time)
+    qt = beat.ecg.qt_interval(t=t, ecg_signal=y)
+    assert np.isclose(qt.start_index, qrs_peak_time, atol=2)
+    assert np.isclose(qt.end_index, qrs_peak_time + t_peak_offset_ms + 2 * t_width_ms / 3, atol=5)
+    assert np.isclose(qt.qt_interval, qt.end_index - qt.start_index)
