@@ -567,3 +567,27 @@ def test_ecg_recovery():
     for k, p in leads.items():
         w = fem.load_vector(omesh, lambda x, p=p: 1.0 / (4 * np.pi * 2.0) / np.sqrt(sum((x[a] - p[a]) ** 2 for a in range(3))))
         assert np.isclose(beat.ecg.assemble_scalar(forms[k]), w @ Im, rtol=1e-7)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """beat.io: write_function / read_timestamps / read_function (the io4dolfinx calls of the demos)."""
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.ones(3)], [5, 4, 3])
+    V = g.functionspace(mesh, ("P", 1))
+    v = g.Function(V, name="v")
+    fname = tmp_path / "chk.bp"
+    beat.io.write_mesh(fname, mesh)
+    snaps = {}
+    for t in (0.0, 0.5, 1.0):
+        v.interpolate(lambda x, t=t: np.sin(3 * x[0] + t) + x[1] * x[2])
+        snaps[t] = np.asarray(v.x.array).copy()
+        beat.io.write_function(fname, v, time=t, name="v")
+    np.testing.assert_array_equal(beat.io.read_timestamps(comm=mesh.comm, filename=fname, function_name="v"), [0.0, 0.5, 1.0])
+    w = g.Function(V)
+    for t in (1.0, 0.0, 0.5):
+        beat.io.read_function(fname, w, time=t, name="v")
+        np.testing.assert_array_equal(np.asarray(w.x.array), snaps[t])
+    with pytest.raises(KeyError):
+        beat.io.read_function(fname, w, time=0.25, name="v")
