@@ -130,6 +130,23 @@ def cpu_baseline(n_side: int, steps: int, rtol: float):
             S[vi] = v
             t += DT
         wall = time.perf_counter() - tic
+        # the same port on ONE core, on a smaller sample of the same workload
+        n1, steps1 = min(n, 64), max(2, min(steps, 10))
+        cport.load().oracle_set_num_threads(1)
+        S1 = sample_states(n1)
+        work1, v1 = np.empty(5 * n1**3), np.empty(n1**3)
+        tic1 = time.perf_counter()
+        t1 = 0.0
+        for _ in range(steps1):
+            cport.tp06_grl1(S1, t1, DT, P)
+            v1[:] = S1[vi]
+            cport.theta_step(A, B, (n1, n1, n1), v1, None, 0.0, rtol, work=work1)
+            S1[vi] = v1
+            t1 += DT
+        wall1 = time.perf_counter() - tic1
+        cport.load().oracle_set_num_threads(threads)
+        c_single = {"value": n1**3 * steps1 / wall1, "unit": "node-updates/s", "cores": 1,
+                    "sample": f"{n1}^3 nodes x {steps1} steps, C oracle on one thread, {wall1:.1f} s"}
         out = {
             "value": n**3 * steps / wall,
             "unit": "node-updates/s",
@@ -137,6 +154,7 @@ def cpu_baseline(n_side: int, steps: int, rtol: float):
             "kind": "port",
             "sample": f"{n}^3 nodes x {steps} steps, TP06 GRL1 + P1 theta-rule Jacobi-PCG (avg {its / steps:.1f} its), "
                       f"C/OpenMP oracle (oracle/beat_oracle.c), {wall:.1f} s",
+            "c_single_core": c_single,
         }
     except Exception as exc:  # no C toolchain on this host: fall back to the NumPy oracle alone
         out = {"value": None, "unit": "node-updates/s", "cores": 0, "kind": "port", "sample": f"C oracle unavailable: {exc}"}

@@ -21,6 +21,10 @@ enum { P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_
        V_leak, Vmax_up, Buf_c, K_buf_c, Buf_sr, K_buf_sr, Buf_ss, K_buf_ss, V_sr, V_ss, Na_o, R_, T_, F_, Cm, V_c,
        stim_start, stim_period, stim_duration, stim_amplitude, K_o, NP };
 
+void oracle_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

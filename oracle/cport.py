@@ -17,6 +17,7 @@ def load():
             raise FileNotFoundError(f"{path} not built: run `make -C oracle`")
         lib = C.CDLL(str(path))
         lib.oracle_num_threads.restype = C.c_int
+        lib.oracle_set_num_threads.argtypes = [C.c_int]
         lib.oracle_tp06_grl1.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_double, C.c_double]
         lib.oracle_stencil_apply.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         lib.oracle_theta_step.restype = C.c_int

@@ -17,7 +17,8 @@ d = Path(sys.argv[1])
 out = Path(sys.argv[2])
 title = sys.argv[3] if len(sys.argv) > 3 else d.name
 OURS = ("ode_step_kernel", "stencil_kernel", "cg_update_kernel", "cg_pupdate_kernel", "reduce_partials_kernel",
-        "pcg_next_kernel", "pcg_begin_kernel", "minmax_partial_kernel", "copy", "fill_kernel", "fused", "cg_")
+        "pcg_next_kernel", "pcg_begin_kernel", "minmax_partial_kernel", "copy", "fill_kernel", "fused", "cg_", "x_flush",
+        "var_", "assemble_rows", "dot_partial", "rows_dirichlet", "ode_run_kernel", "gather_kernel", "scatter_kernel")
 
 
 def short(name):
