@@ -59,7 +59,7 @@ def tp06_defaults():
     return ic, tp06.init_parameter_values(stim_amplitude=0.0), tp06.state_index("V")
 
 
-def init_states(ctx, states, ic, v_index, n_glob, slab, seed):
+def init_states(ctx, states, ic, v_index, n_glob, slab, seed, nz_glob=None):
     """TP06 resting state everywhere, V raised by a 60 mV Gaussian bump (sigma 2 mm) at the box
     centre so that a depolarisation front travels through the timed steps, every other state
     multiplied by (1 + 0.01 u), u ~ U(-1, 1) (seeded per rank)."""
@@ -72,11 +72,12 @@ def init_states(ctx, states, ic, v_index, n_glob, slab, seed):
     yc = torch.arange(ny, device=ctx.device, dtype=torch.float64) * H
     xc = torch.arange(nx, device=ctx.device, dtype=torch.float64) * H
     c = 0.5 * (n_glob - 1) * H
+    cz = 0.5 * ((nz_glob or n_glob) - 1) * H
     for k in range(states.S):
         row = states.rows[k]
         if k == v_index:
             for iz in range(slab.nz):
-                r2 = (zc[iz] - c) ** 2 + (yc[:, None] - c) ** 2 + (xc[None, :] - c) ** 2
+                r2 = (zc[iz] - cz) ** 2 + (yc[:, None] - c) ** 2 + (xc[None, :] - c) ** 2
                 row[iz * plane : (iz + 1) * plane] = (float(ic[k]) + 60.0 * torch.exp(-r2 / (2.0 * 2.0**2))).reshape(-1)
         else:
             u = torch.rand(row.shape[0], generator=gen, device=ctx.device, dtype=torch.float64) * 2.0 - 1.0
@@ -195,6 +196,8 @@ def main():
     ap.add_argument("--pc-degree", type=int, default=int(os.environ.get("BEAT_PC_DEGREE", "1")),
                     help="1 = Jacobi-PCG, m >= 2 = Chebyshev polynomial preconditioner with m terms")
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
+    ap.add_argument("--nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
+                    "BEAT_FORCE_DISTRIBUTED=1 rehearses on one GPU the slab one of 8 ranks owns at 512^3")
     args = ap.parse_args()
     global ISOTROPIC
     ISOTROPIC = args.iso
@@ -226,7 +229,8 @@ def main():
     ctx = Context(local_rank)
     lib = ctx.lib
     n = args.n
-    slab = Slab(n, rank, world)
+    nz_glob = args.nz or n
+    slab = Slab(nz_glob, rank, world)
     plane = n * n
     n_local = plane * slab.nz
     mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
@@ -237,7 +241,7 @@ def main():
 
     ic, params, v_index = tp06_defaults()
     states = StateArray(ctx, len(ic), n_local, plane)
-    init_states(ctx, states, ic, v_index, n, slab, 1234)
+    init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
     v_field = states.row_field(v_index)  # PDE unknown lives in the V row: no ODE<->PDE copies
     import ctypes as C
 
@@ -288,14 +292,14 @@ def main():
     finite = bool(np.isfinite(vmin) and np.isfinite(vmax))
 
     if rank == 0:
-        n_total = n**3
+        n_total = n * n * nz_glob
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (only quoted when this
         # run has the configuration the counters were collected on)
         traffic = None
         tfile = ROOT / "profiles" / "r01_final_512_traffic.json"
         if tfile.is_file():
             tj = json.loads(tfile.read_text())
-            if tj.get("n") == n and tj.get("n_gpus") == world:
+            if tj.get("n") == n and nz_glob == n and tj.get("n_gpus") == world:
                 traffic = tj.get("hbm_bytes_per_launch")
         k_avg = float(np.mean(iters)) if iters else 0.0
         S = len(ic)
@@ -316,7 +320,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n}^3-node " + ("isotropic slab (h=0.1 mm)" if ISOTROPIC else "anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy)") + ", TP06 GRL1 ionic step, "
+                "workload": (f"{n}^3-node " if nz_glob == n else f"{n}x{n}x{nz_glob}-node ") + ("isotropic slab (h=0.1 mm)" if ISOTROPIC else "anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy)") + ", TP06 GRL1 ionic step, "
                             f"P1 consistent-mass theta=0.5 diffusion, Godunov splitting, dt=0.01 ms, "
                             f"PCG rtol={args.rtol:g} (x0 = previous v), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
