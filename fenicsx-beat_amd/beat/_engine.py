@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
+from typing import Any
 
 import numpy as np
 
@@ -25,17 +26,33 @@ from . import _hip
 
 @dataclass
 class Slab:
-    """z-range owned by one rank."""
+    """z-range owned by one rank.  Planes are dealt evenly, or -- with per-plane ``weights`` (tissue nodes per
+    plane of a voxelised geometry) -- so that every rank gets about the same total weight."""
 
     nz_global: int
     rank: int = 0
     world: int = 1
+    weights: Any = None
 
     def __post_init__(self):
-        base, extra = divmod(self.nz_global, self.world)
-        counts = [base + (1 if r < extra else 0) for r in range(self.world)]
-        if min(counts) < 1:
+        if self.world > self.nz_global:
             raise ValueError(f"{self.world} ranks for only {self.nz_global} z-planes")
+        if self.weights is not None and self.world > 1:
+            w = np.asarray(self.weights, dtype=np.float64) + 1e-9  # every plane costs something
+            if len(w) != self.nz_global:
+                raise ValueError("one weight per z-plane expected")
+            cum = np.cumsum(w)
+            cuts = [0]
+            for r in range(1, self.world):
+                k = int(np.argmin(np.abs(cum - cum[-1] * r / self.world))) + 1  # planes [0, k) closest to the share
+                k = max(k, cuts[-1] + 1)                      # at least one plane per rank ...
+                k = min(k, self.nz_global - (self.world - r))  # ... also for the ranks still to come
+                cuts.append(k)
+            cuts.append(self.nz_global)
+            counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+        else:
+            base, extra = divmod(self.nz_global, self.world)
+            counts = [base + (1 if r < extra else 0) for r in range(self.world)]
         self.counts = counts
         self.z0 = sum(counts[: self.rank])
         self.z1 = self.z0 + counts[self.rank]

@@ -350,7 +350,14 @@ class Mesh:
         world = self.comm.size
         if world > 1 and self.dim < 3:
             raise NotImplementedError("slab decomposition is implemented for 3-D boxes only")
-        self.slab = Slab(nodes[2], self.comm.rank, world)
+        weights = None
+        if active is not None and world > 1 and np.asarray(active).size == int(np.prod(self.n)):
+            # voxel mask: balance the slabs by tissue per node plane (a plane touches the voxel layers on both sides)
+            per_layer = np.asarray(active, dtype=bool).reshape(tuple(reversed(self.n))).sum(axis=(1, 2)).astype(np.float64)
+            weights = np.zeros(nodes[2])
+            weights[:-1] += per_layer
+            weights[1:] += per_layer
+        self.slab = Slab(nodes[2], self.comm.rank, world, weights)
         self.shape_local = (nodes[0], nodes[1], self.slab.nz)
         self.plane = nodes[0] * nodes[1]
         self.num_nodes = self.plane * self.slab.nz
@@ -497,6 +504,15 @@ class Mesh:
         nx, ny, nz = self.shape_global
         if self.active is None:
             ok = np.ones(nx * ny * nz, dtype=bool)
+        elif self.active_box is not None:
+            # voxel mask: a node is touched iff one of the (up to 2^dim) voxels around it is active
+            d = self.dim
+            act = self.active_box.reshape(tuple(reversed(self.n)))
+            grid_ok = np.zeros(tuple(reversed(self.shape_global[:d])), dtype=bool)
+            for corner in range(2**d):
+                sl = tuple(slice((corner >> (d - 1 - a)) & 1, ((corner >> (d - 1 - a)) & 1) + act.shape[a]) for a in range(d))
+                grid_ok[sl] |= act
+            ok = grid_ok.ravel()
         else:
             ok = np.zeros(nx * ny * nz, dtype=bool)
             ids = np.nonzero(self.active)[0]

@@ -64,10 +64,8 @@ write_function_on_input_mesh = write_function
 
 
 def _slab_ranges(mesh: grid.Mesh):
-    from ._engine import Slab
-
-    nz = mesh.shape_global[2]
-    return [(s.z0, s.z1) for s in (Slab(nz, r, mesh.comm.size) for r in range(mesh.comm.size))]
+    cuts = np.concatenate([[0], np.cumsum(mesh.slab.counts)])
+    return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
 
 
 def read_timestamps(comm=None, filename=None, function_name: str = "v", **kw) -> np.ndarray:

@@ -74,6 +74,20 @@ class ODESystemSolver:
                 self.states[:] = updated_states
 
 
+def _initial_values(init_states, shape, on_device: bool):
+    """(S, N) initial values as the reference builds them (odesolver.py:149-153): a full array is copied, a
+    per-state vector is broadcast to every point.  On the device the broadcast is done row by row in HBM
+    (no (S, N) host array), signalled by returning the 1-D vector."""
+    if np.shape(init_states) == shape:
+        return np.copy(init_states)
+    vec = np.asarray(init_states, dtype=np.float64)
+    if on_device and vec.shape == (shape[0],):
+        return vec
+    values = np.zeros(shape)
+    values.T[:] = init_states
+    return values
+
+
 class _DeviceODE:
     """(S, N) state array in HBM advanced by a built-in model kernel."""
 
@@ -90,6 +104,13 @@ class _DeviceODE:
         self.monitor = monitor
         self._ppn = None
         self._ppn_src = None
+
+    def set_initial(self, values) -> None:
+        if values.ndim == 1:
+            for k, val in enumerate(values):
+                self.states.row_field(k).fill(float(val))
+        else:
+            self.states.set(values)
 
     def _param_args(self):
         p = self.parameters
@@ -165,18 +186,14 @@ class DolfinODESolver(BaseDolfinODESolver):
     monitor: BaseMonitor = field(default_factory=NullMonitor)
 
     def __post_init__(self):
-        if np.shape(self.init_states) == self.shape:
-            values = np.copy(self.init_states)
-        else:
-            values = np.zeros(self.shape)
-            values.T[:] = self.init_states
         self._aliases: list[grid.Function] = []
         self.on_device = isinstance(self.fun, DeviceModel)
+        values = _initial_values(self.init_states, self.shape, self.on_device)
         if self.on_device:
             mesh = self.v_ode.function_space.mesh
             self._dev = _DeviceODE(self.v_ode._ctx, self.fun, self.num_states, self.num_points, mesh.plane,
                                    self.parameters, self.monitor)
-            self._dev.states.set(values)
+            self._dev.set_initial(values)
             self._v_row = self._dev.states.row_field(self.v_index)
             self._ode = self._dev
         else:
@@ -304,15 +321,11 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
             n_m = int(where.sum())
             self._num_points[marker] = n_m
             self._inds[marker] = where
-            if np.shape(self.init_states[marker]) == self.shape(marker):
-                values = np.copy(self.init_states[marker])
-            else:
-                values = np.zeros(self.shape(marker))
-                values.T[:] = self.init_states[marker]
+            values = _initial_values(self.init_states[marker], self.shape(marker), self.on_device)
             if self.on_device:
                 dev = _DeviceODE(ctx, self.fun[marker], self.num_states[marker], n_m, 0, self.parameters[marker],
                                  self.monitor)
-                dev.states.set(values)
+                dev.set_initial(values)
                 self._odes[marker] = dev
                 self._idx_dev[marker] = ctx.from_numpy(np.nonzero(where)[0].astype(np.int64))
             else:

@@ -154,3 +154,21 @@ def test_exterior_facet_weights_match_the_simplicial_mesh():
             xp[:d] = omesh.x.T
             np.testing.assert_allclose(assemble_facet_weights(mesh, facets),
                                        fem.exterior_facet_weights(omesh, act, pred(xp)), rtol=1e-13, atol=1e-16)
+
+
+def test_slabs_balanced_by_tissue_weight():
+    """Slab(weights=...): contiguous, non-empty z-ranges covering all planes, cut where the cumulative tissue
+    weight is closest to each rank's share (balance masked grids by active voxels per plane)."""
+    from beat._engine import Slab
+
+    w = np.array([0, 0, 1, 5, 9, 9, 5, 1, 0, 0, 0, 0], dtype=float)
+    for world in (1, 2, 3, 4, 12):
+        slabs = [Slab(12, r, world, w) for r in range(world)]
+        assert slabs[0].z0 == 0 and slabs[-1].z1 == 12
+        assert all(a.z1 == b.z0 for a, b in zip(slabs, slabs[1:])) and all(s.nz >= 1 for s in slabs)
+    a, b = (Slab(12, r, 2, w) for r in range(2))
+    assert w[a.z0 : a.z1].sum() == w[b.z0 : b.z1].sum() == 15.0
+    even = [Slab(10, r, 3) for r in range(3)]
+    assert [s.nz for s in even] == [4, 3, 3]
+    with pytest.raises(ValueError):
+        Slab(2, 0, 3)

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] in synthetic form, end to end through the public API on ONE GPU: a truncated
+ellipsoidal shell voxelised on a box, transmural fibre rotation, endo / mid / epi layers from the Laplace solve of
+utils.expand_layer, ToR-ORd-dynCl with one parameter set per layer (DolfinMultiODESolver), endocardial surface
+stimulus, Godunov split steps.
+
+    python tools/bench_biv.py [--n 256] [--steps 10]      # --n 560 gives ~40 M tissue nodes (needs ~150 GB of HBM)
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "fenicsx-beat_amd"))
+
+
+def shell(n, h):
+    ax = (np.arange(n) + 0.5) * h
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    c = n * h / 2.0
+    so = 0.48 * n * h * np.array([1.0, 0.9, 1.0])
+    si = 0.66 * so
+    P = np.stack([X - c, Y - c, Z - c], axis=-1)
+    del X, Y
+    ro = np.sqrt(((P / so) ** 2).sum(-1))
+    ri = np.sqrt(((P / si) ** 2).sum(-1))
+    mask = (ro < 1.0) & (ri > 1.0) & (Z < 0.8 * n * h)
+    depth = np.clip((ri - 1.0) / np.maximum(ri - ro, 1e-12), 0.0, 1.0)
+    rad = P / np.maximum(np.linalg.norm(P, axis=-1, keepdims=True), 1e-12)
+    circ = np.cross(np.array([0.0, 0.0, 1.0]), rad)
+    circ /= np.maximum(np.linalg.norm(circ, axis=-1, keepdims=True), 1e-12)
+    longi = np.cross(rad, circ)
+    ang = np.deg2rad(60.0 - 120.0 * depth)[..., None]
+    f0 = (np.cos(ang) * circ + np.sin(ang) * longi).reshape(-1, 3)
+    return mask, f0, (so, si, c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dt", type=float, default=0.05)
+    args = ap.parse_args()
+    import torch
+
+    import beat
+    from beat import grid as g
+    from beat.models import torord
+
+    n, h = args.n, 0.25
+    tic = time.perf_counter()
+    mask, f0, (so, si, c) = shell(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    tissue = mesh.node_active()
+    print(f"box {n + 1}^3 = {(n + 1) ** 3 / 1e6:.1f} M nodes, {tissue.sum() / 1e6:.2f} M tissue nodes "
+          f"({mask.mean() * 100:.0f} % of the voxels); geometry {time.perf_counter() - tic:.1f} s", flush=True)
+    tic = time.perf_counter()
+    facets = mesh.exterior_facets()
+    xyz = g._node_xyz(mesh, mesh.facet_vertices(facets).ravel()).reshape(len(facets), 4, 3)
+    ctr = xyz.mean(axis=1) - c
+    ro = np.sqrt(((ctr / so) ** 2).sum(axis=1))
+    ri = np.sqrt(((ctr / si) ** 2).sum(axis=1))
+    base = (np.ptp(xyz[:, :, 2], axis=1) < 1e-12) & (ri > 1.0) & (ro < 1.0)
+    values = np.where(base, 0, np.where(np.abs(ri - 1.0) < np.abs(ro - 1.0) * (1.0 / 0.66), 10, 20)).astype(np.int32)
+    ft = g.meshtags(mesh, 2, facets[values > 0], values[values > 0])
+    del xyz, ctr, ro, ri
+    V = g.functionspace(mesh, ("P", 1))
+    layers = beat.utils.expand_layer(V, ft, 10, 20, endo_size=0.3, epi_size=0.3)
+    marker_arr = np.where(tissue, np.asarray(layers.x.array), -1.0)
+    markers = g.Function(V)
+    markers.x.array[:] = marker_arr
+    print(f"facet tags + expand_layer (Laplace PCG on the device): {time.perf_counter() - tic:.1f} s; "
+          f"endo/mid/epi nodes = {[(marker_arr == k).sum() for k in (1, 0, 2)]}", flush=True)
+    tic = time.perf_counter()
+    cond = beat.conductivities.default_conductivities("Bishop")
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    time_c = g.Constant(mesh, 0.0)
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time_c, subdomain_data=ft, marker=10,
+                                           mesh_unit="mm", amplitude=2000.0, start=0.0, duration=1.0)
+    pde = beat.MonodomainModel(time=time_c, mesh=mesh, M=M, I_s=I_s, C_m=0.01,
+                               params={"petsc_options": {"ksp_rtol": 1e-8}})
+    keys = (0, 1, 2)  # celltype parameter of the model: 0 endo, 1 epi, 2 mid; layer markers: 1 endo, 0 mid, 2 epi
+    celltype = {1: 0, 2: 1, 0: 2}
+    ic = torord.init_state_values()
+    ode = beat.odesolver.DolfinMultiODESolver(
+        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
+        fun={k: torord.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
+        parameters={k: torord.init_parameter_values(i_Stim_Amplitude=0.0, celltype=celltype[k]) for k in keys},
+        v_index={k: torord.state_index("v") for k in keys})
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    print(f"operators (device assembly), states: {time.perf_counter() - tic:.1f} s", flush=True)
+    t, dt = 0.0, args.dt
+    its = []
+    for _ in range(args.warmup):
+        solver.step((t, t + dt))
+        t += dt
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step((t, t + dt))
+        its.append(pde.ksp.iterations)
+        t += dt
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - tic
+    vmin, vmax = pde.state.field.minmax()
+    nt = int(tissue.sum())
+    print(f"{wall / args.steps * 1e3:.2f} ms/step, {nt * args.steps / wall / 1e9:.3f} G tissue-node-updates/s, "
+          f"PCG {np.mean(its):.1f} its/step, v in [{vmin:.1f}, {vmax:.1f}] mV (0 = outside the tissue)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
