@@ -29,12 +29,17 @@ class CpuField:
 
 
 class OracleOps:
-    def __init__(self, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab):
+    def __init__(self, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab, per_node=False):
+        """mass_tab / stiff_tab: (27, 15) tables, or with ``per_node`` the (15, n) rows of this slab."""
         self.shape = tuple(int(v) for v in shape_local)
         nx, ny, nz = self.shape
         self.plane, self.n = nx * ny, nx * ny * nz
         self.lo_phys, self.hi_phys = bool(lo_phys), bool(hi_phys)
+        self.per_node = bool(per_node)
         self.mass_tab, self.stiff_tab = np.asarray(mass_tab), np.asarray(stiff_tab)
+        if self.per_node:
+            assert self.mass_tab.shape == (15, self.n) and self.stiff_tab.shape == (15, self.n)
+            self.tissue = self.mass_tab[0] != 0.0
         self.r, self.q, self.z = (CpuField(self.n, self.plane) for _ in range(3))
         self.ring = [CpuField(self.n, self.plane) for _ in range(6)]
         self.p = self.ring[0]
@@ -63,6 +68,11 @@ class OracleOps:
     def set_timestep(self, C_m, theta, dt):
         self.C_m, self.theta, self.dt = C_m, theta, dt
         self.A = C_m * self.mass_tab + theta * dt * self.stiff_tab
+        if self.per_node:  # nodes touched by no element: identity rows
+            self.A[:, ~self.tissue] = 0.0
+            self.A[0, ~self.tissue] = 1.0
+            self.dinv = 1.0 / self.A[0]
+            return
         self.dinv = (1.0 / self.A[:, 0])[self.typ].ravel()
         self._update_pc()
 
@@ -144,7 +154,10 @@ class OracleOps:
             X[-1, 1:-1, 1:-1] = np.nan if poison_ghosts else f.ghost_hi.numpy().reshape(ny, nx)
         y = np.zeros((nz, ny, nx))
         for k, (ox, oy, oz) in enumerate(fem.STENCIL_OFFSETS):
-            y += tab[:, k][self.typ] * X[1 + oz : 1 + oz + nz, 1 + oy : 1 + oy + ny, 1 + ox : 1 + ox + nx]
+            coef = tab[k].reshape(nz, ny, nx) if self.per_node else tab[:, k][self.typ]
+            xs = X[1 + oz : 1 + oz + nz, 1 + oy : 1 + oy + ny, 1 + ox : 1 + ox + nx]
+            # like the kernels: a neighbour is only read where its coefficient is non-zero (poisoned ghosts)
+            y += np.where(coef != 0.0, coef * np.where(coef != 0.0, xs, 0.0), 0.0)
         return y.ravel()
 
     def rhs(self, v_prev, stim_w, stim_amp, x):
@@ -153,6 +166,8 @@ class OracleOps:
         for w, a in zip(stim_w, stim_amp):
             stim += a * w.data.numpy()
         b = self.C_m * Mv - (1 - self.theta) * self.dt * Kv + self.dt * stim
+        if self.per_node:
+            b = np.where(self.tissue, b, 0.0)  # nodes outside the tissue are not part of the system
         r = self.dt * (stim - Kv)
         z = self.dinv * r
         if x is not v_prev:

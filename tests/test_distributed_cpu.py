@@ -119,3 +119,89 @@ def test_slab_partition():
         assert slabs[0].lo_phys and slabs[-1].hi_phys and not slabs[0].hi_phys
     with pytest.raises(ValueError):
         Slab(2, 0, 3)
+
+
+# ---- voxel-masked domain with per-voxel tensors, slabs cut by tissue weight --------------------------------------
+VCELLS, VH = (10, 8, 14), (0.1, 0.1, 0.1)
+
+
+def _voxel_problem():
+    from oracle import fem
+
+    rng = np.random.default_rng(11)
+    nbox = int(np.prod(VCELLS))
+    cc = np.stack(np.meshgrid(*[np.arange(c) + 0.5 for c in reversed(VCELLS)], indexing="ij"), axis=-1)[..., ::-1].reshape(-1, 3)
+    r = np.sqrt((((cc - np.array(VCELLS) / 2.0) / (np.array(VCELLS) / 2.0)) ** 2).sum(axis=1))
+    active = (r < 0.95) & (r > 0.35) & (cc[:, 2] < 11)
+    ang = 0.4 * cc[:, 2]
+    f = np.stack([np.cos(ang), np.sin(ang), 0.0 * ang], axis=1)
+    M = 1.25e-4 * np.eye(3)[None] + (9.5e-4 - 1.25e-4) * f[:, :, None] * f[:, None, :]
+    mesh = fem.BoxMesh(VCELLS, tuple(c * h for c, h in zip(VCELLS, VH)))
+    act_s = np.repeat(active, 6)
+    tissue = fem.assemble_mass(mesh, np.nonzero(act_s)[0]).diagonal() > 0
+    v_prev = np.where(tissue, -85.0 + 100.0 * np.exp(-((mesh.x - 0.4) ** 2).sum(axis=1) / 0.05) + 0.01 * rng.standard_normal(mesh.num_nodes), 0.0)
+    w = fem.stimulus_weights(mesh, np.nonzero(act_s & (mesh.x[mesh.cells].mean(axis=1)[:, 2] < 0.75))[0])
+    return mesh, active, M, v_prev, w
+
+
+def _voxel_worker(rank, world, port, out_dir):
+    for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle_ops import CpuField, OracleOps
+        from beat import _stencil
+        from beat import grid as g
+        from beat._engine import DiffusionSolver
+
+        mesh_o, active, M, v_prev, w = _voxel_problem()
+        mesh = g.create_voxel_mesh(g.COMM_WORLD, active.reshape(tuple(reversed(VCELLS))), VH)  # slabs by tissue weight
+        slab = mesh.slab
+        assert (slab.rank, slab.world) == (rank, world)
+        nx, ny, nz = mesh.shape_global
+        plane = nx * ny
+        mf, kf = _stencil.stencil_fields(3, VCELLS, VH, M, active, z_range=(slab.z0, slab.z1))
+        ops = OracleOps(mesh.shape_local, slab.lo_phys, slab.hi_phys, mf, kf, per_node=True)
+        ops.set_timestep(C_M, THETA, DT)
+        solver = DiffusionSolver(ops, slab, group=mesh.comm.group)
+        sl = slice(slab.z0 * plane, slab.z1 * plane)
+        fv, fx, fw = (CpuField(ops.n, plane) for _ in range(3))
+        fv.data.copy_(torch.from_numpy(v_prev[sl].copy()))
+        fw.data.copy_(torch.from_numpy(w[sl].copy()))
+        res = solver.solve(fv, [fw], [AMP], fx, rtol=1e-12, atol=1e-50, max_it=500)
+        np.savez(Path(out_dir) / f"rank{rank}.npz", x=fx.numpy(), its=res.iterations, reason=res.converged_reason,
+                 z0=slab.z0, z1=slab.z1, bnorm=res.rhs_norm, tissue=int(mesh.node_active().sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_voxel_mask_per_node_rows_slab_decomposed(world, tmp_path):
+    """Per-node rows cut out per rank (stencil_fields z_range), slabs balanced by tissue weight, halo exchange and
+    the deferred-x PCG on gloo: equals the sparse-LU solve of the undivided masked problem."""
+    from oracle import fem
+
+    port = _free_port()
+    mp.spawn(_voxel_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mesh, active, M, v_prev, w = _voxel_problem()
+    act_s = np.repeat(active, 6)
+    model = fem.OracleMonodomainModel(mesh, np.repeat(M, 6, axis=0), [fem.OracleStimulus(lambda t: AMP, w)], C_m=C_M,
+                                      theta=THETA, default_timestep=DT, active_cells=act_s)
+    model.state[:] = v_prev
+    model.assign_previous()
+    model.step((0.0, DT))
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert [int(p["z0"]) for p in parts] == [0] + [int(p["z1"]) for p in parts[:-1]]
+    assert int(parts[-1]["z1"]) == mesh.shape_nodes[2]
+    x = np.concatenate([p["x"] for p in parts])
+    assert np.abs(x - model.state).max() <= 1e-9 * np.abs(model.state).max()
+    assert len({int(p["its"]) for p in parts}) == 1 and all(int(p["reason"]) > 0 for p in parts)
+    # tissue-weighted cuts: no rank holds more than ~1.6x its share of the tissue nodes, and the planes differ
+    tissue = [int(p["tissue"]) for p in parts]
+    assert max(tissue) <= 1.6 * sum(tissue) / world
+    assert len({int(p["z1"]) - int(p["z0"]) for p in parts}) > 1
+    A = model.A.tocsr()
+    _, its_ref, _ = fem.pcg_jacobi(A, model.rhs(THETA * DT, DT), v_prev, rtol=1e-12)
+    assert abs(int(parts[0]["its"]) - its_ref) <= 1
