@@ -16,7 +16,7 @@
 // Algorithmic HBM traffic: 8 B read + 8 B written per node per operator application; the tile
 // halo (+16%) and the chunk's two extra planes are re-reads that the XCD-local L2 mostly absorbs
 // (tiles are dealt to XCDs in contiguous runs, see tile_of_block()).
-#include "beat_common.h"
+#include "beat_pde_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -24,7 +24,12 @@
 #include <cstring>
 #include <vector>
 
+const int beat_pde_detail::kOffsets[45] = {0, 0, 0,  1, 0, 0,  -1, 0, 0,  0, 1, 0,  0, -1, 0,  0, 0, 1,  0, 0, -1,
+                          1, 1, 0,  -1, -1, 0,  0, 1, 1,  0, -1, -1,  1, 0, 1,  -1, 0, -1,
+                          1, 1, 1,  -1, -1, -1};
+
 namespace {
+using namespace beat_pde_detail;
 
 // Tile shape of the stencil kernels: TX x TY nodes per workgroup and plane (TX*TY = 1024, four
 // rows per thread).  Wider tiles read longer contiguous row segments (DRAM page locality) at the
@@ -39,29 +44,13 @@ struct Tile {
   static_assert(TX * TY == 1024 && ROWS_PER_THREAD == 4, "tile must hold 1024 nodes");
 };
 constexpr int TARGET_BLOCKS = 1024;
-constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
-// slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
-enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD };
-constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
 
-const int kOffsets[45] = {0, 0, 0,  1, 0, 0,  -1, 0, 0,  0, 1, 0,  0, -1, 0,  0, 0, 1,  0, 0, -1,
-                          1, 1, 0,  -1, -1, 0,  0, 1, 1,  0, -1, -1,  1, 0, 1,  -1, 0, -1,
-                          1, 1, 1,  -1, -1, -1};
 
 struct Coef15 {
   double c[15];
 };
 
-struct Geom {
-  int nx, ny, nz;
-  int64_t plane;
-  int tiles_x, tiles_y, nchunks, zc, total;
-  int z_lo_phys, z_hi_phys;
-  int tile_tx;  // 64, 128 or 256: which Tile<> instantiation the grid was sized for
-  int z_lo, z_hi;    // planes [z_lo, z_hi) computed by this launch (whole slab: 0, nz)
-  int part_off;      // first block-partial slot this launch writes
-};
 
 struct StencilArgs {
   const double* x;     // input field
@@ -90,7 +79,6 @@ struct StencilArgs {
 // PC: one Horner pass of the polynomial preconditioner z = sum_j c_j (D^-1 A)^j D^-1 r:
 //     out = c_r D^-1 r + D^-1 A in,   in = c_in D^-1 r on the first pass, the previous output afterwards;
 //     the last pass also reduces r.z.
-enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_PC = 3 };
 
 __device__ __forceinline__ int axis_type(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -536,328 +524,9 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_z_kernel(int64_t n, con
 }
 
 
-// ---- variable-coefficient operators (beat_pde_create_var) -----------------------------------------------
-// Voxel-masked domains and spatially varying conductivity: every node carries its own 15 coefficients per
-// operator, stored coefficient-major ((15, ld) arrays, so a wave reads 15 contiguous 512 B segments).  The
-// coefficient streams are 120 of the 136 B/node an application moves, so the neighbour values are simply
-// gathered through L1/L2 (rows of x are contiguous across the wave) instead of being staged through LDS.
-// A neighbour is only read where its coefficient is non-zero: rows never reach outside the box (or into an
-// inactive voxel), so no out-of-range address is formed and stale ghost planes cannot leak NaNs.
-struct VarArgs {
-  const double* T1;  // (15, ld) coefficients
-  const double* T2;  // second operator (RHS: stiffness; APPLY: optional) or nullptr
-  double c1, c2;     // APPLY: y = (c1 T1 + c2 T2) x
-  int64_t ld;
-  const double* x;
-  double* y;         // APPLY: y | SPMV: q | RHS: r
-  double* y2;        // RHS: p
-  double* y3;        // RHS: x (copy of v_) or nullptr
-  const double* dinv;
-  double dt;
-  const double* w[BEAT_MAX_STIM];
-  double amp[BEAT_MAX_STIM];
-  int nstim;
-  double* partials;
-  int part_off;
-  const double* st;
-  int64_t i_lo, i_hi;  // node range of this launch
-  int doff[15];        // linear offsets of the 15 stencil points
-  const int* seg;      // active 256-node segments covering [i_lo, i_hi) (nullptr: every node of the range)
-  int nseg;
-  const double* mdiag; // RHS: mass diagonal (0 = node outside the tissue)
-};
-
-template <int MODE>
-__global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
-  __shared__ double red[4];
-  if (MODE == MODE_SPMV_DOT) {
-    if (a.st[STOP] != 0.0) return;
-  }
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  // Work items: the 256-node segments that hold at least one tissue node (list built at create time); segments
-  // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
-  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
-    const int64_t i = (a.seg ? (int64_t)a.seg[w] * BEAT_BLOCK : a.i_lo + w * BEAT_BLOCK) + threadIdx.x;
-    if (i < a.i_lo || i >= a.i_hi) continue;
-    double s1 = 0.0, s2 = 0.0;
-    double xc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-      const double c1 = a.T1[(int64_t)k * a.ld + i];
-      double c2 = 0.0;
-      if (MODE == MODE_RHS || (MODE == MODE_APPLY && a.T2 != nullptr)) c2 = a.T2[(int64_t)k * a.ld + i];
-      const bool need = (k == 0) || c1 != 0.0 || c2 != 0.0;
-      const double xv = need ? a.x[i + a.doff[k]] : 0.0;
-      if (k == 0) xc = xv;
-      s1 = fma(c1, xv, s1);
-      s2 = fma(c2, xv, s2);
-    }
-    if (MODE == MODE_APPLY) {
-      a.y[i] = a.c1 * s1 + a.c2 * s2;
-    } else if (MODE == MODE_SPMV_DOT) {
-      a.y[i] = s1;
-      acc0 = fma(xc, s1, acc0);
-    } else {  // RHS: T1 = A, T2 = K; b = A v + r, r = dt (stim - K v)
-      double stim = 0.0;
-      for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
-      const double r = a.dt * (stim - s2);
-      const double b = a.mdiag[i] != 0.0 ? s1 + r : 0.0;  // nodes outside the tissue are not part of the system
-      const double zz = a.dinv[i] * r;
-      a.y[i] = r;
-      a.y2[i] = zz;
-      acc0 = fma(b, b, acc0);
-      acc1 = fma(r, zz, acc1);
-      acc2 = fma(r, r, acc2);
-    }
-  }
-  if (MODE == MODE_SPMV_DOT) {
-    const double s0 = beat_block_sum(acc0, red);
-    if (threadIdx.x == 0) a.partials[a.part_off + blockIdx.x] = s0;
-  } else if (MODE == MODE_RHS) {
-    const double s0 = beat_block_sum(acc0, red);
-    const double s1 = beat_block_sum(acc1, red);
-    const double s2 = beat_block_sum(acc2, red);
-    if (threadIdx.x == 0) {
-      a.partials[a.part_off + blockIdx.x] = s0;
-      a.partials[BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s1;
-      a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
-    }
-  }
-}
-
-// PCG vector updates over the active segments (per-node 1/diag)
-__global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __restrict__ seg, int nseg, int64_t n,
-                                                                  const double* __restrict__ st,
-                                                                  double* __restrict__ r, const double* __restrict__ q,
-                                                                  const double* __restrict__ dinv,
-                                                                  double* __restrict__ partials,
-                                                                  double* __restrict__ alphas, int slot) {
-  __shared__ double red[4];
-  if (st[STOP] != 0.0) return;
-  const double alpha = st[RZ] / st[PQ];
-  if (blockIdx.x == 0 && threadIdx.x == 0) alphas[slot] = alpha;
-  double s_rz = 0.0, s_rr = 0.0;
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
-    if (i >= n) continue;
-    const double ri = fma(-alpha, q[i], r[i]);
-    r[i] = ri;
-    s_rz = fma(ri * dinv[i], ri, s_rz);
-    s_rr = fma(ri, ri, s_rr);
-  }
-  const double a0 = beat_block_sum(s_rz, red);
-  const double a1 = beat_block_sum(s_rr, red);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = a0;
-    partials[BEAT_MAX_PARTIALS + blockIdx.x] = a1;
-  }
-}
-
-__global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* __restrict__ seg, int nseg, int64_t n,
-                                                                     const double* __restrict__ st,
-                                                                     const double* __restrict__ r,
-                                                                     const double* __restrict__ p_old,
-                                                                     double* __restrict__ p_new,
-                                                                     const double* __restrict__ dinv) {
-  if (st[STOP] != 0.0) return;
-  const double beta = st[BETA];
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
-    if (i >= n) continue;
-    p_new[i] = fma(beta, p_old[i], dinv[i] * r[i]);
-  }
-}
-
-__global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __restrict__ seg, int nseg, int64_t n,
-                                                               const double* __restrict__ st, double* __restrict__ x,
-                                                               const double* __restrict__ ring, int64_t fld,
-                                                               const double* __restrict__ alphas, int ring_base,
-                                                               int only_if_full) {
-  int nvalid = (int)st[NUPD] - ring_base;
-  nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
-  if (nvalid == 0 || (only_if_full && nvalid < PRING)) return;
-  double a[PRING];
-#pragma unroll
-  for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
-    if (i >= n) continue;
-    double xi = x[i];
-#pragma unroll
-    for (int j = 0; j < PRING; ++j)
-      if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
-    x[i] = xi;
-  }
-}
-
-// flags[s] = 1 if segment s holds a node touched by an element (mass diagonal > 0)
-__global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n, const double* __restrict__ mass_diag,
-                                                                       unsigned char* __restrict__ flags) {
-  __shared__ int any;
-  const int64_t nsegs = (n + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  for (int64_t s = blockIdx.x; s < nsegs; s += gridDim.x) {
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    const int64_t i = s * BEAT_BLOCK + threadIdx.x;
-    if (i < n && mass_diag[i] != 0.0) any = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) flags[s] = (unsigned char)any;
-    __syncthreads();
-  }
-}
-
-// A = C_m Mass + theta dt K per node, 1/diag(A); rows without any element (inactive voxels) become identity
-__global__ __launch_bounds__(BEAT_BLOCK) void var_form_A_kernel(int64_t n, int64_t ld, const double* __restrict__ M,
-                                                                const double* __restrict__ K, double cm, double tdt,
-                                                                double* __restrict__ A, double* __restrict__ dinv) {
-  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
-    double d = cm * M[i] + tdt * K[i];
-    const bool inactive = (M[i] == 0.0);
-    if (inactive) d = 1.0;
-    A[i] = d;
-    dinv[i] = 1.0 / d;
-#pragma unroll
-    for (int k = 1; k < 15; ++k) {
-      const int64_t j = (int64_t)k * ld + i;
-      A[j] = inactive ? 0.0 : cm * M[j] + tdt * K[j];
-    }
-  }
-}
-
-
-// Assembly of the per-node rows on the device from per-voxel data (replaces dolfinx assemble_matrix of
-// base_model.py:114-124 for voxelised geometries).  A voxel's 8x8 element stiffness matrix is linear in its
-// conductivity tensor, K_e[a][b] = sum_ij T[a][b][i][j] M_ij with T fixed by the cell size and the 6-tet
-// subdivision; node i gathers, from the <= 8 active voxels around it, the entries K_e[a][b] (a = its corner in
-// that voxel) into the stencil slot of corner b - corner a.  One thread per node, coalesced row writes.
-struct AsmArgs {
-  int nx, ny, nz;       // local nodes
-  int cx, cy, cz;       // global voxels per axis (1 for unused axes)
-  int z0;               // global plane index of local plane 0
-  const double* T;      // device, [8][8][9]
-  const double* Me;     // device, [8][8] element mass
-  const double* M;      // device (nvox, 9) or nullptr
-  double Mc[9];         // constant tensor when M == nullptr
-  const unsigned char* active;  // device (nvox) or nullptr
-  int64_t ld;
-  double* mass;
-  double* stiff;
-  signed char slot[64];  // stencil slot of (a, b), -1 if corner b - corner a is not a stencil offset
-};
-
-__global__ __launch_bounds__(BEAT_BLOCK) void assemble_rows_kernel(AsmArgs a) {
-  __shared__ double sT[8 * 8 * 9];
-  __shared__ double sMe[64];
-  for (int k = threadIdx.x; k < 8 * 8 * 9; k += BEAT_BLOCK) sT[k] = a.T[k];
-  if (threadIdx.x < 64) sMe[threadIdx.x] = a.Me[threadIdx.x];
-  __syncthreads();
-  const int64_t n = (int64_t)a.nx * a.ny * a.nz;
-  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
-    const int ix = (int)(i % a.nx);
-    const int iy = (int)((i / a.nx) % a.ny);
-    const int iz = (int)(i / ((int64_t)a.nx * a.ny)) + a.z0;
-    double km[15], kk[15];
-#pragma unroll
-    for (int s = 0; s < 15; ++s) km[s] = kk[s] = 0.0;
-    for (int c = 0; c < 8; ++c) {
-      // voxel whose corner `c` is this node
-      const int vx = ix - (c & 1), vy = iy - ((c >> 1) & 1), vz = iz - ((c >> 2) & 1);
-      if (vx < 0 || vx >= a.cx || vy < 0 || vy >= a.cy || vz < 0 || vz >= a.cz) continue;
-      const int64_t v = vx + (int64_t)a.cx * (vy + (int64_t)a.cy * vz);
-      if (a.active != nullptr && a.active[v] == 0) continue;
-      double m[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) m[q] = a.M != nullptr ? a.M[v * 9 + q] : a.Mc[q];
-      for (int b = 0; b < 8; ++b) {
-        const int s = a.slot[c * 8 + b];
-        if (s < 0) continue;
-        const double* t = sT + (c * 8 + b) * 9;
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) acc = fma(t[q], m[q], acc);
-        // runtime slot index: select into the register arrays without dynamic indexing
-#pragma unroll
-        for (int u = 0; u < 15; ++u) {
-          if (u == s) {
-            kk[u] += acc;
-            km[u] += sMe[c * 8 + b];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 15; ++s) {
-      a.mass[(int64_t)s * a.ld + i] = km[s];
-      a.stiff[(int64_t)s * a.ld + i] = kk[s];
-    }
-  }
-}
-
-
-// Dirichlet conditions on per-node rows (symmetric elimination): flagged rows become identity, the couplings of
-// free rows to flagged nodes move to the right-hand side f.
-__global__ __launch_bounds__(BEAT_BLOCK) void rows_dirichlet_kernel(int64_t n, int64_t ld, double* __restrict__ rows,
-                                                                    const unsigned char* __restrict__ flag,
-                                                                    const double* __restrict__ g,
-                                                                    double* __restrict__ f, VarArgs offs) {
-  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
-    if (flag[i]) {
-      f[i] = g[i];
-      rows[i] = 1.0;
-#pragma unroll
-      for (int k = 1; k < 15; ++k) rows[(int64_t)k * ld + i] = 0.0;
-      continue;
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 1; k < 15; ++k) {
-      const double c = rows[(int64_t)k * ld + i];
-      if (c == 0.0) continue;  // rows never couple outside the box, so i + doff is a valid node here
-      const int64_t j = i + offs.doff[k];
-      if (flag[j]) {
-        acc = fma(-c, g[j], acc);
-        rows[(int64_t)k * ld + i] = 0.0;
-      }
-    }
-    f[i] = acc;
-  }
-}
-
 }  // namespace
 
-struct beat_pde {
-  beat_ctx* ctx = nullptr;
-  Geom g{};
-  int64_t n = 0;
-  double h_mass[27 * 15], h_stiff[27 * 15];
-  double h_A[27 * 15], h_B[27 * 15], h_dinv[27];
-  bool have_dt = false;
-  double C_m = 1.0, theta = 0.5, dt = 0.0;
-  // device: 4 padded tables (A, B, Mass, K), then dinv[32]
-  double* d_tabs = nullptr;
-  double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
-  int last_iters = -1;
-  unsigned vec_grid = 1;
-  double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
-  int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
-  double pc_coef[8] = {1.0};
-  // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
-  bool var = false;
-  const double* v_mass = nullptr;
-  const double* v_stiff = nullptr;
-  double* v_A = nullptr;
-  double* v_dinv = nullptr;
-  int64_t v_ld = 0;
-  int* v_seg = nullptr;        // device: indices of the 256-node segments that hold tissue nodes (ascending)
-  std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
-  const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * TABW; }
-  const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * TABW; }
-  const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }
-};
+using namespace beat_pde_detail;
 
 // vector kernels are compiled for both the typed (27 node types) and the per-node 1/diag
 #define BEAT_LAUNCH_VEC(pde, kernel, ...)                                   \
@@ -939,183 +608,6 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
 }
 
 
-// ---- variable-coefficient mode ------------------------------------------------------------------------
-static void var_offsets(const beat_pde* pde, VarArgs& a) {
-  const Geom& g = pde->g;
-  for (int k = 0; k < 15; ++k)
-    a.doff[k] = kOffsets[3 * k] + g.nx * kOffsets[3 * k + 1] + (int)g.plane * kOffsets[3 * k + 2];
-  a.ld = pde->v_ld;
-}
-
-// Work of a launch over planes [z_lo, z_hi): the sub-list of active segments intersecting the range and the grid
-// (= number of block partials the launch writes).
-struct VarRange {
-  const int* seg;
-  int nseg;
-  unsigned grid;
-};
-static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
-  VarRange r{nullptr, 0, 0};
-  if (z_hi <= z_lo) return r;
-  const int64_t i_lo = (int64_t)z_lo * pde->g.plane, i_hi = (int64_t)z_hi * pde->g.plane;
-  int64_t nwork = (i_hi - i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  if (!dense) {
-    const int s_lo = (int)(i_lo / BEAT_BLOCK), s_hi = (int)((i_hi + BEAT_BLOCK - 1) / BEAT_BLOCK);
-    const auto lo = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_lo);
-    const auto hi = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_hi);
-    r.seg = pde->v_seg + (lo - pde->h_seg.begin());
-    r.nseg = (int)(hi - lo);
-    nwork = r.nseg;
-  }
-  r.grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, nwork));
-  return r;
-}
-
-// launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on.
-// `dense` ignores the segment list (APPLY must write every node of y).
-template <int MODE>
-static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int part_off, bool dense = false) {
-  if (z_hi <= z_lo) return 0;
-  const VarRange r = var_range(pde, z_lo, z_hi, dense);
-  a.i_lo = (int64_t)z_lo * pde->g.plane;
-  a.i_hi = (int64_t)z_hi * pde->g.plane;
-  a.part_off = part_off;
-  a.seg = r.seg;
-  a.nseg = r.nseg;
-  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(r.grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
-  return (int)r.grid;
-}
-
-static unsigned var_vec_grid(const beat_pde* pde) {
-  return (unsigned)std::min<size_t>(4096, std::max<size_t>(1, pde->h_seg.size()));
-}
-
-static int var_form_A(beat_pde* pde) {
-  const unsigned grid = (unsigned)std::min<int64_t>(4096, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
-                     pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, pde->v_A, pde->v_dinv);
-  BEAT_LAUNCH_CHECK();
-  return BEAT_OK;
-}
-
-extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
-                                   const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out) {
-  BEAT_REQUIRE(ctx != nullptr && n != nullptr && dev_mass && dev_stiff && out, "null argument");
-  BEAT_REQUIRE(ld >= n[0] * n[1] * n[2], "leading dimension %lld smaller than the node count", (long long)ld);
-  BEAT_REQUIRE(n[0] * n[1] * (n[2] + 2) < ((int64_t)1 << 31), "slab too large for 32-bit stencil offsets");
-  std::vector<double> zeros(27 * 15, 0.0);
-  beat_pde* p = nullptr;
-  int rc = beat_pde_create(ctx, n, z_lo_phys, z_hi_phys, zeros.data(), zeros.data(), &p);
-  if (rc) return rc;
-  p->var = true;
-  p->v_mass = dev_mass;
-  p->v_stiff = dev_stiff;
-  p->v_ld = ld;
-  if (hipMalloc(&p->v_A, sizeof(double) * 15 * (size_t)ld) != hipSuccess ||
-      hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess) {
-    beat_pde_destroy(p);
-    beat_set_error("out of device memory for the %lld-node coefficient rows", (long long)ld);
-    return BEAT_EHIP;
-  }
-  // list of the 256-node segments that hold tissue nodes
-  const int64_t nsegs = (p->n + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  unsigned char* d_flags = nullptr;
-  std::vector<unsigned char> flags((size_t)nsegs);
-  hipError_t e = hipMalloc(&d_flags, (size_t)nsegs);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, nsegs)), dim3(BEAT_BLOCK), 0,
-                       ctx->stream, p->n, dev_mass, d_flags);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, (size_t)nsegs, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_flags);
-  if (e == hipSuccess) {
-    for (int64_t sidx = 0; sidx < nsegs; ++sidx)
-      if (flags[(size_t)sidx]) p->h_seg.push_back((int)sidx);
-    e = hipMalloc(&p->v_seg, sizeof(int) * std::max<size_t>(1, p->h_seg.size()));
-  }
-  if (e == hipSuccess && !p->h_seg.empty())
-    e = hipMemcpy(p->v_seg, p->h_seg.data(), sizeof(int) * p->h_seg.size(), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    beat_pde_destroy(p);
-    beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
-    return BEAT_EHIP;
-  }
-  *out = p;
-  return BEAT_OK;
-}
-
-extern "C" int beat_rows_apply_dirichlet(beat_ctx* ctx, const int64_t n[3], double* dev_rows, int64_t ld,
-                                         const unsigned char* dev_flag, const double* dev_g, double* dev_f) {
-  BEAT_REQUIRE(ctx && n && dev_rows && dev_flag && dev_g && dev_f, "null argument");
-  const int64_t nn = n[0] * n[1] * n[2];
-  BEAT_REQUIRE(nn >= 1 && ld >= nn && nn < ((int64_t)1 << 31), "bad sizes");
-  VarArgs offs{};
-  for (int k = 0; k < 15; ++k)
-    offs.doff[k] = kOffsets[3 * k] + (int)n[0] * kOffsets[3 * k + 1] + (int)(n[0] * n[1]) * kOffsets[3 * k + 2];
-  const unsigned grid = (unsigned)std::min<int64_t>(4096, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(rows_dirichlet_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, nn, ld, dev_rows, dev_flag,
-                     dev_g, dev_f, offs);
-  BEAT_LAUNCH_CHECK();
-  return BEAT_OK;
-}
-
-extern "C" int beat_pde_assemble_rows(beat_ctx* ctx, const int64_t n[3], const int64_t cells[3], int64_t z0,
-                                      const double* host_T, const double* host_Me, const double* dev_M,
-                                      const double* host_M_const, const unsigned char* dev_active,
-                                      double* dev_mass, double* dev_stiff, int64_t ld) {
-  BEAT_REQUIRE(ctx && n && cells && host_T && host_Me && dev_mass && dev_stiff, "null argument");
-  BEAT_REQUIRE(dev_M != nullptr || host_M_const != nullptr, "no conductivity given");
-  BEAT_REQUIRE(n[0] >= 1 && n[1] >= 1 && n[2] >= 1 && ld >= n[0] * n[1] * n[2], "bad sizes");
-  BEAT_REQUIRE(n[0] * n[1] * n[2] < ((int64_t)1 << 40) && cells[0] * cells[1] * cells[2] < ((int64_t)1 << 40),
-               "grid too large");
-  AsmArgs a{};
-  a.nx = (int)n[0];
-  a.ny = (int)n[1];
-  a.nz = (int)n[2];
-  a.cx = (int)cells[0];
-  a.cy = (int)cells[1];
-  a.cz = (int)cells[2];
-  a.z0 = (int)z0;
-  a.M = dev_M;
-  if (host_M_const)
-    for (int q = 0; q < 9; ++q) a.Mc[q] = host_M_const[q];
-  a.active = dev_active;
-  a.ld = ld;
-  a.mass = dev_mass;
-  a.stiff = dev_stiff;
-  for (int ca = 0; ca < 8; ++ca)
-    for (int cb = 0; cb < 8; ++cb) {
-      const int d[3] = {(cb & 1) - (ca & 1), ((cb >> 1) & 1) - ((ca >> 1) & 1), ((cb >> 2) & 1) - ((ca >> 2) & 1)};
-      int slot = -1;
-      for (int k = 0; k < 15; ++k)
-        if (kOffsets[3 * k] == d[0] && kOffsets[3 * k + 1] == d[1] && kOffsets[3 * k + 2] == d[2]) slot = k;
-      a.slot[ca * 8 + cb] = (signed char)slot;
-    }
-  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
-  double* d_t = nullptr;
-  BEAT_HIP_CHECK(hipMalloc(&d_t, sizeof(double) * (8 * 8 * 9 + 64)));
-  hipError_t e = hipMemcpyAsync(d_t, host_T, sizeof(double) * 8 * 8 * 9, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(d_t + 8 * 8 * 9, host_Me, sizeof(double) * 64, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    a.T = d_t;
-    a.Me = d_t + 8 * 8 * 9;
-    const int64_t nn = n[0] * n[1] * n[2];
-    const unsigned grid = (unsigned)std::min<int64_t>(8192, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
-    hipLaunchKernelGGL(assemble_rows_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, a);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host tensors and d_t go out of scope
-  }
-  (void)hipFree(d_t);
-  if (e != hipSuccess) {
-    beat_set_error("beat_pde_assemble_rows: %s", hipGetErrorString(e));
-    return BEAT_EHIP;
-  }
-  return BEAT_OK;
-}
-
 extern "C" int beat_pde_destroy(beat_pde* pde) {
   if (pde == nullptr) return BEAT_OK;
   (void)hipFree(pde->d_tabs);
@@ -1159,7 +651,7 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
   pde->dt = dt;
   pde->have_dt = true;
   pde->last_iters = -1;
-  if (pde->var) return var_form_A(pde);
+  if (pde->var) return beat_var_form_A(pde);
   return upload_tables(pde);
 }
 
@@ -1200,27 +692,7 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   BEAT_REQUIRE(which >= 0 && which < 4, "which must be 0..3");
   BEAT_REQUIRE(which >= 2 || pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(dev_x != dev_y, "in-place apply is not supported");
-  if (pde->var) {
-    VarArgs a{};
-    var_offsets(pde, a);
-    a.x = dev_x;
-    a.y = dev_y;
-    a.c1 = 1.0;
-    a.c2 = 0.0;
-    if (which == 0) {
-      a.T1 = pde->v_A;
-    } else if (which == 1) {  // B = C_m Mass - (1 - theta) dt K
-      a.T1 = pde->v_mass;
-      a.c1 = pde->C_m;
-      a.T2 = pde->v_stiff;
-      a.c2 = -(1.0 - pde->theta) * pde->dt;
-    } else {
-      a.T1 = which == 2 ? pde->v_mass : pde->v_stiff;
-    }
-    launch_var<MODE_APPLY>(pde, a, 0, pde->g.nz, 0, /*dense=*/true);
-    BEAT_LAUNCH_CHECK();
-    return BEAT_OK;
-  }
+  if (pde->var) return beat_var_apply(pde, which, dev_x, dev_y);
   const double* host_tab = which == 0 ? pde->h_A : which == 1 ? pde->h_B : which == 2 ? pde->h_mass : pde->h_stiff;
   StencilArgs a{};
   a.x = dev_x;
@@ -1232,8 +704,7 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   return BEAT_OK;
 }
 
-static int launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st,
-                         double* counter = nullptr) {
+int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const double*)pde->ctx->d_partials, count, nsum, out, st, counter);
   BEAT_LAUNCH_CHECK();
@@ -1247,32 +718,8 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
   BEAT_REQUIRE(dev_r != dev_v_prev && dev_p != dev_v_prev && dev_r != dev_p, "r, p must be distinct work fields");
-  if (pde->var) {
-    VarArgs a{};
-    var_offsets(pde, a);
-    a.T1 = pde->v_A;
-    a.T2 = pde->v_stiff;
-    a.x = dev_v_prev;
-    a.y = dev_r;
-    a.y2 = dev_p;
-    a.y3 = nullptr;
-    if (dev_x != dev_v_prev)  // nodes outside the tissue keep their value: copy everything first
-      BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice,
-                                    pde->ctx->stream));
-    a.dinv = pde->v_dinv;
-    a.mdiag = pde->v_mass;
-    a.dt = pde->dt;
-    for (int k = 0; k < n_stim; ++k) {
-      if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
-      a.w[a.nstim] = host_dev_stim_w[k];
-      a.amp[a.nstim] = host_stim_amp[k];
-      ++a.nstim;
-    }
-    a.partials = pde->ctx->d_partials;
-    const int nb = launch_var<MODE_RHS>(pde, a, 0, pde->g.nz, 0);
-    BEAT_LAUNCH_CHECK();
-    return launch_reduce(pde, nb, 3, dev_red, nullptr);
-  }
+  if (pde->var)
+    return beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_r, dev_p, dev_red);
   StencilArgs a{};
   a.x = dev_v_prev;
   a.y = dev_r;
@@ -1297,7 +744,7 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
   a.partials = pde->ctx->d_partials;
   launch_stencil<MODE_RHS>(pde, a);
   BEAT_LAUNCH_CHECK();
-  return launch_reduce(pde, pde->g.total, 3, dev_red, nullptr);
+  return beat_pde_launch_reduce(pde, pde->g.total, 3, dev_red, nullptr);
 }
 
 extern "C" int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, double atol, int max_it) {
@@ -1311,18 +758,7 @@ extern "C" int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, dou
 extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
   BEAT_REQUIRE(pde != nullptr && dev_p && dev_q && dev_st, "null argument");
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
-  if (pde->var) {
-    VarArgs a{};
-    var_offsets(pde, a);
-    a.T1 = pde->v_A;
-    a.x = dev_p;
-    a.y = dev_q;
-    a.partials = pde->ctx->d_partials;
-    a.st = dev_st;
-    const int nb = launch_var<MODE_SPMV_DOT>(pde, a, 0, pde->g.nz, 0);
-    BEAT_LAUNCH_CHECK();
-    return launch_reduce(pde, nb, 1, dev_st + PQ, dev_st);
-  }
+  if (pde->var) return beat_var_spmv_dot(pde, dev_p, dev_q, dev_st);
   StencilArgs a{};
   a.x = dev_p;
   a.y = dev_q;
@@ -1332,36 +768,16 @@ extern "C" int beat_pde_spmv_dot(beat_pde* pde, const double* dev_p, double* dev
   a.st = dev_st;
   launch_stencil<MODE_SPMV_DOT>(pde, a);
   BEAT_LAUNCH_CHECK();
-  return launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
+  return beat_pde_launch_reduce(pde, pde->g.total, 1, dev_st + PQ, dev_st);
 }
 
 extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part) {
   BEAT_REQUIRE(pde != nullptr && dev_p && dev_q && dev_st, "null argument");
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(part == 0 || part == 1, "part must be 0 (interior) or 1 (boundary planes + reduce)");
+  if (pde->var) return beat_var_spmv_dot_part(pde, dev_p, dev_q, dev_st, part);
   const Geom& f = pde->g;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);  // planes that need no ghost data
-  if (pde->var) {
-    VarArgs a{};
-    var_offsets(pde, a);
-    a.T1 = pde->v_A;
-    a.x = dev_p;
-    a.y = dev_q;
-    a.partials = pde->ctx->d_partials;
-    a.st = dev_st;
-    // block-partial slots: the interior launch owns [0, 4096), the boundary planes follow
-    if (part == 0) {
-      launch_var<MODE_SPMV_DOT>(pde, a, lo, std::max(lo, hi), 0);
-      BEAT_LAUNCH_CHECK();
-      return BEAT_OK;
-    }
-    int off = (int)var_range(pde, lo, std::max(lo, hi), false).grid;  // partial slots of the interior launch (part 0)
-    if (!f.z_lo_phys) off += launch_var<MODE_SPMV_DOT>(pde, a, 0, 1, off);
-    if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch_var<MODE_SPMV_DOT>(pde, a, f.nz - 1, f.nz, off);
-    BEAT_LAUNCH_CHECK();
-    BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
-    return launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
-  }
   StencilArgs a{};
   a.x = dev_p;
   a.y = dev_q;
@@ -1388,7 +804,7 @@ extern "C" int beat_pde_spmv_dot_part(beat_pde* pde, const double* dev_p, double
   }
   BEAT_LAUNCH_CHECK();
   BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
-  return launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
+  return beat_pde_launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
 }
 
 extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, double* dev_r,
@@ -1398,7 +814,7 @@ extern "C" int beat_pde_cg_update(beat_pde* pde, double* dev_st, double* dev_x, 
                      (const double*)dev_st, dev_x, dev_r, dev_p, dev_q, pde->dinv_arg(), pde->h_dinv[13],
                      pde->ctx->d_partials);
   BEAT_LAUNCH_CHECK();
-  return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
+  return beat_pde_launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st);
 }
 
 extern "C" int beat_pde_set_preconditioner(beat_pde* pde, int ncoef, const double* host_coef) {
@@ -1441,7 +857,7 @@ extern "C" int beat_pde_pc_pass(beat_pde* pde, int j, const double* dev_r, doubl
   a.c_r = pde->pc_coef[npass - 1 - j];   // Horner: s_k = c_k D^-1 r + (D^-1 A) s_{k+1}
   launch_stencil<MODE_PC>(pde, a);
   BEAT_LAUNCH_CHECK();
-  if (a.pc_last) return launch_reduce(pde, pde->g.total, 1, dev_red, dev_st);
+  if (a.pc_last) return beat_pde_launch_reduce(pde, pde->g.total, 1, dev_red, dev_st);
   return BEAT_OK;
 }
 
@@ -1489,19 +905,12 @@ extern "C" int beat_pde_ring_size(void) { return PRING; }
 extern "C" int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_q, "null argument");
   BEAT_REQUIRE(slot >= 0 && slot < PRING, "slot %d out of range", slot);
-  if (pde->var) {
-    const unsigned grid = var_vec_grid(pde);
-    hipLaunchKernelGGL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg,
-                       (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_q, (const double*)pde->v_dinv,
-                       pde->ctx->d_partials, pde->d_alphas, slot);
-    BEAT_LAUNCH_CHECK();
-    return launch_reduce(pde, (int)grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
-  }
+  if (pde->var) return beat_var_update_r(pde, dev_st, dev_r, dev_q, slot);
   BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_q, pde->dinv_arg(), pde->h_dinv[13], pde->ctx->d_partials,
                      pde->d_alphas, slot);
   BEAT_LAUNCH_CHECK();
-  return launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
+  return beat_pde_launch_reduce(pde, (int)pde->vec_grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
 }
 
 // scalar roll (beta, latch, iteration count) then p_next = D^-1 r + beta p_cur
@@ -1511,13 +920,7 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
   BEAT_REQUIRE(dev_p_cur != dev_p_next, "the p-update is out of place");
   hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
-  if (pde->var) {
-    hipLaunchKernelGGL(var_pupdate_oop_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                       (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_p_cur,
-                       dev_p_next, (const double*)pde->v_dinv);
-    BEAT_LAUNCH_CHECK();
-    return BEAT_OK;
-  }
+  if (pde->var) return beat_var_pupdate_oop(pde, dev_st, dev_r, dev_p_cur, dev_p_next);
   BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_p_cur, dev_p_next, pde->dinv_arg(), pde->h_dinv[13]);
   BEAT_LAUNCH_CHECK();
@@ -1529,13 +932,7 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
 extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
                                 int64_t field_stride, int ring_base, int only_if_full) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_ring0, "null argument");
-  if (pde->var) {
-    hipLaunchKernelGGL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                       (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
-                       (const double*)pde->d_alphas, ring_base, only_if_full);
-    BEAT_LAUNCH_CHECK();
-    return BEAT_OK;
-  }
+  if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full);
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
                      dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full);

@@ -1,0 +1,76 @@
+// Internal declarations shared by the two translation units of the diffusion step:
+//   beat_pde.hip      constant-coefficient (27 node types) stencil kernels, PCG kernels, the C ABI
+//   beat_pde_var.hip  per-node-coefficient operators, device-side row assembly, Dirichlet elimination
+#pragma once
+#include "beat_common.h"
+
+#include <vector>
+
+namespace beat_pde_detail {
+
+// slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
+enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD };
+constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
+constexpr int TABW = 16;  // padded row width of the device coefficient tables
+
+extern const int kOffsets[45];  // (dx, dy, dz) of the 15 stencil points
+
+struct Geom {
+  int nx, ny, nz;
+  int64_t plane;
+  int tiles_x, tiles_y, nchunks, zc, total;
+  int z_lo_phys, z_hi_phys;
+  int tile_tx;  // 64, 128 or 256: which Tile<> instantiation the grid was sized for
+  int z_lo, z_hi;    // planes [z_lo, z_hi) computed by this launch (whole slab: 0, nz)
+  int part_off;      // first block-partial slot this launch writes
+};
+
+enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_PC = 3 };
+
+}  // namespace beat_pde_detail
+
+struct beat_pde {
+  beat_ctx* ctx = nullptr;
+  beat_pde_detail::Geom g{};
+  int64_t n = 0;
+  double h_mass[27 * 15], h_stiff[27 * 15];
+  double h_A[27 * 15], h_B[27 * 15], h_dinv[27];
+  bool have_dt = false;
+  double C_m = 1.0, theta = 0.5, dt = 0.0;
+  // device: 4 padded tables (A, B, Mass, K), then dinv[32]
+  double* d_tabs = nullptr;
+  double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
+  int last_iters = -1;
+  unsigned vec_grid = 1;
+  double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
+  int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
+  double pc_coef[8] = {1.0};
+  // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
+  bool var = false;
+  const double* v_mass = nullptr;
+  const double* v_stiff = nullptr;
+  double* v_A = nullptr;
+  double* v_dinv = nullptr;
+  int64_t v_ld = 0;
+  int* v_seg = nullptr;        // device: indices of the 256-node segments that hold tissue nodes (ascending)
+  std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
+  const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * beat_pde_detail::TABW; }
+  const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * beat_pde_detail::TABW; }
+  const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }
+};
+
+// fixed-order sum of `count` block partials of `nsum` quantities into out[0..nsum) (beat_pde.hip)
+int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter = nullptr);
+
+// per-node-coefficient variants of the stage operations (beat_pde_var.hip); same contracts as the beat_pde_*
+// entry points that dispatch to them
+int beat_var_form_A(beat_pde* pde);
+int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y);
+int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red);
+int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
+int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
+int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);
+int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next);
+int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
+                   int ring_base, int only_if_full);
