@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--pc-degree", type=int, default=int(os.environ.get("BEAT_PC_DEGREE", "1")),
                     help="1 = Jacobi-PCG, m >= 2 = Chebyshev polynomial preconditioner with m terms")
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
+    ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
+                    "solve instead of inside the next ionic kernel")
     ap.add_argument("--nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
                     "BEAT_FORCE_DISTRIBUTED=1 rehearses on one GPU the slab one of 8 ranks owns at 512^3")
     args = ap.parse_args()
@@ -255,11 +257,15 @@ def main():
     def step(t, i=None):
         if i is not None:
             ev_ode[i][0].record()
-        _hip.check(lib.beat_ode_step(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
-                                     len(p_host), None, 0, t, DT, v_index, None))
+        # the previous solve left its last x += sum alpha_j p_j to this kernel (deferred-x PCG)
+        pend = ops.pending
+        ops.pending = None
+        _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
+                                             len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
+                                             ops.fld, pend[2] if pend else 0))
         if i is not None:
             ev_ode[i][1].record()
-        res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500)
+        res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
         if i is not None:
             ev_pde_end[i].record()
             iters.append(res.iterations)
@@ -279,6 +285,7 @@ def main():
     for i in range(args.steps):
         step(t, i)
         t += DT
+    ops.flush_pending()  # the potential is complete when the timed region ends
     barrier()
     wall = time.perf_counter() - tic
     if world > 1:

@@ -179,6 +179,8 @@ class HipOps:
                      for j in range(nfields - 3)]
         self.p = self.ring[0]
         self.st = ctx.zeros(_hip.ST_SIZE)
+        self.pending = None            # (field, ring_base, count) of a deferred potential update
+        self.st_ptr_for_flush = None   # scalar state the pending update belongs to (None: the handle's own)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
 
@@ -325,12 +327,28 @@ class HipOps:
     def cg_next(self):
         _hip.check(self.lib.beat_pde_cg_next(self.handle, C.c_void_p(self.st.data_ptr()), self.r.ptr, self.p.ptr))
 
-    def solve_single(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it) -> KspResult:
+    def solve_single(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush: bool = False) -> KspResult:
+        """With ``defer_flush`` the last partially filled cycle of search directions is left unapplied and recorded
+        in ``self.pending`` = (field, ring_base, count): the next ionic kernel adds it (beat_ode_step_pending) or
+        ``flush_pending`` does."""
+        self.flush_pending()
         ptrs, amps, k = self._stim_args(stim_w, stim_amp)
         info = _hip.KspInfo()
-        _hip.check(self.lib.beat_pde_solve(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
-                                           C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, C.byref(info)))
+        pend = (C.c_int * 2)()
+        _hip.check(self.lib.beat_pde_solve_ex(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
+                                              C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, int(defer_flush),
+                                              C.byref(info), pend))
+        if pend[1] > 0:
+            self.pending = (x, int(pend[0]), int(pend[1]))
         return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+
+    def flush_pending(self) -> None:
+        """Apply a deferred update of the potential (no-op when nothing is pending)."""
+        if self.pending is not None:
+            x, ring_base, _ = self.pending
+            self.pending = None
+            _hip.check(self.lib.beat_pde_x_flush(self.handle, C.c_void_p(self.st_ptr_for_flush), x.ptr, self.ring[0].ptr,
+                                                 self.fld, ring_base, 0))
 
     def apply(self, which, x, y):
         _hip.check(self.lib.beat_pde_apply(self.handle, which, x.ptr, y.ptr))
@@ -430,10 +448,17 @@ class DiffusionSolver:
             ops.pc_pass(j, slot)
 
     # -- solve ----------------------------------------------------------------------------------
-    def solve(self, v_prev, stim_w, stim_amp, x, rtol=1e-8, atol=1e-50, max_it=1000) -> KspResult:
-        """x <- solution of A x = B v_prev + dt*sum amp_k w_k, started from x0 = v_prev."""
+    def solve(self, v_prev, stim_w, stim_amp, x, rtol=1e-8, atol=1e-50, max_it=1000, defer_flush: bool = False) -> KspResult:
+        """x <- solution of A x = B v_prev + dt*sum amp_k w_k, started from x0 = v_prev.  ``defer_flush``: see
+        HipOps.solve_single (backends without that support simply apply the update)."""
         ops = self.ops
+        can_defer = defer_flush and hasattr(ops, "flush_pending")
+        if hasattr(ops, "flush_pending"):
+            ops.flush_pending()
         if self.dist is None:
+            if can_defer:
+                ops.st_ptr_for_flush = None
+                return ops.solve_single(v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush=True)
             return ops.solve_single(v_prev, stim_w, stim_amp, x, rtol, atol, max_it)
         self.exchange_halo(v_prev)
         ops.rhs(v_prev, stim_w, stim_amp, x)
@@ -477,7 +502,11 @@ class DiffusionSolver:
         if not npass:
             nupd = int(st[_hip.ST_NUPD])
             if nupd % K:
-                ops.x_flush(x, (nupd // K) * K, False)
+                if can_defer:
+                    ops.pending = (x, (nupd // K) * K, nupd % K)
+                    ops.st_ptr_for_flush = ops.st.data_ptr()
+                else:
+                    ops.x_flush(x, (nupd // K) * K, False)
         its = int(st[_hip.ST_ITERS])
         self._last_its = max(its, 1)
         reason = int(st[_hip.ST_REASON]) if st[_hip.ST_STOP] != 0.0 else -3

@@ -59,6 +59,7 @@ SIGNATURES = {
     "beat_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "beat_ode_model_info": (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
     "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
+    "beat_ode_step_pending": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
     "beat_ode_run": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _i64, _int, _int, _vp, _int, _vp]),
     "beat_copy": (_int, [_vp, _vp, _vp, _i64]),
     "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),
@@ -91,6 +92,10 @@ SIGNATURES = {
     "beat_pde_solve": (
         _int,
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],
+    ),
+    "beat_pde_solve_ex": (
+        _int,
+        [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, _int, C.POINTER(KspInfo), C.POINTER(_int)],
     ),
     "beat_field_probe": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
     "beat_field_dot": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_dbl)]),

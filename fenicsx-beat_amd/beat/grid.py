@@ -941,6 +941,7 @@ class Function:
         self._ctx = Context.default()
         self._own = field if field is not None else self._ctx.field(mesh.num_nodes, mesh.plane)
         self._alias = None
+        self._alias_sync = None
         self._version = 0
         self._cache = None
         self._x = _Vector(self)
@@ -956,25 +957,33 @@ class Function:
     @property
     def field(self):
         """Field to READ the current values from."""
-        return self._alias if self._alias is not None else self._own
+        if self._alias is not None:
+            if self._alias_sync is not None:
+                self._alias_sync()  # e.g. a deferred update of the aliased row (fused split step)
+            return self._alias
+        return self._own
 
     def writable_field(self, overwrite_all: bool = True):
         """Field to WRITE into; ends an alias (copying the aliased values first unless everything is
         about to be overwritten).  Call ``_touch()`` after the write."""
         if self._alias is not None:
             if not overwrite_all:
-                self._own.copy_from(self._alias)
+                self._own.copy_from(self.field)
             self._alias = None
+            self._alias_sync = None
         return self._own
 
-    def alias_to(self, field) -> None:
+    def alias_to(self, field, sync=None) -> None:
+        """``sync``: callable run before the aliased field is read (brings it up to date)."""
         self._alias = field
+        self._alias_sync = sync
         self._touch()
 
     def materialize(self) -> None:
         if self._alias is not None:
-            self._own.copy_from(self._alias)
+            self._own.copy_from(self.field)
             self._alias = None
+            self._alias_sync = None
 
     def _touch(self):
         """Call after any device-side modification of the values."""

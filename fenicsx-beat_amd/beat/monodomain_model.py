@@ -56,8 +56,10 @@ class MonodomainModel(BaseModel):
         self.ksp = self._diffusion.solve(self.v_.field, stim_w, stim_amp, x, rtol=rtol, atol=atol, max_it=max_it)
         self._state._touch()
 
-    def solve_in_place(self, field, stim_w, stim_amp):
-        """Fused-step entry: v_ and the unknown share ``field`` (the V row of the ODE state array)."""
+    def solve_in_place(self, field, stim_w, stim_amp, defer_flush: bool = False):
+        """Fused-step entry: v_ and the unknown share ``field`` (the V row of the ODE state array).  With
+        ``defer_flush`` the last update of the potential may stay pending in ``self._ops`` (see HipOps.solve_single)."""
         rtol, atol, max_it = self._solver_tolerances()
-        self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it)
+        self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it,
+                                         defer_flush=defer_flush)
         return self.ksp

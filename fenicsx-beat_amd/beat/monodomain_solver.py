@@ -81,7 +81,8 @@ class MonodomainSplittingSolver:
             with mon.track_time("ode_step"):
                 # functions aliasing the row are re-aliased below, so no materialisation here
                 ode._dev.parameters = ode.parameters
-                ode._dev.step(t0, self.theta * dt)
+                # a deferred x += sum alpha_j p_j of the previous solve is applied by this kernel
+                ode._dev.step(t0, self.theta * dt, v_index=ode.v_index, pending_ops=ode._pending_ops, v_row=row)
             with mon.track_time("pde_step"):
                 theta_pde = pde.parameters["theta"]
                 with pde.monitor.track_time("pde_total_step"):
@@ -97,12 +98,13 @@ class MonodomainSplittingSolver:
                             stim_w.append(s.field)
                             stim_amp.append(a)
                     with pde.monitor.track_time("pde_linear_solve"):
-                        pde.solve_in_place(row, stim_w, stim_amp)
+                        pde.solve_in_place(row, stim_w, stim_amp, defer_flush=True)
+                    ode._pending_ops = pde._ops
                     pde.monitor.record_ksp(pde.ksp)
                 pde.monitor.advance_step(t0, t1)
             with mon.track_time("pde_assign_previous_after"):
                 for f in (pde.state, pde.v_, ode.v_ode):
-                    f.alias_to(row)
+                    f.alias_to(row, sync=pde._ops.flush_pending)
                 ode._aliases = [pde.state, pde.v_, ode.v_ode]
         mon.advance_step(t0, t1)
 

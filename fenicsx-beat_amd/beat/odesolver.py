@@ -128,15 +128,32 @@ class _DeviceODE:
             self._ppn_src = chk
         return None, p.shape[0], C.c_void_p(self._ppn.data_ptr()), self.n
 
-    def step(self, t0, dt, v_index=0, v_copy=None):
+    def step(self, t0, dt, v_index=0, v_copy=None, pending_ops=None, v_row=None):
+        """``pending_ops``: diffusion operators whose last solve deferred its update of ``v_row`` (row v_index of
+        these states): the kernel adds it while loading the potential (beat_ode_step_pending)."""
         hp, npar, ppn, pld = self._param_args()
+        pend = None
+        if pending_ops is not None and pending_ops.pending is not None:
+            if v_row is not None and pending_ops.pending[0].ptr.value == v_row.ptr.value:
+                pend = pending_ops.pending
+                pending_ops.pending = None
+            else:
+                pending_ops.flush_pending()
         with self.monitor.track_time("ode_total_step"):
             with self.monitor.track_time("ode_function_call"):
-                _hip.check(
-                    self.ctx.lib.beat_ode_step(self.ctx.handle, self.model.model_id, self.states.ptr, self.n,
-                                               self.states.ld, hp, npar, ppn, pld, float(t0), float(dt), int(v_index),
-                                               None if v_copy is None else v_copy.ptr)
-                )
+                if pend is not None:
+                    _hip.check(
+                        self.ctx.lib.beat_ode_step_pending(
+                            self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, hp, npar, ppn,
+                            pld, float(t0), float(dt), int(v_index), None if v_copy is None else v_copy.ptr,
+                            pending_ops.handle, pending_ops.ring[0].ptr, pending_ops.fld, int(pend[2]))
+                    )
+                else:
+                    _hip.check(
+                        self.ctx.lib.beat_ode_step(self.ctx.handle, self.model.model_id, self.states.ptr, self.n,
+                                                   self.states.ld, hp, npar, ppn, pld, float(t0), float(dt), int(v_index),
+                                                   None if v_copy is None else v_copy.ptr)
+                    )
             with self.monitor.track_time("ode_state_update"):
                 pass  # updated in place by the kernel
 
@@ -187,6 +204,7 @@ class DolfinODESolver(BaseDolfinODESolver):
 
     def __post_init__(self):
         self._aliases: list[grid.Function] = []
+        self._pending_ops = None  # diffusion operators that may hold a deferred update of the V row (fused step)
         self.on_device = isinstance(self.fun, DeviceModel)
         values = _initial_values(self.init_states, self.shape, self.on_device)
         if self.on_device:
@@ -203,9 +221,16 @@ class DolfinODESolver(BaseDolfinODESolver):
         self._initialize_metadata()
 
     # ---- alias bookkeeping (see grid.Function) ------------------------------------------------
+    def _sync_v(self):
+        """Bring the V row up to date if the last fused diffusion solve left its final update to the next ionic
+        kernel (deferred-x PCG): everything that reads or overwrites the row outside that kernel calls this."""
+        if self._pending_ops is not None:
+            self._pending_ops.flush_pending()
+
     def _release_aliases(self):
         """The V row is about to change outside the fused step: give every function that merely
         aliases it its own copy of the current values first."""
+        self._sync_v()
         for f in self._aliases:
             if f._alias is self._v_row:
                 f.materialize()
@@ -217,6 +242,7 @@ class DolfinODESolver(BaseDolfinODESolver):
         if self.on_device:
             if self.v_ode._alias is self._v_row:
                 return
+            self._sync_v()
             self.v_ode.writable_field().copy_from(self._v_row)
             self.v_ode._touch()
         else:
@@ -234,7 +260,10 @@ class DolfinODESolver(BaseDolfinODESolver):
 
     @property
     def values(self):
-        return self._dev.states.numpy() if self.on_device else self._values
+        if self.on_device:
+            self._sync_v()
+            return self._dev.states.numpy()
+        return self._values
 
     @property
     def num_parameters(self) -> int:

@@ -3,7 +3,7 @@
 //
 // HBM traffic per node-update: 16*NS bytes (each state row read once, written once) plus 8 bytes
 // when the transmembrane potential is mirrored into the PDE vector (dev_v_copy).
-#include "beat_common.h"
+#include "beat_pde_internal.h"
 #include "ionic_models.h"
 #include "generated/torord_dyncl.h"
 
@@ -12,11 +12,22 @@ struct ParamPack {
   double p[NP];
 };
 
+// Search directions of the last diffusion solve whose contribution alpha_j p_j has not been added to the
+// potential row yet (deferred-x PCG, beat_pde_solve_ex with defer_flush): the ionic kernel reads the row anyway,
+// has HBM bandwidth to spare (it is fp64-issue bound) and adds them on the fly, which saves the separate
+// x += sum alpha_j p_j pass (8 (k+2) B/node).
+struct PendingV {
+  const double* ring;    // p_0 (device), p_j = ring + j * fld
+  int64_t fld;
+  const double* alphas;  // device, step lengths alpha_j
+  int count;             // 0: nothing pending
+};
+
 template <class Model, bool PER_NODE>
 __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
-    int v_index, double* __restrict__ v_copy) {
+    int v_index, double* __restrict__ v_copy, PendingV pend) {
   __shared__ double etab[64];
   __shared__ LogEntry ltab[128];
   if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
@@ -25,7 +36,16 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   const FastMath fm{etab, ltab};
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;
-  const NodeIO io{states, ld, i, v_copy, v_index};
+  NodeIO io{states, ld, i, v_copy, v_index};
+  if (pend.count > 0) {
+    // all loads issued together (they overlap with the state loads that follow)
+    io.npend = pend.count;
+#pragma unroll
+    for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
+      io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
+      io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+    }
+  }
   if (PER_NODE) {
     double pl[Model::NP];
 #pragma unroll
@@ -73,7 +93,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
   // is correct through global memory, so generated models round-trip their states through HBM/L2 each
   // step (tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards both variants).
   const RegIO rio{y};
-  const NodeIO gio{states, ld, i, nullptr, 0};
+  NodeIO gio{states, ld, i, nullptr, -1};
   int64_t row = 0;
   for (int beat = 0; beat < nbeats; ++beat) {
     for (int64_t j = 0; j < nsteps; ++j) {
@@ -163,11 +183,11 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
-                      int v_index, double* v_copy) {
+                      int v_index, double* v_copy, const PendingV& pend) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
                "model expects %d parameters, got %d", Model::NP, num_params);
-  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range",
-               v_index);
+  BEAT_REQUIRE((v_copy == nullptr && pend.count == 0) || (v_index >= 0 && v_index < Model::NS),
+               "v_index %d out of range", v_index);
   ParamPack<Model::NP> prm;
   for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
   typename Model::Derived drv = Model::derive(prm.p);
@@ -175,10 +195,10 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
     hipLaunchKernelGGL((ode_step_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
-                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy);
+                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy, pend);
   } else {
     hipLaunchKernelGGL((ode_step_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
-                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy);
+                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy, pend);
   }
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -199,33 +219,46 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
   return BEAT_OK;
 }
 
-extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
-                             const double* host_params, int num_params,
-                             const double* dev_params_per_node, int64_t params_ld, double t, double dt,
-                             int v_index, double* dev_v_copy) {
+static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                             const double* host_params, int num_params, const double* dev_params_per_node,
+                             int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
+                             const PendingV& pend) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
   BEAT_REQUIRE((n + BEAT_BLOCK - 1) / BEAT_BLOCK < (int64_t)0x7fffffff, "n too large");
   if (n == 0) return BEAT_OK;
+#define BEAT_STEP(M)                                                                                             \
+  return launch_ode<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, \
+                       v_index, dev_v_copy, pend)
   switch (model_id) {
-    case BEAT_MODEL_SIMPLE_ODE:
-      return launch_ode<SimpleOde>(ctx, dev_states, n, ld, host_params, num_params,
-                                   dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
-    case BEAT_MODEL_FHN_DEMO:
-      return launch_ode<FhnDemo>(ctx, dev_states, n, ld, host_params, num_params,
-                                 dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
-    case BEAT_MODEL_FHN_README:
-      return launch_ode<FhnReadme>(ctx, dev_states, n, ld, host_params, num_params,
-                                   dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
-    case BEAT_MODEL_TP06_GRL1:
-      return launch_ode<Tp06Grl1>(ctx, dev_states, n, ld, host_params, num_params,
-                                  dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
-    case BEAT_MODEL_TORORD_DYNCL_GRL1:
-      return launch_ode<TorordDynClGrl1>(ctx, dev_states, n, ld, host_params, num_params,
-                                         dev_params_per_node, params_ld, t, dt, v_index, dev_v_copy);
-    default:
-      beat_set_error("unknown model id %d", model_id);
-      return BEAT_EINVAL;
+    case BEAT_MODEL_SIMPLE_ODE: BEAT_STEP(SimpleOde);
+    case BEAT_MODEL_FHN_DEMO: BEAT_STEP(FhnDemo);
+    case BEAT_MODEL_FHN_README: BEAT_STEP(FhnReadme);
+    case BEAT_MODEL_TP06_GRL1: BEAT_STEP(Tp06Grl1);
+    case BEAT_MODEL_TORORD_DYNCL_GRL1: BEAT_STEP(TorordDynClGrl1);
+    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
+#undef BEAT_STEP
+}
+
+extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                             const double* host_params, int num_params,
+                             const double* dev_params_per_node, int64_t params_ld, double t, double dt,
+                             int v_index, double* dev_v_copy) {
+  return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
+                           t, dt, v_index, dev_v_copy, PendingV{nullptr, 0, nullptr, 0});
+}
+
+extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                                     const double* host_params, int num_params,
+                                     const double* dev_params_per_node, int64_t params_ld, double t, double dt,
+                                     int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
+                                     int64_t field_stride, int pending) {
+  static_assert(BEAT_MAX_PENDING == beat_pde_detail::PRING, "pending directions = ring size");
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
+  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending};
+  return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
+                           t, dt, v_index, dev_v_copy, pend);
 }

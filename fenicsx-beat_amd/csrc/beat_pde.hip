@@ -931,7 +931,8 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
 // (ring_j = dev_ring0 + j*field_stride); with only_if_full it acts only when that cycle filled up.
 extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
                                 int64_t field_stride, int ring_base, int only_if_full) {
-  BEAT_REQUIRE(pde != nullptr && dev_st && dev_x && dev_ring0, "null argument");
+  BEAT_REQUIRE(pde != nullptr && dev_x && dev_ring0, "null argument");
+  if (dev_st == nullptr) dev_st = pde->d_st;  // the scalar state of beat_pde_solve[_ex]
   if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full);
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
@@ -944,6 +945,16 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
                               const double* const* host_dev_stim_w, const double* host_stim_amp,
                               int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
                               int max_it, beat_ksp_info* info) {
+  return beat_pde_solve_ex(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_work, rtol, atol, max_it,
+                           0, info, nullptr);
+}
+
+extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
+                                 const double* const* host_dev_stim_w, const double* host_stim_amp,
+                                 int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
+                                 int max_it, int defer_flush, beat_ksp_info* info, int* host_pending) {
+  BEAT_REQUIRE(!defer_flush || host_pending != nullptr, "defer_flush needs host_pending[2]");
+  if (host_pending) host_pending[0] = host_pending[1] = 0;
   BEAT_REQUIRE(pde != nullptr && dev_work != nullptr, "null argument");
   BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "beat_pde_solve is the single-slab path");
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
@@ -1005,8 +1016,14 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
     }
     // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x)
     const int nupd = (int)h[NUPD];
-    if (nupd % PRING != 0)
-      if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) return rc;
+    if (nupd % PRING != 0) {
+      if (defer_flush) {  // the caller adds these directions itself (beat_ode_step_pending / beat_pde_x_flush)
+        host_pending[0] = (nupd / PRING) * PRING;
+        host_pending[1] = nupd % PRING;
+      } else if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) {
+        return rc;
+      }
+    }
   }
   const int iters = (int)h[ITERS];
   pde->last_iters = iters;

@@ -228,13 +228,27 @@ struct FastMath {
   }
 };
 
-// Access to the state-major array for one node (row k at base + k*ld).
+// Access to the state-major array for one node (row k at base + k*ld).  (pa, pp, npend) is the part of the
+// membrane potential the diffusion solve has not written back yet (see beat_ode_step_pending): it is added when
+// row v_index is loaded, in the order x_flush_kernel would have used, so the value is bit-identical to a flushed
+// row; the store writes the complete new value.
+constexpr int BEAT_MAX_PENDING = 6;  // = ring size of the deferred-x PCG
 struct NodeIO {
   double* __restrict__ base;
   int64_t ld, i;
   double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown), may be null
   int v_index;
-  __device__ __forceinline__ double load(int k) const { return base[(int64_t)k * ld + i]; }
+  int npend = 0;
+  double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
+  __device__ __forceinline__ double load(int k) const {
+    double x = base[(int64_t)k * ld + i];
+    if (k == v_index && npend > 0) {
+#pragma unroll
+      for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+        if (j < npend) x = fma(pa[j], pp[j], x);
+    }
+    return x;
+  }
   __device__ __forceinline__ void store(int k, double v) const {
     base[(int64_t)k * ld + i] = v;
     if (v_copy != nullptr && k == v_index) v_copy[i] = v;

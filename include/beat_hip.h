@@ -97,6 +97,16 @@ int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, in
                   const double* host_params, int num_params, const double* dev_params_per_node,
                   int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy);
 
+/* The same step when the preceding diffusion solve deferred its final update of the potential
+ * (beat_pde_solve_ex with defer_flush, or a stage-driven solve that skipped the last beat_pde_x_flush):
+ * row v_index is read as  V + sum_{j < pending} alpha_j p_j  with p_j = dev_ring0 + j*field_stride and the step
+ * lengths kept by `pde`; the new value is stored complete.  Fuses the x += sum alpha_j p_j pass of the
+ * deferred-x PCG into the next ionic kernel, which is fp64-issue bound and has HBM bandwidth to spare. */
+int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                          const double* host_params, int num_params, const double* dev_params_per_node,
+                          int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
+                          beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
+
 /* nbeats x nsteps updates in ONE launch with the node's states held in registers: replaces the Python
  * loops of src/beat/single_cell.py:42-65 (solve_with_save / solve_without_save; t restarts at t0 for every
  * beat and is t0 + j*dt within it) and of src/beat/odesolver.py:24-43.  Optionally records `ntrack` (<= 8)
@@ -249,6 +259,15 @@ int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, doubl
  * dev_work: beat_pde_work_fields() fields (r, q, z, ring[6]) laid out back to back, each with its own
  * ghost planes: size fields*(n_local + 2*nx*ny) doubles. Synchronises. */
 int beat_pde_work_fields(beat_pde* pde);
+/* beat_pde_solve with the option to leave the last, partially filled ring cycle of search directions unapplied:
+ * with defer_flush != 0, host_pending[0] = first iteration of that cycle (ring_base for beat_pde_x_flush) and
+ * host_pending[1] = number of directions still to be added to dev_x (0: dev_x is complete).  The caller must
+ * consume them before the next solve: beat_ode_step_pending, or beat_pde_x_flush(pde, NULL, dev_x, ring, stride,
+ * host_pending[0], 0) where dev_st = NULL selects the handle's own scalar state and ring = dev_work + plane +
+ * 3*(n + 2*plane) is the first search direction of the work array. */
+int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                      const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,
+                      double atol, int max_it, int defer_flush, beat_ksp_info* info, int* host_pending);
 int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
                    double rtol, double atol, int max_it, beat_ksp_info* info);

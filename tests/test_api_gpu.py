@@ -591,3 +591,28 @@ def test_checkpoint_roundtrip(tmp_path):
         np.testing.assert_array_equal(np.asarray(w.x.array), snaps[t])
     with pytest.raises(KeyError):
         beat.io.read_function(fname, w, time=0.25, name="v")
+
+
+def test_deferred_potential_update_is_bit_identical():
+    """The fused split step leaves the last x += sum alpha_j p_j of the diffusion solve to the next ionic kernel
+    (beat_ode_step_pending).  A run that never looks at the potential between steps (update always applied inside
+    the kernel) equals, bit for bit, a run that reads it after every step (update always applied by the flush
+    pass), and reading through any alias (pde.state, pde.v_, ode.v_ode, ode.values) sees the complete value."""
+    runs = {}
+    for peek in (False, True):
+        s = _tp06_slab(True, nsteps=0)
+        ops = s.pde._ops
+        deferred = 0
+        for i in range(12):
+            s.step((i * 0.05, (i + 1) * 0.05))
+            deferred += int(ops.pending is not None)
+            if peek:
+                v = np.asarray(s.pde.state.x.array)
+                assert ops.pending is None
+                np.testing.assert_array_equal(v, np.asarray(s.ode.v_ode.x.array))
+                np.testing.assert_array_equal(v, s.ode.values[17])
+        assert deferred >= 10  # the solve does leave its update pending
+        runs[peek] = s.ode.values.copy()
+        assert ops.pending is None
+        np.testing.assert_array_equal(np.asarray(s.pde.v_.x.array), runs[peek][17])
+    np.testing.assert_array_equal(runs[False], runs[True])
