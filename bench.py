@@ -253,6 +253,7 @@ def main():
     ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     iters = []
+    pend_counts = []  # search directions the timed ionic launches applied on behalf of the previous solve
 
     def step(t, i=None):
         if i is not None:
@@ -260,6 +261,8 @@ def main():
         # the previous solve left its last x += sum alpha_j p_j to this kernel (deferred-x PCG)
         pend = ops.pending
         ops.pending = None
+        if i is not None:
+            pend_counts.append(pend[2] if pend else 0)
         _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
                                              len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
                                              ops.fld, pend[2] if pend else 0))
@@ -310,7 +313,10 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         k_avg = float(np.mean(iters)) if iters else 0.0
         S = len(ic)
-        ode_bytes = 16.0 * S * n_local  # every state row read once + written once
+        # every state row read once + written once, plus one read per pending search direction of the previous
+        # diffusion solve (the launch applies that solve's x += sum alpha_j p_j)
+        k_pend = float(np.mean(pend_counts)) if pend_counts else 0.0
+        ode_bytes = (16.0 * S + 8.0 * k_pend) * n_local
         achieved = ode_bytes / (ode_ms * 1e-3) / 1e9
         step_bytes = (16.0 * S + 16.0 + 88.0 * k_avg) * n_total
         out = {
@@ -349,7 +355,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": ode_bytes,
-                "bytes_per_node": 16.0 * S,
+                "bytes_per_node": 16.0 * S + 8.0 * k_pend,
+                "pending_directions_per_launch": k_pend,
                 "whole_step": {
                     "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,
                     "achieved": step_bytes * args.steps / wall / 1e9 / world,
