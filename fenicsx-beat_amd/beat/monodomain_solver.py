@@ -1,8 +1,8 @@
 """Operator-splitting orchestrator -- interface, step order and monitor keys of
 src/beat/monodomain_solver.py:14-116 (theta = 1 Godunov, theta != 1 adds a corrective ODE step).
 
-When the ODE side is a built-in device model on the PDE's own P1 space and theta == 1, ``step``
-takes a fused route: the ionic kernel updates the state array, the diffusion solve runs in place
+When the ODE side is a built-in device model on the PDE's own P1 space, ``step`` takes a fused route
+(theta == 1: one ionic kernel; theta < 1: the corrective ionic kernel follows the solve): the ionic kernel updates the state array, the diffusion solve runs in place
 on its V row (previous and new potential share the storage), and ``pde.state`` / ``pde.v_`` /
 ``ode.v_ode`` are left as aliases of that row -- same values as the reference's six N-vector
 copies per step (steps 2-4, 6, 7 of the reference sequence), none of the traffic."""
@@ -65,7 +65,7 @@ class MonodomainSplittingSolver:
         ode, pde = self.ode, self.pde
         return (
             self.fused
-            and np.isclose(self.theta, 1.0)
+            and 0.0 < self.theta <= 1.0
             and isinstance(ode, DolfinODESolver)
             and ode.on_device
             and isinstance(pde, MonodomainModel)
@@ -102,6 +102,11 @@ class MonodomainSplittingSolver:
                     ode._pending_ops = pde._ops
                     pde.monitor.record_ksp(pde.ksp)
                 pde.monitor.advance_step(t0, t1)
+            if not np.isclose(self.theta, 1.0):
+                # corrective ionic step of length (1 - theta) dt from t0 + theta dt (monodomain_solver.py:98-113)
+                with mon.track_time("corrective_ode_step"):
+                    ode._dev.step(t0 + self.theta * dt, (1.0 - self.theta) * dt, v_index=ode.v_index,
+                                  pending_ops=ode._pending_ops, v_row=row)
             with mon.track_time("pde_assign_previous_after"):
                 for f in (pde.state, pde.v_, ode.v_ode):
                     f.alias_to(row, sync=pde._ops.flush_pending)
