@@ -189,7 +189,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=512, help="nodes per axis of the cubic slab")
+    ap.add_argument("--size", "--n", dest="n", type=int, default=512,
+                    help="nodes per axis of the cubic slab (use --size under torch.distributed.run: --n is ambiguous there)")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--cpu-sample", type=int, default=160, help="side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -198,7 +199,7 @@ def main():
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
     ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
                     "solve instead of inside the next ionic kernel")
-    ap.add_argument("--nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
+    ap.add_argument("--size-z", "--nz", dest="nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
                     "BEAT_FORCE_DISTRIBUTED=1 rehearses on one GPU the slab one of 8 ranks owns at 512^3")
     args = ap.parse_args()
     global ISOTROPIC
