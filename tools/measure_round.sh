@@ -15,4 +15,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O -o trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O -o pmc_fetch --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O -o pmc_write --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $O/write.log 2>&1
+mkdir -p $O/iso256
+rocprofv3 --kernel-trace --stats -d $O/iso256 -o trace --output-format csv -- python3 $R/bench.py --size 256 --iso --steps 40 --warmup 5 --cpu-sample 0 > $O/iso256/bench.json 2> $O/iso256/trace.log
 ls $O | wc -l
