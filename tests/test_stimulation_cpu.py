@@ -92,3 +92,37 @@ def test_qt_interval():
     assert np.isclose(qt.start_index, qrs_peak_time, atol=2)
     assert np.isclose(qt.end_index, qrs_peak_time + t_peak_offset_ms + 2 * t_width_ms / 3, atol=5)
     assert np.isclose(qt.qt_interval, qt.end_index - qt.start_index)
+
+
+def test_import_shims_expose_the_reference_module_paths():
+    """compat/: the dolfinx / ufl / scifem / mpi4py import lines of the reference's hot-path demos resolve to the
+    beat.grid objects."""
+    import importlib
+    import sys
+    from pathlib import Path
+
+    compat = str(Path(__file__).resolve().parents[1] / "fenicsx-beat_amd" / "compat")
+    shadowed = {m: sys.modules.pop(m) for m in list(sys.modules) if m.split(".")[0] in ("dolfinx", "ufl", "scifem", "mpi4py")}
+    sys.path.insert(0, compat)
+    try:
+        from beat import grid as g
+
+        dolfinx, ufl, scifem = (importlib.import_module(m) for m in ("dolfinx", "ufl", "scifem"))
+        MPI = importlib.import_module("mpi4py.MPI")
+        mesh = dolfinx.mesh.create_unit_square(MPI.COMM_WORLD, 4, 4, dolfinx.mesh.CellType.triangle)
+        assert isinstance(mesh, g.Mesh) and dolfinx.cpp.mesh.CellType is g.CellType
+        time = dolfinx.fem.Constant(mesh, dolfinx.default_scalar_type(0.0))
+        expr = ufl.conditional(ufl.And(ufl.ge(time, 0.0), ufl.le(time, 1.0)), 2.0, 0.0)
+        assert float(expr.evaluate()) == 2.0
+        cells = dolfinx.mesh.locate_entities(mesh, mesh.topology.dim, lambda x: x[0] <= 0.5)
+        tags = dolfinx.mesh.meshtags(mesh, mesh.topology.dim, cells, np.full(len(cells), 1, dtype=np.int32))
+        dx = ufl.Measure("dx", domain=mesh, subdomain_data=tags)
+        assert len(dx(1).cells()) == len(cells) == 16
+        assert scifem.evaluate_function is g.evaluate_function and dolfinx.io.VTXWriter is g.VTXWriter
+        assert MPI.COMM_WORLD.allreduce(3.0, op=MPI.SUM) == 3.0
+    finally:
+        sys.path.remove(compat)
+        for m in list(sys.modules):
+            if m.split(".")[0] in ("dolfinx", "ufl", "scifem", "mpi4py"):
+                del sys.modules[m]
+        sys.modules.update(shadowed)
