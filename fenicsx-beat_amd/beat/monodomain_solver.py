@@ -113,6 +113,64 @@ class MonodomainSplittingSolver:
                 ode._aliases = [pde.state, pde.v_, ode.v_ode]
         mon.advance_step(t0, t1)
 
+    def _can_fuse_multi(self) -> bool:
+        from .odesolver import DolfinMultiODESolver
+
+        ode, pde = self.ode, self.pde
+        return (
+            self.fused
+            and 0.0 < self.theta <= 1.0
+            and isinstance(ode, DolfinMultiODESolver)
+            and ode.on_device
+            and isinstance(pde, MonodomainModel)
+            and ode.v_pde is pde.state
+            and ode.v_ode.x.array.size == pde.state.x.array.size
+        )
+
+    def _fused_multi_step(self, t0, t1):
+        """Per-marker cell models: the potentials are scattered straight into the PDE unknown, the solve runs in
+        place there, the new potentials are gathered back; ``pde.v_`` and ``ode.v_ode`` become aliases of
+        ``pde.state`` -- the values of the literal sequence without its five full-vector copies per step."""
+        ode, pde, mon = self.ode, self.pde, self.monitor
+        dt = t1 - t0
+        with mon.track_time("total_step"):
+            with mon.track_time("ode_step"):
+                ode.step(t0=t0, dt=self.theta * dt)
+            x = pde.state.writable_field(overwrite_all=False)
+            with mon.track_time("ode_to_dolfin"):
+                ode.scatter_v(x)
+            with mon.track_time("pde_step"):
+                theta_pde = pde.parameters["theta"]
+                with pde.monitor.track_time("pde_total_step"):
+                    pde.time.value = t0 + theta_pde * dt
+                    if not abs(dt - float(pde._timestep)) < 1.0e-12:
+                        pde._timestep.value = dt
+                        with pde.monitor.track_time("pde_update_matrices"):
+                            pde._update_matrices()
+                    stim_w, stim_amp = [], []
+                    for s in pde._stimuli:
+                        a = s.amplitude()
+                        if a != 0.0 and s.field is not None:
+                            stim_w.append(s.field)
+                            stim_amp.append(a)
+                    with pde.monitor.track_time("pde_linear_solve"):
+                        pde.solve_in_place(x, stim_w, stim_amp)
+                    pde.monitor.record_ksp(pde.ksp)
+                pde.monitor.advance_step(t0, t1)
+            with mon.track_time("ode_from_dolfin"):
+                ode.gather_v(x)
+            if not np.isclose(self.theta, 1.0):
+                with mon.track_time("corrective_ode_step"):
+                    ode.step(t0 + self.theta * dt, (1.0 - self.theta) * dt)
+                with mon.track_time("corrective_ode_to_dolfin"):
+                    ode.scatter_v(x)
+            pde.state._touch()
+            with mon.track_time("pde_assign_previous_after"):
+                for f in (pde.v_, ode.v_ode):
+                    if f is not pde.state:
+                        f.alias_to(x)
+        mon.advance_step(t0, t1)
+
     def step(self, interval):
         theta = self.theta
         t0, t1 = interval
@@ -121,6 +179,8 @@ class MonodomainSplittingSolver:
 
         if self._can_fuse():
             return self._fused_step(t0, t1)
+        if self._can_fuse_multi():
+            return self._fused_multi_step(t0, t1)
 
         with self.monitor.track_time("total_step"):
             with self.monitor.track_time("ode_step"):

@@ -383,6 +383,20 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
                 arr[self._inds[marker]] = self._values[marker][self.v_index[marker], :]
             self.v_ode.x.array[:] = arr
 
+    def scatter_v(self, dst) -> None:
+        """Potentials of every marker's states -> field ``dst`` (fused split step)."""
+        for marker in self._marker_values:
+            row = self._odes[marker].states.row_field(self.v_index[marker])
+            _hip.check(self._ctx.lib.beat_scatter(self._ctx.handle, dst.ptr, row.ptr,
+                                                  C.c_void_p(self._idx_dev[marker].data_ptr()), row.n))
+
+    def gather_v(self, src) -> None:
+        """Field ``src`` -> the potential rows of every marker's states (fused split step)."""
+        for marker in self._marker_values:
+            row = self._odes[marker].states.row_field(self.v_index[marker])
+            _hip.check(self._ctx.lib.beat_gather(self._ctx.handle, row.ptr, src.ptr,
+                                                 C.c_void_p(self._idx_dev[marker].data_ptr()), row.n))
+
     def from_dolfin(self) -> None:
         if self.on_device:
             src = self.v_ode.field

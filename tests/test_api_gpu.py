@@ -617,3 +617,45 @@ def test_deferred_potential_update_is_bit_identical():
         assert ops.pending is None
         np.testing.assert_array_equal(np.asarray(s.pde.v_.x.array), runs[peek][17])
     np.testing.assert_array_equal(runs[False], runs[True])
+
+
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_fused_multi_celltype_step_equals_reference_sequence(theta):
+    """DolfinMultiODESolver through the fused route (potentials scattered straight into the PDE unknown, in-place
+    solve, gathered back) vs the literal reference sequence: bit-identical states, v_ / v_ode / state agree."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    out = []
+    for fused in (True, False):
+        mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([3.0, 2.0, 1.0])], [12, 8, 4])
+        time = g.Constant(mesh, 0.0)
+        cells = g.locate_entities(mesh, 3, lambda x: x[0] <= 0.75 + 1e-10)
+        tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+        chi = beat.conductivities.default_conductivities("Niederer")["chi"]
+        I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=chi, time=time, subdomain_data=tags, marker=1,
+                                               mesh_unit="mm", amplitude=50_000.0, duration=1.0)
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=np.diag([9.5e-4, 1.3e-4, 1.3e-4]), I_s=I_s, C_m=0.01, dx=I_s.dZ)
+        V = g.functionspace(mesh, ("P", 1))
+        markers = g.Function(V)
+        xs = mesh.node_coordinates(pad3=True)[:, 0]
+        markers.x.array[:] = np.where(xs < 1.0, 0.0, np.where(xs < 2.0, 1.0, 2.0))
+        keys = (0, 1, 2)
+        params = {0: tp06.init_parameter_values(stim_amplitude=0.0), 1: tp06.init_parameter_values(stim_amplitude=0.0, g_Ks=0.098),
+                  2: tp06.init_parameter_values(stim_amplitude=0.0, g_to=0.073)}
+        ode = beat.odesolver.DolfinMultiODESolver(
+            v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: 19 for k in keys},
+            fun={k: tp06.generalized_rush_larsen for k in keys}, init_states={k: tp06.init_state_values() for k in keys},
+            parameters=params, v_index={k: tp06.state_index("V") for k in keys})
+        solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta, fused=fused)
+        assert solver._can_fuse_multi() == fused
+        for i in range(25):
+            solver.step((i * 0.05, (i + 1) * 0.05))
+        v = np.asarray(pde.state.x.array).copy()
+        np.testing.assert_array_equal(v, np.asarray(pde.v_.x.array))
+        np.testing.assert_array_equal(v, np.asarray(ode.v_ode.x.array))
+        out.append((v, ode.full_values.copy()))
+        assert v.max() > -60.0
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
