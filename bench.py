@@ -225,7 +225,16 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from beat import _hip, _stencil
+    from beat import _hip
+
+    if not _hip.library_path().is_file():  # a checkout without the built artefacts (the .so is not tracked)
+        if rank == 0:
+            import __graft_entry__ as entry
+
+            entry.build()
+        if world > 1 or force_dist:
+            dist.barrier()
+    from beat import _stencil
     from beat._device import Context, StateArray
     from beat._engine import DiffusionSolver, HipOps, Slab
 
