@@ -1,30 +1,38 @@
-"""Conductivity helpers (interface of src/beat/conductivities.py:29-118).  With a constant fibre
-direction the tensor ``M = s_l f(x)f + s_t (I - f(x)f)`` is a plain (dim, dim) NumPy matrix; with a
-fibre field given per cell (grid.CellField) it is a CellField of (dim, dim) tensors."""
+"""Conductivity helpers: the public functions of the reference's module (src/beat/conductivities.py:29-118) on the
+structured-grid data model.
+
+The monodomain tensor is ``M = s_l f f^T + s_t (I - f f^T)`` with ``s = (g_i g_e / (g_i + g_e)) / chi`` in uA/mV
+(:63-104).  A constant fibre direction gives a plain (dim, dim) matrix, a per-cell fibre field (``grid.CellField``)
+a per-cell tensor field that ``MonodomainModel`` turns into per-node stencil rows.
+"""
 
 from __future__ import annotations
 
-import logging
 from typing import NamedTuple
 
 import numpy as np
 
 from .units import to_quantity, ureg
 
-logger = logging.getLogger(__name__)
+# published parameter sets: (unit of the conductivities, g_il, g_it, g_el, g_et, chi in 1/cm)
+_PRESETS = {
+    "Niederer": ("S/m", 0.17, 0.019, 0.62, 0.24, 1400.0),
+    "Bishop": ("S/m", 0.34, 0.060, 0.12, 0.08, 1400.0),
+    "Potse": ("mS/cm", 3.0, 0.3, 3.0, 1.2, 800.0),
+}
+_KEYS = ("g_il", "g_it", "g_el", "g_et")
 
 
 def default_conductivities(name="Niederer") -> dict:
-    if name == "Niederer":
-        return {"g_il": 0.17 * ureg("S/m"), "g_it": 0.019 * ureg("S/m"), "g_el": 0.62 * ureg("S/m"),
-                "g_et": 0.24 * ureg("S/m"), "chi": 1400.0 * ureg("cm**-1")}
-    elif name == "Bishop":
-        return {"g_il": 0.34 * ureg("S/m"), "g_it": 0.060 * ureg("S/m"), "g_el": 0.12 * ureg("S/m"),
-                "g_et": 0.08 * ureg("S/m"), "chi": 1400.0 * ureg("cm**-1")}
-    elif name == "Potse":
-        return {"g_il": 3.0 * ureg("mS/cm"), "g_it": 0.3 * ureg("mS/cm"), "g_el": 3.0 * ureg("mS/cm"),
-                "g_et": 1.2 * ureg("mS/cm"), "chi": 800.0 * ureg("cm**-1")}
-    raise ValueError(f"Unknown conductivity tensor {name}")
+    """Intra-/extracellular conductivities along (l) and across (t) the fibres and the surface-to-volume ratio of
+    a named parameter set, as quantities with units."""
+    try:
+        unit, *values, chi = _PRESETS[name]
+    except KeyError:
+        raise ValueError(f"Unknown conductivity tensor {name}") from None
+    out = {key: value * ureg(unit) for key, value in zip(_KEYS, values)}
+    out["chi"] = chi * ureg("cm**-1")
+    return out
 
 
 class Conductivities(NamedTuple):
@@ -32,39 +40,35 @@ class Conductivities(NamedTuple):
     s_t: float
 
 
+def _series(g_i, g_e):
+    """two conductors in series (harmonic mean of intra- and extracellular conductivity), in S/m"""
+    a, b = to_quantity(g_i, "S/m"), to_quantity(g_e, "S/m")
+    return a * b / (a + b)
+
+
 def get_harmonic_mean_conductivity(chi, g_il=0.17, g_it=0.019, g_el=0.62, g_et=0.24) -> Conductivities:
-    sigma_il, sigma_it = to_quantity(g_il, "S/m"), to_quantity(g_it, "S/m")
-    sigma_el, sigma_et = to_quantity(g_el, "S/m"), to_quantity(g_et, "S/m")
-
-    def harmonic_mean(a, b):
-        return a * b / (a + b)
-
-    sigma_l = harmonic_mean(sigma_il, sigma_el)
-    sigma_t = harmonic_mean(sigma_it, sigma_et)
-    if not isinstance(chi, ureg.Quantity):
-        chi = chi * ureg("cm**-1")
-    s_l = (sigma_l / chi).to("uA/mV").magnitude
-    s_t = (sigma_t / chi).to("uA/mV").magnitude
-    return Conductivities(s_l, s_t)
+    """(s_l, s_t) in uA/mV: the monodomain conductivities divided by the surface-to-volume ratio ``chi``
+    (a bare number is taken as 1/cm)."""
+    chi_q = chi if isinstance(chi, ureg.Quantity) else chi * ureg("cm**-1")
+    return Conductivities(*((_series(gi, ge) / chi_q).to("uA/mV").magnitude for gi, ge in ((g_il, g_el), (g_it, g_et))))
 
 
-def conductivity_tensor(s_l: float, s_t: float, f0) -> np.ndarray:
-    from .grid import CellField, Constant, Function
+def conductivity_tensor(s_l: float, s_t: float, f0):
+    """``s_l f f^T + s_t (I - f f^T)`` for a constant direction (vector / ``grid.Constant``) or a per-cell field."""
+    from . import grid
 
-    if isinstance(f0, Function):
+    if isinstance(f0, grid.Function):
         raise NotImplementedError("nodal fibre fields are not implemented: pass the fibres per cell (grid.CellField)")
-    if isinstance(f0, CellField):
-        f = f0.values
-        dim = f.shape[1]
-        ff = f[:, :, None] * f[:, None, :]
-        return CellField(f0.mesh, s_t * np.eye(dim)[None] + (s_l - s_t) * ff)
-    f = np.asarray(f0.value if isinstance(f0, Constant) else f0, dtype=np.float64)
-    dim = len(f)
-    return s_l * np.outer(f, f) + s_t * (np.eye(dim) - np.outer(f, f))
+    if isinstance(f0, grid.CellField):
+        fibres = f0.values
+        eye = np.eye(fibres.shape[1])
+        return grid.CellField(f0.mesh, s_t * eye[None] + (s_l - s_t) * np.einsum("ci,cj->cij", fibres, fibres))
+    direction = np.asarray(f0.value if isinstance(f0, grid.Constant) else f0, dtype=np.float64)
+    ff = np.outer(direction, direction)
+    return s_t * np.eye(len(direction)) + (s_l - s_t) * ff
 
 
-def define_conductivity_tensor(chi, f0, g_il=0.17, g_it=0.019, g_el=0.62, g_et=0.24) -> np.ndarray:
+def define_conductivity_tensor(chi, f0, g_il=0.17, g_it=0.019, g_el=0.62, g_et=0.24):
     if f0 is None:
         raise ValueError("f0 must be provided")
-    s_l, s_t = get_harmonic_mean_conductivity(chi, g_il, g_it, g_el, g_et)
-    return conductivity_tensor(s_l, s_t, f0)
+    return conductivity_tensor(*get_harmonic_mean_conductivity(chi, g_il, g_it, g_el, g_et), f0)

@@ -1,133 +1,149 @@
-"""Monitors threaded through the PDE / ODE / splitting solvers (interface and emitted keys as
-src/beat/telemetry.py:15-136).  Kernels are asynchronous, so ``PerformanceMonitor.track_time``
-synchronises the device stream when a timed region ends; ``NullMonitor`` never synchronises."""
+"""Monitors threaded through the PDE / ODE / splitting solvers.
+
+Public contract of the reference's telemetry module (src/beat/telemetry.py:15-136): a monitor offers
+``track_time(name)`` (context manager), ``record_ksp(ksp)`` and ``advance_step(t0, t1)``; ``PerformanceMonitor``
+exposes ``timings``, ``step_counter``, the ``ksp_*`` statistics, ``display_summary()`` and ``save_summary(path)``
+with the keys ``total_steps`` / ``ksp`` / ``timings``.
+
+Kernels are launched asynchronously here, so a timed region is closed only after the device stream has drained
+(``synchronize=True``); the do-nothing monitor never synchronises and is what the solvers use by default.
+"""
 
 from __future__ import annotations
 
-import abc
 import json
 import logging
 import time
-from contextlib import contextmanager
 from pathlib import Path
-from typing import Dict, Union
 
 logger = logging.getLogger(__name__)
 
 
-class BaseMonitor(abc.ABC):
-    @abc.abstractmethod
-    @contextmanager
+class _Region:
+    """Context manager object handed out by track_time: adds the elapsed wall time to ``sink[name]`` on exit."""
+
+    __slots__ = ("sink", "name", "sync", "start")
+
+    def __init__(self, sink, name, sync):
+        self.sink, self.name, self.sync = sink, name, sync
+
+    def __enter__(self):
+        self.start = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sync is not None:
+            self.sync()
+        self.sink[self.name] = self.sink.get(self.name, 0.0) + (time.perf_counter() - self.start)
+        return False
+
+
+class _NoRegion:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_REGION = _NoRegion()
+
+
+class BaseMonitor:
+    """Interface; the defaults do nothing, so a subclass overrides only the hooks it cares about."""
+
     def track_time(self, name: str):
-        yield
+        return _NO_REGION
 
-    @abc.abstractmethod
     def record_ksp(self, ksp) -> None:
-        pass
+        return None
 
-    @abc.abstractmethod
     def advance_step(self, t0: float, t1: float) -> None:
-        pass
+        return None
 
 
 class NullMonitor(BaseMonitor):
-    @contextmanager
-    def track_time(self, name: str):
-        yield
-
-    def record_ksp(self, ksp) -> None:
-        pass
-
-    def advance_step(self, t0: float, t1: float) -> None:
-        pass
+    """Explicit do-nothing monitor (the solvers' default)."""
 
 
-def _device_sync():
+def _drain_device():
     from ._device import Context
 
-    if Context._default is not None:
-        Context._default.synchronize()
+    ctx = Context._default
+    if ctx is not None:
+        ctx.synchronize()
 
 
 class PerformanceMonitor(BaseMonitor):
-    """Accumulates wall time per named region and KSP statistics; logs every ``log_frequency``
-    steps; ``save_summary`` writes {"total_steps", "ksp": {...}, "timings"} on rank 0."""
+    """Wall time per named region, linear-solver statistics, a log line every ``log_frequency`` steps."""
+
+    _KSP_GETTERS = (("ksp_last_iterations", "getIterationNumber", int),
+                    ("ksp_last_residual_norm", "getResidualNorm", float),
+                    ("ksp_last_converged_reason", "getConvergedReason", int))
 
     def __init__(self, log_frequency: int = 1, comm=None, synchronize: bool = True):
-        from .grid import COMM_WORLD
-
+        if comm is None:
+            from .grid import COMM_WORLD as comm
+        self.comm = comm
         self.log_frequency = log_frequency
-        self.comm = comm if comm is not None else COMM_WORLD
         self.synchronize = synchronize
+        self.timings: dict[str, float] = {}
         self.step_counter = 0
-        self.timings: Dict[str, float] = {}
         self.ksp_total_iterations = 0
         self.ksp_max_iterations = 0
         self.ksp_last_iterations = 0
         self.ksp_last_residual_norm = 0.0
         self.ksp_last_converged_reason = 0
 
-    @contextmanager
+    # -- hooks ------------------------------------------------------------------------------------------------
     def track_time(self, name: str):
-        tic = time.perf_counter()
-        try:
-            yield
-        finally:
-            if self.synchronize:
-                _device_sync()
-            toc = time.perf_counter()
-            self.timings[name] = self.timings.get(name, 0.0) + (toc - tic)
+        return _Region(self.timings, name, _drain_device if self.synchronize else None)
 
     def record_ksp(self, ksp) -> None:
-        try:
-            iterations = int(ksp.getIterationNumber())
-            self.ksp_last_iterations = iterations
-            self.ksp_total_iterations += iterations
-            self.ksp_max_iterations = max(self.ksp_max_iterations, iterations)
-            self.ksp_last_residual_norm = float(ksp.getResidualNorm())
-            self.ksp_last_converged_reason = int(ksp.getConvergedReason())
-        except Exception:
-            pass
+        """Reads iteration count, residual norm and converged reason off a KSP-like object (anything else, e.g.
+        ``None`` before the first solve, is ignored)."""
+        if not all(hasattr(ksp, getter) for _, getter, _ in self._KSP_GETTERS):
+            return
+        for attr, getter, cast in self._KSP_GETTERS:
+            setattr(self, attr, cast(getattr(ksp, getter)()))
+        self.ksp_total_iterations += self.ksp_last_iterations
+        if self.ksp_last_iterations > self.ksp_max_iterations:
+            self.ksp_max_iterations = self.ksp_last_iterations
 
     def advance_step(self, t0: float, t1: float) -> None:
         self.step_counter += 1
-        if self.log_frequency <= 0 or self.step_counter % self.log_frequency != 0:
-            return
-        timing_text = ", ".join(f"{name}={value:.6f}s" for name, value in self.timings.items())
-        logger.info(
-            f"PDE step timing step={self.step_counter}, "
-            f"t=({t0:.5f}, {t1:.5f}), "
-            f"ksp_iterations={self.ksp_last_iterations}, "
-            f"ksp_residual_norm={self.ksp_last_residual_norm:.6e}, "
-            f"ksp_converged_reason={self.ksp_last_converged_reason}, "
-            f"{timing_text}",
-        )
+        if self.log_frequency > 0 and self.step_counter % self.log_frequency == 0:
+            parts = [f"PDE step timing step={self.step_counter}", f"t=({t0:.5f}, {t1:.5f})",
+                     f"ksp_iterations={self.ksp_last_iterations}",
+                     f"ksp_residual_norm={self.ksp_last_residual_norm:.6e}",
+                     f"ksp_converged_reason={self.ksp_last_converged_reason}"]
+            parts += [f"{key}={seconds:.6f}s" for key, seconds in self.timings.items()]
+            logger.info(", ".join(parts))
+
+    # -- reports (rank 0 only) -----------------------------------------------------------------------------------
+    def _report(self) -> dict:
+        return {"total_steps": self.step_counter,
+                "ksp": {"total_iterations": self.ksp_total_iterations, "max_iterations": self.ksp_max_iterations},
+                "timings": self.timings}
 
     def display_summary(self) -> None:
         if self.comm.rank != 0:
             return
-        summary = ["\n" + "=" * 50, f"{'PERFORMANCE SUMMARY':^50}", "=" * 50]
-        summary.append(f"Total Steps:           {self.step_counter}")
-        summary.append(f"KSP Total Iterations:  {self.ksp_total_iterations}")
-        summary.append(f"KSP Max Iterations:    {self.ksp_max_iterations}")
-        summary.append("-" * 50)
-        summary.append(f"{'Metric':<35} | {'Time (s)':>10}")
-        summary.append("-" * 50)
-        for name, duration in sorted(self.timings.items(), key=lambda x: x[1], reverse=True):
-            summary.append(f"{name:<35} | {duration:>10.4f}")
-        summary.append("=" * 50 + "\n")
-        logger.info("\n".join(summary))
+        rule = "=" * 50
+        rows = sorted(self.timings.items(), key=lambda kv: -kv[1])
+        text = [rule, "PERFORMANCE SUMMARY".center(50), rule,
+                f"Total Steps:           {self.step_counter}",
+                f"KSP Total Iterations:  {self.ksp_total_iterations}",
+                f"KSP Max Iterations:    {self.ksp_max_iterations}",
+                "-" * 50, f"{'Metric':<35} | {'Time (s)':>10}", "-" * 50]
+        text += [f"{key:<35} | {seconds:>10.4f}" for key, seconds in rows]
+        text.append(rule)
+        logger.info("\n" + "\n".join(text) + "\n")
 
-    def save_summary(self, filepath: Union[str, Path]) -> None:
+    def save_summary(self, filepath) -> None:
         if self.comm.rank != 0:
             return
-        data = {
-            "total_steps": self.step_counter,
-            "ksp": {"total_iterations": self.ksp_total_iterations, "max_iterations": self.ksp_max_iterations},
-            "timings": self.timings,
-        }
-        filepath = Path(filepath)
-        filepath.parent.mkdir(parents=True, exist_ok=True)
-        with open(filepath, "w") as f:
-            json.dump(data, f, indent=4)
-        logger.info(f"Performance summary saved to {filepath}")
+        target = Path(filepath)
+        target.parent.mkdir(parents=True, exist_ok=True)
+        target.write_text(json.dumps(self._report(), indent=4))
+        logger.info("Performance summary saved to %s", target)

@@ -126,3 +126,56 @@ def test_import_shims_expose_the_reference_module_paths():
             if m.split(".")[0] in ("dolfinx", "ufl", "scifem", "mpi4py"):
                 del sys.modules[m]
         sys.modules.update(shadowed)
+
+
+def test_performance_monitor_contract(tmp_path, caplog):
+    """telemetry: the attributes and keys the reference's own tests rely on (tests/test_telemetry.py)."""
+    import json
+    import logging
+    import time
+
+    from beat.telemetry import NullMonitor, PerformanceMonitor
+
+    null = NullMonitor()
+    with null.track_time("anything"):
+        pass
+    null.record_ksp(None)
+    null.advance_step(0.0, 0.1)
+
+    mon = PerformanceMonitor(log_frequency=2, synchronize=False)
+    for _ in range(2):
+        with mon.track_time("dummy_work"):
+            time.sleep(0.01)
+    assert mon.timings["dummy_work"] >= 0.02
+
+    class Ksp:
+        def __init__(self, its):
+            self.its = its
+
+        def getIterationNumber(self):
+            return self.its
+
+        def getResidualNorm(self):
+            return 1e-6
+
+        def getConvergedReason(self):
+            return 2
+
+    mon.record_ksp(Ksp(5))
+    mon.record_ksp(None)  # ignored
+    mon.record_ksp(Ksp(7))
+    assert (mon.ksp_last_iterations, mon.ksp_total_iterations, mon.ksp_max_iterations) == (7, 12, 7)
+    assert mon.ksp_last_residual_norm == 1e-6 and mon.ksp_last_converged_reason == 2
+    with caplog.at_level(logging.INFO, logger="beat.telemetry"):
+        mon.advance_step(0.0, 0.1)
+        assert len(caplog.records) == 0
+        mon.advance_step(0.1, 0.2)
+        assert len(caplog.records) == 1 and "PDE step timing step=2" in caplog.records[0].message
+        assert "dummy_work=" in caplog.records[0].message
+        mon.display_summary()
+        assert len(caplog.records) == 2 and "PERFORMANCE SUMMARY" in caplog.records[1].message
+    mon.timings["test_metric"] = 1.234
+    out = tmp_path / "sub" / "summary.json"
+    mon.save_summary(out)
+    data = json.loads(out.read_text())
+    assert data["total_steps"] == 2 and data["ksp"]["total_iterations"] == 12 and data["timings"]["test_metric"] == 1.234
