@@ -60,6 +60,20 @@ class Comm:
         if d:
             d.barrier(self.group)
 
+    def allreduce_array(self, values):
+        """Element-wise sum of a small float array over the ranks (returns a NumPy array)."""
+        values = np.asarray(values, dtype=np.float64)
+        d = self._dist()
+        if not d:
+            return values
+        import torch
+
+        t = torch.from_numpy(values.copy())
+        if d.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        d.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
     def allreduce(self, value, op=None):
         d = self._dist()
         if not d:
@@ -1018,14 +1032,13 @@ class Function:
 
 
 def evaluate_function(f: Function, points) -> np.ndarray:
-    """``scifem.evaluate_function(f, points)`` for P1 functions on the box mesh (single rank)."""
+    """``scifem.evaluate_function(f, points)`` for P1 functions on the box mesh; on a slab-decomposed mesh every
+    rank returns the same values (partial sums over the vertices it owns, all-reduced)."""
     import ctypes as C
 
     from . import _hip
 
     mesh = f.function_space.mesh
-    if mesh.comm.size > 1:
-        raise NotImplementedError("point evaluation on a decomposed mesh")
     pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
     d = mesh.dim
     # callers evaluate the same probe points every time step: locate them once per mesh
@@ -1056,15 +1069,29 @@ def evaluate_function(f: Function, points) -> np.ndarray:
     return _probe(f, idx, wts)
 
 
+def _local_probe_args(mesh: Mesh, idx: np.ndarray, wts: np.ndarray):
+    """GLOBAL vertex ids / weights -> this rank's share: vertices of other slabs get weight 0 (and a valid dummy
+    index); summing the ranks' partial values gives the interpolated value without any ghost data."""
+    lo, hi = mesh.slab.z0 * mesh.plane, mesh.slab.z1 * mesh.plane
+    own = (idx >= lo) & (idx < hi)
+    return np.where(own, idx - lo, 0).astype(np.int64), np.where(own, wts, 0.0)
+
+
 def _probe(f: "Function", idx: np.ndarray, wts: np.ndarray) -> np.ndarray:
     import ctypes as C
 
     from . import _hip
 
+    mesh = f.function_space.mesh
+    if mesh.comm.size > 1:
+        idx, wts = _local_probe_args(mesh, idx, wts)
+        idx, wts = np.ascontiguousarray(idx), np.ascontiguousarray(wts)
     out = np.zeros(len(idx))
     ctx = f._ctx
     _hip.check(ctx.lib.beat_field_probe(ctx.handle, f.field.ptr, idx.ctypes.data_as(C.c_void_p),
                                         wts.ctypes.data_as(C.c_void_p), len(idx), out.ctypes.data_as(C.c_void_p)))
+    if mesh.comm.size > 1:
+        out = mesh.comm.allreduce_array(out)
     return out.reshape(-1, 1)
 
 

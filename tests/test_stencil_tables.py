@@ -172,3 +172,28 @@ def test_slabs_balanced_by_tissue_weight():
     assert [s.nz for s in even] == [4, 3, 3]
     with pytest.raises(ValueError):
         Slab(2, 0, 3)
+
+
+def test_probe_weights_split_over_slabs_sum_to_the_global_interpolation():
+    """evaluate_function on a decomposed mesh: every rank keeps only the vertices of its own slab; the partial
+    sums add up to the global P1 interpolation (checked here without devices, slab by slab)."""
+    from types import SimpleNamespace
+
+    from beat import grid as g
+    from beat._engine import Slab
+
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([1.0, 1.0, 2.0])], [4, 4, 8])
+    rng = np.random.default_rng(0)
+    values = rng.standard_normal(mesh.num_nodes_global)
+    idx = rng.integers(0, mesh.num_nodes_global, size=(6, 4))
+    wts = rng.random((6, 4))
+    total = (wts * values[idx]).sum(axis=1)
+    parts = np.zeros(6)
+    for r in range(3):
+        slab = Slab(mesh.shape_global[2], r, 3)
+        local = SimpleNamespace(slab=slab, plane=mesh.plane)
+        li, lw = g._local_probe_args(local, idx, wts)
+        owned = values[slab.z0 * mesh.plane : slab.z1 * mesh.plane]
+        assert li.min() >= 0 and li.max() < len(owned)
+        parts += (lw * owned[li]).sum(axis=1)
+    np.testing.assert_allclose(parts, total, rtol=1e-14)
