@@ -7,7 +7,7 @@ from __future__ import annotations
 import abc
 import logging
 from enum import Enum, auto
-from typing import Any, Literal, NamedTuple, Sequence
+from typing import Any, Literal, NamedTuple
 
 import numpy as np
 

@@ -10,8 +10,6 @@ from __future__ import annotations
 
 import logging
 
-import numpy as np
-
 from . import grid
 from ._engine import DiffusionSolver, build_ops, conductivity_array
 from .base_model import BaseModel

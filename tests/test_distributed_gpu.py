@@ -18,7 +18,6 @@ def _free_port():
 
 @pytest.mark.parametrize("per_node", [False, True])
 def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node):
-    import torch
     import torch.distributed as dist
 
     from beat import _stencil

@@ -1,7 +1,6 @@
 """GPU: the HIP path against the committed golden fixtures (tests/golden/, generated from the
 reference's own modules and model specification by tests/golden/make_golden.py)."""
 
-import ctypes as C
 import json
 from pathlib import Path
 

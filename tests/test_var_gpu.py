@@ -60,8 +60,7 @@ def test_per_node_operators_match_assembled_matrices(hip_ctx, cells, L):
     """A, B, Mass, K applied by the per-node kernels vs scipy CSR matrices assembled cell by cell over the
     active cells with per-cell tensors: <= 1e-13 * ||row||_1 * max|x|.  Rows of untouched nodes are identity
     for A and zero for Mass / K.  Ghost planes are poisoned with NaN."""
-    from beat import _hip, _stencil
-    from beat._device import Field
+    from beat import _stencil
     from beat._engine import HipOps
 
     ctx = hip_ctx

@@ -19,7 +19,6 @@ def main():
     args = ap.parse_args()
     import torch
 
-    from beat import _stencil
     from beat._device import Context
     from beat._engine import HipOps
 
