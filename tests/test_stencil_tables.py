@@ -197,3 +197,29 @@ def test_probe_weights_split_over_slabs_sum_to_the_global_interpolation():
         assert li.min() >= 0 and li.max() < len(owned)
         parts += (lw * owned[li]).sum(axis=1)
     np.testing.assert_allclose(parts, total, rtol=1e-14)
+
+
+def test_voxelize_tetrahedra():
+    """geometry.voxelize_tetrahedra: a box tetrahedral mesh rasterised at its own cell size gives a full mask of the
+    same cell counts (+ padding ring); a subset of its cells gives exactly the voxels whose centres they contain, and
+    per-tetrahedron data arrive in the voxels."""
+    import beat
+    from beat import grid as g
+
+    om = fem.BoxMesh((4, 3, 2), (2.0, 1.5, 1.0))
+    fib = np.zeros((len(om.cells), 3))
+    fib[:, 0] = om.x[om.cells].mean(axis=1)[:, 0]  # a per-tet value that varies in x
+    vg = beat.geometry.voxelize_tetrahedra(g.COMM_WORLD, om.x, om.cells, 0.5, cell_data={"f0": fib})
+    assert vg.mask.shape == (4, 5, 6) and vg.mask[1:-1, 1:-1, 1:-1].all() and vg.mask.sum() == 24
+    assert vg.mesh.n == (6, 5, 4) and np.allclose(vg.mesh.lower, -0.5)
+    f0 = vg.cell_data["f0"].reshape(4, 5, 6, 3)
+    centres_x = (np.arange(6) + 0.5) * 0.5 - 0.5
+    inside = vg.mask
+    # the containing tetrahedron's centroid lies in the same voxel column, within half a cell
+    assert np.abs(f0[..., 0][inside] - np.broadcast_to(centres_x, (4, 5, 6))[inside]).max() <= 0.25 + 1e-12
+    assert (vg.tet_index.reshape(4, 5, 6)[~inside] == -1).all()
+    # a finer raster of the lower-left part: volume of the mask ~ volume of the selected tetrahedra
+    sel = om.x[om.cells].mean(axis=1)[:, 0] < 1.0
+    vg2 = beat.geometry.voxelize_tetrahedra(g.COMM_WORLD, om.x, om.cells[sel], 0.125)
+    vol, _ = fem._cell_geometry(om)
+    assert abs(vg2.mask.sum() * 0.125**3 - vol[sel].sum()) < 0.02 * vol[sel].sum()
