@@ -658,6 +658,13 @@ def meshtags(mesh: Mesh, dim: int, entities, values) -> MeshTags:
     return MeshTags(mesh, int(dim), entities[order], values[order])
 
 
+class _IntegralType(str):
+    """'dx' / 'ds'; calling it gives ufl's long name ("cell" / "exterior_facet"), as ``Measure.integral_type()``."""
+
+    def __call__(self):
+        return {"dx": "cell", "ds": "exterior_facet"}[str(self)]
+
+
 class Measure:
     """``ufl.Measure("dx", domain=mesh, subdomain_data=tags)``; calling it with a marker restricts
     the integration domain to the cells carrying that tag."""
@@ -665,7 +672,7 @@ class Measure:
     def __init__(self, integral_type="dx", domain=None, subdomain_data=None, subdomain_id=None, metadata=None):
         if integral_type not in ("dx", "ds"):
             raise NotImplementedError("only cell ('dx') and exterior-facet ('ds') measures are implemented")
-        self.integral_type = integral_type
+        self.integral_type = _IntegralType(integral_type)
         self.domain = domain
         self.subdomain_data = subdomain_data
         self.subdomain_id = subdomain_id

@@ -179,3 +179,19 @@ def test_performance_monitor_contract(tmp_path, caplog):
     mon.save_summary(out)
     data = json.loads(out.read_text())
     assert data["total_steps"] == 2 and data["ksp"]["total_iterations"] == 12 and data["timings"]["test_metric"] == 1.234
+
+
+@pytest.mark.parametrize("dim,subdomain_dim,integral_type", [(2, 1, "exterior_facet"), (2, 2, "cell"), (3, 2, "exterior_facet"), (3, 3, "cell")])
+def test_get_dZ_and_effective_dim(dim, subdomain_dim, integral_type):
+    """tests/test_stimulation.py:110-205 of the reference for the entity dimensions this package has
+    (cells and exterior facets)."""
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 2, 2, g.CellType.triangle) if dim == 2 else g.create_unit_cube(g.COMM_WORLD, 2, 2, 2)
+    ents = g.locate_entities(mesh, subdomain_dim, lambda x: np.logical_and(x[0] <= 0.5, x[1] <= 0.5))
+    tags = g.meshtags(mesh, subdomain_dim, ents, np.full(len(ents), 1, dtype=np.int32))
+    assert len(ents) > 0
+    dZ = beat.stimulation.get_dZ(mesh, tags)
+    assert isinstance(dZ, g.Measure) and dZ.integral_type() == integral_type
+    assert beat.stimulation.compute_effective_dim(mesh, tags) == subdomain_dim + (3 - dim)

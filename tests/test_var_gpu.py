@@ -521,3 +521,54 @@ def test_expand_layer_and_surface_stimulus_on_voxel_shell():
         solver.step((i * 0.05, (i + 1) * 0.05))
     v = np.asarray(pde.state.x.array)
     assert v[endo_nodes].mean() > v[tissue & ~endo_nodes].mean() + 5.0 and np.isfinite(v).all()
+
+
+def _square_layers(biv: bool):
+    """The set-up of the reference's tests/test_utils.py: unit square, N = 50, facet tags on the left (and, for the
+    bi-ventricular variant, bottom-left / top-left) and right edges; endo_size = epi_size = 0.3."""
+    import beat
+    from beat import grid as g
+
+    N, tol = 50, 1.0e-8
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N, g.CellType.triangle)
+    fdim = mesh.topology.dim - 1
+    if biv:
+        groups = [g.locate_entities_boundary(mesh, fdim, lambda x: np.logical_and(x[1] <= tol, x[0] <= 0.5 + tol)),
+                  g.locate_entities_boundary(mesh, fdim, lambda x: np.logical_and(x[1] >= 1 - tol, x[0] <= 0.5 + tol)),
+                  g.locate_entities_boundary(mesh, fdim, lambda x: x[0] >= 1 - tol)]
+    else:
+        groups = [g.locate_entities_boundary(mesh, fdim, lambda x: x[0] <= tol),
+                  g.locate_entities_boundary(mesh, fdim, lambda x: x[0] >= 1 - tol)]
+    facets = np.hstack(groups)
+    values = np.hstack([np.full(len(f), k + 1) for k, f in enumerate(groups)])
+    order = np.argsort(facets)
+    ft = g.meshtags(mesh, fdim, facets[order], values[order])
+    V = g.functionspace(mesh, ("Lagrange", 1))
+    kw = dict(V=V, ft=ft, endo_size=0.3, epi_size=0.3, output_mid_marker=4, output_endo_marker=3, output_epi_marker=1)
+    if biv:
+        return beat.utils.expand_layer_biv(endo_lv_marker=1, endo_rv_marker=2, epi_marker=3, **kw)
+    return beat.utils.expand_layer(endo_marker=1, epi_marker=2, **kw)
+
+
+def test_expand_layer_single():
+    """tests/test_utils.py:10-69 of the reference."""
+    from beat import grid as g
+
+    markers = _square_layers(False)
+    points = np.array([(x, y) for x in [0.0, 0.1, 0.2] for y in [0.0, 0.5, 1.0]])
+    assert np.allclose(g.evaluate_function(markers, points), 3)
+    assert np.allclose(g.evaluate_function(markers, points + np.array([0.4, 0.0])), 4)
+    assert np.allclose(g.evaluate_function(markers, points + np.array([0.8, 0.0])), 1)
+
+
+def test_expand_layer_biv():
+    """tests/test_utils.py:72-149 of the reference."""
+    from beat import grid as g
+
+    markers = _square_layers(True)
+    endo_points = np.array([(0.0, 0.0), (0.0, 1.0), (0.2, 0.2), (0.2, 0.8)])
+    mid_points = np.array([(0.5 + i, 0.5 + j) for i in [-0.1, 0.0, 0.1] for j in [-0.1, 0.0, 0.1]] + [(0.0, 0.5)])
+    epi_points = np.array([(1.0, 0.0), (1.0, 1.0), (0.8, 0.2), (0.8, 0.8)])
+    assert np.allclose(g.evaluate_function(markers, endo_points), 3)
+    assert np.allclose(g.evaluate_function(markers, mid_points), 4)
+    assert np.allclose(g.evaluate_function(markers, epi_points), 1)
