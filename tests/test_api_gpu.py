@@ -284,6 +284,44 @@ def test_monodomain_splitting_analytic(mode):
     assert np.array_equal(ode.values[0], np.asarray(pde.state.x.array))
 
 
+def _split_error(N, dt, theta=1.0, T=1.0):
+    """L2 error at t = T of the split system of tests/test_monodomain_solver.py (v = cos cos sin t, s = -cos cos cos t,
+    forward-Euler ODE on the device, P1 ODE space)."""
+    import beat
+    from beat import grid as g
+
+    mesh = g.create_unit_square(g.COMM_WORLD, N, N)
+    time = g.Constant(mesh, 0.0)
+    x = g.SpatialCoordinate(mesh)
+    I_s = 8 * g.pi**2 * g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * g.sin(time)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=I_s)
+    V_ode = beat.utils.space_from_string("CG_1", mesh, dim=1)
+    s = g.Function(V_ode)
+    s.interpolate(lambda p: -np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]))
+    init_states = np.zeros((2, s.x.array.size))
+    init_states[1, :] = np.asarray(s.x.array)
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V_ode), v_pde=pde.state, fun=beat.models.simple.forward_euler,
+                                         init_states=init_states, parameters=None, num_states=2, v_index=0)
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta)
+    solver.solve((0.0, T), dt=dt)
+    return _l2_error(mesh, pde.state.x.array,
+                     lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(float(time)))
+
+
+def test_monodomain_splitting_spatial_convergence():
+    """tests/test_monodomain_solver.py:90-149 (CG_1): N = 8, 16, 32 at dt = 0.001 -> average rate > 1.85."""
+    errors = [_split_error(2**level, 0.001) for level in range(3, 6)]
+    rates = [np.log2(e1 / e2) for e1, e2 in zip(errors[:-1], errors[1:])]
+    assert sum(rates) / len(rates) > 1.85, (errors, rates)
+
+
+def test_monodomain_splitting_temporal_convergence():
+    """tests/test_monodomain_solver.py:152-216 (theta = 1, CG_1): N = 150, dt = 1/8, 1/16, 1/32 -> average rate > 1."""
+    errors = [_split_error(150, 1.0 / 2**level) for level in range(3, 6)]
+    rates = [np.log2(e1 / e2) for e1, e2 in zip(errors[:-1], errors[1:])]
+    assert sum(rates) / len(rates) > 1.0, (errors, rates)
+
+
 def _tp06_slab(fused, theta=1.0, nsteps=40, stim=True, ksp_rtol=None):
     import beat
     from beat import grid as g
