@@ -65,6 +65,7 @@ SIGNATURES = {
     "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),
     "beat_gather": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "beat_scatter": (_int, [_vp, _vp, _vp, _vp, _i64]),
+    "beat_interp2": (_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "beat_pde_create": (_int, [_vp, C.POINTER(_i64), _int, _int, _vp, _vp, C.POINTER(_vp)]),
     "beat_pde_assemble_rows": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "beat_rows_apply_dirichlet": (_int, [_vp, C.POINTER(_i64), _vp, _i64, _vp, _vp, _vp]),

@@ -752,32 +752,87 @@ class _Element:
 
 
 class FunctionSpace:
+    """P1 (the PDE space, values on the device with ghost planes), DG0 (host-side cell data), and -- as ODE spaces
+    only -- P2 and DG1, whose functions are plain device vectors exchanged with P1 by interpolation
+    (``utils.local_project``)."""
+
     def __init__(self, mesh: Mesh, family="Lagrange", degree=1):
         fam = {"P": "Lagrange", "CG": "Lagrange", "Lagrange": "Lagrange"}.get(family)
-        if family in ("DG", "Discontinuous Lagrange") and degree == 0:
-            fam = "DG"  # piecewise constants: host-side data only (stimulus fields, see CellFunction)
-        elif fam is None or degree != 1:
-            raise NotImplementedError(
-                f"only continuous P1 (and DG0 data) spaces are implemented on the HIP backend (got {family} {degree})"
-            )
+        if family in ("DG", "Discontinuous Lagrange", "dP") and degree in (0, 1):
+            fam = "DG"  # degree 0: host-side cell data (CellFunction); degree 1: ODE space
+        elif fam is None or degree not in (1, 2):
+            raise NotImplementedError(f"function space {family} {degree} is not implemented on the HIP backend")
+        if (fam, degree) != ("Lagrange", 1) and mesh.comm.size > 1 and degree != 0:
+            raise NotImplementedError("P2 / DG1 ODE spaces are implemented on one rank only")
         self.mesh = mesh
         self.family = fam
         self.degree = degree
         self._element = _Element(fam, degree)
+        self._layout = None
 
     def ufl_element(self):
         return self._element
 
     @property
+    def is_p1(self) -> bool:
+        return self.family == "Lagrange" and self.degree == 1
+
+    # -- degrees of freedom of the non-P1 spaces ------------------------------------------------------------------
+    def _edges(self):
+        """(first vertex, second vertex) of every edge of the simplicial mesh: node i and i + o for the forward
+        stencil offsets o that stay inside the box (every such pair shares a box cell, hence an edge)."""
+        mesh = self.mesh
+        nx, ny, nz = mesh.shape_global
+        iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        node = (ix + nx * (iy + ny * iz)).ravel()
+        ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
+        a, b = [], []
+        for ox, oy, oz in _stencil.OFFSETS[1::2]:
+            if (oy and mesh.dim < 2) or (oz and mesh.dim < 3):
+                continue
+            ok = (ix + ox < nx) & (iy + oy < ny) & (iz + oz < nz)
+            a.append(node[ok])
+            b.append(node[ok] + ox + nx * (oy + ny * oz))
+        return np.concatenate(a), np.concatenate(b)
+
+    def layout(self):
+        """(from_p1, to_p1): from_p1 = (idx (n, 2), w (n, 2)) expressing every dof as a combination of P1 vertex
+        values (the P1 interpolant evaluated at the dof's point); to_p1 = for every vertex one dof located there."""
+        if self._layout is None:
+            mesh = self.mesh
+            nv = mesh.num_nodes_global
+            if self.family == "Lagrange" and self.degree == 2:
+                ea, eb = self._edges()
+                idx = np.concatenate([np.stack([np.arange(nv), np.arange(nv)], axis=1), np.stack([ea, eb], axis=1)])
+                w = np.concatenate([np.tile([1.0, 0.0], (nv, 1)), np.full((len(ea), 2), 0.5)])
+                to_p1 = np.arange(nv, dtype=np.int64)
+            elif self.family == "DG" and self.degree == 1:
+                verts = mesh.cell_vertices(mesh.all_cells()).ravel()
+                idx = np.stack([verts, verts], axis=1)
+                w = np.tile([1.0, 0.0], (len(verts), 1))
+                to_p1 = np.zeros(nv, dtype=np.int64)
+                to_p1[verts[::-1]] = np.arange(len(verts))[::-1]  # first dof sitting at each vertex
+            else:
+                raise NotImplementedError("layout is only needed for P2 / DG1 spaces")
+            self._layout = ((np.ascontiguousarray(idx, dtype=np.int64), np.ascontiguousarray(w)), to_p1)
+        return self._layout
+
+    @property
     def num_dofs(self):
-        if self.family == "DG":
+        if self.family == "DG" and self.degree == 0:
             return self.mesh.num_box_cells * self.mesh.simplices_per_cell
-        return self.mesh.num_nodes
+        if self.is_p1:
+            return self.mesh.num_nodes
+        return len(self.layout()[0][0])
 
     def tabulate_dof_coordinates(self):
-        if self.family == "DG":
+        if self.family == "DG" and self.degree == 0:
             return cell_midpoints(self.mesh, np.arange(self.num_dofs, dtype=np.int64))
-        return self.mesh.node_coordinates(pad3=True)
+        if self.is_p1:
+            return self.mesh.node_coordinates(pad3=True)
+        (idx, w), _ = self.layout()
+        xyz = self.mesh.node_coordinates(pad3=True, local=False)
+        return w[:, :1] * xyz[idx[:, 0]] + w[:, 1:] * xyz[idx[:, 1]]
 
 
 def functionspace(mesh: Mesh, element, **kw) -> FunctionSpace:
@@ -949,7 +1004,7 @@ class Function:
     the moment the two would diverge)."""
 
     def __new__(cls, V: FunctionSpace = None, *a, **kw):
-        if V is not None and getattr(V, "family", None) == "DG":
+        if V is not None and getattr(V, "family", None) == "DG" and V.degree == 0:
             return CellFunction(V, *a, **kw)
         return super().__new__(cls)
 
@@ -960,7 +1015,12 @@ class Function:
         self.name = name
         mesh = V.mesh
         self._ctx = Context.default()
-        self._own = field if field is not None else self._ctx.field(mesh.num_nodes, mesh.plane)
+        if field is not None:
+            self._own = field
+        elif V.is_p1:
+            self._own = self._ctx.field(mesh.num_nodes, mesh.plane)
+        else:  # P2 / DG1 ODE spaces: a plain device vector (never an operand of the stencil kernels)
+            self._own = self._ctx.field(V.num_dofs, 0)
         self._alias = None
         self._alias_sync = None
         self._version = 0
@@ -1018,7 +1078,7 @@ class Function:
         return self._cache[1]
 
     def interpolate(self, f) -> None:
-        x = self.function_space.mesh.node_coordinates(pad3=True).T
+        x = self.function_space.tabulate_dof_coordinates().T
         if isinstance(f, Expression):
             f = f.expr
         if isinstance(f, Expr):

@@ -209,7 +209,8 @@ class DolfinODESolver(BaseDolfinODESolver):
         values = _initial_values(self.init_states, self.shape, self.on_device)
         if self.on_device:
             mesh = self.v_ode.function_space.mesh
-            self._dev = _DeviceODE(self.v_ode._ctx, self.fun, self.num_states, self.num_points, mesh.plane,
+            plane = mesh.plane if self.v_ode.function_space.is_p1 else 0  # only P1 rows are stencil operands
+            self._dev = _DeviceODE(self.v_ode._ctx, self.fun, self.num_states, self.num_points, plane,
                                    self.parameters, self.monitor)
             self._dev.set_initial(values)
             self._v_row = self._dev.states.row_field(self.v_index)

@@ -13,17 +13,44 @@ from . import _hip, grid
 logger = logging.getLogger(__name__)
 
 
+def _interp_maps(V):
+    """device copies of the interpolation maps of a P2 / DG1 space (cached on the space)"""
+    from ._device import Context
+
+    if getattr(V, "_dev_maps", None) is None:
+        ctx = Context.default()
+        (idx, w), to_p1 = V.layout()
+        pick = np.stack([to_p1, to_p1], axis=1)
+        one = np.tile([1.0, 0.0], (len(to_p1), 1))
+        V._dev_maps = {"from_p1": (ctx.from_numpy(idx), ctx.from_numpy(w)),
+                       "to_p1": (ctx.from_numpy(np.ascontiguousarray(pick)), ctx.from_numpy(np.ascontiguousarray(one)))}
+    return V._dev_maps
+
+
 def local_project(v: grid.Function, V: grid.FunctionSpace, u: grid.Function | None = None):
-    """ODE-space -> PDE-space transfer.  Both are P1 on the same mesh here, i.e. the identity-copy
-    branch of utils.py:52-54 (a device-to-device copy)."""
+    """ODE-space <-> PDE-space transfer (utils.py:26-58): a copy when both have the same degrees of freedom (the hot
+    path: P1 on both sides), otherwise the interpolation of ``v`` at the points of ``V`` -- between P1 and a P2 / DG1
+    ODE space that is a fixed two-term combination per dof, applied on the device (beat_interp2)."""
     U = grid.Function(V) if u is None else u
-    if v.x.array.size != U.x.array.size:
-        raise NotImplementedError("projection between different spaces is not implemented on the HIP backend")
-    U.x.array[:] = v.x.array
+    src_space = v.function_space
+    if v.x.array.size == U.x.array.size:
+        U.x.array[:] = v.x.array
+        return U
+    if src_space.is_p1 and not V.is_p1:
+        idx, w = _interp_maps(V)["from_p1"]
+    elif V.is_p1 and not src_space.is_p1:
+        idx, w = _interp_maps(src_space)["to_p1"]
+    else:
+        raise NotImplementedError("projection between two non-P1 spaces is not implemented")
+    dst = U.writable_field()
+    ctx = U._ctx
+    _hip.check(ctx.lib.beat_interp2(ctx.handle, dst.ptr, v.field.ptr, C.c_void_p(idx.data_ptr()), C.c_void_p(w.data_ptr()), dst.n))
+    U._touch()
     return U
 
 
 def space_from_string(space_string: str, mesh: grid.Mesh, dim: int = 1) -> grid.FunctionSpace:
+    """'{family}_{degree}' -> function space (utils.py:86-112): P / CG / Lagrange 1 and 2, DG / dP 0 and 1."""
     family, degree = space_string.split("_")
     if dim != 1:
         raise NotImplementedError("vector spaces are not implemented")

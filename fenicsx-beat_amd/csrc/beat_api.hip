@@ -235,6 +235,26 @@ __global__ __launch_bounds__(BEAT_BLOCK) void minmax_partial_kernel(const double
 }
 
 namespace {
+__global__ __launch_bounds__(BEAT_BLOCK) void interp2_kernel(double* __restrict__ dst, const double* __restrict__ src,
+                                                             const int64_t* __restrict__ idx,
+                                                             const double* __restrict__ w, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  for (int64_t j = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; j < n; j += stride)
+    dst[j] = fma(w[2 * j], src[idx[2 * j]], w[2 * j + 1] * src[idx[2 * j + 1]]);
+}
+}  // namespace
+
+extern "C" int beat_interp2(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx,
+                            const double* dev_w, int64_t n) {
+  BEAT_REQUIRE(ctx != nullptr && dev_dst && dev_src && dev_idx && dev_w && n >= 0, "bad argument");
+  if (n == 0) return BEAT_OK;
+  hipLaunchKernelGGL(interp2_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst, dev_src, dev_idx,
+                     dev_w, n);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+namespace {
 __global__ __launch_bounds__(BEAT_BLOCK) void dot_partial_kernel(const double* __restrict__ x,
                                                                  const double* __restrict__ y, int64_t n,
                                                                  double* __restrict__ partials) {

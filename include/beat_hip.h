@@ -125,6 +125,12 @@ int beat_fill(beat_ctx* ctx, double* dev_dst, double value, int64_t n);
 int beat_gather(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, int64_t n);
 int beat_scatter(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, int64_t n);
 
+/* dst[j] = w[2j] src[idx[2j]] + w[2j+1] src[idx[2j+1]]: interpolation between the PDE's P1 space and an ODE space
+ * with other degrees of freedom (P2: vertices and edge midpoints, DG1: vertices per cell) -- utils.local_project,
+ * utils.py:26-58, as used by ode_to_pde / pde_to_ode (odesolver.py:101-115). */
+int beat_interp2(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, const double* dev_w,
+                 int64_t n);
+
 /* ---- diffusion (PDE) step: replaces LinearProblem assembly + KSP solve
  *      src/beat/base_model.py:114-124,188-245 ---------------------------------------------- */
 /* Structured-grid operator of one z-slab.

@@ -284,9 +284,9 @@ def test_monodomain_splitting_analytic(mode):
     assert np.array_equal(ode.values[0], np.asarray(pde.state.x.array))
 
 
-def _split_error(N, dt, theta=1.0, T=1.0):
+def _split_error(N, dt, theta=1.0, T=1.0, odespace="CG_1"):
     """L2 error at t = T of the split system of tests/test_monodomain_solver.py (v = cos cos sin t, s = -cos cos cos t,
-    forward-Euler ODE on the device, P1 ODE space)."""
+    forward-Euler ODE on the device; ODE space CG_1, CG_2 or DG_1 as the reference parametrises it)."""
     import beat
     from beat import grid as g
 
@@ -295,29 +295,41 @@ def _split_error(N, dt, theta=1.0, T=1.0):
     x = g.SpatialCoordinate(mesh)
     I_s = 8 * g.pi**2 * g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * g.sin(time)
     pde = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=I_s)
-    V_ode = beat.utils.space_from_string("CG_1", mesh, dim=1)
+    V_ode = beat.utils.space_from_string(odespace, mesh, dim=1)
     s = g.Function(V_ode)
     s.interpolate(lambda p: -np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]))
     init_states = np.zeros((2, s.x.array.size))
     init_states[1, :] = np.asarray(s.x.array)
     ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V_ode), v_pde=pde.state, fun=beat.models.simple.forward_euler,
                                          init_states=init_states, parameters=None, num_states=2, v_index=0)
+    assert ode.num_points == V_ode.num_dofs
     solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta)
     solver.solve((0.0, T), dt=dt)
     return _l2_error(mesh, pde.state.x.array,
                      lambda p: np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * np.sin(float(time)))
 
 
-def test_monodomain_splitting_spatial_convergence():
-    """tests/test_monodomain_solver.py:90-149 (CG_1): N = 8, 16, 32 at dt = 0.001 -> average rate > 1.85."""
-    errors = [_split_error(2**level, 0.001) for level in range(3, 6)]
+@pytest.mark.parametrize("odespace", ["CG_1", "CG_2", "DG_1"])
+def test_monodomain_splitting_analytic_other_ode_spaces(odespace):
+    """tests/test_monodomain_solver.py:33-87 with the ODE on a P2 / DG1 space (transfers by interpolation,
+    utils.local_project): N = 50, dt = 0.01 -> error < 0.002 as for the P1 ODE space."""
+    if odespace == "CG_1":
+        pytest.skip("covered by test_monodomain_splitting_analytic")
+    assert _split_error(50, 0.01, odespace=odespace) < 0.002
+
+
+@pytest.mark.parametrize("odespace", ["CG_1", "CG_2", "DG_1"])
+def test_monodomain_splitting_spatial_convergence(odespace):
+    """tests/test_monodomain_solver.py:90-149: N = 8, 16, 32 at dt = 0.001 -> average rate > 1.85."""
+    errors = [_split_error(2**level, 0.001, odespace=odespace) for level in range(3, 6)]
     rates = [np.log2(e1 / e2) for e1, e2 in zip(errors[:-1], errors[1:])]
     assert sum(rates) / len(rates) > 1.85, (errors, rates)
 
 
-def test_monodomain_splitting_temporal_convergence():
-    """tests/test_monodomain_solver.py:152-216 (theta = 1, CG_1): N = 150, dt = 1/8, 1/16, 1/32 -> average rate > 1."""
-    errors = [_split_error(150, 1.0 / 2**level) for level in range(3, 6)]
+@pytest.mark.parametrize("odespace", ["CG_1", "CG_2", "DG_1"])
+def test_monodomain_splitting_temporal_convergence(odespace):
+    """tests/test_monodomain_solver.py:152-216 (theta = 1): N = 150, dt = 1/8, 1/16, 1/32 -> average rate > 1."""
+    errors = [_split_error(150, 1.0 / 2**level, odespace=odespace) for level in range(3, 6)]
     rates = [np.log2(e1 / e2) for e1, e2 in zip(errors[:-1], errors[1:])]
     assert sum(rates) / len(rates) > 1.0, (errors, rates)
 

@@ -223,3 +223,34 @@ def test_voxelize_tetrahedra():
     vg2 = beat.geometry.voxelize_tetrahedra(g.COMM_WORLD, om.x, om.cells[sel], 0.125)
     vol, _ = fem._cell_geometry(om)
     assert abs(vg2.mask.sum() * 0.125**3 - vol[sel].sum()) < 0.02 * vol[sel].sum()
+
+
+def test_p2_and_dg1_ode_space_layouts():
+    """Degrees of freedom of the P2 / DG1 ODE spaces: counts against the oracle's simplicial mesh (vertices + unique
+    edges; (d+1) per cell), coordinates, and the maps used by utils.local_project (P1 interpolant at the dof points,
+    one dof per vertex back)."""
+    from beat import grid as g
+
+    for cells in ((3, 2), (2, 2, 2)):
+        d = len(cells)
+        mesh = g.create_rectangle(g.COMM_WORLD, [np.zeros(2), np.ones(2)], list(cells)) if d == 2 else \\
+            g.create_box(g.COMM_WORLD, [np.zeros(3), np.ones(3)], list(cells))
+        om = fem.BoxMesh(cells, (1.0,) * d)
+        edges = {(min(c[a], c[b]), max(c[a], c[b])) for c in om.cells for a in range(d + 1) for b in range(a + 1, d + 1)}
+        V2, Vd = g.FunctionSpace(mesh, "CG", 2), g.FunctionSpace(mesh, "DG", 1)
+        assert V2.num_dofs == om.num_nodes + len(edges) and Vd.num_dofs == len(om.cells) * (d + 1)
+        (idx, w), to_p1 = V2.layout()
+        assert {(min(a, b), max(a, b)) for a, b in idx[om.num_nodes:]} == edges and np.allclose(w.sum(axis=1), 1.0)
+        xyz = mesh.node_coordinates(pad3=True, local=False)
+        X2 = V2.tabulate_dof_coordinates()
+        np.testing.assert_allclose(X2[: om.num_nodes], xyz)
+        np.testing.assert_allclose(X2[om.num_nodes:], 0.5 * (xyz[idx[om.num_nodes:, 0]] + xyz[idx[om.num_nodes:, 1]]))
+        (idx, w), to_p1 = Vd.layout()
+        np.testing.assert_allclose(Vd.tabulate_dof_coordinates()[to_p1], xyz)
+        # a linear function survives P1 -> space -> P1 exactly
+        f = xyz @ np.array([0.3, -1.2, 0.7])
+        for V in (V2, Vd):
+            (idx, w), to_p1 = V.layout()
+            on_space = w[:, 0] * f[idx[:, 0]] + w[:, 1] * f[idx[:, 1]]
+            np.testing.assert_allclose(on_space, V.tabulate_dof_coordinates() @ np.array([0.3, -1.2, 0.7]), atol=1e-14)
+            np.testing.assert_allclose(on_space[to_p1], f, atol=1e-14)
