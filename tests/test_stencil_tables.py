@@ -233,8 +233,8 @@ def test_p2_and_dg1_ode_space_layouts():
 
     for cells in ((3, 2), (2, 2, 2)):
         d = len(cells)
-        mesh = g.create_rectangle(g.COMM_WORLD, [np.zeros(2), np.ones(2)], list(cells)) if d == 2 else \\
-            g.create_box(g.COMM_WORLD, [np.zeros(3), np.ones(3)], list(cells))
+        make = g.create_rectangle if d == 2 else g.create_box
+        mesh = make(g.COMM_WORLD, [np.zeros(d), np.ones(d)], list(cells))
         om = fem.BoxMesh(cells, (1.0,) * d)
         edges = {(min(c[a], c[b]), max(c[a], c[b])) for c in om.cells for a in range(d + 1) for b in range(a + 1, d + 1)}
         V2, Vd = g.FunctionSpace(mesh, "CG", 2), g.FunctionSpace(mesh, "DG", 1)
