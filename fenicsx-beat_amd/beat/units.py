@@ -87,15 +87,33 @@ class Quantity:
     def _coerce(self, o):
         return o if isinstance(o, Quantity) else Quantity(o, _BASE["dimensionless"])
 
+    @staticmethod
+    def _label(a: str, op: str, b: str) -> str:
+        if not b:
+            return a
+        if not a:
+            return b if op == "*" else f"1/({b})"
+        return f"({a}){op}({b})"
+
     def __mul__(self, o):
         o = self._coerce(o)
-        return Quantity(self.magnitude * o.magnitude, self._unit * o._unit)
+        return Quantity(self.magnitude * o.magnitude, self._unit * o._unit, self._label(self._text, "*", o._text))
 
     __rmul__ = __mul__
 
     def __truediv__(self, o):
         o = self._coerce(o)
-        return Quantity(self.magnitude / o.magnitude, self._unit / o._unit)
+        return Quantity(self.magnitude / o.magnitude, self._unit / o._unit, self._label(self._text, "/", o._text))
+
+    def __eq__(self, o):
+        """Equal physical quantities compare equal whatever units they are written in (as in pint)."""
+        o = self._coerce(o) if not isinstance(o, Quantity) else o
+        if any(abs(a - b) > 1e-12 for a, b in zip(self._unit.dims, o._unit.dims)):
+            return False
+        a, b = self.magnitude * self._unit.factor, o.magnitude * o._unit.factor
+        return bool(abs(a - b) <= 1e-12 * max(abs(a), abs(b), 1e-300))
+
+    __hash__ = None
 
     def __rtruediv__(self, o):
         return self._coerce(o) / self

@@ -195,3 +195,19 @@ def test_get_dZ_and_effective_dim(dim, subdomain_dim, integral_type):
     dZ = beat.stimulation.get_dZ(mesh, tags)
     assert isinstance(dZ, g.Measure) and dZ.integral_type() == integral_type
     assert beat.stimulation.compute_effective_dim(mesh, tags) == subdomain_dim + (3 - dim)
+
+
+def test_unit_helpers_of_define_stimulus():
+    """tests/test_stimulation.py:208-250 of the reference: compute_stimulus_unit, convert_chi, convert_amplitude."""
+    import beat
+
+    ureg = beat.units.ureg
+    for effective_dim, mesh_unit, expected in [(0, "cm", "uA"), (1, "cm", "uA"), (2, "cm", "uA/cm"), (3, "cm", "uA/cm**2"),
+                                               (2, "mm", "uA/mm"), (3, "mm", "uA/mm**2")]:
+        assert beat.stimulation.compute_stimulus_unit(effective_dim, mesh_unit) == ureg(expected)
+    assert beat.stimulation.convert_chi(1.0, "cm") == 1.0 * ureg("cm**-1")
+    assert beat.stimulation.convert_chi(2.0 * ureg("mm**-1"), "cm") == 2.0 * ureg("mm**-1")
+    for effective_dim, unit in [(1, "uA / cm"), (2, "uA / cm**2"), (3, "uA / cm**3")]:
+        assert beat.stimulation.convert_amplitude(effective_dim, 2.0) == 2.0 * ureg(unit)
+    assert 1.0 * ureg("cm") == 10.0 * ureg("mm") and not (1.0 * ureg("cm") == 1.0 * ureg("ms"))
+    assert "uF" in repr(1.0 * ureg("uF/cm**2"))
