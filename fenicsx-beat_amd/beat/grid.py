@@ -777,6 +777,17 @@ class FunctionSpace:
     def is_p1(self) -> bool:
         return self.family == "Lagrange" and self.degree == 1
 
+    @property
+    def dofmap(self):
+        """``V.dofmap.index_map.size_local`` etc. (demos/pace_train.py:133-137): local / global dof counts; there are
+        no ghost dofs in ``x.array`` (ghost planes are a device-side detail)."""
+        from types import SimpleNamespace
+
+        n = self.num_dofs
+        n_global = self.mesh.num_nodes_global if self.is_p1 else n
+        return SimpleNamespace(index_map=SimpleNamespace(size_local=n, num_ghosts=0, size_global=n_global),
+                               index_map_bs=1)
+
     # -- degrees of freedom of the non-P1 spaces ------------------------------------------------------------------
     def _edges(self):
         """(first vertex, second vertex) of every edge of the simplicial mesh: node i and i + o for the forward
