@@ -53,6 +53,15 @@ def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node
         (x1, r1), (x2, r2) = results
         assert r2.converged_reason > 0 and abs(r1.iterations - r2.iterations) <= 1
         np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-9 * np.abs(x1).max())
+        # deferred last update through the collective path: pending until flushed, then the same bits
+        fx3 = ops.new_field()
+        res3 = solver.solve(fv, [], [], fx3, rtol=1e-11, atol=1e-50, max_it=200, defer_flush=True)
+        assert res3.iterations == r2.iterations
+        if res3.iterations % 6:
+            assert ops.pending is not None and not np.array_equal(fx3.numpy(), x2)
+        ops.flush_pending()
+        assert ops.pending is None
+        np.testing.assert_array_equal(fx3.numpy(), x2)
     finally:
         if created:
             dist.destroy_process_group()
