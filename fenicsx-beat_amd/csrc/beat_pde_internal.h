@@ -52,7 +52,7 @@ struct beat_pde {
   double* v_A = nullptr;
   double* v_dinv = nullptr;
   int64_t v_ld = 0;
-  int* v_seg = nullptr;        // device: indices of the 256-node segments that hold tissue nodes (ascending)
+  int* v_seg = nullptr;        // device: indices of the 64-node segments that hold tissue nodes (ascending)
   std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * beat_pde_detail::TABW; }
   const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * beat_pde_detail::TABW; }

@@ -11,6 +11,11 @@
 namespace {
 using namespace beat_pde_detail;
 
+// Granularity of the tissue bookkeeping: one wavefront's worth of consecutive nodes.  A workgroup takes
+// VAR_SEGS_PER_BLOCK list entries at a time, one per wave.
+constexpr int VAR_SEG = 64;
+constexpr int VAR_SEGS_PER_BLOCK = BEAT_BLOCK / VAR_SEG;
+
 // ---- variable-coefficient operators (beat_pde_create_var) -----------------------------------------------
 // Voxel-masked domains and spatially varying conductivity: every node carries its own 15 coefficients per
 // operator, stored coefficient-major ((15, ld) arrays, so a wave reads 15 contiguous 512 B segments).  The
@@ -37,7 +42,7 @@ struct VarArgs {
   const double* st;
   int64_t i_lo, i_hi;  // node range of this launch
   int doff[15];        // linear offsets of the 15 stencil points
-  const int* seg;      // active 256-node segments covering [i_lo, i_hi) (nullptr: every node of the range)
+  const int* seg;      // active segments (VAR_SEG nodes each) covering [i_lo, i_hi) (nullptr: every node of the range)
   int nseg;
   const double* mdiag; // RHS: mass diagonal (0 = node outside the tissue)
 };
@@ -49,11 +54,12 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
     if (a.st[STOP] != 0.0) return;
   }
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  // Work items: the 256-node segments that hold at least one tissue node (list built at create time); segments
+  // Work items: the wavefront-sized segments that hold at least one tissue node (list built at create time); segments
   // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
-  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
-    const int64_t i = (a.seg ? (int64_t)a.seg[w] * BEAT_BLOCK : a.i_lo + w * BEAT_BLOCK) + threadIdx.x;
+  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
+  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = (a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG) + lane;
     if (i < a.i_lo || i >= a.i_hi) continue;
     double s1 = 0.0, s2 = 0.0;
     double xc = 0.0;
@@ -124,8 +130,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __r
   const double alpha = st[RZ] / st[PQ];
   if (blockIdx.x == 0 && threadIdx.x == 0) alphas[slot] = alpha;
   double s_rz = 0.0, s_rr = 0.0;
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n) continue;
     const double ri = fma(-alpha, q[i], r[i]);
     r[i] = ri;
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* 
                                                                      const double* __restrict__ dinv) {
   if (st[STOP] != 0.0) return;
   const double beta = st[BETA];
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n) continue;
     p_new[i] = fma(beta, p_old[i], dinv[i] * r[i]);
   }
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
-  for (int w = blockIdx.x; w < nseg; w += gridDim.x) {
-    const int64_t i = (int64_t)seg[w] * BEAT_BLOCK + threadIdx.x;
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n) continue;
     double xi = x[i];
 #pragma unroll
@@ -177,19 +183,16 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
   }
 }
 
-// flags[s] = 1 if segment s holds a node touched by an element (mass diagonal > 0)
+// flags[s] = 1 if segment s (VAR_SEG consecutive nodes) holds a node touched by an element (mass diagonal > 0)
 __global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n, const double* __restrict__ mass_diag,
                                                                        unsigned char* __restrict__ flags) {
-  __shared__ int any;
-  const int64_t nsegs = (n + BEAT_BLOCK - 1) / BEAT_BLOCK;
-  for (int64_t s = blockIdx.x; s < nsegs; s += gridDim.x) {
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    const int64_t i = s * BEAT_BLOCK + threadIdx.x;
-    if (i < n && mass_diag[i] != 0.0) any = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) flags[s] = (unsigned char)any;
-    __syncthreads();
+  const int64_t nsegs = (n + VAR_SEG - 1) / VAR_SEG;
+  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  for (int64_t s = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; s < nsegs; s += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = s * VAR_SEG + lane;
+    const bool mine = i < n && mass_diag[i] != 0.0;
+    const unsigned long long any = __ballot(mine);
+    if (lane == 0) flags[s] = any != 0ull ? 1 : 0;
   }
 }
 
@@ -336,16 +339,16 @@ static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
   VarRange r{nullptr, 0, 0};
   if (z_hi <= z_lo) return r;
   const int64_t i_lo = (int64_t)z_lo * pde->g.plane, i_hi = (int64_t)z_hi * pde->g.plane;
-  int64_t nwork = (i_hi - i_lo + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  int64_t nwork = (i_hi - i_lo + VAR_SEG - 1) / VAR_SEG;
   if (!dense) {
-    const int s_lo = (int)(i_lo / BEAT_BLOCK), s_hi = (int)((i_hi + BEAT_BLOCK - 1) / BEAT_BLOCK);
+    const int s_lo = (int)(i_lo / VAR_SEG), s_hi = (int)((i_hi + VAR_SEG - 1) / VAR_SEG);
     const auto lo = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_lo);
     const auto hi = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_hi);
     r.seg = pde->v_seg + (lo - pde->h_seg.begin());
     r.nseg = (int)(hi - lo);
     nwork = r.nseg;
   }
-  r.grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, nwork));
+  r.grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, (nwork + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK));
   return r;
 }
 
@@ -365,7 +368,7 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
 }
 
 static unsigned var_vec_grid(const beat_pde* pde) {
-  return (unsigned)std::min<size_t>(4096, std::max<size_t>(1, pde->h_seg.size()));
+  return (unsigned)std::min<size_t>(4096, std::max<size_t>(1, (pde->h_seg.size() + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK));
 }
 
 int beat_var_form_A(beat_pde* pde) {
@@ -395,14 +398,14 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     beat_set_error("out of device memory for the %lld-node coefficient rows", (long long)ld);
     return BEAT_EHIP;
   }
-  // list of the 256-node segments that hold tissue nodes
-  const int64_t nsegs = (p->n + BEAT_BLOCK - 1) / BEAT_BLOCK;
+  // list of the segments (VAR_SEG consecutive nodes) that hold tissue nodes
+  const int64_t nsegs = (p->n + VAR_SEG - 1) / VAR_SEG;
   unsigned char* d_flags = nullptr;
   std::vector<unsigned char> flags((size_t)nsegs);
   hipError_t e = hipMalloc(&d_flags, (size_t)nsegs);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, nsegs)), dim3(BEAT_BLOCK), 0,
-                       ctx->stream, p->n, dev_mass, d_flags);
+    hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, (nsegs + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK)),
+                       dim3(BEAT_BLOCK), 0, ctx->stream, p->n, dev_mass, d_flags);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, (size_t)nsegs, hipMemcpyDeviceToHost, ctx->stream);

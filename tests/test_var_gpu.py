@@ -218,7 +218,12 @@ def test_per_node_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl)
     ctx.synchronize()
     q1 = ops.q.numpy().copy()
     pq = float(ops.st[3])
-    np.testing.assert_allclose(q1, ref, rtol=0, atol=1e-13 * np.abs(ref).max() * 10)
+    # nodes outside the tissue carry identity rows; wavefront-sized segments without any tissue are never touched
+    # by the solver's kernels, so such a node holds either p (identity applied) or the 0 it was initialised with
+    tl = touched[z0 * plane : z1 * plane]
+    np.testing.assert_allclose(q1[tl], ref[tl], rtol=0, atol=1e-13 * np.abs(ref).max() * 10)
+    outside = q1[~tl]
+    assert np.all((outside == 0.0) | (outside == ref[~tl]))
     glo, ghi = p.ghost_lo.clone(), p.ghost_hi.clone()
     ops.q.fill(float("nan"))
     p.ghost_lo.fill_(float("nan"))
@@ -229,7 +234,10 @@ def test_per_node_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl)
     p.ghost_hi.copy_(ghi)
     ops.spmv_boundary(p)
     ctx.synchronize()
-    np.testing.assert_array_equal(ops.q.numpy(), q1)
+    q2 = ops.q.numpy()
+    written = ~np.isnan(q2)  # segments without tissue keep the NaN fill: nobody writes or reads them
+    assert written[tl].all()
+    np.testing.assert_array_equal(q2[written], q1[written])
     assert np.isclose(float(ops.st[3]), pq, rtol=1e-13)
 
 
