@@ -332,6 +332,7 @@ class HipOps:
         in ``self.pending`` = (field, ring_base, count): the next ionic kernel adds it (beat_ode_step_pending) or
         ``flush_pending`` does."""
         self.flush_pending()
+        self.st_ptr_for_flush = None  # a pending update of this solve belongs to the handle's own scalar state
         ptrs, amps, k = self._stim_args(stim_w, stim_amp)
         info = _hip.KspInfo()
         pend = (C.c_int * 2)()
