@@ -134,7 +134,9 @@ class _DeviceODE:
         hp, npar, ppn, pld = self._param_args()
         pend = None
         if pending_ops is not None and pending_ops.pending is not None:
-            if v_row is not None and pending_ops.pending[0].ptr.value == v_row.ptr.value:
+            model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
+            if (v_row is not None and int(v_index) == model_v
+                    and pending_ops.pending[0].ptr.value == v_row.ptr.value):
                 pend = pending_ops.pending
                 pending_ops.pending = None
             else:

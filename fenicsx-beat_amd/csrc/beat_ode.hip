@@ -23,7 +23,7 @@ struct PendingV {
   int count;             // 0: nothing pending
 };
 
-template <class Model, bool PER_NODE>
+template <class Model, bool PER_NODE, bool PEND>
 __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
@@ -36,24 +36,34 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   const FastMath fm{etab, ltab};
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;
-  NodeIO io{states, ld, i, v_copy, v_index};
-  if (pend.count > 0) {
+  if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    io.npend = pend.count;
+    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
       io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
       io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
     }
-  }
-  if (PER_NODE) {
-    double pl[Model::NP];
+    if (PER_NODE) {
+      double pl[Model::NP];
 #pragma unroll
-    for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
-    const typename Model::Derived dl = Model::derive(pl);
-    Model::step(io, pl, dl, fm, t, dt);
+      for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      const typename Model::Derived dl = Model::derive(pl);
+      Model::step(io, pl, dl, fm, t, dt);
+    } else {
+      Model::step(io, prm.p, drv, fm, t, dt);
+    }
   } else {
-    Model::step(io, prm.p, drv, fm, t, dt);
+    const NodeIO io{states, ld, i, v_copy, v_index};
+    if (PER_NODE) {
+      double pl[Model::NP];
+#pragma unroll
+      for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      const typename Model::Derived dl = Model::derive(pl);
+      Model::step(io, pl, dl, fm, t, dt);
+    } else {
+      Model::step(io, prm.p, drv, fm, t, dt);
+    }
   }
 }
 
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
   // is correct through global memory, so generated models round-trip their states through HBM/L2 each
   // step (tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards both variants).
   const RegIO rio{y};
-  NodeIO gio{states, ld, i, nullptr, -1};
+  const NodeIO gio{states, ld, i, nullptr, -1};
   int64_t row = 0;
   for (int beat = 0; beat < nbeats; ++beat) {
     for (int64_t j = 0; j < nsteps; ++j) {
@@ -186,20 +196,30 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
                       int v_index, double* v_copy, const PendingV& pend) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
                "model expects %d parameters, got %d", Model::NP, num_params);
-  BEAT_REQUIRE((v_copy == nullptr && pend.count == 0) || (v_index >= 0 && v_index < Model::NS),
-               "v_index %d out of range", v_index);
+  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
+  BEAT_REQUIRE(pend.count == 0 || v_index == Model::V_INDEX,
+               "a pending update needs v_index = %d (the model's membrane potential), got %d", Model::V_INDEX, v_index);
   ParamPack<Model::NP> prm;
   for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
   typename Model::Derived drv = Model::derive(prm.p);
   const unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  const dim3 g3(grid), b3(BEAT_BLOCK);
+#define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
+  hipLaunchKernelGGL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
+                     dt, v_index, v_copy, pend)
   if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
-    hipLaunchKernelGGL((ode_step_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
-                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy, pend);
+    if (pend.count > 0)
+      BEAT_LAUNCH_ODE(true, true);
+    else
+      BEAT_LAUNCH_ODE(true, false);
   } else {
-    hipLaunchKernelGGL((ode_step_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream,
-                       states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy, pend);
+    if (pend.count > 0)
+      BEAT_LAUNCH_ODE(false, true);
+    else
+      BEAT_LAUNCH_ODE(false, false);
   }
+#undef BEAT_LAUNCH_ODE
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }

@@ -228,21 +228,34 @@ struct FastMath {
   }
 };
 
-// Access to the state-major array for one node (row k at base + k*ld).  (pa, pp, npend) is the part of the
-// membrane potential the diffusion solve has not written back yet (see beat_ode_step_pending): it is added when
-// row v_index is loaded, in the order x_flush_kernel would have used, so the value is bit-identical to a flushed
-// row; the store writes the complete new value.
-constexpr int BEAT_MAX_PENDING = 6;  // = ring size of the deferred-x PCG
+// Access to the state-major array for one node (row k at base + k*ld).
 struct NodeIO {
   double* __restrict__ base;
   int64_t ld, i;
   double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown), may be null
   int v_index;
-  int npend = 0;
+  __device__ __forceinline__ double load(int k) const { return base[(int64_t)k * ld + i]; }
+  __device__ __forceinline__ void store(int k, double v) const {
+    base[(int64_t)k * ld + i] = v;
+    if (v_copy != nullptr && k == v_index) v_copy[i] = v;
+  }
+};
+
+// The same with a pending update of the membrane potential (beat_ode_step_pending): row VIDX -- a compile-time
+// constant, Model::V_INDEX, so that every other load stays a plain load -- is read as
+// V + sum_j pa[j] pp[j], accumulated in the order x_flush_kernel uses (bit-identical to a flushed row); the store
+// writes the complete new value.
+constexpr int BEAT_MAX_PENDING = 6;  // = ring size of the deferred-x PCG
+template <int VIDX>
+struct NodeIOPending {
+  double* __restrict__ base;
+  int64_t ld, i;
+  double* __restrict__ v_copy;
+  int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
   __device__ __forceinline__ double load(int k) const {
     double x = base[(int64_t)k * ld + i];
-    if (k == v_index && npend > 0) {
+    if (k == VIDX) {
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING; ++j)
         if (j < npend) x = fma(pa[j], pp[j], x);
@@ -251,7 +264,7 @@ struct NodeIO {
   }
   __device__ __forceinline__ void store(int k, double v) const {
     base[(int64_t)k * ld + i] = v;
-    if (v_copy != nullptr && k == v_index) v_copy[i] = v;
+    if (k == VIDX && v_copy != nullptr) v_copy[i] = v;
   }
 };
 
@@ -267,7 +280,7 @@ struct RegIO {
 // v' = -a s, s' = b v, forward Euler  (tests/test_odesolver.py:11-17)
 // ------------------------------------------------------------------------------------------------
 struct SimpleOde {
-  static constexpr int NS = 2, NP = 2;
+  static constexpr int NS = 2, NP = 2, V_INDEX = 0;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
@@ -286,7 +299,7 @@ struct SimpleOde {
 // states [s, V]; parameters [V_peak, V_rest, a, b, c_1, c_2, c_3, stim_amplitude, stim_duration, stim_start]
 // ------------------------------------------------------------------------------------------------
 struct FhnDemo {
-  static constexpr int NS = 2, NP = 10;
+  static constexpr int NS = 2, NP = 10, V_INDEX = 1;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
@@ -314,7 +327,7 @@ struct FhnDemo {
 // states [s, v]; parameters [c_1, c_2, c_3, a, b, v_amp, v_rest, v_peak, stim_amplitude, stim_duration, stim_start]
 // ------------------------------------------------------------------------------------------------
 struct FhnReadme {
-  static constexpr int NS = 2, NP = 11;
+  static constexpr int NS = 2, NP = 11, V_INDEX = 1;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
   struct Derived {};
@@ -358,7 +371,7 @@ struct FhnReadme {
 //  * parameter-only sub-expressions are evaluated once per launch on the host (Derived).
 // ------------------------------------------------------------------------------------------------
 struct Tp06Grl1 {
-  static constexpr int NS = 19, NP = 53;
+  static constexpr int NS = 19, NP = 53, V_INDEX = 17;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };

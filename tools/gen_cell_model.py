@@ -236,7 +236,8 @@ def main():
     w('#include "../ionic_models.h"')
     w("")
     w(f"struct {struct} {{")
-    w(f"  static constexpr int NS = {len(states)}, NP = {len(params)};")
+    v_index = next((i for i, name in enumerate(states) if name.lower() == "v"), 0)
+    w(f"  static constexpr int NS = {len(states)}, NP = {len(params)}, V_INDEX = {v_index};  // V_INDEX: membrane potential")
     w("  static constexpr bool REGISTER_LOOP = false;  // see ode_run_kernel")
     w(f"  static constexpr int WAVES = {WAVES};           // waves per SIMD the kernels are compiled for")
     w("  struct Derived {};")
