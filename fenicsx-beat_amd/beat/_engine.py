@@ -199,8 +199,11 @@ class HipOps:
         if M.ndim == 3:
             if M.shape != (nvox, dim, dim):
                 raise ValueError(f"per-voxel conductivity has shape {M.shape}, expected ({nvox}, {dim}, {dim})")
-            M9 = np.zeros((nvox, 3, 3))
-            M9[:, :dim, :dim] = M
+            if dim == 3:
+                M9 = M  # already (nvox, 3, 3): no padded copy
+            else:
+                M9 = np.zeros((nvox, 3, 3))
+                M9[:, :dim, :dim] = M
             m_dev = ctx.from_numpy(M9.reshape(nvox, 9))
         else:
             m_const = np.zeros((3, 3))

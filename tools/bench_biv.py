@@ -17,25 +17,30 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "fenicsx-beat_amd"))
 
 
-def shell(n, h):
-    ax = (np.arange(n) + 0.5) * h
-    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+def shell(n, h, chunk=32):
+    """mask (n, n, n) and fibre directions (n^3, 3) of the shell, generated in z-chunks to keep the host
+    footprint at the size of the outputs"""
     c = n * h / 2.0
     so = 0.48 * n * h * np.array([1.0, 0.9, 1.0])
     si = 0.66 * so
-    P = np.stack([X - c, Y - c, Z - c], axis=-1)
-    del X, Y
-    ro = np.sqrt(((P / so) ** 2).sum(-1))
-    ri = np.sqrt(((P / si) ** 2).sum(-1))
-    mask = (ro < 1.0) & (ri > 1.0) & (Z < 0.8 * n * h)
-    depth = np.clip((ri - 1.0) / np.maximum(ri - ro, 1e-12), 0.0, 1.0)
-    rad = P / np.maximum(np.linalg.norm(P, axis=-1, keepdims=True), 1e-12)
-    circ = np.cross(np.array([0.0, 0.0, 1.0]), rad)
-    circ /= np.maximum(np.linalg.norm(circ, axis=-1, keepdims=True), 1e-12)
-    longi = np.cross(rad, circ)
-    ang = np.deg2rad(60.0 - 120.0 * depth)[..., None]
-    f0 = (np.cos(ang) * circ + np.sin(ang) * longi).reshape(-1, 3)
-    return mask, f0, (so, si, c)
+    mask = np.zeros((n, n, n), dtype=bool)
+    f0 = np.zeros((n, n, n, 3))
+    ax = (np.arange(n) + 0.5) * h
+    for z0 in range(0, n, chunk):
+        z1 = min(n, z0 + chunk)
+        Z, Y, X = np.meshgrid(ax[z0:z1], ax, ax, indexing="ij")
+        P = np.stack([X - c, Y - c, Z - c], axis=-1)
+        ro = np.sqrt(((P / so) ** 2).sum(-1))
+        ri = np.sqrt(((P / si) ** 2).sum(-1))
+        mask[z0:z1] = (ro < 1.0) & (ri > 1.0) & (Z < 0.8 * n * h)
+        depth = np.clip((ri - 1.0) / np.maximum(ri - ro, 1e-12), 0.0, 1.0)
+        rad = P / np.maximum(np.linalg.norm(P, axis=-1, keepdims=True), 1e-12)
+        circ = np.cross(np.array([0.0, 0.0, 1.0]), rad)
+        circ /= np.maximum(np.linalg.norm(circ, axis=-1, keepdims=True), 1e-12)
+        longi = np.cross(rad, circ)
+        ang = np.deg2rad(60.0 - 120.0 * depth)[..., None]
+        f0[z0:z1] = np.cos(ang) * circ + np.sin(ang) * longi
+    return mask, f0.reshape(-1, 3), (so, si, c)
 
 
 def main():
