@@ -330,6 +330,19 @@ static void var_offsets(const beat_pde* pde, VarArgs& a) {
 
 // Work of a launch over planes [z_lo, z_hi): the sub-list of active segments intersecting the range and the grid
 // (= number of block partials the launch writes).
+// Grid-stride kernels are launched with exactly the number of workgroups the chip holds at once (occupancy x CUs):
+// every wave then sweeps the segment list in lockstep with its neighbours.  Measured on the 401^3 shell: SpMV 676 us
+// with 4096 workgroups, 610 us with the 1536 resident ones, 687 / 918 us with 1280 / 1792.
+template <class Kernel>
+static unsigned resident_blocks(Kernel kernel) {
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BEAT_BLOCK, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+    return 4096;
+  return (unsigned)std::min(per_cu * cus, BEAT_MAX_PARTIALS / 4);
+}
+
 struct VarRange {
   const int* seg;
   int nseg;
@@ -348,8 +361,14 @@ static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
     r.nseg = (int)(hi - lo);
     nwork = r.nseg;
   }
-  r.grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, (nwork + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK));
+  r.grid = (unsigned)std::max<int64_t>(1, (nwork + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK);  // capped by the launcher
   return r;
+}
+
+template <int MODE>
+static unsigned var_stencil_grid(unsigned wanted) {
+  static const unsigned resident = resident_blocks(var_stencil_kernel<MODE>);
+  return std::min(wanted, resident);
 }
 
 // launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on.
@@ -363,12 +382,14 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.part_off = part_off;
   a.seg = r.seg;
   a.nseg = r.nseg;
-  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(r.grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
-  return (int)r.grid;
+  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+  return (int)var_stencil_grid<MODE>(r.grid);
 }
 
 static unsigned var_vec_grid(const beat_pde* pde) {
-  return (unsigned)std::min<size_t>(4096, std::max<size_t>(1, (pde->h_seg.size() + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK));
+  // the vector kernels use 12-20 VGPRs: eight waves per SIMD, i.e. eight workgroups per CU
+  static const unsigned resident = resident_blocks(var_update_r_kernel);
+  return (unsigned)std::min<size_t>(resident, std::max<size_t>(1, (pde->h_seg.size() + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK));
 }
 
 int beat_var_form_A(beat_pde* pde) {
@@ -570,13 +591,13 @@ int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, do
   a.y = dev_q;
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
-  // block-partial slots: the interior launch owns [0, 4096), the boundary planes follow
+  // block-partial slots: the interior launch's come first, the boundary planes follow
   if (part == 0) {
     launch_var<MODE_SPMV_DOT>(pde, a, lo, std::max(lo, hi), 0);
     BEAT_LAUNCH_CHECK();
     return BEAT_OK;
   }
-  int off = (int)var_range(pde, lo, std::max(lo, hi), false).grid;  // partial slots of the interior launch (part 0)
+  int off = (int)var_stencil_grid<MODE_SPMV_DOT>(var_range(pde, lo, std::max(lo, hi), false).grid);  // partial slots of the interior launch (part 0)
   if (!f.z_lo_phys) off += launch_var<MODE_SPMV_DOT>(pde, a, 0, 1, off);
   if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch_var<MODE_SPMV_DOT>(pde, a, f.nz - 1, f.nz, off);
   BEAT_LAUNCH_CHECK();
