@@ -620,6 +620,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
   (void)hipFree(pde->v_seg);
+  (void)hipFree(pde->v_segmask);
   delete pde;
   return BEAT_OK;
 }

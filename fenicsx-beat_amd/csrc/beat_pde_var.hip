@@ -43,8 +43,8 @@ struct VarArgs {
   int64_t i_lo, i_hi;  // node range of this launch
   int doff[15];        // linear offsets of the 15 stencil points
   const int* seg;      // active segments (VAR_SEG nodes each) covering [i_lo, i_hi) (nullptr: every node of the range)
+  const unsigned long long* segmask;  // per list entry: which of its nodes are tissue nodes
   int nseg;
-  const double* mdiag; // RHS: mass diagonal (0 = node outside the tissue)
 };
 
 template <int MODE>
@@ -61,6 +61,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
   for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG) + lane;
     if (i < a.i_lo || i >= a.i_hi) continue;
+    // lanes on nodes outside the tissue issue no loads or stores: lines without a tissue node are never fetched
+    if (a.seg && !((a.segmask[w] >> lane) & 1ull)) continue;
     double s1 = 0.0, s2 = 0.0;
     double xc = 0.0;
 #pragma unroll
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       double stim = 0.0;
       for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
       const double r = a.dt * (stim - s2);
-      const double b = a.mdiag[i] != 0.0 ? s1 + r : 0.0;  // nodes outside the tissue are not part of the system
+      const double b = s1 + r;  // (nodes outside the tissue are masked out above: not part of the system)
       const double zz = a.dinv[i] * r;
       a.y[i] = r;
       a.y2[i] = zz;
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
 }
 
 // PCG vector updates over the active segments (per-node 1/diag)
-__global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+__global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __restrict__ seg,
+    const unsigned long long* __restrict__ segmask, int nseg, int64_t n,
                                                                   const double* __restrict__ st,
                                                                   double* __restrict__ r, const double* __restrict__ q,
                                                                   const double* __restrict__ dinv,
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __r
   double s_rz = 0.0, s_rr = 0.0;
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
-    if (i >= n) continue;
+    if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     const double ri = fma(-alpha, q[i], r[i]);
     r[i] = ri;
     s_rz = fma(ri * dinv[i], ri, s_rz);
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __r
   }
 }
 
-__global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+__global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* __restrict__ seg,
+    const unsigned long long* __restrict__ segmask, int nseg, int64_t n,
                                                                      const double* __restrict__ st,
                                                                      const double* __restrict__ r,
                                                                      const double* __restrict__ p_old,
@@ -156,12 +160,13 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* 
   const double beta = st[BETA];
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
-    if (i >= n) continue;
+    if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     p_new[i] = fma(beta, p_old[i], dinv[i] * r[i]);
   }
 }
 
-__global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __restrict__ seg, int nseg, int64_t n,
+__global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __restrict__ seg,
+    const unsigned long long* __restrict__ segmask, int nseg, int64_t n,
                                                                const double* __restrict__ st, double* __restrict__ x,
                                                                const double* __restrict__ ring, int64_t fld,
                                                                const double* __restrict__ alphas, int ring_base,
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
-    if (i >= n) continue;
+    if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     double xi = x[i];
 #pragma unroll
     for (int j = 0; j < PRING; ++j)
@@ -183,16 +188,16 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
   }
 }
 
-// flags[s] = 1 if segment s (VAR_SEG consecutive nodes) holds a node touched by an element (mass diagonal > 0)
+// flags[s]: bit l set if node VAR_SEG s + l is touched by an element (mass diagonal > 0)
 __global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n, const double* __restrict__ mass_diag,
-                                                                       unsigned char* __restrict__ flags) {
+                                                                       unsigned long long* __restrict__ flags) {
   const int64_t nsegs = (n + VAR_SEG - 1) / VAR_SEG;
   const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
   for (int64_t s = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; s < nsegs; s += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = s * VAR_SEG + lane;
     const bool mine = i < n && mass_diag[i] != 0.0;
     const unsigned long long any = __ballot(mine);
-    if (lane == 0) flags[s] = any != 0ull ? 1 : 0;
+    if (lane == 0) flags[s] = any;
   }
 }
 
@@ -345,11 +350,12 @@ static unsigned resident_blocks(Kernel kernel) {
 
 struct VarRange {
   const int* seg;
+  const unsigned long long* segmask;
   int nseg;
   unsigned grid;
 };
 static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
-  VarRange r{nullptr, 0, 0};
+  VarRange r{nullptr, nullptr, 0, 0};
   if (z_hi <= z_lo) return r;
   const int64_t i_lo = (int64_t)z_lo * pde->g.plane, i_hi = (int64_t)z_hi * pde->g.plane;
   int64_t nwork = (i_hi - i_lo + VAR_SEG - 1) / VAR_SEG;
@@ -358,6 +364,7 @@ static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
     const auto lo = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_lo);
     const auto hi = std::lower_bound(pde->h_seg.begin(), pde->h_seg.end(), s_hi);
     r.seg = pde->v_seg + (lo - pde->h_seg.begin());
+    r.segmask = pde->v_segmask + (lo - pde->h_seg.begin());
     r.nseg = (int)(hi - lo);
     nwork = r.nseg;
   }
@@ -381,6 +388,7 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.i_hi = (int64_t)z_hi * pde->g.plane;
   a.part_off = part_off;
   a.seg = r.seg;
+  a.segmask = r.segmask;
   a.nseg = r.nseg;
   hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
   return (int)var_stencil_grid<MODE>(r.grid);
@@ -421,24 +429,31 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
   }
   // list of the segments (VAR_SEG consecutive nodes) that hold tissue nodes
   const int64_t nsegs = (p->n + VAR_SEG - 1) / VAR_SEG;
-  unsigned char* d_flags = nullptr;
-  std::vector<unsigned char> flags((size_t)nsegs);
-  hipError_t e = hipMalloc(&d_flags, (size_t)nsegs);
+  unsigned long long* d_flags = nullptr;
+  std::vector<unsigned long long> flags((size_t)nsegs), masks;
+  hipError_t e = hipMalloc(&d_flags, sizeof(unsigned long long) * (size_t)nsegs);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, (nsegs + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK)),
                        dim3(BEAT_BLOCK), 0, ctx->stream, p->n, dev_mass, d_flags);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, (size_t)nsegs, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, sizeof(unsigned long long) * (size_t)nsegs, hipMemcpyDeviceToHost,
+                                          ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_flags);
   if (e == hipSuccess) {
     for (int64_t sidx = 0; sidx < nsegs; ++sidx)
-      if (flags[(size_t)sidx]) p->h_seg.push_back((int)sidx);
+      if (flags[(size_t)sidx]) {
+        p->h_seg.push_back((int)sidx);
+        masks.push_back(flags[(size_t)sidx]);
+      }
     e = hipMalloc(&p->v_seg, sizeof(int) * std::max<size_t>(1, p->h_seg.size()));
   }
+  if (e == hipSuccess) e = hipMalloc(&p->v_segmask, sizeof(unsigned long long) * std::max<size_t>(1, masks.size()));
   if (e == hipSuccess && !p->h_seg.empty())
     e = hipMemcpy(p->v_seg, p->h_seg.data(), sizeof(int) * p->h_seg.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !masks.empty())
+    e = hipMemcpy(p->v_segmask, masks.data(), sizeof(unsigned long long) * masks.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     beat_pde_destroy(p);
     beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
@@ -554,7 +569,6 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
     BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice,
                                   pde->ctx->stream));
   a.dinv = pde->v_dinv;
-  a.mdiag = pde->v_mass;
   a.dt = pde->dt;
   for (int k = 0; k < n_stim; ++k) {
     if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
@@ -607,7 +621,7 @@ int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, do
 
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   const unsigned grid = var_vec_grid(pde);
-  hipLaunchKernelGGL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg,
+  hipLaunchKernelGGL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask,
                      (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_q, (const double*)pde->v_dinv,
                      pde->ctx->d_partials, pde->d_alphas, slot);
   BEAT_LAUNCH_CHECK();
@@ -616,7 +630,7 @@ int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double
 
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next) {
   hipLaunchKernelGGL(var_pupdate_oop_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                     (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_p_cur,
+                     (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_p_cur,
                      dev_p_next, (const double*)pde->v_dinv);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -625,7 +639,7 @@ int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, con
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                    int ring_base, int only_if_full) {
   hipLaunchKernelGGL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                     (const int*)pde->v_seg, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
+                     (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
                      (const double*)pde->d_alphas, ring_base, only_if_full);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
