@@ -65,3 +65,141 @@ def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node
     finally:
         if created:
             dist.destroy_process_group()
+
+
+class _ThreadWorld:
+    """A torch.distributed look-alike for several threads of one process, each playing one rank: the pieces
+    DiffusionSolver uses (all_reduce on device tensors, P2POp / batch_isend_irecv of ghost planes).  A one-GPU box
+    cannot host a multi-rank RCCL group (one rank per device), so this is how the N > 1 orchestration is run against
+    the real HIP kernels -- slabs with live ghost planes, split SpMV, boundary-plane launches -- before the
+    driver's multi-GPU run; RCCL itself is covered by the one-rank group above and by torch."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.mail = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+
+    def rank_view(self, rank):
+        return _ThreadRank(self, rank)
+
+
+class _ThreadRank:
+    class ReduceOp:
+        SUM = "sum"
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, world, rank):
+        self.w, self.rank = world, rank
+
+    def all_reduce(self, t, op=None, group=None):
+        w = self.w
+        w.slots[self.rank] = t.clone()
+        w.barrier.wait(timeout=120)
+        total = w.slots[0].clone()
+        for other in w.slots[1:]:
+            total += other
+        w.barrier.wait(timeout=120)  # everyone has read the slots before they are reused
+        t.copy_(total)
+
+    def P2POp(self, fn, tensor, peer, group=None):
+        return (fn, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        reqs = []
+        for fn, tensor, peer in ops:
+            if fn == self.isend:
+                self.w.mail[(self.rank, peer)].put(tensor.clone())
+            else:
+                reqs.append(_ThreadRecv(self.w.mail[(peer, self.rank)], tensor))
+        return reqs
+
+
+class _ThreadRecv:
+    def __init__(self, box, tensor):
+        self.box, self.tensor = box, tensor
+
+    def wait(self):
+        self.tensor.copy_(self.box.get(timeout=120))
+
+
+@pytest.mark.parametrize("per_node,world", [(False, 2), (False, 3), (True, 3)])
+def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world):
+    """world ranks as threads, each with its own context, slab operators and DiffusionSolver: the assembled solution
+    equals the undivided solve, iteration counts agree, and the deferred last update flushes to the same values."""
+    import threading
+
+    from beat import _stencil
+    from beat._device import Context
+    from beat._engine import DiffusionSolver, HipOps, Slab
+
+    nx, ny, nz = 40, 33, 19
+    cells = (nx - 1, ny - 1, nz - 1)
+    h = (0.1, 0.1, 0.1)
+    f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
+    M = 9.5e-4 * np.outer(f0, f0) + 1.25e-4 * (np.eye(3) - np.outer(f0, f0))
+    active = None
+    if per_node:
+        cc = np.stack(np.meshgrid(np.arange(nz - 1), np.arange(ny - 1), np.arange(nx - 1), indexing="ij"), -1).reshape(-1, 3)
+        active = ((cc - np.array([9, 16, 20])) ** 2).sum(axis=1) < 15**2
+
+    def operators(z_range):
+        if per_node:
+            return _stencil.stencil_fields(3, cells, h, M, active, z_range=z_range)
+        return _stencil.stencil_tables(3, h, M)
+
+    plane = nx * ny
+    rng = np.random.default_rng(5)
+    v = -85.0 + 30.0 * rng.random(nx * ny * nz)
+    w_stim = np.zeros_like(v)
+    w_stim[: 3 * plane] = rng.random(3 * plane) * 1e-3
+    if per_node:  # only tissue nodes carry a stimulus weight
+        tissue = operators(None)[0][0] != 0.0
+        w_stim *= tissue
+
+    def solve(ctx, slab, dist_view, out, key):
+        ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *operators((slab.z0, slab.z1)), per_node=per_node)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        solver = DiffusionSolver(ops, slab, force_distributed=dist_view is not None)
+        if dist_view is not None:
+            solver.dist = dist_view
+        fv, fx, fw, fx2 = ops.new_field(), ops.new_field(), ops.new_field(), ops.new_field()
+        sl = slice(slab.z0 * plane, slab.z1 * plane)
+        fv.set(v[sl])
+        fw.set(w_stim[sl])
+        res = solver.solve(fv, [fw], [0.7], fx, rtol=1e-11, atol=1e-50, max_it=200)
+        res2 = solver.solve(fv, [fw], [0.7], fx2, rtol=1e-11, atol=1e-50, max_it=200, defer_flush=True)
+        ops.flush_pending()
+        ctx.synchronize()
+        out[key] = (fx.numpy().copy(), res, fx2.numpy().copy(), res2)
+
+    out = {}
+    solve(hip_ctx, Slab(nz), None, out, "whole")
+    tw = _ThreadWorld(world)
+    errors = []
+
+    def run(rank):
+        try:
+            solve(Context(), Slab(nz, rank, world), tw.rank_view(rank), out, rank)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((rank, exc))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    x_whole, r_whole, _, _ = out["whole"]
+    x_parts = np.concatenate([out[r][0] for r in range(world)])
+    x_defer = np.concatenate([out[r][2] for r in range(world)])
+    its = {out[r][1].iterations for r in range(world)}
+    assert len(its) == 1 and abs(its.pop() - r_whole.iterations) <= 1
+    assert all(out[r][1].converged_reason > 0 for r in range(world))
+    np.testing.assert_allclose(x_parts, x_whole, rtol=0, atol=1e-9 * np.abs(x_whole).max())
+    np.testing.assert_array_equal(x_defer, x_parts)
