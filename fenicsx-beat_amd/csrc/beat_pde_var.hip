@@ -49,10 +49,8 @@ struct VarArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
+  static_assert(MODE == MODE_APPLY || MODE == MODE_RHS, "the PCG's SpMV is var_spmv_kernel");
   __shared__ double red[4];
-  if (MODE == MODE_SPMV_DOT) {
-    if (a.st[STOP] != 0.0) return;
-  }
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   // Work items: the wavefront-sized segments that hold at least one tissue node (list built at create time); segments
   // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
@@ -64,7 +62,6 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
     // lanes on nodes outside the tissue issue no loads or stores: lines without a tissue node are never fetched
     if (a.seg && !((a.segmask[w] >> lane) & 1ull)) continue;
     double s1 = 0.0, s2 = 0.0;
-    double xc = 0.0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
       // The operators are symmetric: the coefficient towards a "backward" neighbour (even slot k, offset
@@ -83,15 +80,11 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       if (MODE == MODE_APPLY && a.T2 != nullptr) c2 = a.T2[src];
       const bool need = (k == 0) || c1 != 0.0 || c2 != 0.0;
       const double xv = need ? a.x[i + a.doff[k]] : 0.0;
-      if (k == 0) xc = xv;
       s1 = fma(c1, xv, s1);
       s2 = fma(c2, xv, s2);
     }
     if (MODE == MODE_APPLY) {
       a.y[i] = a.c1 * s1 + a.c2 * s2;
-    } else if (MODE == MODE_SPMV_DOT) {
-      a.y[i] = s1;
-      acc0 = fma(xc, s1, acc0);
     } else {  // RHS: T1 = A, T2 = K; b = A v + r, r = dt (stim - K v)
       double stim = 0.0;
       for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
@@ -105,10 +98,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       acc2 = fma(r, r, acc2);
     }
   }
-  if (MODE == MODE_SPMV_DOT) {
-    const double s0 = beat_block_sum(acc0, red);
-    if (threadIdx.x == 0) a.partials[a.part_off + blockIdx.x] = s0;
-  } else if (MODE == MODE_RHS) {
+  if (MODE == MODE_RHS) {
     const double s0 = beat_block_sum(acc0, red);
     const double s1 = beat_block_sum(acc1, red);
     const double s2 = beat_block_sum(acc2, red);
@@ -118,6 +108,103 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
     }
   }
+}
+
+// q = A p and the block partials of p.q: the PCG's matrix-vector product, one wavefront per 64-node list entry.
+//
+// The 15 stencil points lie in 7 rows of x ((dy, dz) pairs); a row's dx = 0 value of lane l is the dx = +1 value of
+// lane l-1 and the dx = -1 value of lane l+1, so each row is loaded once and shifted across the wave (DPP / bpermute)
+// instead of being gathered two or three times through L1: 7 row loads plus one 8-lane load for the values just
+// outside the segment (lane 63's +1 taps, lane 0's -1 taps) replace 15 gathers (SpMV 0.71 -> 0.59 ms on a 401^3
+// shell: the kernel is bound by the rate of its 512-B gathers, not by HBM bytes; 0.49 ms would be the time without
+// those loads at all).  Measured and not adopted: taking the slot-2 coefficient from the neighbouring lane's slot 1 as
+// well (0.64 ms) and capping the kernel at 80 VGPRs for six waves per SIMD (0.63 ms, 12 spills).  A lane loads a row value if it
+// needs it itself or a neighbouring lane does (ballots of the coefficient tests); values are selected, never
+// multiplied by a zero coefficient, so stale ghost planes cannot leak NaNs.  The sums are accumulated in slot order
+// 0..14 exactly as var_stencil_kernel does.
+__device__ __forceinline__ double var_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
+  __shared__ double red[4];
+  if (a.st[STOP] != 0.0) return;
+  // rows of the stencil: slot of the dx = 0 point, of the dx = +1 point and of the dx = -1 point (-1: none)
+  constexpr int kBase[7] = {0, 3, 4, 5, 6, 9, 10};
+  constexpr int kPlus[7] = {1, 7, -1, 11, -1, 13, -1};
+  constexpr int kMinus[7] = {2, -1, 8, -1, 12, -1, 14};
+  double acc0 = 0.0;
+  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
+  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
+    const int64_t i = seg0 + lane;
+    const bool active = i >= a.i_lo && i < a.i_hi && (!a.seg || ((a.segmask[w] >> lane) & 1ull));
+    double c[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      // symmetric operator: the coefficient towards a backward neighbour is that neighbour's forward coefficient
+      // (see var_stencil_kernel)
+      int64_t src = (int64_t)k * a.ld + i;
+      if (k >= 2 && (k & 1) == 0) {
+        const int64_t jn = i + a.doff[k];
+        if (jn >= 0) src = (int64_t)(k - 1) * a.ld + jn;
+      }
+      c[k] = active ? a.T1[src] : 0.0;
+    }
+    unsigned long long bp[7], bm[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      bp[r] = kPlus[r] >= 0 ? __ballot(c[kPlus[r] >= 0 ? kPlus[r] : 0] != 0.0) : 0ull;
+      bm[r] = kMinus[r] >= 0 ? __ballot(c[kMinus[r] >= 0 ? kMinus[r] : 0] != 0.0) : 0ull;
+    }
+    // values just outside the segment: lanes 0..3 fetch lane 63's +1 taps (rows 0, 1, 3, 5), lanes 4..7 lane 0's
+    // -1 taps (rows 0, 2, 4, 6)
+    double edge = 0.0;
+    {
+      const int e = lane & 7;
+      const bool plus = e < 4;
+      const int off = e == 0 || e == 4 ? a.doff[0] : e == 1 ? a.doff[3] : e == 2 ? a.doff[5] : e == 3 ? a.doff[9]
+                      : e == 5 ? a.doff[4] : e == 6 ? a.doff[6] : a.doff[10];
+      const unsigned long long wanted = e == 0 ? bp[0] >> 63 : e == 1 ? bp[1] >> 63 : e == 2 ? bp[3] >> 63
+                                        : e == 3 ? bp[5] >> 63 : e == 4 ? bm[0] : e == 5 ? bm[2] : e == 6 ? bm[4] : bm[6];
+      if (lane < 8 && (wanted & 1ull)) edge = a.x[seg0 + (plus ? VAR_SEG : -1) + off];
+    }
+    double xk[15];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int kb = kBase[r];
+      const bool own = kb == 0 ? active : c[kb] != 0.0;
+      const unsigned long long wanted = (bp[r] << 1) | (bm[r] >> 1);  // lane l-1 wants its +1, lane l+1 its -1 tap
+      const double X = (own || ((wanted >> lane) & 1ull)) ? a.x[i + a.doff[kb]] : 0.0;
+      xk[kb] = own ? X : 0.0;
+      if (kPlus[r] >= 0) {
+        const int kp = kPlus[r] >= 0 ? kPlus[r] : 0;
+        const int e = r == 0 ? 0 : r == 1 ? 1 : r == 3 ? 2 : 3;
+        const double shifted = __shfl_down(X, 1, VAR_SEG);
+        const double v = lane == VAR_SEG - 1 ? var_readlane(edge, e) : shifted;
+        xk[kp] = c[kp] != 0.0 ? v : 0.0;
+      }
+      if (kMinus[r] >= 0) {
+        const int km = kMinus[r] >= 0 ? kMinus[r] : 0;
+        const int e = r == 0 ? 4 : r == 2 ? 5 : r == 4 ? 6 : 7;
+        const double shifted = __shfl_up(X, 1, VAR_SEG);
+        const double v = lane == 0 ? var_readlane(edge, e) : shifted;
+        xk[km] = c[km] != 0.0 ? v : 0.0;
+      }
+    }
+    double s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s1 = fma(c[k], xk[k], s1);
+    if (active) {
+      a.y[i] = s1;
+      acc0 = fma(xk[0], s1, acc0);
+    }
+  }
+  const double s0 = beat_block_sum(acc0, red);
+  if (threadIdx.x == 0) a.partials[a.part_off + blockIdx.x] = s0;
 }
 
 // PCG vector updates over the active segments (per-node 1/diag)
@@ -374,7 +461,12 @@ static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
 
 template <int MODE>
 static unsigned var_stencil_grid(unsigned wanted) {
-  static const unsigned resident = resident_blocks(var_stencil_kernel<MODE>);
+  static const unsigned resident = [] {
+    if constexpr (MODE == MODE_SPMV_DOT)
+      return resident_blocks(var_spmv_kernel);
+    else
+      return resident_blocks(var_stencil_kernel<MODE>);
+  }();
   return std::min(wanted, resident);
 }
 
@@ -390,7 +482,11 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.seg = r.seg;
   a.segmask = r.segmask;
   a.nseg = r.nseg;
-  hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+  if constexpr (MODE == MODE_SPMV_DOT)
+    hipLaunchKernelGGL(var_spmv_kernel, dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+  else
+    hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0,
+                       pde->ctx->stream, a);
   return (int)var_stencil_grid<MODE>(r.grid);
 }
 
