@@ -18,11 +18,14 @@ constexpr int VAR_SEGS_PER_BLOCK = BEAT_BLOCK / VAR_SEG;
 
 // ---- variable-coefficient operators (beat_pde_create_var) -----------------------------------------------
 // Voxel-masked domains and spatially varying conductivity: every node carries its own 15 coefficients per
-// operator, stored coefficient-major ((15, ld) arrays, so a wave reads 15 contiguous 512 B segments).  The
-// coefficient streams are 120 of the 136 B/node an application moves, so the neighbour values are simply
-// gathered through L1/L2 (rows of x are contiguous across the wave) instead of being staged through LDS.
-// A neighbour is only read where its coefficient is non-zero: rows never reach outside the box (or into an
-// inactive voxel), so no out-of-range address is formed and stale ghost planes cannot leak NaNs.
+// operator, stored coefficient-major ((15, ld) arrays: a wave reads contiguous 512 B segments).  Work is organised
+// by a list of the 64-node segments that hold tissue, one list entry per wavefront, with a 64-bit mask of the
+// tissue nodes in it: lanes on other nodes issue no loads or stores, segments without tissue are never visited.
+// The PCG's matrix-vector product is var_spmv_kernel (rows of x loaded once and shifted across the wave, backward
+// coefficients read as the neighbours' forward ones); the right-hand side and the plain application y = (c1 T1 +
+// c2 T2) x gather their neighbour values through L1/L2 (var_stencil_kernel).  A neighbour value is only used where
+// its coefficient is non-zero: rows never reach outside the box (or into an inactive voxel), so no out-of-range
+// address is formed and stale ghost planes cannot leak NaNs.
 struct VarArgs {
   const double* T1;  // (15, ld) coefficients
   const double* T2;  // second operator (RHS: stiffness; APPLY: optional) or nullptr
