@@ -52,6 +52,9 @@ def local_project(v: grid.Function, V: grid.FunctionSpace, u: grid.Function | No
 def space_from_string(space_string: str, mesh: grid.Mesh, dim: int = 1) -> grid.FunctionSpace:
     """'{family}_{degree}' -> function space (utils.py:86-112): P / CG / Lagrange 1 and 2, DG / dP 0 and 1."""
     family, degree = space_string.split("_")
+    known = ("Lagrange", "P", "CG", "Discontinuous Lagrange", "DG", "dP", "Quadrature", "Q", "Quad")
+    if family not in known:  # same error as the reference's parse_element (utils.py:80-83)
+        raise ValueError(f"Unknown element family: {family}, available families: {list(known)}")
     if dim != 1:
         raise NotImplementedError("vector spaces are not implemented")
     return grid.FunctionSpace(mesh, family, int(degree))
