@@ -228,6 +228,13 @@ struct FastMath {
   }
 };
 
+// The generated models' Goldman-Hodgkin-Katz fluxes  v g / (exp(c v) - 1)  are 0/0 at v = 0 and their v-derivative
+// loses all accuracy next to it (relative error ~ ulp / (c v F/RT)^2; see tools/gen_cell_model.py): the intermediates
+// they go through are evaluated at a potential kept at least 1e-4 mV away from the singular value.  That leaves the
+// derivative five correct digits; on the rare step a node spends inside the window its rates are evaluated up to
+// 1e-4 mV off, which moves an increment by |d increment / dv| * 1e-4 mV (~2e-5 of the increment).
+__device__ __forceinline__ double beat_guard(double v) { return fabs(v) < 1.0e-4 ? copysign(1.0e-4, v) : v; }
+
 // Access to the state-major array for one node (row k at base + k*ld).
 struct NodeIO {
   double* __restrict__ base;
@@ -667,14 +674,31 @@ struct Tp06Grl1 {
     // ---- L-type calcium current (.ode:241) ---------------------------------------------------------------------
     // exp(2 (V - 15) F/RT) is kept as its own exp(): i_CaL divides by (eCaL - 1), which cancels near
     // V = 15 mV and would amplify the few-ulp error of a value derived from e6
-    const double eCaL = fm.exp(2.0 * (v - 15.0) * q.FRT);
     const double w15 = v - 15.0;
+    const double xCaL = 2.0 * w15 * q.FRT;
+    const double eCaL = fm.exp(xCaL);
+    // The specification's w15 (..)/(eCaL - 1) is 0/0 at V = 15 mV.  Its value is fine next to the singularity, but
+    // its V-derivative is a difference of two O(1/x) terms: the relative error of J_V grows like ulp/x^2, and a
+    // node that passes within ~1e-10 mV of 15 mV (it happens: ~1e8 node-crossings per simulated beat at 512^3) gets
+    // |J_V| ~ 1e8 of either sign, and exp(J_V dt) overflows.  Inside |x| < 1e-2 (|V - 15| < 0.13 mV) the factor
+    // x/(e^x - 1) and its derivative are therefore taken from their series; outside nothing changes, bit for bit.
+    const bool nearCaL = fabs(xCaL) < 1.0e-2;
     double rDc, rpCa;
-    rcp2(eCaL - 1.0, vCai + p[K_pCa], rDc, rpCa);
+    rcp2(nearCaL ? 1.0 : eCaL - 1.0, vCai + p[K_pCa], rDc, rpCa);
     const double NCaL = 0.25 * vCass * eCaL - p[Ca_o];
-    const double i_CaL = gates_CaL * w15 * NCaL * rDc;
-    dI_dV += gates_CaL * (NCaL * rDc + w15 * (2.0 * q.FRT) * eCaL * (p[Ca_o] - 0.25 * vCass) * rDc * rDc);
-    const double di_CaL_dCass = gates_CaL * w15 * 0.25 * eCaL * rDc;
+    double i_CaL = gates_CaL * w15 * NCaL * rDc;
+    double dCaL_dV = gates_CaL * (NCaL * rDc + w15 * (2.0 * q.FRT) * eCaL * (p[Ca_o] - 0.25 * vCass) * rDc * rDc);
+    double di_CaL_dCass = gates_CaL * w15 * 0.25 * eCaL * rDc;
+    if (nearCaL) {
+      const double x2 = xCaL * xCaL;
+      const double phi = 1.0 + xCaL * (-0.5 + xCaL * (1.0 / 12.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 30240.0))));
+      const double dphi = -0.5 + xCaL * (1.0 / 6.0 + x2 * (-1.0 / 180.0 + x2 * (1.0 / 5040.0)));
+      const double B = phi * q.halfRTF;  // (V - 15)/(e^x - 1)
+      i_CaL = gates_CaL * NCaL * B;
+      dCaL_dV = gates_CaL * (0.25 * vCass * eCaL * phi + NCaL * dphi);
+      di_CaL_dCass = gates_CaL * 0.25 * eCaL * B;
+    }
+    dI_dV += dCaL_dV;
     const double i_p_Ca = p[g_pCa] * vCai * rpCa;
     const double di_pCa_dCai = p[g_pCa] * p[K_pCa] * rpCa * rpCa;
     I_tot += i_CaL + i_p_Ca;

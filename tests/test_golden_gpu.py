@@ -251,3 +251,35 @@ def test_run_kernel_equals_repeated_steps(model):
     np.testing.assert_array_equal(yr, ys)
     assert tr.shape == (5, 1, 70)
     np.testing.assert_array_equal(tr[0, 0], y0[m.state_index(m.v_name)])
+
+
+def test_torord_step_is_regular_through_the_ghk_singularity():
+    """The Goldman-Hodgkin-Katz fluxes of the specification (ICaL, ICaNa, ICaK, ICab, INab) are 0/0 at v = 0 and their
+    v-derivative loses all accuracy next to it; the generated kernel evaluates them at a potential kept 1e-4 mV away
+    (csrc/ionic_models.h: beat_guard).  From plateau states with v within 1e-15 .. 1e-3 mV of 0 every state stays
+    finite, and each increment lies on the smooth curve through the values at +-0.01 .. +-0.04 mV (literal
+    evaluation) up to the guard's own footprint: inside the window the rates are evaluated up to 1e-4 mV off, i.e. an
+    increment moves by at most |d increment / dv| * 1e-4 mV."""
+    from beat.models import torord
+
+    g = np.load(GOLD / "torord_spec.npz")
+    vi = torord.state_index("v")
+    traj = g["traj_states"]
+    col = int(np.argmin(np.abs(traj[vi])))  # the sample of the paced action potential closest to 0 mV
+    offsets = np.array([-0.04, -0.03, -0.02, -0.01, -1e-3, -0.9e-4, -1e-6, -1e-10, -1e-15, 0.0, 1e-15, 1e-10, 1e-6,
+                        0.9e-4, 1e-3, 0.01, 0.02, 0.03, 0.04])
+    S = np.repeat(traj[:, col : col + 1], len(offsets), axis=1)
+    S[vi] = offsets
+    P = torord.init_parameter_values()
+    out = torord.generalized_rush_larsen(states=S, t=float(g["traj_step_t"]), parameters=P, dt=float(g["traj_dt"]))
+    assert np.isfinite(out).all()
+    inc = out - S
+    far = np.abs(offsets) >= 0.01
+    for k in range(S.shape[0]):
+        coef = np.polyfit(offsets[far], inc[k, far], 3)
+        fit = np.polyval(coef, offsets)
+        scale = np.abs(inc[k]).max()
+        slope = abs(coef[-2])  # d increment / dv at v = 0
+        # (only the guarded inputs move, so it is their partial slope that counts: allow 3x the total slope)
+        bound = 3.0 * slope * 1.0e-4 + 1e-6 * scale
+        assert np.abs(inc[k] - fit).max() <= bound, (g["state_names"][k], np.abs(inc[k] - fit).max(), bound)

@@ -496,3 +496,59 @@ def test_deferred_x_ring_wrap_and_over_enqueue(hip_ctx):
     ops3.set_timestep(0.01, 0.5, 0.5)
     x_cls, r_cls = solve(DiffusionSolver(ops3, Slab(nn[2]), force_distributed=False), ops3, v_hard, 1e-12)
     np.testing.assert_array_equal(x_cls, x_hard)
+
+
+def test_tp06_step_is_regular_through_the_cal_singularity(hip_ctx):
+    """i_CaL of the specification is 0/0 at V = 15 mV and its V-derivative loses all accuracy next to it (the
+    literal expression gave |J_V| ~ 1e8 and V = inf at V = 15.000000000027 in a 256^3 run).  The kernel takes
+    x/(e^x - 1) from its series inside |V - 15| < 0.13 mV: every state stays finite there, the update is smooth across
+    the switch, and outside the window the kernel still agrees with the literal oracle."""
+    from beat import _hip
+    from beat.models import tp06
+    from oracle import ionic
+
+    # the plateau state of the node that blew up (V replaced below)
+    base = np.array([0.26252164857130134, 0.01686034782909001, 0.019263565352823808, 0.999298678112656,
+                     7.787943035125431e-11, 4.991947762659259e-10, 0.9550340372923384, 0.7192870635966016,
+                     0.48840230274567625, 0.4037323643965525, 0.10531142458561057, 0.2803574590153299,
+                     0.37626961261077424, 0.0006787249606944496, 2.892319135034567, 0.9153873040549239,
+                     8.59497902253472, 15.0, 136.901828032133])
+    iv = tp06.state_index("V")
+    offsets = np.array([-0.4, -0.2, -0.14, -0.13, -1e-2, -1e-3, -1e-6, -1e-9, -2.7e-11, -1.8e-15, 0.0, 1.8e-15,
+                        2.7367e-11, 1e-9, 1e-6, 1e-3, 1e-2, 0.13, 0.14, 0.2, 0.4])
+    S = np.repeat(base[:, None], len(offsets), axis=1)
+    S[iv] = 15.0 + offsets
+    p = tp06.init_parameter_values(stim_amplitude=0.0)
+    dt = 0.01
+    out = _ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, p, 0.0, dt, v_index=iv)
+    assert np.isfinite(out).all()
+    # outside the window: the literal oracle (same tolerance as the random-state parity test)
+    far = np.abs(offsets) > 0.135
+    ref = ionic.tp06_generalized_rush_larsen(S[:, far], 0.0, dt, p)
+    np.testing.assert_allclose(out[:, far], ref, rtol=1e-9, atol=1e-12)
+    # inside the window: the literal specification evaluated with 40 significant digits (mpmath through sympy's
+    # lambdify) for the two states the L-type current drives, V and Ca_ss; V = 15 exactly is 0/0 there and is
+    # checked against its neighbours instead
+    import mpmath
+    import sympy
+
+    ys = sympy.symbols(" ".join(ionic.TP06_STATES), real=True)
+    ps = sympy.symbols(" ".join("p_" + n for n in ionic.TP06_PARAMETERS), real=True)
+    tt = sympy.Symbol("t", real=True)
+    fs = ionic.tp06_rhs(ys, tt, ps, ns=ionic._sympy_ns())
+    rows = [iv, tp06.state_index("Ca_ss")]
+    fn = sympy.lambdify([*ys, tt, *ps], [(fs[k], sympy.diff(fs[k], ys[k])) for k in rows], modules="mpmath")
+    mpmath.mp.dps = 40
+    try:
+        for c, off in enumerate(offsets):
+            if off == 0.0:
+                continue
+            vals = fn(*[mpmath.mpf(float(x)) for x in S[:, c]], mpmath.mpf(0), *[mpmath.mpf(float(x)) for x in p])
+            for k, (f, J) in zip(rows, vals):
+                exact = float(mpmath.mpf(float(S[k, c])) + f * (mpmath.exp(J * dt) - 1) / J)
+                assert abs(out[k, c] - exact) <= 1e-11 * max(abs(exact), 1e-3), (k, off, out[k, c], exact)
+    finally:
+        mpmath.mp.dps = 15
+    mid = list(offsets).index(0.0)
+    for k in rows:
+        assert abs(out[k, mid] - 0.5 * (out[k, mid - 1] + out[k, mid + 1])) <= 1e-13 * max(abs(out[k, mid]), 1e-3)

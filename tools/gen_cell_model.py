@@ -93,6 +93,9 @@ class Printer(C99CodePrinter):
     def _print_log(self, e):
         return f"fm.log({self._print(e.args[0])})"
 
+    def _print_beat_guard(self, e):
+        return f"beat_guard({self._print(e.args[0])})"
+
     def _print_Abs(self, e):
         return f"fabs({self._print(e.args[0])})"
 
@@ -118,6 +121,49 @@ class Printer(C99CodePrinter):
 
     def _print_Symbol(self, e):
         return SYMBOL_NAMES.get(e.name, e.name)
+
+
+class beat_guard(sympy.Function):
+    """The membrane potential kept a hair away from a removable singularity (printed as the device function of that
+    name); its derivative is taken as 1."""
+
+    nargs = 1
+
+    def fdiff(self, argindex=1):
+        return sympy.Integer(1)
+
+
+def ghk_singular_inputs(exprs, states):
+    """Names of the intermediates through which Goldman-Hodgkin-Katz fluxes  w g / (exp(u) - 1)  see the membrane
+    potential (w, u proportional to v: 0/0 at v = 0), and the potential's symbol.
+
+    The value of such a flux is fine next to the singularity, but its v-derivative is a difference of two O(1/u)
+    terms whose relative error grows like ulp / u^2: a node that passes within ~1e-10 mV of 0 gets a self-derivative
+    of ~1e8 of either sign and the Rush-Larsen exponential overflows (seen with the hand-written TP06 kernel at
+    256^3, where the singular potential is 15 mV).  The generated kernels therefore evaluate these intermediates at
+    a potential that is never closer than beat_guard's 1e-4 mV to the singular value."""
+    names, vsym = set(), None
+    for e in exprs.values():
+        for q in e.atoms(sympy.Pow):
+            if not (q.exp.is_Number and float(q.exp) < 0 and q.base.is_Add and len(q.base.args) == 2):
+                continue
+            ex = [t for t in q.base.args if isinstance(t, sympy.exp)]
+            if len(ex) != 1 or not any(t.is_Number and float(t) == -1.0 for t in q.base.args):
+                continue
+            inputs = {sy.name for sy in ex[0].args[0].free_symbols if sy.name in exprs}
+            for name in inputs:  # u must vanish with exactly one state (the potential), and so must a co-factor
+                d = exprs[name]
+                sv = [sy for sy in d.free_symbols if sy.name in states]
+                if len(sv) == 1 and d.subs(sv[0], 0) == 0:
+                    vsym = sv[0]
+                    names.add(name)
+    if vsym is not None:  # numerators: every other intermediate that is a multiple of the same potential alone
+        for name, d in exprs.items():
+            sv = [sy for sy in d.free_symbols if sy.name in states]
+            if sv == [vsym] and not any(sy.name in exprs for sy in d.free_symbols) and d.subs(vsym, 0) == 0 \
+                    and sympy.simplify(d / vsym).is_constant(vsym):
+                names.add(name)
+    return names, vsym
 
 
 SYMBOL_NAMES: dict[str, str] = {}
@@ -146,6 +192,14 @@ def build(spec: OdeSpec):
         exprs[name] = e
         order.append(name)
         ns[name] = sympy.Symbol(name, real=True)
+    guarded, vsym = ghk_singular_inputs(exprs, states)
+    if guarded:
+        vg = sympy.Symbol(f"{vsym.name}_ghk", real=True)
+        for name in guarded:
+            exprs[name] = exprs[name].subs(vsym, vg)
+        exprs[vg.name] = beat_guard(vsym)
+        order.insert(0, vg.name)
+        print(f"Goldman-Hodgkin-Katz inputs evaluated at the guarded potential {vg.name}:", ", ".join(sorted(guarded)))
     # transitive state dependencies of every intermediate
     dep: dict[str, set[str]] = {}
     for name in order:
