@@ -552,3 +552,81 @@ def test_tp06_step_is_regular_through_the_cal_singularity(hip_ctx):
     mid = list(offsets).index(0.0)
     for k in rows:
         assert abs(out[k, mid] - 0.5 * (out[k, mid - 1] + out[k, mid + 1])) <= 1e-13 * max(abs(out[k, mid]), 1e-3)
+
+
+def _sweep_shapes():
+    """Seeded random grid shapes around every tile boundary of the stencil kernels (tiles are 64 x 16, 128 x 8 or
+    256 x 4 nodes, chosen by nx; 16 planes per z-chunk), plus hand-picked edge cases."""
+    rng = np.random.default_rng(20260101)
+    shapes = [(255, 3, 2), (256, 4, 1), (257, 5, 3), (300, 9, 2), (513, 2, 2), (127, 8, 17), (128, 9, 16), (129, 7, 2),
+              (63, 16, 3), (64, 17, 2), (65, 15, 33), (2, 2, 2), (1, 1, 40), (3, 40, 1), (600, 1, 1)]
+    for _ in range(12):
+        shapes.append((int(rng.integers(1, 330)), int(rng.integers(1, 20)), int(rng.integers(1, 8))))  # <= 50 k nodes
+    return shapes
+
+
+@pytest.mark.parametrize("cells", _sweep_shapes())
+def test_operator_and_solve_sweep_over_grid_shapes(hip_ctx, cells):
+    """A x and one theta-step on grids whose node counts straddle the tile and chunk sizes of the kernels, against the
+    oracle's assembled matrices / sparse solve; then the same operators through the per-node path with a random voxel
+    mask."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    from beat import _hip, _stencil
+    from beat._device import Field
+    from beat._engine import HipOps
+    from oracle import fem
+
+    ctx = hip_ctx
+    L = tuple(0.1 * c for c in cells)
+    mesh = fem.BoxMesh(cells, L)
+    Mten = _conductivity("aniso3", 3)
+    Mass, K = fem.assemble_mass(mesh), fem.assemble_stiffness(mesh, Mten)
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    A = (C_m * Mass + theta * dt * K).tocsr()
+    B = (C_m * Mass - (1 - theta) * dt * K).tocsr()
+    n = mesh.num_nodes
+    nn = tuple(c + 1 for c in cells)
+    plane = nn[0] * nn[1]
+    rng = np.random.default_rng(sum(cells))
+    x = rng.standard_normal(n)
+    ops = HipOps(ctx, nn, True, True, *_stencil.stencil_tables(3, (0.1, 0.1, 0.1), Mten))
+    ops.set_timestep(C_m, theta, dt)
+    fx, fy = ops.new_field(), ops.new_field()
+    fx.set(x)
+    fx.ghost_lo.fill_(float("nan"))
+    fx.ghost_hi.fill_(float("nan"))
+    ops.apply(0, fx, fy)
+    ref = A @ x
+    scale = (abs(A) @ np.ones(n)).max() * np.abs(x).max()
+    assert np.abs(fy.numpy() - ref).max() <= 1e-13 * scale
+    v_prev = -85.0 + 30.0 * rng.random(n)
+    fv, fs = ops.new_field(), ops.new_field()
+    fv.set(v_prev)
+    res = ops.solve_single(fv, [], [], fs, 1e-12, 1e-50, 500)
+    exact = spla.spsolve(A.tocsc(), B @ v_prev)
+    assert res.converged_reason > 0
+    np.testing.assert_allclose(fs.numpy(), exact, rtol=0, atol=1e-9 * np.abs(exact).max())
+    # per-node rows on a random voxel mask of the same box
+    active = rng.random(int(np.prod(cells))) < 0.6
+    if not active.any():
+        active[0] = True
+    mf, kf = _stencil.stencil_fields(3, cells, (0.1, 0.1, 0.1), Mten, active)
+    var = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
+    var.set_timestep(C_m, theta, dt)
+    act_s = np.repeat(active, 6)  # six tetrahedra per box cell
+    Mass_a = fem.assemble_mass(mesh, np.nonzero(act_s)[0])
+    K_a = fem.assemble_stiffness(mesh, np.broadcast_to(Mten, (len(act_s), 3, 3)) * act_s[:, None, None])
+    tissue = Mass_a.diagonal() > 0
+    ident = sp.diags(np.where(tissue, 0.0, 1.0))
+    A_a = (C_m * Mass_a + theta * dt * K_a + ident).tocsc()
+    B_a = (C_m * Mass_a - (1 - theta) * dt * K_a + ident).tocsr()
+    v2 = np.where(tissue, v_prev, 0.0)
+    exact2 = spla.spsolve(A_a, B_a @ v2)
+    gv, gs = var.new_field(), var.new_field()
+    gv.set(v2)
+    gs.set(v2)
+    res2 = var.solve_single(gv, [], [], gs, 1e-12, 1e-50, 500)
+    assert res2.converged_reason > 0
+    np.testing.assert_allclose(gs.numpy()[tissue], exact2[tissue], rtol=0, atol=1e-9 * max(1.0, np.abs(exact2).max()))
