@@ -630,3 +630,43 @@ def test_operator_and_solve_sweep_over_grid_shapes(hip_ctx, cells):
     res2 = var.solve_single(gv, [], [], gs, 1e-12, 1e-50, 500)
     assert res2.converged_reason > 0
     np.testing.assert_allclose(gs.numpy()[tissue], exact2[tissue], rtol=0, atol=1e-9 * max(1.0, np.abs(exact2).max()))
+
+
+@pytest.mark.parametrize("cells", [(255, 3), (256, 4), (257, 5), (1023, 1), (63, 17), (64, 16), (65, 15), (1, 1), (2, 300),
+                                   (300,), (1,), (64,), (257,)])
+def test_operator_and_solve_sweep_2d_1d(hip_ctx, cells):
+    """The same sweep for 2-D and 1-D grids (one plane / one row of the 3-D kernels)."""
+    import scipy.sparse.linalg as spla
+
+    from beat import _stencil
+    from beat._engine import HipOps
+    from oracle import fem
+
+    dim = len(cells)
+    L = tuple(0.1 * c for c in cells)
+    mesh = fem.BoxMesh(cells, L)
+    Mten = np.array([[2.0, 0.3], [0.3, 1.0]]) * 1e-3 if dim == 2 else 1e-3
+    Mass, K = fem.assemble_mass(mesh), fem.assemble_stiffness(mesh, Mten)
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    A = (C_m * Mass + theta * dt * K).tocsr()
+    B = (C_m * Mass - (1 - theta) * dt * K).tocsr()
+    n = mesh.num_nodes
+    nn = tuple(c + 1 for c in cells) + (1,) * (3 - dim)
+    rng = np.random.default_rng(sum(cells) + dim)
+    ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_tables(dim, (0.1,) * dim, Mten))
+    ops.set_timestep(C_m, theta, dt)
+    x = rng.standard_normal(n)
+    fx, fy = ops.new_field(), ops.new_field()
+    fx.set(x)
+    fx.ghost_lo.fill_(float("nan"))
+    fx.ghost_hi.fill_(float("nan"))
+    ops.apply(0, fx, fy)
+    scale = (abs(A) @ np.ones(n)).max() * np.abs(x).max()
+    assert np.abs(fy.numpy() - A @ x).max() <= 1e-13 * scale
+    v_prev = -85.0 + 30.0 * rng.random(n)
+    fv, fs = ops.new_field(), ops.new_field()
+    fv.set(v_prev)
+    res = ops.solve_single(fv, [], [], fs, 1e-12, 1e-50, 500)
+    assert res.converged_reason > 0
+    exact = spla.spsolve(A.tocsc(), B @ v_prev)
+    np.testing.assert_allclose(fs.numpy(), exact, rtol=0, atol=1e-9 * np.abs(exact).max())
