@@ -204,3 +204,76 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz):
     assert all(out[r][1].converged_reason > 0 for r in range(world))
     np.testing.assert_allclose(x_parts, x_whole, rtol=0, atol=1e-9 * np.abs(x_whole).max())
     np.testing.assert_array_equal(x_defer, x_parts)
+
+
+def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx):
+    """bench.py's N > 1 step (TP06 ionic kernel applying the previous solve's pending directions on the slab's V row,
+    then the slab-decomposed diffusion solve with the deferred last update) on 3 ranks played by threads: after 25 steps
+    the assembled state array equals the one-rank run to 1e-9 (the reductions are summed in a different order)."""
+    import ctypes as C
+    import threading
+
+    from beat import _hip, _stencil
+    from beat._device import Context, StateArray
+    from beat._engine import DiffusionSolver, HipOps, Slab
+    from beat.models import tp06
+
+    nx, ny, nz, world, nsteps = 24, 17, 11, 3, 25
+    plane = nx * ny
+    f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
+    M = 9.5301e-4 * np.outer(f0, f0) + 1.2576e-4 * (np.eye(3) - np.outer(f0, f0))
+    tabs = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
+    ic = tp06.init_state_values()
+    p_host = np.ascontiguousarray(tp06.init_parameter_values(stim_amplitude=0.0))
+    vi = tp06.state_index("V")
+    rng = np.random.default_rng(2)
+    S0 = np.repeat(ic[:, None], plane * nz, axis=1) * (1.0 + 0.01 * rng.uniform(-1, 1, (len(ic), plane * nz)))
+    zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    S0[vi] = ic[vi] + 70.0 * np.exp(-((xx - 6) ** 2 + (yy - 8) ** 2 + (zz - 5) ** 2).ravel() / 18.0)
+
+    def run(ctx, slab, dist_view, out, key):
+        n_local = plane * slab.nz
+        ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *tabs)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        solver = DiffusionSolver(ops, slab, force_distributed=dist_view is not None)
+        if dist_view is not None:
+            solver.dist = dist_view
+        states = StateArray(ctx, len(ic), n_local, plane)
+        states.set(S0[:, slab.z0 * plane : slab.z1 * plane])
+        v_field = states.row_field(vi)
+        its = []
+        for step in range(nsteps):
+            pend = ops.pending
+            ops.pending = None
+            _hip.check(ctx.lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld,
+                                                     p_host.ctypes.data_as(C.c_void_p), len(p_host), None, 0, 0.05 * step, 0.05,
+                                                     vi, None, ops.handle, ops.ring[0].ptr, ops.fld, pend[2] if pend else 0))
+            its.append(solver.solve(v_field, [], [], v_field, rtol=1e-10, atol=1e-50, max_it=200, defer_flush=True).iterations)
+        ops.flush_pending()
+        ctx.synchronize()
+        out[key] = (states.numpy().copy(), its)
+
+    out, errors = {}, []
+    run(hip_ctx, Slab(nz), None, out, "whole")
+    tw = _ThreadWorld(world)
+
+    def worker(rank):
+        try:
+            run(Context(), Slab(nz, rank, world), tw.rank_view(rank), out, rank)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((rank, exc))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    whole, its_whole = out["whole"]
+    parts = np.concatenate([out[r][0] for r in range(world)], axis=1)
+    assert all(out[r][1] == out[0][1] for r in range(world))
+    assert max(abs(a - b) for a, b in zip(out[0][1], its_whole)) <= 1
+    assert whole[vi].max() > 0.0  # the stimulated region fired
+    scale = np.maximum(np.abs(whole), 1e-6 * np.abs(ic)[:, None] + 1e-12)
+    assert (np.abs(parts - whole) / scale).max() < 1e-9
