@@ -17,9 +17,16 @@ import beat
 from beat import grid as g
 from beat.models import tp06
 
-REFERENCE_DX05 = {  # ms, dx = 0.5 mm (reference demo, table at the end of the script)
-    0.05: dict(P1=1.25, P2=51.1, P3=34.9, P4=58.9, P5=14.1, P6=49.5, P7=34.0, P8=56.65, P9=26.05),
-    0.01: dict(P1=1.22, P2=50.85, P3=33.96, P4=58.05, P5=13.98, P6=49.36, P7=33.07, P8=55.91, P9=25.64),
+REFERENCE_TABLE = {  # (dx mm, dt ms) -> activation times at P1..P9 in ms (the table at the end of the reference's demo)
+    (0.5, 0.05): (1.25, 51.1, 34.9, 58.9, 14.1, 49.5, 34.0, 56.65, 26.05),
+    (0.5, 0.01): (1.22, 50.85, 33.96, 58.05, 13.98, 49.36, 33.07, 55.91, 25.64),
+    (0.5, 0.005): (1.215, 50.775, 33.825, 57.96, 13.97, 49.345, 32.945, 55.825, 25.595),
+    (0.2, 0.05): (1.25, 29.7, 32.9, 40.2, 9.55, 30.0, 32.95, 39.9, 18.9),
+    (0.2, 0.01): (1.24, 29.09, 31.25, 38.66, 9.34, 29.4, 31.29, 38.42, 18.14),
+    (0.2, 0.005): (1.235, 29.015, 31.05, 38.475, 9.315, 29.32, 31.08, 38.235, 18.045),
+    (0.1, 0.05): (1.25, 26.85, 33.3, 40.35, 8.4, 27.5, 33.85, 40.55, 18.95),
+    (0.1, 0.01): (1.23, 25.64, 31.46, 38.08, 8.03, 26.24, 31.94, 38.21, 17.95),
+    (0.1, 0.005): (1.225, 25.5, 31.26, 37.81, 7.99, 26.09, 31.72, 37.93, 17.835),
 }
 
 
@@ -66,7 +73,8 @@ def main():
         t += dt
     wall = wallclock.perf_counter() - tic
     print(f"{mesh.num_nodes} nodes, {nsteps} steps of {dt} ms in {wall:.2f} s ({wall / nsteps * 1e3:.2f} ms/step)")
-    ref = REFERENCE_DX05.get(dt) if abs(args.dx - 0.5) < 1e-12 else None
+    row = REFERENCE_TABLE.get((round(args.dx, 6), round(dt, 6)))
+    ref = dict(zip(points, row)) if row else None
     for p in points:
         line = f"  {p}: {activation[p] if activation[p] is not None else float('nan'):8.2f} ms"
         if ref:
