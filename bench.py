@@ -204,6 +204,11 @@ def main():
     args = ap.parse_args()
     global ISOTROPIC
     ISOTROPIC = args.iso
+    # stdout carries exactly one line, the JSON result: libraries that write to file descriptor 1 themselves (RCCL
+    # prints a five-line version banner when its communicator is created) are sent to stderr instead
+    sys.stdout.flush()
+    result_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
 
@@ -379,7 +384,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, args.rtol)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_stream, flush=True)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
