@@ -260,6 +260,13 @@ def main():
     states = StateArray(ctx, len(ic), n_local, plane)
     init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
     v_field = states.row_field(v_index)  # PDE unknown lives in the V row: no ODE<->PDE copies
+    if world > 1:
+        # RCCL creates its point-to-point channels on first use (seconds): do that outside any timed step, whatever
+        # --warmup says.  The exchange fills the V row's ghost planes with the neighbours' boundary planes, which is
+        # what the first right-hand side needs anyway.
+        solver.exchange_halo(v_field)
+        dist.all_reduce(torch.zeros(2, dtype=torch.float64, device=ctx.device))
+        torch.cuda.synchronize()
     import ctypes as C
 
     p_host = np.ascontiguousarray(params)
