@@ -217,6 +217,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # BEAT_DIST_BACKEND=gloo: rehearsal of the multi-process path with several ranks sharing one GPU (host-staged
+    # transport, beat._engine._HostStagedDist); the numbers of such a run mean nothing
+    backend = os.environ.get("BEAT_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     # BEAT_FORCE_DISTRIBUTED=1 rehearses the collective code path (RCCL all-reduces, stage kernels driven
     # from Python) on a single rank; the reported numbers are then NOT the single-GPU headline.
@@ -228,7 +233,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from beat import _hip
 
@@ -265,7 +273,7 @@ def main():
         # --warmup says.  The exchange fills the V row's ghost planes with the neighbours' boundary planes, which is
         # what the first right-hand side needs anyway.
         solver.exchange_halo(v_field)
-        dist.all_reduce(torch.zeros(2, dtype=torch.float64, device=ctx.device))
+        dist.all_reduce(torch.zeros(2, dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu"))
         torch.cuda.synchronize()
     import ctypes as C
 
@@ -314,13 +322,19 @@ def main():
     barrier()
     wall = time.perf_counter() - tic
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=ctx.device)
+        w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
 
     ode_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ode]))
     pde_ms = float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(args.steps)]))
     vmin, vmax = v_field.minmax()
+    if world > 1:  # extrema over all slabs (NaN-propagating: a non-finite value on any rank shows)
+        ext = torch.tensor([-vmin, vmax], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+        bad = torch.tensor([0.0 if np.isfinite(vmin) and np.isfinite(vmax) else 1.0], dtype=torch.float64, device=ext.device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        vmin, vmax = (-float(ext[0]), float(ext[1])) if float(bad[0]) == 0.0 else (float("nan"), float("nan"))
     finite = bool(np.isfinite(vmin) and np.isfinite(vmax))
 
     if rank == 0:
@@ -360,7 +374,8 @@ def main():
                             f"PCG rtol={args.rtol:g} (x0 = previous v), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
-                "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else ""),
+                "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else "")
+                               + ("" if backend == "nccl" else f" (REHEARSAL on {backend}, ranks share a GPU: not a measurement)"),
                 "pcg_iterations_per_step": k_avg,
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
@@ -396,7 +411,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if not finite:
-        raise SystemExit("non-finite membrane potential after the timed steps")
+        raise SystemExit("non-finite membrane potential after the timed steps")  # every rank sees the same verdict
 
 
 if __name__ == "__main__":

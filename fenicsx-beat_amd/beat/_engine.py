@@ -396,6 +396,50 @@ def build_ops(ctx, mesh, M: np.ndarray) -> "HipOps":
     return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass, stiff, per_node=True)
 
 
+class _HostStagedDist:
+    """``torch.distributed`` on a backend without device-tensor point-to-point (gloo) for device fields: messages and
+    all-reduces go through host copies.  A rehearsal transport only -- it lets several ranks share ONE GPU, where RCCL
+    (one rank per device) cannot run, so that the multi-process path can be exercised end to end on a one-GPU box
+    (``BEAT_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2``).  The product
+    transport is RCCL."""
+
+    class _Request:
+        def __init__(self, work, device_dst=None, host=None):
+            self.work, self.device_dst, self.host = work, device_dst, host
+
+        def wait(self):
+            self.work.wait()
+            if self.device_dst is not None:
+                self.device_dst.copy_(self.host)
+
+    def __init__(self, dist):
+        self._dist = dist
+        self.ReduceOp = dist.ReduceOp
+        self.isend, self.irecv = dist.isend, dist.irecv
+        self.get_global_rank = dist.get_global_rank
+
+    def P2POp(self, fn, tensor, peer, group=None):
+        return (fn, tensor, peer, group)
+
+    def batch_isend_irecv(self, ops):
+        import torch
+
+        reqs = []
+        for fn, tensor, peer, group in ops:
+            if fn is self.isend:
+                host = tensor.cpu()
+                reqs.append(self._Request(self._dist.isend(host, peer, group=group), host=host))
+            else:
+                host = torch.empty(tensor.shape, dtype=tensor.dtype)
+                reqs.append(self._Request(self._dist.irecv(host, peer, group=group), tensor, host))
+        return reqs
+
+    def all_reduce(self, t, op=None, group=None):
+        host = t.cpu()
+        self._dist.all_reduce(host, op=op if op is not None else self.ReduceOp.SUM, group=group)
+        t.copy_(host)
+
+
 class DiffusionSolver:
     """theta-rule diffusion step on one slab of a (possibly) decomposed grid."""
 
@@ -408,6 +452,8 @@ class DiffusionSolver:
             import torch.distributed as dist
 
             self.dist = dist
+            if dist.is_initialized() and dist.get_backend(group) != "nccl" and getattr(getattr(ops, "st", None), "is_cuda", False):
+                self.dist = _HostStagedDist(dist)  # device fields on a host-only backend: rehearsal transport
         else:
             self.dist = None
 

@@ -277,3 +277,31 @@ def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx):
     assert whole[vi].max() > 0.0  # the stimulated region fired
     scale = np.maximum(np.abs(whole), 1e-6 * np.abs(ic)[:, None] + 1e-12)
     assert (np.abs(parts - whole) / scale).max() < 1e-9
+
+
+def test_bench_multi_process_rehearsal_on_one_gpu():
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one process per rank), with the
+    two ranks sharing this box's GPU over the host-staged gloo transport (BEAT_DIST_BACKEND=gloo; RCCL needs one
+    device per rank): stdout is exactly one JSON line, it reports both ranks' work, the state is finite, and the PCG
+    iteration count equals the one-process run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    common = ["--steps", "4", "--warmup", "1", "--size", "48", "--cpu-sample", "0"]
+    one = subprocess.run([sys.executable, str(root / "bench.py"), *common], capture_output=True, text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, BEAT_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", *common],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, two.stdout[-2000:]
+    r1, r2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["config"]["nodes"] == 48**3 and r2["config"]["finite"] and r2["cpu_baseline"] is None
+    assert abs(r2["config"]["pcg_iterations_per_step"] - r1["config"]["pcg_iterations_per_step"]) <= 0.5
+    assert abs(r2["config"]["v_max"] - r1["config"]["v_max"]) < 1.0  # same bump; the gates' 1 % noise is seeded per rank
