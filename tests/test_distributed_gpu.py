@@ -305,3 +305,41 @@ def test_bench_multi_process_rehearsal_on_one_gpu():
     assert r2["n_gpus"] == 2 and r2["config"]["nodes"] == 48**3 and r2["config"]["finite"] and r2["cpu_baseline"] is None
     assert abs(r2["config"]["pcg_iterations_per_step"] - r1["config"]["pcg_iterations_per_step"]) <= 0.5
     assert abs(r2["config"]["v_max"] - r1["config"]["v_max"]) < 1.0  # same bump; the gates' 1 % noise is seeded per rank
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
+    """The reference's own call sequence (geometry, stimulus, MonodomainModel, DolfinODESolver, splitting solver,
+    evaluate_function, x.array) run by `world` processes, the communicator cutting the mesh into z-slabs
+    (tests/_api_ranks_script.py; ranks share this box's GPU over the host-staged gloo transport): after 60 TP06 steps
+    the concatenated potential, every state row and the probe values equal the one-process run to 1e-10, with the
+    same PCG iteration count."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    script = str(root / "tests" / "_api_ranks_script.py")
+    d1, dn = tmp_path / "one", tmp_path / "many"
+    d1.mkdir()
+    dn.mkdir()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, script, str(d1)], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, str(dn)],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+    assert many.returncode == 0, many.stderr[-3000:]
+    a = np.load(d1 / "rank0.npz")
+    parts = [np.load(dn / f"rank{r}.npz") for r in range(world)]
+    assert [int(p["z0"]) for p in parts] == sorted(int(p["z0"]) for p in parts) and int(parts[-1]["z1"]) == 9
+    assert sum(int(p["nodes"]) for p in parts) == int(a["nodes"])
+    v = np.concatenate([p["v"] for p in parts])
+    S = np.concatenate([p["states"] for p in parts], axis=1)
+    assert a["v"].max() > 0.0  # the stimulated corner fired
+    np.testing.assert_allclose(v, a["v"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(S, a["states"], rtol=1e-10, atol=1e-12)
+    for p in parts:
+        np.testing.assert_allclose(p["probes"], a["probes"], rtol=0, atol=1e-10)
+        assert int(p["its"]) == int(a["its"])
