@@ -87,6 +87,19 @@ class Comm:
         return float(t.item())
 
 
+    def allreduce_max(self, value) -> float:
+        d = self._dist()
+        if not d:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if d.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        d.all_reduce(t, op=d.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+
 COMM_WORLD = Comm()
 
 

@@ -74,12 +74,13 @@ def laplace_dirichlet(V: grid.FunctionSpace, bcs, rtol: float = 1e-10, atol: flo
     from ._engine import HipOps
 
     mesh = V.mesh
-    if mesh.comm.size > 1:
-        raise NotImplementedError("layer markers are computed on one rank")
+    # A one-off set-up solve: on a slab-decomposed mesh every rank solves the WHOLE problem (facet ids and their
+    # vertices are global, so every rank knows all the conditions) and keeps its slab of the solution -- replicas, no
+    # communication; the full-box rows are freed afterwards (51 GB for a 141 M-node box: fits beside the slab data).
     ctx = Context.default()
+    shape, n, plane = mesh.shape_global, mesh.num_nodes_global, mesh.plane
     ops0 = HipOps.from_voxels(ctx, mesh.dim, mesh.n, mesh.h, np.eye(mesh.dim),
-                              None if mesh.active is None else mesh._box_active().ravel(), mesh.shape_local, 0, True, True)
-    n = mesh.num_nodes
+                              None if mesh.active is None else mesh._box_active().ravel(), shape, 0, True, True)
     flag = np.zeros(n, dtype=np.uint8)
     g = np.zeros(n)
     for facets, value in bcs:
@@ -92,14 +93,18 @@ def laplace_dirichlet(V: grid.FunctionSpace, bcs, rtol: float = 1e-10, atol: flo
     gfld, ffld, xfld = ops0.new_field(), ops0.new_field(), ops0.new_field()
     gfld.set(g)
     stiff = ops0._stiff_dev  # modified in place: ops0 is not used for anything else
-    _hip.check(ctx.lib.beat_rows_apply_dirichlet(ctx.handle, (C.c_int64 * 3)(*mesh.shape_local), C.c_void_p(stiff.data_ptr()), n,
+    _hip.check(ctx.lib.beat_rows_apply_dirichlet(ctx.handle, (C.c_int64 * 3)(*shape), C.c_void_p(stiff.data_ptr()), n,
                                                  C.c_void_p(flag_dev.data_ptr()), gfld.ptr, ffld.ptr))
-    ops = HipOps(ctx, mesh.shape_local, True, True, ops0._mass_dev, stiff, per_node=True)
+    ops = HipOps(ctx, shape, True, True, ops0._mass_dev, stiff, per_node=True)
     ops.set_timestep(0.0, 1.0, 1.0)  # A = K
     res = ops.solve_single(gfld, [ffld], [1.0], xfld, rtol, atol, max_it)
     logger.info("Laplace solve: %d PCG iterations, |r| = %.3e", res.iterations, res.residual_norm)
     u = grid.Function(V, name="laplace")
-    u.writable_field().copy_from(xfld)
+    dst = u.writable_field()
+    if mesh.comm.size > 1:
+        dst.data.copy_(xfld.data[mesh.slab.z0 * plane : mesh.slab.z1 * plane])
+    else:
+        dst.copy_from(xfld)
     u._touch()
     return u
 

@@ -343,3 +343,38 @@ def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
     for p in parts:
         np.testing.assert_allclose(p["probes"], a["probes"], rtol=0, atol=1e-10)
         assert int(p["its"]) == int(a["its"])
+
+
+def test_voxel_shell_pipeline_on_three_ranks_matches_one_process(tmp_path):
+    """BASELINE configs[4] in small (tools/bench_biv.py: voxelised shell, per-voxel fibres, expand_layer markers from the
+    Laplace solve, ToR-ORd endo/mid/epi through DolfinMultiODESolver, endocardial surface stimulus) on 3 processes --
+    slabs cut by tissue weight, per-node operators per slab, the Laplace set-up solve replicated on every rank -- against
+    one process: identical layer markers, potentials equal to 1e-9 after 20 steps, same PCG iteration counts."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    script = str(root / "tools" / "bench_biv.py")
+    d1, dn = tmp_path / "one", tmp_path / "many"
+    d1.mkdir()
+    dn.mkdir()
+    args = ["--size", "40", "--steps", "20", "--warmup", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, script, *args, "--save", str(d1)], capture_output=True, text=True, timeout=600,
+                         cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                           "127.0.0.1", "--master-port", str(_free_port()), script, *args, "--save", str(dn)],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+    assert many.returncode == 0, many.stderr[-3000:]
+    a = np.load(d1 / "rank0.npz")
+    parts = [np.load(dn / f"rank{r}.npz") for r in range(3)]
+    counts = [int(p["z1"]) - int(p["z0"]) for p in parts]
+    assert sum(counts) == 41 and len(set(counts)) > 1  # cut by tissue weight, not evenly
+    np.testing.assert_array_equal(np.concatenate([p["markers"] for p in parts]), a["markers"])
+    assert a["v"].max() > 0.0
+    np.testing.assert_allclose(np.concatenate([p["v"] for p in parts]), a["v"], rtol=0, atol=1e-9)
+    for p in parts:
+        np.testing.assert_array_equal(p["its"], a["its"])

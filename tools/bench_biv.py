@@ -45,12 +45,24 @@ def shell(n, h, chunk=32):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=256, help="voxels per axis (--n clashes with torchrun's own options)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dt", type=float, default=0.05)
+    ap.add_argument("--save", default="", help="directory for rank<r>.npz (potential, layer markers, slab) after the run")
     args = ap.parse_args()
+    import os
+
     import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # one process per rank (torch.distributed.run); BEAT_DIST_BACKEND=gloo: ranks share one GPU (rehearsal)
+        import torch.distributed as dist
+
+        backend = os.environ.get("BEAT_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
 
     import beat
     from beat import grid as g
@@ -113,8 +125,19 @@ def main():
     wall = time.perf_counter() - tic
     vmin, vmax = pde.state.field.minmax()
     nt = int(tissue.sum())
-    print(f"{wall / args.steps * 1e3:.2f} ms/step, {nt * args.steps / wall / 1e9:.3f} G tissue-node-updates/s, "
-          f"PCG {np.mean(its):.1f} its/step, v in [{vmin:.1f}, {vmax:.1f}] mV (0 = outside the tissue)", flush=True)
+    if args.save:
+        np.savez(os.path.join(args.save, f"rank{mesh.comm.rank}.npz"), v=np.asarray(pde.state.x.array), markers=marker_arr,
+                 z0=mesh.slab.z0, z1=mesh.slab.z1, its=np.array(its))
+    if world > 1:
+        nt = int(mesh.comm.allreduce(float(nt)))
+        vmin, vmax = -mesh.comm.allreduce_max(-vmin), mesh.comm.allreduce_max(vmax)
+    if mesh.comm.rank == 0:
+        print(f"{wall / args.steps * 1e3:.2f} ms/step, {nt * args.steps / wall / 1e9:.3f} G tissue-node-updates/s, "
+          f"PCG {np.mean(its):.1f} its/step, v in [{vmin:.1f}, {vmax:.1f}] mV (0 = outside the tissue)"
+          + (f"  [{world} ranks]" if world > 1 else ""), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
