@@ -46,9 +46,22 @@ for step in range(60):
     if step % 10 == 9:
         probes.append(g.evaluate_function(pde.state, points).ravel().copy())
 v = np.asarray(pde.state.x.array).copy()
+# ECG recovery (mass solve of K v + lead integrals: all-reduced dot products) and a checkpoint round trip
+# (one file per rank; read back on this communicator and compared with what was written)
+ecg = beat.ECGRecovery(v=pde.state, M=M, C_m=0.01, sigma_b=1.0, petsc_options={"ksp_rtol": 1e-12, "ksp_atol": 1e-30})
+forms = [ecg.eval(p) for p in ((8.0, 1.0, 2.0), (-2.0, 4.0, 5.0))]
+ecg.solve()
+leads = np.array([comm.allreduce(beat.ecg.assemble_scalar(f)) for f in forms])  # callers reduce, as with dolfinx
+chk = out_dir / "chk.bp"
+beat.io.write_mesh(chk, mesh)
+beat.io.write_function(chk, pde.state, time=t, name="v")
+back = g.Function(pde.state.function_space)
+beat.io.read_function(chk, back, time=t, name="v")
+roundtrip_ok = bool(np.array_equal(np.asarray(back.x.array), v))
 full = ode.full_values if hasattr(ode, "full_values") else None
 np.savez(out_dir / f"rank{comm.rank}.npz", v=v, probes=np.array(probes), z0=mesh.slab.z0, z1=mesh.slab.z1,
-         states=np.asarray(ode.values), its=pde.ksp.getIterationNumber(), nodes=mesh.num_nodes)
+         states=np.asarray(ode.values), its=pde.ksp.getIterationNumber(), nodes=mesh.num_nodes, leads=leads,
+         roundtrip_ok=roundtrip_ok)
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()

@@ -343,6 +343,9 @@ def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
     for p in parts:
         np.testing.assert_allclose(p["probes"], a["probes"], rtol=0, atol=1e-10)
         assert int(p["its"]) == int(a["its"])
+        # ECG leads (distributed mass solve + all-reduced lead integrals) and the per-rank checkpoint files
+        np.testing.assert_allclose(p["leads"], a["leads"], rtol=1e-9, atol=1e-14)
+        assert bool(p["roundtrip_ok"]) and abs(float(a["leads"][0])) > 0.0
 
 
 def test_voxel_shell_pipeline_on_three_ranks_matches_one_process(tmp_path):
