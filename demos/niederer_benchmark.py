@@ -72,7 +72,10 @@ def main():
                 activation[p] = t
         t += dt
     wall = wallclock.perf_counter() - tic
-    print(f"{mesh.num_nodes} nodes, {nsteps} steps of {dt} ms in {wall:.2f} s ({wall / nsteps * 1e3:.2f} ms/step)")
+    if mesh.comm.rank != 0:  # several ranks (python -m torch.distributed.run --nproc-per-node N ...): one report
+        return
+    print(f"{mesh.num_nodes_global} nodes on {mesh.comm.size} rank(s), {nsteps} steps of {dt} ms in {wall:.2f} s "
+          f"({wall / nsteps * 1e3:.2f} ms/step)")
     row = REFERENCE_TABLE.get((round(args.dx, 6), round(dt, 6)))
     ref = dict(zip(points, row)) if row else None
     for p in points:

@@ -32,12 +32,33 @@ class Comm:
 
     @staticmethod
     def _dist():
+        """torch.distributed if a process group exists.  Under a launcher that exports RANK / WORLD_SIZE > 1
+        (``python -m torch.distributed.run --nproc-per-node N script.py`` -- what ``mpirun -n N`` is to the reference)
+        the default group is created on first use: one process per GPU, RCCL; ``BEAT_DIST_BACKEND=gloo`` for a
+        rehearsal with ranks sharing a device."""
         try:
             import torch.distributed as dist
-
-            return dist if dist.is_available() and dist.is_initialized() else None
         except Exception:  # pragma: no cover
             return None
+        if not dist.is_available():
+            return None
+        if not dist.is_initialized():
+            import os
+
+            if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or "RANK" not in os.environ:
+                return None
+            import torch
+
+            backend = os.environ.get("BEAT_DIST_BACKEND", "nccl")
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
+                kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+            else:
+                backend, kw = "gloo", {}
+            dist.init_process_group(backend, **kw)
+        return dist
 
     @property
     def rank(self) -> int:
