@@ -195,10 +195,27 @@ class HipOps:
         c3 = [int(v) for v in cells] + [1] * (3 - dim)
         T, Me = _stencil.voxel_element_tensors(dim, h)
         M = np.asarray(M, dtype=np.float64)
+        if M.ndim == 3 and M.shape != (nvox, dim, dim):
+            raise ValueError(f"per-voxel conductivity has shape {M.shape}, expected ({nvox}, {dim}, {dim})")
+        if active is not None:
+            active = np.asarray(active, dtype=bool).ravel()
+            if active.size != nvox:
+                raise ValueError(f"active mask has {active.size} entries for {nvox} voxels")
+        # a slab only needs the voxel layers that touch its node planes: upload those, and let the kernel see a voxel
+        # grid that starts at the first of them
+        z0 = int(z0)
+        if dim == 3:
+            lo, hi = max(z0 - 1, 0), min(z0 + int(shape_local[2]), c3[2])
+            if (lo, hi) != (0, c3[2]):
+                per_layer = c3[0] * c3[1]
+                if M.ndim == 3:
+                    M = M[lo * per_layer : hi * per_layer]
+                if active is not None:
+                    active = active[lo * per_layer : hi * per_layer]
+                c3[2], z0 = hi - lo, z0 - lo
+                nvox = per_layer * c3[2]
         m_dev, m_const = None, None
         if M.ndim == 3:
-            if M.shape != (nvox, dim, dim):
-                raise ValueError(f"per-voxel conductivity has shape {M.shape}, expected ({nvox}, {dim}, {dim})")
             if dim == 3:
                 M9 = M  # already (nvox, 3, 3): no padded copy
             else:
@@ -210,9 +227,6 @@ class HipOps:
             m_const[:dim, :dim] = _stencil.conductivity_matrix(M, dim)
         a_dev = None
         if active is not None:
-            active = np.asarray(active, dtype=bool).ravel()
-            if active.size != nvox:
-                raise ValueError(f"active mask has {active.size} entries for {nvox} voxels")
             a_dev = ctx.from_numpy(active.astype(np.uint8))
         nx, ny, nz = (int(v) for v in shape_local)
         n = nx * ny * nz
