@@ -735,3 +735,47 @@ def test_fused_multi_celltype_step_equals_reference_sequence(theta):
         assert v.max() > -60.0
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("dim,theta_split,theta_pde", [(2, 1.0, 0.5), (2, 0.5, 1.0), (3, 1.0, 1.0), (3, 0.5, 0.5), (3, 1.0, 0.75)])
+def test_fused_route_equals_literal_route_over_options(dim, theta_split, theta_pde):
+    """Fused vs literal stepping (the reference's sequence of copies) over what the other tests hold fixed: 2-D and 3-D
+    meshes, backward-Euler / Crank-Nicolson / theta = 0.75 diffusion, Godunov and Strang splitting, and a time step
+    that changes twice during the run (base_model.py:225-230: matrices are rebuilt when dt changes) with a stimulus that
+    switches off in between.  Same values to 1e-12."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    def run(fused):
+        if dim == 3:
+            geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=3.0, Ly=2.0, Lz=1.0, dx=0.25)
+        else:
+            geo = beat.geometry.get_2D_slab_geometry(comm=g.COMM_WORLD, Lx=4.0, Ly=3.0, dx=0.25)
+        mesh = geo.mesh
+        time = g.Constant(mesh, 0.0)
+        cond = beat.conductivities.default_conductivities("Niederer")
+        cells = g.locate_entities(mesh, dim, lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+        tags = g.meshtags(mesh, dim, cells, np.full(len(cells), 1, dtype=np.int32))
+        I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                               mesh_unit="mm", amplitude=50_000.0, start=0.0, duration=1.0)
+        M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01, dx=I_s.dZ,
+                                   params={"theta": theta_pde, "petsc_options": {"ksp_rtol": 1e-12}})
+        ode = beat.odesolver.DolfinODESolver(
+            v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+            init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+            num_states=19, v_index=tp06.state_index("V"))
+        solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta_split, fused=fused)
+        t = 0.0
+        for dt, n in ((0.05, 12), (0.02, 15), (0.1, 8)):  # stimulus ends at 1 ms, inside the second block
+            for _ in range(n):
+                solver.step((t, t + dt))
+                t += dt
+        return solver
+
+    a, b = run(True), run(False)
+    va, vb = np.asarray(a.pde.state.x.array), np.asarray(b.pde.state.x.array)
+    assert va.max() > 0.0 and np.isfinite(va).all()
+    np.testing.assert_allclose(va, vb, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a.ode.values, b.ode.values, rtol=1e-12, atol=1e-14)
