@@ -46,6 +46,33 @@ def test_generate_random_activation_assertion():
         beat.stimulation.generate_random_activation(mesh=domain, time=t, points=np.zeros((2, 3)), delays=np.zeros(3))
 
 
+def test_generate_random_activation_recursion():
+    """tests/test_stimulation.py:389-425 of the reference: 1500 stimulation points at the default recursion limit --
+    building the expression, printing it and evaluating it must not recurse per point."""
+    import sys
+
+    import beat
+    from beat import grid as g
+
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(1000)
+    try:
+        mesh = g.create_unit_cube(g.COMM_WORLD, 2, 2, 2)
+        time = g.Constant(mesh, 0.0)
+        rng = np.random.default_rng(0)
+        num_points = 1500
+        expr = beat.stimulation.generate_random_activation(mesh=mesh, time=time, points=rng.random((num_points, 3)),
+                                                            delays=rng.random(num_points), stim_start=0.0, stim_duration=2.0,
+                                                            stim_amplitude=1.0, tol=1e-12)
+        assert isinstance(str(expr), str)
+        f = g.Function(g.functionspace(mesh, ("DG", 0)))
+        time.value = 1.0
+        f.interpolate(expr)
+        assert np.isfinite(f.x.array).all()
+    finally:
+        sys.setrecursionlimit(old)
+
+
 def test_generate_random_activation_respects_voxel_mask():
     import beat
     from beat import grid as g
