@@ -381,3 +381,51 @@ def test_voxel_shell_pipeline_on_three_ranks_matches_one_process(tmp_path):
     np.testing.assert_allclose(np.concatenate([p["v"] for p in parts]), a["v"], rtol=0, atol=1e-9)
     for p in parts:
         np.testing.assert_array_equal(p["its"], a["its"])
+
+
+def test_rccl_ghost_plane_exchange_on_field_slices(hip_ctx):
+    """The product's halo exchange (`DiffusionSolver.start_halo / finish_halo`: torch.distributed.batch_isend_irecv over
+    RCCL on slices of a field) with real RCCL point-to-point operations -- on a one-rank group a rank can only talk to
+    itself, so both neighbours are rank 0: the first owned plane must arrive in one ghost plane and the last in the
+    other, for a plain field and for a row of a state array (padded leading dimension), in stream order with the kernels
+    that wrote the planes."""
+    import torch.distributed as dist
+
+    from beat import _stencil
+    from beat._device import StateArray
+    from beat._engine import DiffusionSolver, HipOps
+
+    ctx = hip_ctx
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=ctx.device)
+        created = True
+    try:
+        nx, ny, nz = 37, 21, 6
+        plane = nx * ny
+
+        class Interior:  # a slab with live neighbours on both sides
+            rank, world, nz, lo_phys, hi_phys = 0, 2, 6, False, False
+
+        class SelfPeer(DiffusionSolver):
+            def _peer(self, group_rank):
+                return 0
+
+        ops = HipOps(ctx, (nx, ny, nz), False, False, *_stencil.stencil_tables(3, (0.1, 0.1, 0.1), np.eye(3) * 1e-3))
+        solver = SelfPeer(ops, Interior())
+        rng = np.random.default_rng(4)
+        states = StateArray(ctx, 3, plane * nz, plane)
+        for field in (ops.new_field(), states.row_field(1)):
+            for rep in range(3):
+                vals = rng.standard_normal(plane * nz)
+                field.set(vals)                      # written on the stream right before the exchange
+                field.ghost_lo.fill_(float("nan"))
+                field.ghost_hi.fill_(float("nan"))
+                solver.exchange_halo(field)
+                ctx.synchronize()
+                np.testing.assert_array_equal(field.ghost_lo.cpu().numpy(), vals[:plane])
+                np.testing.assert_array_equal(field.ghost_hi.cpu().numpy(), vals[-plane:])
+                np.testing.assert_array_equal(field.numpy(), vals)
+    finally:
+        if created:
+            dist.destroy_process_group()
