@@ -240,13 +240,14 @@ def main():
 
     from beat import _hip
 
-    if not _hip.library_path().is_file():  # a checkout without the built artefacts (the .so is not tracked)
-        if rank == 0:
-            import __graft_entry__ as entry
+    # a checkout without the built artefacts (the .so is not tracked): rank 0 builds, everybody waits -- the barrier is
+    # unconditional, so a rank that only looks once the file is already there cannot skip it and leave rank 0 waiting
+    if rank == 0 and not _hip.library_path().is_file():
+        import __graft_entry__ as entry
 
-            entry.build()
-        if world > 1 or force_dist:
-            dist.barrier()
+        entry.build()
+    if world > 1 or force_dist:
+        dist.barrier()
     from beat import _stencil
     from beat._device import Context, StateArray
     from beat._engine import DiffusionSolver, HipOps, Slab
