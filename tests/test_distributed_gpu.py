@@ -292,12 +292,12 @@ def test_bench_multi_process_rehearsal_on_one_gpu():
 
     root = Path(__file__).resolve().parents[1]
     common = ["--steps", "4", "--warmup", "1", "--size", "48", "--cpu-sample", "0"]
-    one = subprocess.run([sys.executable, str(root / "bench.py"), *common], capture_output=True, text=True, timeout=600, cwd=root)
+    one = subprocess.run([sys.executable, str(root / "bench.py"), *common], capture_output=True, text=True, timeout=300, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     env = dict(os.environ, BEAT_DIST_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", *common],
-                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     lines = [ln for ln in two.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, two.stdout[-2000:]
@@ -325,11 +325,11 @@ def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
     d1.mkdir()
     dn.mkdir()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    one = subprocess.run([sys.executable, script, str(d1)], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    one = subprocess.run([sys.executable, script, str(d1)], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert one.returncode == 0, one.stderr[-3000:]
     many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, str(dn)],
-                          capture_output=True, text=True, timeout=600, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
     assert many.returncode == 0, many.stderr[-3000:]
     a = np.load(d1 / "rank0.npz")
     parts = [np.load(dn / f"rank{r}.npz") for r in range(world)]
@@ -365,12 +365,12 @@ def test_voxel_shell_pipeline_on_three_ranks_matches_one_process(tmp_path):
     dn.mkdir()
     args = ["--size", "40", "--steps", "20", "--warmup", "0"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    one = subprocess.run([sys.executable, script, *args, "--save", str(d1)], capture_output=True, text=True, timeout=600,
+    one = subprocess.run([sys.executable, script, *args, "--save", str(d1)], capture_output=True, text=True, timeout=300,
                          cwd=root, env=env)
     assert one.returncode == 0, one.stderr[-3000:]
     many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
                            "127.0.0.1", "--master-port", str(_free_port()), script, *args, "--save", str(dn)],
-                          capture_output=True, text=True, timeout=600, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
     assert many.returncode == 0, many.stderr[-3000:]
     a = np.load(d1 / "rank0.npz")
     parts = [np.load(dn / f"rank{r}.npz") for r in range(3)]
