@@ -670,3 +670,36 @@ def test_operator_and_solve_sweep_2d_1d(hip_ctx, cells):
     assert res.converged_reason > 0
     exact = spla.spsolve(A.tocsc(), B @ v_prev)
     np.testing.assert_allclose(fs.numpy(), exact, rtol=0, atol=1e-9 * np.abs(exact).max())
+
+
+def test_tp06_step_on_edge_case_states(hip_ctx):
+    """60 000 states drawn from edge values -- potentials on both sides of every branch and singular point of the
+    specification (-40 mV, 15 mV, 0), gates at exactly 0 and 1 and at 1e-300, concentrations over five decades -- and
+    three step sizes: the kernel's result is finite everywhere (the literal oracle is not: ~2 % of these columns hit its
+    0/0 at 15 mV) and agrees with the oracle to 1e-10 wherever the oracle is finite and away from 15 mV."""
+    from beat import _hip
+    from oracle import ionic
+
+    rng = np.random.default_rng(99)
+    n = 60000
+    S = _random_tp06_states(n, 5)
+    idx = ionic.tp06_state_index
+    S[idx("V")] = rng.choice([-120.0, -100.0, -86.2, -40.0, -40.0 + 1e-12, -39.999999, 0.0, 15.0, 15.0 + 1e-13, 14.99999,
+                              35.0, 60.0, 80.0], n) + rng.choice([0.0, 1e-9, -1e-9, 0.3], n)
+    for gate in ["Xr1", "Xr2", "Xs", "m", "h", "j", "d", "f", "f2", "fCass", "s", "r", "R_prime"]:
+        S[idx(gate)] = rng.choice([0.0, 1.0, 1e-300, 1e-12, 0.5, 1 - 1e-16], n)
+    S[idx("Ca_i")] = rng.choice([1e-7, 1e-5, 1e-4, 1e-3, 1e-2], n)
+    S[idx("Ca_ss")] = rng.choice([1e-7, 1e-4, 1e-3, 1e-1, 1.0], n)
+    S[idx("Ca_SR")] = rng.choice([0.01, 1.0, 4.0, 10.0], n)
+    S[idx("Na_i")] = rng.choice([2.0, 8.6, 20.0, 50.0], n)
+    S[idx("K_i")] = rng.choice([50.0, 136.9, 160.0], n)
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    for dt in (0.05, 0.01, 0.5):
+        out = _ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, P, 0.0, dt)
+        assert np.isfinite(out).all()
+        with np.errstate(all="ignore"):
+            ref = ionic.tp06_generalized_rush_larsen(S, 0.0, dt, P)
+        ok = np.isfinite(ref).all(axis=0) & (np.abs(S[idx("V")] - 15.0) > 0.2)
+        assert ok.mean() > 0.7 and not np.isfinite(ref).all()
+        err = np.abs(out[:, ok] - ref[:, ok]) / np.maximum(np.abs(ref[:, ok]), 1e-3)
+        assert err.max() < 1e-10, err.max()
