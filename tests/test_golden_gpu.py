@@ -283,3 +283,35 @@ def test_torord_step_is_regular_through_the_ghk_singularity():
         # (only the guarded inputs move, so it is their partial slope that counts: allow 3x the total slope)
         bound = 3.0 * slope * 1.0e-4 + 1e-6 * scale
         assert np.abs(inc[k] - fit).max() <= bound, (g["state_names"][k], np.abs(inc[k] - fit).max(), bound)
+
+
+def test_torord_step_on_edge_case_states():
+    """40 000 states from edge values -- potentials at and next to 0 mV (the singular point of the GHK fluxes), far
+    hyper- and depolarised, gates at exactly 0 / 1 / 1e-300, concentrations scaled by 0.05 .. 10 -- for the three cell
+    types and three step sizes: every output is finite.  The one exception is the specification's own: it divides by
+    km2n = jca (ToRORd_dynCl_endo.ode, `anca_*`), so a jca gate of exactly 0 -- unreachable by its relaxation dynamics --
+    is not generated here."""
+    from beat.models import torord
+
+    g = np.load(GOLD / "torord_spec.npz")
+    names = list(g["state_names"])
+    rng = np.random.default_rng(7)
+    n = 40000
+    base = g["traj_states"]
+    S = base[:, rng.integers(0, base.shape[1], n)].copy()
+    vi = torord.state_index("v")
+    S[vi] = rng.choice([-120.0, -95.0, -88.0, -40.0, 0.0, 1e-13, -1e-13, 5e-5, 1e-3, 20.0, 60.0, 90.0], n) + rng.choice([0.0, 1e-9, 0.25], n)
+    scaled = ("nai", "nass", "ki", "kss", "cai", "cass", "cansr", "cajsr", "cli", "clss", "CaMKt", "Jrel_np", "Jrel_p")
+    for k, name in enumerate(names):
+        if name == "v":
+            continue
+        if name in scaled:
+            S[k] *= rng.choice([0.05, 0.5, 1.0, 2.0, 10.0], n)
+        else:
+            S[k] = rng.choice([1.0, 1e-300, 1e-9, 0.5, 1 - 1e-16] if name == "jca" else [0.0, 1.0, 1e-300, 1e-9, 0.5, 1 - 1e-16], n)
+    for celltype in (0, 1, 2):
+        P = torord.init_parameter_values(celltype=float(celltype))
+        for dt in (0.05, 0.01, 0.5):
+            out = torord.generalized_rush_larsen(states=S, t=0.0, parameters=P, dt=dt)
+            bad = ~np.isfinite(out).all(axis=0)
+            assert not bad.any(), (celltype, dt, int(bad.sum()), [names[r] for r in np.flatnonzero(~np.isfinite(out[:, np.flatnonzero(bad)[0]]))])
