@@ -703,3 +703,35 @@ def test_tp06_step_on_edge_case_states(hip_ctx):
         assert ok.mean() > 0.7 and not np.isfinite(ref).all()
         err = np.abs(out[:, ok] - ref[:, ok]) / np.maximum(np.abs(ref[:, ok]), 1e-3)
         assert err.max() < 1e-10, err.max()
+
+
+@pytest.mark.parametrize("per_node", [False, True])
+def test_pcg_degenerate_right_hand_sides(hip_ctx, per_node):
+    """Fields for which the initial residual vanishes (constant: K v = 0; zero; 1e-300) return at once with the input
+    unchanged, with and without the deferred last update; a field of size 1e150 converges without overflow."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    nn = (33, 17, 9)
+    M = np.diag([1e-3, 5e-4, 2e-4])
+    rng = np.random.default_rng(0)
+    if per_node:
+        cells = tuple(n - 1 for n in nn)
+        active = rng.random(int(np.prod(cells))) < 0.7
+        ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_fields(3, cells, (0.1,) * 3, M, active), per_node=True)
+    else:
+        ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_tables(3, (0.1,) * 3, M))
+    ops.set_timestep(0.01, 0.5, 0.05)
+    n = int(np.prod(nn))
+    fv, fx = ops.new_field(), ops.new_field()
+    for v in (np.full(n, -85.0), np.zeros(n), np.full(n, 1e-300)):
+        fv.set(v)
+        for defer in (False, True):
+            fx.set(np.full(n, 7.0))
+            res = ops.solve_single(fv, [], [], fx, 1e-8, 1e-50, 200, defer_flush=defer)
+            ops.flush_pending()
+            assert res.iterations == 0 and res.converged_reason > 0
+            np.testing.assert_array_equal(fx.numpy(), v)
+    fv.set(1e150 * rng.standard_normal(n))
+    res = ops.solve_single(fv, [], [], fx, 1e-8, 1e-50, 200)
+    assert res.converged_reason > 0 and 0 < res.iterations < 40 and np.isfinite(fx.numpy()).all()
