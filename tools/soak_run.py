@@ -41,6 +41,8 @@ t = 0.0
 prev = None
 for step in range(nsteps):
     check = step >= start_check and step % 100 == 0
+    if step % 1000 == 0 and not check:
+        print(step, "(not checked yet)", flush=True)  # heartbeat: a silent run looks hung to the job runner
     if check:
         ops.flush_pending()
         prev = [r.clone() for r in states.rows]
