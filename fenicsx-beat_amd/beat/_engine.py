@@ -355,7 +355,22 @@ class HipOps:
         pend = (C.c_int * 2)()
         _hip.check(self.lib.beat_pde_solve_ex(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
                                               C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, int(defer_flush),
-                                              C.byref(info), pend))
+                                              C.byref(info), pend), allow_not_converged=True)
+        if pend[1] > 0:
+            self.pending = (x, int(pend[0]), int(pend[1]))
+        return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+
+    def solve_dist(self, comm: "LibComm", v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush: bool = False) -> KspResult:
+        """The slab-decomposed solve as ONE C call (beat_pde_solve_dist): halo exchange and all-reduces are issued
+        by the library on ``comm``; same deferred-update contract as solve_single."""
+        self.flush_pending()
+        self.st_ptr_for_flush = None
+        ptrs, amps, k = self._stim_args(stim_w, stim_amp)
+        info = _hip.KspInfo()
+        pend = (C.c_int * 2)()
+        _hip.check(self.lib.beat_pde_solve_dist(self.handle, comm.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
+                                                C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, int(defer_flush),
+                                                C.byref(info), pend), allow_not_converged=True)
         if pend[1] > 0:
             self.pending = (x, int(pend[0]), int(pend[1]))
         return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
@@ -454,26 +469,159 @@ class _HostStagedDist:
         t.copy_(host)
 
 
+class LibComm:
+    """``beat_comm`` of this rank (include/beat_hip.h): the transport the in-library decomposed solve uses.
+
+    ``transport="rccl"``: RCCL communicators created by the library (ghost planes on its side stream, all-reduces
+    on the compute stream); rank 0's unique id reaches the other ranks through ``torch.distributed`` (any backend) --
+    that broadcast at set-up is all PyTorch contributes.  ``transport="callbacks"``: both operations are handed back
+    to Python and staged through the host over ``dist`` (gloo) -- the rehearsal transport for several ranks sharing
+    one GPU, where RCCL (one rank per device) cannot run.  ``peers``: override of (peer_lo, peer_hi), used by the
+    one-rank periodic self-exchange test."""
+
+    def __init__(self, ctx, slab: Slab, dist=None, group=None, transport: str = "rccl", peers=None):
+        self.ctx, self.slab, self.dist, self.group = ctx, slab, dist, group
+        lib = ctx.lib
+        rank, world = slab.rank, slab.world
+        peer_lo, peer_hi = peers if peers is not None else (-1 if slab.lo_phys else rank - 1, -1 if slab.hi_phys else rank + 1)
+        self.peer_lo, self.peer_hi = int(peer_lo), int(peer_hi)
+        handle = C.c_void_p()
+        self.transport = transport
+        if transport == "rccl":
+            ids = C.create_string_buffer(2 * _hip.UNIQUE_ID_BYTES)
+            if world > 1:
+                box = [None]
+                if rank == 0:
+                    _hip.check(lib.beat_comm_unique_id(ids))
+                    box[0] = ids.raw
+                src = 0 if group is None else dist.get_global_rank(group, 0)
+                dist.broadcast_object_list(box, src=src, group=group)
+                ids = C.create_string_buffer(box[0], 2 * _hip.UNIQUE_ID_BYTES)
+            else:
+                _hip.check(lib.beat_comm_unique_id(ids))
+            _hip.check(lib.beat_comm_create_rccl(ctx.handle, rank, world, self.peer_lo, self.peer_hi, ids, C.byref(handle)))
+        elif transport == "callbacks":
+            self._halo_cb = _hip.HALO_FN(self._halo)          # keep the thunks alive with the object
+            self._allreduce_cb = _hip.ALLREDUCE_FN(self._allreduce)
+            _hip.check(lib.beat_comm_create_callbacks(ctx.handle, rank, world, self.peer_lo, self.peer_hi, self._halo_cb,
+                                                      self._allreduce_cb, None, C.byref(handle)))
+        else:
+            raise ValueError(f"unknown transport {transport!r}")
+        self.handle = handle
+
+    # -- host-staged callbacks (rehearsal transport) ------------------------------------------------------------
+    def _d2h(self, ptr, count):
+        out = np.empty(int(count))
+        _hip.check(self.ctx.lib.beat_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), 8 * int(count)))
+        return out
+
+    def _h2d(self, ptr, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        _hip.check(self.ctx.lib.beat_memcpy_h2d(self.ctx.handle, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), 8 * arr.size))
+
+    def _global(self, group_rank: int) -> int:
+        return group_rank if self.group is None else self.dist.get_global_rank(self.group, group_rank)
+
+    def _halo(self, user, first, ghost_lo, last, ghost_hi, plane):
+        try:
+            import torch
+
+            d, ops, recvs = self.dist, [], []
+            for send_ptr, recv_ptr, peer in ((first, ghost_lo, self.peer_lo), (last, ghost_hi, self.peer_hi)):
+                if peer < 0:
+                    continue
+                out = torch.from_numpy(self._d2h(send_ptr, plane))
+                inn = torch.empty(int(plane), dtype=torch.float64)
+                ops.append(d.P2POp(d.isend, out, self._global(peer), self.group))
+                ops.append(d.P2POp(d.irecv, inn, self._global(peer), self.group))
+                recvs.append((recv_ptr, inn))
+            for req in (d.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            for recv_ptr, inn in recvs:
+                self._h2d(recv_ptr, inn.numpy())
+            return 0
+        except Exception:  # an exception must not unwind through the C frames
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    def _allreduce(self, user, values, count):
+        try:
+            import torch
+
+            t = torch.from_numpy(self._d2h(values, count))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._h2d(values, t.numpy())
+            return 0
+        except Exception:
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    # -- the two operations on their own ---------------------------------------------------------------------------
+    def exchange_halo(self, field) -> None:
+        _hip.check(self.ctx.lib.beat_comm_halo_exchange(self.handle, field.ptr, field.n, field.plane))
+
+    def allreduce_sum(self, tensor) -> None:
+        _hip.check(self.ctx.lib.beat_comm_allreduce_sum(self.handle, C.c_void_p(tensor.data_ptr()), int(tensor.numel())))
+
+    def close(self) -> None:
+        if self.handle:
+            self.ctx.lib.beat_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DiffusionSolver:
     """theta-rule diffusion step on one slab of a (possibly) decomposed grid."""
 
-    def __init__(self, ops, slab: Slab, group=None, force_distributed: bool = False):
+    def __init__(self, ops, slab: Slab, group=None, force_distributed: bool = False, stage_driven: bool | None = None,
+                 libcomm: "LibComm | None" = None):
+        """Decomposed grids (``slab.world > 1``, or ``force_distributed`` on one rank for tests): with the HIP
+        backend the whole solve is one library call over a :class:`LibComm` (RCCL when ``torch.distributed`` runs on
+        nccl, host-staged callbacks on any other backend -- the rehearsal transport).  ``stage_driven=True`` (env
+        ``BEAT_STAGE_DRIVEN=1``) keeps the iteration in Python, stage by stage over ``torch.distributed``: that is
+        the orchestration the CPU tests run with oracle-backed ``ops`` on gloo, and the only route for the
+        polynomial preconditioner."""
+        import os
+
         self.ops = ops
         self.slab = slab
         self.group = group
         self._last_its = 8
+        self.libcomm = libcomm
+        if stage_driven is None:
+            stage_driven = os.environ.get("BEAT_STAGE_DRIVEN", "0") == "1"
         if slab.world > 1 or force_distributed:  # force_distributed: run the collective path on 1 rank (tests)
             import torch.distributed as dist
 
             self.dist = dist
-            if dist.is_initialized() and dist.get_backend(group) != "nccl" and getattr(getattr(ops, "st", None), "is_cuda", False):
+            on_device = getattr(getattr(ops, "st", None), "is_cuda", False)
+            nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+            if dist.is_initialized() and not nccl and on_device:
                 self.dist = _HostStagedDist(dist)  # device fields on a host-only backend: rehearsal transport
+            if self.libcomm is None and on_device and not stage_driven and isinstance(ops, HipOps):
+                if nccl or slab.world == 1:
+                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "rccl")
+                else:
+                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "callbacks")
         else:
             self.dist = None
 
     # -- communication ------------------------------------------------------------------------
     def exchange_halo(self, field) -> None:
         """Send the first/last owned plane to the z-neighbours, receive into the ghost planes."""
+        if self.libcomm is not None:
+            if self.slab.world > 1:
+                self.libcomm.exchange_halo(field)
+            return
         self.finish_halo(self.start_halo(field))
 
     def finish_halo(self, reqs) -> None:
@@ -519,11 +667,13 @@ class DiffusionSolver:
         can_defer = defer_flush and hasattr(ops, "flush_pending")
         if hasattr(ops, "flush_pending"):
             ops.flush_pending()
-        if self.dist is None:
+        if self.dist is None and self.libcomm is None:
             if can_defer:
                 ops.st_ptr_for_flush = None
                 return ops.solve_single(v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush=True)
             return ops.solve_single(v_prev, stim_w, stim_amp, x, rtol, atol, max_it)
+        if self.libcomm is not None and ops.pc_num_passes == 0:
+            return ops.solve_dist(self.libcomm, v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush=bool(can_defer))
         self.exchange_halo(v_prev)
         ops.rhs(v_prev, stim_w, stim_amp, x)
         self._allreduce(ops.st[0:3])
@@ -574,9 +724,6 @@ class DiffusionSolver:
         its = int(st[_hip.ST_ITERS])
         self._last_its = max(its, 1)
         reason = int(st[_hip.ST_REASON]) if st[_hip.ST_STOP] != 0.0 else -3
-        res = KspResult(its, float(np.sqrt(st[_hip.ST_RR])), reason, float(np.sqrt(st[_hip.ST_BB])))
-        if reason < 0:
-            raise _hip.BeatHipError(
-                f"PCG did not converge in {its} iterations (||r|| = {res.residual_norm:.3e}, ||b|| = {res.rhs_norm:.3e})"
-            )
-        return res
+        # a solve that ran out of iterations is REPORTED (converged_reason < 0, as PETSc's KSP), not raised: the
+        # caller decides (BaseModel.step -> Status.NOT_CONVERGING / ksp_error_if_not_converged)
+        return KspResult(its, float(np.sqrt(st[_hip.ST_RR])), reason, float(np.sqrt(st[_hip.ST_BB])))

@@ -103,6 +103,25 @@ SIGNATURES = {
     "beat_field_minmax": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }
 
+# callbacks of a beat_comm whose transport is supplied by the caller (include/beat_hip.h)
+HALO_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _i64)
+ALLREDUCE_FN = C.CFUNCTYPE(_int, _vp, _vp, _int)
+UNIQUE_ID_BYTES = 128
+E_NOT_CONVERGED = -3
+
+SIGNATURES.update({
+    "beat_comm_unique_id": (_int, [_vp]),
+    "beat_comm_create_rccl": (_int, [_vp, _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
+    "beat_comm_create_callbacks": (_int, [_vp, _int, _int, _int, _int, HALO_FN, ALLREDUCE_FN, _vp, C.POINTER(_vp)]),
+    "beat_comm_destroy": (_int, [_vp]),
+    "beat_comm_halo_exchange": (_int, [_vp, _vp, _i64, _i64]),
+    "beat_comm_allreduce_sum": (_int, [_vp, _vp, _int]),
+    "beat_pde_solve_dist": (
+        _int,
+        [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, _int, C.POINTER(KspInfo), C.POINTER(_int)],
+    ),
+})
+
 _lib = None
 
 
@@ -129,7 +148,11 @@ def load():
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, allow_not_converged: bool = False) -> None:
+    """Raise on a failed call.  ``allow_not_converged``: a solve that hit max_it is reported through its
+    beat_ksp_info (converged_reason < 0), as PETSc's KSP does, not raised."""
+    if rc == E_NOT_CONVERGED and allow_not_converged:
+        return
     if rc != 0:
         msg = load().beat_last_error().decode(errors="replace")
         raise BeatHipError(f"libbeat_hip error {rc}: {msg}")

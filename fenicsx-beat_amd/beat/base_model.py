@@ -142,6 +142,7 @@ class BaseModel:
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
         self.ksp = None  # KSP-like record of the last solve
+        self.status = Status.OK  # NOT_CONVERGING once a linear solve has run out of iterations
 
     @abc.abstractmethod
     def _setup_state_space(self) -> None: ...
@@ -184,6 +185,20 @@ class BaseModel:
         max_it = int(opts.get("ksp_max_it", 10_000))
         return rtol, atol, max_it
 
+    def _check_converged(self) -> None:
+        """A solve that hit ksp_max_it is reported the way PETSc reports it -- ``ksp.getConvergedReason() < 0``, seen
+        by the monitor (telemetry.py:67-76) -- and makes ``solve()`` return ``Status.NOT_CONVERGING``
+        (base_model.py:23-30); it only raises with ``petsc_options["ksp_error_if_not_converged"]``."""
+        ksp = self.ksp
+        if ksp is None or ksp.converged_reason >= 0:
+            return
+        self.status = Status.NOT_CONVERGING
+        msg = (f"linear solve did not converge: reason {ksp.converged_reason} after {ksp.iterations} iterations, "
+               f"||r|| = {ksp.residual_norm:.3e}, ||b|| = {ksp.rhs_norm:.3e}")
+        if (self.parameters.get("petsc_options") or {}).get("ksp_error_if_not_converged"):
+            raise RuntimeError(msg)
+        logger.warning(msg)
+
     def _update_matrices(self):
         """A = C_m Mass + theta dt K, B = C_m Mass - (1 - theta) dt K for the current dt
         (base_model.py:188-194)."""
@@ -217,6 +232,7 @@ class BaseModel:
                 self._solve_linear(stim_w, stim_amp)
 
             self.monitor.record_ksp(self.ksp)
+            self._check_converged()
 
             with self.monitor.track_time("pde_scatter_forward"):
                 pass  # ghost planes are refreshed by the halo exchange inside the solve
@@ -236,6 +252,7 @@ class BaseModel:
             dt = T - T0
         t0 = T0
         t1 = T0 + dt
+        self.status = Status.OK
         while True:
             logger.info("Solving on t = (%g, %g)" % (t0, t1))
             self.step((t0, t1))
@@ -244,4 +261,4 @@ class BaseModel:
             self.assign_previous()
             t0 = t1
             t1 = t0 + dt
-        return Results(state=self.state, status=Status.OK)
+        return Results(state=self.state, status=self.status)

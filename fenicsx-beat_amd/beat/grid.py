@@ -96,6 +96,10 @@ class Comm:
         return t.cpu().numpy()
 
     def allreduce(self, value, op=None):
+        """mpi4py's ``comm.allreduce(value, op=MPI.SUM | MPI.MAX | MPI.MIN | MPI.PROD)`` for one scalar."""
+        key = "sum" if op is None else str(op).lower()
+        if key not in ("sum", "max", "min", "prod"):
+            raise ValueError(f"unsupported reduction {op!r}: use MPI.SUM, MPI.MAX, MPI.MIN or MPI.PROD")
         d = self._dist()
         if not d:
             return value
@@ -104,7 +108,8 @@ class Comm:
         t = torch.tensor([float(value)], dtype=torch.float64)
         if d.get_backend(self.group) == "nccl":
             t = t.cuda()
-        d.all_reduce(t, group=self.group)
+        rop = {"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN, "prod": d.ReduceOp.PRODUCT}[key]
+        d.all_reduce(t, op=rop, group=self.group)
         return float(t.item())
 
 

@@ -33,10 +33,15 @@ def _mesh_meta(mesh: grid.Mesh) -> dict:
 
 
 def write_mesh(filename, mesh: grid.Mesh, **kw) -> None:
+    """Starts a NEW checkpoint (io4dolfinx.write_mesh opens its file in write mode): whatever an earlier run left
+    under ``filename`` -- time stamps, function slabs -- is removed, so that ``read_timestamps`` / ``read_function``
+    never mix two runs.  ``write_function`` then appends to it."""
     if mesh.comm.rank == 0:
-        Path(filename).mkdir(parents=True, exist_ok=True)
-        meta = _load_meta(filename)
-        meta["mesh"] = _mesh_meta(mesh)
+        root = Path(filename)
+        root.mkdir(parents=True, exist_ok=True)
+        for old in root.glob("*_r*.npy"):
+            old.unlink()
+        meta = {"mesh": _mesh_meta(mesh), "functions": {}}
         _meta_path(filename).write_text(json.dumps(meta))
     mesh.comm.Barrier()
 
@@ -85,9 +90,10 @@ def read_function(filename, u: grid.Function, time: float = 0.0, name: str | Non
     if meta["mesh"] is not None and list(meta["mesh"]["shape_global"]) != list(mesh.shape_global):
         raise ValueError(f"checkpoint grid {meta['mesh']['shape_global']} does not match the mesh {mesh.shape_global}")
     times = np.asarray(entry["times"])
-    k = int(np.argmin(np.abs(times - time)))
-    if not np.isclose(times[k], time, rtol=0, atol=1e-9):
+    hits = np.nonzero(np.isclose(times, time, rtol=0, atol=1e-9))[0]
+    if len(hits) == 0:
         raise KeyError(f"no time stamp {time} for {name!r} in {filename} (have {times.tolist()})")
+    k = int(hits[-1])  # a time stamp written twice: the later write wins
     plane = mesh.plane
     z0, z1 = mesh.slab.z0, mesh.slab.z1
     out = np.empty((z1 - z0) * plane)

@@ -132,10 +132,63 @@ class DeviceModel:
         return (out[:, 0].copy() if one_d else out), tr
 
 
+class DeviceParameters:
+    """Per-node parameters ``(P, N)`` (demos/pace_train.py:133-167) kept resident in HBM.
+
+    A plain NumPy ``(P, N)`` array handed to an ODE solver is compared with the copy that was uploaded before every
+    step (the reference passes the live array to ``fun`` each step, so in-place edits must be seen: exact, but one
+    O(P N) host pass per step).  This handle removes that pass: the values live on the device, ``set`` / ``set_row``
+    replace them and bump ``version``; nothing is checked or moved per step."""
+
+    ndim = 2
+
+    def __init__(self, values, ctx=None):
+        from .._device import Context
+
+        self.ctx = ctx or Context.default()
+        self.version = 0
+        self._dev = None
+        self.set(values)
+
+    @property
+    def shape(self):
+        return tuple(self._dev.shape)
+
+    def __len__(self) -> int:
+        return int(self._dev.shape[0])
+
+    @property
+    def tensor(self):
+        return self._dev
+
+    def set(self, values) -> None:
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim != 2:
+            raise ValueError(f"per-node parameters must be (P, N), got shape {v.shape}")
+        if self._dev is not None and tuple(self._dev.shape) == v.shape:
+            self._dev.copy_(self.ctx.torch.from_numpy(v))
+        else:
+            self._dev = self.ctx.from_numpy(v).reshape(v.shape)
+        self.version += 1
+
+    def set_row(self, k: int, values) -> None:
+        """One parameter at every node (a scalar is broadcast)."""
+        row = np.broadcast_to(np.asarray(values, dtype=np.float64), (self._dev.shape[1],))
+        self._dev[int(k)].copy_(self.ctx.torch.from_numpy(np.ascontiguousarray(row)))
+        self.version += 1
+
+    def numpy(self) -> np.ndarray:
+        return self._dev.cpu().numpy()
+
+
 def host_and_device_parameters(ctx, parameters, num_parameters, n):
     """Split ``parameters`` into (host (P,) array | None, device (P, N) tensor | None, ld)."""
     if parameters is None:
         return None, None, 0
+    if isinstance(parameters, DeviceParameters):
+        if parameters.shape != (num_parameters, n):
+            raise ValueError(f"per-node parameters must have shape ({num_parameters}, {n}), got {parameters.shape}")
+        return None, parameters.tensor, n
     p = np.asarray(parameters, dtype=np.float64)
     if p.ndim == 1:
         if p.shape[0] != num_parameters:

@@ -60,4 +60,5 @@ class MonodomainModel(BaseModel):
         rtol, atol, max_it = self._solver_tolerances()
         self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it,
                                          defer_flush=defer_flush)
+        self._check_converged()
         return self.ksp

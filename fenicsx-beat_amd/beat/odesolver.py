@@ -17,7 +17,7 @@ from typing import Any, Callable, NamedTuple
 import numpy as np
 
 from . import _hip, grid
-from .models._base import DeviceModel, host_and_device_parameters
+from .models._base import DeviceModel, DeviceParameters, host_and_device_parameters
 from .telemetry import BaseMonitor, NullMonitor
 from .utils import local_project
 
@@ -103,7 +103,7 @@ class _DeviceODE:
         self.parameters = parameters
         self.monitor = monitor
         self._ppn = None
-        self._ppn_src = None
+        self._ppn_host = None  # what the device copy was uploaded from
 
     def set_initial(self, values) -> None:
         if values.ndim == 1:
@@ -116,16 +116,20 @@ class _DeviceODE:
         p = self.parameters
         if p is None:
             return None, 0, None, 0
+        if isinstance(p, DeviceParameters):  # resident handle: nothing to check or move per step
+            _, dev, ld = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
+            return None, p.shape[0], C.c_void_p(dev.data_ptr()), ld
         p = np.asarray(p, dtype=np.float64)
         if p.ndim == 1:
             hp = np.ascontiguousarray(p)
             self._keep = hp
             return hp.ctypes.data_as(C.c_void_p), len(hp), None, 0
-        # per-node parameters: re-upload when the caller's array changed (cheap checksum)
-        chk = (p.shape, float(p.sum()), float(np.abs(p).sum()))
-        if self._ppn is None or self._ppn_src != chk:
+        # per-node NumPy parameters: the reference hands the live array to ``fun`` every step (odesolver.py:70-76),
+        # so any in-place edit must reach the kernel.  Exact comparison with the copy that was uploaded (one host
+        # pass over (P, N) per step; pass a DeviceParameters handle to avoid it on large grids).
+        if self._ppn is None or self._ppn_host.shape != p.shape or not np.array_equal(self._ppn_host, p):
             _, self._ppn, _ = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
-            self._ppn_src = chk
+            self._ppn_host = p.copy()
         return None, p.shape[0], C.c_void_p(self._ppn.data_ptr()), self.n
 
     def step(self, t0, dt, v_index=0, v_copy=None, pending_ops=None, v_row=None):

@@ -2,6 +2,7 @@
 #include "beat_common.h"
 
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -214,12 +215,15 @@ __global__ __launch_bounds__(BEAT_BLOCK) void minmax_partial_kernel(const double
                                                                     double* __restrict__ part) {
   __shared__ double smin[4], smax[4];
   double lo = DBL_MAX, hi = -DBL_MAX;
+  int bad = 0;  // fmin / fmax drop NaNs (minNum semantics): track them separately, numpy.min/max propagate them
   const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
     const double v = x[i];
+    bad |= (v != v);
     lo = fmin(lo, v);
     hi = fmax(hi, v);
   }
+  bad = __syncthreads_or(bad);
   lo = beat_wave_min(lo);
   hi = beat_wave_max(hi);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -229,8 +233,9 @@ __global__ __launch_bounds__(BEAT_BLOCK) void minmax_partial_kernel(const double
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
-    part[2 * blockIdx.x + 1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    part[2 * blockIdx.x] = bad ? qnan : fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    part[2 * blockIdx.x + 1] = bad ? qnan : fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
   }
 }
 
@@ -294,11 +299,13 @@ extern "C" int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t
                                 hipMemcpyDeviceToHost, ctx->stream));
   BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   double lo = DBL_MAX, hi = -DBL_MAX;
+  bool bad = false;  // a NaN anywhere in the field makes both extrema NaN (as numpy.min / numpy.max)
   for (unsigned b = 0; b < grid; ++b) {
+    bad = bad || h[2 * b] != h[2 * b] || h[2 * b + 1] != h[2 * b + 1];
     lo = h[2 * b] < lo ? h[2 * b] : lo;
     hi = h[2 * b + 1] > hi ? h[2 * b + 1] : hi;
   }
-  *host_min = lo;
-  *host_max = hi;
+  *host_min = bad ? std::nan("") : lo;
+  *host_max = bad ? std::nan("") : hi;
   return BEAT_OK;
 }

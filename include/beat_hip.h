@@ -278,6 +278,51 @@ int beat_pde_solve(beat_pde* pde, const double* dev_v_prev, const double* const*
                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work,
                    double rtol, double atol, int max_it, beat_ksp_info* info);
 
+/* ---- slab-decomposed diffusion solve: one C call per solve, communication inside the library -------------
+ * Replaces, on a grid cut into z-slabs (one rank per GPU), what PETSc does inside KSP.solve on a partitioned
+ * mesh: the neighbour exchange of ghost values (b.ghostUpdate / VecScatter, src/beat/base_model.py:203-206,242)
+ * and the all-reduces of the dot products (KSP.solve, base_model.py:236).
+ *
+ * A beat_comm is the transport of one rank:
+ *  - RCCL (the product; RCCL = the NCCL API over xGMI): two communicators, one for the ghost-plane
+ *    send/recv pairs -- issued on a library-owned, non-blocking side HIP stream and ordered against the compute
+ *    stream with events, so that they overlap with the stencil on the interior planes -- and one for the
+ *    all-reduces, which sit on the critical path and are issued on the context's compute stream.  librccl is
+ *    opened with dlopen when the first communicator is created (the library itself has no link-time dependency
+ *    on it).  The caller distributes the 128-byte unique id of rank 0 (beat_comm_unique_id) to all ranks by
+ *    whatever means it has (torch.distributed, MPI, a file).
+ *  - callbacks (tests / rehearsal on hardware where RCCL cannot run, e.g. several ranks sharing one GPU): the
+ *    two operations are delegated to the caller; they must be complete (stream-ordered on the context's stream)
+ *    when the callback returns.
+ * peer_lo / peer_hi: rank owning the slab below / above this one, -1 on a physical boundary. */
+typedef struct beat_comm beat_comm;
+#define BEAT_UNIQUE_ID_BYTES 128
+int beat_comm_unique_id(void* host_id_out /* 2 * BEAT_UNIQUE_ID_BYTES: ids of the two communicators */);
+int beat_comm_create_rccl(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, const void* host_id,
+                          beat_comm** out);
+/* Exchange the slab-boundary planes of one field: the first interior plane goes to peer_lo and the plane
+ * received from it lands in the ghost plane below the field; likewise the last plane / upper ghost plane with
+ * peer_hi.  dev_* point at the four planes (each plane_doubles long); a side without a peer passes NULL. */
+typedef int (*beat_halo_fn)(void* user, const double* dev_first, double* dev_ghost_lo, const double* dev_last,
+                            double* dev_ghost_hi, int64_t plane_doubles);
+typedef int (*beat_allreduce_fn)(void* user, double* dev_values, int count); /* in-place sum over the ranks */
+int beat_comm_create_callbacks(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, beat_halo_fn halo,
+                               beat_allreduce_fn allreduce, void* user, beat_comm** out);
+int beat_comm_destroy(beat_comm* comm);
+/* The two operations on their own (set-up code, tests): complete in stream order on the context's stream. */
+int beat_comm_halo_exchange(beat_comm* comm, double* dev_field, int64_t n, int64_t plane_doubles);
+int beat_comm_allreduce_sum(beat_comm* comm, double* dev_values, int count);
+/* beat_pde_solve_ex on a decomposed grid: same arguments, results and deferred-flush contract; every rank calls
+ * it with its own slab handle (z_lo_phys / z_hi_phys = whether peer_lo / peer_hi is absent).  Per iteration: ghost
+ * planes of p travel on the side stream while q = A p is computed on the planes that need none, then the one or
+ * two boundary planes; all-reduce of p.q; r -= alpha q; all-reduce of (r.z, r.r); p = z + beta p.  The host
+ * enqueues as many iterations as the previous solve needed and reads the device-side convergence latch once
+ * (iterations and the latch are identical on all ranks because they derive from all-reduced values only). */
+int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev,
+                        const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                        double* dev_x, double* dev_work, double rtol, double atol, int max_it, int defer_flush,
+                        beat_ksp_info* info, int* host_pending);
+
 /* P1 point evaluation: out[k] = sum_j w[k,j] * field[idx[k,j]], j < 4
  * (scifem.evaluate_function stand-in, demos/niederer_benchmark.py:285).  Synchronises. */
 int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
@@ -285,7 +330,8 @@ int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host
 /* sum_i x_i y_i on the local slab: lead integrals of the ECG recovery, ecg.py:295-298 (assemble_scalar of
  * (1/(4 pi sigma_b)) Im / |x - p| dx = weights . Im with precomputed nodal weights).  Synchronises. */
 int beat_field_dot(beat_ctx* ctx, const double* dev_x, const double* dev_y, int64_t n, double* host_out);
-/* min / max of a field (demos read v.max(), v.min() every step; avoids a full D2H).  Synchronises. */
+/* min / max of a field (demos read v.max(), v.min() every step; avoids a full D2H); NaN-propagating as
+ * numpy.min / numpy.max: a NaN anywhere makes both results NaN.  Synchronises. */
 int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t n, double* host_min, double* host_max);
 
 #ifdef __cplusplus

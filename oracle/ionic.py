@@ -413,3 +413,12 @@ MODELS = {
     "fhn_readme": (fhn_readme_forward_euler, 2),
     "tp06_grl1": (tp06_generalized_rush_larsen, 19),
 }
+
+
+def _register_torord():
+    from . import torord  # hand restatement of the 45-state ToR-ORd-dynCl model (own module: it is long)
+
+    MODELS["torord_dyncl_grl1"] = (torord.torord_generalized_rush_larsen, 45)
+
+
+_register_torord()

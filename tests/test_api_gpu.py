@@ -779,3 +779,115 @@ def test_fused_route_equals_literal_route_over_options(dim, theta_split, theta_p
     assert va.max() > 0.0 and np.isfinite(va).all()
     np.testing.assert_allclose(va, vb, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(a.ode.values, b.ode.values, rtol=1e-12, atol=1e-14)
+
+
+# ---- per-node parameters: in-place edits by the caller must reach the kernel (demos/pace_train.py:133-167) -------
+def test_per_node_parameter_edits_are_seen_and_device_handle():
+    """The reference hands the live ``parameters`` array to ``fun`` every step.  A (P, N) NumPy array edited in place
+    between steps -- here a pacing patch MOVED to another site of equal size, which keeps the array's sum and absolute
+    sum -- must be picked up; a resident ``DeviceParameters`` handle gives the same values with nothing checked or
+    moved per step, and changes through ``set_row``."""
+    from beat import grid as g
+    from beat.models import tp06
+    from beat.odesolver import DeviceParameters, DolfinODESolver
+    from oracle import ionic
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 9, 9)
+    V = g.functionspace(mesh, ("P", 1))
+    n = 100
+    ic = tp06.init_state_values()
+    ia = tp06.parameter_index("stim_amplitude")
+    base = tp06.init_parameter_values(stim_start=0.0, stim_duration=5.0, stim_amplitude=0.0)
+    P = np.repeat(base[:, None], n, axis=1)
+    P[ia, :10] = -52.0
+    dt = 0.05
+
+    def solver(params):
+        return DolfinODESolver(v_ode=g.Function(V), v_pde=g.Function(V), fun=tp06.generalized_rush_larsen, init_states=ic,
+                               parameters=params, num_states=len(ic), v_index=tp06.state_index("V"))
+
+    ode = solver(P)
+    ref = np.repeat(ionic.tp06_init_state_values()[:, None], n, axis=1)
+    Pr = P.copy()
+    for i in range(4):
+        if i == 2:  # move the patch: same sum, same absolute sum, different nodes
+            P[ia, :10] = 0.0
+            P[ia, 50:60] = -52.0
+            Pr = P.copy()
+        ode.step(i * dt, dt)
+        ref = ionic.tp06_generalized_rush_larsen(ref, i * dt, dt, Pr)
+    out = ode.values
+    err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-10, err.max()
+    vi = tp06.state_index("V")
+    assert out[vi, 55] > out[vi, 80] + 1.0 and out[vi, 5] > out[vi, 80] + 1.0  # both sites were paced, in turn
+
+    P0 = np.repeat(base[:, None], n, axis=1)
+    P0[ia, :10] = -52.0
+    handle = DeviceParameters(P0)
+    assert handle.shape == (53, n) and len(handle) == 53 and handle.version == 1
+    ode2 = solver(handle)
+    for i in range(4):
+        if i == 2:
+            row = np.zeros(n)
+            row[50:60] = -52.0
+            handle.set_row(ia, row)
+            assert handle.version == 2
+        ode2.step(i * dt, dt)
+    np.testing.assert_array_equal(ode2.values, out)
+    np.testing.assert_array_equal(handle.numpy(), P)
+
+
+def test_field_extrema_propagate_nan():
+    """``v.min()`` / ``v.max()`` of a device function (beat_field_minmax) behave as numpy's on a blown-up state: one
+    NaN node, or an all-NaN field, gives NaN for both; infinities are ordinary values."""
+    from beat._device import Context
+
+    ctx = Context.default()
+    n = 70_001
+    f = ctx.field(n, 0)
+    vals = np.linspace(-3.0, 5.0, n)
+    f.set(vals)
+    assert f.minmax() == (-3.0, 5.0)
+    for bad in (0, 12_345, n - 1):
+        v = vals.copy()
+        v[bad] = np.nan
+        f.set(v)
+        lo, hi = f.minmax()
+        assert np.isnan(lo) and np.isnan(hi), (bad, lo, hi)
+    f.set(np.full(n, np.nan))
+    lo, hi = f.minmax()
+    assert np.isnan(lo) and np.isnan(hi)
+    v = vals.copy()
+    v[7] = np.inf
+    v[9] = -np.inf
+    f.set(v)
+    assert f.minmax() == (-np.inf, np.inf)
+
+
+def test_pde_solve_reports_non_convergence_as_status():
+    """base_model.py:23-30: ``solve`` returns Results(state, status); a linear solve that runs out of iterations gives
+    Status.NOT_CONVERGING and a negative ``getConvergedReason()`` seen by the monitor (telemetry.py:67-76) instead of
+    an exception; ``ksp_error_if_not_converged`` raises, as PETSc's option of that name."""
+    import beat
+    from beat import grid as g
+    from beat.base_model import Status
+    from beat.telemetry import PerformanceMonitor
+
+    mesh = g.create_unit_square(g.COMM_WORLD, 24, 24)
+    time = g.Constant(mesh, 0.0)
+    x = g.SpatialCoordinate(mesh)
+    stim = g.cos(2 * g.pi * x[0]) * g.cos(3 * g.pi * x[1])
+    mon = PerformanceMonitor()
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=stim, monitor=mon,
+                               params={"petsc_options": {"ksp_rtol": 1e-14, "ksp_max_it": 2}})
+    res = pde.solve((0.0, 0.3), dt=0.1)
+    assert res.status == Status.NOT_CONVERGING and pde.ksp.getConvergedReason() < 0
+    assert mon.ksp_last_converged_reason < 0 and mon.ksp_last_iterations == 2
+    assert np.isfinite(np.asarray(res.state.x.array)).all()
+    ok = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=stim, params={"petsc_options": {"ksp_rtol": 1e-10}})
+    assert ok.solve((0.0, 0.3), dt=0.1).status == Status.OK
+    strict = beat.MonodomainModel(time=time, mesh=mesh, M=1.0, I_s=stim,
+                                  params={"petsc_options": {"ksp_rtol": 1e-14, "ksp_max_it": 2, "ksp_error_if_not_converged": True}})
+    with pytest.raises(RuntimeError, match="did not converge"):
+        strict.step((0.0, 0.1))

@@ -1,6 +1,8 @@
-"""GPU: the collective code path of beat._engine.DiffusionSolver (stage kernels driven from Python,
-RCCL all-reduces on slices of the device-side solver state, split SpMV) on a ONE-rank NCCL group --
-what can be exercised of the N > 1 path on a single-GPU box -- against the fused single-slab solve."""
+"""GPU: the slab-decomposed diffusion solve -- the in-library loop (beat_pde_solve_dist: RCCL ghost-plane exchange on
+the library's side stream, RCCL all-reduces, split SpMV; one C call per solve) and the stage-driven Python loop it
+replaced on the product path -- as far as a single-GPU box allows: one-rank RCCL communicators (also with the rank as
+its own z-neighbour, so that the library's ncclSend/ncclRecv pairs really run), several ranks played by threads or by
+processes sharing the GPU over host-staged callbacks, against the fused single-slab solve."""
 
 import socket
 
@@ -42,17 +44,22 @@ def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node
         rng = np.random.default_rng(3)
         v = -85.0 + 30.0 * rng.random(nx * ny * nz)
         results = []
-        for force in (False, True):
+        for mode in ("fused", "stage", "lib"):  # "lib" last: the deferred-update checks below run through it
             ops = HipOps(ctx, (nx, ny, nz), True, True, mt, kt, per_node=per_node)
             ops.set_timestep(0.01, 0.5, 0.05)
-            solver = DiffusionSolver(ops, Slab(nz), force_distributed=force)
+            solver = DiffusionSolver(ops, Slab(nz), force_distributed=mode != "fused", stage_driven=mode == "stage")
+            assert (solver.libcomm is not None) == (mode == "lib")
             fv, fx = ops.new_field(), ops.new_field()
             fv.set(v)
             res = solver.solve(fv, [], [], fx, rtol=1e-11, atol=1e-50, max_it=200)
             results.append((fx.numpy(), res))
-        (x1, r1), (x2, r2) = results
+        (x1, r1), (xs, rs), (x2, r2) = results
         assert r2.converged_reason > 0 and abs(r1.iterations - r2.iterations) <= 1
         np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-9 * np.abs(x1).max())
+        # one rank: the library loop, the Python stage loop and the fused solve run the same kernels in the same order
+        np.testing.assert_array_equal(xs, x2)
+        np.testing.assert_array_equal(x1, x2)
+        assert rs.iterations == r2.iterations == r1.iterations
         # deferred last update through the collective path: pending until flushed, then the same bits
         fx3 = ops.new_field()
         res3 = solver.solve(fv, [], [], fx3, rtol=1e-11, atol=1e-50, max_it=200, defer_flush=True)
@@ -109,6 +116,9 @@ class _ThreadRank:
     def P2POp(self, fn, tensor, peer, group=None):
         return (fn, tensor, peer)
 
+    def get_global_rank(self, group, rank):
+        return rank
+
     def batch_isend_irecv(self, ops):
         reqs = []
         for fn, tensor, peer in ops:
@@ -127,11 +137,27 @@ class _ThreadRecv:
         self.tensor.copy_(self.box.get(timeout=120))
 
 
+def _thread_solver(ops, slab, dist_view, loop):
+    """DiffusionSolver of one thread-rank: ``loop="lib"`` runs beat_pde_solve_dist over a callback communicator whose
+    transport is the thread world; ``loop="stage"`` the Python stage loop over the same world."""
+    from beat._engine import DiffusionSolver, LibComm
+
+    if dist_view is None:
+        return DiffusionSolver(ops, slab)
+    if loop == "lib":
+        return DiffusionSolver(ops, slab, force_distributed=True, libcomm=LibComm(ops.ctx, slab, dist_view, None, "callbacks"))
+    solver = DiffusionSolver(ops, slab, force_distributed=True, stage_driven=True)
+    solver.dist = dist_view
+    return solver
+
+
+@pytest.mark.parametrize("loop", ["lib", "stage"])
 @pytest.mark.parametrize("per_node,world,nz", [(False, 2, 19), (False, 3, 19), (True, 3, 19), (False, 4, 5), (True, 4, 6),
                                                (False, 5, 5)])
-def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz):
+def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, loop):
     """world ranks as threads, each with its own context, slab operators and DiffusionSolver: the assembled solution
-    equals the undivided solve, iteration counts agree, and the deferred last update flushes to the same values."""
+    equals the undivided solve, iteration counts agree, and the deferred last update flushes to the same values --
+    through the in-library loop (callback transport) and through the stage-driven Python loop."""
     import threading
 
     from beat import _stencil
@@ -165,9 +191,7 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz):
     def solve(ctx, slab, dist_view, out, key):
         ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *operators((slab.z0, slab.z1)), per_node=per_node)
         ops.set_timestep(0.01, 0.5, 0.05)
-        solver = DiffusionSolver(ops, slab, force_distributed=dist_view is not None)
-        if dist_view is not None:
-            solver.dist = dist_view
+        solver = _thread_solver(ops, slab, dist_view, loop)
         fv, fx, fw, fx2 = ops.new_field(), ops.new_field(), ops.new_field(), ops.new_field()
         sl = slice(slab.z0 * plane, slab.z1 * plane)
         fv.set(v[sl])
@@ -206,7 +230,8 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz):
     np.testing.assert_array_equal(x_defer, x_parts)
 
 
-def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx):
+@pytest.mark.parametrize("loop", ["lib", "stage"])
+def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop):
     """bench.py's N > 1 step (TP06 ionic kernel applying the previous solve's pending directions on the slab's V row,
     then the slab-decomposed diffusion solve with the deferred last update) on 3 ranks played by threads: after 25 steps
     the assembled state array equals the one-rank run to 1e-9 (the reductions are summed in a different order)."""
@@ -235,9 +260,7 @@ def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx):
         n_local = plane * slab.nz
         ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *tabs)
         ops.set_timestep(0.01, 0.5, 0.05)
-        solver = DiffusionSolver(ops, slab, force_distributed=dist_view is not None)
-        if dist_view is not None:
-            solver.dist = dist_view
+        solver = _thread_solver(ops, slab, dist_view, loop)
         states = StateArray(ctx, len(ic), n_local, plane)
         states.set(S0[:, slab.z0 * plane : slab.z1 * plane])
         v_field = states.row_field(vi)
@@ -412,7 +435,7 @@ def test_rccl_ghost_plane_exchange_on_field_slices(hip_ctx):
                 return 0
 
         ops = HipOps(ctx, (nx, ny, nz), False, False, *_stencil.stencil_tables(3, (0.1, 0.1, 0.1), np.eye(3) * 1e-3))
-        solver = SelfPeer(ops, Interior())
+        solver = SelfPeer(ops, Interior(), stage_driven=True)
         rng = np.random.default_rng(4)
         states = StateArray(ctx, 3, plane * nz, plane)
         for field in (ops.new_field(), states.row_field(1)):
@@ -429,3 +452,130 @@ def test_rccl_ghost_plane_exchange_on_field_slices(hip_ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+class _PeriodicSelf:
+    """torch.distributed look-alike of ONE rank that is its own lower and upper z-neighbour (a periodic stack of one
+    slab): what the library's one-rank RCCL communicator with peers (0, 0) does, with plain device copies."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    isend, irecv = "isend", "irecv"
+
+    def all_reduce(self, t, op=None, group=None):
+        pass  # one rank: the sum is the value
+
+    def P2POp(self, fn, tensor, peer, group=None):
+        return (fn, tensor)
+
+    def batch_isend_irecv(self, ops):
+        # DiffusionSolver.start_halo posts [send first, recv ghost_lo, send last, recv ghost_hi]
+        (_, first), (_, ghost_lo), (_, last), (_, ghost_hi) = ops
+        ghost_hi.copy_(first)
+        ghost_lo.copy_(last)
+        return []
+
+
+@pytest.mark.parametrize("per_node", [False, True])
+def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_node):
+    """The in-library solve with REAL RCCL point-to-point traffic on its side stream: a one-rank communicator whose
+    lower and upper peers are the rank itself (the only multi-message topology a one-GPU box can host) makes the slab
+    periodic in z -- ghost planes live on both faces, ncclSend/ncclRecv pairs in a group per SpMV, events between the
+    side and the compute stream, boundary planes computed after the receive.  The stage-driven Python loop with the
+    same periodic exchange done by device copies must give the same bits; the exchange on its own is checked too
+    (plain field and a padded state-array row)."""
+    from beat import _stencil
+    from beat._device import StateArray
+    from beat._engine import DiffusionSolver, HipOps, LibComm
+
+    ctx = hip_ctx
+    nx, ny, nz = 37, 21, 9
+    plane = nx * ny
+    M = np.diag([9.5e-4, 1.25e-4, 4.0e-4])
+    if per_node:  # rows of the middle third of a three times taller grid: interior-type rows on both slab faces
+        mt, kt = _stencil.stencil_fields(3, (nx - 1, ny - 1, 3 * nz - 1), (0.1, 0.1, 0.1), M, None, z_range=(nz, 2 * nz))
+    else:
+        mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
+
+    class Interior:  # a slab with live neighbours on both sides
+        rank, world, nz, lo_phys, hi_phys, z0, z1 = 0, 1, 9, False, False, 0, 9
+
+    rng = np.random.default_rng(11)
+    v = -85.0 + 30.0 * rng.random(plane * nz)
+    w = rng.random(plane * nz) * 1e-3
+    comm = LibComm(ctx, Interior(), transport="rccl", peers=(0, 0))
+    try:
+        # the exchange on its own
+        states = StateArray(ctx, 3, plane * nz, plane)
+        for field in (ctx.field(plane * nz, plane), states.row_field(1)):
+            vals = rng.standard_normal(plane * nz)
+            field.set(vals)
+            field.ghost_lo.fill_(float("nan"))
+            field.ghost_hi.fill_(float("nan"))
+            comm.exchange_halo(field)
+            ctx.synchronize()
+            np.testing.assert_array_equal(field.ghost_lo.cpu().numpy(), vals[-plane:])
+            np.testing.assert_array_equal(field.ghost_hi.cpu().numpy(), vals[:plane])
+            np.testing.assert_array_equal(field.numpy(), vals)
+        out = {}
+        for mode in ("stage", "lib"):
+            ops = HipOps(ctx, (nx, ny, nz), False, False, mt, kt, per_node=per_node)
+            ops.set_timestep(0.01, 0.5, 0.05)
+            if mode == "lib":
+                solver = DiffusionSolver(ops, Interior(), force_distributed=True, libcomm=comm)
+            else:
+                solver = DiffusionSolver(ops, Interior(), force_distributed=True, stage_driven=True)
+                solver.dist = _PeriodicSelf()
+                solver.slab = type("S", (), dict(rank=0, world=2, lo_phys=False, hi_phys=False))()  # start_halo posts both sides
+            fv, fw, fx = ops.new_field(), ops.new_field(), ops.new_field()
+            fv.set(v)
+            fw.set(w)
+            res = solver.solve(fv, [fw], [0.7], fx, rtol=1e-11, atol=1e-50, max_it=200)
+            fx2 = ops.new_field()
+            res2 = solver.solve(fv, [fw], [0.7], fx2, rtol=1e-11, atol=1e-50, max_it=200, defer_flush=True)
+            ops.flush_pending()
+            ctx.synchronize()
+            out[mode] = (fx.numpy().copy(), res, fx2.numpy().copy(), res2)
+        (xs, rs, xs2, _), (xl, rl, xl2, rl2) = out["stage"], out["lib"]
+        assert rl.converged_reason > 0 and 3 < rl.iterations < 60 and rl.iterations == rs.iterations == rl2.iterations
+        np.testing.assert_array_equal(xl, xs)
+        np.testing.assert_array_equal(xl2, xl)
+        np.testing.assert_array_equal(xs2, xs)
+        # the periodic operator really couples the two faces: the solution differs from the Neumann-faced one
+        ops_n = HipOps(ctx, (nx, ny, nz), True, True, mt, kt, per_node=per_node)
+        ops_n.set_timestep(0.01, 0.5, 0.05)
+        fv, fw, fx = ops_n.new_field(), ops_n.new_field(), ops_n.new_field()
+        fv.set(v)
+        fw.set(w)
+        DiffusionSolver(ops_n, type("S", (), dict(rank=0, world=1, lo_phys=True, hi_phys=True, nz=nz))()).solve(
+            fv, [fw], [0.7], fx, rtol=1e-11, atol=1e-50, max_it=200)
+        assert np.abs(fx.numpy() - xl).max() > 1e-3
+    finally:
+        comm.close()
+
+
+def test_non_convergence_is_reported_not_raised(hip_ctx):
+    """A solve that runs out of iterations returns converged_reason = -3 (KSP_DIVERGED_ITS) with the last iterate in x
+    -- fused solve and in-library decomposed solve -- instead of raising (src/beat/base_model.py:23-30,
+    telemetry.py:67-76 read the reason from the KSP)."""
+    from beat import _stencil
+    from beat._engine import DiffusionSolver, HipOps, Slab
+
+    ctx = hip_ctx
+    nx, ny, nz = 24, 20, 12
+    mt, kt = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), np.eye(3) * 1e-3)
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal(nx * ny * nz)
+    for force in (False, True):
+        ops = HipOps(ctx, (nx, ny, nz), True, True, mt, kt)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        solver = DiffusionSolver(ops, Slab(nz), force_distributed=force)
+        fv, fx = ops.new_field(), ops.new_field()
+        fv.set(v)
+        res = solver.solve(fv, [], [], fx, rtol=1e-14, atol=1e-50, max_it=2)
+        assert res.converged_reason == -3 and res.iterations == 2 and res.residual_norm > 0.0
+        x2 = fx.numpy().copy()
+        assert np.isfinite(x2).all() and not np.array_equal(x2, v)
+        res = solver.solve(fv, [], [], fx, rtol=1e-11, atol=1e-50, max_it=200)
+        assert res.converged_reason > 0

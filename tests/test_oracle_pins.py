@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from oracle import fem, ionic, splitting
+from oracle import fem, ionic, splitting, torord
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -51,6 +51,68 @@ def test_tp06_single_cell_action_potential_is_physiological():
     assert 10.0 < up < 12.5  # fires right after the model's own stimulus (t = 10 ms)
     apd90 = (np.nonzero(vs > vs.min() + 0.1 * (vs.max() - vs.min()))[0][-1]) * dt - up
     assert 250.0 < apd90 < 330.0
+
+
+# ---- ToR-ORd-dynCl: the hand restatement (oracle/torord.py) against the reference's .ode specification ----------
+def test_torord_hand_restatement_matches_the_ode_spec():
+    """oracle/torord.py shares nothing with the fixture's generator chain (no .ode parser, no SymPy: hand-ordered
+    expressions + forward-mode dual numbers); the fixture is the reference's .ode text evaluated by
+    tests/golden/ode_spec.py.  Names, defaults, RHS (1e-13), total self-derivatives (1e-11) and one GRL1 step for
+    endo / epi / mid."""
+    g = np.load(GOLD / "torord_spec.npz")
+    assert tuple(g["state_names"]) == torord.TORORD_STATES
+    assert tuple(g["parameter_names"]) == torord.TORORD_PARAMETERS
+    np.testing.assert_array_equal(g["state_defaults"], torord.torord_init_state_values())
+    np.testing.assert_array_equal(g["parameter_defaults"], torord.torord_init_parameter_values())
+    S, t, dt = g["states"], float(g["t"]), float(g["dt"])
+    for celltype in (0, 1, 2):
+        P = torord.torord_init_parameter_values(celltype=float(celltype))
+        f, J = torord.torord_rhs_and_linearized(S, t, P)
+        np.testing.assert_allclose(f, g[f"rhs_celltype{celltype}"], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(J, g[f"jac_celltype{celltype}"], rtol=1e-11, atol=1e-300)
+        assert (np.abs(J) > 0).all()  # no state is advanced by forward Euler for structural reasons
+        out = torord.torord_generalized_rush_larsen(S, t, dt, P)
+        np.testing.assert_allclose(out, g[f"grl1_celltype{celltype}"], rtol=1e-12, atol=1e-300)
+    # the cell types really differ
+    assert not np.allclose(g["grl1_celltype0"], g["grl1_celltype1"], rtol=1e-9)
+
+
+def test_torord_hand_restatement_along_an_action_potential():
+    """One GRL1 step from the 60 states the fixture sampled along a paced action potential of the specification
+    (upstroke, plateau, repolarisation), and per-node parameters: a (112, N) array with a different cell type per
+    node gives what the uniform calls give."""
+    g = np.load(GOLD / "torord_spec.npz")
+    P = torord.torord_init_parameter_values()
+    S = g["traj_states"]
+    out = torord.torord_generalized_rush_larsen(S, float(g["traj_step_t"]), float(g["traj_dt"]), P)
+    np.testing.assert_allclose(out, g["traj_grl1"], rtol=1e-11, atol=1e-300)
+    n = S.shape[1]
+    ct = np.arange(n) % 3
+    Pn = np.repeat(P[:, None], n, axis=1)
+    Pn[torord.torord_parameter_index("celltype")] = ct
+    per_node = torord.torord_generalized_rush_larsen(S, 5.0, 0.02, Pn)
+    for c in (0, 1, 2):
+        ref = torord.torord_generalized_rush_larsen(S[:, ct == c], 5.0, 0.02, torord.torord_init_parameter_values(celltype=float(c)))
+        np.testing.assert_array_equal(per_node[:, ct == c], ref)
+
+
+def test_torord_single_cell_action_potential_is_physiological():
+    """The model's own stimulus (-53 A/F for 1 ms at t = 0) fires one endocardial cell: overshoot 20-60 mV, APD90
+    in the human ventricular range, back at rest after 450 ms (dt = 0.1 ms keeps the CPU suite short;
+    demos/biv_endocardial.py:134 uses 0.05)."""
+    S = torord.torord_init_state_values()[:, None].copy()
+    P = torord.torord_init_parameter_values()
+    vi = torord.torord_state_index("v")
+    dt, t, vs = 0.1, 0.0, []
+    for _ in range(int(450 / dt)):
+        S = torord.torord_generalized_rush_larsen(S, t, dt, P)
+        t += dt
+        vs.append(S[vi, 0])
+    vs = np.array(vs)
+    assert np.isfinite(S).all() and 20.0 < vs.max() < 60.0 and vs[-1] < -85.0
+    up = np.nonzero(vs > 0)[0][0]
+    apd90 = (np.nonzero(vs > vs.min() + 0.1 * (vs.max() - vs.min()))[0][-1] - up) * dt
+    assert 220.0 < apd90 < 330.0, apd90
 
 
 def test_grl1_converges_to_the_ode_solution():

@@ -405,6 +405,112 @@ def test_voxel_shell_torord_celltypes_runs():
         assert np.isfinite(ode.values(k)).all()
 
 
+def test_voxel_shell_torord_endocardial_pacing_matches_oracle():
+    """BASELINE configs[4] in miniature, the workload of demos/biv_endocardial.py:187-282: voxelised shell, fibre
+    rotation, endo / mid / epi layers from utils.expand_layer, ToR-ORd-dynCl with one parameter set per layer
+    (DolfinMultiODESolver, generated 45-state kernel), endocardial SURFACE stimulus of 2000 uA/cm^2 for 1 ms, 24
+    Godunov steps of 0.05 ms (the stimulus ends after step 20).  Every state of every tissue node against the oracle:
+    the hand-written NumPy ToR-ORd (oracle/torord.py, independent of the kernel generator's parser) + literally
+    assembled P1 FEM on the active simplices with sparse-LU solves + exterior-triangle stimulus weights; 1e-7
+    relative as the TP06 twin above.  Also the explanation of the > 100 mV peaks seen at full size: they are the
+    stimulus itself at convex staircase corners of the stimulated surface (largest surface-to-volume share), present
+    bit for bit in the oracle, and gone a few ms after the stimulus ends."""
+    import beat
+    from beat import grid as g
+    from beat.models import torord
+    from oracle import fem, splitting
+    from oracle import torord as otor
+
+    n, h = (20, 18, 14), 0.5
+    mask, depth, f0 = _shell_geometry(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    ft = _shell_facet_tags(mesh, n, h)
+    V = g.functionspace(mesh, ("P", 1))
+    tissue = mesh.node_active()
+    layers = beat.utils.expand_layer(V, ft, 10, 20, endo_size=0.3, epi_size=0.3)  # 1 endo / 0 mid / 2 epi
+    marker_arr = np.where(tissue, np.asarray(layers.x.array), -1.0)
+    assert all((marker_arr == k).sum() > 50 for k in (0, 1, 2))
+    markers = g.Function(V)
+    markers.x.array[:] = marker_arr
+    cond = beat.conductivities.default_conductivities("Bishop")
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    time = g.Constant(mesh, 0.0)
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=ft, marker=10,
+                                           mesh_unit="mm", amplitude=2000.0, start=0.0, duration=1.0)
+    assert I_s.dZ.integral_type == "ds"
+    C_m = 0.01
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, params={"petsc_options": {"ksp_rtol": 1e-13}})
+    keys = (1, 0, 2)
+    celltype = {1: 0, 2: 1, 0: 2}  # layer marker -> the model's celltype parameter (0 endo, 1 epi, 2 mid)
+    ic = torord.init_state_values()
+    vi = torord.state_index("v")
+    params = {k: torord.init_parameter_values(i_Stim_Amplitude=0.0, celltype=celltype[k]) for k in keys}
+    ode = beat.odesolver.DolfinMultiODESolver(
+        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
+        fun={k: torord.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
+        parameters=params, v_index={k: vi for k in keys})
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    dt, nsteps = 0.05, 24
+    peak = []
+    for i in range(nsteps):
+        solver.step((i * dt, (i + 1) * dt))
+        peak.append(float(np.asarray(pde.state.x.array)[tissue].max()))
+
+    # ---- oracle ----------------------------------------------------------------------------------------------
+    omesh = fem.BoxMesh(n, tuple(c * h for c in n))
+    act_s = np.repeat(mask.ravel(), 6)
+    endo_nodes = np.zeros(omesh.num_nodes, dtype=bool)
+    endo_nodes[np.unique(mesh.facet_vertices(ft.find(10)))] = True
+    zb = np.floor(0.8 * n[2]) * h  # triangles in the (untagged) base plane are not part of the endocardium
+    w = fem.exterior_facet_weights(omesh, act_s, endo_nodes,
+                                   facet_filter=lambda X: ~(np.abs(X[:, :, 2] - zb) < 1e-9).all(axis=1))
+    amp = 2000.0 / 1400.0 / 10.0  # uA/cm^2 / cm^-1 = uA/cm -> uA/mm (stimulation.py:153-183)
+    model = fem.OracleMonodomainModel(omesh, np.repeat(M.values, 6, axis=0), [fem.OracleStimulus(fem.window(0.0, 1.0, amp), w)],
+                                      C_m=C_m, theta=0.5, active_cells=act_s)
+    assert tuple(otor.TORORD_STATES) == torord.generalized_rush_larsen.state_names
+    oparams = {k: otor.torord_init_parameter_values(i_Stim_Amplitude=0.0, celltype=float(celltype[k])) for k in keys}
+    for k in keys:
+        np.testing.assert_array_equal(oparams[k], np.asarray(params[k]))
+    oode = splitting.OracleMultiODE(marker_arr, {k: otor.torord_init_state_values() for k in keys}, oparams,
+                                    {k: otor.torord_generalized_rush_larsen for k in keys}, {k: 45 for k in keys},
+                                    {k: vi for k in keys})
+    opeak = []
+    for i in range(nsteps):
+        t0 = i * dt
+        oode.step(t0, dt)
+        oode.to_dolfin()
+        model.state[:] = oode.v_ode
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        oode.v_ode[:] = model.state
+        oode.from_dolfin()
+        opeak.append(float(model.state[tissue].max()))
+    sdef = np.abs(otor.torord_init_state_values())[:, None]
+    for k in keys:
+        out, ref = ode.values(k), oode.values[k]
+        assert np.isfinite(out).all()
+        err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6 * sdef + 1e-12)
+        assert err.max() < 1e-7, (k, err.max(), np.unravel_index(err.argmax(), err.shape))
+    v = np.asarray(pde.state.x.array)
+    assert np.all(v[~tissue] == 0.0)
+    # the stimulated surface fires, the far wall is still at rest; the three layers keep their own parameter sets
+    assert v[tissue].max() > 0.0 and v[tissue].min() < -85.0
+    # peaks: identical in the oracle at every step, attained on the stimulated surface, largest while the stimulus
+    # is on (steps 1..20), and the largest of them sits on a node with (nearly) the largest surface-to-volume share
+    np.testing.assert_allclose(peak, opeak, rtol=1e-9, atol=1e-7)
+    i_max = int(np.argmax(np.where(tissue, v, -np.inf)))
+    assert endo_nodes[i_max]
+    assert int(np.argmax(peak)) < 21 and peak[19] > 40.0
+    m_lumped = np.asarray(fem.assemble_mass(omesh, np.nonzero(act_s)[0]).sum(axis=1)).ravel()
+    share = np.where(w > 0, w / np.maximum(m_lumped, 1e-300), 0.0)  # surface per volume of a node, 1/mm
+    v20 = model.state  # (oracle potential after the last step, same as the device's to 1e-7)
+    hot = np.argsort(share)[-max(1, int(0.02 * (share > 0).sum())):]
+    assert v20[hot].mean() > v20[endo_nodes].mean() + 10.0
+    # forcing alone, before any ionic or diffusive response: dv/dt = amp * share / C_m (mV/ms) -- the flat-surface
+    # value 2 amp / (C_m h) = 57 mV/ms at h = 0.5 and up to three times that at a convex corner
+    assert np.isclose(np.median(share[share > 0]) , 2.0 / h, rtol=0.5) and share.max() > 1.9 * 2.0 / h
+
+
 @pytest.mark.parametrize("cells,h", [((22, 17, 13), (0.1, 0.12, 0.09)), ((40, 31), (0.05, 0.04)), ((15,), (0.1,))])
 def test_device_row_assembly_equals_host_assembly(hip_ctx, cells, h):
     """beat_pde_assemble_rows (per-voxel tensors + mask, on the device) vs _stencil.stencil_fields (NumPy, itself
