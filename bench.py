@@ -85,6 +85,41 @@ def init_states(ctx, states, ic, v_index, n_glob, slab, seed, nz_glob=None):
             del u
 
 
+def developed_front_profile(ctx, n, ic, params, v_index, rtol):
+    """(19, n) TP06 states of a travelling depolarisation front along x, from a 1-D pre-run ON THE DEVICE: an n-node
+    cable with the 3-D problem's h, dt and xx-conductivity, left end raised to +20 mV, stepped (same ionic kernel,
+    same theta-rule solve) until the front has reached the middle of the cable.  Returns (profile tensor, steps)."""
+    import ctypes as C
+
+    from beat import _hip, _stencil
+    from beat._device import StateArray
+    from beat._engine import DiffusionSolver, HipOps, Slab
+
+    mxx = float(conductivity()[0, 0])
+    mt, kt = _stencil.stencil_tables(1, (H,), np.array([[mxx]]))
+    ops = HipOps(ctx, (n, 1, 1), True, True, mt, kt)
+    ops.set_timestep(C_M, THETA, DT)
+    solver = DiffusionSolver(ops, Slab(1))
+    sa = StateArray(ctx, len(ic), n, n)
+    for k in range(len(ic)):
+        sa.rows[k].fill_(float(ic[k]))
+    sa.rows[v_index][:20].fill_(20.0)
+    v = sa.row_field(v_index)
+    p_host = np.ascontiguousarray(params)
+    steps, t = 0, 0.0
+    while steps < 20000:
+        for _ in range(200):
+            _hip.check(ctx.lib.beat_ode_step(ctx.handle, _hip.MODEL_TP06_GRL1, sa.ptr, n, sa.ld, p_host.ctypes.data_as(C.c_void_p),
+                                             len(p_host), None, 0, t, DT, v_index, None))
+            solver.solve(v, [], [], v, rtol=rtol, atol=1e-50, max_it=500)
+            t += DT
+        steps += 200
+        up = (sa.rows[v_index] > -40.0).nonzero()
+        if up.numel() and int(up.max()) >= n // 2:
+            break
+    return sa.rows.clone(), steps
+
+
 def cpu_baseline(n_side: int, steps: int, rtol: float):
     """The oracle's C restatement (oracle/beat_oracle.c: TP06 GRL1 + 15-point-stencil Jacobi-PCG, OpenMP over
     nodes) timed on this host's cores on an n_side^3 sample of the same workload; the single-threaded NumPy
@@ -199,6 +234,7 @@ def main():
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
     ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
                     "solve instead of inside the next ionic kernel")
+    ap.add_argument("--no-front", action="store_true", help="skip the second, developed-front measurement")
     ap.add_argument("--size-z", "--nz", dest="nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
                     "BEAT_FORCE_DISTRIBUTED=1 rehearses on one GPU the slab one of 8 ranks owns at 512^3")
     args = ap.parse_args()
@@ -281,54 +317,59 @@ def main():
     p_host = np.ascontiguousarray(params)
     p_ptr = p_host.ctypes.data_as(C.c_void_p)
 
-    ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    iters = []
-    pend_counts = []  # search directions the timed ionic launches applied on behalf of the previous solve
-
-    def step(t, i=None):
-        if i is not None:
-            ev_ode[i][0].record()
-        # the previous solve left its last x += sum alpha_j p_j to this kernel (deferred-x PCG)
-        pend = ops.pending
-        ops.pending = None
-        if i is not None:
-            pend_counts.append(pend[2] if pend else 0)
-        _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
-                                             len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
-                                             ops.fld, pend[2] if pend else 0))
-        if i is not None:
-            ev_ode[i][1].record()
-        res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
-        if i is not None:
-            ev_pde_end[i].record()
-            iters.append(res.iterations)
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    t = 0.0
-    for _ in range(args.warmup):
-        step(t)
-        t += DT
-    barrier()
-    tic = time.perf_counter()
-    for i in range(args.steps):
-        step(t, i)
-        t += DT
-    ops.flush_pending()  # the potential is complete when the timed region ends
-    barrier()
-    wall = time.perf_counter() - tic
-    if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+    def timed_run(t, warmup, steps):
+        """`warmup` untimed steps, then exactly `steps` timed ones bracketed by barriers; returns the statistics."""
+        ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        iters, pend_counts = [], []  # pend: search directions the timed ionic launches applied for the previous solve
 
-    ode_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ode]))
-    pde_ms = float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(args.steps)]))
+        def step(t, i=None):
+            if i is not None:
+                ev_ode[i][0].record()
+            # the previous solve left its last x += sum alpha_j p_j to this kernel (deferred-x PCG, DESIGN.md 4)
+            pend = ops.pending
+            ops.pending = None
+            if i is not None:
+                pend_counts.append(pend[2] if pend else 0)
+            _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
+                                                 len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
+                                                 ops.fld, pend[2] if pend else 0))
+            if i is not None:
+                ev_ode[i][1].record()
+            res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
+            if res.converged_reason <= 0:
+                raise SystemExit(f"PCG did not converge: reason {res.converged_reason} after {res.iterations} iterations")
+            if i is not None:
+                ev_pde_end[i].record()
+                iters.append(res.iterations)
+
+        for _ in range(warmup):
+            step(t)
+            t += DT
+        barrier()
+        tic = time.perf_counter()
+        for i in range(steps):
+            step(t, i)
+            t += DT
+        ops.flush_pending()  # the potential is complete when the timed region ends
+        barrier()
+        wall = time.perf_counter() - tic
+        if world > 1:
+            w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w.item())
+        return dict(t=t, wall=wall, iters=iters, pend_counts=pend_counts,
+                    ode_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_ode])),
+                    pde_ms=float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(steps)])))
+
+    run = timed_run(0.0, args.warmup, args.steps)
+    wall, iters, pend_counts, ode_ms, pde_ms = run["wall"], run["iters"], run["pend_counts"], run["ode_ms"], run["pde_ms"]
     vmin, vmax = v_field.minmax()
     if world > 1:  # extrema over all slabs (NaN-propagating: a non-finite value on any rank shows)
         ext = torch.tensor([-vmin, vmax], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
@@ -337,6 +378,42 @@ def main():
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         vmin, vmax = (-float(ext[0]), float(ext[1])) if float(bad[0]) == 0.0 else (float("nan"), float("nan"))
     finite = bool(np.isfinite(vmin) and np.isfinite(vmax))
+
+    # Second regime, same grid, same run: a DEVELOPED depolarisation front (the headline's timed steps follow a smooth
+    # bump, whose right-hand side needs about half the PCG iterations a travelling wave needs).  A planar TP06 front
+    # from a 1-D device pre-run is extruded over the slab, a few steps let the iteration count settle, then the same
+    # number of steps is timed the same way.
+    front = None
+    if finite and not args.no_front:
+        tic = time.perf_counter()
+        prof, pre_steps = developed_front_profile(ctx, n, ic, params, v_index, args.rtol)
+        for k in range(states.S):
+            states.rows[k].view(-1, n).copy_(prof[k][None, :].expand(n_local // n, n))
+        del prof
+        setup_s = time.perf_counter() - tic
+        fr = timed_run(0.0, max(args.warmup, 5), args.steps)
+        fmin, fmax = v_field.minmax()
+        if world > 1:
+            ext = torch.tensor([-fmin, fmax, 0.0 if np.isfinite(fmin) and np.isfinite(fmax) else 1.0], dtype=torch.float64,
+                               device=ctx.device if backend == "nccl" else "cpu")
+            dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+            fmin, fmax = (-float(ext[0]), float(ext[1])) if float(ext[2]) == 0.0 else (float("nan"), float("nan"))
+        finite = finite and bool(np.isfinite(fmin) and np.isfinite(fmax))
+        kf = float(np.mean(fr["iters"]))
+        front = {
+            "what": f"planar TP06 depolarisation front normal to x at mid-slab, extruded from a 1-D device pre-run of {pre_steps} "
+                    f"steps ({setup_s:.1f} s, untimed); {max(args.warmup, 5)} warm-up + {args.steps} timed steps",
+            "value": n * n * nz_glob * args.steps / fr["wall"],
+            "unit": "node-updates/s",
+            "ms_per_step": fr["wall"] / args.steps * 1e3,
+            "pcg_iterations_per_step": kf,
+            "ode_ms": fr["ode_ms"],
+            "pde_ms": fr["pde_ms"],
+            "bytes_per_node_update": 16.0 * len(ic) + 16.0 + 88.0 * kf,
+            "frac_of_8TBs_per_gpu": (16.0 * len(ic) + 16.0 + 88.0 * kf) * n * n * nz_glob * args.steps / fr["wall"] / 1e9 / world / HBM_PEAK_GBS,
+            "v_min": fmin,
+            "v_max": fmax,
+        }
 
     if rank == 0:
         n_total = n * n * nz_glob
@@ -403,6 +480,7 @@ def main():
                 },
             },
         }
+        out["developed_front"] = front
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, args.rtol)
         else:

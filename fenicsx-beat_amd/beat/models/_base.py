@@ -174,7 +174,7 @@ class DeviceParameters:
     def set_row(self, k: int, values) -> None:
         """One parameter at every node (a scalar is broadcast)."""
         row = np.broadcast_to(np.asarray(values, dtype=np.float64), (self._dev.shape[1],))
-        self._dev[int(k)].copy_(self.ctx.torch.from_numpy(np.ascontiguousarray(row)))
+        self._dev[int(k)].copy_(self.ctx.torch.from_numpy(np.array(row, dtype=np.float64)))
         self.version += 1
 
     def numpy(self) -> np.ndarray:

@@ -183,3 +183,129 @@ def test_per_node_operator_properties_on_a_large_voxel_shell(hip_ctx):
     assert float(ay_.data.abs().max()) <= 1e-13 * float(ax_.data.abs().max())
     ops.apply(2, ones, ax_)
     assert np.isclose(_dot(ctx, ones, ax_), mask.sum() * h**3, rtol=1e-12)
+
+
+def test_voxel_shell_torord_pipeline_at_full_size(hip_ctx):
+    """BASELINE.json configs[4] at its own size on one GPU (tools/bench_biv.py --size 520: 521^3-node box, ~37 M tissue
+    nodes, fibre rotation, expand_layer markers, ToR-ORd-dynCl endo / mid / epi, 2000 uA/cm^2 endocardial surface
+    stimulus for 1 ms; the workload of demos/biv_endocardial.py:187-282) -- size-independent properties, since no CPU
+    oracle reaches this size (the same pipeline is compared state by state with the oracle at small size in
+    tests/test_var_gpu.py::test_voxel_shell_torord_endocardial_pacing_matches_oracle):
+
+      * per-node operators: A symmetric, K 1 = 0 on the tissue, 1^T Mass 1 = tissue volume;
+      * a diffusion solve meets its own stopping test when the residual is recomputed from scratch (b - A x);
+      * 64 split steps of 0.05 ms: everything finite, every gate of the three cell types in [0, 1], Markov occupancies
+        non-negative, concentrations positive;
+      * the extrema are explained: the potential peaks far above a physiological overshoot only WHILE the surface
+        stimulus is on, at nodes of the stimulated (endocardial) surface -- the P1 surface load of 2000 uA/cm^2 on a
+        staircase surface, which the oracle reproduces bit for bit at small size -- and is back at an ordinary overshoot 2.2 ms
+        after the stimulus ends (below +70 mV); the undershoot below rest sits next to the stimulated surface (consistent-mass
+        Galerkin, non-monotone) and is bounded."""
+    import importlib.util
+    from pathlib import Path
+
+    import torch
+
+    from beat.models import torord
+
+    ctx = hip_ctx
+    spec = importlib.util.spec_from_file_location("bench_biv", Path(__file__).resolve().parents[1] / "tools" / "bench_biv.py")
+    bench_biv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench_biv)
+    P = bench_biv.build(520, rtol=1e-8, verbose=False)
+    mesh, tissue, pde, ode, solver, ft, h = P["mesh"], P["tissue"], P["pde"], P["ode"], P["solver"], P["ft"], P["h"]
+    nt = int(tissue.sum())
+    assert mesh.num_nodes == 521**3 and 35e6 < nt < 40e6
+    ops = pde._ops
+    n = ops.n
+    tissue_dev = ctx.from_numpy(tissue)
+
+    # ---- operator properties ---------------------------------------------------------------------------------------
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(9)
+    x, y, ax, ay = (ops.new_field() for _ in range(4))
+    x.data.copy_(torch.randn(n, generator=gen, device=ctx.device, dtype=torch.float64))
+    y.data.copy_(torch.randn(n, generator=gen, device=ctx.device, dtype=torch.float64))
+    ops.set_timestep(0.01, 0.5, 0.05)
+    ops.apply(0, x, ax)
+    ops.apply(0, y, ay)
+    lhs, rhs = _dot(ctx, y, ax), _dot(ctx, x, ay)
+    assert abs(lhs - rhs) <= 1e-12 * np.sqrt(_dot(ctx, ax, ax) * _dot(ctx, y, y))
+    assert torch.equal(ax.data[~tissue_dev], x.data[~tissue_dev])  # identity rows outside the tissue
+    y.fill(1.0)
+    ops.apply(3, y, ay)
+    ops.apply(3, x, ax)
+    assert float(ay.data.abs().max()) <= 1e-13 * float(ax.data.abs().max())
+    ops.apply(2, y, ay)
+    assert np.isclose(float(ay.data[tissue_dev].sum()), P["voxels"] * h**3, rtol=1e-11)
+
+    # ---- a solve meets its stopping test with the residual recomputed from scratch ----------------------------------
+    v0 = ops.new_field()
+    v0.data.copy_(torch.where(tissue_dev, -88.0 + 40.0 * torch.rand(n, generator=gen, device=ctx.device, dtype=torch.float64),
+                              torch.zeros((), dtype=torch.float64, device=ctx.device)))
+    res = pde._diffusion.solve(v0, [], [], x, rtol=1e-8, atol=1e-50, max_it=200)
+    assert res.converged_reason > 0 and 3 <= res.iterations <= 60
+    ops.apply(1, v0, ay)  # b = B v
+    ops.apply(0, x, ax)   # A x
+    r = (ay.data - ax.data)[tissue_dev]
+    rnorm, bnorm = float(torch.linalg.vector_norm(r)), float(torch.linalg.vector_norm(ay.data[tissue_dev]))
+    assert np.isclose(bnorm, res.rhs_norm, rtol=1e-10)
+    assert rnorm <= 1.05e-8 * bnorm
+    del x, y, ax, ay, v0, r
+
+    # ---- split steps -------------------------------------------------------------------------------------------------
+    endo = np.zeros(mesh.num_nodes, dtype=bool)
+    endo[np.unique(mesh.facet_vertices(ft.find(10)))] = True
+    endo_dev = ctx.from_numpy(endo)
+    dt = 0.05
+    peaks, lows, its = [], [], []
+    at_peak = None
+    for i in range(64):
+        solver.step((i * dt, (i + 1) * dt))
+        its.append(pde.ksp.iterations)
+        v = pde.state.field.data
+        vt = torch.where(tissue_dev, v, torch.full((), -80.0, dtype=torch.float64, device=ctx.device))
+        peaks.append(float(vt.max()))
+        lows.append(float(vt.min()))
+        if i == 19:  # last step with the stimulus on
+            at_peak = (int(vt.argmax()), int(vt.argmin()))
+    assert np.isfinite(peaks).all() and np.isfinite(lows).all() and max(its) <= 40
+    v = pde.state.field.data
+    assert torch.equal(v[~tissue_dev], torch.zeros_like(v[~tissue_dev]))  # nothing leaks out of the tissue
+    # (i) the peak belongs to the stimulus: it is reached on the last stimulated step, on the stimulated surface
+    assert int(np.argmax(peaks)) == 19 and 100.0 < peaks[19] < 600.0, peaks[:24]
+    assert bool(endo_dev[at_peak[0]])
+    # (ii) 2.2 ms after the stimulus the maximum is an ordinary ToR-ORd overshoot
+    assert 0.0 < peaks[-1] < 70.0, peaks[-1]
+    # (iii) undershoot: bounded, and its node is within two voxels of the stimulated surface
+    assert -130.0 < min(lows) < -88.0
+    iz, rem = divmod(at_peak[1], 521 * 521)
+    iy, ix = divmod(rem, 521)
+    e3 = endo.reshape(521, 521, 521)
+    assert e3[max(iz - 2, 0):iz + 3, max(iy - 2, 0):iy + 3, max(ix - 2, 0):ix + 3].any()
+    # (iv) the far wall is still at rest: activation has not crossed the wall in 3.2 ms
+    assert lows[-1] < -85.0
+
+    gates = ["a", "ap", "iF", "iFp", "iS", "iSp", "d", "fcaf", "fcafp", "fcas", "ff_", "ffp",
+             "fs", "jca", "nca_i", "nca_ss", "h", "hp", "j", "jp", "m", "hL", "hLp", "mL", "xs1", "xs2"]
+    # occupancies of the IKr Markov model: generalized Rush-Larsen advances each state on its own,
+    # y <- y e^(-out dt) + (in/out)(1 - e^(-out dt)), which keeps them non-negative but does not conserve their sum; at
+    # the unphysiological potentials under the stimulus (+300 mV: the voltage-dependent rates grow like e^(1.5 vF/RT))
+    # single occupancies overshoot 1 transiently -- a property of the scheme the reference uses, not of the kernel
+    markov = ["C1", "C2", "C3", "I_", "O_"]
+    positive = ["CaMKt", "cai", "cajsr", "cansr", "cass", "cli", "clss", "ki", "kss", "nai", "nass"]
+    for marker in (0, 1, 2):
+        states = ode._odes[marker].states
+        for name in gates:
+            lo, hi = states.row_field(torord.state_index(name)).minmax()
+            assert 0.0 <= lo and hi <= 1.0 + 1e-12, (marker, name, lo, hi)
+        for name in markov:
+            lo, hi = states.row_field(torord.state_index(name)).minmax()
+            assert 0.0 <= lo and hi < 2.0, (marker, name, lo, hi)
+        for name in positive:
+            lo, hi = states.row_field(torord.state_index(name)).minmax()
+            assert lo > 0.0 and np.isfinite(hi), (marker, name, lo, hi)
+        lo, hi = states.row_field(torord.state_index("v")).minmax()
+        assert np.isfinite(lo) and np.isfinite(hi)
+    print(f"configs[4] full size: {nt / 1e6:.1f} M tissue nodes, peak {peaks[19]:.1f} mV at stimulus end, {peaks[-1]:.1f} mV "
+          f"2.2 ms later, min {min(lows):.1f} mV, PCG {np.mean(its):.1f} its/step")

@@ -43,6 +43,60 @@ def shell(n, h, chunk=32):
     return mask, f0.reshape(-1, 3), (so, si, c)
 
 
+def build(n, h=0.25, rtol=1e-8, verbose=True):
+    """The whole pipeline through the public API; returns its pieces (mesh, tissue mask of the nodes, facet tags,
+    layer markers, pde, ode, solver, shell semi-axes)."""
+    import beat
+    from beat import grid as g
+    from beat.models import torord
+
+    say = (lambda *a: print(*a, flush=True)) if verbose else (lambda *a: None)
+    tic = time.perf_counter()
+    mask, f0, (so, si, c) = shell(n, h)
+    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
+    tissue = mesh.node_active()
+    say(f"box {n + 1}^3 = {(n + 1) ** 3 / 1e6:.1f} M nodes, {tissue.sum() / 1e6:.2f} M tissue nodes "
+        f"({mask.mean() * 100:.0f} % of the voxels); geometry {time.perf_counter() - tic:.1f} s")
+    tic = time.perf_counter()
+    facets = mesh.exterior_facets()
+    xyz = g._node_xyz(mesh, mesh.facet_vertices(facets).ravel()).reshape(len(facets), 4, 3)
+    ctr = xyz.mean(axis=1) - c
+    ro = np.sqrt(((ctr / so) ** 2).sum(axis=1))
+    ri = np.sqrt(((ctr / si) ** 2).sum(axis=1))
+    base = (np.ptp(xyz[:, :, 2], axis=1) < 1e-12) & (ri > 1.0) & (ro < 1.0)
+    values = np.where(base, 0, np.where(np.abs(ri - 1.0) < np.abs(ro - 1.0) * (1.0 / 0.66), 10, 20)).astype(np.int32)
+    ft = g.meshtags(mesh, 2, facets[values > 0], values[values > 0])
+    del xyz, ctr, ro, ri
+    V = g.functionspace(mesh, ("P", 1))
+    layers = beat.utils.expand_layer(V, ft, 10, 20, endo_size=0.3, epi_size=0.3)
+    marker_arr = np.where(tissue, np.asarray(layers.x.array), -1.0)
+    markers = g.Function(V)
+    markers.x.array[:] = marker_arr
+    say(f"facet tags + expand_layer (Laplace PCG on the device): {time.perf_counter() - tic:.1f} s; "
+        f"endo/mid/epi nodes = {[(marker_arr == k).sum() for k in (1, 0, 2)]}")
+    tic = time.perf_counter()
+    cond = beat.conductivities.default_conductivities("Bishop")
+    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
+    del f0
+    time_c = g.Constant(mesh, 0.0)
+    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time_c, subdomain_data=ft, marker=10,
+                                           mesh_unit="mm", amplitude=2000.0, start=0.0, duration=1.0)
+    pde = beat.MonodomainModel(time=time_c, mesh=mesh, M=M, I_s=I_s, C_m=0.01,
+                               params={"petsc_options": {"ksp_rtol": rtol}})
+    keys = (0, 1, 2)  # celltype parameter of the model: 0 endo, 1 epi, 2 mid; layer markers: 1 endo, 0 mid, 2 epi
+    celltype = {1: 0, 2: 1, 0: 2}
+    ic = torord.init_state_values()
+    ode = beat.odesolver.DolfinMultiODESolver(
+        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
+        fun={k: torord.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
+        parameters={k: torord.init_parameter_values(i_Stim_Amplitude=0.0, celltype=celltype[k]) for k in keys},
+        v_index={k: torord.state_index("v") for k in keys})
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    say(f"operators (device assembly), states: {time.perf_counter() - tic:.1f} s")
+    return dict(mesh=mesh, tissue=tissue, ft=ft, marker_arr=marker_arr, pde=pde, ode=ode, solver=solver, h=h,
+                voxels=int(mask.sum()), semi_axes=(so, si, c))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", "--n", dest="n", type=int, default=256, help="voxels per axis (--n clashes with torchrun's own options)")
@@ -64,52 +118,8 @@ def main():
         torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
 
-    import beat
-    from beat import grid as g
-    from beat.models import torord
-
-    n, h = args.n, 0.25
-    tic = time.perf_counter()
-    mask, f0, (so, si, c) = shell(n, h)
-    mesh = g.create_voxel_mesh(g.COMM_WORLD, mask, h)
-    tissue = mesh.node_active()
-    print(f"box {n + 1}^3 = {(n + 1) ** 3 / 1e6:.1f} M nodes, {tissue.sum() / 1e6:.2f} M tissue nodes "
-          f"({mask.mean() * 100:.0f} % of the voxels); geometry {time.perf_counter() - tic:.1f} s", flush=True)
-    tic = time.perf_counter()
-    facets = mesh.exterior_facets()
-    xyz = g._node_xyz(mesh, mesh.facet_vertices(facets).ravel()).reshape(len(facets), 4, 3)
-    ctr = xyz.mean(axis=1) - c
-    ro = np.sqrt(((ctr / so) ** 2).sum(axis=1))
-    ri = np.sqrt(((ctr / si) ** 2).sum(axis=1))
-    base = (np.ptp(xyz[:, :, 2], axis=1) < 1e-12) & (ri > 1.0) & (ro < 1.0)
-    values = np.where(base, 0, np.where(np.abs(ri - 1.0) < np.abs(ro - 1.0) * (1.0 / 0.66), 10, 20)).astype(np.int32)
-    ft = g.meshtags(mesh, 2, facets[values > 0], values[values > 0])
-    del xyz, ctr, ro, ri
-    V = g.functionspace(mesh, ("P", 1))
-    layers = beat.utils.expand_layer(V, ft, 10, 20, endo_size=0.3, epi_size=0.3)
-    marker_arr = np.where(tissue, np.asarray(layers.x.array), -1.0)
-    markers = g.Function(V)
-    markers.x.array[:] = marker_arr
-    print(f"facet tags + expand_layer (Laplace PCG on the device): {time.perf_counter() - tic:.1f} s; "
-          f"endo/mid/epi nodes = {[(marker_arr == k).sum() for k in (1, 0, 2)]}", flush=True)
-    tic = time.perf_counter()
-    cond = beat.conductivities.default_conductivities("Bishop")
-    M = beat.conductivities.define_conductivity_tensor(f0=g.CellField(mesh, f0), **cond)
-    time_c = g.Constant(mesh, 0.0)
-    I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time_c, subdomain_data=ft, marker=10,
-                                           mesh_unit="mm", amplitude=2000.0, start=0.0, duration=1.0)
-    pde = beat.MonodomainModel(time=time_c, mesh=mesh, M=M, I_s=I_s, C_m=0.01,
-                               params={"petsc_options": {"ksp_rtol": 1e-8}})
-    keys = (0, 1, 2)  # celltype parameter of the model: 0 endo, 1 epi, 2 mid; layer markers: 1 endo, 0 mid, 2 epi
-    celltype = {1: 0, 2: 1, 0: 2}
-    ic = torord.init_state_values()
-    ode = beat.odesolver.DolfinMultiODESolver(
-        v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: len(ic) for k in keys},
-        fun={k: torord.generalized_rush_larsen for k in keys}, init_states={k: ic for k in keys},
-        parameters={k: torord.init_parameter_values(i_Stim_Amplitude=0.0, celltype=celltype[k]) for k in keys},
-        v_index={k: torord.state_index("v") for k in keys})
-    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
-    print(f"operators (device assembly), states: {time.perf_counter() - tic:.1f} s", flush=True)
+    P = build(args.n)
+    mesh, tissue, marker_arr, pde, solver = P["mesh"], P["tissue"], P["marker_arr"], P["pde"], P["solver"]
     t, dt = 0.0, args.dt
     its = []
     for _ in range(args.warmup):
