@@ -972,12 +972,53 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
   beat_ctx* ctx = pde->ctx;
   double* h = ctx->h_pinned;
   const int npass = pde->pc_ncoef - 1;
-  int rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
+  const bool rr = beat_rr_available(pde);  // constant coefficients + Jacobi: the loop that never stores q = A p
+  int rc;
+  if (rr) {
+    BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
+    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+  } else {
+    rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
+  }
   if (rc) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
   int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
-  if (npass > 0) {
+  if (rr) {
+    // iteration i: p_i = D^-1 r + beta p_{i-1} and p_i . A p_i in one pass (ring slot i % PRING), then
+    // r_new = r - alpha A p_i with A p_i recomputed (written to the other of the two residual buffers: the kernel
+    // then needs no store-before-load ordering), then the scalar roll
+    double* rbuf[2] = {r, q};
+    while (true) {
+      chunk = std::min(chunk, max_it - launched);
+      for (int it = 0; it < chunk; ++it) {
+        const int i = launched + it, slot = i % PRING;
+        double* p_cur = ring + (int64_t)slot * fld;
+        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        if ((rc = beat_rr_pdot(pde, st, rbuf[i & 1], p_old, p_cur))) return rc;
+        if ((rc = beat_rr_rupd(pde, st, rbuf[i & 1], rbuf[(i + 1) & 1], p_cur, slot))) return rc;
+        if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
+          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+        }
+      }
+      launched += chunk;
+      BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+      BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (h[STOP] != 0.0 || launched >= max_it) break;
+      chunk = 2;
+    }
+    const int nupd = (int)h[NUPD];
+    if (nupd % PRING != 0) {
+      if (defer_flush) {
+        host_pending[0] = (nupd / PRING) * PRING;
+        host_pending[1] = nupd % PRING;
+      } else if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) {
+        return rc;
+      }
+    }
+  } else if (npass > 0) {
     // polynomial preconditioner: classic in-place recurrences with p = ring[0]
     double* p = ring;
     for (int j = 0; j < npass; ++j)

@@ -75,3 +75,10 @@ int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next);
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                    int ring_base, int only_if_full);
+
+// register-row kernels of the constant-coefficient Jacobi-PCG that never stores q = A p (beat_pde_rr.hip)
+bool beat_rr_available(const beat_pde* pde);
+int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
+                int n_stim, double* dev_x, double* dev_r, double* dev_st);
+int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new);
+int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot);

@@ -1,0 +1,496 @@
+// Constant-coefficient diffusion solve without a stored q = A p: "register-row" stencil kernels.
+//
+// The 15-point P1 stencil touches 7 rows of x (3 of the plane z, 2 of z+1, 2 of z-1).  A wave owns 62 consecutive
+// x-nodes (lanes 1..62; lanes 0 and 63 carry the x-halo) of RY = 4 consecutive rows and marches along z with the
+// 3 x 6 row values it needs held in registers: every row is loaded ONCE per wave (one coalesced 512 B request),
+// the x +- 1 neighbours come from the adjacent lanes by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1, no
+// LDS, no barriers), and the plane z+2 is in flight while plane z is computed.  The y-halo rows (6 rows loaded
+// per 4 rows computed) are re-reads that the XCD's L2 serves.
+//
+// With the operator this cheap to re-apply, the PCG never stores q:
+//   K_A  (pdot):  p_new = D^-1 r + beta p_old  formed while loading, stored once;  partial  p_new . (A p_new)
+//   K_B  (rupd):  alpha = r.z / p.q;  r -= alpha (A p)  with A p recomputed from p;  partials  r.D^-1 r, r.r
+// i.e. 24 + 24 B/node per iteration instead of 16 (SpMV) + 24 (r update) + 24 (p update) = 64, and the right-hand
+// side writes r only (16 B instead of 24; the first K_A forms p_0 = D^-1 r itself).  Values are those of the
+// classic three-kernel loop up to the order in which the block partial sums are added.
+//
+// Replaces, like beat_pde.hip, dolfinx assemble_vector + PETSc KSP.solve of src/beat/base_model.py:196-236.
+#include "beat_pde_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+using namespace beat_pde_detail;
+
+constexpr int SEG = 62;  // x-nodes computed per wave and row (lanes 1..62)
+// rows computed per wave: template parameter RY (2 or 4; BEAT_RR_RY, default 4), NR = RY + 2 rows held per plane;
+// PD: planes fetched ahead of their use (BEAT_RR_PD)
+
+struct Coef {
+  double c[15];
+};
+
+struct RGeom {
+  int nx, ny, nz;
+  int64_t plane;
+  int ry;
+  int nsegx, nrb, nchunks, zc;
+  int total_waves, total_blocks;
+  int z_lo_phys, z_hi_phys;
+};
+
+enum { RR_PDOT = 0, RR_RUPD = 1, RR_RHS = 2 };
+
+struct RArgs {
+  const double* x;      // PDOT: r | RUPD: p | RHS: v_
+  const double* x2;     // PDOT: p_old | RUPD: r
+  double* y;            // PDOT: p_new | RUPD: r_new (another buffer than r) | RHS: r
+  double* y2;           // RHS: x (copy of v_) or nullptr
+  const double* tab;    // A table (PDOT, RUPD) | Mass table (RHS)
+  const double* tab2;   // RHS: K table
+  const double* dinv;   // 1/diag(A) per node type
+  Coef ci, ci2;         // interior rows of tab / tab2
+  double dinv_i;
+  double cm, omt_dt, dt;
+  const double* w[BEAT_MAX_STIM];
+  double amp[BEAT_MAX_STIM];
+  int nstim;
+  double* partials;
+  double* st;           // PCG scalar state
+  double* alphas;       // RUPD: step lengths of the deferred-x ring
+  int slot;
+};
+
+// lane i <- lane i-1 (lane 0 <- 0) / lane i <- lane i+1 (lane 63 <- 0); all 64 lanes must be active
+__device__ __forceinline__ double from_left(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);  // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_right(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);  // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int axis_type3(int i, int n, int lo_phys, int hi_phys) {
+  if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
+  if (i == 0 && lo_phys) return 0;
+  if (i == n - 1 && hi_phys) return 2;
+  return 1;
+}
+
+__device__ __forceinline__ int xcd_block(int b, int total) {
+  const int per = (total + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+// X / X2 / Y / Y2: the fields of RArgs::x, x2, y, y2 as separate restrict-qualified kernel parameters -- the launch
+// passes distinct buffers (the residual update writes r out of place), and without the no-alias guarantee every
+// store would have to complete (s_waitcnt vmcnt(0)) before the next plane's loads may issue.
+template <int MODE, int RY, int PD>
+__global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
+                                                        const double* __restrict__ X2, double* __restrict__ Y,
+                                                        double* __restrict__ Y2) {
+  constexpr int NR = RY + 2;
+  __shared__ double red[4];
+  // boundary rows of the coefficient tables and 1/diag per node type, staged in LDS: the lanes on a face of the box
+  // look them up every step, and a global load there would put a full vmcnt(0) drain -- outstanding stores and the
+  // prefetched plane included -- into the march
+  __shared__ double s_dinv[32];
+  __shared__ double s_tab[27 * TABW];
+  __shared__ double s_tab2[MODE == RR_RHS ? 27 * TABW : 1];
+  if (MODE != RR_RHS) {
+    if (a.st[STOP] != 0.0) return;  // convergence latch (uniform over the grid)
+  }
+  for (int i = threadIdx.x; i < 27 * TABW; i += BEAT_BLOCK) {
+    s_tab[i] = a.tab[i];
+    if (MODE == RR_RHS) s_tab2[i] = a.tab2[i];
+  }
+  if (threadIdx.x < 27) s_dinv[threadIdx.x] = a.dinv[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int blk = xcd_block(blockIdx.x, g.total_blocks);
+  const int w = blk * 4 + (threadIdx.x >> 6);
+  const bool wave_ok = blk < g.total_blocks && w < g.total_waves;
+  const int seg = w % g.nsegx;
+  const int rb = (w / g.nsegx) % g.nrb;
+  const int chunk = w / (g.nsegx * g.nrb);
+  const int gx = seg * SEG - 1 + lane;
+  const int y0 = rb * RY - 1;  // global row of register row 0
+  const int zb = chunk * g.zc;
+  const int ze = wave_ok ? min(zb + g.zc, g.nz) : zb;
+  const bool x_in = wave_ok && gx >= 0 && gx < g.nx;
+  const bool x_out = x_in && lane >= 1 && lane <= SEG;  // this lane produces outputs
+  const int tx = axis_type3(gx, g.nx, 1, 1);
+  bool row_in[NR];
+  int txy[NR];  // tx + 3 ty of the register rows
+  int off[NR];  // in-plane offset of the (clamped, always addressable) element this lane loads of each row
+  const int cx = min(max(gx, 0), g.nx - 1);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int gy = y0 + r;
+    row_in[r] = x_in && gy >= 0 && gy < g.ny;
+    txy[r] = tx + 3 * axis_type3(gy, g.ny, 1, 1);
+    off[r] = min(max(gy, 0), g.ny - 1) * g.nx + cx;
+  }
+  double beta = 0.0, alpha = 0.0;
+  if (MODE == RR_PDOT) beta = a.st[BETA];
+  if (MODE == RR_RUPD) {
+    alpha = a.st[RZ] / a.st[PQ];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.alphas[a.slot] = alpha;
+  }
+  const bool have_old = beta != 0.0;  // first direction: p_old may hold anything and is not read
+
+  // Loads are unconditional (no divergent branches around them): out-of-box lanes read a clamped, valid element
+  // and the value is replaced by 0 afterwards; the planes -1 and nz are the ghost planes every field carries.
+  // Plane k is fetched PD steps before the step that first needs it (as plane z+1 of step z = k-1) into raw slot
+  // (step index) % PD; the loop is unrolled by PD so that the slots are static registers.
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
+  double rvn[PD][RY];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    Cm[r] = C0[r] = Cp[r] = 0.0;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) ra[u][r] = rb2[u][r] = 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+#pragma unroll
+    for (int j = 0; j < RY; ++j) rvn[u][j] = 0.0;
+  // The march starts PD + 2 steps early: those steps only fill the pipeline (planes z_b-1, z_b, ...).
+  for (int zz = zb - 2 - PD; zz < ze; zz += PD) {
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+    const int z = zz + u;
+    if (z < ze) {
+    const int k = z + 1;  // plane whose raw values (slot u) become the staged plane z+1 now
+    if (k >= zb - 1 && k <= ze) {  // staged values of plane k; PDOT forms p_new here and stores the rows this wave owns
+      const bool zok = (k >= 0 || !g.z_lo_phys) && (k < g.nz || !g.z_hi_phys);
+      const int tz9 = 9 * axis_type3(k, g.nz, g.z_lo_phys, g.z_hi_phys);
+      const bool own_plane = k >= zb && k < ze;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double c = ra[u][r];
+        if (MODE == RR_PDOT) {
+          const int type = txy[r] + tz9;
+          const double di = s_dinv[type];  // (a select against the kernel argument a.dinv_i trips an LDS-pointer cast bug in hipcc 7.2)
+          // p_new = D^-1 r + beta p_old (same expression as cg_pupdate_oop_kernel; p_old unread while beta = 0)
+          c = have_old ? fma(beta, rb2[u][r], di * ra[u][r]) : di * ra[u][r];
+        }
+        c = (zok && row_in[r]) ? c : 0.0;
+        Cp[r] = c;
+        if (MODE == RR_PDOT) {
+          if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
+            Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx] = c;
+        }
+      }
+    }
+    double rv[RY];
+    if (MODE == RR_RUPD) {  // residual values of the owned rows of plane z (fetched PD steps ago)
+#pragma unroll
+      for (int j = 0; j < RY; ++j) rv[j] = rvn[u][j];
+      if (z + PD >= zb && z + PD < ze) {
+        const double* __restrict__ br = X2 + (int64_t)(z + PD) * g.plane;
+#pragma unroll
+        for (int j = 0; j < RY; ++j) rvn[u][j] = br[off[j + 1]];
+      }
+    }
+    {
+      const int kf = k + PD;  // fetched now into the slot just consumed
+      if (kf >= zb - 1 && kf <= ze) {
+        const int cz = min(max(kf, -1), g.nz);
+        const double* __restrict__ bx = X + (int64_t)cz * g.plane;
+        const double* __restrict__ bx2 = (MODE == RR_PDOT && have_old) ? X2 + (int64_t)cz * g.plane : bx;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          ra[u][r] = bx[off[r]];
+          if (MODE == RR_PDOT) rb2[u][r] = bx2[off[r]];
+        }
+      }
+    }
+    if (z >= zb) {
+    // x-neighbours by lane shifts (every lane takes part)
+    double L0[NR], R0[NR], Rp[NR], Lm[NR];
+#pragma unroll
+    for (int r = 0; r < NR - 1; ++r) {
+      L0[r] = from_left(C0[r]);
+      Lm[r] = from_left(Cm[r]);
+    }
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+      R0[r] = from_right(C0[r]);
+      Rp[r] = from_right(Cp[r]);
+    }
+    const int tz = axis_type3(z, g.nz, g.z_lo_phys, g.z_hi_phys);
+#pragma unroll
+    for (int j = 0; j < RY; ++j) {
+      const int r = j + 1;
+      double v[15];
+      v[0] = C0[r];
+      v[1] = R0[r];
+      v[2] = L0[r];
+      v[3] = C0[r + 1];
+      v[4] = C0[r - 1];
+      v[5] = Cp[r];
+      v[6] = Cm[r];
+      v[7] = R0[r + 1];
+      v[8] = L0[r - 1];
+      v[9] = Cp[r + 1];
+      v[10] = Cm[r - 1];
+      v[11] = Rp[r];
+      v[12] = Lm[r];
+      v[13] = Rp[r + 1];
+      v[14] = Lm[r - 1];
+      if (x_out && row_in[r]) {
+        const int type = txy[r] + 9 * tz;
+        const int64_t gi = (int64_t)z * g.plane + (int64_t)(y0 + r) * g.nx + gx;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
+        if (MODE == RR_RHS) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+          double di = s_dinv[13];
+          if (type != 13) {
+            s = 0.0;
+            s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+              s = fma(s_tab[type * TABW + k], v[k], s);
+              s2 = fma(s_tab2[type * TABW + k], v[k], s2);
+            }
+            di = s_dinv[type];
+          }
+          double stim = 0.0;
+          for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
+          const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
+          const double rr = a.dt * (stim - s2);
+          const double zz = di * rr;
+          Y[gi] = rr;
+          if (Y2 != nullptr) Y2[gi] = v[0];
+          acc0 = fma(b, b, acc0);
+          acc1 = fma(rr, zz, acc1);
+          acc2 = fma(rr, rr, acc2);
+        } else {
+          double di = s_dinv[13];
+          if (type != 13) {
+            s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s = fma(s_tab[type * TABW + k], v[k], s);
+            di = s_dinv[type];
+          }
+          if (MODE == RR_PDOT) {
+            acc0 = fma(v[0], s, acc0);  // p . (A p)
+          } else {                      // r -= alpha (A p)
+            const double ri = fma(-alpha, s, rv[j]);
+            Y[gi] = ri;
+            acc0 = fma(ri * di, ri, acc0);
+            acc1 = fma(ri, ri, acc1);
+          }
+        }
+      }
+    }
+    }  // z >= zb
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      Cm[r] = C0[r];
+      C0[r] = Cp[r];
+    }
+    }  // z < ze
+  }
+  }
+
+  if (MODE == RR_PDOT) {
+    const double s0 = beat_block_sum(acc0, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = s0;
+  } else if (MODE == RR_RUPD) {
+    const double s0 = beat_block_sum(acc0, red);
+    const double s1 = beat_block_sum(acc1, red);
+    if (threadIdx.x == 0) {
+      a.partials[blockIdx.x] = s0;
+      a.partials[BEAT_MAX_PARTIALS + blockIdx.x] = s1;
+    }
+  } else {
+    const double s0 = beat_block_sum(acc0, red);
+    const double s1 = beat_block_sum(acc1, red);
+    const double s2 = beat_block_sum(acc2, red);
+    if (threadIdx.x == 0) {
+      a.partials[blockIdx.x] = s0;
+      a.partials[BEAT_MAX_PARTIALS + blockIdx.x] = s1;
+      a.partials[2 * BEAT_MAX_PARTIALS + blockIdx.x] = s2;
+    }
+  }
+}
+
+// scalar roll between K_B and the next K_A (beta, iteration count, convergence latch): pcg_next_kernel of beat_pde.hip
+__global__ void rr_next_kernel(double* st) {
+  if (st[STOP] != 0.0) return;
+  st[BETA] = st[RZN] / st[RZ];
+  st[RZ] = st[RZN];
+  st[RR] = st[RRN];
+  st[ITERS] += 1.0;
+  const double tr = st[RTOL] * st[RTOL] * st[BB];
+  if (st[RR] <= st[TOL2]) {
+    st[STOP] = 1.0;
+    st[REASON] = st[RR] <= tr ? 2.0 : 3.0;
+  } else if (st[ITERS] >= st[MAXIT]) {
+    st[STOP] = 1.0;
+    st[REASON] = -3.0;
+  }
+}
+
+int rr_rows() {
+  static const int ry = [] {
+    const char* e = std::getenv("BEAT_RR_RY");
+    const int v = e ? std::atoi(e) : 4;
+    return (v == 2 || v == 4) ? v : 4;
+  }();
+  return ry;
+}
+
+int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 3)
+  static const int pd = [] {
+    const char* e = std::getenv("BEAT_RR_PD");
+    const int v = e ? std::atoi(e) : 1;
+    return (v >= 1 && v <= 3) ? v : 1;
+  }();
+  return pd;
+}
+
+RGeom make_geom(const beat_pde* pde) {
+  const Geom& f = pde->g;
+  RGeom g{};
+  const int RY = g.ry = rr_rows();
+  g.nx = f.nx;
+  g.ny = f.ny;
+  g.nz = f.nz;
+  g.plane = f.plane;
+  g.z_lo_phys = f.z_lo_phys;
+  g.z_hi_phys = f.z_hi_phys;
+  g.nsegx = (f.nx + SEG - 1) / SEG;
+  g.nrb = (f.ny + RY - 1) / RY;
+  const int64_t per_layer = ((int64_t)g.nsegx * g.nrb + 3) / 4;  // blocks per z-chunk
+  int target = 4096;  // measured at 512^3: 1024 -> 12.3, 2048 -> 11.3, 4096 -> 11.0 ms per solve (before the store-wait fix)
+  if (const char* e = std::getenv("BEAT_RR_BLOCKS")) target = std::max(1, std::atoi(e));
+  int nchunks = (int)std::max<int64_t>(1, (target + per_layer - 1) / per_layer);
+  nchunks = std::min(nchunks, g.nz);
+  g.zc = (g.nz + nchunks - 1) / nchunks;
+  g.nchunks = (g.nz + g.zc - 1) / g.zc;
+  while ((int64_t)g.nsegx * g.nrb * g.nchunks > (int64_t)4 * BEAT_MAX_PARTIALS && g.nchunks > 1) {  // fewer, longer chunks
+    g.zc *= 2;
+    g.nchunks = (g.nz + g.zc - 1) / g.zc;
+  }
+  g.total_waves = g.nsegx * g.nrb * g.nchunks;
+  g.total_blocks = (g.total_waves + 3) / 4;
+  return g;
+}
+
+Coef interior_row(const double* tab) {
+  Coef c;
+  for (int k = 0; k < 15; ++k) c.c[k] = tab[13 * 15 + k];
+  return c;
+}
+
+template <int MODE>
+void launch_rr(const beat_pde* pde, const RGeom& g, const RArgs& a) {
+  const dim3 grid((unsigned)(((g.total_blocks + 7) / 8) * 8)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
+  hipStream_t s = pde->ctx->stream;
+#define BEAT_RR_LAUNCH(RYV, PDV) \
+  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV>), grid, block, 0, s, g, a, a.x, a.x2, a.y, a.y2)
+  const int pd = rr_prefetch();
+  if (g.ry == 2) {
+    if (pd == 2) BEAT_RR_LAUNCH(2, 2); else if (pd == 3) BEAT_RR_LAUNCH(2, 3); else BEAT_RR_LAUNCH(2, 1);
+  } else {
+    if (pd == 2) BEAT_RR_LAUNCH(4, 2); else if (pd == 3) BEAT_RR_LAUNCH(4, 3); else BEAT_RR_LAUNCH(4, 1);
+  }
+#undef BEAT_RR_LAUNCH
+}
+}  // namespace
+
+bool beat_rr_available(const beat_pde* pde) {
+  if (pde->var || pde->pc_ncoef != 1) return false;
+  if (const char* e = std::getenv("BEAT_RR")) {
+    if (e[0] == '0') return false;
+  }
+  const RGeom g = make_geom(pde);
+  return (int64_t)g.total_blocks + 8 <= BEAT_MAX_PARTIALS;
+}
+
+// Right-hand side in residual form (see beat_pde_rhs) without the p output.
+int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
+                int n_stim, double* dev_x, double* dev_r, double* dev_st) {
+  const RGeom g = make_geom(pde);
+  RArgs a{};
+  a.x = dev_v_prev;
+  a.y = dev_r;
+  a.y2 = (dev_x == dev_v_prev) ? nullptr : dev_x;
+  a.tab = pde->d_tab(2);
+  a.tab2 = pde->d_tab(3);
+  a.dinv = pde->d_dinv();
+  a.ci = interior_row(pde->h_mass);
+  a.ci2 = interior_row(pde->h_stiff);
+  a.dinv_i = pde->h_dinv[13];
+  a.cm = pde->C_m;
+  a.omt_dt = (1.0 - pde->theta) * pde->dt;
+  a.dt = pde->dt;
+  a.nstim = 0;
+  for (int k = 0; k < n_stim; ++k) {
+    if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
+    a.w[a.nstim] = host_dev_stim_w[k];
+    a.amp[a.nstim] = host_stim_amp[k];
+    ++a.nstim;
+  }
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  launch_rr<RR_RHS>(pde, g, a);
+  BEAT_LAUNCH_CHECK();
+  return beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 3, dev_st, nullptr);
+}
+
+// p_new = D^-1 r + st[BETA] p_old (p_old unread while beta = 0), LOCAL p_new . A p_new -> dev_st[PQ]
+int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new) {
+  const RGeom g = make_geom(pde);
+  RArgs a{};
+  a.x = dev_r;
+  a.x2 = dev_p_old;
+  a.y = dev_p_new;
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.ci = interior_row(pde->h_A);
+  a.dinv_i = pde->h_dinv[13];
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  launch_rr<RR_PDOT>(pde, g, a);
+  BEAT_LAUNCH_CHECK();
+  return beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 1, dev_st + PQ, dev_st);
+}
+
+// alpha = st[RZ]/st[PQ] (kept for `slot`); r_new = r - alpha A p (out of place); LOCAL r.D^-1 r, r.r ->
+// dev_st[RZN..RRN]; counts the update; then the scalar roll (beta, latch).
+int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot) {
+  const RGeom g = make_geom(pde);
+  RArgs a{};
+  a.x = dev_p;
+  a.x2 = dev_r;
+  a.y = dev_r_new;
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.ci = interior_row(pde->h_A);
+  a.dinv_i = pde->h_dinv[13];
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  a.alphas = pde->d_alphas;
+  a.slot = slot;
+  launch_rr<RR_RUPD>(pde, g, a);
+  BEAT_LAUNCH_CHECK();
+  const int rc = beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 2, dev_st + RZN, dev_st, dev_st + NUPD);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rr_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
