@@ -75,10 +75,10 @@ def init_states(ctx, states, ic, v_index, n_glob, slab, seed, nz_glob=None):
     cz = 0.5 * ((nz_glob or n_glob) - 1) * H
     for k in range(states.S):
         row = states.rows[k]
-        if k == v_index:
-            for iz in range(slab.nz):
-                r2 = (zc[iz] - cz) ** 2 + (yc[:, None] - c) ** 2 + (xc[None, :] - c) ** 2
-                row[iz * plane : (iz + 1) * plane] = (float(ic[k]) + 60.0 * torch.exp(-r2 / (2.0 * 2.0**2))).reshape(-1)
+        if k == v_index:  # one broadcast expression over the slab (no per-plane device copies)
+            r2 = (zc[:, None, None] - cz) ** 2 + (yc[None, :, None] - c) ** 2 + (xc[None, None, :] - c) ** 2
+            row.view(slab.nz, ny, nx).copy_(float(ic[k]) + 60.0 * torch.exp(-r2 / (2.0 * 2.0**2)))
+            del r2
         else:
             u = torch.rand(row.shape[0], generator=gen, device=ctx.device, dtype=torch.float64) * 2.0 - 1.0
             row.copy_(float(ic[k]) * (1.0 + 0.01 * u))
@@ -417,14 +417,18 @@ def main():
 
     if rank == 0:
         n_total = n * n * nz_glob
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (only quoted when this
-        # run has the configuration the counters were collected on)
-        traffic = None
-        tfile = ROOT / "profiles" / "r01_final_512_traffic.json"
+        # HBM bytes and VALU counters per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+        # very command (tools/measure_round2.sh -> profiles/r02_512_pmc.json); only quoted when this run has the
+        # configuration the counters were collected on
+        traffic, valu = None, None
+        tfile = ROOT / "profiles" / "r02_512_pmc.json"
         if tfile.is_file():
             tj = json.loads(tfile.read_text())
-            if tj.get("n") == n and nz_glob == n and tj.get("n_gpus") == world:
-                traffic = tj.get("hbm_bytes_per_launch")
+            cfg = tj.get("config", {})
+            kern = tj.get("kernels", {}).get("ode_step_kernel<Tp06Grl1, false, true>")
+            if cfg.get("n") == n and nz_glob == n and cfg.get("n_gpus") == world and kern:
+                traffic = kern.get("hbm_read_bytes", 0.0) + kern.get("hbm_write_bytes", 0.0)
+                valu = kern
         k_avg = float(np.mean(iters)) if iters else 0.0
         S = len(ic)
         # every state row read once + written once, plus one read per pending search direction of the previous
@@ -463,6 +467,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
+                # the yardstick above is the HBM roofline (the path is bandwidth-shaped); what actually limits THIS
+                # kernel is fp64 VALU issue: see "valu"
+                "limiter": "valu_fp64_issue",
                 "kernel": "ode_step_kernel<Tp06Grl1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -472,6 +479,15 @@ def main():
                 "algorithmic_bytes_per_launch": ode_bytes,
                 "bytes_per_node": 16.0 * S + 8.0 * k_pend,
                 "pending_directions_per_launch": k_pend,
+                "valu": None if valu is None else {
+                    "instr_per_node": valu["valu_instr_per_wave"],  # one node per lane: per-wave count = per-node count
+                    "valu_busy_frac": valu["valu_busy"],            # PMC: SIMD cycles spent issuing VALU
+                    # issue time of those instructions at the 2.4 GHz peak clock (4 cycles per wave64 fp64/32-bit
+                    # VALU op on a SIMD16) over the kernel time measured live in this run
+                    "frac_of_issue_peak": valu["valu_instr_per_wave"] * 4.0 * (n_local / 64.0) / (1024.0 * 2.4e9) / (ode_ms * 1e-3),
+                    "effective_clock_GHz": valu["gui_cycles_per_xcd"] / (valu["avg_us"] * 1e-6) / 1e9,
+                    "source": "profiles/r02_512_pmc.json (rocprofv3 SQ/GRBM pass of this command, tools/measure_round2.sh)",
+                },
                 "whole_step": {
                     "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,
                     "achieved": step_bytes * args.steps / wall / 1e9 / world,

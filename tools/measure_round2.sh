@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-2 measurement on the GPU box (run through gpurun from the repo root): the default bench line, then the SAME
+# bench command under rocprofv3 -- kernel trace + stats, and three PMC passes (FETCH_SIZE | WRITE_SIZE | SQ / GRBM
+# counters), each in its own run with the kernel trace only.  Results land in gpurun_out/prof_r02/; condense them with
+#   python tools/summarize_prof.py gpurun_out/prof_r02 profiles/r02_512.md "..." --json profiles/r02_512_pmc.json
+set -e
+R=$PWD
+O=$R/gpurun_out/prof_r02
+rm -rf $O
+mkdir -p $O
+timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O -o trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-front > $O/trace.json 2> $O/trace.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O -o pmc_fetch --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-front > $O/fetch.json 2> $O/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O -o pmc_write --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-front > $O/write.json 2> $O/write.log
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O -o pmc_sq --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-front > $O/sq.json 2> $O/sq.log
+rm -f $O/*kernel_trace.csv $O/*agent_info.csv
+# the counter files run to hundreds of MB: condense them here, keep the summaries and the kernel statistics
+cd $R
+python3 tools/summarize_prof.py $O $O/summary.md "Round 2: bench.py (512^3 TP06, 1 MI355X) under rocprofv3" --json $O/summary.json > /dev/null
+rm -f $O/*counter_collection.csv
+du -sh $O
+cat $O/summary.md
