@@ -391,8 +391,9 @@ def conductivity_array(M, mesh) -> np.ndarray:
     """(dim, dim) for a constant tensor, (ncells, dim, dim) for a per-cell field (grid.CellField or array)."""
     from . import _stencil, grid
 
-    if isinstance(M, grid.Function):
-        raise NotImplementedError("nodal conductivity fields are not implemented: pass the tensor per cell")
+    if isinstance(M, (grid.Function, grid.VectorFunction)):
+        raise TypeError("the conductivity is a tensor: build it from a fibre field with "
+                        "beat.conductivities.define_conductivity_tensor (vector P1 functions and per-cell fields are accepted)")
     if isinstance(M, grid.CellField):
         M = M.values
     if isinstance(M, grid.Constant):

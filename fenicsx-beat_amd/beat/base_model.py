@@ -67,12 +67,12 @@ class _CompiledStimulus:
         self.general = None
         if self.zero:
             self.amplitude = lambda: 0.0
-        elif self.facets is not None:
-            if sep is None or sep[0] is not None:
-                raise NotImplementedError("coordinate-dependent surface stimuli are not implemented")
-            temporal = sep[1]
+        elif self.facets is not None and sep is not None:
+            # any UFL expression on a surface measure (stimulation.py:14-24, base_model.py:247-248): the
+            # coordinate-dependent factor goes into the nodal weights by quadrature on the facets
+            spatial, temporal = sep
             self.field = model._ctx.field(mesh.num_nodes, mesh.plane)
-            self.field.set(assemble_facet_weights(mesh, self.facets))
+            self.field.set(assemble_facet_weights(mesh, self.facets, spatial))
             self.amplitude = (lambda: 1.0) if temporal is None else (lambda: float(temporal.evaluate()))
         elif sep is not None:
             spatial, temporal = sep
@@ -113,7 +113,10 @@ class _CompiledStimulus:
         return 1.0 if self._nonzero else 0.0
 
     def _refresh(self) -> float:
-        self.field.set(assemble_weights(self.model._mesh, self.cells, self.general))
+        if self.facets is not None:
+            self.field.set(assemble_facet_weights(self.model._mesh, self.facets, self.general))
+        else:
+            self.field.set(assemble_weights(self.model._mesh, self.cells, self.general))
         return 1.0
 
 

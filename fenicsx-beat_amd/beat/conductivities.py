@@ -57,8 +57,21 @@ def conductivity_tensor(s_l: float, s_t: float, f0):
     """``s_l f f^T + s_t (I - f f^T)`` for a constant direction (vector / ``grid.Constant``) or a per-cell field."""
     from . import grid
 
+    if isinstance(f0, grid.VectorFunction):
+        # fibre direction as a vector P1 function (geo.f0 of the reference's ventricular geometries): inside a
+        # simplex f = sum_a lambda_a f_a, so M(x) is quadratic and the stiffness integrals (constant gradients) see
+        # exactly its cell average   s_t I + (s_l - s_t) / ((d+1)(d+2)) sum_ab (1 + delta_ab) f_a f_b^T
+        mesh = f0.function_space.mesh
+        d = mesh.dim
+        if f0.function_space.value_size != d:
+            raise ValueError(f"fibre field has {f0.function_space.value_size} components on a {d}-D mesh")
+        verts = mesh.cell_vertices(np.arange(mesh.num_cells_global, dtype=np.int64))  # (ncells, d+1) global node ids
+        F = f0.values[verts]                                       # (ncells, d+1, d)
+        tot = F.sum(axis=1)
+        ff = (np.einsum("ci,cj->cij", tot, tot) + np.einsum("cai,caj->cij", F, F)) / ((d + 1) * (d + 2))
+        return grid.CellField(mesh, s_t * np.eye(d)[None] + (s_l - s_t) * ff)
     if isinstance(f0, grid.Function):
-        raise NotImplementedError("nodal fibre fields are not implemented: pass the fibres per cell (grid.CellField)")
+        raise NotImplementedError("scalar functions are not fibre fields: use a vector P1 function or a grid.CellField")
     if isinstance(f0, grid.CellField):
         fibres = f0.values
         eye = np.eye(fibres.shape[1])

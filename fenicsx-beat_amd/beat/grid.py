@@ -885,10 +885,65 @@ class FunctionSpace:
         return w[:, :1] * xyz[idx[:, 0]] + w[:, 1:] * xyz[idx[:, 1]]
 
 
-def functionspace(mesh: Mesh, element, **kw) -> FunctionSpace:
+class VectorFunctionSpace:
+    """``functionspace(mesh, ("P", 1, (dim,)))``: vector P1 -- the space of the fibre / sheet fields the reference's
+    geometries carry (``geo.f0``).  Its functions are host-side nodal data (:class:`VectorFunction`); they enter the
+    hot path only through the conductivity tensor, which is reduced to one tensor per simplex when the operators are
+    assembled."""
+
+    def __init__(self, mesh: Mesh, value_size: int):
+        if mesh.comm.size > 1:
+            raise NotImplementedError("nodal vector fields are implemented on one rank (pass the fibres per cell on several)")
+        self.mesh = mesh
+        self.value_size = int(value_size)
+        self.family, self.degree = "Lagrange", 1
+        self._element = _Element("Lagrange", 1)
+
+    def ufl_element(self):
+        return self._element
+
+    is_p1 = False
+
+    @property
+    def num_dofs(self) -> int:
+        return self.mesh.num_nodes_global * self.value_size
+
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        return self.mesh.node_coordinates(pad3=True)
+
+
+class VectorFunction:
+    """Vector P1 function: nodal values (num_nodes, value_size) on the host; ``x.array`` is the flat, node-major
+    (xyzxyz...) view dolfinx uses for blocked spaces."""
+
+    def __init__(self, V: VectorFunctionSpace, name: str = "f"):
+        self.function_space = V
+        self.name = name
+        self.values = np.zeros((V.mesh.num_nodes_global, V.value_size))
+        self._x = _CellVector(self.values.reshape(-1))
+
+    @property
+    def x(self):
+        return self._x
+
+    def interpolate(self, f) -> None:
+        """``f(x)`` with x of shape (3, num_nodes) returning (value_size, num_nodes), as dolfinx."""
+        x = self.function_space.tabulate_dof_coordinates().T
+        self.values[:] = np.asarray(f(x), dtype=np.float64).reshape(self.function_space.value_size, -1).T
+
+    def ufl_element(self):
+        return self.function_space.ufl_element()
+
+
+def functionspace(mesh: Mesh, element, **kw):
     if isinstance(element, _Element):
         return FunctionSpace(mesh, element.family_name, element.degree())
     family, degree = element[0], element[1]
+    if len(element) > 2 and element[2] not in (None, ()):  # ("P", 1, (dim,)): vector P1
+        shape = tuple(element[2])
+        if len(shape) != 1 or family not in ("P", "CG", "Lagrange") or degree != 1:
+            raise NotImplementedError(f"function space {element} is not implemented on the HIP backend")
+        return VectorFunctionSpace(mesh, shape[0])
     return FunctionSpace(mesh, family, degree)
 
 
@@ -1054,6 +1109,8 @@ class Function:
     the moment the two would diverge)."""
 
     def __new__(cls, V: FunctionSpace = None, *a, **kw):
+        if isinstance(V, VectorFunctionSpace):
+            return VectorFunction(V, *a, **kw)
         if V is not None and getattr(V, "family", None) == "DG" and V.degree == 0:
             return CellFunction(V, *a, **kw)
         return super().__new__(cls)

@@ -117,25 +117,40 @@ def _gauss_simplex(d: int, m: int = 5):
     return lam, w / w.sum()
 
 
-def assemble_facet_weights(mesh, facets) -> np.ndarray:
-    """Nodal weights  w_i = int_{facets} phi_i dS  on the LOCAL slab for exterior facets (stimulation.py:63-111,
-    the ``ds`` branch): an edge gives L/2 to both ends; a box-cell face is two triangles split along the diagonal
-    from its lowest to its highest corner, which therefore get A/3 each and the other two corners A/6."""
+def assemble_facet_weights(mesh, facets, spatial: grid.Expr | None = None) -> np.ndarray:
+    """Nodal weights  w_i = int_{facets} f phi_i dS  on the LOCAL slab for exterior facets (stimulation.py:63-111,
+    the ``ds`` branch; ``f`` = the coordinate-dependent factor ``spatial`` of the stimulus expression or 1): an edge
+    gives L/2 to both ends; a box-cell face is two triangles split along the diagonal from its lowest to its highest
+    corner, which therefore get A/3 each and the other two corners A/6.  With a spatial factor the integrals are
+    taken by Gauss quadrature on every edge / triangle (as UFL does for a non-constant integrand)."""
     facets = np.asarray(facets, dtype=np.int64)
     verts = mesh.facet_vertices(facets)
     area = mesh.facet_area(facets)
-    if mesh.dim == 2:
-        share = np.array([0.5, 0.5])
-    elif mesh.dim == 3:
-        share = np.array([1.0 / 3.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 3.0])
-    else:
+    if mesh.dim not in (2, 3):
         raise ValueError("facet integrals need a 2-D or 3-D mesh")
     w = np.zeros(mesh.num_nodes)
     lo, hi = mesh.slab.z0 * mesh.plane, mesh.slab.z1 * mesh.plane
-    v = verts.ravel()
-    c = (area[:, None] * share[None, :]).ravel()
-    sel = (v >= lo) & (v < hi)
-    np.add.at(w, v[sel] - lo, c[sel])
+    if spatial is None:
+        share = np.array([0.5, 0.5]) if mesh.dim == 2 else np.array([1.0 / 3.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 3.0])
+        v = verts.ravel()
+        c = (area[:, None] * share[None, :]).ravel()
+        sel = (v >= lo) & (v < hi)
+        np.add.at(w, v[sel] - lo, c[sel])
+        return w
+    # simplices of the facets: the edge itself, or the two triangles of a face (each half its area)
+    if mesh.dim == 2:
+        simplices, meas = [verts], [area]
+    else:
+        simplices, meas = [verts[:, [0, 1, 3]], verts[:, [0, 2, 3]]], [0.5 * area, 0.5 * area]
+    lam, wq = _gauss_simplex(mesh.dim - 1)
+    for sv, m in zip(simplices, meas):
+        X = grid._node_xyz(mesh, sv.ravel()).reshape(sv.shape + (3,))
+        xq = np.einsum("qa,cad->dcq", lam, X)  # (3, nfacets, nq)
+        fq = np.broadcast_to(np.asarray(spatial.evaluate(xq), dtype=np.float64), xq.shape[1:])
+        contrib = m[:, None] * np.einsum("cq,q,qa->ca", fq, wq, lam)
+        v, c = sv.ravel(), contrib.ravel()
+        sel = (v >= lo) & (v < hi)
+        np.add.at(w, v[sel] - lo, c[sel])
     return w
 
 

@@ -217,6 +217,50 @@ def exterior_facet_weights(mesh: BoxMesh, active_cells=None, node_ok=None, facet
     return w
 
 
+def exterior_facet_load(mesh: BoxMesh, f, active_cells=None, node_ok=None, facet_filter=None, m: int = 6) -> np.ndarray:
+    """b_i = int_{exterior facets} f(x) phi_i dS (a UFL expression times the test function on a ``ds`` measure:
+    stimulation.py:14-24, base_model.py:247-248), f taking x of shape (dim, npts); same facet selection as
+    ``exterior_facet_weights``; Gauss rule of 2m-(d-1) exactness on every exterior edge / triangle."""
+    d = mesh.dim
+    cells = mesh.cells if active_cells is None else mesh.cells[np.asarray(active_cells, dtype=bool)]
+    faces = np.concatenate([np.delete(cells, k, axis=1) for k in range(d + 1)], axis=0)
+    faces = np.sort(faces, axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    ext = uniq[counts == 1]
+    if node_ok is not None:
+        ext = ext[np.asarray(node_ok, dtype=bool)[ext].all(axis=1)]
+    if facet_filter is not None:
+        ext = ext[np.asarray(facet_filter(mesh.x[ext]), dtype=bool)]
+    X = mesh.x[ext]  # (nf, d, dim)
+    if d == 2:
+        meas = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+    else:
+        meas = 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+    lam, w = _simplex_quadrature(d - 1, m)
+    w = w / w.sum()
+    xq = np.einsum("qa,fad->fqd", lam, X)
+    fq = np.asarray(f(xq.reshape(-1, d).T)).reshape(xq.shape[0], -1)
+    loc = np.einsum("fq,q,qa->fa", fq, w, lam) * meas[:, None]
+    b = np.zeros(mesh.num_nodes)
+    np.add.at(b, ext.ravel(), loc.ravel())
+    return b
+
+
+def assemble_stiffness_nodal_fibres(mesh: BoxMesh, f_nodal: np.ndarray, s_l: float, s_t: float, m: int = 4) -> sp.csr_matrix:
+    """K_ij = int (s_l f f^T + s_t (I - f f^T)) grad phi_j . grad phi_i dx with the fibre direction f a vector P1
+    FUNCTION (nodal values ``f_nodal`` (num_nodes, dim), interpolated linearly inside every simplex -- the UFL
+    expression conductivities.py:101-104 builds from ``geo.f0``), integrated by quadrature at the points of every
+    simplex (not by averaging the tensor in closed form, which is what the product does)."""
+    d = mesh.dim
+    lam, w = _simplex_quadrature(d, m)
+    w = w / w.sum()
+    F = np.asarray(f_nodal, dtype=np.float64)[mesh.cells]  # (nc, d+1, d)
+    fq = np.einsum("qa,cad->cqd", lam, F)                  # fibre at the quadrature points
+    ff = np.einsum("cqi,cqj,q->cij", fq, fq, w)            # cell average of f f^T
+    Mbar = s_t * np.eye(d)[None] + (s_l - s_t) * ff
+    return assemble_stiffness(mesh, Mbar)
+
+
 # Degree-precision quadrature used only to integrate smooth manufactured sources and
 # L2 errors (the reference lets UFL pick a degree / uses quadrature_degree=8).
 def _simplex_quadrature(d: int, m: int = 6):

@@ -686,3 +686,131 @@ def test_expand_layer_biv():
     assert np.allclose(g.evaluate_function(markers, endo_points), 3)
     assert np.allclose(g.evaluate_function(markers, mid_points), 4)
     assert np.allclose(g.evaluate_function(markers, epi_points), 1)
+
+
+# ---- UFL expressions on surface measures; fibre fields given as vector P1 functions ---------------------------------
+@pytest.mark.parametrize("dim", [2, 3])
+def test_coordinate_dependent_surface_stimulus_matches_oracle(dim):
+    """stimulation.py:14-24 / base_model.py:247-248: a Stimulus is ANY expression times the test function on a measure,
+    also a coordinate-dependent one on a surface (``ds``) measure.  Separable expression f(x) g(t): the nodal load
+    equals the oracle's Gauss integration of f phi_i over the exterior simplices (independent quadrature code), and
+    three theta-steps match the oracle's assembled solve; an expression that mixes x and t inside one factor is
+    re-integrated every step."""
+    import beat
+    from beat import grid as g
+    from oracle import fem
+
+    if dim == 2:
+        cells, L = (14, 9), (1.4, 0.9)
+        mesh = g.create_rectangle(g.COMM_WORLD, [(0.0, 0.0), L], cells)
+    else:
+        cells, L = (9, 7, 5), (0.9, 0.7, 0.5)
+        mesh = g.create_box(g.COMM_WORLD, [(0.0, 0.0, 0.0), L], cells)
+    fdim = mesh.topology.dim - 1
+    facets = g.locate_entities_boundary(mesh, fdim, lambda x: x[0] <= 1e-10)  # the face x = 0
+    ft = g.meshtags(mesh, fdim, np.sort(facets), np.full(len(facets), 3, dtype=np.int32))
+    ds = g.Measure("ds", domain=mesh, subdomain_data=ft)  # restricted to the tagged face by the Stimulus' marker
+    time = g.Constant(mesh, 0.0)
+    x = g.SpatialCoordinate(mesh)
+    t = g.variable(time)
+    spatial = 1.0 + g.sin(3.0 * x[1]) * (x[dim - 1] + 0.25)
+    expr = spatial * (2.0 + g.cos(t))
+    M = 0.02 * np.eye(dim) + 0.01 * np.ones((dim, dim))
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=beat.stimulation.Stimulus(expr=expr, dZ=ds, marker=3), C_m=1.0,
+                               params={"petsc_options": {"ksp_rtol": 1e-13}})
+    omesh = fem.BoxMesh(cells, L)
+    on_face = np.abs(omesh.x[:, 0]) < 1e-10
+    f = lambda X: 1.0 + np.sin(3.0 * X[1]) * (X[dim - 1] + 0.25)  # noqa: E731
+    w_ref = fem.exterior_facet_load(omesh, f, node_ok=on_face)
+    w = pde._stimuli[0].field.numpy()
+    assert np.abs(w_ref).max() > 0 and np.all(w[~on_face] == 0.0)
+    np.testing.assert_allclose(w, w_ref, rtol=1e-11, atol=1e-15)
+    model = fem.OracleMonodomainModel(omesh, M, [fem.OracleStimulus(lambda tt: 2.0 + np.cos(tt), w_ref)], C_m=1.0, theta=0.5)
+    dt = 0.05
+    for i in range(3):
+        pde.step((i * dt, (i + 1) * dt))
+        pde.assign_previous()
+        model.step((i * dt, (i + 1) * dt))
+        model.assign_previous()
+    v = np.asarray(pde.state.x.array)
+    assert np.abs(v).max() > 1e-3
+    np.testing.assert_allclose(v, model.state, rtol=0, atol=1e-11 * np.abs(model.state).max())
+
+    # x and t inside one factor: no separation possible, the facet integral is taken again at every step
+    time2 = g.Constant(mesh, 0.0)
+    expr2 = g.sin(2.0 * x[1] + g.variable(time2))
+    pde2 = beat.MonodomainModel(time=time2, mesh=mesh, M=M, I_s=beat.stimulation.Stimulus(expr=expr2, dZ=ds, marker=3), C_m=1.0,
+                                params={"petsc_options": {"ksp_rtol": 1e-13}})
+    model2 = fem.OracleMonodomainModel(omesh, M, [], C_m=1.0, theta=0.5)
+    for i in range(3):
+        tm = (i + 0.5) * dt  # theta = 0.5: the form is evaluated at t0 + theta dt (base_model.py:216-223)
+        model2.stimuli = [fem.OracleStimulus(lambda tt: 1.0, fem.exterior_facet_load(omesh, lambda X, tm=tm: np.sin(2.0 * X[1] + tm),
+                                                                                     node_ok=on_face))]
+        pde2.step((i * dt, (i + 1) * dt))
+        pde2.assign_previous()
+        model2.step((i * dt, (i + 1) * dt))
+        model2.assign_previous()
+    np.testing.assert_allclose(np.asarray(pde2.state.x.array), model2.state, rtol=0, atol=1e-11 * np.abs(model2.state).max())
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_nodal_fibre_function_conductivity_matches_quadrature_assembly(hip_ctx, dim):
+    """conductivities.py:101-118 with ``f0`` a vector P1 FUNCTION (the reference's ``geo.f0``): M(x) = s_l f f^T +
+    s_t (I - f f^T) varies inside every simplex.  The operators (per-node rows from the closed-form cell average of
+    the tensor) equal the oracle's stiffness matrix integrated by quadrature at the points of every simplex, and a
+    theta-step matches the assembled sparse solve."""
+    import beat
+    from beat import grid as g
+    from oracle import fem
+
+    ctx = hip_ctx
+    if dim == 2:
+        cells, L = (12, 10), (1.2, 1.0)
+        mesh = g.create_rectangle(g.COMM_WORLD, [(0.0, 0.0), L], cells)
+    else:
+        cells, L = (8, 7, 6), (0.8, 0.7, 0.6)
+        mesh = g.create_box(g.COMM_WORLD, [(0.0, 0.0, 0.0), L], cells)
+    V = g.functionspace(mesh, ("P", 1, (dim,)))
+    f0 = g.Function(V)
+
+    def fibres(x):  # rotating, normalised at the nodes
+        ang = 0.4 + 2.0 * x[0] + 1.5 * x[1] * x[1] + (0.7 * x[2] if dim == 3 else 0.0)
+        comp = [np.cos(ang), np.sin(ang)] + ([0.3 * np.sin(3.0 * x[0])] if dim == 3 else [])
+        F = np.array(comp)
+        return F / np.linalg.norm(F, axis=0)
+
+    f0.interpolate(fibres)
+    assert f0.x.array.shape == (mesh.num_nodes_global * dim,)
+    cond = beat.conductivities.default_conductivities("Niederer")
+    s_l, s_t = beat.conductivities.get_harmonic_mean_conductivity(**cond)
+    M = beat.conductivities.define_conductivity_tensor(f0=f0, **cond)
+    time = g.Constant(mesh, 0.0)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, C_m=0.01, params={"petsc_options": {"ksp_rtol": 1e-13}})
+    omesh = fem.BoxMesh(cells, L)
+    np.testing.assert_allclose(omesh.x, mesh.node_coordinates(pad3=False), atol=1e-14)
+    K = fem.assemble_stiffness_nodal_fibres(omesh, fibres(omesh.x.T).T, s_l, s_t, m=4)
+    Mass = fem.assemble_mass(omesh)
+    ops = pde._ops
+    n = omesh.num_nodes
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(n)
+    fx, fy = ops.new_field(), ops.new_field()
+    fx.set(x)
+    ops.apply(3, fx, fy)
+    ctx.synchronize()
+    ref = K @ x
+    assert np.abs(fy.numpy() - ref).max() <= 1e-12 * (abs(K) @ np.ones(n)).max() * np.abs(x).max()
+    # a constant fibre field would give a different operator: the variation inside the cells matters
+    K0 = fem.assemble_stiffness(omesh, s_l * np.outer(fibres(np.zeros((3, 1)))[:, 0], fibres(np.zeros((3, 1)))[:, 0])
+                                + s_t * (np.eye(dim) - np.outer(fibres(np.zeros((3, 1)))[:, 0], fibres(np.zeros((3, 1)))[:, 0])))
+    assert np.abs((K0 - K) @ x).max() > 1e-3 * np.abs(ref).max()
+    # one theta-step against the sparse direct solve
+    import scipy.sparse.linalg as spla
+
+    v0 = -80.0 + 30.0 * np.exp(-((omesh.x - 0.4) ** 2).sum(axis=1) / 0.05)
+    pde.v_.x.array[:] = v0
+    dt, theta, C_m = 0.05, 0.5, 0.01
+    pde.step((0.0, dt))
+    A = (C_m * Mass + theta * dt * K).tocsc()
+    b = (C_m * Mass - (1 - theta) * dt * K) @ v0
+    np.testing.assert_allclose(np.asarray(pde.state.x.array), spla.spsolve(A, b), rtol=0, atol=1e-9 * np.abs(v0).max())
