@@ -598,6 +598,11 @@ class DiffusionSolver:
         self.group = group
         self._last_its = 8
         self.libcomm = libcomm
+        if isinstance(ops, HipOps) and slab.world > 1 and hasattr(slab, "nz_global"):
+            # z type of the ghost planes: a face of the whole grid when the neighbour owns just that one plane
+            lo = 0 if (not slab.lo_phys and slab.z0 - 1 == 0) else 1
+            hi = 2 if (not slab.hi_phys and slab.z1 == slab.nz_global - 1) else 1
+            _hip.check(ops.lib.beat_pde_set_ghost_types(ops.handle, lo, hi))
         if stage_driven is None:
             stage_driven = os.environ.get("BEAT_STAGE_DRIVEN", "0") == "1"
         if slab.world > 1 or force_distributed:  # force_distributed: run the collective path on 1 rank (tests)

@@ -110,6 +110,7 @@ UNIQUE_ID_BYTES = 128
 E_NOT_CONVERGED = -3
 
 SIGNATURES.update({
+    "beat_pde_set_ghost_types": (_int, [_vp, _int, _int]),
     "beat_comm_unique_id": (_int, [_vp]),
     "beat_comm_create_rccl": (_int, [_vp, _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
     "beat_comm_create_callbacks": (_int, [_vp, _int, _int, _int, _int, HALO_FN, ALLREDUCE_FN, _vp, C.POINTER(_vp)]),

@@ -245,20 +245,49 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   double* st = pde->d_st;
   double* h = ctx->h_pinned;
   int rc;
+  const bool rr = beat_rr_available(pde);  // constant coefficients: the kernels that never store q = A p
   // ghost planes of v_ for the right-hand side (the reference's scatter_forward after the previous solve)
   if ((rc = halo_start(comm, const_cast<double*>(dev_v_prev), n, plane))) return rc;
   if ((rc = halo_wait(comm))) return rc;
-  if ((rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st))) return rc;
+  if (rr) {
+    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+  } else {
+    rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
+  }
+  if (rc) return rc;
   if ((rc = allreduce_sum(comm, st + BB, 3))) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
   int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
+  if (rr && (rc = halo_start(comm, rbuf[0], n, plane))) return rc;  // ghost planes of r_0
   while (true) {
     chunk = std::min(chunk, max_it - launched);
     for (int it = 0; it < chunk; ++it) {
       const int i = launched + it, slot = i % PRING;
       double* p_cur = ring + (int64_t)slot * fld;
       double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
+      if (rr) {
+        // p_i = D^-1 r_i + beta p_{i-1} and p_i . A p_i: the planes that need no ghost data while the ghost planes of
+        // r_i travel, then the boundary planes, which also keep p_i on the ghost planes (no exchange of p)
+        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        double* r_cur = rbuf[i & 1];
+        double* r_new = rbuf[(i + 1) & 1];
+        if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 0))) return rc;
+        if ((rc = halo_wait(comm))) return rc;
+        if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 1))) return rc;
+        if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
+        if ((rc = beat_rr_rupd(pde, st, r_cur, r_new, p_cur, slot, false))) return rc;  // r_{i+1}, local r.z and r.r
+        if ((rc = halo_start(comm, r_new, n, plane))) return rc;  // travels behind the reductions and the next part 0
+        if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
+        if (slot == PRING - 1) {
+          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+        }
+        if ((rc = beat_rr_next(pde, st))) return rc;
+        continue;
+      }
       if ((rc = halo_start(comm, p_cur, n, plane))) return rc;                  // ghost planes of p travel ...
       if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 0))) return rc;       // ... while the interior is computed
       if ((rc = halo_wait(comm))) return rc;
@@ -276,6 +305,9 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (h[STOP] != 0.0 || launched >= max_it) break;
     chunk = 2;
+  }
+  if (rr) {  // the exchange started after the last residual update has no consumer: drain it before anything else
+    if ((rc = halo_wait(comm))) return rc;  // touches those ghost planes
   }
   const int nupd = (int)h[NUPD];
   if (nupd % PRING != 0) {

@@ -612,6 +612,14 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
 }
 
 
+extern "C" int beat_pde_set_ghost_types(beat_pde* pde, int ghost_lo_type, int ghost_hi_type) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(ghost_lo_type >= 0 && ghost_lo_type <= 2 && ghost_hi_type >= 0 && ghost_hi_type <= 2, "node types are 0, 1 or 2");
+  pde->ghost_lo_tz = ghost_lo_type;
+  pde->ghost_hi_tz = ghost_hi_type;
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_destroy(beat_pde* pde) {
   if (pde == nullptr) return BEAT_OK;
   (void)hipFree(pde->d_tabs);

@@ -43,6 +43,9 @@ struct beat_pde {
   int last_iters = -1;
   unsigned vec_grid = 1;
   double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
+  // z node type of the ghost planes (the neighbouring slabs' boundary planes): 1 unless that plane is a face of the
+  // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
+  int ghost_lo_tz = 1, ghost_hi_tz = 1;
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
   // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
@@ -81,4 +84,8 @@ bool beat_rr_available(const beat_pde* pde);
 int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
                 int n_stim, double* dev_x, double* dev_r, double* dev_st);
 int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new);
-int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot);
+int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
+                      int part);
+int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot,
+                 bool roll = true);
+int beat_rr_next(beat_pde* pde, double* dev_st);

@@ -39,6 +39,9 @@ struct RGeom {
   int nsegx, nrb, nchunks, zc;
   int total_waves, total_blocks;
   int z_lo_phys, z_hi_phys;
+  int z_lo, z_hi;                  // planes [z_lo, z_hi) computed by this launch (whole slab: 0, nz)
+  int part_off;                    // first block-partial slot this launch writes
+  int ghost_lo_tz, ghost_hi_tz;    // z node type (0 low face, 1 interior, 2 high face) of the ghost planes -1 / nz
 };
 
 enum { RR_PDOT = 0, RR_RUPD = 1, RR_RHS = 2 };
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
   const int chunk = w / (g.nsegx * g.nrb);
   const int gx = seg * SEG - 1 + lane;
   const int y0 = rb * RY - 1;  // global row of register row 0
-  const int zb = chunk * g.zc;
-  const int ze = wave_ok ? min(zb + g.zc, g.nz) : zb;
+  const int zb = g.z_lo + chunk * g.zc;
+  const int ze = wave_ok ? min(zb + g.zc, g.z_hi) : zb;
   const bool x_in = wave_ok && gx >= 0 && gx < g.nx;
   const bool x_out = x_in && lane >= 1 && lane <= SEG;  // this lane produces outputs
   const int tx = axis_type3(gx, g.nx, 1, 1);
@@ -170,8 +173,11 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
     const int k = z + 1;  // plane whose raw values (slot u) become the staged plane z+1 now
     if (k >= zb - 1 && k <= ze) {  // staged values of plane k; PDOT forms p_new here and stores the rows this wave owns
       const bool zok = (k >= 0 || !g.z_lo_phys) && (k < g.nz || !g.z_hi_phys);
-      const int tz9 = 9 * axis_type3(k, g.nz, g.z_lo_phys, g.z_hi_phys);
-      const bool own_plane = k >= zb && k < ze;
+      // ghost planes (another rank's boundary planes): their z type comes with the geometry; PDOT keeps p_new there
+      // too -- both neighbours form it from the same exchanged r and the same p_old, so it needs no exchange of its own
+      const int tz9 = 9 * (k < 0 ? g.ghost_lo_tz : k >= g.nz ? g.ghost_hi_tz : axis_type3(k, g.nz, g.z_lo_phys, g.z_hi_phys));
+      const bool own_plane = (k >= zb && k < ze) || (k == -1 && zb == 0 && !g.z_lo_phys) ||
+                             (k == g.nz && ze == g.nz && !g.z_hi_phys);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         double c = ra[u][r];
@@ -307,22 +313,22 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
 
   if (MODE == RR_PDOT) {
     const double s0 = beat_block_sum(acc0, red);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = s0;
+    if (threadIdx.x == 0) a.partials[g.part_off + blockIdx.x] = s0;
   } else if (MODE == RR_RUPD) {
     const double s0 = beat_block_sum(acc0, red);
     const double s1 = beat_block_sum(acc1, red);
     if (threadIdx.x == 0) {
-      a.partials[blockIdx.x] = s0;
-      a.partials[BEAT_MAX_PARTIALS + blockIdx.x] = s1;
+      a.partials[g.part_off + blockIdx.x] = s0;
+      a.partials[BEAT_MAX_PARTIALS + g.part_off + blockIdx.x] = s1;
     }
   } else {
     const double s0 = beat_block_sum(acc0, red);
     const double s1 = beat_block_sum(acc1, red);
     const double s2 = beat_block_sum(acc2, red);
     if (threadIdx.x == 0) {
-      a.partials[blockIdx.x] = s0;
-      a.partials[BEAT_MAX_PARTIALS + blockIdx.x] = s1;
-      a.partials[2 * BEAT_MAX_PARTIALS + blockIdx.x] = s2;
+      a.partials[g.part_off + blockIdx.x] = s0;
+      a.partials[BEAT_MAX_PARTIALS + g.part_off + blockIdx.x] = s1;
+      a.partials[2 * BEAT_MAX_PARTIALS + g.part_off + blockIdx.x] = s2;
     }
   }
 }
@@ -362,7 +368,8 @@ int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 
   return pd;
 }
 
-RGeom make_geom(const beat_pde* pde) {
+// Decomposition of the planes [z_lo, z_hi) of the slab into waves; block partials are written from slot part_off on.
+RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off) {
   const Geom& f = pde->g;
   RGeom g{};
   const int RY = g.ry = rr_rows();
@@ -372,23 +379,33 @@ RGeom make_geom(const beat_pde* pde) {
   g.plane = f.plane;
   g.z_lo_phys = f.z_lo_phys;
   g.z_hi_phys = f.z_hi_phys;
+  g.z_lo = z_lo;
+  g.z_hi = z_hi;
+  g.part_off = part_off;
+  g.ghost_lo_tz = pde->ghost_lo_tz;
+  g.ghost_hi_tz = pde->ghost_hi_tz;
   g.nsegx = (f.nx + SEG - 1) / SEG;
   g.nrb = (f.ny + RY - 1) / RY;
+  const int nzr = std::max(0, z_hi - z_lo);
   const int64_t per_layer = ((int64_t)g.nsegx * g.nrb + 3) / 4;  // blocks per z-chunk
   int target = 4096;  // measured at 512^3: 1024 -> 12.3, 2048 -> 11.3, 4096 -> 11.0 ms per solve (before the store-wait fix)
   if (const char* e = std::getenv("BEAT_RR_BLOCKS")) target = std::max(1, std::atoi(e));
   int nchunks = (int)std::max<int64_t>(1, (target + per_layer - 1) / per_layer);
-  nchunks = std::min(nchunks, g.nz);
-  g.zc = (g.nz + nchunks - 1) / nchunks;
-  g.nchunks = (g.nz + g.zc - 1) / g.zc;
-  while ((int64_t)g.nsegx * g.nrb * g.nchunks > (int64_t)4 * BEAT_MAX_PARTIALS && g.nchunks > 1) {  // fewer, longer chunks
+  nchunks = std::max(1, std::min(nchunks, nzr));
+  g.zc = std::max(1, (nzr + nchunks - 1) / nchunks);
+  g.nchunks = (nzr + g.zc - 1) / g.zc;
+  while ((int64_t)g.nsegx * g.nrb * g.nchunks > (int64_t)2 * BEAT_MAX_PARTIALS && g.nchunks > 1) {  // fewer, longer chunks
     g.zc *= 2;
-    g.nchunks = (g.nz + g.zc - 1) / g.zc;
+    g.nchunks = (nzr + g.zc - 1) / g.zc;
   }
   g.total_waves = g.nsegx * g.nrb * g.nchunks;
   g.total_blocks = (g.total_waves + 3) / 4;
   return g;
 }
+
+RGeom make_geom(const beat_pde* pde) { return make_geom(pde, 0, pde->g.nz, 0); }
+
+inline int grid_blocks(const RGeom& g) { return ((g.total_blocks + 7) / 8) * 8; }
 
 Coef interior_row(const double* tab) {
   Coef c;
@@ -398,7 +415,8 @@ Coef interior_row(const double* tab) {
 
 template <int MODE>
 void launch_rr(const beat_pde* pde, const RGeom& g, const RArgs& a) {
-  const dim3 grid((unsigned)(((g.total_blocks + 7) / 8) * 8)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
+  if (g.total_blocks <= 0) return;
+  const dim3 grid((unsigned)grid_blocks(g)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
   hipStream_t s = pde->ctx->stream;
 #define BEAT_RR_LAUNCH(RYV, PDV) \
   hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV>), grid, block, 0, s, g, a, a.x, a.x2, a.y, a.y2)
@@ -418,7 +436,8 @@ bool beat_rr_available(const beat_pde* pde) {
     if (e[0] == '0') return false;
   }
   const RGeom g = make_geom(pde);
-  return (int64_t)g.total_blocks + 8 <= BEAT_MAX_PARTIALS;
+  const RGeom gb = make_geom(pde, 0, 1, 0);  // a one-plane boundary launch of the decomposed solve
+  return (int64_t)grid_blocks(g) + 2 * grid_blocks(gb) <= BEAT_MAX_PARTIALS;
 }
 
 // Right-hand side in residual form (see beat_pde_rhs) without the p output.
@@ -449,12 +468,16 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   a.st = dev_st;
   launch_rr<RR_RHS>(pde, g, a);
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 3, dev_st, nullptr);
+  return beat_pde_launch_reduce(pde, grid_blocks(g), 3, dev_st, nullptr);
 }
 
-// p_new = D^-1 r + st[BETA] p_old (p_old unread while beta = 0), LOCAL p_new . A p_new -> dev_st[PQ]
-int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new) {
-  const RGeom g = make_geom(pde);
+// p_new = D^-1 r + st[BETA] p_old (p_old unread while beta = 0), LOCAL p_new . A p_new -> dev_st[PQ].
+// In two parts on a decomposed grid (as beat_pde_spmv_dot_part): part 0 = the planes whose stencil needs no ghost
+// plane (enqueue it while the ghost planes of r travel), part 1 = the one or two slab-boundary planes -- which also
+// keep p_new on the ghost planes next to them -- and the reduction of all block partials.
+int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
+                      int part) {
+  const Geom& f = pde->g;
   RArgs a{};
   a.x = dev_r;
   a.x2 = dev_p_old;
@@ -465,14 +488,39 @@ int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const doubl
   a.dinv_i = pde->h_dinv[13];
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
-  launch_rr<RR_PDOT>(pde, g, a);
+  const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0);
+  if (part == 0) {
+    launch_rr<RR_PDOT>(pde, gi, a);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
+  int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
+  if (!f.z_lo_phys) {
+    const RGeom gb = make_geom(pde, 0, 1, off);
+    launch_rr<RR_PDOT>(pde, gb, a);
+    off += grid_blocks(gb);
+  }
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) {
+    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off);
+    launch_rr<RR_PDOT>(pde, gb, a);
+    off += grid_blocks(gb);
+  }
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 1, dev_st + PQ, dev_st);
+  BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+  return beat_pde_launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
 }
 
-// alpha = st[RZ]/st[PQ] (kept for `slot`); r_new = r - alpha A p (out of place); LOCAL r.D^-1 r, r.r ->
-// dev_st[RZN..RRN]; counts the update; then the scalar roll (beta, latch).
-int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot) {
+int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new) {
+  if (int rc = beat_rr_pdot_part(pde, dev_st, dev_r, dev_p_old, dev_p_new, 0)) return rc;
+  return beat_rr_pdot_part(pde, dev_st, dev_r, dev_p_old, dev_p_new, 1);
+}
+
+// alpha = st[RZ]/st[PQ] (kept for `slot`); r_new = r - alpha A p (out of place; ghost planes of p current); LOCAL
+// r.D^-1 r, r.r -> dev_st[RZN..RRN]; counts the update; with `roll` the scalar roll (beta, latch) follows -- a
+// decomposed solve all-reduces dev_st[RZN..RRN] first and calls beat_rr_next itself.
+int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot,
+                 bool roll) {
   const RGeom g = make_geom(pde);
   RArgs a{};
   a.x = dev_p;
@@ -488,8 +536,12 @@ int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev
   a.slot = slot;
   launch_rr<RR_RUPD>(pde, g, a);
   BEAT_LAUNCH_CHECK();
-  const int rc = beat_pde_launch_reduce(pde, (int)(((g.total_blocks + 7) / 8) * 8), 2, dev_st + RZN, dev_st, dev_st + NUPD);
-  if (rc) return rc;
+  const int rc = beat_pde_launch_reduce(pde, grid_blocks(g), 2, dev_st + RZN, dev_st, dev_st + NUPD);
+  if (rc || !roll) return rc;
+  return beat_rr_next(pde, dev_st);
+}
+
+int beat_rr_next(beat_pde* pde, double* dev_st) {
   hipLaunchKernelGGL(rr_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;

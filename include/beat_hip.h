@@ -177,6 +177,11 @@ int beat_rows_apply_dirichlet(beat_ctx* ctx, const int64_t n[3], double* dev_row
 int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_phys, int z_hi_phys,
                         const double* dev_mass, const double* dev_stiff, int64_t ld, beat_pde** out);
 int beat_pde_destroy(beat_pde* pde);
+/* Node type along z (0 = low face of the whole grid, 1 = interior, 2 = high face) of the two ghost planes of a slab
+ * whose z faces are not physical: 1 unless the neighbouring rank owns a single plane that is itself a face of the
+ * grid.  Needed by the decomposed constant-coefficient solve, which forms the search direction on the ghost planes
+ * itself (D^-1 there depends on the type).  Default (1, 1). */
+int beat_pde_set_ghost_types(beat_pde* pde, int ghost_lo_type, int ghost_hi_type);
 /* (dx,dy,dz) of the 15 stencil points, 45 ints. */
 const int* beat_stencil_offsets(void);
 /* A = C_m*Mass + theta*dt*K ; B = C_m*Mass - (1-theta)*dt*K  (base_model.py:188-194, called
@@ -315,9 +320,12 @@ int beat_comm_allreduce_sum(beat_comm* comm, double* dev_values, int count);
 /* beat_pde_solve_ex on a decomposed grid: same arguments, results and deferred-flush contract; every rank calls
  * it with its own slab handle (z_lo_phys / z_hi_phys = whether peer_lo / peer_hi is absent).  Per iteration: ghost
  * planes of p travel on the side stream while q = A p is computed on the planes that need none, then the one or
- * two boundary planes; all-reduce of p.q; r -= alpha q; all-reduce of (r.z, r.r); p = z + beta p.  The host
- * enqueues as many iterations as the previous solve needed and reads the device-side convergence latch once
- * (iterations and the latch are identical on all ranks because they derive from all-reduced values only). */
+ * two boundary planes; all-reduce of p.q; r -= alpha q; all-reduce of (r.z, r.r); p = z + beta p.  On
+ * constant-coefficient grids (the kernels that never store q, beat_pde_rr.hip) it is the ghost planes of r that
+ * travel -- overlapped with the two reductions and the interior part of the next p-and-dot pass -- and every rank
+ * forms p on its ghost planes itself.  The host enqueues as many iterations as the previous solve needed and reads
+ * the device-side convergence latch once (iterations and the latch are identical on all ranks because they derive
+ * from all-reduced values only). */
 int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev,
                         const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
                         double* dev_x, double* dev_work, double rtol, double atol, int max_it, int defer_flush,

@@ -483,7 +483,8 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
     lower and upper peers are the rank itself (the only multi-message topology a one-GPU box can host) makes the slab
     periodic in z -- ghost planes live on both faces, ncclSend/ncclRecv pairs in a group per SpMV, events between the
     side and the compute stream, boundary planes computed after the receive.  The stage-driven Python loop with the
-    same periodic exchange done by device copies must give the same bits; the exchange on its own is checked too
+    same periodic exchange done by device copies must give the same values (the same bits where both run the same
+    kernels); the exchange on its own is checked too
     (plain field and a padded state-array row)."""
     from beat import _stencil
     from beat._device import StateArray
@@ -538,8 +539,12 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
             ctx.synchronize()
             out[mode] = (fx.numpy().copy(), res, fx2.numpy().copy(), res2)
         (xs, rs, xs2, _), (xl, rl, xl2, rl2) = out["stage"], out["lib"]
-        assert rl.converged_reason > 0 and 3 < rl.iterations < 60 and rl.iterations == rs.iterations == rl2.iterations
-        np.testing.assert_array_equal(xl, xs)
+        assert rl.converged_reason > 0 and 3 < rl.iterations < 60 and rl.iterations == rl2.iterations
+        assert abs(rl.iterations - rs.iterations) <= 1
+        if per_node:  # same kernels in the same order
+            np.testing.assert_array_equal(xl, xs)
+        else:         # the library loop runs the register-row kernels (ghost planes of r travel, p is formed on them)
+            np.testing.assert_allclose(xl, xs, rtol=0, atol=1e-9 * np.abs(xs).max())
         np.testing.assert_array_equal(xl2, xl)
         np.testing.assert_array_equal(xs2, xs)
         # the periodic operator really couples the two faces: the solution differs from the Neumann-faced one
