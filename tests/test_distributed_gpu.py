@@ -56,10 +56,16 @@ def test_collective_path_on_one_rank_matches_single_slab_solve(hip_ctx, per_node
         (x1, r1), (xs, rs), (x2, r2) = results
         assert r2.converged_reason > 0 and abs(r1.iterations - r2.iterations) <= 1
         np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-9 * np.abs(x1).max())
-        # one rank: the library loop and the Python stage loop run the same kernels in the same order (the fused solve
-        # uses the register-row kernels on constant-coefficient grids: same values up to the summation order)
-        np.testing.assert_array_equal(xs, x2)
-        assert rs.iterations == r2.iterations
+        # one rank: per-node rows -- library loop, Python stage loop and fused solve run the same kernels in the same
+        # order; constant coefficients -- the fused solve and the library loop run the register-row kernels (same
+        # bits), the stage loop the classic three-kernel iteration (same values up to the summation order)
+        if per_node:
+            np.testing.assert_array_equal(xs, x2)
+            assert rs.iterations == r2.iterations
+        else:
+            np.testing.assert_array_equal(x1, x2)
+            np.testing.assert_allclose(xs, x2, rtol=0, atol=1e-11 * np.abs(x2).max())
+            assert abs(rs.iterations - r2.iterations) <= 1 and r1.iterations == r2.iterations
         # deferred last update through the collective path: pending until flushed, then the same bits
         fx3 = ops.new_field()
         res3 = solver.solve(fv, [], [], fx3, rtol=1e-11, atol=1e-50, max_it=200, defer_flush=True)
