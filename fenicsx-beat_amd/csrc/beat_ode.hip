@@ -28,9 +28,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
     int v_index, double* __restrict__ v_copy, PendingV pend) {
-  __shared__ double etab[64];
+  __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
-  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
+  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
   const FastMath fm{etab, ltab};
@@ -80,9 +81,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
     const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
     TrackSpec track, double* __restrict__ trace) {
-  __shared__ double etab[64];
+  __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
-  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
+  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
   const FastMath fm{etab, ltab};
