@@ -5,7 +5,7 @@
 // when the transmembrane potential is mirrored into the PDE vector (dev_v_copy).
 #include "beat_pde_internal.h"
 #include "ionic_models.h"
-#include "generated/torord_dyncl.h"
+#include "torord_dyncl.h"
 
 template <int NP>
 struct ParamPack {
@@ -100,10 +100,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
     for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
     dl = Model::derive(pl);
   }
-  // Hand-written models keep the states in registers across steps (RegIO).  The generated ToR-ORd step
-  // (heavy register spilling) produced wrong values through RegIO with ROCm 7.2 while the identical step
-  // is correct through global memory, so generated models round-trip their states through HBM/L2 each
-  // step (tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards both variants).
+  // Models keep the states in registers across steps (RegIO).  REGISTER_LOOP = false routes a model's step through
+  // global memory instead: needed by round 1's generated ToR-ORd step, whose heavy spilling produced wrong values
+  // through RegIO with ROCm 7.2; no model in the library uses it any more (the hand-organised ToR-ORd kernel has no
+  // spills), tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards every model.
   const RegIO rio{y};
   const NodeIO gio{states, ld, i, nullptr, -1};
   int64_t row = 0;

@@ -1,0 +1,892 @@
+// ToR-ORd-dynCl (Tomek, Rodriguez et al. 2019/2020 with dynamic chloride), 45 states, first-order generalized
+// Rush-Larsen -- hand-organised kernel.
+// Specification: odes/torord/ToRORd_dynCl_endo.ode (states :1-74, parameters :76-275, expressions :277-633), as
+// advanced by the reference's ventricular demos (demos/biv_endocardial.py:124-173, one parameter set per cell type).
+// Scheme: gotranx `generalized_rush_larsen` (see Tp06Grl1 in ionic_models.h and oracle/ionic.py):
+//   y_i += f_i (exp(J_i dt) - 1) / J_i  if |J_i| > 1e-8 else dt f_i,   J_i = total d f_i / d y_i.
+//
+// Organisation (what the generated kernel of round 1 could not have: it kept 192 doubles live and ran at one wave
+// per SIMD with spills):
+//  * the step is a sequence of fenced BLOCKS, one per current / flux family.  A block loads the gate states it owns,
+//    computes its current together with ONLY the partial derivatives some state's self-derivative needs, adds both to
+//    running sums and stores its gates; its intermediates die with the block.
+//  * running sums: for the membrane potential and each of the nine ion-concentration states the total current it
+//    sees and that current's derivative w.r.t. the state itself (20 doubles), e.g.
+//        d nai / dt = -Acap/(F vmyo) * I_nai + JdiffNa vss/vmyo,   I_nai = INa + INaL + INab + ICaNa_i + 3 INaK + 3 INaCa_i.
+//  * derivatives inside a block are taken by forward-mode dual numbers with a COMPILE-TIME sparsity mask (Du<M>): a
+//    quantity carries a tangent only for the directions it depends on, so the compiler emits exactly the chain-rule
+//    terms that are structurally non-zero and the block reads like the specification.
+//  * parameter-only sub-expressions, including every celltype switch, are evaluated once per launch (Derived).
+//  * exponentials with a common slope share one exp(); the total derivatives through the Debye-Hueckel activity
+//    coefficients and through the CaMK-dependent phosphorylation fraction are kept where a state sees them
+//    (cai, nai, ki, cass, nass, kss), as the reference's fully resolved self-derivative has them.
+// Compiles for the host too (tests/test_torord_host.py builds it with g++ against the golden fixture): everything it
+// needs from the device side comes through BEAT_HD / the FM template parameter / beat_rcp / beat_guard / BEAT_TFENCE.
+#pragma once
+
+#include <cmath>
+
+#ifndef BEAT_TORORD_HOST_TEST
+#include "ionic_models.h"
+#define BEAT_HD __host__ __device__
+#define BEAT_DV __device__ __forceinline__
+#define BEAT_TFENCE() __builtin_amdgcn_sched_barrier(0)
+// Pins a running sum at this point of the program: the scheduling fences order only instructions with side effects,
+// and a block whose results merely flow into sums that are consumed at the very end (the pumps, the GHK fluxes) would
+// otherwise be emitted down there, where everything else is live too.
+#define BEAT_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
+namespace torord_detail {
+
+// value + up to three tangents; bit k of M set <=> tangent k is structurally non-zero
+template <unsigned M>
+struct Du {
+  double v;
+  double d[3];
+};
+template <unsigned M>
+BEAT_DV Du<M> mk(double v, double d0 = 0.0, double d1 = 0.0, double d2 = 0.0) {
+  Du<M> r;
+  r.v = v;
+  r.d[0] = d0;
+  r.d[1] = d1;
+  r.d[2] = d2;
+  return r;
+}
+#define BEAT_DU_FOR(k, MASK) \
+  _Pragma("unroll") for (int k = 0; k < 3; ++k) if (((MASK) >> k) & 1u)
+
+template <unsigned A, unsigned B>
+BEAT_DV Du<A | B> operator+(const Du<A>& a, const Du<B>& b) {
+  Du<A | B> r;
+  r.v = a.v + b.v;
+  BEAT_DU_FOR(k, A | B) r.d[k] = ((A >> k) & 1u) ? (((B >> k) & 1u) ? a.d[k] + b.d[k] : a.d[k]) : b.d[k];
+  return r;
+}
+template <unsigned A, unsigned B>
+BEAT_DV Du<A | B> operator-(const Du<A>& a, const Du<B>& b) {
+  Du<A | B> r;
+  r.v = a.v - b.v;
+  BEAT_DU_FOR(k, A | B) r.d[k] = ((A >> k) & 1u) ? (((B >> k) & 1u) ? a.d[k] - b.d[k] : a.d[k]) : -b.d[k];
+  return r;
+}
+template <unsigned A, unsigned B>
+BEAT_DV Du<A | B> operator*(const Du<A>& a, const Du<B>& b) {
+  Du<A | B> r;
+  r.v = a.v * b.v;
+  BEAT_DU_FOR(k, A | B) {
+    if (((A >> k) & 1u) && ((B >> k) & 1u))
+      r.d[k] = fma(a.d[k], b.v, a.v * b.d[k]);
+    else if ((A >> k) & 1u)
+      r.d[k] = a.d[k] * b.v;
+    else
+      r.d[k] = a.v * b.d[k];
+  }
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator+(const Du<A>& a, double b) {
+  Du<A> r = a;
+  r.v = a.v + b;
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator+(double b, const Du<A>& a) {
+  return a + b;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator-(const Du<A>& a, double b) {
+  Du<A> r = a;
+  r.v = a.v - b;
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator-(double b, const Du<A>& a) {
+  Du<A> r;
+  r.v = b - a.v;
+  BEAT_DU_FOR(k, A) r.d[k] = -a.d[k];
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator*(const Du<A>& a, double b) {
+  Du<A> r;
+  r.v = a.v * b;
+  BEAT_DU_FOR(k, A) r.d[k] = a.d[k] * b;
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> operator*(double b, const Du<A>& a) {
+  return a * b;
+}
+// 1 / a
+template <unsigned A>
+BEAT_DV Du<A> inv(const Du<A>& a) {
+  Du<A> r;
+  r.v = beat_rcp(a.v);
+  const double m = -r.v * r.v;
+  BEAT_DU_FOR(k, A) r.d[k] = m * a.d[k];
+  return r;
+}
+template <unsigned A, unsigned B>
+BEAT_DV Du<A | B> operator/(const Du<A>& a, const Du<B>& b) {
+  return a * inv(b);
+}
+template <unsigned B>
+BEAT_DV Du<B> operator/(double a, const Du<B>& b) {
+  return inv(b) * a;
+}
+template <class FM, unsigned A>
+BEAT_DV Du<A> dexp(const FM& fm, const Du<A>& a) {
+  Du<A> r;
+  r.v = fm.exp(a.v);
+  BEAT_DU_FOR(k, A) r.d[k] = r.v * a.d[k];
+  return r;
+}
+template <unsigned A>
+BEAT_DV Du<A> sq(const Du<A>& a) {
+  return a * a;
+}
+template <unsigned A>
+BEAT_DV Du<A> cube(const Du<A>& a) {
+  return a * a * a;
+}
+
+}  // namespace torord_detail
+
+struct TorordDynClGrl1 {
+  static constexpr int NS = 45, NP = 112, V_INDEX = 42;  // V_INDEX: membrane potential
+  // ode_run_kernel keeps the states of hand-written models in registers across steps (the generated kernel of round 1
+  // spilled so heavily that this miscompiled and had to go through memory)
+  static constexpr bool REGISTER_LOOP = true;
+  static constexpr int WAVES = 2;  // waves per SIMD the kernels are compiled for
+  enum S {
+    S_C1, S_C2, S_C3, S_I_, S_O_, S_CaMKt, S_Jrel_np, S_Jrel_p, S_a, S_ap, S_iF, S_iFp, S_iS, S_iSp, S_cai,
+    S_cajsr, S_cansr, S_cass, S_cli, S_clss, S_ki, S_kss, S_nai, S_nass, S_d, S_fcaf, S_fcafp, S_fcas, S_ff_,
+    S_ffp, S_fs, S_jca, S_nca_i, S_nca_ss, S_h, S_hp, S_j, S_jp, S_m, S_hL, S_hLp, S_mL, S_v, S_xs1, S_xs2
+  };
+  enum P {
+    A_atp_, K_atp_, K_o_n_, fkatp_, gkatp_, Aff_, ICaL_fractionSS_, Kmn_, PCa_b_, dielConstant_, k2n_,
+    offset_, tjca_, vShift_, BSLmax_, BSRmax_, KmBSL_, KmBSR_, cmdnmax_b_, csqnmax_, kmcmdn_, kmcsqn_,
+    kmtrpn_, trpnmax_, CaMKo_, KmCaM_, KmCaMK_, aCaMK_, bCaMK_, EKshift_, Gto_b_, F_, R_, T_, zca_, zcl_,
+    zk_, zna_, Fjunc_, GClCa_, GClb_, KdClCa_, GK1_b_, GKb_b_, GKr_b_, alpha_1_, beta_1_, GKs_b_, GNa_,
+    GNaL_b_, thL_, Gncx_b_, INaCa_fractionSS_, KmCaAct_, kasymm_, kcaoff_, kcaon_, kna1_, kna2_, kna3_, qca_,
+    qna_, wca_, wna_, wnaca_, GpCa_, KmCap_, H_, Khp_, Kki_, Kko_, Kmgatp_, Knai0_, Knao0_, Knap_, Kxkur_,
+    MgADP_, MgATP_, Pnak_b_, delta_, eP_, k1m_, k1p_, k2m_, k2p_, k3m_, k3p_, k4m_, k4p_, Jrel_b_, bt_,
+    cajsr_half_, Jup_b_, L_, rad__, PCab_, PKNa_, PNab_, cao_, clo_, ko_, nao_, celltype_, i_Stim_Amplitude_,
+    i_Stim_End_, i_Stim_Period_, i_Stim_PulseDuration_, i_Stim_Start_, tauCa_, tauCl_, tauK_, tauNa_
+  };
+
+  // parameter-only sub-expressions (celltype switches resolved: .ode PCa, Gto, Pnak, Gncx, GK1, GKb, GKr, GKs, GNaL,
+  // upScale, cmdnmax, Jrel_inf)
+  struct Derived {
+    double FRT, FFRT, RTFna, RTFk, RTFcl;
+    double cAF_myo, cAF_ss, cA2F_myo, cA2F_ss, vss_vmyo, vnsr_vmyo, vjsr_vss, vjsr_vnsr;
+    double PCa, PCap, Gto, Pnak, Gncx_i, Gncx_ss, GK1s, GKb, GKrs, GKs, GNaL, upScale, cmdnmax, relScale, gKatp;
+    double is_epi;
+    double cA, gcao_cao, gko_ko, gnao_nao;     // Debye-Hueckel constant; extracellular activities gamma * conc
+    double nk_a2, nk_a4, nk_b1, nk_cb3, nk_koK2, nk_1koK2, nk_Pden0;  // INaK
+    double nc_k1, nc_h11, nc_cao;              // INaCa
+    double a_rel, a_relp, btp;
+  };
+  BEAT_HD static Derived derive(const double* p) {
+    Derived q;
+    const double RTF = p[R_] * p[T_] / p[F_];
+    q.FRT = p[F_] / (p[R_] * p[T_]);
+    q.FFRT = p[F_] * p[F_] / (p[R_] * p[T_]);
+    q.RTFna = RTF / p[zna_];
+    q.RTFk = RTF / p[zk_];
+    q.RTFcl = RTF / p[zcl_];
+    const double Ageo = p[L_] * ((2.0 * 3.14) * p[rad__]) + p[rad__] * ((2.0 * 3.14) * p[rad__]);
+    const double Acap = 2.0 * Ageo;
+    const double vcell = p[L_] * (p[rad__] * ((1000.0 * 3.14) * p[rad__]));
+    const double vjsr = 0.0048 * vcell, vmyo = 0.68 * vcell, vnsr = 0.0552 * vcell, vss = 0.02 * vcell;
+    q.cAF_myo = Acap / (p[F_] * vmyo);
+    q.cAF_ss = Acap / (p[F_] * vss);
+    q.cA2F_myo = Acap / ((2.0 * p[F_]) * vmyo);
+    q.cA2F_ss = Acap / ((2.0 * p[F_]) * vss);
+    q.vss_vmyo = vss / vmyo;
+    q.vnsr_vmyo = vnsr / vmyo;
+    q.vjsr_vss = vjsr / vss;
+    q.vjsr_vnsr = vjsr / vnsr;
+    const bool epi = p[celltype_] == 1.0, mid = p[celltype_] == 2.0;
+    q.is_epi = epi ? 1.0 : 0.0;
+    q.PCa = epi ? 1.2 * p[PCa_b_] : mid ? 2.0 * p[PCa_b_] : p[PCa_b_];
+    q.PCap = 1.1 * q.PCa;
+    q.Gto = (epi || mid) ? 2.0 * p[Gto_b_] : p[Gto_b_];
+    q.Pnak = epi ? 0.9 * p[Pnak_b_] : mid ? 0.7 * p[Pnak_b_] : p[Pnak_b_];
+    const double Gncx = epi ? 1.1 * p[Gncx_b_] : mid ? 1.4 * p[Gncx_b_] : p[Gncx_b_];
+    q.Gncx_i = Gncx * (1.0 - p[INaCa_fractionSS_]);
+    q.Gncx_ss = Gncx * p[INaCa_fractionSS_];
+    const double sko = sqrt(p[ko_] / 5.0);
+    q.GK1s = (epi ? 1.2 * p[GK1_b_] : mid ? 1.3 * p[GK1_b_] : p[GK1_b_]) * sko;
+    q.GKb = epi ? 0.6 * p[GKb_b_] : p[GKb_b_];
+    q.GKrs = (epi ? 1.3 * p[GKr_b_] : mid ? 0.8 * p[GKr_b_] : p[GKr_b_]) * sko;
+    q.GKs = epi ? 1.4 * p[GKs_b_] : p[GKs_b_];
+    q.GNaL = epi ? 0.6 * p[GNaL_b_] : p[GNaL_b_];
+    q.upScale = epi ? 1.3 : 1.0;
+    q.cmdnmax = epi ? 1.3 * p[cmdnmax_b_] : p[cmdnmax_b_];
+    q.relScale = mid ? 1.7 : 1.0;
+    q.gKatp = (1.0 / ((p[A_atp_] / p[K_atp_]) * (p[A_atp_] / p[K_atp_]) + 1.0)) * (pow(p[ko_] / p[K_o_n_], 0.24) * (p[fkatp_] * p[gkatp_]));
+    const double TD = p[T_] * p[dielConstant_];
+    q.cA = 1820000.0 / (TD * sqrt(TD));
+    const double Io = (0.5 * (4.0 * p[cao_] + (p[clo_] + (p[ko_] + p[nao_])))) / 1000.0;
+    const double gIo = sqrt(Io) / (sqrt(Io) + 1.0) - 0.3 * Io;
+    q.gcao_cao = exp((-q.cA * 4.0) * gIo) * p[cao_];
+    q.gko_ko = exp((-q.cA * 1.0) * gIo) * p[ko_];
+    q.gnao_nao = exp((-q.cA * 1.0) * gIo) * p[nao_];
+    q.nk_a2 = p[k2p_];
+    q.nk_a4 = ((p[MgATP_] * p[k4p_]) / p[Kmgatp_]) / (1.0 + p[MgATP_] / p[Kmgatp_]);
+    q.nk_b1 = p[MgADP_] * p[k1m_];
+    q.nk_cb3 = (p[H_] * p[k3m_]) / (1.0 + p[MgATP_] / p[Kmgatp_]);
+    q.nk_koK2 = (p[ko_] / p[Kko_]) * (p[ko_] / p[Kko_]);
+    q.nk_1koK2 = (1.0 + p[ko_] / p[Kko_]) * (1.0 + p[ko_] / p[Kko_]);
+    q.nk_Pden0 = p[H_] / p[Khp_] + 1.0;
+    const double h10 = (p[nao_] / p[kna1_]) * (1.0 + p[nao_] / p[kna2_]) + (p[kasymm_] + 1.0);
+    q.nc_h11 = (p[nao_] * p[nao_]) / (p[kna2_] * (h10 * p[kna1_]));
+    q.nc_k1 = p[kcaon_] * (p[cao_] * (1.0 / h10));
+    q.nc_cao = p[cao_];
+    q.a_rel = 0.5 * p[bt_];
+    q.btp = 1.25 * p[bt_];
+    q.a_relp = 0.5 * q.btp;
+    return q;
+  }
+
+  BEAT_DV static double grl1(double y, double f, double J, double expm1Jdt, double dt) {
+    return y + ((fabs(J) > 1e-8) ? f * beat_rcp(J) * expm1Jdt : f * dt);
+  }
+  // gate with f = (inf - y) * rate, J = -rate  =>  y += (inf - y) (1 - exp(-dt rate))
+  template <class FM>
+  BEAT_DV static double gate(const FM& fm, double y, double inf, double rate, double dt) {
+    return y + (inf - y) * (1.0 - fm.exp(-dt * rate));
+  }
+  template <class FM>
+  BEAT_DV static double advance(const FM& fm, double y, double f, double J, double dt) {
+    return grl1(y, f, J, fm.exp(J * dt) - 1.0, dt);
+  }
+
+  template <class IO, class FM>
+  BEAT_DV static void step(const IO& io, const double* p, const Derived& q, const FM& fm, double t, double dt) {
+    using namespace torord_detail;
+    // directions of the dual numbers, per block: 0 = v always; 1, 2 = the block's ion concentrations
+    constexpr unsigned DV = 1u, D1 = 2u, D2 = 4u;
+
+    const double v = io.load(S_v);
+    // The Goldman-Hodgkin-Katz fluxes are 0/0 at v = 0: everything that sees the potential through vF/RT is evaluated
+    // at a potential kept 1e-4 mV away from it (beat_guard, derivative 1), as the generated kernel did
+    const double vg = beat_guard(v);
+    const double vfrt = vg * q.FRT, vffrt = vg * q.FFRT;
+    const double e1 = fm.exp(vfrt), e2 = e1 * e1;
+
+    // running sums: total current seen by the state and its derivative w.r.t. the state
+    double Iv = 0.0, dIv = 0.0;
+    double Inai = 0.0, dInai = 0.0, Inass = 0.0, dInass = 0.0;
+    double Iki = 0.0, dIki = 0.0, Ikss = 0.0, dIkss = 0.0;
+    double Icai = 0.0, dIcai = 0.0, Icass = 0.0, dIcass = 0.0;
+
+    // The two pumps come first: their dual-number intermediates are the widest of the step (four x_k with three
+    // tangents each), and at this point nothing but the potential and the first running sums is live.
+    // ---- INaK (.ode:418-444): directions 0 = v, 1 = nai, 2 = ki --------------------------------------------------------
+    {
+      const double nai = io.load(S_nai), ki = io.load(S_ki);
+      const Du<DV> Knai = dexp(fm, mk<DV>(p[delta_] * vfrt * (1.0 / 3.0), p[delta_] * q.FRT * (1.0 / 3.0))) * p[Knai0_];
+      const Du<DV> Knao = dexp(fm, mk<DV>(vfrt * (1.0 - p[delta_]) * (1.0 / 3.0), (1.0 - p[delta_]) * q.FRT * (1.0 / 3.0))) * p[Knao0_];
+      const Du<D1> Nai = mk<D1>(nai, 0.0, 1.0);
+      const Du<D2> Ki = mk<D2>(ki, 0.0, 0.0, 1.0);
+      const Du<D1 | D2> P = p[eP_] / ((Nai * (1.0 / p[Knap_]) + q.nk_Pden0) + Ki * (1.0 / p[Kxkur_]));
+      const Du<DV | D1> xn = Nai / Knai;
+      const Du<D2> xk = Ki * (1.0 / p[Kki_]);
+      const Du<DV | D1 | D2> rD1 = inv((sq(1.0 + xk) + cube(1.0 + xn)) - 1.0);
+      const Du<DV | D1 | D2> a1 = (p[k1p_] * cube(xn)) * rD1;
+      const Du<DV | D1 | D2> b4 = (p[k4m_] * sq(xk)) * rD1;
+      BEAT_TFENCE();
+      const Du<DV> yo = p[nao_] / Knao;
+      const Du<DV> rD3 = inv((cube(1.0 + yo) + q.nk_1koK2) - 1.0);
+      const Du<DV> a3 = (p[k3p_] * q.nk_koK2) * rD3;
+      const Du<DV> b2 = (p[k2m_] * cube(yo)) * rD3;
+      const Du<D1 | D2> b3 = q.nk_cb3 * P;
+      const double a2 = q.nk_a2, a4 = q.nk_a4, b1 = q.nk_b1;
+      BEAT_TFENCE();
+      // INaK = Pnak (zk JnakK + zna JnakNa), JnakK = 2 (E4 b1 - E3 a1), JnakNa = 3 (E1 a3 - E2 b3), E_k = x_k / sum x:
+      // the x_k are formed one after the other and folded into the numerator and the sum (not kept, nor the E_k)
+      const double cK = 2.0 * p[zk_], cN = 3.0 * p[zna_];
+      auto x = a2 * (a1 * b3) + (b3 * (a2 * b4) + (a2 * (a1 * a4) + b3 * (b2 * b4)));   // x1
+      auto S = x;
+      auto N = cN * (x * a3);
+      x = b4 * (a2 * a3) + (b4 * (a3 * b1) + (a3 * (a1 * a2) + b4 * (b1 * b2)));        // x2
+      S = S + x;
+      N = N - cN * (x * b3);
+      x = b1 * (a3 * a4) + (a4 * (b1 * b2) + (a4 * (a2 * a3) + b1 * (b2 * b3)));        // x3
+      S = S + x;
+      N = N - cK * (x * a1);
+      x = a1 * (b2 * b3) + (a1 * (a4 * b2) + (a1 * (a3 * a4) + b2 * (b3 * b4)));        // x4
+      S = S + x;
+      N = N + (cK * b1) * x;
+      const auto INaK = q.Pnak * (N * inv(S));
+      Iv += INaK.v;
+      dIv += INaK.d[0];
+      Inai += 3.0 * INaK.v;
+      dInai += 3.0 * INaK.d[1];
+      Iki += -2.0 * INaK.v;
+      dIki += -2.0 * INaK.d[2];
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai); BEAT_PIN(Iki); BEAT_PIN(dIki);
+    }
+    BEAT_TFENCE();
+
+    // ---- INaCa, myoplasm and subspace (.ode:446-525): directions 0 = v, 1 = Na, 2 = Ca --------------------------------
+    {
+      const double nai = io.load(S_nai), cai = io.load(S_cai), nass = io.load(S_nass), cass = io.load(S_cass);
+      const Du<DV> hca = dexp(fm, mk<DV>(p[qca_] * vfrt, p[qca_] * q.FRT));
+      const Du<DV> hna = dexp(fm, mk<DV>(p[qna_] * vfrt, p[qna_] * q.FRT));
+      // v-only part, shared by both compartments
+      const Du<DV> rhna = inv(hna);
+      const Du<DV> h7 = (p[nao_] / p[kna3_]) * (1.0 + rhna) + 1.0;
+      const Du<DV> h9 = inv(h7);
+      const Du<DV> h8 = (p[nao_] / p[kna3_]) * (rhna * h9);
+      const Du<DV> k3pp = h8 * p[wnaca_];
+      const Du<DV> k3 = h9 * p[wca_] + k3pp;
+      const Du<DV> k8 = (p[wna_] * q.nc_h11) * h8;
+      const Du<DV> rhca = inv(hca);
+      const double k1 = q.nc_k1, k2 = p[kcaoff_], k5 = p[kcaoff_];
+#define BEAT_NCX(NA, CA, GN, IV, DIV, INA, DINA, ICA, DICA)                                                          \
+  {                                                                                                                  \
+    const Du<D1> Na = mk<D1>(NA, 0.0, 1.0);                                                                          \
+    const Du<D2> Ca = mk<D2>(CA, 0.0, 0.0, 1.0);                                                                     \
+    const Du<DV | D1> h1 = (Na * (1.0 / p[kna3_])) * (hna + 1.0) + 1.0;                                              \
+    const Du<DV | D1> h3 = inv(h1);                                                                                  \
+    const Du<DV | D1> h2 = ((hna * Na) * (1.0 / p[kna3_])) * h3;                                                     \
+    const Du<D1> h4 = (Na * (1.0 / p[kna1_])) * (1.0 + Na * (1.0 / p[kna2_])) + 1.0;                                 \
+    const Du<D1> h6 = inv(h4);                                                                                       \
+    const Du<D1> h5 = ((Na * Na) * (1.0 / (p[kna2_] * p[kna1_]))) * h6;                                              \
+    const Du<DV | D1> k4pp = h2 * p[wnaca_];                                                                         \
+    const Du<DV | D1> k4 = (h3 * p[wca_]) * rhca + k4pp;                                                             \
+    const Du<D1 | D2> k6 = p[kcaon_] * (Ca * h6);                                                                    \
+    const Du<DV | D1> k7 = p[wna_] * (h2 * h5);                                                                      \
+    /* I = allo G (zca JCa + zna JNa), JCa = E2 k2 - E1 k1, JNa = E3 k4pp + 3 (E4 k7 - E1 k8) - E2 k3pp, E_k = x_k / sum x:    */ \
+    /* each x_k is folded into the numerator and the sum as soon as it is formed                                          */ \
+    Du<DV | D1 | D2> S, N;                                                                                             \
+    {                                                                                                                  \
+      const auto x1 = (k2 * k4) * (k6 + k7) + (k5 * k7) * (k2 + k3);                                                   \
+      S = x1;                                                                                                          \
+      N = x1 * (k8 * (-3.0 * p[zna_]) - p[zca_] * k1);                                                                 \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const auto x2 = (k1 * k7) * (k4 + k5) + (k4 * k6) * (k1 + k8);                                                   \
+      S = S + x2;                                                                                                      \
+      N = N + x2 * (p[zca_] * k2 - p[zna_] * k3pp);                                                                    \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const auto x3 = (k1 * k3) * (k6 + k7) + (k6 * k8) * (k2 + k3);                                                   \
+      S = S + x3;                                                                                                      \
+      N = N + x3 * (p[zna_] * k4pp);                                                                                   \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const auto x4 = (k2 * k8) * (k4 + k5) + (k3 * k5) * (k1 + k8);                                                   \
+      S = S + x4;                                                                                                      \
+      N = N + x4 * ((3.0 * p[zna_]) * k7);                                                                             \
+    }                                                                                                                  \
+    const double km2 = p[KmCaAct_] * p[KmCaAct_];                                                                      \
+    const Du<D2> allo = (Ca * Ca) * inv(Ca * Ca + km2);                                                                \
+    const auto I = (allo * (GN)) * (N * inv(S));                                                                       \
+    IV += I.v;                                                                                                       \
+    DIV += I.d[0];                                                                                                   \
+    INA += 3.0 * I.v;                                                                                                \
+    DINA += 3.0 * I.d[1];                                                                                            \
+    ICA += -2.0 * I.v;                                                                                               \
+    DICA += -2.0 * I.d[2];                                                                                           \
+    BEAT_PIN(IV); BEAT_PIN(DIV); BEAT_PIN(INA); BEAT_PIN(DINA); BEAT_PIN(ICA); BEAT_PIN(DICA);                       \
+  }
+      BEAT_NCX(nai, cai, q.Gncx_i, Iv, dIv, Inai, dInai, Icai, dIcai)
+      BEAT_TFENCE();
+      BEAT_NCX(nass, cass, q.Gncx_ss, Iv, dIv, Inass, dInass, Icass, dIcass)
+#undef BEAT_NCX
+    }
+    BEAT_TFENCE();
+
+    // ---- CaMK (.ode:413-416): phosphorylated fraction fp = 1/(1 + KmCaMK/CaMKa), shared by INa, INaL, Ito, ICaL, Jup,
+    //      Jrel (the specification writes it out six times) ---------------------------------------------------------
+    const double cass = io.load(S_cass);
+    double fp, dfp_dcass;
+    {
+      const double CaMKt = io.load(S_CaMKt);
+      const double rk = beat_rcp(cass + p[KmCaM_]);
+      const double rc = cass * rk;                                   // 1/(KmCaM/cass + 1)
+      const double CaMKb = p[CaMKo_] * (1.0 - CaMKt) * rc;
+      const double dCaMKb_dcass = p[CaMKo_] * (1.0 - CaMKt) * p[KmCaM_] * rk * rk;
+      const double dCaMKb_dCaMKt = -p[CaMKo_] * rc;
+      const double CaMKa = CaMKb + CaMKt;
+      const double ra = beat_rcp(CaMKa + p[KmCaMK_]);
+      fp = CaMKa * ra;
+      dfp_dcass = p[KmCaMK_] * ra * ra * dCaMKb_dcass;
+      const double f = -CaMKt * p[bCaMK_] + (CaMKb * p[aCaMK_]) * (CaMKb + CaMKt);
+      const double J = -p[bCaMK_] + p[aCaMK_] * (dCaMKb_dCaMKt * (CaMKb + CaMKt) + CaMKb * (dCaMKb_dCaMKt + 1.0));
+      io.store(S_CaMKt, advance(fm, CaMKt, f, J, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- reversal potentials (.ode:527-532) ---------------------------------------------------------------------------
+    const double nai = io.load(S_nai), ki = io.load(S_ki);
+    const double rnai = beat_rcp(nai), rki = beat_rcp(ki);
+    const double ENa = q.RTFna * fm.log(p[nao_] * rnai);
+    const double EK = q.RTFk * fm.log(p[ko_] * rki);
+    const double uK = v - EK;                                        // driving force of the K currents
+    const double dENa = -q.RTFna * rnai, dEK = -q.RTFk * rki;         // d E / d (own concentration)
+    BEAT_TFENCE();
+
+    // ---- INa (.ode:577-599) -------------------------------------------------------------------------------------------
+    // shared with INaL: tm = tmL
+    const double tm_rate = beat_rcp(0.06487 * fm.exp(-((v - 4.823) * (1.0 / 51.12)) * ((v - 4.823) * (1.0 / 51.12))) +
+                                    0.1292 * fm.exp(-((v + 45.79) * (1.0 / 15.54)) * ((v + 45.79) * (1.0 / 15.54))));
+    {
+      const double m = io.load(S_m), h = io.load(S_h), hp = io.load(S_hp), j = io.load(S_j), jp = io.load(S_jp);
+      const double gNa = (m * m * m) * p[GNa_] * (j * (h * (1.0 - fp)) + jp * (fp * hp));
+      const double INa = gNa * (v - ENa);
+      Iv += INa;
+      dIv += gNa;
+      Inai += INa;
+      dInai += -gNa * dENa;
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai);
+      BEAT_TFENCE();
+      const double em = fm.exp(-(v + 56.86) * (1.0 / 9.03));
+      const double eh = fm.exp((v + 71.55) * (1.0 / 7.43));
+      const double rm = beat_rcp(em + 1.0), rh = beat_rcp(eh + 1.0), rhp = beat_rcp(eh * 2.2423782291926058 + 1.0);  // exp(6/7.43)
+      BEAT_TFENCE();
+      double rate_h, rate_j;
+      if (v > -40.0) {
+        const double ea = fm.exp(0.0900900900900901 * v);
+        rate_h = 0.77 * ea * beat_rcp(0.13 * ea + 0.0497581410839387);
+        rate_j = 0.6 * fm.exp(0.157 * v) * beat_rcp(1.0 * fm.exp(0.1 * v) + 0.0407622039783662);
+      } else {
+        rate_h = 4.43126792958051e-7 * fm.exp(-0.147058823529412 * v) + (2.7 * fm.exp(0.079 * v) + 310000.0 * fm.exp(0.3485 * v));
+        const double aj = -(v + 37.78) * (25428.0 * fm.exp(0.28831 * v) + 6.948e-6) * fm.exp(-0.04391 * v) *
+                          beat_rcp(50262745825.954 * fm.exp(0.311 * v) + 1.0);
+        const double bj = 0.02424 * fm.exp(0.12728 * v) * beat_rcp(1.0 * fm.exp(0.1378 * v) + 0.00396086833990426);
+        rate_j = aj + bj;
+      }
+      BEAT_TFENCE();
+      io.store(S_m, gate(fm, m, rm * rm, tm_rate, dt));
+      io.store(S_h, gate(fm, h, rh * rh, rate_h, dt));
+      io.store(S_hp, gate(fm, hp, rhp * rhp, rate_h, dt));
+      BEAT_TFENCE();
+      io.store(S_j, gate(fm, j, rh * rh, rate_j, dt));
+      io.store(S_jp, gate(fm, jp, rh * rh, rate_j * (1.0 / 1.46), dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- INaL (.ode:561-575) ------------------------------------------------------------------------------------------
+    {
+      const double mL = io.load(S_mL), hL = io.load(S_hL), hLp = io.load(S_hLp);
+      const double gNaL = mL * q.GNaL * (fp * hLp + hL * (1.0 - fp));
+      const double INaL = gNaL * (v - ENa);
+      Iv += INaL;
+      dIv += gNaL;
+      Inai += INaL;
+      dInai += -gNaL * dENa;
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai);
+      BEAT_TFENCE();
+      const double ehL = fm.exp((v + 87.61) * (1.0 / 7.488));
+      io.store(S_mL, gate(fm, mL, beat_rcp(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0), tm_rate, dt));
+      io.store(S_hL, gate(fm, hL, beat_rcp(ehL + 1.0), beat_rcp(p[thL_]), dt));
+      io.store(S_hLp, gate(fm, hLp, beat_rcp(ehL * 2.288717124596482 + 1.0), beat_rcp(3.0 * p[thL_]), dt));  // exp(6.2/7.488)
+    }
+    BEAT_TFENCE();
+
+    // ---- Ito (.ode:379-403) -------------------------------------------------------------------------------------------
+    {
+      const double ve = p[EKshift_] + v;
+      const double a = io.load(S_a), ap = io.load(S_ap), iF = io.load(S_iF), iFp = io.load(S_iFp), iS = io.load(S_iS),
+                   iSp = io.load(S_iSp);
+      const double AiF = beat_rcp(fm.exp((ve - 213.6) * (1.0 / 151.2)) + 1.0);
+      const double dAiF = -AiF * (1.0 - AiF) * (1.0 / 151.2);
+      const double i_ = AiF * iF + (1.0 - AiF) * iS, ip = AiF * iFp + (1.0 - AiF) * iSp;
+      const double gto = q.Gto * (i_ * (a * (1.0 - fp)) + ip * (ap * fp));
+      const double dgto = q.Gto * (dAiF * (iF - iS) * (a * (1.0 - fp)) + dAiF * (iFp - iSp) * (ap * fp));
+      const double Ito = gto * uK;
+      Iv += Ito;
+      dIv += gto + dgto * uK;
+      Iki += Ito;
+      dIki += -gto * dEK;
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
+      BEAT_TFENCE();
+      const double ea = fm.exp(-(ve - 14.34) * (1.0 / 14.82));
+      const double ass = beat_rcp(ea + 1.0), assp = beat_rcp(ea * 1.9635691902911017 + 1.0);  // exp(10/14.82)
+      const double et = fm.exp(-(ve - 18.4099) * (1.0 / 29.3814));
+      // 3.5/(exp((ve + 100)/29.3814) + 1): exp((ve + 100)/29.3814) = exp(118.4099/29.3814) / et
+      const double ta_rate = (beat_rcp(1.2089 * (et + 1.0)) + 3.5 * et * beat_rcp(56.266384148520984 + et)) * (1.0 / 1.0515);
+      BEAT_TFENCE();
+      const double iss = beat_rcp(fm.exp((ve + 43.94) * (1.0 / 5.711)) + 1.0);
+      double delta_epi = 1.0;
+      if (q.is_epi != 0.0) delta_epi = 1.0 - 0.95 * beat_rcp(fm.exp((ve + 70.0) * (1.0 / 5.0)) + 1.0);
+      const double tiF = delta_epi * (4.562 + beat_rcp(0.3933 * fm.exp(-(ve + 100.0) * (1.0 / 100.0)) +
+                                                       0.08004 * fm.exp((ve + 50.0) * (1.0 / 16.59))));
+      BEAT_TFENCE();
+      const double tiS = delta_epi * (23.62 + beat_rcp(0.001416 * fm.exp(-(ve + 96.52) * (1.0 / 59.05)) +
+                                                       1.78e-8 * fm.exp((ve + 114.1) * (1.0 / 8.079))));
+      BEAT_TFENCE();
+      const double xdev = fmin(-(ve - 12.23) * (1.0 / 0.2154), 700.0);  // exp() of it overflows below -138 mV
+      const double dti_develop = 1.354 + 0.0001 * beat_rcp(fm.exp(xdev) + fm.exp((ve - 167.4) * (1.0 / 15.89)));
+      const double dti_recover = 1.0 - 0.5 * beat_rcp(fm.exp((ve + 70.0) * (1.0 / 20.0)) + 1.0);
+      BEAT_TFENCE();
+      const double rdd = beat_rcp(dti_develop * dti_recover);
+      const double rtiF = beat_rcp(tiF), rtiS = beat_rcp(tiS);
+      io.store(S_a, gate(fm, a, ass, ta_rate, dt));
+      io.store(S_ap, gate(fm, ap, assp, ta_rate, dt));
+      BEAT_TFENCE();
+      io.store(S_iF, gate(fm, iF, iss, rtiF, dt));
+      io.store(S_iFp, gate(fm, iFp, iss, rtiF * rdd, dt));
+      BEAT_TFENCE();
+      io.store(S_iS, gate(fm, iS, iss, rtiS, dt));
+      io.store(S_iSp, gate(fm, iSp, iss, rtiS * rdd, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- ICaL gates and the common gate factors of ICaL / ICaNa / ICaK (.ode:312-377) ---------------------------------
+    //   I_X_c = frac_c * scale_X * Gc * Phi_X_c,  Gc = d [ (1 - fp) (f (1 - nca) + nca fca jca) PCa + fp (fp_ (1 - nca) + nca fcap jca) PCap ]
+    const double cai = io.load(S_cai);
+    double G_i, dG_i_dv, G_ss, dG_ss_dv, dG_ss_dfp;
+    {
+      const double d = io.load(S_d), ff = io.load(S_ff_), fs = io.load(S_fs), fcaf = io.load(S_fcaf), fcas = io.load(S_fcas),
+                   jca = io.load(S_jca), ffp = io.load(S_ffp), fcafp = io.load(S_fcafp);
+      const double nca_i = io.load(S_nca_i), nca_ss = io.load(S_nca_ss);
+      const double sA = beat_rcp(fm.exp((v - 10.0) * (1.0 / 10.0)) + 1.0);
+      const double Afcaf = 0.3 + 0.6 * sA, dAfcaf = -0.06 * sA * (1.0 - sA);
+      const double Afs = 1.0 - p[Aff_];
+      const double f = p[Aff_] * ff + Afs * fs, fpx = p[Aff_] * ffp + Afs * fs;
+      const double fca = Afcaf * fcaf + (1.0 - Afcaf) * fcas, fcap = Afcaf * fcafp + (1.0 - Afcaf) * fcas;
+      const double dfca = dAfcaf * (fcaf - fcas), dfcap = dAfcaf * (fcafp - fcas);
+      {
+        const double A = f * (1.0 - nca_i) + nca_i * (fca * jca), Ap = fpx * (1.0 - nca_i) + nca_i * (fcap * jca);
+        G_i = d * ((1.0 - fp) * A * q.PCa + fp * Ap * q.PCap);
+        dG_i_dv = d * ((1.0 - fp) * (nca_i * jca * dfca) * q.PCa + fp * (nca_i * jca * dfcap) * q.PCap);
+      }
+      {
+        const double A = f * (1.0 - nca_ss) + nca_ss * (fca * jca), Ap = fpx * (1.0 - nca_ss) + nca_ss * (fcap * jca);
+        G_ss = d * ((1.0 - fp) * A * q.PCa + fp * Ap * q.PCap);
+        dG_ss_dv = d * ((1.0 - fp) * (nca_ss * jca * dfca) * q.PCa + fp * (nca_ss * jca * dfcap) * q.PCap);
+        dG_ss_dfp = d * (Ap * q.PCap - A * q.PCa);
+      }
+      BEAT_PIN(G_i); BEAT_PIN(dG_i_dv); BEAT_PIN(G_ss); BEAT_PIN(dG_ss_dv); BEAT_PIN(dG_ss_dfp);
+      BEAT_TFENCE();
+      // gates
+      const double dss = (v >= 31.4978) ? 1.0 : 1.0763 * fm.exp(-1.007 * fm.exp(-0.0829 * v));
+      const double vs = v + p[vShift_];
+      const double td = (p[offset_] + 0.6) + beat_rcp(fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0)));
+      BEAT_TFENCE();
+      const double fss = beat_rcp(fm.exp((v + 19.58) * (1.0 / 3.696)) + 1.0);
+      const double e20 = fm.exp((v + 20.0) * (1.0 / 10.0));
+      const double tff = 7.0 + beat_rcp(0.0045 * beat_rcp(e20) + 0.0045 * e20);
+      BEAT_TFENCE();
+      const double tfs = 1000.0 + beat_rcp(3.5e-5 * fm.exp(-(v + 5.0) * (1.0 / 4.0)) + 3.5e-5 * fm.exp((v + 5.0) * (1.0 / 6.0)));
+      BEAT_TFENCE();
+      const double e4 = fm.exp((v - 4.0) * (1.0 / 7.0));
+      const double tfcaf = 7.0 + beat_rcp(0.04 * beat_rcp(e4) + 0.04 * e4);
+      BEAT_TFENCE();
+      const double tfcas = 100.0 + beat_rcp(0.00012 * fm.exp(-v * (1.0 / 3.0)) + 0.00012 * fm.exp(v * (1.0 / 7.0)));
+      const double jcass = beat_rcp(fm.exp((v + 18.08) * (1.0 / 2.7916)) + 1.0);
+      BEAT_TFENCE();
+      const double rtff = beat_rcp(tff), rtfcaf = beat_rcp(tfcaf);
+      io.store(S_d, gate(fm, d, dss, beat_rcp(td), dt));
+      io.store(S_ff_, gate(fm, ff, fss, rtff, dt));
+      BEAT_TFENCE();
+      io.store(S_ffp, gate(fm, ffp, fss, rtff * (1.0 / 2.5), dt));
+      io.store(S_fs, gate(fm, fs, fss, beat_rcp(tfs), dt));
+      BEAT_TFENCE();
+      io.store(S_fcaf, gate(fm, fcaf, fss, rtfcaf, dt));
+      io.store(S_fcafp, gate(fm, fcafp, fss, rtfcaf * (1.0 / 2.5), dt));
+      BEAT_TFENCE();
+      io.store(S_fcas, gate(fm, fcas, fss, beat_rcp(tfcas), dt));
+      io.store(S_jca, gate(fm, jca, jcass, beat_rcp(p[tjca_]), dt));
+      BEAT_TFENCE();
+      // nca: f = anca k2n - km2n nca, km2n = jca, anca = 1/(k2n/km2n + (Kmn/ca + 1)^4): J = -jca
+      {
+        const double xi = p[Kmn_] * beat_rcp(cai) + 1.0, xs = p[Kmn_] * beat_rcp(cass) + 1.0;
+        const double k2j = p[k2n_] * beat_rcp(jca);
+        const double anca_i = beat_rcp(k2j + (xi * xi) * (xi * xi)), anca_ss = beat_rcp(k2j + (xs * xs) * (xs * xs));
+        const double em1 = fm.exp(-jca * dt) - 1.0;
+        io.store(S_nca_i, grl1(nca_i, anca_i * p[k2n_] - jca * nca_i, -jca, em1, dt));
+        io.store(S_nca_ss, grl1(nca_ss, anca_ss * p[k2n_] - jca * nca_ss, -jca, em1, dt));
+      }
+    }
+    BEAT_TFENCE();
+
+    // ---- Goldman-Hodgkin-Katz fluxes of the L-type channel, background Ca and Na (.ode:326-347, 600-602, 610) ----------
+    double ICaL_ss;  // needed again by the ryanodine receptor
+    {
+      const double cli = io.load(S_cli), clss = io.load(S_clss), nass = io.load(S_nass), kss = io.load(S_kss);
+      // dual directions: 0 = v, 1 = the ion the flux carries (cai / nai / ki, cass / nass / kss)
+      const Du<DV> Ve1 = mk<DV>(e1, e1 * q.FRT), Ve2 = mk<DV>(e2, 2.0 * e2 * q.FRT);
+      const Du<DV> Vff = mk<DV>(vffrt, q.FFRT);
+      const Du<DV> R1 = inv(Ve1 - 1.0), R2 = inv(Ve2 - 1.0);
+      const double fi = 1.0 - p[ICaL_fractionSS_], fs_ = p[ICaL_fractionSS_];
+      // myoplasm: activity coefficients gamma = exp(-cA z^2 g(I)), g = sqrt(I)/(1 + sqrt(I)) - 0.3 I, I = ionic strength
+      {
+        const double Ii = (0.5 * (4.0 * cai + (cli + (ki + nai)))) * (1.0 / 1000.0);
+        const double sI = sqrt(Ii), r1s = beat_rcp(1.0 + sI);
+        const double g = sI * r1s - 0.3 * Ii;
+        const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;          // dg/dI
+        const double g1 = fm.exp(-q.cA * g);                              // z = 1
+        const double g2 = (g1 * g1) * (g1 * g1);                          // z = 2: exp(-4 cA g)
+        const double dg1_dI = -q.cA * dg * g1, dg2_dI = -4.0 * q.cA * dg * g2;
+        const Du<DV> Gi = mk<DV>(G_i, dG_i_dv);
+        {  // Ca: d I / d cai = 2/1000
+          const Du<D1> act = mk<D1>(g2 * cai, 0.0, g2 + cai * dg2_dI * 0.002);
+          const Du<DV | D1> Phi = (4.0 * Vff) * (act * Ve2 - q.gcao_cao) * R2;
+          const Du<DV | D1> ICaL_i = fi * (Gi * Phi);
+          const Du<DV | D1> ICab = p[PCab_] * Phi;
+          Iv += ICaL_i.v + ICab.v;
+          dIv += ICaL_i.d[0] + ICab.d[0];
+          Icai += ICaL_i.v + ICab.v;
+          dIcai += ICaL_i.d[1] + ICab.d[1];
+          BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Icai); BEAT_PIN(dIcai);
+        }
+        {  // Na: d I / d nai = 0.5/1000
+          const Du<D1> act = mk<D1>(g1 * nai, 0.0, g1 + nai * dg1_dI * 0.0005);
+          const Du<DV | D1> ICaNa_i = (fi * 0.00125) * (Gi * (Vff * (act * Ve1 - q.gnao_nao) * R1));
+          const Du<DV | D1> INab = p[PNab_] * (Vff * (mk<D1>(nai, 0.0, 1.0) * Ve1 - p[nao_]) * R1);
+          Iv += ICaNa_i.v + INab.v;
+          dIv += ICaNa_i.d[0] + INab.d[0];
+          Inai += ICaNa_i.v + INab.v;
+          dInai += ICaNa_i.d[1] + INab.d[1];
+          BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai);
+        }
+        {  // K
+          const Du<D1> act = mk<D1>(g1 * ki, 0.0, g1 + ki * dg1_dI * 0.0005);
+          const Du<DV | D1> ICaK_i = (fi * 0.0003574) * (Gi * (Vff * (act * Ve1 - q.gko_ko) * R1));
+          Iv += ICaK_i.v;
+          dIv += ICaK_i.d[0];
+          Iki += ICaK_i.v;
+          dIki += ICaK_i.d[1];
+          BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
+        }
+      }
+      BEAT_TFENCE();
+      // subspace: the gate factor also depends on cass through fp
+      {
+        const double Is = (0.5 * (4.0 * cass + (clss + (kss + nass)))) * (1.0 / 1000.0);
+        const double sI = sqrt(Is), r1s = beat_rcp(1.0 + sI);
+        const double g = sI * r1s - 0.3 * Is;
+        const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;
+        const double g1 = fm.exp(-q.cA * g);
+        const double g2 = (g1 * g1) * (g1 * g1);
+        const double dg1_dI = -q.cA * dg * g1, dg2_dI = -4.0 * q.cA * dg * g2;
+        {
+          const Du<DV | D1> Gs = mk<DV | D1>(G_ss, dG_ss_dv, dG_ss_dfp * dfp_dcass);
+          const Du<D1> act = mk<D1>(g2 * cass, 0.0, g2 + cass * dg2_dI * 0.002);
+          const Du<DV | D1> I = fs_ * (Gs * ((4.0 * Vff) * (act * Ve2 - q.gcao_cao) * R2));
+          ICaL_ss = I.v;
+          Iv += I.v;
+          dIv += I.d[0];
+          Icass += I.v;
+          dIcass += I.d[1];
+          BEAT_PIN(ICaL_ss); BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Icass); BEAT_PIN(dIcass);
+        }
+        const Du<DV> Gs = mk<DV>(G_ss, dG_ss_dv);
+        {
+          const Du<D1> act = mk<D1>(g1 * nass, 0.0, g1 + nass * dg1_dI * 0.0005);
+          const Du<DV | D1> I = (fs_ * 0.00125) * (Gs * (Vff * (act * Ve1 - q.gnao_nao) * R1));
+          Iv += I.v;
+          dIv += I.d[0];
+          Inass += I.v;
+          dInass += I.d[1];
+          BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inass); BEAT_PIN(dInass);
+        }
+        {
+          const Du<D1> act = mk<D1>(g1 * kss, 0.0, g1 + kss * dg1_dI * 0.0005);
+          const Du<DV | D1> I = (fs_ * 0.0003574) * (Gs * (Vff * (act * Ve1 - q.gko_ko) * R1));
+          Iv += I.v;
+          dIv += I.d[0];
+          Ikss += I.v;
+          dIkss += I.d[1];
+          BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Ikss); BEAT_PIN(dIkss);
+        }
+      }
+    }
+    BEAT_TFENCE();
+
+    // ---- K currents: IK1, IKb, IKr (+ Markov states), IKs (+ gates), I_katp (.ode:534-575, 612-615) --------------------
+    {
+      // IK1: aK1, bK1 functions of u = v - EK
+      const double ea = fm.exp(0.1217 * (uK - 49.934));
+      const double aK1 = 4.094 * beat_rcp(ea + 1.0), daK1 = -aK1 * 0.1217 * ea * beat_rcp(ea + 1.0);
+      const double eb1 = 15.72 * fm.exp(0.0674 * (uK - 3.257)), eb2 = fm.exp(0.0618 * (uK - 594.31));
+      const double eb3 = fm.exp(-0.1629 * (uK + 14.207));
+      const double rb = beat_rcp(eb3 + 1.0);
+      const double bK1 = (eb1 + eb2) * rb;
+      const double dbK1 = (0.0674 * eb1 + 0.0618 * eb2) * rb + bK1 * 0.1629 * eb3 * rb;
+      const double rab = beat_rcp(aK1 + bK1);
+      const double K1ss = aK1 * rab, dK1ss = (daK1 * bK1 - aK1 * dbK1) * rab * rab;
+      const double gK1 = q.GK1s * K1ss;
+      const double dIK1_du = q.GK1s * dK1ss * uK + gK1;
+      BEAT_TFENCE();
+      // IKb
+      const double ekb = fm.exp(-(v - 10.8968) * (1.0 / 23.9871));
+      const double xkb = beat_rcp(ekb + 1.0);
+      const double gKb = q.GKb * xkb;
+      const double dIKb_dv = q.GKb * (xkb * (1.0 - xkb) * (1.0 / 23.9871)) * uK + gKb;
+      BEAT_TFENCE();
+      // IKr
+      const double O_ = io.load(S_O_);
+      const double gKr = O_ * q.GKrs;
+      const double Iu = (gK1 + gKb + gKr + q.gKatp) * uK;  // IK1 + IKb + IKr + I_katp
+      Iv += Iu;
+      dIv += dIK1_du + dIKb_dv + gKr + q.gKatp;
+      Iki += Iu;
+      dIki += (dIK1_du + gKb + gKr + q.gKatp) * (-dEK);
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
+      {
+        const double C1 = io.load(S_C1), C2 = io.load(S_C2), C3 = io.load(S_C3), I_ = io.load(S_I_);
+        const double alpha = 0.1161 * fm.exp(0.299 * vfrt), alpha_2 = 0.0578 * fm.exp(0.971 * vfrt);
+        BEAT_TFENCE();
+        const double alpha_C2ToI = 5.2e-5 * fm.exp(1.525 * vfrt), alpha_i = 0.2533 * fm.exp(0.5953 * vfrt);
+        BEAT_TFENCE();
+        const double beta_ = 0.2442 * fm.exp(-1.604 * vfrt), beta_2 = 0.000349 * fm.exp(-1.062 * vfrt);
+        const double beta_i = 0.06525 * fm.exp(-0.8209 * vfrt);
+        BEAT_TFENCE();
+        const double beta_ItoC2 = (alpha_C2ToI * (beta_2 * beta_i)) * beat_rcp(alpha_2 * alpha_i);
+        const double a1_ = p[alpha_1_], b1_ = p[beta_1_];
+        io.store(S_C1, advance(fm, C1, -C1 * (alpha_C2ToI + (alpha_2 + b1_)) + (I_ * beta_ItoC2 + (C2 * a1_ + O_ * beta_2)),
+                               -(alpha_C2ToI + (alpha_2 + b1_)), dt));
+        BEAT_TFENCE();
+        io.store(S_C2, advance(fm, C2, -C2 * (a1_ + beta_) + (C1 * b1_ + C3 * alpha), -(a1_ + beta_), dt));
+        io.store(S_C3, advance(fm, C3, C2 * beta_ - C3 * alpha, -alpha, dt));
+        BEAT_TFENCE();
+        io.store(S_I_, advance(fm, I_, -I_ * (beta_ItoC2 + beta_i) + (C1 * alpha_C2ToI + O_ * alpha_i), -(beta_ItoC2 + beta_i), dt));
+        io.store(S_O_, advance(fm, O_, -O_ * (alpha_i + beta_2) + (C1 * alpha_2 + I_ * beta_i), -(alpha_i + beta_2), dt));
+      }
+    }
+    BEAT_TFENCE();
+    {
+      // IKs: reversal potential with the Na permeability; KsCa depends on cai (no state's self-derivative sees that)
+      const double xs1 = io.load(S_xs1), xs2 = io.load(S_xs2);
+      const double rks = beat_rcp(p[PKNa_] * nai + ki);
+      const double EKs = q.RTFk * fm.log((p[PKNa_] * p[nao_] + p[ko_]) * rks);
+      const double KsCa = 1.0 + 0.6 * beat_rcp(fm.exp(1.4 * fm.log(3.8e-5 * beat_rcp(cai))) + 1.0);
+      const double gKs = xs2 * (xs1 * (q.GKs * KsCa));
+      const double IKs = gKs * (v - EKs);
+      Iv += IKs;
+      dIv += gKs;
+      Iki += IKs;
+      dIki += gKs * (q.RTFk * rks);
+      BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
+      BEAT_TFENCE();
+      const double xsss = beat_rcp(fm.exp(-(v + 11.6) * (1.0 / 8.932)) + 1.0);
+      const double txs1 = 817.3 + beat_rcp(0.0002326 * fm.exp((v + 48.28) * (1.0 / 17.8)) + 0.001292 * fm.exp(-(v + 210.0) * (1.0 / 230.0)));
+      const double rtxs2 = 0.01 * fm.exp((v - 50.0) * (1.0 / 20.0)) + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
+      io.store(S_xs1, gate(fm, xs1, xsss, beat_rcp(txs1), dt));
+      io.store(S_xs2, gate(fm, xs2, xsss, rtxs2, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- chloride currents and concentrations (.ode:604-608, 403-404) ---------------------------------------------------
+    {
+      const double cli = io.load(S_cli), clss = io.load(S_clss);
+      const double ECl = q.RTFcl * fm.log(p[clo_] * beat_rcp(cli)), EClss = q.RTFcl * fm.log(p[clo_] * beat_rcp(clss));
+      const double g_junc = (p[Fjunc_] * p[GClCa_]) * cass * beat_rcp(cass + p[KdClCa_]);
+      const double g_sl = (p[GClCa_] * (1.0 - p[Fjunc_])) * cai * beat_rcp(cai + p[KdClCa_]);
+      const double IClCa_junc = g_junc * (v - EClss), IClCa_sl = g_sl * (v - ECl), IClb = p[GClb_] * (v - ECl);
+      Iv += IClCa_junc + IClCa_sl + IClb;
+      dIv += g_junc + g_sl + p[GClb_];
+      const double JdiffCl = (clss - cli) * beat_rcp(p[tauNa_]);  // the specification divides by tauNa, not tauCl
+      const double rt = beat_rcp(p[tauNa_]);
+      // d ECl / d cli = -RTFcl / cli
+      const double f_cli = q.cAF_myo * (IClCa_sl + IClb) + JdiffCl * q.vss_vmyo;
+      const double J_cli = q.cAF_myo * (g_sl + p[GClb_]) * (q.RTFcl * beat_rcp(cli)) - q.vss_vmyo * rt;
+      const double f_clss = -JdiffCl + q.cAF_ss * IClCa_junc;
+      const double J_clss = -rt + q.cAF_ss * g_junc * (q.RTFcl * beat_rcp(clss));
+      io.store(S_cli, advance(fm, cli, f_cli, J_cli, dt));
+      io.store(S_clss, advance(fm, clss, f_clss, J_clss, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- membrane potential (.ode:600-604) ----------------------------------------------------------------------------
+    double Istim = 0.0;
+    {
+      const double since = -p[i_Stim_Period_] * floor(-(p[i_Stim_Start_] - t) / p[i_Stim_Period_]) - p[i_Stim_Start_] + t;
+      if (p[i_Stim_Start_] <= t && p[i_Stim_PulseDuration_] >= since) Istim = p[i_Stim_Amplitude_];
+      // IpCa: sarcolemmal Ca pump
+      const double rp = beat_rcp(p[KmCap_] + cai);
+      const double IpCa = p[GpCa_] * cai * rp;
+      Iv += IpCa;
+      Icai += IpCa;
+      dIcai += p[GpCa_] * p[KmCap_] * rp * rp;
+      io.store(S_v, advance(fm, v, -(Istim + Iv), -dIv, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- sodium and potassium (.ode:405-411) --------------------------------------------------------------------------
+    {
+      const double nass = io.load(S_nass), kss = io.load(S_kss);
+      const double rtNa = beat_rcp(p[tauNa_]), rtK = beat_rcp(p[tauK_]);
+      const double JdiffNa = (nass - nai) * rtNa, JdiffK = (kss - ki) * rtK;
+      io.store(S_nai, advance(fm, nai, -q.cAF_myo * Inai + JdiffNa * q.vss_vmyo, -q.cAF_myo * dInai - q.vss_vmyo * rtNa, dt));
+      io.store(S_nass, advance(fm, nass, -JdiffNa - q.cAF_ss * Inass, -rtNa - q.cAF_ss * dInass, dt));
+      BEAT_TFENCE();
+      io.store(S_ki, advance(fm, ki, -q.cAF_myo * (Iki + Istim) + JdiffK * q.vss_vmyo, -q.cAF_myo * dIki - q.vss_vmyo * rtK, dt));
+      io.store(S_kss, advance(fm, kss, -JdiffK - q.cAF_ss * Ikss, -rtK - q.cAF_ss * dIkss, dt));
+    }
+    BEAT_TFENCE();
+
+    // ---- calcium: SERCA, ryanodine receptor, translocation, buffers (.ode:398-402, 617-633) -----------------------------
+    {
+      const double cajsr = io.load(S_cajsr), cansr = io.load(S_cansr);
+      const double Jrel_np = io.load(S_Jrel_np), Jrel_p = io.load(S_Jrel_p);
+      const double rtCa = beat_rcp(p[tauCa_]);
+      const double Jdiff = (cass - cai) * rtCa;
+      // SERCA
+      const double ru = beat_rcp(cai + 0.00092), rup = beat_rcp((cai + 0.00092) - 0.00017);
+      const double cu = q.upScale * 0.005425, cup = (q.upScale * 2.75) * 0.005425;
+      const double Jupnp = cai * cu * ru, Jupp = cai * cup * rup;
+      const double Jleak = (0.0048825 * cansr) * (1.0 / 15.0);
+      const double Jup = p[Jup_b_] * (-Jleak + (Jupnp * (1.0 - fp) + Jupp * fp));
+      const double dJup_dcai = p[Jup_b_] * ((1.0 - fp) * cu * 0.00092 * ru * ru + fp * cup * (0.00092 - 0.00017) * rup * rup);
+      // release
+      const double Jrel = p[Jrel_b_] * (Jrel_np * (1.0 - fp) + Jrel_p * fp);
+      const double dJrel_dcass = p[Jrel_b_] * (Jrel_p - Jrel_np) * dfp_dcass;
+      const double Jtr = (cansr - cajsr) * (1.0 / 60.0);
+      {
+        const double hr = p[cajsr_half_] * beat_rcp(cajsr);
+        const double h2 = hr * hr, h4 = h2 * h2;
+        const double rh8 = beat_rcp(h4 * h4 + 1.0);
+        const double Jrel_inf = q.relScale * ((ICaL_ss * (-q.a_rel)) * rh8);
+        const double Jrel_infp = q.relScale * ((ICaL_ss * (-q.a_relp)) * rh8);
+        const double rc = beat_rcp(1.0 + 0.0123 * beat_rcp(cajsr));
+        const double tau_rel = fmax(p[bt_] * rc, 0.001), tau_relp = fmax(q.btp * rc, 0.001);
+        io.store(S_Jrel_np, gate(fm, Jrel_np, Jrel_inf, beat_rcp(tau_rel), dt));
+        io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, beat_rcp(tau_relp), dt));
+      }
+      BEAT_TFENCE();
+      {  // cai: d/dt = Bcai * inner
+        const double rt = beat_rcp(cai + p[kmtrpn_]), rm = beat_rcp(cai + p[kmcmdn_]);
+        const double bt_ = p[kmtrpn_] * p[trpnmax_] * rt * rt, bm = q.cmdnmax * p[kmcmdn_] * rm * rm;
+        const double B = beat_rcp(bt_ + (bm + 1.0));
+        const double dB = B * B * (2.0 * bt_ * rt + 2.0 * bm * rm);
+        const double inner = (-q.cA2F_myo * Icai - Jup * q.vnsr_vmyo) + Jdiff * q.vss_vmyo;
+        const double dinner = (-q.cA2F_myo * dIcai - dJup_dcai * q.vnsr_vmyo) - q.vss_vmyo * rtCa;
+        io.store(S_cai, advance(fm, cai, B * inner, dB * inner + B * dinner, dt));
+      }
+      BEAT_TFENCE();
+      {  // cass
+        const double rl = beat_rcp(p[KmBSL_] + cass), rr = beat_rcp(p[KmBSR_] + cass);
+        const double bl = p[BSLmax_] * p[KmBSL_] * rl * rl, br = p[BSRmax_] * p[KmBSR_] * rr * rr;
+        const double B = beat_rcp(bl + (br + 1.0));
+        const double dB = B * B * (2.0 * bl * rl + 2.0 * br * rr);
+        const double inner = -Jdiff + (-q.cA2F_ss * Icass + Jrel * q.vjsr_vss);
+        const double dinner = -rtCa + (-q.cA2F_ss * dIcass + dJrel_dcass * q.vjsr_vss);
+        io.store(S_cass, advance(fm, cass, B * inner, dB * inner + B * dinner, dt));
+      }
+      BEAT_TFENCE();
+      {  // cajsr
+        const double rq = beat_rcp(cajsr + p[kmcsqn_]);
+        const double bq = p[csqnmax_] * p[kmcsqn_] * rq * rq;
+        const double B = beat_rcp(bq + 1.0);
+        const double dB = B * B * (2.0 * bq * rq);
+        const double inner = -Jrel + Jtr;
+        io.store(S_cajsr, advance(fm, cajsr, B * inner, dB * inner - B * (1.0 / 60.0), dt));
+      }
+      BEAT_TFENCE();
+      // cansr
+      io.store(S_cansr, advance(fm, cansr, Jup - Jtr * q.vjsr_vnsr,
+                                -p[Jup_b_] * (0.0048825 * (1.0 / 15.0)) - (1.0 / 60.0) * q.vjsr_vnsr, dt));
+    }
+  }
+};

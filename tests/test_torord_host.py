@@ -1,0 +1,77 @@
+"""CPU: the hand-organised ToR-ORd-dynCl step (fenicsx-beat_amd/csrc/torord_dyncl.h -- the very source the HIP kernel
+compiles) built for the host with g++ (tests/torord_host_harness.cpp: libm exp / log / division in place of the device's
+table-driven ones) and checked against
+
+* the golden fixture generated from the reference's ``.ode`` specification (tests/golden/torord_spec.npz): one GRL1 step
+  for endo / epi / mid and along a paced action potential, 1e-11 relative to the state scale;
+* the independent NumPy oracle (oracle/torord.py) on per-node parameters and over a 400-step trajectory.
+
+The arithmetic organisation of the kernel (blocks, running sums, sparse dual numbers) is therefore verified without a
+GPU; the GPU suite then checks the device build of the same source."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import torord
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden"
+
+
+@pytest.fixture(scope="module")
+def host_step(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this machine")
+    d = tmp_path_factory.mktemp("torord_host")
+    exe = d / "torord_host"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "torord_host_harness.cpp")], check=True)
+
+    def run(S, P, t, dt):
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        np.ascontiguousarray(S).tofile(d / "s.bin")
+        np.ascontiguousarray(P, dtype=np.float64).tofile(d / "p.bin")
+        subprocess.run([str(exe), str(d / "s.bin"), str(d / "p.bin"), str(d / "o.bin"), str(S.shape[1]), repr(float(t)),
+                        repr(float(dt))], check=True)
+        return np.fromfile(d / "o.bin").reshape(S.shape)
+
+    return run
+
+
+def _err(out, ref, defaults):
+    return np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6 * np.abs(defaults)[:, None] + 1e-12)
+
+
+def test_hand_kernel_source_matches_the_ode_spec_fixture(host_step):
+    g = np.load(GOLD / "torord_spec.npz")
+    for celltype in (0, 1, 2):
+        P = torord.torord_init_parameter_values(celltype=float(celltype))
+        out = host_step(g["states"], P, float(g["t"]), float(g["dt"]))
+        assert _err(out, g[f"grl1_celltype{celltype}"], g["state_defaults"]).max() < 1e-11
+    out = host_step(g["traj_states"], torord.torord_init_parameter_values(), float(g["traj_step_t"]), float(g["traj_dt"]))
+    assert _err(out, g["traj_grl1"], g["state_defaults"]).max() < 1e-11
+
+
+def test_hand_kernel_source_matches_the_numpy_oracle(host_step):
+    """Per-node parameters (a different cell type and stimulus per node, inside and outside the model's own stimulus
+    window) and a 400-step trajectory through the upstroke, against oracle/torord.py."""
+    g = np.load(GOLD / "torord_spec.npz")
+    S = g["traj_states"]
+    n = S.shape[1]
+    P = np.repeat(torord.torord_init_parameter_values()[:, None], n, axis=1)
+    P[torord.torord_parameter_index("celltype")] = np.arange(n) % 3
+    P[torord.torord_parameter_index("i_Stim_Amplitude")] = np.where(np.arange(n) % 2, -53.0, 0.0)
+    for t in (0.5, 7.0):  # inside / outside the 1 ms stimulus window
+        out = host_step(S, P, t, 0.02)
+        ref = torord.torord_generalized_rush_larsen(S, t, 0.02, P)
+        assert _err(out, ref, g["state_defaults"]).max() < 1e-11
+    y = torord.torord_init_state_values()[:, None].copy()
+    yo = y.copy()
+    P1 = torord.torord_init_parameter_values()
+    for i in range(400):
+        y = host_step(y, P1, i * 0.01, 0.01)
+        yo = torord.torord_generalized_rush_larsen(yo, i * 0.01, 0.01, P1)
+    assert yo[torord.torord_state_index("v"), 0] > 0.0  # fired
+    assert _err(y, yo, g["state_defaults"]).max() < 1e-9

@@ -1,0 +1,66 @@
+// Host build of the hand-organised ToR-ORd-dynCl step (fenicsx-beat_amd/csrc/torord_dyncl.h) for the CPU test suite:
+// the same source the HIP kernel compiles, with exp / log / reciprocal from libm.
+//   torord_host <states.bin> <params.bin> <out.bin> n t dt     (states: (45, n) doubles row-major; params: (112,) or (112, n))
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define BEAT_TORORD_HOST_TEST 1
+#define BEAT_HD
+#define BEAT_DV inline
+#define BEAT_TFENCE() ((void)0)
+#define BEAT_PIN(x) ((void)0)
+static inline double beat_rcp(double x) { return 1.0 / x; }
+static inline double beat_guard(double v) { return std::fabs(v) < 1.0e-4 ? std::copysign(1.0e-4, v) : v; }
+struct HostMath {
+  double exp(double x) const { return std::exp(x); }
+  double log(double x) const { return std::log(x); }
+};
+using std::exp;
+using std::fabs;
+using std::floor;
+using std::fma;
+using std::fmax;
+using std::fmin;
+using std::pow;
+using std::sqrt;
+#include "../fenicsx-beat_amd/csrc/torord_dyncl.h"
+
+struct HostIO {
+  const double* in;
+  double* out;
+  long n, i;
+  double load(int k) const { return in[(long)k * n + i]; }
+  void store(int k, double v) const { out[(long)k * n + i] = v; }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const long n = std::atol(argv[4]);
+  const double t = std::atof(argv[5]), dt = std::atof(argv[6]);
+  std::vector<double> S(45 * n), O(45 * n, 0.0);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(S.data(), 8, S.size(), f) != S.size()) return 3;
+  std::fclose(f);
+  f = std::fopen(argv[2], "rb");
+  if (!f) return 3;
+  std::vector<double> P(112 * n);
+  const size_t got = std::fread(P.data(), 8, P.size(), f);
+  std::fclose(f);
+  const bool per_node = got == P.size() && n > 1;
+  if (!per_node && got < 112) return 3;
+  const HostMath fm;
+  for (long i = 0; i < n; ++i) {
+    double pl[112];
+    for (int k = 0; k < 112; ++k) pl[k] = per_node ? P[(long)k * n + i] : P[k];
+    const TorordDynClGrl1::Derived q = TorordDynClGrl1::derive(pl);
+    const HostIO io{S.data(), O.data(), n, i};
+    TorordDynClGrl1::step(io, pl, q, fm, t, dt);
+  }
+  f = std::fopen(argv[3], "wb");
+  if (!f) return 4;
+  std::fwrite(O.data(), 8, O.size(), f);
+  std::fclose(f);
+  return 0;
+}

@@ -10,7 +10,11 @@ Reads a gotran ``.ode`` model specification (the reference keeps them under odes
 
 usage: gen_cell_model.py <model.ode> <StructName> <out_header> <out_py>
 
-The generated files are ordinary source (committed); the tool only has to be re-run when a model is added.
+The generated files are ordinary source; the tool only has to be re-run when a model is added.  It is the way to
+bring a new model up quickly (correct values, golden-test green) -- not the way to a fast kernel: ToR-ORd-dynCl's
+generated step kept 192 doubles live and ran at one wave per SIMD with spills (9.4 ms at 256^3); the kernel the library
+ships for that model is hand-organised (fenicsx-beat_amd/csrc/torord_dyncl.h, 3.7 ms), and only the names / defaults
+module this tool wrote (beat/models/_torord_dyncl_data.py) is still in use.
 """
 
 from __future__ import annotations
