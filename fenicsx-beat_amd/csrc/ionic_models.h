@@ -24,7 +24,9 @@
 // is < 4e-17, so the result is within ~1 ulp.  k is rounded with the 1.5 * 2^52 trick: one fma gives the rounded
 // value in the mantissa and k as a signed integer in the low dword (no v_rndne / v_cvt).  No overflow / NaN
 // handling: arguments in these models are bounded (|x| < 700); large negative arguments underflow to 0 through
-// v_ldexp_f64.  13 VALU instructions (16 with the 64-entry table and a degree-5 polynomial, ~27 for the library
+// v_ldexp_f64 -- as long as |x| < 5.8e6 (k must fit the low dword): arguments that are rate * dt products (gate updates,
+// exp(J dt)) can exceed that at unphysiological potentials and are clamped by their callers (beat_clamp_exp_arg).
+// 13 VALU instructions (16 with the 64-entry table and a degree-5 polynomial, ~27 for the library
 // routine) -- the ionic kernels are fp64-issue bound and the TP06 step evaluates 51 of them per node.
 // ------------------------------------------------------------------------------------------------
 constexpr int BEAT_EXP_TAB = 256;
@@ -239,6 +241,10 @@ __device__ const LogEntry kLogTab[128] = {
 #ifndef BEAT_ODE_WAVES
 #define BEAT_ODE_WAVES 2
 #endif
+
+// exp() argument of a rate * dt product, kept inside the range FastMath::exp handles (below -746 the result is 0,
+// above 710 it is inf: the clamp changes no finite value)
+__device__ __forceinline__ double beat_clamp_exp_arg(double x) { return fmin(fmax(x, -746.0), 710.0); }
 
 // 1/x: hardware estimate (~26 bits) + one third-order step r (1 + e + e^2), e = 1 - x r
 __device__ __forceinline__ double beat_rcp(double x) {
@@ -501,17 +507,17 @@ struct Tp06Grl1 {
     id = rcd * c;
   }
   __device__ static __forceinline__ double grl1(const FastMath& fm, double y, double fy, double J, double dt) {
-    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(J * dt) - 1.0) * rcp(J) : fy * dt);
+    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(beat_clamp_exp_arg(J * dt)) - 1.0) * rcp(J) : fy * dt);
   }
   // same with 1/J supplied by the caller (batched); rJ is only used where |J| > 1e-8
   __device__ static __forceinline__ double grl1r(const FastMath& fm, double y, double fy, double J, double rJ,
                                                  double dt) {
-    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(J * dt) - 1.0) * rJ : fy * dt);
+    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(beat_clamp_exp_arg(J * dt)) - 1.0) * rJ : fy * dt);
   }
   __device__ static __forceinline__ double guard(double J) { return (fabs(J) > 1e-8) ? J : 1.0; }
   // gate with f = (inf - y)/tau, J = -1/tau
   __device__ static __forceinline__ double gate(const FastMath& fm, double y, double inf, double rtau, double dt) {
-    return y + (inf - y) * (1.0 - fm.exp(-dt * rtau));
+    return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rtau, -746.0)));
   }
 
   // Fence for the instruction scheduler: the step is ~3000 straight-line instructions with ~50

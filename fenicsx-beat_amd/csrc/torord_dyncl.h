@@ -258,11 +258,11 @@ struct TorordDynClGrl1 {
   // gate with f = (inf - y) * rate, J = -rate  =>  y += (inf - y) (1 - exp(-dt rate))
   template <class FM>
   BEAT_DV static double gate(const FM& fm, double y, double inf, double rate, double dt) {
-    return y + (inf - y) * (1.0 - fm.exp(-dt * rate));
+    return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rate, -746.0)));  // rates reach 1e21/ms at +350 mV: see FastMath::exp
   }
   template <class FM>
   BEAT_DV static double advance(const FM& fm, double y, double f, double J, double dt) {
-    return grl1(y, f, J, fm.exp(J * dt) - 1.0, dt);
+    return grl1(y, f, J, fm.exp(fmin(fmax(J * dt, -746.0), 710.0)) - 1.0, dt);
   }
 
   template <class IO, class FM>
@@ -602,7 +602,7 @@ struct TorordDynClGrl1 {
         const double xi = p[Kmn_] * beat_rcp(cai) + 1.0, xs = p[Kmn_] * beat_rcp(cass) + 1.0;
         const double k2j = p[k2n_] * beat_rcp(jca);
         const double anca_i = beat_rcp(k2j + (xi * xi) * (xi * xi)), anca_ss = beat_rcp(k2j + (xs * xs) * (xs * xs));
-        const double em1 = fm.exp(-jca * dt) - 1.0;
+        const double em1 = fm.exp(fmax(-jca * dt, -746.0)) - 1.0;
         io.store(S_nca_i, grl1(nca_i, anca_i * p[k2n_] - jca * nca_i, -jca, em1, dt));
         io.store(S_nca_ss, grl1(nca_ss, anca_ss * p[k2n_] - jca * nca_ss, -jca, em1, dt));
       }

@@ -315,3 +315,44 @@ def test_torord_step_on_edge_case_states():
             out = torord.generalized_rush_larsen(states=S, t=0.0, parameters=P, dt=dt)
             bad = ~np.isfinite(out).all(axis=0)
             assert not bad.any(), (celltype, dt, int(bad.sum()), [names[r] for r in np.flatnonzero(~np.isfinite(out[:, np.flatnonzero(bad)[0]]))])
+
+
+@pytest.mark.parametrize("model_name", ["torord", "tp06"])
+def test_steps_stay_finite_and_right_at_unphysiological_potentials(model_name):
+    """Potentials from -135 to +360 mV (a 2000 uA/cm^2 surface stimulus drives staircase corners of a voxel mesh to
+    +230 mV, BASELINE configs[4]): gate rates reach 1e21 / ms there, so rate * dt leaves the range the kernels' exp()
+    handles by itself -- those arguments are clamped (the result is 0 either way).  Every state finite and equal to the
+    NumPy oracle (libm arithmetic), 1e-7 relative to the state scale (the Markov occupancies lose digits to cancellation
+    up there)."""
+    from beat.models import torord, tp06
+    from oracle import ionic
+    from oracle import torord as otor
+
+    n = 400
+    rng = np.random.default_rng(4)
+    if model_name == "torord":
+        model, vname = torord, "v"
+        step = otor.torord_generalized_rush_larsen
+        S = np.repeat(otor.torord_init_state_values()[:, None], n, axis=1)
+        names = otor.TORORD_STATES
+        gates = ["m", "h", "j", "hp", "jp", "d", "ff_", "fs", "a", "iF", "iS", "xs1", "xs2", "mL", "hL", "O_", "C1", "C2", "I_"]
+        params = [otor.torord_init_parameter_values(celltype=float(c), i_Stim_Amplitude=0.0) for c in (0, 1, 2)]
+    else:
+        model, vname = tp06, "V"
+        step = ionic.tp06_generalized_rush_larsen
+        S = np.repeat(ionic.tp06_init_state_values()[:, None], n, axis=1)
+        names = ionic.TP06_STATES
+        gates = ["Xr1", "Xr2", "Xs", "m", "h", "j", "d", "f", "f2", "fCass", "s", "r"]
+        params = [ionic.tp06_init_parameter_values(stim_amplitude=0.0)]
+    S[names.index(vname)] = np.linspace(-135.0, 360.0, n)
+    for gname in gates:
+        S[names.index(gname)] = rng.uniform(0.0, 1.0, n)
+    scale = np.abs(S[:, :1]) * 1e-6 + 1e-12
+    for P in params:
+        for dt in (0.05, 0.01):
+            out = model.generalized_rush_larsen(states=S, t=5.0, parameters=P, dt=dt)
+            assert np.isfinite(out).all(), [names[i] for i in np.unique(np.argwhere(~np.isfinite(out))[:, 0])]
+            ref = step(S, 5.0, dt, P)
+            ok = np.isfinite(ref)
+            err = np.abs(out - ref) / np.maximum(np.abs(ref), scale)
+            assert err[ok].max() < 1e-7, (model_name, dt, names[np.unravel_index(np.where(ok, err, 0).argmax(), err.shape)[0]])
