@@ -668,6 +668,19 @@ def test_checkpoint_roundtrip(tmp_path):
         np.testing.assert_array_equal(np.asarray(w.x.array), snaps[t])
     with pytest.raises(KeyError):
         beat.io.read_function(fname, w, time=0.25, name="v")
+    # a second run into the same path starts a NEW checkpoint (write_mesh opens in write mode): no time stamp or slab
+    # of the first run survives, and a time stamp written twice within a run reads back the later write
+    beat.io.write_mesh(fname, mesh)
+    assert not list(fname.glob("*_r*.npy"))
+    v.interpolate(lambda x: 7.0 + x[0])
+    beat.io.write_function(fname, v, time=0.5, name="v")
+    v.interpolate(lambda x: 9.0 - x[1])
+    beat.io.write_function(fname, v, time=0.5, name="v")
+    np.testing.assert_array_equal(beat.io.read_timestamps(comm=mesh.comm, filename=fname, function_name="v"), [0.5, 0.5])
+    beat.io.read_function(fname, w, time=0.5, name="v")
+    np.testing.assert_array_equal(np.asarray(w.x.array), np.asarray(v.x.array))
+    with pytest.raises(KeyError):
+        beat.io.read_function(fname, w, time=1.0, name="v")
 
 
 def test_deferred_potential_update_is_bit_identical():

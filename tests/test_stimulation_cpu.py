@@ -260,3 +260,23 @@ def test_reference_telemetry_tests_run_unchanged_against_this_package(tmp_path):
                           "-c", os.devnull], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "6 passed" in run.stdout
+
+
+def test_comm_allreduce_honours_the_reduction_op():
+    """mpi4py's comm.allreduce(value, op=...) on the communicator stand-in: SUM / MAX / MIN / PROD map to the matching
+    collective (one rank: the value itself), anything else raises instead of silently summing."""
+    from beat import grid as g
+
+    sys_path_shim = __import__("sys").path
+    compat = str(__import__("pathlib").Path(g.__file__).resolve().parents[1] / "compat")
+    if compat not in sys_path_shim:
+        sys_path_shim.insert(0, compat)
+    from mpi4py import MPI
+
+    comm = MPI.COMM_WORLD
+    for op in (None, MPI.SUM, MPI.MAX, MPI.MIN, MPI.PROD):
+        assert comm.allreduce(3.5, op=op) == 3.5
+    import pytest
+
+    with pytest.raises(ValueError):
+        comm.allreduce(1.0, op="xor")
