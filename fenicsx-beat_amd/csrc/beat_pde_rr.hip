@@ -350,13 +350,24 @@ __global__ void rr_next_kernel(double* st) {
   }
 }
 
-int rr_rows() {
-  static const int ry = [] {
+// Rows per wave and blocks per launch: on big slabs (>= 64 M nodes) 4 rows and ~4096 blocks are best (the 6-of-4 row
+// halo amortises, chunks stay long); on small ones -- 256^3, or the 512 x 512 x 64 slab one of 8 ranks owns -- the
+// launch is over in ~100 us, chunks of a few planes would spend their time in the three-plane prologue, and 2 rows /
+// ~2048 blocks (twice the waves per plane, chunks of 16 planes) measured best (tools/rr_small_sweep.sh: 1.69 vs 1.89 ms
+// per solve on the slab, 1.61 vs 1.77 at 256^3; the classic kernels: 1.78 / 1.66).  BEAT_RR_RY / BEAT_RR_BLOCKS override.
+int rr_rows(int64_t nodes) {
+  static const int forced = [] {
     const char* e = std::getenv("BEAT_RR_RY");
-    const int v = e ? std::atoi(e) : 4;
-    return (v == 2 || v == 4) ? v : 4;
+    const int v = e ? std::atoi(e) : 0;
+    return (v == 2 || v == 4) ? v : 0;
   }();
-  return ry;
+  if (forced) return forced;
+  return nodes >= ((int64_t)64 << 20) ? 4 : 2;
+}
+
+int rr_target_blocks(int64_t nodes) {
+  if (const char* e = std::getenv("BEAT_RR_BLOCKS")) return std::max(1, std::atoi(e));
+  return nodes >= ((int64_t)64 << 20) ? 4096 : 2048;
 }
 
 int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 3)
@@ -372,7 +383,8 @@ int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 
 RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off) {
   const Geom& f = pde->g;
   RGeom g{};
-  const int RY = g.ry = rr_rows();
+  const int64_t nodes = (int64_t)f.nx * f.ny * f.nz;
+  const int RY = g.ry = rr_rows(nodes);
   g.nx = f.nx;
   g.ny = f.ny;
   g.nz = f.nz;
@@ -388,8 +400,7 @@ RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off) {
   g.nrb = (f.ny + RY - 1) / RY;
   const int nzr = std::max(0, z_hi - z_lo);
   const int64_t per_layer = ((int64_t)g.nsegx * g.nrb + 3) / 4;  // blocks per z-chunk
-  int target = 4096;  // measured at 512^3: 1024 -> 12.3, 2048 -> 11.3, 4096 -> 11.0 ms per solve (before the store-wait fix)
-  if (const char* e = std::getenv("BEAT_RR_BLOCKS")) target = std::max(1, std::atoi(e));
+  const int target = rr_target_blocks(nodes);  // 512^3: 1024 -> 12.3, 2048 -> 11.3, 4096 -> 11.0 ms per solve (early version)
   int nchunks = (int)std::max<int64_t>(1, (target + per_layer - 1) / per_layer);
   nchunks = std::max(1, std::min(nchunks, nzr));
   g.zc = std::max(1, (nzr + nchunks - 1) / nchunks);
