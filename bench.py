@@ -6,10 +6,12 @@ diffusion solve) on a 512^3 anisotropic-fibre slab, dt = 0.01 ms  (BASELINE.json
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU; the grid is cut into z-slabs (strong scaling: the 512^3 grid is fixed, the
-slabs shrink as N grows).  A "step" is one call of the hot path of
-``MonodomainSplittingSolver.step`` (src/beat/monodomain_solver.py:53-116, theta_split = 1,
-theta_pde = 0.5): ionic step on every node, then right-hand-side build + Jacobi-PCG to
-``--rtol`` relative to ||b||.  Inputs are synthetic and already resident in HBM when the timed
+slabs shrink as N grows).  A "step" is one call of ``MonodomainSplittingSolver.step``
+(src/beat/monodomain_solver.py:53-116, theta_split = 1, theta_pde = 0.5) of THIS package's drop-in
+classes -- ``MonodomainModel`` + ``DolfinODESolver`` + ``MonodomainSplittingSolver`` built exactly as the
+reference's demos build them: ionic step on every node, then right-hand-side build + Jacobi-PCG to
+``--rtol`` relative to ||b||.  (``--direct`` drives the same kernels by bare C-ABI calls instead; at
+this size the two agree to the run-to-run spread.)  Inputs are synthetic and already resident in HBM when the timed
 region starts.  Rank 0 prints ONE JSON line.
 """
 
@@ -235,6 +237,8 @@ def main():
     ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
                     "solve instead of inside the next ionic kernel")
     ap.add_argument("--no-front", action="store_true", help="skip the second, developed-front measurement")
+    ap.add_argument("--direct", action="store_true", help="drive the kernels by bare C-ABI calls (beat_ode_step_pending + "
+                    "DiffusionSolver.solve) instead of the public API's MonodomainSplittingSolver.step")
     ap.add_argument("--size-z", "--nz", dest="nz", type=int, default=0, help="z planes of the global grid (default: --n); e.g. --nz 64 with "
                     "BEAT_FORCE_DISTRIBUTED=1 rehearses on one GPU the slab one of 8 ranks owns at 512^3")
     args = ap.parse_args()
@@ -288,21 +292,72 @@ def main():
     from beat._device import Context, StateArray
     from beat._engine import DiffusionSolver, HipOps, Slab
 
-    ctx = Context(local_rank)
-    lib = ctx.lib
     n = args.n
     nz_glob = args.nz or n
-    slab = Slab(nz_glob, rank, world)
     plane = n * n
-    n_local = plane * slab.nz
-    mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
-    ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
-    ops.set_preconditioner(args.pc_degree)
-    ops.set_timestep(C_M, THETA, DT)
-    solver = DiffusionSolver(ops, slab, force_distributed=force_dist)
-
     ic, params, v_index = tp06_defaults()
-    states = StateArray(ctx, len(ic), n_local, plane)
+    use_api = not (args.direct or args.no_defer)
+    api_solver = mon = None
+    if use_api:
+        # the reference's own construction sequence (demos/niederer_benchmark.py:101-225) on this package's classes
+        import beat
+        from beat import grid as g
+
+        class EventMonitor(beat.telemetry.BaseMonitor):
+            """HIP events around the ionic and the diffusion stage of the fused step (its track_time keys
+            "ode_step" / "pde_step"), on the stream the kernels are launched on."""
+
+            def __init__(self):
+                self.events, self.armed = {}, None
+
+            def track_time(self, name):
+                mon_, key = self, (self.armed, name)
+
+                class Region:
+                    def __enter__(self_r):
+                        if mon_.armed is not None and name in ("ode_step", "pde_step"):
+                            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                            mon_.events[key] = ev
+                            ev[0].record()
+                        return self_r
+
+                    def __exit__(self_r, *exc):
+                        if key in mon_.events and mon_.armed is not None and name in ("ode_step", "pde_step"):
+                            mon_.events[key][1].record()
+                        return False
+
+                return Region()
+
+        mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([(n - 1) * H, (n - 1) * H, (nz_glob - 1) * H])],
+                            [n - 1, n - 1, nz_glob - 1])
+        slab = mesh.slab
+        time_c = g.Constant(mesh, 0.0)
+        pde = beat.MonodomainModel(time=time_c, mesh=mesh, M=conductivity(), C_m=C_M,
+                                   params={"theta": THETA, "petsc_options": {"ksp_rtol": args.rtol, "ksp_atol": 1e-50, "ksp_max_it": 500}})
+        ctx = pde._ctx
+        ops = pde._ops
+        ops.set_preconditioner(args.pc_degree)
+        solver = pde._diffusion
+        V = g.functionspace(mesh, ("P", 1))
+        from beat.models import tp06
+
+        ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+                                             init_states=ic, parameters=params, num_states=len(ic), v_index=v_index)
+        mon = EventMonitor()
+        api_solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, monitor=mon)
+        states = ode._dev.states  # the (19, N_local) device array the solver owns
+        n_local = plane * slab.nz
+    else:
+        ctx = Context(local_rank)
+        slab = Slab(nz_glob, rank, world)
+        n_local = plane * slab.nz
+        mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
+        ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+        ops.set_preconditioner(args.pc_degree)
+        ops.set_timestep(C_M, THETA, DT)
+        solver = DiffusionSolver(ops, slab, force_distributed=force_dist)
+        states = StateArray(ctx, len(ic), n_local, plane)
+    lib = ctx.lib
     init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
     v_field = states.row_field(v_index)  # PDE unknown lives in the V row: no ODE<->PDE copies
     if world > 1:
@@ -327,26 +382,37 @@ def main():
         """`warmup` untimed steps, then exactly `steps` timed ones bracketed by barriers; returns the statistics."""
         ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        if mon is not None:
+            mon.events.clear()
         iters, pend_counts = [], []  # pend: search directions the timed ionic launches applied for the previous solve
 
         def step(t, i=None):
-            if i is not None:
-                ev_ode[i][0].record()
-            # the previous solve left its last x += sum alpha_j p_j to this kernel (deferred-x PCG, DESIGN.md 4)
+            # the previous solve left its last x += sum alpha_j p_j to this step's ionic kernel (deferred-x PCG, DESIGN.md 4)
             pend = ops.pending
-            ops.pending = None
             if i is not None:
                 pend_counts.append(pend[2] if pend else 0)
-            _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
-                                                 len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
-                                                 ops.fld, pend[2] if pend else 0))
-            if i is not None:
-                ev_ode[i][1].record()
-            res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
+            if use_api:
+                mon.armed = i
+                api_solver.step((t, t + DT))
+                res = pde.ksp
+                if i is not None:
+                    ev_ode[i] = mon.events.pop((i, "ode_step"))
+                    ev_pde_end[i] = mon.events.pop((i, "pde_step"))[1]
+            else:
+                if i is not None:
+                    ev_ode[i][0].record()
+                ops.pending = None
+                _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
+                                                     len(p_host), None, 0, t, DT, v_index, None, ops.handle, ops.ring[0].ptr,
+                                                     ops.fld, pend[2] if pend else 0))
+                if i is not None:
+                    ev_ode[i][1].record()
+                res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
+                if i is not None:
+                    ev_pde_end[i].record()
             if res.converged_reason <= 0:
                 raise SystemExit(f"PCG did not converge: reason {res.converged_reason} after {res.iterations} iterations")
             if i is not None:
-                ev_pde_end[i].record()
                 iters.append(res.iterations)
 
         for _ in range(warmup):
@@ -456,6 +522,8 @@ def main():
                             f"PCG rtol={args.rtol:g} (x0 = previous v), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
+                "driver": ("public API: beat.MonodomainSplittingSolver.step on MonodomainModel + DolfinODESolver" if use_api
+                           else "direct C-ABI calls (beat_ode_step_pending + DiffusionSolver.solve)"),
                 "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else "")
                                + ("" if backend == "nccl" else f" (REHEARSAL on {backend}, ranks share a GPU: not a measurement)"),
                 "pcg_iterations_per_step": k_avg,

@@ -380,6 +380,7 @@ class HipOps:
         if self.pending is not None:
             x, ring_base, _ = self.pending
             self.pending = None
+            self.flushes = getattr(self, "flushes", 0) + 1  # separate passes taken (the fused step should take none)
             _hip.check(self.lib.beat_pde_x_flush(self.handle, C.c_void_p(self.st_ptr_for_flush), x.ptr, self.ring[0].ptr,
                                                  self.fld, ring_base, 0))
 
@@ -605,6 +606,7 @@ class DiffusionSolver:
             _hip.check(ops.lib.beat_pde_set_ghost_types(ops.handle, lo, hi))
         if stage_driven is None:
             stage_driven = os.environ.get("BEAT_STAGE_DRIVEN", "0") == "1"
+        force_distributed = force_distributed or os.environ.get("BEAT_FORCE_DISTRIBUTED", "0") == "1"
         if slab.world > 1 or force_distributed:  # force_distributed: run the collective path on 1 rank (tests)
             import torch.distributed as dist
 

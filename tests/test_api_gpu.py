@@ -702,6 +702,12 @@ def test_deferred_potential_update_is_bit_identical():
                 np.testing.assert_array_equal(v, np.asarray(s.ode.v_ode.x.array))
                 np.testing.assert_array_equal(v, s.ode.values[17])
         assert deferred >= 10  # the solve does leave its update pending
+        if not peek:
+            # ... and the next ionic kernel consumes it: size queries on the aliased vectors (what _can_fuse asks at
+            # every step) are not reads of the potential and must not cost a flush pass
+            assert s.pde.state.x.array.size == s.ode.num_points == len(s.pde.v_.x.array)
+            assert s.pde.state.x.array.shape == (s.ode.num_points,)
+            assert getattr(ops, "flushes", 0) == 0 and ops.pending is not None
         runs[peek] = s.ode.values.copy()
         assert ops.pending is None
         np.testing.assert_array_equal(np.asarray(s.pde.v_.x.array), runs[peek][17])
