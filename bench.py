@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
     ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
                     "solve instead of inside the next ionic kernel")
+    ap.add_argument("--guess-order", type=int, default=int(os.environ.get("BEAT_GUESS_ORDER", "2")), choices=[0, 1, 2],
+                    help="initial guess of each diffusion solve: 0 = the ionic step's potential, 1 / 2 = plus the previous "
+                    "increment / the linear extrapolation of the last two (beat_pde_set_guess_order; the package default is 2)")
     ap.add_argument("--no-front", action="store_true", help="skip the second, developed-front measurement")
     ap.add_argument("--direct", action="store_true", help="drive the kernels by bare C-ABI calls (beat_ode_step_pending + "
                     "DiffusionSolver.solve) instead of the public API's MonodomainSplittingSolver.step")
@@ -333,7 +336,8 @@ def main():
         slab = mesh.slab
         time_c = g.Constant(mesh, 0.0)
         pde = beat.MonodomainModel(time=time_c, mesh=mesh, M=conductivity(), C_m=C_M,
-                                   params={"theta": THETA, "petsc_options": {"ksp_rtol": args.rtol, "ksp_atol": 1e-50, "ksp_max_it": 500}})
+                                   params={"theta": THETA, "petsc_options": {"ksp_rtol": args.rtol, "ksp_atol": 1e-50, "ksp_max_it": 500,
+                                                                              "ksp_guess_order": args.guess_order}})
         ctx = pde._ctx
         ops = pde._ops
         ops.set_preconditioner(args.pc_degree)
@@ -354,6 +358,7 @@ def main():
         mass_tab, stiff_tab = _stencil.stencil_tables(3, (H, H, H), conductivity())
         ops = HipOps(ctx, (n, n, slab.nz), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
         ops.set_preconditioner(args.pc_degree)
+        ops.set_guess_order(args.guess_order)
         ops.set_timestep(C_M, THETA, DT)
         solver = DiffusionSolver(ops, slab, force_distributed=force_dist)
         states = StateArray(ctx, len(ic), n_local, plane)
@@ -456,6 +461,7 @@ def main():
         for k in range(states.S):
             states.rows[k].view(-1, n).copy_(prof[k][None, :].expand(n_local // n, n))
         del prof
+        ops.guess_reset()  # the recorded increments belong to the overwritten state
         setup_s = time.perf_counter() - tic
         fr = timed_run(0.0, max(args.warmup, 5), args.steps)
         fmin, fmax = v_field.minmax()
@@ -500,7 +506,9 @@ def main():
         # every state row read once + written once, plus one read per pending search direction of the previous
         # diffusion solve (the launch applies that solve's x += sum alpha_j p_j)
         k_pend = float(np.mean(pend_counts)) if pend_counts else 0.0
-        ode_bytes = (16.0 * S + 8.0 * k_pend) * n_local
+        # ... and, with an extrapolated initial guess, the increments it is built from (read) and the new one (written)
+        g_bytes = 8.0 * args.guess_order + 8.0 if args.guess_order else 0.0
+        ode_bytes = (16.0 * S + 8.0 * k_pend + g_bytes) * n_local
         achieved = ode_bytes / (ode_ms * 1e-3) / 1e9
         step_bytes = (16.0 * S + 16.0 + 88.0 * k_avg) * n_total
         out = {
@@ -519,7 +527,8 @@ def main():
             "config": {
                 "workload": (f"{n}^3-node " if nz_glob == n else f"{n}x{n}x{nz_glob}-node ") + ("isotropic slab (h=0.1 mm)" if ISOTROPIC else "anisotropic-fibre slab (h=0.1 mm, fibre 30 deg in xy)") + ", TP06 GRL1 ionic step, "
                             f"P1 consistent-mass theta=0.5 diffusion, Godunov splitting, dt=0.01 ms, "
-                            f"PCG rtol={args.rtol:g} (x0 = previous v), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
+                            f"PCG rtol={args.rtol:g} (x0 = " + ("previous v" if args.guess_order == 0 else "previous v + last increment" if args.guess_order == 1
+                                                          else "previous v + linear extrapolation of the last two increments") + "), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
                 "driver": ("public API: beat.MonodomainSplittingSolver.step on MonodomainModel + DolfinODESolver" if use_api
@@ -527,6 +536,7 @@ def main():
                 "parallelism": f"z-slabs x{world}" + (" (forced collective path)" if force_dist else "")
                                + ("" if backend == "nccl" else f" (REHEARSAL on {backend}, ranks share a GPU: not a measurement)"),
                 "pcg_iterations_per_step": k_avg,
+                "guess_order": args.guess_order,
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
                 "v_min": vmin,
@@ -545,7 +555,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": ode_bytes,
-                "bytes_per_node": 16.0 * S + 8.0 * k_pend,
+                "bytes_per_node": 16.0 * S + 8.0 * k_pend + g_bytes,
                 "pending_directions_per_launch": k_pend,
                 "valu": None if valu is None else {
                     "instr_per_node": valu["valu_instr_per_wave"],  # one node per lane: per-wave count = per-node count

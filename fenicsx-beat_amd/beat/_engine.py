@@ -16,6 +16,7 @@ src/beat/base_model.py:203-242 (MPI neighbour exchange + PETSc-internal all-redu
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -183,6 +184,7 @@ class HipOps:
         self.st_ptr_for_flush = None   # scalar state the pending update belongs to (None: the handle's own)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
+        self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for order 2 by default)
 
     @classmethod
     def from_voxels(cls, ctx, dim, cells, h, M, active, shape_local, z0, lo_phys, hi_phys):
@@ -356,7 +358,7 @@ class HipOps:
         _hip.check(self.lib.beat_pde_solve_ex(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
                                               C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, int(defer_flush),
                                               C.byref(info), pend), allow_not_converged=True)
-        if pend[1] > 0:
+        if pend[1] > 0 or self.lib.beat_pde_guess_pending(self.handle):  # (the guess increment alone may be due)
             self.pending = (x, int(pend[0]), int(pend[1]))
         return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
 
@@ -371,9 +373,21 @@ class HipOps:
         _hip.check(self.lib.beat_pde_solve_dist(self.handle, comm.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
                                                 C.c_void_p(self.work.data_ptr()), rtol, atol, max_it, int(defer_flush),
                                                 C.byref(info), pend), allow_not_converged=True)
-        if pend[1] > 0:
+        if pend[1] > 0 or self.lib.beat_pde_guess_pending(self.handle):
             self.pending = (x, int(pend[0]), int(pend[1]))
         return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+
+    def set_guess_order(self, order: int) -> None:
+        """0: every solve starts from x0 = v_; 1 / 2: from v_ plus the previous increment / the linear extrapolation
+        of the last two (beat_pde_set_guess_order).  Drops the history."""
+        self.flush_pending()
+        _hip.check(self.lib.beat_pde_set_guess_order(self.handle, int(order)))
+        self.guess_order = int(order)
+
+    def guess_reset(self) -> None:
+        """Forget the recorded increments (the potential was overwritten: the next solve starts from x0 = v_)."""
+        self.flush_pending()
+        _hip.check(self.lib.beat_pde_guess_reset(self.handle))
 
     def flush_pending(self) -> None:
         """Apply a deferred update of the potential (no-op when nothing is pending)."""

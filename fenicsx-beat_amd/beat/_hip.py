@@ -84,6 +84,10 @@ SIGNATURES = {
     "beat_pde_cg_update_r": (_int, [_vp, _vp, _vp, _vp, _int]),
     "beat_pde_cg_next_oop": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "beat_pde_x_flush": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int]),
+    "beat_pde_set_guess_order": (_int, [_vp, _int]),
+    "beat_pde_guess_reset": (_int, [_vp]),
+    "beat_pde_guess_pending": (_int, [_vp]),
+    "beat_pde_guess_history": (_int, [_vp, _vp, _vp, _vp]),
     "beat_pde_set_preconditioner": (_int, [_vp, _int, _vp]),
     "beat_pde_pc_num_passes": (_int, [_vp]),
     "beat_pde_pc_pass": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),

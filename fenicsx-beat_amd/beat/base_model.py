@@ -5,6 +5,7 @@ with the DOLFINx assembly + PETSc KSP replaced by the matrix-free HIP operators 
 from __future__ import annotations
 
 import abc
+import os
 import logging
 from enum import Enum, auto
 from typing import Any, Literal, NamedTuple
@@ -142,6 +143,11 @@ class BaseModel:
         self._setup_state_space()
         self._timestep = grid.Constant(mesh, self.parameters["default_timestep"])
         self._setup_operators()
+        # initial guess of the linear solves from the previous steps' increments (PETSc's KSPGuess; the reference
+        # leaves it off): petsc_options["ksp_guess_order"] in {0, 1, 2}, default BEAT_GUESS_ORDER or 2
+        order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", 2))
+        if hasattr(self._ops, "set_guess_order"):
+            self._ops.set_guess_order(int(order))
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
         self.ksp = None  # KSP-like record of the last solve

@@ -252,6 +252,14 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if (rr) {
     BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+    beat_guess_begin(pde);
+    if (pde->guess.out != nullptr && pde->guess.c1 != 0.0) {
+      // ghost planes of the most recent increment (written by the deferred update since the last solve; the older
+      // one's were exchanged a step ago)
+      if ((rc = halo_start(comm, const_cast<double*>(pde->guess.h1), n, plane))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+    }
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
@@ -283,7 +291,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         if ((rc = halo_start(comm, r_new, n, plane))) return rc;  // travels behind the reductions and the next part 0
         if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
         if (slot == PRING - 1) {
-          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+            return rc;
         }
         if ((rc = beat_rr_next(pde, st))) return rc;
         continue;
@@ -309,12 +318,13 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if (rr) {  // the exchange started after the last residual update has no consumer: drain it before anything else
     if ((rc = halo_wait(comm))) return rc;  // touches those ghost planes
   }
-  const int nupd = (int)h[NUPD];
-  if (nupd % PRING != 0) {
+  const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
+  const GuessTerms last = beat_guess_terms(pde, base);
+  if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
     if (defer_flush) {
-      host_pending[0] = (nupd / PRING) * PRING;
+      host_pending[0] = base;
       host_pending[1] = nupd % PRING;
-    } else if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) {
+    } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
       return rc;
     }
   }

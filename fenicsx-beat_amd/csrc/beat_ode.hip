@@ -20,7 +20,10 @@ struct PendingV {
   const double* ring;    // p_0 (device), p_j = ring + j * fld
   int64_t fld;
   const double* alphas;  // device, step lengths alpha_j
-  int count;             // 0: nothing pending
+  int count;             // 0: no search direction pending
+  // the solve started from an extrapolated guess (beat_pde_set_guess_order): v += inc, inc = c1 h1 + c2 h2 +
+  // sum alpha_j p_j, and inc is recorded in gt.out as the step's diffusion increment (gt.out == nullptr: no guess)
+  beat_pde_detail::GuessTerms gt;
 };
 
 template <class Model, bool PER_NODE, bool PEND>
@@ -39,11 +42,22 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   if (i >= n) return;
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}};
+    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, nullptr};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
       io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
       io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+    }
+    if (pend.gt.out != nullptr) {
+      double e = 0.0;
+      if (pend.gt.accumulate) {
+        io.gacc = pend.gt.out[i];
+      } else {
+        if (pend.gt.c1 != 0.0) e = pend.gt.c1 * __builtin_nontemporal_load(pend.gt.h1 + i);
+        if (pend.gt.c2 != 0.0) e = fma(pend.gt.c2, __builtin_nontemporal_load(pend.gt.h2 + i), e);
+      }
+      io.ge = e;
+      io.gout = pend.gt.out + i;
     }
     if (PER_NODE) {
       double pl[Model::NP];
@@ -199,7 +213,8 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
                "model expects %d parameters, got %d", Model::NP, num_params);
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
-  BEAT_REQUIRE(pend.count == 0 || v_index == Model::V_INDEX,
+  const bool have_pend = pend.count > 0 || pend.gt.out != nullptr;
+  BEAT_REQUIRE(!have_pend || v_index == Model::V_INDEX,
                "a pending update needs v_index = %d (the model's membrane potential), got %d", Model::V_INDEX, v_index);
   ParamPack<Model::NP> prm;
   for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
@@ -211,12 +226,12 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
                      dt, v_index, v_copy, pend)
   if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
-    if (pend.count > 0)
+    if (have_pend)
       BEAT_LAUNCH_ODE(true, true);
     else
       BEAT_LAUNCH_ODE(true, false);
   } else {
-    if (pend.count > 0)
+    if (have_pend)
       BEAT_LAUNCH_ODE(false, true);
     else
       BEAT_LAUNCH_ODE(false, false);
@@ -269,7 +284,7 @@ extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, in
                              const double* dev_params_per_node, int64_t params_ld, double t, double dt,
                              int v_index, double* dev_v_copy) {
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
-                           t, dt, v_index, dev_v_copy, PendingV{nullptr, 0, nullptr, 0});
+                           t, dt, v_index, dev_v_copy, PendingV{nullptr, 0, nullptr, 0, {}});
 }
 
 extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
@@ -280,7 +295,11 @@ extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_st
   static_assert(BEAT_MAX_PENDING == beat_pde_detail::PRING, "pending directions = ring size");
   BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
   BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
-  PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending};
+  PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
+  if (pde != nullptr && pde->guess_pending) {  // this launch is the application the deferring solve left open
+    pend.gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
                            t, dt, v_index, dev_v_copy, pend);
 }

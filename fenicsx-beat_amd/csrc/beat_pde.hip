@@ -490,20 +490,40 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_oop_kernel(Geom g, cons
 
 // x += sum_{j < nvalid} alphas[j] * P_j, nvalid = clamp(executed updates - ring_base, 0, PRING).
 // Runs regardless of the latch: it is what brings x up to date after convergence.
+// With guess terms (gt.out != nullptr): inc = c1 h1 + c2 h2 + sum alpha_j P_j;  x += inc;  out = inc  (out may be h2);
+// with gt.accumulate: inc = sum alpha_j P_j;  x += inc;  out += inc.
 __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const double* __restrict__ st,
                                                              double* __restrict__ x,
                                                              const double* __restrict__ ring, int64_t fld,
                                                              const double* __restrict__ alphas, int ring_base,
-                                                             int only_if_full) {
+                                                             int only_if_full, GuessTerms gt) {
   int nvalid = (int)st[NUPD] - ring_base;
   nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
   // in-loop flushes are enqueued ahead of time: they must do nothing unless their ring cycle really
   // filled up (a partially filled last cycle is flushed once, after the host has seen the latch)
-  if (nvalid == 0 || (only_if_full && nvalid < PRING)) return;
+  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.out == nullptr)) return;
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
+  if (gt.out != nullptr) {
+    const double* h1 = gt.h1;
+    const double* h2 = gt.h2;  // may alias gt.out (read before written, same index)
+    double* out = gt.out;
+    for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
+      double inc = 0.0;
+      if (!gt.accumulate) {
+        if (gt.c1 != 0.0) inc = gt.c1 * h1[i];
+        if (gt.c2 != 0.0) inc = fma(gt.c2, h2[i], inc);
+      }
+#pragma unroll
+      for (int j = 0; j < PRING; ++j)
+        if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
+      x[i] += inc;
+      out[i] = gt.accumulate ? out[i] + inc : inc;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
     double xi = x[i];
 #pragma unroll
@@ -625,6 +645,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->d_tabs);
   (void)hipFree(pde->d_st);
   (void)hipFree(pde->d_alphas);
+  (void)hipFree(pde->d_hist_alloc);
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
   (void)hipFree(pde->v_seg);
@@ -664,6 +685,7 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
   pde->dt = dt;
   pde->have_dt = true;
   pde->last_iters = -1;
+  pde->hist_n = 0;  // increments of another time step say nothing about this one
   if (pde->var) return beat_var_form_A(pde);
   return upload_tables(pde);
 }
@@ -731,6 +753,8 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
   BEAT_REQUIRE(dev_r != dev_v_prev && dev_p != dev_v_prev && dev_r != dev_p, "r, p must be distinct work fields");
+  BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+  beat_guess_skip(pde);  // the stage-driven loops start from x0 = v_
   if (pde->var)
     return beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_r, dev_p, dev_red);
   StencilArgs a{};
@@ -942,16 +966,110 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
 
 // x += sum_j alpha_j ring_j over the valid directions of the ring cycle starting at iteration ring_base
 // (ring_j = dev_ring0 + j*field_stride); with only_if_full it acts only when that cycle filled up.
+int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
+                           int ring_base, int only_if_full, const GuessTerms& gt) {
+  if (dev_st == nullptr) dev_st = pde->d_st;  // the scalar state of beat_pde_solve[_ex]
+  if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
+                     dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full, gt);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
                                 int64_t field_stride, int ring_base, int only_if_full) {
   BEAT_REQUIRE(pde != nullptr && dev_x && dev_ring0, "null argument");
-  if (dev_st == nullptr) dev_st = pde->d_st;  // the scalar state of beat_pde_solve[_ex]
-  if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full);
-  const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
-                     dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full);
-  BEAT_LAUNCH_CHECK();
+  // the application a deferring solve left to its caller carries that solve's guess terms
+  GuessTerms gt{};
+  if (pde->guess_pending && !only_if_full) {
+    gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
+  return beat_pde_x_flush_terms(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
+}
+
+// ---- extrapolated initial guess --------------------------------------------------------------------------------
+extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(order >= 0 && order <= 2, "guess order must be 0, 1 or 2, got %d", order);
+  BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending: apply it before changing the guess order");
+  pde->guess_order = order;
+  pde->hist_n = 0;
+  pde->guess = GuessTerms{};
+  if (order > 0 && pde->d_hist_alloc == nullptr) {
+    const int64_t fld = pde->n + 2 * pde->g.plane;
+    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * 2 * fld));
+    BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * 2 * fld, pde->ctx->stream));
+    pde->d_hist[0] = pde->d_hist_alloc + pde->g.plane;
+    pde->d_hist[1] = pde->d_hist[0] + fld;
+  }
   return BEAT_OK;
+}
+
+extern "C" int beat_pde_guess_reset(beat_pde* pde) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending");
+  pde->hist_n = 0;
+  return BEAT_OK;
+}
+
+// 1 when the last deferring solve left an application to its caller that carries guess terms (it is due even when the
+// count of pending search directions is 0)
+extern "C" int beat_pde_guess_pending(const beat_pde* pde) { return pde != nullptr && pde->guess_pending ? 1 : 0; }
+
+// device pointers of the recorded increments (most recent first) and how many are valid: a decomposed caller exchanges
+// the ghost planes of the most recent one after the deferred update has been applied
+extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_h0, double** dev_h1, int* count) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  if (dev_h0) *dev_h0 = pde->d_hist[0];
+  if (dev_h1) *dev_h1 = pde->d_hist[1];
+  if (count) *count = pde->hist_n;
+  return BEAT_OK;
+}
+
+void beat_guess_skip(beat_pde* pde) {
+  pde->hist_n = 0;
+  pde->guess = GuessTerms{};
+}
+
+void beat_guess_begin(beat_pde* pde) {
+  pde->guess = GuessTerms{};
+  if (pde->guess_order <= 0 || pde->d_hist[0] == nullptr) return;
+  GuessTerms& g = pde->guess;
+  const int use = std::min(pde->guess_order, pde->hist_n);
+  g.h1 = pde->d_hist[0];
+  g.h2 = pde->d_hist[1];
+  g.c1 = use == 2 ? 2.0 : use == 1 ? 1.0 : 0.0;
+  g.c2 = use == 2 ? -1.0 : 0.0;
+  g.out = pde->d_hist[1];  // the older increment's storage takes the new one
+}
+
+// Terms of an x update for the ring cycle starting at iteration ring_base: the first cycle carries e and writes the
+// increment, later ones add to it.
+GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base) {
+  GuessTerms g = pde->guess;
+  if (g.out != nullptr && ring_base > 0) g.accumulate = 1;
+  return g;
+}
+
+bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
+  const bool partial = nupd % PRING != 0;
+  if (pde->guess.out == nullptr) return partial;
+  const bool e_due = nupd == 0 && pde->guess.c1 != 0.0;  // no ring cycle carried e to x yet
+  if (nupd == 0 && !e_due) {  // x = v_ is the answer and nothing was recorded: the history ends here
+    beat_guess_skip(pde);
+    return false;
+  }
+  const bool due = partial || e_due;
+  if (due && deferred) {
+    pde->guess_final = beat_guess_terms(pde, (nupd / PRING) * PRING);
+    pde->guess_pending = true;
+  }
+  // the new increment lives in (or is about to be written to) d_hist[1]: it becomes the most recent one
+  std::swap(pde->d_hist[0], pde->d_hist[1]);
+  pde->hist_n = std::min(2, pde->hist_n + 1);
+  return due;
 }
 
 extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
@@ -986,6 +1104,8 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
     BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+    beat_guess_begin(pde);
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
@@ -1008,7 +1128,8 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
         if ((rc = beat_rr_pdot(pde, st, rbuf[i & 1], p_old, p_cur))) return rc;
         if ((rc = beat_rr_rupd(pde, st, rbuf[i & 1], rbuf[(i + 1) & 1], p_cur, slot))) return rc;
         if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
-          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+            return rc;
         }
       }
       launched += chunk;
@@ -1017,12 +1138,13 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
       if (h[STOP] != 0.0 || launched >= max_it) break;
       chunk = 2;
     }
-    const int nupd = (int)h[NUPD];
-    if (nupd % PRING != 0) {
+    const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
+    const GuessTerms last = beat_guess_terms(pde, base);
+    if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
       if (defer_flush) {
-        host_pending[0] = (nupd / PRING) * PRING;
+        host_pending[0] = base;
         host_pending[1] = nupd % PRING;
-      } else if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) {
+      } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
         return rc;
       }
     }

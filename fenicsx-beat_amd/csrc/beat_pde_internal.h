@@ -27,6 +27,19 @@ struct Geom {
 
 enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_PC = 3 };
 
+// Extrapolated initial guess (beat_pde_set_guess_order): the solve starts from x0 = v_ + e, e = c1 h1 + c2 h2, where
+// h1, h2 are the increments x - v_ of the two previous solves.  e is never added to x by a pass of its own: it rides
+// with the deferred update x += e + sum alpha_j p_j, which also records the new increment in `out`.
+struct GuessTerms {
+  const double* h1 = nullptr;
+  const double* h2 = nullptr;
+  double c1 = 0.0, c2 = 0.0;
+  double* out = nullptr;  // nullptr: no guess in use (plain x += sum alpha_j p_j)
+  // an x update of a later ring cycle of the same solve: e went to x with the first cycle, this one adds its
+  // directions to x and to the increment already in `out` (h1, h2, c1, c2 unused)
+  int accumulate = 0;
+};
+
 }  // namespace beat_pde_detail
 
 struct beat_pde {
@@ -46,6 +59,14 @@ struct beat_pde {
   // z node type of the ghost planes (the neighbouring slabs' boundary planes): 1 unless that plane is a face of the
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
+  // initial guess from the previous solves' increments (0: x0 = v_; 1: + d1; 2: + 2 d1 - d2), see GuessTerms
+  int guess_order = 0;
+  double* d_hist[2] = {nullptr, nullptr};  // fields with ghost planes; [0] = most recent increment
+  double* d_hist_alloc = nullptr;
+  int hist_n = 0;                          // valid increments in d_hist
+  beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
+  bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
+  beat_pde_detail::GuessTerms guess_final{};  // ... with these terms
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
   // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
@@ -77,7 +98,18 @@ int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, do
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next);
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
-                   int ring_base, int only_if_full);
+                   int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);
+
+// initial-guess bookkeeping (beat_pde.hip).  A solve path that supports the guess calls beat_guess_begin before its
+// right-hand side, passes beat_guess_terms(pde, ring_base) to every x update and ends with beat_guess_end; every
+// other path calls beat_guess_skip (the history does not survive a solve that did not record its increment).
+void beat_guess_begin(beat_pde* pde);
+void beat_guess_skip(beat_pde* pde);
+beat_pde_detail::GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base);
+// nupd = executed updates; returns true when an application (e and/or the last partial ring cycle) is still due
+bool beat_guess_end(beat_pde* pde, int nupd, bool deferred);
+int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
+                           int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);
 
 // register-row kernels of the constant-coefficient Jacobi-PCG that never stores q = A p (beat_pde_rr.hip)
 bool beat_rr_available(const beat_pde* pde);

@@ -64,6 +64,13 @@ struct RArgs {
   double* st;           // PCG scalar state
   double* alphas;       // RUPD: step lengths of the deferred-x ring
   int slot;
+  // RHS with an extrapolated initial guess x0 = v_ + e, e = gc1 h1 + gc2 h2 (increments of the previous solves):
+  // r = b - A x0 = dt (stim - K v_) - A e;  taba / cia: the A table
+  const double* h1;
+  const double* h2;
+  double gc1, gc2;
+  const double* taba;
+  Coef cia;
 };
 
 // lane i <- lane i-1 (lane 0 <- 0) / lane i <- lane i+1 (lane 63 <- 0); all 64 lanes must be active
@@ -90,14 +97,16 @@ __device__ __forceinline__ int xcd_block(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
-// X / X2 / Y / Y2: the fields of RArgs::x, x2, y, y2 as separate restrict-qualified kernel parameters -- the launch
+// X / X2 / Y / Y2 / X3: the fields of RArgs::x, x2 (RHS with a guess: h1), y, y2, h2 as separate restrict-qualified kernel parameters -- the launch
 // passes distinct buffers (the residual update writes r out of place), and without the no-alias guarantee every
 // store would have to complete (s_waitcnt vmcnt(0)) before the next plane's loads may issue.
-template <int MODE, int RY, int PD>
+template <int MODE, int RY, int PD, bool GUESS = false>
 __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
                                                         const double* __restrict__ X2, double* __restrict__ Y,
-                                                        double* __restrict__ Y2) {
+                                                        double* __restrict__ Y2, const double* __restrict__ X3) {
   constexpr int NR = RY + 2;
+  constexpr int NE = GUESS ? NR : 1;  // rows of the second register window (the guess increment e)
+  static_assert(!GUESS || MODE == RR_RHS, "the initial guess enters the right-hand side only");
   __shared__ double red[4];
   // boundary rows of the coefficient tables and 1/diag per node type, staged in LDS: the lanes on a face of the box
   // look them up every step, and a global load there would put a full vmcnt(0) drain -- outstanding stores and the
@@ -105,12 +114,14 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
   __shared__ double s_dinv[32];
   __shared__ double s_tab[27 * TABW];
   __shared__ double s_tab2[MODE == RR_RHS ? 27 * TABW : 1];
+  __shared__ double s_taba[GUESS ? 27 * TABW : 1];
   if (MODE != RR_RHS) {
     if (a.st[STOP] != 0.0) return;  // convergence latch (uniform over the grid)
   }
   for (int i = threadIdx.x; i < 27 * TABW; i += BEAT_BLOCK) {
     s_tab[i] = a.tab[i];
     if (MODE == RR_RHS) s_tab2[i] = a.tab2[i];
+    if (GUESS) s_taba[i] = a.taba[i];
   }
   if (threadIdx.x < 27) s_dinv[threadIdx.x] = a.dinv[threadIdx.x];
   __syncthreads();
@@ -154,6 +165,16 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
   double rvn[PD][RY];
+  // GUESS: the same window of e = gc1 h1 + gc2 h2; the raw h1, h2 values wait in their own slots and are combined
+  // when the plane is staged (combining at the fetch would wait for the loads there and end the prefetch)
+  double Em[NE], E0[NE], Ep[NE], re1[PD][NE], re2[PD][NE];
+  const bool two_hist = GUESS && a.gc2 != 0.0;
+#pragma unroll
+  for (int r = 0; r < NE; ++r) {
+    Em[r] = E0[r] = Ep[r] = 0.0;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) re1[u][r] = re2[u][r] = 0.0;
+  }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     Cm[r] = C0[r] = Cp[r] = 0.0;
@@ -189,6 +210,11 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
         }
         c = (zok && row_in[r]) ? c : 0.0;
         Cp[r] = c;
+        if (GUESS) {
+          constexpr int q = GUESS ? 1 : 0;
+          const double e = fma(a.gc2, re2[u][r * q], a.gc1 * re1[u][r * q]);  // (re2 = 0 while one increment is in use)
+          Ep[r * q] = (zok && row_in[r]) ? e : 0.0;
+        }
         if (MODE == RR_PDOT) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
             Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx] = c;
@@ -216,6 +242,15 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
           ra[u][r] = bx[off[r]];
           if (MODE == RR_PDOT) rb2[u][r] = bx2[off[r]];
         }
+        if (GUESS) {
+          const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (h1, h2 come as X2, X3: see the note on aliasing)
+          const double* __restrict__ b2 = two_hist ? X3 + (int64_t)cz * g.plane : b1;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            re1[u][r < NE ? r : 0] = b1[off[r]];
+            if (two_hist) re2[u][r < NE ? r : 0] = b2[off[r]];
+          }
+        }
       }
     }
     if (z >= zb) {
@@ -230,6 +265,19 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
     for (int r = 1; r < NR; ++r) {
       R0[r] = from_right(C0[r]);
       Rp[r] = from_right(Cp[r]);
+    }
+    double eL0[NE], eR0[NE], eRp[NE], eLm[NE];
+    if (GUESS) {
+#pragma unroll
+      for (int r = 0; r < NE - 1; ++r) {
+        eL0[r] = from_left(E0[r]);
+        eLm[r] = from_left(Em[r]);
+      }
+#pragma unroll
+      for (int r = 1; r < NE; ++r) {
+        eR0[r] = from_right(E0[r]);
+        eRp[r] = from_right(Ep[r]);
+      }
     }
     const int tz = axis_type3(z, g.nz, g.z_lo_phys, g.z_hi_phys);
 #pragma unroll
@@ -275,7 +323,36 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
           double stim = 0.0;
           for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
           const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
-          const double rr = a.dt * (stim - s2);
+          double rr = a.dt * (stim - s2);
+          if (GUESS) {  // - A e
+            constexpr int q = GUESS ? 1 : 0;  // (keeps the indices in range in the instantiations without a window)
+            const int re_ = r * q, rp = (r + 1) * q, rm = (r - 1) * q;
+            double ev[15];
+            ev[0] = E0[re_];
+            ev[1] = eR0[re_];
+            ev[2] = eL0[re_];
+            ev[3] = E0[rp];
+            ev[4] = E0[rm];
+            ev[5] = Ep[re_];
+            ev[6] = Em[re_];
+            ev[7] = eR0[rp];
+            ev[8] = eL0[rm];
+            ev[9] = Ep[rp];
+            ev[10] = Em[rm];
+            ev[11] = eRp[re_];
+            ev[12] = eLm[re_];
+            ev[13] = eRp[rp];
+            ev[14] = eLm[rm];
+            double se = 0.0;
+            if (type != 13) {
+#pragma unroll
+              for (int k = 0; k < 15; ++k) se = fma(s_taba[type * TABW + k], ev[k], se);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 15; ++k) se = fma(a.cia.c[k], ev[k], se);
+            }
+            rr -= se;
+          }
           const double zz = di * rr;
           Y[gi] = rr;
           if (Y2 != nullptr) Y2[gi] = v[0];
@@ -306,6 +383,13 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
     for (int r = 0; r < NR; ++r) {
       Cm[r] = C0[r];
       C0[r] = Cp[r];
+    }
+    if (GUESS) {
+#pragma unroll
+      for (int r = 0; r < NE; ++r) {
+        Em[r] = E0[r];
+        E0[r] = Ep[r];
+      }
     }
     }  // z < ze
   }
@@ -380,11 +464,11 @@ int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 
 }
 
 // Decomposition of the planes [z_lo, z_hi) of the slab into waves; block partials are written from slot part_off on.
-RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off) {
+RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows = 0) {
   const Geom& f = pde->g;
   RGeom g{};
   const int64_t nodes = (int64_t)f.nx * f.ny * f.nz;
-  const int RY = g.ry = rr_rows(nodes);
+  const int RY = g.ry = rows ? rows : rr_rows(nodes);
   g.nx = f.nx;
   g.ny = f.ny;
   g.nz = f.nz;
@@ -424,13 +508,14 @@ Coef interior_row(const double* tab) {
   return c;
 }
 
-template <int MODE>
+template <int MODE, bool GUESS = false>
 void launch_rr(const beat_pde* pde, const RGeom& g, const RArgs& a) {
   if (g.total_blocks <= 0) return;
   const dim3 grid((unsigned)grid_blocks(g)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
   hipStream_t s = pde->ctx->stream;
 #define BEAT_RR_LAUNCH(RYV, PDV) \
-  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV>), grid, block, 0, s, g, a, a.x, a.x2, a.y, a.y2)
+  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV, GUESS>), grid, block, 0, s, g, a, a.x, GUESS ? a.h1 : a.x2, a.y, a.y2, \
+                     GUESS ? a.h2 : nullptr)
   const int pd = rr_prefetch();
   if (g.ry == 2) {
     if (pd == 2) BEAT_RR_LAUNCH(2, 2); else if (pd == 3) BEAT_RR_LAUNCH(2, 3); else BEAT_RR_LAUNCH(2, 1);
@@ -454,7 +539,10 @@ bool beat_rr_available(const beat_pde* pde) {
 // Right-hand side in residual form (see beat_pde_rhs) without the p output.
 int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
                 int n_stim, double* dev_x, double* dev_r, double* dev_st) {
-  const RGeom g = make_geom(pde);
+  const GuessTerms& gt = pde->guess;
+  const bool guess = gt.out != nullptr && gt.c1 != 0.0;
+  // with a guess the kernel holds two register windows (v_ and e): 2 rows per wave keep it at the other kernels' occupancy
+  const RGeom g = guess ? make_geom(pde, 0, pde->g.nz, 0, 2) : make_geom(pde);
   RArgs a{};
   a.x = dev_v_prev;
   a.y = dev_r;
@@ -477,7 +565,17 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   }
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
-  launch_rr<RR_RHS>(pde, g, a);
+  if (guess) {  // r = b - A (v_ + e): the second register window
+    a.h1 = gt.h1;
+    a.h2 = gt.h2;
+    a.gc1 = gt.c1;
+    a.gc2 = gt.c2;
+    a.taba = pde->d_tab(0);
+    a.cia = interior_row(pde->h_A);
+    launch_rr<RR_RHS, true>(pde, g, a);
+  } else {
+    launch_rr<RR_RHS>(pde, g, a);
+  }
   BEAT_LAUNCH_CHECK();
   return beat_pde_launch_reduce(pde, grid_blocks(g), 3, dev_st, nullptr);
 }

@@ -260,16 +260,29 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
                                                                const double* __restrict__ st, double* __restrict__ x,
                                                                const double* __restrict__ ring, int64_t fld,
                                                                const double* __restrict__ alphas, int ring_base,
-                                                               int only_if_full) {
+                                                               int only_if_full, GuessTerms gt) {
   int nvalid = (int)st[NUPD] - ring_base;
   nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
-  if (nvalid == 0 || (only_if_full && nvalid < PRING)) return;
+  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.out == nullptr)) return;
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
+    if (gt.out != nullptr) {  // inc = c1 h1 + c2 h2 + sum alpha_j P_j;  x += inc;  out = inc  (see x_flush_kernel)
+      double inc = 0.0;
+      if (!gt.accumulate) {
+        if (gt.c1 != 0.0) inc = gt.c1 * gt.h1[i];
+        if (gt.c2 != 0.0) inc = fma(gt.c2, gt.h2[i], inc);
+      }
+#pragma unroll
+      for (int j = 0; j < PRING; ++j)
+        if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
+      x[i] += inc;
+      gt.out[i] = gt.accumulate ? gt.out[i] + inc : inc;
+      continue;
+    }
     double xi = x[i];
 #pragma unroll
     for (int j = 0; j < PRING; ++j)
@@ -736,10 +749,10 @@ int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, con
 }
 
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
-                   int ring_base, int only_if_full) {
+                   int ring_base, int only_if_full, const GuessTerms& gt) {
   hipLaunchKernelGGL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
-                     (const double*)pde->d_alphas, ring_base, only_if_full);
+                     (const double*)pde->d_alphas, ring_base, only_if_full, gt);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }

@@ -316,9 +316,20 @@ struct NodeIOPending {
   double* __restrict__ v_copy;
   int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
+  double ge;     // initial-guess part of the increment (when gout != nullptr)
+  double gacc;   // what earlier ring cycles of the same solve already recorded in *gout (0 unless accumulating)
+  double* gout;  // where the step's diffusion increment is recorded, or nullptr
   __device__ __forceinline__ double load(int k) const {
     double x = base[(int64_t)k * ld + i];
     if (k == VIDX) {
+      if (gout != nullptr) {  // same expression and order as x_flush_kernel's guess branch
+        double inc = ge;
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+          if (j < npend) inc = fma(pa[j], pp[j], inc);
+        *gout = gacc + inc;  // (gacc = 0.0 exactly unless a later cycle: the sum is then inc itself)
+        return x + inc;
+      }
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING; ++j)
         if (j < npend) x = fma(pa[j], pp[j], x);

@@ -236,11 +236,13 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, 
     np.testing.assert_array_equal(x_defer, x_parts)
 
 
-@pytest.mark.parametrize("loop", ["lib", "stage"])
-def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop):
+@pytest.mark.parametrize("loop,order", [("lib", 0), ("lib", 2), ("lib", 1), ("stage", 0)])
+def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order):
     """bench.py's N > 1 step (TP06 ionic kernel applying the previous solve's pending directions on the slab's V row,
     then the slab-decomposed diffusion solve with the deferred last update) on 3 ranks played by threads: after 25 steps
-    the assembled state array equals the one-rank run to 1e-9 (the reductions are summed in a different order)."""
+    the assembled state array equals the one-rank run to 1e-9 (the reductions are summed in a different order).
+    order > 0: the solves start from the extrapolated guess (beat_pde_set_guess_order) -- the ionic kernel then also
+    records the step's diffusion increment, whose ghost planes the next decomposed solve exchanges."""
     import ctypes as C
     import threading
 
@@ -265,6 +267,7 @@ def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop):
     def run(ctx, slab, dist_view, out, key):
         n_local = plane * slab.nz
         ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *tabs)
+        ops.set_guess_order(order)
         ops.set_timestep(0.01, 0.5, 0.05)
         solver = _thread_solver(ops, slab, dist_view, loop)
         states = StateArray(ctx, len(ic), n_local, plane)

@@ -1,0 +1,131 @@
+"""How many Jacobi-PCG iterations does the diffusion solve need from different initial guesses?
+
+    x0 = v                       (what the library does: the ionic step's output)
+    x0 = v + d1                  (d1 = previous step's diffusion increment x - v)
+    x0 = v + 2 d1 - d2           (linear extrapolation of the increment)
+
+Same stopping test as the library (||r|| <= rtol ||b||).  Runs the bench workload (bump, then developed front) on
+one GPU at a reduced size with a PCG written in torch over beat_pde_apply, so no kernel has to exist before the
+numbers say whether it is worth writing.  Usage: python tools/guess_probe.py [n] [steps]
+"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "fenicsx-beat_amd"))
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from beat import _hip, _stencil  # noqa: E402
+from beat._device import Context, Field, StateArray  # noqa: E402
+from beat._engine import HipOps, Slab  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    rtol = 1e-8
+    ctx = Context(0)
+    slab = Slab(n, 0, 1)
+    plane = n * n
+    N = plane * n
+    ic, params, v_index = bench.tp06_defaults()
+    mass_tab, stiff_tab = _stencil.stencil_tables(3, (bench.H,) * 3, bench.conductivity())
+    ops = HipOps(ctx, (n, n, n), slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+    ops.set_timestep(bench.C_M, bench.THETA, bench.DT)
+    states = StateArray(ctx, len(ic), N, plane)
+    lib = ctx.lib
+    p_host = np.ascontiguousarray(params)
+    p_ptr = p_host.ctypes.data_as(C.c_void_p)
+    v = states.row_field(v_index)
+    fx, fy = Field(ctx, N, plane), Field(ctx, N, plane)
+
+    def A(x):
+        fx.data.copy_(x)
+        ops.apply(0, fx, fy)
+        return fy.data.clone()
+
+    def B(x):
+        fx.data.copy_(x)
+        ops.apply(1, fx, fy)
+        return fy.data.clone()
+
+    # diagonal of A: nodes of equal parity in x, y, z do not couple (stencil reach 1)
+    diag = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    idx = torch.arange(n, device=ctx.device)
+    for c in range(8):
+        m = (((idx % 2) == (c & 1))[None, None, :] & ((idx % 2) == ((c >> 1) & 1))[None, :, None]
+             & ((idx % 2) == ((c >> 2) & 1))[:, None, None]).reshape(-1).to(torch.float64)
+        diag += A(m) * m
+    dinv = 1.0 / diag
+
+    def pcg(b, x0, bb):
+        x = x0.clone()
+        r = b - A(x)
+        tol2 = rtol * rtol * bb
+        k = 0
+        rr = float(r @ r)
+        r0 = rr
+        if rr <= tol2:
+            return x, 0, r0
+        z = dinv * r
+        p = z.clone()
+        rz = float(r @ z)
+        while True:
+            q = A(p)
+            alpha = rz / float(p @ q)
+            x += alpha * p
+            r -= alpha * q
+            k += 1
+            rr = float(r @ r)
+            if rr <= tol2 or k >= 200:
+                return x, k, r0
+            z = dinv * r
+            rzn = float(r @ z)
+            p = z + (rzn / rz) * p
+            rz = rzn
+
+    def run(label, nsteps):
+        d1 = d2 = None
+        t = 0.0
+        rows = []
+        for i in range(nsteps):
+            _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, N, states.ld, p_ptr, len(p_host),
+                                                 None, 0, t, bench.DT, v_index, None, ops.handle, ops.ring[0].ptr, ops.fld, 0))
+            v0 = v.data.clone()
+            b = B(v0)
+            bb = float(b @ b)
+            x, k0, r0 = pcg(b, v0, bb)
+            ks, rs = [k0], [r0]
+            for g in ((v0 + d1) if d1 is not None else None, (v0 + 2 * d1 - d2) if d2 is not None else None):
+                if g is None:
+                    ks.append(-1), rs.append(float("nan"))
+                    continue
+                xg, kg, rg = pcg(b, g, bb)
+                ks.append(kg), rs.append(rg)
+            d2, d1 = d1, x - v0
+            v.data.copy_(x)
+            rows.append(ks)
+            t += bench.DT
+            if i % 5 == 4 or i < 6:
+                print(f"{label} step {i:3d}: k(v)={ks[0]} k(v+d1)={ks[1]} k(v+2d1-d2)={ks[2]}  r0/b: "
+                      + " ".join(f"{np.sqrt(r / bb):.2e}" for r in rs), flush=True)
+        rows = np.array(rows[5:])
+        print(f"{label}: mean iterations after 5 steps: v {rows[:, 0].mean():.2f}, v+d1 {rows[:, 1].mean():.2f}, "
+              f"v+2d1-d2 {rows[:, 2].mean():.2f}", flush=True)
+
+    bench.init_states(ctx, states, ic, v_index, n, slab, 1234, n)
+    run("bump", steps)
+    prof, pre = bench.developed_front_profile(ctx, n, ic, params, v_index, rtol)
+    for k in range(states.S):
+        states.rows[k].view(-1, n).copy_(prof[k][None, :].expand(N // n, n))
+    run("front", steps)
+
+
+if __name__ == "__main__":
+    main()
