@@ -261,6 +261,19 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
       if ((rc = halo_wait(comm))) return rc;
     }
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+  } else if (pde->var) {
+    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+    beat_guess_begin(pde);
+    const bool guess = pde->guess.out != nullptr && pde->guess.c1 != 0.0;
+    double* e = q + fld;  // the work field z
+    if (guess) {  // the increment is formed on the own nodes; its ghost planes come from the neighbours
+      if ((rc = beat_var_guess_increment(pde, e))) return rc;
+      if ((rc = halo_start(comm, e, n, plane))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+    }
+    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, guess ? e : nullptr);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }
@@ -305,7 +318,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
       if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
       if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
       if (slot == PRING - 1) {
-        if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+          return rc;
       }
       if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
     }

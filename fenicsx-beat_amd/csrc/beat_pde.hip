@@ -1107,6 +1107,17 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+  } else if (pde->var && npass == 0) {
+    // per-node rows, Jacobi: the guess increment e is materialised in the work field z (unused by this loop) and
+    // gathered by the right-hand side next to v_
+    BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
+    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+    beat_guess_begin(pde);
+    const bool guess = pde->guess.out != nullptr && pde->guess.c1 != 0.0;
+    if (guess && (rc = beat_var_guess_increment(pde, z))) return rc;
+    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, guess ? z : nullptr);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }
@@ -1180,7 +1191,8 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
         if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
         if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
         if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
-          if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, i + 1 - PRING, 1))) return rc;
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+            return rc;
         }
         if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
       }
@@ -1190,13 +1202,15 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
       if (h[STOP] != 0.0 || launched >= max_it) break;
       chunk = 2;
     }
-    // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x)
-    const int nupd = (int)h[NUPD];
-    if (nupd % PRING != 0) {
+    // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x) and / or the
+    // guess increment
+    const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
+    const GuessTerms last = beat_guess_terms(pde, base);
+    if (beat_guess_end(pde, nupd, defer_flush != 0)) {
       if (defer_flush) {  // the caller adds these directions itself (beat_ode_step_pending / beat_pde_x_flush)
-        host_pending[0] = (nupd / PRING) * PRING;
+        host_pending[0] = base;
         host_pending[1] = nupd % PRING;
-      } else if ((rc = beat_pde_x_flush(pde, st, dev_x, ring, fld, (nupd / PRING) * PRING, 0))) {
+      } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
         return rc;
       }
     }

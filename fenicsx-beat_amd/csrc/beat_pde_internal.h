@@ -92,7 +92,9 @@ int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, cons
 int beat_var_form_A(beat_pde* pde);
 int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y);
 int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
-                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red);
+                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red,
+                 const double* dev_e = nullptr);  // dev_e: initial-guess increment (r = b - A (v_ + e)) or nullptr
+int beat_var_guess_increment(beat_pde* pde, double* dev_e);
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);

@@ -32,6 +32,7 @@ struct VarArgs {
   double c1, c2;     // APPLY: y = (c1 T1 + c2 T2) x
   int64_t ld;
   const double* x;
+  const double* x2;  // RHS: the initial-guess increment e (x0 = v_ + e, r = b - A x0), or nullptr
   double* y;         // APPLY: y | SPMV: q | RHS: r
   double* y2;        // RHS: p
   double* y3;        // RHS: x (copy of v_) or nullptr
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
     if (i < a.i_lo || i >= a.i_hi) continue;
     // lanes on nodes outside the tissue issue no loads or stores: lines without a tissue node are never fetched
     if (a.seg && !((a.segmask[w] >> lane) & 1ull)) continue;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, se = 0.0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
       // The operators are symmetric: the coefficient towards a "backward" neighbour (even slot k, offset
@@ -85,14 +86,19 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
       const double xv = need ? a.x[i + a.doff[k]] : 0.0;
       s1 = fma(c1, xv, s1);
       s2 = fma(c2, xv, s2);
+      if (MODE == MODE_RHS && a.x2 != nullptr) {  // A e, same gather pattern
+        const double ev = (k == 0 || c1 != 0.0) ? a.x2[i + a.doff[k]] : 0.0;
+        se = fma(c1, ev, se);
+      }
     }
     if (MODE == MODE_APPLY) {
       a.y[i] = a.c1 * s1 + a.c2 * s2;
     } else {  // RHS: T1 = A, T2 = K; b = A v + r, r = dt (stim - K v)
       double stim = 0.0;
       for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
-      const double r = a.dt * (stim - s2);
-      const double b = s1 + r;  // (nodes outside the tissue are masked out above: not part of the system)
+      const double r0 = a.dt * (stim - s2);
+      const double b = s1 + r0;  // (nodes outside the tissue are masked out above: not part of the system)
+      const double r = r0 - se;  // residual at x0 = v_ + e (se = 0 without a guess)
       const double zz = a.dinv[i] * r;
       a.y[i] = r;
       a.y2[i] = zz;
@@ -288,6 +294,21 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
     for (int j = 0; j < PRING; ++j)
       if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
     x[i] = xi;
+  }
+}
+
+// e = c1 h1 + c2 h2 on the tissue nodes: the initial-guess increment, materialised once per solve so that the
+// right-hand side gathers one field instead of two (the gathers, not the bytes, bound that kernel)
+__global__ __launch_bounds__(BEAT_BLOCK) void var_guess_kernel(const int* __restrict__ seg,
+    const unsigned long long* __restrict__ segmask, int nseg, int64_t n, const double* __restrict__ h1,
+                                                               const double* __restrict__ h2, double c1, double c2,
+                                                               double* __restrict__ e) {
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
+    if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
+    double v = c1 * h1[i];
+    if (c2 != 0.0) v = fma(c2, h2[i], v);
+    e[i] = v;
   }
 }
 
@@ -667,13 +688,26 @@ int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y)
   return BEAT_OK;
 }
 
+// e = c1 h1 + c2 h2 of the solve in progress into the work field dev_e (tissue nodes; its ghost planes are the
+// caller's business on a decomposed grid)
+int beat_var_guess_increment(beat_pde* pde, double* dev_e) {
+  const GuessTerms& gt = pde->guess;
+  hipLaunchKernelGGL(var_guess_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+                     (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, gt.h1,
+                     gt.h2, gt.c1, gt.c2, dev_e);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
-                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red) {
+                 const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red,
+                 const double* dev_e) {
   VarArgs a{};
   var_offsets(pde, a);
   a.T1 = pde->v_A;
   a.T2 = pde->v_stiff;
   a.x = dev_v_prev;
+  a.x2 = dev_e;
   a.y = dev_r;
   a.y2 = dev_p;
   a.y3 = nullptr;

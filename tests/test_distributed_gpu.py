@@ -236,13 +236,15 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, 
     np.testing.assert_array_equal(x_defer, x_parts)
 
 
-@pytest.mark.parametrize("loop,order", [("lib", 0), ("lib", 2), ("lib", 1), ("stage", 0)])
-def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order):
+@pytest.mark.parametrize("loop,order,per_node", [("lib", 0, False), ("lib", 2, False), ("lib", 1, False), ("stage", 0, False),
+                                                 ("lib", 2, True), ("lib", 0, True)])
+def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order, per_node):
     """bench.py's N > 1 step (TP06 ionic kernel applying the previous solve's pending directions on the slab's V row,
     then the slab-decomposed diffusion solve with the deferred last update) on 3 ranks played by threads: after 25 steps
     the assembled state array equals the one-rank run to 1e-9 (the reductions are summed in a different order).
     order > 0: the solves start from the extrapolated guess (beat_pde_set_guess_order) -- the ionic kernel then also
-    records the step's diffusion increment, whose ghost planes the next decomposed solve exchanges."""
+    records the step's diffusion increment, whose ghost planes the next decomposed solve exchanges.  per_node: the
+    same on a voxel-masked domain with per-node operator rows (the guess increment is materialised and exchanged)."""
     import ctypes as C
     import threading
 
@@ -255,7 +257,15 @@ def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order):
     plane = nx * ny
     f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
     M = 9.5301e-4 * np.outer(f0, f0) + 1.2576e-4 * (np.eye(3) - np.outer(f0, f0))
-    tabs = _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
+    cells = (nx - 1, ny - 1, nz - 1)
+    cc = np.stack(np.meshgrid(np.arange(nz - 1), np.arange(ny - 1), np.arange(nx - 1), indexing="ij"), -1).reshape(-1, 3)
+    active = ((cc - np.array([5, 8, 9])) ** 2).sum(axis=1) < 9**2
+
+    def operators(z_range):
+        if per_node:
+            return _stencil.stencil_fields(3, cells, (0.1, 0.1, 0.1), M, active, z_range=z_range)
+        return _stencil.stencil_tables(3, (0.1, 0.1, 0.1), M)
+
     ic = tp06.init_state_values()
     p_host = np.ascontiguousarray(tp06.init_parameter_values(stim_amplitude=0.0))
     vi = tp06.state_index("V")
@@ -266,7 +276,7 @@ def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order):
 
     def run(ctx, slab, dist_view, out, key):
         n_local = plane * slab.nz
-        ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *tabs)
+        ops = HipOps(ctx, (nx, ny, slab.nz), slab.lo_phys, slab.hi_phys, *operators((slab.z0, slab.z1)), per_node=per_node)
         ops.set_guess_order(order)
         ops.set_timestep(0.01, 0.5, 0.05)
         solver = _thread_solver(ops, slab, dist_view, loop)
