@@ -74,3 +74,34 @@ __device__ __forceinline__ double beat_block_sum(double v, double* smem) {
   __syncthreads();
   return s;
 }
+
+namespace beat_pde_detail {
+// Extrapolated initial guess (beat_pde_set_guess_order): the solve starts from x0 = v_ + e, where e was prepared by
+// the previous solve's x update from the increments d = x - v_ of the last solves (e = d1, or 2 d1 - d2).  e is never
+// added to x by a pass of its own: it rides with the deferred update  x += inc, inc = e + sum alpha_j p_j,  which
+// also records d <- inc and prepares the next guess  e <- a inc + b d_old  in place.
+struct GuessTerms {
+  double* d = nullptr;  // most recent increment (in: d_old, out: this solve's); nullptr: no guess in use
+  double* e = nullptr;  // in: this solve's guess increment (if use_e), out: the next solve's
+  double a = 1.0, b = 0.0;
+  int use_e = 0;
+  // an x update of a later ring cycle of the same solve: e went to x with the first cycle, this one adds its
+  // directions to x and to what the first cycle recorded (d += inc, e += a inc)
+  int accumulate = 0;
+};
+
+// what an x update does to (d, e) once its increment is known -- one expression shared by the flush kernels and the
+// ionic kernel's pending path, so that both leave the same bits behind.  d_old / e_old: the values the two fields
+// held (read by the caller up front, together with its other loads; unused ones may be anything)
+__device__ __forceinline__ bool beat_guess_needs_d(const GuessTerms& gt) { return gt.accumulate || gt.b != 0.0; }
+__device__ __forceinline__ void beat_guess_record(const GuessTerms& gt, double* d, double* e, double inc, double d_old,
+                                                  double e_old) {
+  if (gt.accumulate) {
+    *d = d_old + inc;
+    *e = fma(gt.a, inc, e_old);
+  } else {
+    *d = inc;
+    *e = gt.b != 0.0 ? fma(gt.b, d_old, gt.a * inc) : gt.a * inc;
+  }
+}
+}  // namespace beat_pde_detail

@@ -254,10 +254,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    if (pde->guess.out != nullptr && pde->guess.c1 != 0.0) {
-      // ghost planes of the most recent increment (written by the deferred update since the last solve; the older
-      // one's were exchanged a step ago)
-      if ((rc = halo_start(comm, const_cast<double*>(pde->guess.h1), n, plane))) return rc;
+    if (pde->guess.use_e) {  // ghost planes of the guess increment (written by the x update of the previous solve)
+      if ((rc = halo_start(comm, pde->guess.e, n, plane))) return rc;
       if ((rc = halo_wait(comm))) return rc;
     }
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
@@ -266,14 +264,12 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    const bool guess = pde->guess.out != nullptr && pde->guess.c1 != 0.0;
-    double* e = q + fld;  // the work field z
-    if (guess) {  // the increment is formed on the own nodes; its ghost planes come from the neighbours
-      if ((rc = beat_var_guess_increment(pde, e))) return rc;
-      if ((rc = halo_start(comm, e, n, plane))) return rc;
+    if (pde->guess.use_e) {  // ghost planes of the guess increment
+      if ((rc = halo_start(comm, pde->guess.e, n, plane))) return rc;
       if ((rc = halo_wait(comm))) return rc;
     }
-    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, guess ? e : nullptr);
+    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
+                      pde->guess.use_e ? pde->guess.e : nullptr);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }
@@ -281,7 +277,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if ((rc = allreduce_sum(comm, st + BB, 3))) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
-  int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  int chunk = beat_pde_first_chunk(pde);
   double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
   if (rr && (rc = halo_start(comm, rbuf[0], n, plane))) return rc;  // ghost planes of r_0
   while (true) {

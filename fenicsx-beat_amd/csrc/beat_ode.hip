@@ -21,8 +21,8 @@ struct PendingV {
   int64_t fld;
   const double* alphas;  // device, step lengths alpha_j
   int count;             // 0: no search direction pending
-  // the solve started from an extrapolated guess (beat_pde_set_guess_order): v += inc, inc = c1 h1 + c2 h2 +
-  // sum alpha_j p_j, and inc is recorded in gt.out as the step's diffusion increment (gt.out == nullptr: no guess)
+  // the solve started from an extrapolated guess (beat_pde_set_guess_order): v += inc, inc = e + sum alpha_j p_j,
+  // inc is recorded as the step's diffusion increment and the next guess prepared (gt.d == nullptr: no guess)
   beat_pde_detail::GuessTerms gt;
 };
 
@@ -42,22 +42,16 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   if (i >= n) return;
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, nullptr};
+    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
       io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
       io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
     }
-    if (pend.gt.out != nullptr) {
-      double e = 0.0;
-      if (pend.gt.accumulate) {
-        io.gacc = pend.gt.out[i];
-      } else {
-        if (pend.gt.c1 != 0.0) e = pend.gt.c1 * __builtin_nontemporal_load(pend.gt.h1 + i);
-        if (pend.gt.c2 != 0.0) e = fma(pend.gt.c2, __builtin_nontemporal_load(pend.gt.h2 + i), e);
-      }
-      io.ge = e;
-      io.gout = pend.gt.out + i;
+    if (pend.gt.d != nullptr) {
+      io.gt = pend.gt;
+      io.ge = (pend.gt.accumulate || pend.gt.use_e) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
+      io.gd = beat_pde_detail::beat_guess_needs_d(pend.gt) ? __builtin_nontemporal_load(pend.gt.d + i) : 0.0;
     }
     if (PER_NODE) {
       double pl[Model::NP];
@@ -213,7 +207,7 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
                "model expects %d parameters, got %d", Model::NP, num_params);
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
-  const bool have_pend = pend.count > 0 || pend.gt.out != nullptr;
+  const bool have_pend = pend.count > 0 || pend.gt.d != nullptr;
   BEAT_REQUIRE(!have_pend || v_index == Model::V_INDEX,
                "a pending update needs v_index = %d (the model's membrane potential), got %d", Model::V_INDEX, v_index);
   ParamPack<Model::NP> prm;

@@ -490,8 +490,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void cg_pupdate_oop_kernel(Geom g, cons
 
 // x += sum_{j < nvalid} alphas[j] * P_j, nvalid = clamp(executed updates - ring_base, 0, PRING).
 // Runs regardless of the latch: it is what brings x up to date after convergence.
-// With guess terms (gt.out != nullptr): inc = c1 h1 + c2 h2 + sum alpha_j P_j;  x += inc;  out = inc  (out may be h2);
-// with gt.accumulate: inc = sum alpha_j P_j;  x += inc;  out += inc.
+// With guess terms (gt.d != nullptr): inc = e + sum alpha_j P_j;  x += inc;  then beat_guess_record (d, e updated).
 __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const double* __restrict__ st,
                                                              double* __restrict__ x,
                                                              const double* __restrict__ ring, int64_t fld,
@@ -501,26 +500,23 @@ __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const do
   nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
   // in-loop flushes are enqueued ahead of time: they must do nothing unless their ring cycle really
   // filled up (a partially filled last cycle is flushed once, after the host has seen the latch)
-  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.out == nullptr)) return;
+  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.d == nullptr)) return;
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
-  if (gt.out != nullptr) {
-    const double* h1 = gt.h1;
-    const double* h2 = gt.h2;  // may alias gt.out (read before written, same index)
-    double* out = gt.out;
+  if (gt.d != nullptr) {
+    double* d = gt.d;
+    double* e = gt.e;
     for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
-      double inc = 0.0;
-      if (!gt.accumulate) {
-        if (gt.c1 != 0.0) inc = gt.c1 * h1[i];
-        if (gt.c2 != 0.0) inc = fma(gt.c2, h2[i], inc);
-      }
+      const double e_old = (gt.accumulate || gt.use_e) ? e[i] : 0.0;
+      const double d_old = beat_guess_needs_d(gt) ? d[i] : 0.0;
+      double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
       for (int j = 0; j < PRING; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
-      out[i] = gt.accumulate ? out[i] + inc : inc;
+      beat_guess_record(gt, d + i, e + i, inc, d_old, e_old);
     }
     return;
   }
@@ -1018,12 +1014,12 @@ extern "C" int beat_pde_guess_reset(beat_pde* pde) {
 // count of pending search directions is 0)
 extern "C" int beat_pde_guess_pending(const beat_pde* pde) { return pde != nullptr && pde->guess_pending ? 1 : 0; }
 
-// device pointers of the recorded increments (most recent first) and how many are valid: a decomposed caller exchanges
-// the ghost planes of the most recent one after the deferred update has been applied
-extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_h0, double** dev_h1, int* count) {
+// device pointers of the last recorded increment d = x - v_ and of the guess increment e prepared for the next solve,
+// and the number of solves recorded since the history was dropped (0: the next solve starts from x0 = v_)
+extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, int* count) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
-  if (dev_h0) *dev_h0 = pde->d_hist[0];
-  if (dev_h1) *dev_h1 = pde->d_hist[1];
+  if (dev_d) *dev_d = pde->d_hist[0];
+  if (dev_e) *dev_e = pde->d_hist[1];
   if (count) *count = pde->hist_n;
   return BEAT_OK;
 }
@@ -1037,26 +1033,28 @@ void beat_guess_begin(beat_pde* pde) {
   pde->guess = GuessTerms{};
   if (pde->guess_order <= 0 || pde->d_hist[0] == nullptr) return;
   GuessTerms& g = pde->guess;
-  const int use = std::min(pde->guess_order, pde->hist_n);
-  g.h1 = pde->d_hist[0];
-  g.h2 = pde->d_hist[1];
-  g.c1 = use == 2 ? 2.0 : use == 1 ? 1.0 : 0.0;
-  g.c2 = use == 2 ? -1.0 : 0.0;
-  g.out = pde->d_hist[1];  // the older increment's storage takes the new one
+  g.d = pde->d_hist[0];
+  g.e = pde->d_hist[1];
+  g.use_e = pde->hist_n >= 1;
+  // the guess after this solve: with two increments on record (this one and the previous) and order 2 the linear
+  // extrapolation 2 d_new - d_old, otherwise d_new
+  const bool extrapolate = pde->guess_order >= 2 && pde->hist_n >= 1;
+  g.a = extrapolate ? 2.0 : 1.0;
+  g.b = extrapolate ? -1.0 : 0.0;
 }
 
-// Terms of an x update for the ring cycle starting at iteration ring_base: the first cycle carries e and writes the
+// Terms of an x update for the ring cycle starting at iteration ring_base: the first cycle carries e and records the
 // increment, later ones add to it.
 GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base) {
   GuessTerms g = pde->guess;
-  if (g.out != nullptr && ring_base > 0) g.accumulate = 1;
+  if (g.d != nullptr && ring_base > 0) g.accumulate = 1;
   return g;
 }
 
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
   const bool partial = nupd % PRING != 0;
-  if (pde->guess.out == nullptr) return partial;
-  const bool e_due = nupd == 0 && pde->guess.c1 != 0.0;  // no ring cycle carried e to x yet
+  if (pde->guess.d == nullptr) return partial;
+  const bool e_due = nupd == 0 && pde->guess.use_e;  // no ring cycle carried e to x yet
   if (nupd == 0 && !e_due) {  // x = v_ is the answer and nothing was recorded: the history ends here
     beat_guess_skip(pde);
     return false;
@@ -1066,8 +1064,6 @@ bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
     pde->guess_final = beat_guess_terms(pde, (nupd / PRING) * PRING);
     pde->guess_pending = true;
   }
-  // the new increment lives in (or is about to be written to) d_hist[1]: it becomes the most recent one
-  std::swap(pde->d_hist[0], pde->d_hist[1]);
   pde->hist_n = std::min(2, pde->hist_n + 1);
   return due;
 }
@@ -1108,23 +1104,21 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     beat_guess_begin(pde);
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
   } else if (pde->var && npass == 0) {
-    // per-node rows, Jacobi: the guess increment e is materialised in the work field z (unused by this loop) and
-    // gathered by the right-hand side next to v_
+    // per-node rows, Jacobi: the right-hand side gathers the guess increment e next to v_
     BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
     BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    const bool guess = pde->guess.out != nullptr && pde->guess.c1 != 0.0;
-    if (guess && (rc = beat_var_guess_increment(pde, z))) return rc;
-    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, guess ? z : nullptr);
+    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
+                      pde->guess.use_e ? pde->guess.e : nullptr);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }
   if (rc) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
-  int chunk = pde->last_iters > 0 ? pde->last_iters : 8;
+  int chunk = beat_pde_first_chunk(pde);
   if (rr) {
     // iteration i: p_i = D^-1 r + beta p_{i-1} and p_i . A p_i in one pass (ring slot i % PRING), then
     // r_new = r - alpha A p_i with A p_i recomputed (written to the other of the two residual buffers: the kernel

@@ -4,6 +4,8 @@
 #pragma once
 #include "beat_common.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace beat_pde_detail {
@@ -27,19 +29,6 @@ struct Geom {
 
 enum { MODE_APPLY = 0, MODE_SPMV_DOT = 1, MODE_RHS = 2, MODE_PC = 3 };
 
-// Extrapolated initial guess (beat_pde_set_guess_order): the solve starts from x0 = v_ + e, e = c1 h1 + c2 h2, where
-// h1, h2 are the increments x - v_ of the two previous solves.  e is never added to x by a pass of its own: it rides
-// with the deferred update x += e + sum alpha_j p_j, which also records the new increment in `out`.
-struct GuessTerms {
-  const double* h1 = nullptr;
-  const double* h2 = nullptr;
-  double c1 = 0.0, c2 = 0.0;
-  double* out = nullptr;  // nullptr: no guess in use (plain x += sum alpha_j p_j)
-  // an x update of a later ring cycle of the same solve: e went to x with the first cycle, this one adds its
-  // directions to x and to the increment already in `out` (h1, h2, c1, c2 unused)
-  int accumulate = 0;
-};
-
 }  // namespace beat_pde_detail
 
 struct beat_pde {
@@ -61,9 +50,9 @@ struct beat_pde {
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
   // initial guess from the previous solves' increments (0: x0 = v_; 1: + d1; 2: + 2 d1 - d2), see GuessTerms
   int guess_order = 0;
-  double* d_hist[2] = {nullptr, nullptr};  // fields with ghost planes; [0] = most recent increment
+  double* d_hist[2] = {nullptr, nullptr};  // fields with ghost planes: [0] = d (last increment), [1] = e (next guess)
   double* d_hist_alloc = nullptr;
-  int hist_n = 0;                          // valid increments in d_hist
+  int hist_n = 0;                          // solves recorded since the history was last dropped (capped at 2)
   beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
   beat_pde_detail::GuessTerms guess_final{};  // ... with these terms
@@ -84,6 +73,17 @@ struct beat_pde {
   const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }
 };
 
+// Iterations enqueued before the host first looks at the convergence latch: the previous solve's count plus one.  A
+// latched iteration costs four empty launches (~20 us); one short costs a host round trip with the GPU idle plus a
+// second one after the catch-up iterations, and consecutive time steps differ by one iteration all the time.
+inline int beat_pde_first_chunk(const beat_pde* pde) {
+  static const int extra = [] {
+    const char* e = std::getenv("BEAT_CHUNK_EXTRA");
+    return e ? std::max(0, std::atoi(e)) : 1;
+  }();
+  return pde->last_iters >= 0 ? std::max(1, pde->last_iters + extra) : 8;
+}
+
 // fixed-order sum of `count` block partials of `nsum` quantities into out[0..nsum) (beat_pde.hip)
 int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter = nullptr);
 
@@ -94,7 +94,6 @@ int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y)
 int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                  const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red,
                  const double* dev_e = nullptr);  // dev_e: initial-guess increment (r = b - A (v_ + e)) or nullptr
-int beat_var_guess_increment(beat_pde* pde, double* dev_e);
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);

@@ -64,11 +64,8 @@ struct RArgs {
   double* st;           // PCG scalar state
   double* alphas;       // RUPD: step lengths of the deferred-x ring
   int slot;
-  // RHS with an extrapolated initial guess x0 = v_ + e, e = gc1 h1 + gc2 h2 (increments of the previous solves):
-  // r = b - A x0 = dt (stim - K v_) - A e;  taba / cia: the A table
-  const double* h1;
-  const double* h2;
-  double gc1, gc2;
+  // RHS with an extrapolated initial guess x0 = v_ + e:  r = b - A x0 = dt (stim - K v_) - A e;  taba / cia: the A table
+  const double* e;
   const double* taba;
   Coef cia;
 };
@@ -97,13 +94,13 @@ __device__ __forceinline__ int xcd_block(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
-// X / X2 / Y / Y2 / X3: the fields of RArgs::x, x2 (RHS with a guess: h1), y, y2, h2 as separate restrict-qualified kernel parameters -- the launch
+// X / X2 / Y / Y2: the fields of RArgs::x, x2 (RHS with a guess: e), y, y2 as separate restrict-qualified kernel parameters -- the launch
 // passes distinct buffers (the residual update writes r out of place), and without the no-alias guarantee every
 // store would have to complete (s_waitcnt vmcnt(0)) before the next plane's loads may issue.
 template <int MODE, int RY, int PD, bool GUESS = false>
-__global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
+__global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
                                                         const double* __restrict__ X2, double* __restrict__ Y,
-                                                        double* __restrict__ Y2, const double* __restrict__ X3) {
+                                                        double* __restrict__ Y2) {
   constexpr int NR = RY + 2;
   constexpr int NE = GUESS ? NR : 1;  // rows of the second register window (the guess increment e)
   static_assert(!GUESS || MODE == RR_RHS, "the initial guess enters the right-hand side only");
@@ -165,15 +162,13 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
   double rvn[PD][RY];
-  // GUESS: the same window of e = gc1 h1 + gc2 h2; the raw h1, h2 values wait in their own slots and are combined
-  // when the plane is staged (combining at the fetch would wait for the loads there and end the prefetch)
-  double Em[NE], E0[NE], Ep[NE], re1[PD][NE], re2[PD][NE];
-  const bool two_hist = GUESS && a.gc2 != 0.0;
+  // GUESS: the same window of e (fetched with the plane of v_, staged with it)
+  double Em[NE], E0[NE], Ep[NE], re1[PD][NE];
 #pragma unroll
   for (int r = 0; r < NE; ++r) {
     Em[r] = E0[r] = Ep[r] = 0.0;
 #pragma unroll
-    for (int u = 0; u < PD; ++u) re1[u][r] = re2[u][r] = 0.0;
+    for (int u = 0; u < PD; ++u) re1[u][r] = 0.0;
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -212,8 +207,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
         Cp[r] = c;
         if (GUESS) {
           constexpr int q = GUESS ? 1 : 0;
-          const double e = fma(a.gc2, re2[u][r * q], a.gc1 * re1[u][r * q]);  // (re2 = 0 while one increment is in use)
-          Ep[r * q] = (zok && row_in[r]) ? e : 0.0;
+          Ep[r * q] = (zok && row_in[r]) ? re1[u][r * q] : 0.0;
         }
         if (MODE == RR_PDOT) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
@@ -243,13 +237,9 @@ __global__ __launch_bounds__(BEAT_BLOCK) void rr_kernel(RGeom g, RArgs a, const 
           if (MODE == RR_PDOT) rb2[u][r] = bx2[off[r]];
         }
         if (GUESS) {
-          const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (h1, h2 come as X2, X3: see the note on aliasing)
-          const double* __restrict__ b2 = two_hist ? X3 + (int64_t)cz * g.plane : b1;
+          const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            re1[u][r < NE ? r : 0] = b1[off[r]];
-            if (two_hist) re2[u][r < NE ? r : 0] = b2[off[r]];
-          }
+          for (int r = 0; r < NR; ++r) re1[u][r < NE ? r : 0] = b1[off[r]];
         }
       }
     }
@@ -514,8 +504,7 @@ void launch_rr(const beat_pde* pde, const RGeom& g, const RArgs& a) {
   const dim3 grid((unsigned)grid_blocks(g)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
   hipStream_t s = pde->ctx->stream;
 #define BEAT_RR_LAUNCH(RYV, PDV) \
-  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV, GUESS>), grid, block, 0, s, g, a, a.x, GUESS ? a.h1 : a.x2, a.y, a.y2, \
-                     GUESS ? a.h2 : nullptr)
+  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV, GUESS>), grid, block, 0, s, g, a, a.x, GUESS ? a.e : a.x2, a.y, a.y2)
   const int pd = rr_prefetch();
   if (g.ry == 2) {
     if (pd == 2) BEAT_RR_LAUNCH(2, 2); else if (pd == 3) BEAT_RR_LAUNCH(2, 3); else BEAT_RR_LAUNCH(2, 1);
@@ -540,7 +529,7 @@ bool beat_rr_available(const beat_pde* pde) {
 int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
                 int n_stim, double* dev_x, double* dev_r, double* dev_st) {
   const GuessTerms& gt = pde->guess;
-  const bool guess = gt.out != nullptr && gt.c1 != 0.0;
+  const bool guess = gt.d != nullptr && gt.use_e;
   // with a guess the kernel holds two register windows (v_ and e): 2 rows per wave keep it at the other kernels' occupancy
   const RGeom g = guess ? make_geom(pde, 0, pde->g.nz, 0, 2) : make_geom(pde);
   RArgs a{};
@@ -566,10 +555,7 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
   if (guess) {  // r = b - A (v_ + e): the second register window
-    a.h1 = gt.h1;
-    a.h2 = gt.h2;
-    a.gc1 = gt.c1;
-    a.gc2 = gt.c2;
+    a.e = gt.e;
     a.taba = pde->d_tab(0);
     a.cia = interior_row(pde->h_A);
     launch_rr<RR_RHS, true>(pde, g, a);

@@ -269,24 +269,22 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
                                                                int only_if_full, GuessTerms gt) {
   int nvalid = (int)st[NUPD] - ring_base;
   nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
-  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.out == nullptr)) return;
+  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.d == nullptr)) return;
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
-    if (gt.out != nullptr) {  // inc = c1 h1 + c2 h2 + sum alpha_j P_j;  x += inc;  out = inc  (see x_flush_kernel)
-      double inc = 0.0;
-      if (!gt.accumulate) {
-        if (gt.c1 != 0.0) inc = gt.c1 * gt.h1[i];
-        if (gt.c2 != 0.0) inc = fma(gt.c2, gt.h2[i], inc);
-      }
+    if (gt.d != nullptr) {  // inc = e + sum alpha_j P_j;  x += inc;  (d, e) updated  (see x_flush_kernel)
+      const double e_old = (gt.accumulate || gt.use_e) ? gt.e[i] : 0.0;
+      const double d_old = beat_guess_needs_d(gt) ? gt.d[i] : 0.0;
+      double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
       for (int j = 0; j < PRING; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
-      gt.out[i] = gt.accumulate ? gt.out[i] + inc : inc;
+      beat_guess_record(gt, gt.d + i, gt.e + i, inc, d_old, e_old);
       continue;
     }
     double xi = x[i];
@@ -294,21 +292,6 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
     for (int j = 0; j < PRING; ++j)
       if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
     x[i] = xi;
-  }
-}
-
-// e = c1 h1 + c2 h2 on the tissue nodes: the initial-guess increment, materialised once per solve so that the
-// right-hand side gathers one field instead of two (the gathers, not the bytes, bound that kernel)
-__global__ __launch_bounds__(BEAT_BLOCK) void var_guess_kernel(const int* __restrict__ seg,
-    const unsigned long long* __restrict__ segmask, int nseg, int64_t n, const double* __restrict__ h1,
-                                                               const double* __restrict__ h2, double c1, double c2,
-                                                               double* __restrict__ e) {
-  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
-    const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
-    if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
-    double v = c1 * h1[i];
-    if (c2 != 0.0) v = fma(c2, h2[i], v);
-    e[i] = v;
   }
 }
 
@@ -684,17 +667,6 @@ int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y)
     a.T1 = which == 2 ? pde->v_mass : pde->v_stiff;
   }
   launch_var<MODE_APPLY>(pde, a, 0, pde->g.nz, 0, /*dense=*/true);
-  BEAT_LAUNCH_CHECK();
-  return BEAT_OK;
-}
-
-// e = c1 h1 + c2 h2 of the solve in progress into the work field dev_e (tissue nodes; its ghost planes are the
-// caller's business on a decomposed grid)
-int beat_var_guess_increment(beat_pde* pde, double* dev_e) {
-  const GuessTerms& gt = pde->guess;
-  hipLaunchKernelGGL(var_guess_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                     (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, gt.h1,
-                     gt.h2, gt.c1, gt.c2, dev_e);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }

@@ -316,18 +316,17 @@ struct NodeIOPending {
   double* __restrict__ v_copy;
   int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
-  double ge;     // initial-guess part of the increment (when gout != nullptr)
-  double gacc;   // what earlier ring cycles of the same solve already recorded in *gout (0 unless accumulating)
-  double* gout;  // where the step's diffusion increment is recorded, or nullptr
+  double ge, gd;                    // what the fields e and d held at this node (when gt.d != nullptr; read up front)
+  beat_pde_detail::GuessTerms gt;   // where the step's diffusion increment is recorded and the next guess prepared
   __device__ __forceinline__ double load(int k) const {
     double x = base[(int64_t)k * ld + i];
     if (k == VIDX) {
-      if (gout != nullptr) {  // same expression and order as x_flush_kernel's guess branch
-        double inc = ge;
+      if (gt.d != nullptr) {  // same expressions and order as x_flush_kernel's guess branch
+        double inc = gt.accumulate ? 0.0 : ge;
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
           if (j < npend) inc = fma(pa[j], pp[j], inc);
-        *gout = gacc + inc;  // (gacc = 0.0 exactly unless a later cycle: the sum is then inc itself)
+        beat_pde_detail::beat_guess_record(gt, gt.d + i, gt.e + i, inc, gd, ge);
         return x + inc;
       }
 #pragma unroll
