@@ -184,7 +184,7 @@ class HipOps:
         self.st_ptr_for_flush = None   # scalar state the pending update belongs to (None: the handle's own)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
-        self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for order 2 by default)
+        self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for order 3 by default)
 
     @classmethod
     def from_voxels(cls, ctx, dim, cells, h, M, active, shape_local, z0, lo_phys, hi_phys):
@@ -378,8 +378,8 @@ class HipOps:
         return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
 
     def set_guess_order(self, order: int) -> None:
-        """0: every solve starts from x0 = v_; 1 / 2: from v_ plus the previous increment / the linear extrapolation
-        of the last two (beat_pde_set_guess_order).  Drops the history."""
+        """0: every solve starts from x0 = v_; m = 1..4: from v_ plus the degree-(m-1) extrapolation in time of the last
+        m diffusion increments (beat_pde_set_guess_order).  Drops the history."""
         self.flush_pending()
         _hip.check(self.lib.beat_pde_set_guess_order(self.handle, int(order)))
         self.guess_order = int(order)

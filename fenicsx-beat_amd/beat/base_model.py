@@ -144,8 +144,9 @@ class BaseModel:
         self._timestep = grid.Constant(mesh, self.parameters["default_timestep"])
         self._setup_operators()
         # initial guess of the linear solves from the previous steps' increments (PETSc's KSPGuess; the reference
-        # leaves it off): petsc_options["ksp_guess_order"] in {0, 1, 2}, default BEAT_GUESS_ORDER or 2
-        order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", 2))
+        # leaves it off): petsc_options["ksp_guess_order"] in 0..4, default BEAT_GUESS_ORDER or 3 (quadratic
+        # extrapolation in time: best on the benchmark's steps, second to the cubic on a developed front)
+        order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", 3))
         if hasattr(self._ops, "set_guess_order"):
             self._ops.set_guess_order(int(order))
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]

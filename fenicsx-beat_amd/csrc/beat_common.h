@@ -77,13 +77,17 @@ __device__ __forceinline__ double beat_block_sum(double v, double* smem) {
 
 namespace beat_pde_detail {
 // Extrapolated initial guess (beat_pde_set_guess_order): the solve starts from x0 = v_ + e, where e was prepared by
-// the previous solve's x update from the increments d = x - v_ of the last solves (e = d1, or 2 d1 - d2).  e is never
-// added to x by a pass of its own: it rides with the deferred update  x += inc, inc = e + sum alpha_j p_j,  which
-// also records d <- inc and prepares the next guess  e <- a inc + b d_old  in place.
+// the previous solve's x update from the increments d = x - v_ of the last solves: polynomial extrapolation in time
+// of degree m - 1 through the last m increments, e = sum_{i=1..m} (-1)^(i+1) C(m, i) d_i  (m = 1: d1; 2: 2 d1 - d2;
+// 3: 3 d1 - 3 d2 + d3; 4: 4 d1 - 6 d2 + 4 d3 - d4).  e is never added to x by a pass of its own: it rides with the
+// deferred update  x += inc, inc = e + sum alpha_j p_j,  which also records d <- inc (over the oldest increment kept)
+// and prepares the next guess  e <- a inc + cd d_old + sum cp_j dp_j  in place.
+constexpr int BEAT_GUESS_MAX_ORDER = 4;
 struct GuessTerms {
-  double* d = nullptr;  // most recent increment (in: d_old, out: this solve's); nullptr: no guess in use
-  double* e = nullptr;  // in: this solve's guess increment (if use_e), out: the next solve's
-  double a = 1.0, b = 0.0;
+  double* d = nullptr;   // in: the oldest increment kept, out: this solve's; nullptr: no guess in use
+  const double* dp[BEAT_GUESS_MAX_ORDER - 2] = {nullptr, nullptr};  // the newer increments (d1, d2): read only
+  double* e = nullptr;   // in: this solve's guess increment (if use_e), out: the next solve's
+  double a = 1.0, cd = 0.0, cp[BEAT_GUESS_MAX_ORDER - 2] = {0.0, 0.0};
   int use_e = 0;
   // an x update of a later ring cycle of the same solve: e went to x with the first cycle, this one adds its
   // directions to x and to what the first cycle recorded (d += inc, e += a inc)
@@ -91,17 +95,23 @@ struct GuessTerms {
 };
 
 // what an x update does to (d, e) once its increment is known -- one expression shared by the flush kernels and the
-// ionic kernel's pending path, so that both leave the same bits behind.  d_old / e_old: the values the two fields
-// held (read by the caller up front, together with its other loads; unused ones may be anything)
-__device__ __forceinline__ bool beat_guess_needs_d(const GuessTerms& gt) { return gt.accumulate || gt.b != 0.0; }
+// ionic kernel's pending path, so that both leave the same bits behind.  d_old / dp_old / e_old: the values the
+// fields held (read by the caller up front, together with its other loads; unused ones may be anything)
+__device__ __forceinline__ bool beat_guess_needs_d(const GuessTerms& gt) { return gt.accumulate || gt.cd != 0.0; }
+__device__ __forceinline__ bool beat_guess_needs_dp(const GuessTerms& gt, int j) { return !gt.accumulate && gt.cp[j] != 0.0; }
+__device__ __forceinline__ bool beat_guess_needs_e(const GuessTerms& gt) { return gt.accumulate || gt.use_e; }
 __device__ __forceinline__ void beat_guess_record(const GuessTerms& gt, double* d, double* e, double inc, double d_old,
-                                                  double e_old) {
+                                                  double dp0_old, double dp1_old, double e_old) {
   if (gt.accumulate) {
     *d = d_old + inc;
     *e = fma(gt.a, inc, e_old);
   } else {
+    double en = gt.a * inc;
+    if (gt.cp[0] != 0.0) en = fma(gt.cp[0], dp0_old, en);
+    if (gt.cp[1] != 0.0) en = fma(gt.cp[1], dp1_old, en);
+    if (gt.cd != 0.0) en = fma(gt.cd, d_old, en);
     *d = inc;
-    *e = gt.b != 0.0 ? fma(gt.b, d_old, gt.a * inc) : gt.a * inc;
+    *e = en;
   }
 }
 }  // namespace beat_pde_detail

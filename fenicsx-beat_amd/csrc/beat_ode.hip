@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   if (i >= n) return;
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, {}};
+    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
       io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
@@ -50,8 +50,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     }
     if (pend.gt.d != nullptr) {
       io.gt = pend.gt;
-      io.ge = (pend.gt.accumulate || pend.gt.use_e) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
+      io.ge = beat_pde_detail::beat_guess_needs_e(pend.gt) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
       io.gd = beat_pde_detail::beat_guess_needs_d(pend.gt) ? __builtin_nontemporal_load(pend.gt.d + i) : 0.0;
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 0) ? __builtin_nontemporal_load(pend.gt.dp[0] + i) : 0.0;
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 1) ? __builtin_nontemporal_load(pend.gt.dp[1] + i) : 0.0;
     }
     if (PER_NODE) {
       double pl[Model::NP];

@@ -509,14 +509,16 @@ __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const do
     double* d = gt.d;
     double* e = gt.e;
     for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
-      const double e_old = (gt.accumulate || gt.use_e) ? e[i] : 0.0;
+      const double e_old = beat_guess_needs_e(gt) ? e[i] : 0.0;
       const double d_old = beat_guess_needs_d(gt) ? d[i] : 0.0;
+      const double dp0 = beat_guess_needs_dp(gt, 0) ? gt.dp[0][i] : 0.0;
+      const double dp1 = beat_guess_needs_dp(gt, 1) ? gt.dp[1][i] : 0.0;
       double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
       for (int j = 0; j < PRING; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
-      beat_guess_record(gt, d + i, e + i, inc, d_old, e_old);
+      beat_guess_record(gt, d + i, e + i, inc, d_old, dp0, dp1, e_old);
     }
     return;
   }
@@ -988,17 +990,18 @@ extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
 extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
-  BEAT_REQUIRE(order >= 0 && order <= 2, "guess order must be 0, 1 or 2, got %d", order);
+  BEAT_REQUIRE(order >= 0 && order <= BEAT_GUESS_MAX_ORDER, "guess order must be 0..%d, got %d", BEAT_GUESS_MAX_ORDER, order);
   BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending: apply it before changing the guess order");
   pde->guess_order = order;
   pde->hist_n = 0;
   pde->guess = GuessTerms{};
   if (order > 0 && pde->d_hist_alloc == nullptr) {
     const int64_t fld = pde->n + 2 * pde->g.plane;
-    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * 2 * fld));
-    BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * 2 * fld, pde->ctx->stream));
-    pde->d_hist[0] = pde->d_hist_alloc + pde->g.plane;
-    pde->d_hist[1] = pde->d_hist[0] + fld;
+    constexpr int NF = BEAT_GUESS_MAX_ORDER;  // MAX_ORDER - 1 increments + the guess
+    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * NF * fld));
+    BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * NF * fld, pde->ctx->stream));
+    for (int j = 0; j < NF - 1; ++j) pde->d_hist[j] = pde->d_hist_alloc + pde->g.plane + (int64_t)j * fld;
+    pde->d_guess = pde->d_hist_alloc + pde->g.plane + (int64_t)(NF - 1) * fld;
   }
   return BEAT_OK;
 }
@@ -1019,7 +1022,7 @@ extern "C" int beat_pde_guess_pending(const beat_pde* pde) { return pde != nullp
 extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, int* count) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
   if (dev_d) *dev_d = pde->d_hist[0];
-  if (dev_e) *dev_e = pde->d_hist[1];
+  if (dev_e) *dev_e = pde->d_guess;
   if (count) *count = pde->hist_n;
   return BEAT_OK;
 }
@@ -1033,14 +1036,24 @@ void beat_guess_begin(beat_pde* pde) {
   pde->guess = GuessTerms{};
   if (pde->guess_order <= 0 || pde->d_hist[0] == nullptr) return;
   GuessTerms& g = pde->guess;
-  g.d = pde->d_hist[0];
-  g.e = pde->d_hist[1];
+  // increments kept: order - 1 (at least one), newest first in d_hist; the oldest one's storage takes this solve's
+  const int nb = std::max(1, pde->guess_order - 1);
+  g.d = pde->d_hist[nb - 1];
+  for (int j = 0; j + 1 < nb; ++j) g.dp[j] = pde->d_hist[j];
+  g.e = pde->d_guess;
   g.use_e = pde->hist_n >= 1;
-  // the guess after this solve: with two increments on record (this one and the previous) and order 2 the linear
-  // extrapolation 2 d_new - d_old, otherwise d_new
-  const bool extrapolate = pde->guess_order >= 2 && pde->hist_n >= 1;
-  g.a = extrapolate ? 2.0 : 1.0;
-  g.b = extrapolate ? -1.0 : 0.0;
+  // the guess after this solve extrapolates through the m increments then on record (this one included):
+  // e = sum_{i=0}^{m-1} (-1)^i C(m, i+1) D_i,  D_0 = this solve's, D_i = d_hist[i-1] as it is now
+  const int m = std::min(pde->guess_order, pde->hist_n + 1);
+  static const double binom[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
+  g.a = binom[m][1];
+  for (int i = 1; i < m; ++i) {
+    const double c = ((i & 1) ? -1.0 : 1.0) * binom[m][i + 1];
+    if (i - 1 == nb - 1)
+      g.cd = c;
+    else
+      g.cp[i - 1] = c;
+  }
 }
 
 // Terms of an x update for the ring cycle starting at iteration ring_base: the first cycle carries e and records the
@@ -1064,7 +1077,13 @@ bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
     pde->guess_final = beat_guess_terms(pde, (nupd / PRING) * PRING);
     pde->guess_pending = true;
   }
-  pde->hist_n = std::min(2, pde->hist_n + 1);
+  {  // this solve's increment is the most recent one now
+    const int nb = std::max(1, pde->guess_order - 1);
+    double* newest = pde->d_hist[nb - 1];
+    for (int j = nb - 1; j > 0; --j) pde->d_hist[j] = pde->d_hist[j - 1];
+    pde->d_hist[0] = newest;
+  }
+  pde->hist_n = std::min(BEAT_GUESS_MAX_ORDER, pde->hist_n + 1);
   return due;
 }
 

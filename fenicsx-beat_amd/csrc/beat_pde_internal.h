@@ -48,11 +48,12 @@ struct beat_pde {
   // z node type of the ghost planes (the neighbouring slabs' boundary planes): 1 unless that plane is a face of the
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
-  // initial guess from the previous solves' increments (0: x0 = v_; 1: + d1; 2: + 2 d1 - d2), see GuessTerms
+  // initial guess from the previous solves' increments (0: x0 = v_; m: + the degree-(m-1) extrapolation of the last m), see GuessTerms
   int guess_order = 0;
-  double* d_hist[2] = {nullptr, nullptr};  // fields with ghost planes: [0] = d (last increment), [1] = e (next guess)
+  double* d_hist[3] = {nullptr, nullptr, nullptr};  // fields with ghost planes: the last increments, newest first
+  double* d_guess = nullptr;               // the guess increment e prepared for the next solve
   double* d_hist_alloc = nullptr;
-  int hist_n = 0;                          // solves recorded since the history was last dropped (capped at 2)
+  int hist_n = 0;                          // solves recorded since the history was last dropped (capped at the maximal order)
   beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
   beat_pde_detail::GuessTerms guess_final{};  // ... with these terms

@@ -277,14 +277,16 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     if (gt.d != nullptr) {  // inc = e + sum alpha_j P_j;  x += inc;  (d, e) updated  (see x_flush_kernel)
-      const double e_old = (gt.accumulate || gt.use_e) ? gt.e[i] : 0.0;
+      const double e_old = beat_guess_needs_e(gt) ? gt.e[i] : 0.0;
       const double d_old = beat_guess_needs_d(gt) ? gt.d[i] : 0.0;
+      const double dp0 = beat_guess_needs_dp(gt, 0) ? gt.dp[0][i] : 0.0;
+      const double dp1 = beat_guess_needs_dp(gt, 1) ? gt.dp[1][i] : 0.0;
       double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
       for (int j = 0; j < PRING; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
-      beat_guess_record(gt, gt.d + i, gt.e + i, inc, d_old, e_old);
+      beat_guess_record(gt, gt.d + i, gt.e + i, inc, d_old, dp0, dp1, e_old);
       continue;
     }
     double xi = x[i];

@@ -316,7 +316,7 @@ struct NodeIOPending {
   double* __restrict__ v_copy;
   int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
-  double ge, gd;                    // what the fields e and d held at this node (when gt.d != nullptr; read up front)
+  double ge, gd, gp0, gp1;          // what the fields e, d, dp[0], dp[1] held at this node (when gt.d != nullptr; read up front)
   beat_pde_detail::GuessTerms gt;   // where the step's diffusion increment is recorded and the next guess prepared
   __device__ __forceinline__ double load(int k) const {
     double x = base[(int64_t)k * ld + i];
@@ -326,7 +326,7 @@ struct NodeIOPending {
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
           if (j < npend) inc = fma(pa[j], pp[j], inc);
-        beat_pde_detail::beat_guess_record(gt, gt.d + i, gt.e + i, inc, gd, ge);
+        beat_pde_detail::beat_guess_record(gt, gt.d + i, gt.e + i, inc, gd, gp0, gp1, ge);
         return x + inc;
       }
 #pragma unroll

@@ -277,23 +277,27 @@ int beat_pde_work_fields(beat_pde* pde);
  * host_pending[0], 0) where dev_st = NULL selects the handle's own scalar state and ring = dev_work + plane +
  * 3*(n + 2*plane) is the first search direction of the work array. */
 /* Initial guess from the previous solves (what PETSc offers as KSPGuess / -ksp_guess_type; the reference leaves
- * it off and starts from 0, base_model.py:141-151).  With order m > 0 the operator keeps the increments
- * d = x - v_ of the last m solves and starts the next solve from x0 = v_ + d1 (m = 1) or v_ + 2 d1 - d2 (m = 2,
- * linear extrapolation in time) instead of x0 = v_: the same system is solved to the same ||r|| <= rtol ||b||, in
- * fewer iterations when consecutive solves are consecutive time steps (a travelling front: 8.9 -> 5.4, see
- * DESIGN.md 4).  Supported by beat_pde_solve[_ex] and beat_pde_solve_dist with Jacobi; the stage functions and the
- * polynomial preconditioner always start from x0 = v_.  The guess costs no pass of its own: it is part of the
- * deferred update (x += e + sum alpha_j p_j), which also records the new increment.  Consequences for callers
- * that defer (defer_flush != 0): the update may be due even when host_pending[1] == 0 -- ask
- * beat_pde_guess_pending -- and it must be applied through this operator (beat_ode_step_pending with `pde`, or
- * beat_pde_x_flush), which clears the flag.  beat_pde_set_timestep and beat_pde_guess_reset drop the history
- * (call the latter when the potential is overwritten between steps; a stale history costs iterations, not
- * accuracy).  Memory: 2 more fields.  Default order: 0. */
+ * it off and starts from 0, base_model.py:141-151).  With order m in 1..4 the operator keeps the increments
+ * d = x - v_ of the last solves and starts the next one from x0 = v_ + e, e = the polynomial extrapolation of degree
+ * m - 1 through the last m increments (m = 1: d1; 2: 2 d1 - d2; 3: 3 d1 - 3 d2 + d3; 4: 4 d1 - 6 d2 + 4 d3 - d4; fewer
+ * while fewer are on record), instead of x0 = v_: the same system is solved to the same ||r|| <= rtol ||b||, in
+ * fewer iterations when consecutive solves are consecutive time steps (512^3 TP06, rtol 1e-8: 4.95 -> 1.7 per step
+ * behind the initial perturbation, 8.0 -> 3.75 on a travelling front with m = 3).  Supported by
+ * beat_pde_solve[_ex] and beat_pde_solve_dist with Jacobi on the register-row and the per-node-row kernels; the stage
+ * functions, the LDS-tiled constant-coefficient loop and the polynomial preconditioner always start from x0 = v_ and
+ * drop the history.  The guess costs no pass of its own: it is part of the deferred update (x += e + sum alpha_j
+ * p_j), which also records the new increment and prepares the next e in place.  Consequences for callers that
+ * defer (defer_flush != 0): the update may be due even when host_pending[1] == 0 -- ask beat_pde_guess_pending --
+ * and it must be applied through this operator (beat_ode_step_pending with `pde`, or beat_pde_x_flush), which clears
+ * the flag.  beat_pde_set_timestep and beat_pde_guess_reset drop the history (call the latter when the potential is
+ * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: 4 more fields, allocated
+ * when an order > 0 is first set.  Default order: 0 (the Python layer's BaseModel asks for 3). */
 int beat_pde_set_guess_order(beat_pde* pde, int order);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);
-/* the recorded increments, most recent first, and how many are valid (tests, checkpoints) */
-int beat_pde_guess_history(const beat_pde* pde, double** dev_h0, double** dev_h1, int* count);
+/* the last recorded increment, the guess increment prepared for the next solve, and the number of solves on record
+ * since the history was dropped, capped at 4 (tests, checkpoints) */
+int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, int* count);
 
 int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                       const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,
