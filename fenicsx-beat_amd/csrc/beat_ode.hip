@@ -6,6 +6,7 @@
 #include "beat_pde_internal.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include "ionic_models.h"
 #include "torord_dyncl.h"
@@ -29,6 +30,16 @@ struct PendingV {
   beat_pde_detail::GuessTerms gt;
 };
 
+// Layout of ode_step_kernel's kernel-argument segment up to the uniform parameters (all members 8-byte aligned): the
+// tile loop re-reads them through an opaque copy of the segment pointer (see the kernel).
+template <class Model>
+struct OdeStepKernArgHead {
+  double* states;
+  int64_t n, ld;
+  ParamPack<Model::NP> prm;
+  typename Model::Derived drv;
+};
+
 template <class Model, bool PER_NODE, bool PEND>
 __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
@@ -47,6 +58,16 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   for (int64_t tile = blockIdx.x; tile * BEAT_BLOCK < n; tile += gridDim.x) {
   const int64_t i = tile * BEAT_BLOCK + threadIdx.x;
   if (i >= n) break;
+  // The ~90 uniform doubles (parameters, per-launch derived constants) are scalar loads from the kernel-argument
+  // segment.  Left to itself the compiler hoists all of them out of the tile loop, runs out of SGPRs and parks them in
+  // VGPR lanes: 640 v_readlane / v_writelane per node on the VALU that is this kernel's bottleneck.  Reading them
+  // through a pointer the optimiser cannot see through keeps the loads where they are used (SALU, scalar cache).
+  typedef const __attribute__((address_space(4))) char* KArgPtr;
+  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const double* p_uni = (const double*)(ka + offsetof(OdeStepKernArgHead<Model>, prm));
+  const typename Model::Derived& d_uni =
+      *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
     NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
     } else {
-      Model::step(io, prm.p, drv, fm, t, dt);
+      Model::step(io, p_uni, d_uni, fm, t, dt);
     }
   } else {
     const NodeIO io{states, ld, i, v_copy, v_index};
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
     } else {
-      Model::step(io, prm.p, drv, fm, t, dt);
+      Model::step(io, p_uni, d_uni, fm, t, dt);
     }
   }
   }
