@@ -162,32 +162,42 @@ extern "C" int beat_comm_destroy(beat_comm* c) {
   return BEAT_OK;
 }
 
-// Start the exchange of the boundary planes of `f` (interior pointer, n doubles, ghost planes around it): on the
-// side stream once the compute stream has produced the planes.  With callbacks the exchange completes here.
-static int halo_start(beat_comm* c, double* f, int64_t n, int64_t plane) {
+// Start the exchange of the boundary planes of `f` (interior pointer, n doubles, ghost planes around it) -- and of a
+// second field `f2` in the same RCCL group when given (one group latency for both) -- on the side stream once the
+// compute stream has produced the planes.  With callbacks the exchange completes here.
+static int halo_start(beat_comm* c, double* f, int64_t n, int64_t plane, double* f2 = nullptr) {
   if (c->peer_lo < 0 && c->peer_hi < 0) return BEAT_OK;
-  const double* first = c->peer_lo >= 0 ? f : nullptr;
-  double* ghost_lo = c->peer_lo >= 0 ? f - plane : nullptr;
-  const double* last = c->peer_hi >= 0 ? f + n - plane : nullptr;
-  double* ghost_hi = c->peer_hi >= 0 ? f + n : nullptr;
+  double* fields[2] = {f, f2};
+  const int nf = f2 ? 2 : 1;
   if (!c->rccl) {
-    const int rc = c->halo(c->user, first, ghost_lo, last, ghost_hi, plane);
-    if (rc) {
-      beat_set_error("halo callback failed (%d)", rc);
-      return BEAT_EHIP;
+    for (int k = 0; k < nf; ++k) {
+      double* g = fields[k];
+      const int rc = c->halo(c->user, c->peer_lo >= 0 ? g : nullptr, c->peer_lo >= 0 ? g - plane : nullptr,
+                             c->peer_hi >= 0 ? g + n - plane : nullptr, c->peer_hi >= 0 ? g + n : nullptr, plane);
+      if (rc) {
+        beat_set_error("halo callback failed (%d)", rc);
+        return BEAT_EHIP;
+      }
     }
     return BEAT_OK;
   }
   BEAT_HIP_CHECK(hipEventRecord(c->ev_ready, c->ctx->stream));
   BEAT_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
-  // posting order: both sends, then the receives in the opposite order -- between two different ranks there is at
-  // most one message per direction, so the order is immaterial; on a one-rank communicator whose two peers are
-  // the rank itself (tests) it makes the exchange periodic (ghost_hi <- first plane, ghost_lo <- last plane)
+  // posting order: both sends, then the receives in the opposite order -- between two different ranks messages of
+  // one direction are matched in the order posted (field by field on both sides); on a one-rank communicator whose
+  // two peers are the rank itself (tests) it makes the exchange periodic (ghost_hi <- first plane, ghost_lo <- last)
   BEAT_RCCL_CHECK(g_rccl.GroupStart());
-  if (first) BEAT_RCCL_CHECK(g_rccl.Send(first, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
-  if (last) BEAT_RCCL_CHECK(g_rccl.Send(last, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
-  if (ghost_hi) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_hi, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
-  if (ghost_lo) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_lo, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
+  for (int k = 0; k < nf; ++k) {
+    double* g = fields[k];
+    const double* first = c->peer_lo >= 0 ? g : nullptr;
+    double* ghost_lo = c->peer_lo >= 0 ? g - plane : nullptr;
+    const double* last = c->peer_hi >= 0 ? g + n - plane : nullptr;
+    double* ghost_hi = c->peer_hi >= 0 ? g + n : nullptr;
+    if (first) BEAT_RCCL_CHECK(g_rccl.Send(first, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
+    if (last) BEAT_RCCL_CHECK(g_rccl.Send(last, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
+    if (ghost_hi) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_hi, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
+    if (ghost_lo) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_lo, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
+  }
   BEAT_RCCL_CHECK(g_rccl.GroupEnd());
   BEAT_HIP_CHECK(hipEventRecord(c->ev_halo, c->side));
   return BEAT_OK;
@@ -246,28 +256,24 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   double* h = ctx->h_pinned;
   int rc;
   const bool rr = beat_rr_available(pde);  // constant coefficients: the kernels that never store q = A p
-  // ghost planes of v_ for the right-hand side (the reference's scatter_forward after the previous solve)
-  if ((rc = halo_start(comm, const_cast<double*>(dev_v_prev), n, plane))) return rc;
+  // ghost planes of v_ for the right-hand side (the reference's scatter_forward after the previous solve) and, in the
+  // same exchange, of the guess increment e (written by the x update of the previous solve)
+  const bool guess_path = (rr || pde->var) && pde->guess_order > 0 && pde->d_guess != nullptr && pde->hist_n >= 1;
+  if ((rc = halo_start(comm, const_cast<double*>(dev_v_prev), n, plane, guess_path ? pde->d_guess : nullptr))) return rc;
   if ((rc = halo_wait(comm))) return rc;
   if (rr) {
     BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    if (pde->guess.use_e) {  // ghost planes of the guess increment (written by the x update of the previous solve)
-      if ((rc = halo_start(comm, pde->guess.e, n, plane))) return rc;
-      if ((rc = halo_wait(comm))) return rc;
-    }
+    BEAT_REQUIRE(!pde->guess.use_e || guess_path, "guess increment without ghost planes");
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
   } else if (pde->var) {
     BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    if (pde->guess.use_e) {  // ghost planes of the guess increment
-      if ((rc = halo_start(comm, pde->guess.e, n, plane))) return rc;
-      if ((rc = halo_wait(comm))) return rc;
-    }
+    BEAT_REQUIRE(!pde->guess.use_e || guess_path, "guess increment without ghost planes");
     rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
                       pde->guess.use_e ? pde->guess.e : nullptr);
   } else {

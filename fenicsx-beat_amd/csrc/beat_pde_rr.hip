@@ -531,7 +531,12 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   const GuessTerms& gt = pde->guess;
   const bool guess = gt.d != nullptr && gt.use_e;
   // with a guess the kernel holds two register windows (v_ and e): 2 rows per wave keep it at the other kernels' occupancy
-  const RGeom g = guess ? make_geom(pde, 0, pde->g.nz, 0, 2) : make_geom(pde);
+  static const int guess_rows = [] {  // BEAT_RR_GUESS_RY = 2 | 4 (experiments)
+    const char* e = std::getenv("BEAT_RR_GUESS_RY");
+    const int v = e ? std::atoi(e) : 2;
+    return v == 4 ? 4 : 2;
+  }();
+  const RGeom g = guess ? make_geom(pde, 0, pde->g.nz, 0, guess_rows) : make_geom(pde);
   RArgs a{};
   a.x = dev_v_prev;
   a.y = dev_r;
