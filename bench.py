@@ -82,8 +82,10 @@ def init_states(ctx, states, ic, v_index, n_glob, slab, seed, nz_glob=None):
             row.view(slab.nz, ny, nx).copy_(float(ic[k]) + 60.0 * torch.exp(-r2 / (2.0 * 2.0**2)))
             del r2
         else:
-            u = torch.rand(row.shape[0], generator=gen, device=ctx.device, dtype=torch.float64) * 2.0 - 1.0
-            row.copy_(float(ic[k]) * (1.0 + 0.01 * u))
+            u = torch.rand(row.shape[0], generator=gen, device=ctx.device, dtype=torch.float64)
+            u.mul_(2.0).sub_(1.0)  # in place, same values as before: one temporary row, not three (1024^3: 8.6 GB each)
+            u.mul_(0.01).add_(1.0).mul_(float(ic[k]))
+            row.copy_(u)
             del u
 
 
@@ -559,11 +561,12 @@ def main():
                 "bytes_per_node": 16.0 * S + 8.0 * k_pend + g_bytes,
                 "pending_directions_per_launch": k_pend,
                 "valu": None if valu is None else {
-                    "instr_per_node": valu["valu_instr_per_wave"],  # one node per lane: per-wave count = per-node count
+                    # a wave walks over several 64-node tiles: instructions per wave x waves / (nodes / 64)
+                    "instr_per_node": valu["valu_instr_per_wave"] * valu.get("waves", n_local / 64.0) * 64.0 / n_local,
                     "valu_busy_frac": valu["valu_busy"],            # PMC: SIMD cycles spent issuing VALU
                     # issue time of those instructions at the 2.4 GHz peak clock (4 cycles per wave64 fp64/32-bit
                     # VALU op on a SIMD16) over the kernel time measured live in this run
-                    "frac_of_issue_peak": valu["valu_instr_per_wave"] * 4.0 * (n_local / 64.0) / (1024.0 * 2.4e9) / (ode_ms * 1e-3),
+                    "frac_of_issue_peak": valu["valu_instr_per_wave"] * valu.get("waves", n_local / 64.0) * 4.0 / (1024.0 * 2.4e9) / (ode_ms * 1e-3),
                     "effective_clock_GHz": valu["gui_cycles_per_xcd"] / (valu["avg_us"] * 1e-6) / 1e9,
                     "source": "profiles/r02_512_pmc.json (rocprofv3 SQ/GRBM pass of this command, tools/measure_round2.sh)",
                 },

@@ -995,13 +995,19 @@ extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   pde->guess_order = order;
   pde->hist_n = 0;
   pde->guess = GuessTerms{};
-  if (order > 0 && pde->d_hist_alloc == nullptr) {
+  // fields: the max(order - 1, 1) increments kept + the guess (1024^3: 8.6 GB each -- only what the order needs)
+  const int need = order > 0 ? std::max(1, order - 1) + 1 : 0;
+  if (need > pde->hist_fields) {
     const int64_t fld = pde->n + 2 * pde->g.plane;
-    constexpr int NF = BEAT_GUESS_MAX_ORDER;  // MAX_ORDER - 1 increments + the guess
-    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * NF * fld));
-    BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * NF * fld, pde->ctx->stream));
-    for (int j = 0; j < NF - 1; ++j) pde->d_hist[j] = pde->d_hist_alloc + pde->g.plane + (int64_t)j * fld;
-    pde->d_guess = pde->d_hist_alloc + pde->g.plane + (int64_t)(NF - 1) * fld;
+    BEAT_HIP_CHECK(hipStreamSynchronize(pde->ctx->stream));
+    (void)hipFree(pde->d_hist_alloc);
+    pde->d_hist_alloc = nullptr;
+    pde->hist_fields = 0;
+    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * need * fld));
+    BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * need * fld, pde->ctx->stream));
+    pde->hist_fields = need;
+    for (int j = 0; j < need - 1; ++j) pde->d_hist[j] = pde->d_hist_alloc + pde->g.plane + (int64_t)j * fld;
+    pde->d_guess = pde->d_hist_alloc + pde->g.plane + (int64_t)(need - 1) * fld;
   }
   return BEAT_OK;
 }

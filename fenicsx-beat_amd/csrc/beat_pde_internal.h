@@ -53,6 +53,7 @@ struct beat_pde {
   double* d_hist[3] = {nullptr, nullptr, nullptr};  // fields with ghost planes: the last increments, newest first
   double* d_guess = nullptr;               // the guess increment e prepared for the next solve
   double* d_hist_alloc = nullptr;
+  int hist_fields = 0;                     // fields in d_hist_alloc
   int hist_n = 0;                          // solves recorded since the history was last dropped (capped at the maximal order)
   beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...

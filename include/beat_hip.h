@@ -290,8 +290,8 @@ int beat_pde_work_fields(beat_pde* pde);
  * defer (defer_flush != 0): the update may be due even when host_pending[1] == 0 -- ask beat_pde_guess_pending --
  * and it must be applied through this operator (beat_ode_step_pending with `pde`, or beat_pde_x_flush), which clears
  * the flag.  beat_pde_set_timestep and beat_pde_guess_reset drop the history (call the latter when the potential is
- * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: 4 more fields, allocated
- * when an order > 0 is first set.  Default order: 0 (the Python layer's BaseModel asks for 3). */
+ * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: max(m - 1, 1) + 1 more fields,
+ * allocated when the order is set.  Default order: 0 (the Python layer's BaseModel asks for 3). */
 int beat_pde_set_guess_order(beat_pde* pde, int order);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);
