@@ -128,6 +128,8 @@ def spectrum_bounds(A_tab: np.ndarray, ratio: float = 5.0) -> tuple[float, float
 
 
 class HipOps:
+    default_small = True  # small grids: whole solve in one launch (tests flip this to exercise the multi-launch kernels)
+
     """The product compute backend: every method is one C-ABI call into libbeat_hip.so."""
 
     def __init__(self, ctx, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab, per_node: bool = False):
@@ -185,6 +187,8 @@ class HipOps:
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
         self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for order 3 by default)
+        if not type(self).default_small:
+            self.set_small(False)
 
     @classmethod
     def from_voxels(cls, ctx, dim, cells, h, M, active, shape_local, z0, lo_phys, hi_phys):
@@ -383,6 +387,11 @@ class HipOps:
         self.flush_pending()
         _hip.check(self.lib.beat_pde_set_guess_order(self.handle, int(order)))
         self.guess_order = int(order)
+
+    def set_small(self, enable: bool) -> None:
+        """Grids of a few thousand nodes are solved in one launch of one workgroup (beat_pde_small.hip); False keeps
+        this operator on the multi-launch kernels (tests of those kernels on small grids, deferral semantics)."""
+        _hip.check(self.lib.beat_pde_set_small_grid_solve(self.handle, int(bool(enable))))
 
     def guess_reset(self) -> None:
         """Forget the recorded increments (the potential was overwritten: the next solve starts from x0 = v_)."""

@@ -84,6 +84,7 @@ SIGNATURES = {
     "beat_pde_cg_update_r": (_int, [_vp, _vp, _vp, _vp, _int]),
     "beat_pde_cg_next_oop": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "beat_pde_x_flush": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int]),
+    "beat_pde_set_small_grid_solve": (_int, [_vp, _int]),
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
     "beat_pde_guess_reset": (_int, [_vp]),
     "beat_pde_guess_pending": (_int, [_vp]),
@@ -103,6 +104,7 @@ SIGNATURES = {
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, _int, C.POINTER(KspInfo), C.POINTER(_int)],
     ),
     "beat_field_probe": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
+    "beat_field_probe_record": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
     "beat_field_dot": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_dbl)]),
     "beat_field_minmax": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }

@@ -1212,22 +1212,15 @@ class Function:
         return g
 
 
-def evaluate_function(f: Function, points) -> np.ndarray:
-    """``scifem.evaluate_function(f, points)`` for P1 functions on the box mesh; on a slab-decomposed mesh every
-    rank returns the same values (partial sums over the vertices it owns, all-reduced)."""
-    import ctypes as C
-
-    from . import _hip
-
-    mesh = f.function_space.mesh
+def _locate_points(mesh: "Mesh", points):
+    """Vertices (GLOBAL ids) and barycentric weights of the simplex each point lies in, cached per mesh: callers
+    evaluate the same probe points every time step."""
     pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
     d = mesh.dim
-    # callers evaluate the same probe points every time step: locate them once per mesh
     cache = mesh.__dict__.setdefault("_probe_cache", {})
     key = pts.tobytes()
     if key in cache:
-        idx, wts = cache[key]
-        return _probe(f, idx, wts)
+        return cache[key]
     idx = np.zeros((len(pts), 4), dtype=np.int64)
     wts = np.zeros((len(pts), 4), dtype=np.float64)
     lower, h, n = np.array(mesh.lower), np.array(mesh.h), np.array(mesh.n)
@@ -1247,7 +1240,63 @@ def evaluate_function(f: Function, points) -> np.ndarray:
         wts[k, : d + 1] = best[1]
     if len(cache) < 64:
         cache[key] = (idx, wts)
+    return idx, wts
+
+
+def evaluate_function(f: Function, points) -> np.ndarray:
+    """``scifem.evaluate_function(f, points)`` for P1 functions on the box mesh; on a slab-decomposed mesh every
+    rank returns the same values (partial sums over the vertices it owns, all-reduced)."""
+    idx, wts = _locate_points(f.function_space.mesh, points)
     return _probe(f, idx, wts)
+
+
+class ProbeRecorder:
+    """Point values of a P1 function recorded step by step ON THE DEVICE: ``record()`` enqueues one tiny kernel and
+    returns, ``values()`` reads the whole record back ((steps, points) array).  For time loops that look at probes
+    every step -- the reference's Niederer demo calls ``scifem.evaluate_function`` once per step
+    (demos/niederer_benchmark.py:285-291), which on a GPU is one host synchronisation per step; the recorded values
+    are the ones ``evaluate_function`` returns (same kernel)."""
+
+    def __init__(self, f: Function, points, capacity: int = 4096):
+        mesh = f.function_space.mesh
+        idx, wts = _locate_points(mesh, points)
+        if mesh.comm.size > 1:
+            idx, wts = _local_probe_args(mesh, idx, wts)
+        self._f, self._mesh = f, mesh
+        self._idx, self._wts = np.ascontiguousarray(idx), np.ascontiguousarray(wts)
+        self.npts = len(self._idx)
+        self.capacity = int(capacity)
+        self._buf = f._ctx.zeros(self.capacity * self.npts)
+        self._rows = 0       # rows in the device buffer
+        self._done = []      # host copies of full buffers
+
+    def record(self) -> None:
+        import ctypes as C
+
+        from . import _hip
+
+        if self._rows == self.capacity:
+            self._done.append(self._read())
+            self._rows = 0
+        ctx = self._f._ctx
+        out = C.c_void_p(self._buf.data_ptr() + 8 * self._rows * self.npts)
+        _hip.check(ctx.lib.beat_field_probe_record(ctx.handle, self._f.field.ptr, self._idx.ctypes.data_as(C.c_void_p),
+                                                   self._wts.ctypes.data_as(C.c_void_p), self.npts, out))
+        self._rows += 1
+
+    def _read(self) -> np.ndarray:
+        part = self._buf[: self._rows * self.npts].cpu().numpy().reshape(self._rows, self.npts).copy()
+        if self._mesh.comm.size > 1:  # every rank holds the partial sums over the vertices it owns
+            part = self._mesh.comm.allreduce_array(part.ravel()).reshape(part.shape)
+        return part
+
+    def __len__(self) -> int:
+        return sum(len(a) for a in self._done) + self._rows
+
+    def values(self) -> np.ndarray:
+        """All rows recorded so far, (steps, points).  Synchronises."""
+        parts = self._done + ([self._read()] if self._rows else [])
+        return np.concatenate(parts) if parts else np.zeros((0, self.npts))
 
 
 def _local_probe_args(mesh: Mesh, idx: np.ndarray, wts: np.ndarray):

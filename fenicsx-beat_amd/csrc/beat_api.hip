@@ -211,6 +211,24 @@ extern "C" int beat_field_probe(beat_ctx* ctx, const double* dev_field, const in
   return BEAT_OK;
 }
 
+// The same evaluation into a caller-owned device buffer, without any synchronisation: a time loop records one row of
+// probe values per step and reads them back in one piece every so often.
+extern "C" int beat_field_probe_record(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
+                                       const double* host_w, int npts, double* dev_out) {
+  BEAT_REQUIRE(ctx != nullptr && dev_field && host_idx && host_w && dev_out && npts >= 0, "bad argument");
+  for (int base = 0; base < npts; base += 16) {
+    ProbeBatch b;
+    b.n = npts - base < 16 ? npts - base : 16;
+    for (int k = 0; k < 4 * b.n; ++k) {
+      b.idx[k] = host_idx[4 * base + k];
+      b.w[k] = host_w[4 * base + k];
+    }
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, dev_out + base);
+    BEAT_LAUNCH_CHECK();
+  }
+  return BEAT_OK;
+}
+
 __global__ __launch_bounds__(BEAT_BLOCK) void minmax_partial_kernel(const double* __restrict__ x, int64_t n,
                                                                     double* __restrict__ part) {
   __shared__ double smin[4], smax[4];

@@ -987,6 +987,12 @@ extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev
   return beat_pde_x_flush_terms(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
 }
 
+extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  pde->small_enabled = enable != 0;
+  return BEAT_OK;
+}
+
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
 extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
@@ -1070,6 +1076,14 @@ GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base) {
   return g;
 }
 
+void beat_guess_advance(beat_pde* pde) {
+  const int nb = std::max(1, pde->guess_order - 1);
+  double* newest = pde->d_hist[nb - 1];
+  for (int j = nb - 1; j > 0; --j) pde->d_hist[j] = pde->d_hist[j - 1];
+  pde->d_hist[0] = newest;
+  pde->hist_n = std::min(BEAT_GUESS_MAX_ORDER, pde->hist_n + 1);
+}
+
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
   const bool partial = nupd % PRING != 0;
   if (pde->guess.d == nullptr) return partial;
@@ -1083,13 +1097,7 @@ bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
     pde->guess_final = beat_guess_terms(pde, (nupd / PRING) * PRING);
     pde->guess_pending = true;
   }
-  {  // this solve's increment is the most recent one now
-    const int nb = std::max(1, pde->guess_order - 1);
-    double* newest = pde->d_hist[nb - 1];
-    for (int j = nb - 1; j > 0; --j) pde->d_hist[j] = pde->d_hist[j - 1];
-    pde->d_hist[0] = newest;
-  }
-  pde->hist_n = std::min(BEAT_GUESS_MAX_ORDER, pde->hist_n + 1);
+  beat_guess_advance(pde);
   return due;
 }
 
@@ -1110,6 +1118,10 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
   BEAT_REQUIRE(pde != nullptr && dev_work != nullptr, "null argument");
   BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "beat_pde_solve is the single-slab path");
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
+  if (beat_small_available(pde)) {  // a few thousand nodes: the whole solve in one launch of one workgroup
+    BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
+    return beat_small_solve(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, rtol, atol, max_it, info);
+  }
   const int64_t fld = pde->n + 2 * pde->g.plane;
   double* r = dev_work + pde->g.plane;
   double* q = r + fld;

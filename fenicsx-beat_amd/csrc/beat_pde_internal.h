@@ -58,6 +58,7 @@ struct beat_pde {
   beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
   beat_pde_detail::GuessTerms guess_final{};  // ... with these terms
+  bool small_enabled = true;  // grids of a few thousand nodes: whole solve in one launch (beat_pde_small.hip)
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
   // variable-coefficient mode (beat_pde_create_var): caller-owned Mass / K rows, A and 1/diag owned here
@@ -113,6 +114,14 @@ beat_pde_detail::GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base)
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred);
 int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                            int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);
+
+void beat_guess_advance(beat_pde* pde);  // this solve's increment has been recorded: it is the most recent one now
+
+// one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
+bool beat_small_available(const beat_pde* pde);
+int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                     const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
+                     beat_ksp_info* info);
 
 // register-row kernels of the constant-coefficient Jacobi-PCG that never stores q = A p (beat_pde_rr.hip)
 bool beat_rr_available(const beat_pde* pde);

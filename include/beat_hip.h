@@ -299,6 +299,15 @@ int beat_pde_guess_pending(const beat_pde* pde);
  * since the history was dropped, capped at 4 (tests, checkpoints) */
 int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, int* count);
 
+/* Small grids (constant coefficients, Jacobi, undivided, <= 8192 nodes -- the reference's own CPU-sized cases, e.g.
+ * the Niederer slab at dx = 0.5 mm): beat_pde_solve[_ex] runs the whole solve -- right-hand side, every iteration,
+ * update of dev_x, bookkeeping of the initial guess -- in one launch of one workgroup (search direction in LDS, dot
+ * products as block reductions), because a multi-launch iteration there is nothing but launch latency
+ * (demos/niederer_benchmark.py: 0.38 -> 0.18 ms per split step).  Same iteration and stopping test, different
+ * summation order in the dot products; nothing is ever left pending (host_pending = {0, 0}).  On by default
+ * (BEAT_SMALL=0 disables it for the process), per operator: */
+int beat_pde_set_small_grid_solve(beat_pde* pde, int enable);
+
 int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                       const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,
                       double atol, int max_it, int defer_flush, beat_ksp_info* info, int* host_pending);
@@ -358,6 +367,11 @@ int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev
  * (scifem.evaluate_function stand-in, demos/niederer_benchmark.py:285).  Synchronises. */
 int beat_field_probe(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
                      const double* host_w, int npts, double* host_out);
+/* The same into a device buffer (npts doubles), enqueued like any kernel: a time loop that looks at its probes every
+ * step (demos/niederer_benchmark.py:285-291) records them per step and reads the record back once in a while
+ * instead of synchronising every step. */
+int beat_field_probe_record(beat_ctx* ctx, const double* dev_field, const int64_t* host_idx,
+                            const double* host_w, int npts, double* dev_out);
 /* sum_i x_i y_i on the local slab: lead integrals of the ECG recovery, ecg.py:295-298 (assemble_scalar of
  * (1/(4 pi sigma_b)) Im / |x - p| dx = weights . Im with precomputed nodal weights).  Synchronises. */
 int beat_field_dot(beat_ctx* ctx, const double* dev_x, const double* dev_y, int64_t n, double* host_out);

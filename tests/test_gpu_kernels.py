@@ -10,6 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["one-launch", "multi-launch"])
+def small_grid_path(request):
+    """Grids of a few thousand nodes are solved by one workgroup in one launch (csrc/beat_pde_small.hip) unless the
+    operator is told otherwise: every test of this module runs on both paths."""
+    from beat._engine import HipOps
+
+    old = HipOps.default_small
+    HipOps.default_small = request.param == "one-launch"
+    yield request.param
+    HipOps.default_small = old
+
+
 def _ptr_array(ptrs):
     arr = (C.c_void_p * max(1, len(ptrs)))()
     for i, p in enumerate(ptrs):
@@ -735,3 +747,76 @@ def test_pcg_degenerate_right_hand_sides(hip_ctx, per_node):
     fv.set(1e150 * rng.standard_normal(n))
     res = ops.solve_single(fv, [], [], fx, 1e-8, 1e-50, 200)
     assert res.converged_reason > 0 and 0 < res.iterations < 40 and np.isfinite(fx.numpy()).all()
+
+
+@pytest.mark.parametrize("nn", [(41, 15, 7), (32, 16, 16), (100, 1, 1), (64, 32, 1), (2, 2, 2)])
+def test_one_launch_solve_equals_the_multi_launch_solve(hip_ctx, nn):
+    """csrc/beat_pde_small.hip (whole solve of a small grid in one workgroup) against the multi-launch kernels on the
+    same operator: a sequence of solves with a stimulus and the extrapolated guess -- same iteration counts, solutions
+    equal to rounding (the dot products are summed in another order), same recorded history; a solve cut short by
+    max_it reports -3 with the same iterate; an atol-dominated stopping test reports reason 3; 8192 nodes is the
+    largest grid taken (8 per thread), one more node goes to the multi-launch path."""
+    import ctypes as C
+
+    from beat import _hip, _stencil
+    from beat._engine import HipOps
+
+    dim = 3 - sum(1 for v in nn[1:] if v == 1) if nn != (2, 2, 2) else 3
+    n = int(np.prod(nn))
+    M = np.array([[2.0, 0.3, 0.0], [0.3, 1.0, 0.1], [0.0, 0.1, 0.5]])[:dim, :dim] * 1e-3
+    rng = np.random.default_rng(n)
+    w = rng.random(n) * 1e-3
+    noise = 0.01 * rng.random(n)
+    xs = np.arange(n) % nn[0]
+    out = {}
+    for small in (True, False):
+        ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_tables(dim, (0.1,) * dim, M))
+        ops.set_small(small)
+        ops.set_guess_order(3)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        fv, fw, fx = ops.new_field(), ops.new_field(), ops.new_field()
+        fw.set(w)
+        rec = []
+        for step in range(5):
+            fv.set(-85.0 + 60.0 * np.exp(-((xs - 3.0 - 0.4 * step) ** 2) / 8.0) + noise * (step == 0))
+            res = ops.solve_single(fv, [fw], [0.7 if step < 3 else 0.0], fx, 1e-11, 1e-50, 500, defer_flush=bool(step % 2))
+            ops.flush_pending()
+            rec.append((res.iterations, res.converged_reason, fx.numpy().copy(), res.residual_norm, res.rhs_norm))
+        h0, cnt = C.c_void_p(), C.c_int()
+        _hip.check(ops.lib.beat_pde_guess_history(ops.handle, C.byref(h0), None, C.byref(cnt)))
+        d = hip_ctx.torch.empty(n, dtype=hip_ctx.torch.float64, device=hip_ctx.device)
+        _hip.check(ops.lib.beat_copy(hip_ctx.handle, C.c_void_p(d.data_ptr()), h0, n))
+        cut = ops.solve_single(fv, [fw], [0.3], fx, 1e-14, 1e-50, 2)
+        x_cut = fx.numpy().copy()
+        ops.guess_reset()
+        loose = ops.solve_single(fv, [fw], [0.3], fx, 1e-30, 1e-6, 500)
+        out[small] = (rec, d.cpu().numpy(), cnt.value, cut, x_cut, loose)
+    (ra, da, ca, cuta, xa, la), (rb, db, cb, cutb, xb, lb) = out[True], out[False]
+    for (ia, qa, va, rna, bna), (ib, qb, vb, rnb, bnb) in zip(ra, rb):
+        assert qa > 0 and qb > 0 and abs(ia - ib) <= 1
+        np.testing.assert_allclose(va, vb, rtol=0, atol=1e-9 * np.abs(vb).max())
+        assert np.isclose(bna, bnb, rtol=1e-12)
+    assert ca == cb == 4
+    np.testing.assert_allclose(da, db, rtol=0, atol=1e-9 * 85.0)
+    assert cuta.converged_reason == cutb.converged_reason == -3 and cuta.iterations == cutb.iterations == 2
+    np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-9 * np.abs(xb).max())
+    assert la.converged_reason == lb.converged_reason == 3
+
+
+def test_one_launch_solve_size_limit(hip_ctx):
+    """8192 nodes are solved in one launch, 8193 are not (observable: a deferring solve leaves its update pending only
+    on the multi-launch path)."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    for nn, one_launch in (((32, 16, 16), True), ((8193, 1, 1), False)):
+        dim = 3 if nn[1] > 1 else 1
+        ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_tables(dim, (0.1,) * dim, 1e-3))
+        ops.set_small(True)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        fv, fx = ops.new_field(), ops.new_field()
+        fv.set(-85.0 + 50.0 * np.exp(-((np.arange(int(np.prod(nn))) % nn[0] - 5.0) ** 2) / 9.0))
+        res = ops.solve_single(fv, [], [], fx, 1e-8, 1e-50, 500, defer_flush=True)
+        assert res.converged_reason > 0 and res.iterations % 6 != 0, res
+        assert (ops.pending is None) == one_launch
+        ops.flush_pending()
