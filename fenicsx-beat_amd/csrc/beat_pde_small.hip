@@ -2,10 +2,10 @@
 //
 // On a grid of a few thousand nodes (the Niederer slab at dx = 0.5 mm: 41 x 15 x 7 = 4305) every kernel of the
 // multi-launch PCG finishes in a couple of microseconds and a solve is nothing but launch latency: 5 dependent
-// launches per iteration, 0.30 ms per solve at 15-20 iterations.  Here one 1024-thread workgroup does the right-hand
+// launches per iteration, 0.30 ms per solve at 15-20 iterations.  Here one 512-thread workgroup does the right-hand
 // side, all iterations and the update of x: the search direction lives in LDS (the only vector a node's neighbours
 // read), r, the accumulated increment and 1/diag of a thread's own nodes in registers, the dot products are block
-// reductions (wave shuffle + 16 partials in LDS, summed in a fixed order by every thread: deterministic), the
+// reductions (wave shuffle + 8 partials in LDS, summed in a fixed order by every thread: deterministic), the
 // convergence test is the library's (||r|| <= max(rtol ||b||, atol)), an iteration costs three barriers.
 //
 // Same arithmetic as beat_pde_solve's loop (Jacobi-PCG from x0 = v_ + e, x = v_ + e + sum alpha_j p_j), different
@@ -20,7 +20,10 @@
 namespace {
 using namespace beat_pde_detail;
 
-constexpr int SMALL_THREADS = 1024;
+// 512 threads, up to 16 nodes each: Niederer dx = 0.5 mm measured 0.17 / 0.15 / 0.16 ms per split step with 1024 / 512 /
+// 256 threads (fewer waves: cheaper barriers and reductions, same LDS traffic; fewer still: too few waves to hide it)
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_MAX_PER_THREAD = 16;
 constexpr int SMALL_WAVES = SMALL_THREADS / 64;
 
 struct SmallArgs {
@@ -61,13 +64,35 @@ __device__ __forceinline__ double block_sum_all(double v, double* part) {
   return s;
 }
 
+// two sums behind one barrier
+__device__ __forceinline__ void block_sum_all2(double& u, double& v, double* part) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    u += __shfl_xor(u, off, 64);
+    v += __shfl_xor(v, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[threadIdx.x >> 6] = u;
+    part[SMALL_WAVES + (threadIdx.x >> 6)] = v;
+  }
+  __syncthreads();
+  double su = 0.0, sv = 0.0;
+#pragma unroll
+  for (int k = 0; k < SMALL_WAVES; ++k) {
+    su += part[k];
+    sv += part[SMALL_WAVES + k];
+  }
+  u = su;
+  v = sv;
+}
+
 template <int M>
 __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
   extern __shared__ double lds[];
   double* tabA = lds;                       // 27 * TABW
   double* tabB = tabA + 27 * TABW;          // 27 * TABW
-  double* part = tabB + 27 * TABW;          // 4 * SMALL_WAVES (alternating partial buffers)
-  double* dinv = part + 4 * SMALL_WAVES;    // 32
+  double* part = tabB + 27 * TABW;          // 6 * SMALL_WAVES (alternating partial buffers)
+  double* dinv = part + 6 * SMALL_WAVES;    // 32
   double* pbuf = dinv + 32;                 // margin + n + margin
   double* p = pbuf + a.margin;
   const int tid = threadIdx.x;
@@ -81,7 +106,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
     pbuf[i] = 0.0;
     pbuf[a.margin + a.n + i] = 0.0;
   }
-  // the nodes this thread owns: tid, tid + 1024, ...
+  // the nodes this thread owns: tid, tid + 512, ...
   // (r, the accumulated increment and the node type stay in registers; v_, e and 1/diag are re-read where needed)
   int type[M];
   double r[M], xinc[M];
@@ -135,8 +160,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
       acc_rr = fma(r[j], r[j], acc_rr);
     }
   }
-  double rz = block_sum_all(acc_rz, part + SMALL_WAVES);
-  double rr = block_sum_all(acc_rr, part + 2 * SMALL_WAVES);
+  block_sum_all2(acc_rz, acc_rr, part + SMALL_WAVES);
+  double rz = acc_rz, rr = acc_rr;
   const double tr = a.rtol * a.rtol * bb, ta = a.atol * a.atol;
   const double tol2 = tr > ta ? tr : ta;
   int iters = 0, reason = 0;
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
         acc_pq = fma(p[i], s, acc_pq);
       }
     }
-    const double pq = block_sum_all(acc_pq, part + 3 * SMALL_WAVES);  // barrier: every read of p is done
+    const double pq = block_sum_all(acc_pq, part + ((iters & 1) ? 0 : 3 * SMALL_WAVES));  // barrier: every read of p is done
     const double alpha = rz / pq;
     acc_rz = acc_rr = 0.0;
 #pragma unroll
@@ -180,8 +205,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
         acc_rr = fma(r[j], r[j], acc_rr);
       }
     }
-    const double rzn = block_sum_all(acc_rz, part);
-    rr = block_sum_all(acc_rr, part + SMALL_WAVES);
+    block_sum_all2(acc_rz, acc_rr, part + ((iters & 1) ? 4 * SMALL_WAVES : SMALL_WAVES));
+    const double rzn = acc_rz;
+    rr = acc_rr;
     const double beta = rzn / rz;
     rz = rzn;
     ++iters;
@@ -226,13 +252,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
 }
 
 size_t small_lds_bytes(const beat_pde* pde, int margin) {
-  return sizeof(double) * ((size_t)2 * 27 * TABW + 4 * SMALL_WAVES + 32 + (size_t)pde->n + 2 * (size_t)margin);
+  return sizeof(double) * ((size_t)2 * 27 * TABW + 6 * SMALL_WAVES + 32 + (size_t)pde->n + 2 * (size_t)margin);
 }
 
 int small_margin(const beat_pde* pde) { return (int)(pde->g.plane + pde->g.nx + 1 + 7) / 8 * 8; }
 }  // namespace
 
-// Grids the one-workgroup solve takes: constant coefficients, Jacobi, both z faces physical, at most 8 nodes per
+// Grids the one-workgroup solve takes: constant coefficients, Jacobi, both z faces physical, at most 16 nodes per
 // thread (their r, increment and A p in registers) and the search direction + tables within the 160 KB of LDS.  BEAT_SMALL=0 switches it off for
 // the process, beat_pde_set_small_grid_solve for one operator.
 bool beat_small_available(const beat_pde* pde) {
@@ -242,7 +268,7 @@ bool beat_small_available(const beat_pde* pde) {
   }();
   if (!enabled || !pde->small_enabled || pde->var || pde->pc_ncoef != 1) return false;
   if (!pde->g.z_lo_phys || !pde->g.z_hi_phys) return false;
-  if (pde->n > (int64_t)8 * SMALL_THREADS) return false;
+  if (pde->n > (int64_t)SMALL_MAX_PER_THREAD * SMALL_THREADS) return false;
   return small_lds_bytes(pde, small_margin(pde)) <= (size_t)150 * 1024;
 }
 
@@ -296,8 +322,16 @@ int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* cons
     BEAT_SMALL_LAUNCH(2);
   else if (per_thread <= 4)
     BEAT_SMALL_LAUNCH(4);
-  else
+  else if (per_thread <= 6)
+    BEAT_SMALL_LAUNCH(6);
+  else if (per_thread <= 8)
     BEAT_SMALL_LAUNCH(8);
+  else if (per_thread <= 10)
+    BEAT_SMALL_LAUNCH(10);
+  else if (per_thread <= 12)
+    BEAT_SMALL_LAUNCH(12);
+  else
+    BEAT_SMALL_LAUNCH(16);
 #undef BEAT_SMALL_LAUNCH
   BEAT_LAUNCH_CHECK();
   double* h = pde->ctx->h_pinned;

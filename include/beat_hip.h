@@ -303,7 +303,7 @@ int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, 
  * the Niederer slab at dx = 0.5 mm): beat_pde_solve[_ex] runs the whole solve -- right-hand side, every iteration,
  * update of dev_x, bookkeeping of the initial guess -- in one launch of one workgroup (search direction in LDS, dot
  * products as block reductions), because a multi-launch iteration there is nothing but launch latency
- * (demos/niederer_benchmark.py: 0.38 -> 0.18 ms per split step).  Same iteration and stopping test, different
+ * (demos/niederer_benchmark.py: 0.38 -> 0.15 ms per split step).  Same iteration and stopping test, different
  * summation order in the dot products; nothing is ever left pending (host_pending = {0, 0}).  On by default
  * (BEAT_SMALL=0 disables it for the process), per operator: */
 int beat_pde_set_small_grid_solve(beat_pde* pde, int enable);
