@@ -2,7 +2,7 @@
 array for non-finite values every 100 steps and, if one appears, prints the node, the step and the node's states before
 and after the ionic kernel.  This is how the V = 15 mV singularity of the TP06 L-type current was found.
 
-    python tools/soak_run.py [n] [first_checked_step] [steps] [nodefer]
+    python tools/soak_run.py [n] [first_checked_step] [steps] [defer|nodefer] [guess order, default 3]
 """
 import ctypes as C
 import sys
@@ -22,6 +22,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 start_check = int(sys.argv[2]) if len(sys.argv) > 2 else 2400
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 3100
 defer = (sys.argv[4] != "nodefer") if len(sys.argv) > 4 else True
+guess_order = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 ctx = Context(0)
 lib = ctx.lib
 slab = Slab(n, 0, 1)
@@ -29,6 +30,7 @@ plane = n * n
 N = plane * n
 ops = HipOps(ctx, (n, n, n), True, True, *_stencil.stencil_tables(3, (bench.H,) * 3, bench.conductivity()))
 ops.set_preconditioner(1)
+ops.set_guess_order(guess_order)
 ops.set_timestep(bench.C_M, bench.THETA, bench.DT)
 solver = DiffusionSolver(ops, slab)
 ic, params, v_index = bench.tp06_defaults()
@@ -39,6 +41,7 @@ p_host = np.ascontiguousarray(params)
 p_ptr = p_host.ctypes.data_as(C.c_void_p)
 t = 0.0
 prev = None
+all_its = []
 for step in range(nsteps):
     check = step >= start_check and step % 100 == 0
     if step % 1000 == 0 and not check:
@@ -66,7 +69,13 @@ for step in range(nsteps):
         bad = [k for k, r in enumerate(states.rows) if not bool(torch.isfinite(r).all())]
         print("non-finite rows before the solve:", bad)
         break
+    all_its.append(res.iterations)
     if check and step % 1000 == 0:
         ops.flush_pending()
         print(step, res.iterations, float(v_field.data.min()), float(v_field.data.max()), flush=True)
     t += bench.DT
+ops.flush_pending()
+its = np.array(all_its)
+print(f"guess order {guess_order}: {len(its)} steps, PCG iterations mean {its.mean():.2f} max {its.max()}, per 1000 steps "
+      + " ".join(f"{its[k:k + 1000].mean():.2f}" for k in range(0, len(its), 1000)))
+print("final v in [%.6f, %.6f], sum %.9e" % (float(v_field.data.min()), float(v_field.data.max()), float(v_field.data.sum())))
