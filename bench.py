@@ -238,9 +238,10 @@ def main():
     ap.add_argument("--iso", action="store_true", help="isotropic conductivity (configs[2], use with --n 256)")
     ap.add_argument("--no-defer", action="store_true", help="apply x += sum alpha_j p_j in its own pass after every "
                     "solve instead of inside the next ionic kernel")
-    ap.add_argument("--guess-order", type=int, default=int(os.environ.get("BEAT_GUESS_ORDER", "3")), choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--guess-order", type=int, default=int(os.environ.get("BEAT_GUESS_ORDER", "-1")), choices=[-1, 0, 1, 2, 3, 4],
                     help="initial guess of each diffusion solve: 0 = the ionic step's potential, m = plus the degree-(m-1) "
-                    "extrapolation in time of the last m diffusion increments (beat_pde_set_guess_order; the package default is 3)")
+                    "extrapolation in time of the last m diffusion increments, -1 = quadratic or cubic chosen per solve by the "
+                    "iteration counts seen (beat_pde_set_guess_order; -1 is the package default)")
     ap.add_argument("--no-front", action="store_true", help="skip the second, developed-front measurement")
     ap.add_argument("--direct", action="store_true", help="drive the kernels by bare C-ABI calls (beat_ode_step_pending + "
                     "DiffusionSolver.solve) instead of the public API's MonodomainSplittingSolver.step")
@@ -509,7 +510,7 @@ def main():
         # diffusion solve (the launch applies that solve's x += sum alpha_j p_j)
         k_pend = float(np.mean(pend_counts)) if pend_counts else 0.0
         # ... and, with an extrapolated initial guess, the increments it is built from (read) and the new one (written)
-        g_bytes = 8.0 * (args.guess_order + 2) if args.guess_order else 0.0  # reads e, d.., writes d, e
+        g_bytes = 8.0 * ((args.guess_order if args.guess_order > 0 else 4) + 2) if args.guess_order else 0.0  # reads e, d.., writes d, e
         ode_bytes = (16.0 * S + 8.0 * k_pend + g_bytes) * n_local
         achieved = ode_bytes / (ode_ms * 1e-3) / 1e9
         step_bytes = (16.0 * S + 16.0 + 88.0 * k_avg) * n_total
@@ -531,7 +532,8 @@ def main():
                             f"P1 consistent-mass theta=0.5 diffusion, Godunov splitting, dt=0.01 ms, "
                             f"PCG rtol={args.rtol:g} (x0 = " + ("previous v", "previous v + last increment", "previous v + linear extrapolation of the last two increments",
                                                           "previous v + quadratic extrapolation of the last three increments",
-                                                          "previous v + cubic extrapolation of the last four increments")[args.guess_order] + "), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
+                                                          "previous v + cubic extrapolation of the last four increments",
+                                                          "previous v + quadratic or cubic extrapolation of the last increments, chosen per solve")[args.guess_order] + "), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
                 "driver": ("public API: beat.MonodomainSplittingSolver.step on MonodomainModel + DolfinODESolver" if use_api

@@ -186,7 +186,7 @@ class HipOps:
         self.st_ptr_for_flush = None   # scalar state the pending update belongs to (None: the handle's own)
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
-        self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for order 3 by default)
+        self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for "auto" by default)
         if not type(self).default_small:
             self.set_small(False)
 
@@ -383,7 +383,12 @@ class HipOps:
 
     def set_guess_order(self, order: int) -> None:
         """0: every solve starts from x0 = v_; m = 1..4: from v_ plus the degree-(m-1) extrapolation in time of the last
-        m diffusion increments (beat_pde_set_guess_order).  Drops the history."""
+        m diffusion increments; "auto" (-1): quadratic or cubic, whichever has been leaving the smaller initial residual
+        (beat_pde_set_guess_order).  Drops the history."""
+        if isinstance(order, str):
+            if order != "auto":
+                raise ValueError(f"guess order must be an integer 0..4 or 'auto', got {order!r}")
+            order = -1
         self.flush_pending()
         _hip.check(self.lib.beat_pde_set_guess_order(self.handle, int(order)))
         self.guess_order = int(order)

@@ -144,11 +144,12 @@ class BaseModel:
         self._timestep = grid.Constant(mesh, self.parameters["default_timestep"])
         self._setup_operators()
         # initial guess of the linear solves from the previous steps' increments (PETSc's KSPGuess; the reference
-        # leaves it off): petsc_options["ksp_guess_order"] in 0..4, default BEAT_GUESS_ORDER or 3 (quadratic
-        # extrapolation in time: best on the benchmark's steps, second to the cubic on a developed front)
-        order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", 3))
+        # leaves it off): petsc_options["ksp_guess_order"] in 0..4 or "auto", default BEAT_GUESS_ORDER or "auto" (quadratic
+        # or cubic extrapolation in time, whichever has been costing fewer iterations: the quadratic on the benchmark's
+        # steps, the cubic on a developed front)
+        order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", "auto"))
         if hasattr(self._ops, "set_guess_order"):
-            self._ops.set_guess_order(int(order))
+            self._ops.set_guess_order("auto" if order in ("auto", "-1", -1) else int(order))
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
         self.ksp = None  # KSP-like record of the last solve

@@ -258,7 +258,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   const bool rr = beat_rr_available(pde);  // constant coefficients: the kernels that never store q = A p
   // ghost planes of v_ for the right-hand side (the reference's scatter_forward after the previous solve) and, in the
   // same exchange, of the guess increment e (written by the x update of the previous solve)
-  const bool guess_path = (rr || pde->var) && pde->guess_order > 0 && pde->d_guess != nullptr && pde->hist_n >= 1;
+  const bool guess_path = (rr || pde->var) && pde->guess_order != 0 && pde->d_guess != nullptr && pde->hist_n >= 1;
   if ((rc = halo_start(comm, const_cast<double*>(dev_v_prev), n, plane, guess_path ? pde->d_guess : nullptr))) return rc;
   if ((rc = halo_wait(comm))) return rc;
   if (rr) {
@@ -336,6 +336,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   }
   const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
   const GuessTerms last = beat_guess_terms(pde, base);
+  beat_guess_observe(pde, (int)h[ITERS]);
   if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
     if (defer_flush) {
       host_pending[0] = base;

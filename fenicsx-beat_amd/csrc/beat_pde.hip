@@ -336,6 +336,7 @@ __global__ void pcg_begin_kernel(double* st, double rtol, double atol, double ma
   st[ATOL] = atol;
   st[MAXIT] = max_it;
   st[BETA] = 0.0;
+  st[RR0] = rr;
   const bool done = rr <= tol2;
   st[STOP] = done ? 1.0 : 0.0;
   st[REASON] = done ? (rr <= tr ? 2.0 : 3.0) : 0.0;
@@ -684,6 +685,7 @@ extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, do
   pde->have_dt = true;
   pde->last_iters = -1;
   pde->hist_n = 0;  // increments of another time step say nothing about this one
+  pde->auto_e_order = 0;
   if (pde->var) return beat_var_form_A(pde);
   return upload_tables(pde);
 }
@@ -996,11 +998,17 @@ extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
 extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
-  BEAT_REQUIRE(order >= 0 && order <= BEAT_GUESS_MAX_ORDER, "guess order must be 0..%d, got %d", BEAT_GUESS_MAX_ORDER, order);
+  BEAT_REQUIRE(order >= -1 && order <= BEAT_GUESS_MAX_ORDER, "guess order must be -1 (adaptive) or 0..%d, got %d",
+               BEAT_GUESS_MAX_ORDER, order);
   BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending: apply it before changing the guess order");
   pde->guess_order = order;
   pde->hist_n = 0;
   pde->guess = GuessTerms{};
+  pde->auto_next = 3;
+  pde->auto_e_order = 0;
+  pde->auto_seen[0] = pde->auto_seen[1] = 0;
+  pde->auto_since_probe = 0;
+  if (order < 0) order = BEAT_GUESS_MAX_ORDER;  // adaptive: the fields the cubic needs
   // fields: the max(order - 1, 1) increments kept + the guess (1024^3: 8.6 GB each -- only what the order needs)
   const int need = order > 0 ? std::max(1, order - 1) + 1 : 0;
   if (need > pde->hist_fields) {
@@ -1022,6 +1030,7 @@ extern "C" int beat_pde_guess_reset(beat_pde* pde) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
   BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending");
   pde->hist_n = 0;
+  pde->auto_e_order = 0;
   return BEAT_OK;
 }
 
@@ -1041,22 +1050,26 @@ extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_d, doubl
 
 void beat_guess_skip(beat_pde* pde) {
   pde->hist_n = 0;
+  pde->auto_e_order = 0;
   pde->guess = GuessTerms{};
 }
 
+static inline int guess_max_order(const beat_pde* pde) { return pde->guess_order < 0 ? BEAT_GUESS_MAX_ORDER : pde->guess_order; }
+
 void beat_guess_begin(beat_pde* pde) {
   pde->guess = GuessTerms{};
-  if (pde->guess_order <= 0 || pde->d_hist[0] == nullptr) return;
+  if (pde->guess_order == 0 || pde->d_hist[0] == nullptr) return;
   GuessTerms& g = pde->guess;
   // increments kept: order - 1 (at least one), newest first in d_hist; the oldest one's storage takes this solve's
-  const int nb = std::max(1, pde->guess_order - 1);
+  const int nb = std::max(1, guess_max_order(pde) - 1);
   g.d = pde->d_hist[nb - 1];
   for (int j = 0; j + 1 < nb; ++j) g.dp[j] = pde->d_hist[j];
   g.e = pde->d_guess;
   g.use_e = pde->hist_n >= 1;
   // the guess after this solve extrapolates through the m increments then on record (this one included):
   // e = sum_{i=0}^{m-1} (-1)^i C(m, i+1) D_i,  D_0 = this solve's, D_i = d_hist[i-1] as it is now
-  const int m = std::min(pde->guess_order, pde->hist_n + 1);
+  const int want = pde->guess_order < 0 ? pde->auto_next : pde->guess_order;
+  const int m = std::min(want, pde->hist_n + 1);
   static const double binom[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
   g.a = binom[m][1];
   for (int i = 1; i < m; ++i) {
@@ -1077,11 +1090,39 @@ GuessTerms beat_guess_terms(const beat_pde* pde, int ring_base) {
 }
 
 void beat_guess_advance(beat_pde* pde) {
-  const int nb = std::max(1, pde->guess_order - 1);
+  const int nb = std::max(1, guess_max_order(pde) - 1);
   double* newest = pde->d_hist[nb - 1];
   for (int j = nb - 1; j > 0; --j) pde->d_hist[j] = pde->d_hist[j - 1];
   pde->d_hist[0] = newest;
   pde->hist_n = std::min(BEAT_GUESS_MAX_ORDER, pde->hist_n + 1);
+}
+
+// Adaptive order: called by the solve paths once the host has the scalar state of the solve that just ended, before
+// beat_guess_end / beat_guess_advance.  Scores the order the guess was built with by what it is for -- the
+// iterations the solve took (the norm of the initial residual is a poor judge: the cubic's is smaller even where it
+// costs more iterations, because what is left is the amplified noise of the recorded increments, rough, and Jacobi-PCG
+// takes longer over it than over the smooth truncation error of the quadratic) -- and picks the order of the guess
+// after next (the next one is being prepared by this solve's x update, whose coefficients were fixed when it began).
+void beat_guess_observe(beat_pde* pde, int iterations) {
+  if (pde->guess_order >= 0) return;
+  const int used = pde->auto_e_order;  // order behind the e this solve started from (0: none yet, or fewer increments)
+  if (used >= 3) {
+    const int k = used - 3;
+    pde->auto_score[k] = pde->auto_seen[k] ? 0.5 * pde->auto_score[k] + 0.5 * iterations : (double)iterations;
+    pde->auto_seen[k] = 1;
+  }
+  // the e the x update of THIS solve prepares has order min(auto_next, increments on record): remember it for the
+  // next observation, then choose for the one after
+  const int prepared = std::min(pde->auto_next, pde->hist_n + 1);
+  pde->auto_e_order = prepared >= 3 && prepared == pde->auto_next ? prepared : 0;
+  int best = 3;
+  if (pde->auto_seen[0] && pde->auto_seen[1]) best = pde->auto_score[1] < pde->auto_score[0] - 0.05 ? 4 : 3;
+  else if (pde->auto_seen[0]) best = 4;  // the cubic has not been looked at yet
+  if (pde->auto_seen[0] && pde->auto_seen[1] && ++pde->auto_since_probe >= 16) {
+    pde->auto_since_probe = 0;
+    best = best == 3 ? 4 : 3;  // one solve with the other order keeps its score current
+  }
+  pde->auto_next = best;
 }
 
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
@@ -1182,6 +1223,7 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     }
     const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
     const GuessTerms last = beat_guess_terms(pde, base);
+    beat_guess_observe(pde, (int)h[ITERS]);
     if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
       if (defer_flush) {
         host_pending[0] = base;
@@ -1237,6 +1279,7 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     // guess increment
     const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
     const GuessTerms last = beat_guess_terms(pde, base);
+    beat_guess_observe(pde, (int)h[ITERS]);
     if (beat_guess_end(pde, nupd, defer_flush != 0)) {
       if (defer_flush) {  // the caller adds these directions itself (beat_ode_step_pending / beat_pde_x_flush)
         host_pending[0] = base;

@@ -11,7 +11,7 @@
 namespace beat_pde_detail {
 
 // slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
-enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD };
+enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD, RR0 };  // RR0: r.r of the initial guess
 constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
 constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
@@ -49,7 +49,17 @@ struct beat_pde {
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
   // initial guess from the previous solves' increments (0: x0 = v_; m: + the degree-(m-1) extrapolation of the last m), see GuessTerms
-  int guess_order = 0;
+  int guess_order = 0;                     // as configured: 0..4, or -1 = choose between 3 and 4 per solve (below)
+  // adaptive choice (guess_order = -1).  The cubic extrapolation wins where the increments change fast (a travelling
+  // front), the quadratic where they are smooth and the rtol-sized noise of the recorded increments, amplified by the
+  // sum of |coefficients| (7 vs 15), sets the initial residual: keep a running mean of the iteration count per
+  // order, use the better one, look at the other one every 16th solve.  Iteration counts are global: every rank of a
+  // decomposed solve takes the same decisions.
+  int auto_next = 3;                       // order of the guess the NEXT x update prepares
+  int auto_e_order = 0;                    // order the guess now in e was built with (0: none / not adaptive)
+  double auto_score[2] = {0.0, 0.0};       // running mean of the iterations per solve for orders 3, 4
+  int auto_seen[2] = {0, 0};
+  int auto_since_probe = 0;
   double* d_hist[3] = {nullptr, nullptr, nullptr};  // fields with ghost planes: the last increments, newest first
   double* d_guess = nullptr;               // the guess increment e prepared for the next solve
   double* d_hist_alloc = nullptr;
@@ -115,7 +125,8 @@ bool beat_guess_end(beat_pde* pde, int nupd, bool deferred);
 int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                            int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);
 
-void beat_guess_advance(beat_pde* pde);  // this solve's increment has been recorded: it is the most recent one now
+void beat_guess_advance(beat_pde* pde);
+void beat_guess_observe(beat_pde* pde, int iterations);  // of the solve that just ended (adaptive order)  // this solve's increment has been recorded: it is the most recent one now
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

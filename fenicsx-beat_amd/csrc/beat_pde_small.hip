@@ -162,6 +162,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
   }
   block_sum_all2(acc_rz, acc_rr, part + SMALL_WAVES);
   double rz = acc_rz, rr = acc_rr;
+  const double rr0 = rr;
   const double tr = a.rtol * a.rtol * bb, ta = a.atol * a.atol;
   const double tol2 = tr > ta ? tr : ta;
   int iters = 0, reason = 0;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void pcg_small_kernel(SmallArgs a) {
   }
   if (tid == 0) {
     a.st[BB] = bb;
+    a.st[RR0] = rr0;
     a.st[RR] = rr;
     a.st[RZ] = rz;
     a.st[ITERS] = (double)iters;
@@ -337,7 +339,10 @@ int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* cons
   double* h = pde->ctx->h_pinned;
   BEAT_HIP_CHECK(hipMemcpyAsync(h, pde->d_st, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
   BEAT_HIP_CHECK(hipStreamSynchronize(s));
-  if (pde->guess.d != nullptr) beat_guess_advance(pde);  // the kernel recorded this solve's increment
+  if (pde->guess.d != nullptr) {  // the kernel recorded this solve's increment
+    beat_guess_observe(pde, (int)h[ITERS]);
+    beat_guess_advance(pde);
+  }
   const int iters = (int)h[ITERS], reason = (int)h[REASON];
   pde->last_iters = iters;
   if (info) {

@@ -289,9 +289,12 @@ int beat_pde_work_fields(beat_pde* pde);
  * p_j), which also records the new increment and prepares the next e in place.  Consequences for callers that
  * defer (defer_flush != 0): the update may be due even when host_pending[1] == 0 -- ask beat_pde_guess_pending --
  * and it must be applied through this operator (beat_ode_step_pending with `pde`, or beat_pde_x_flush), which clears
- * the flag.  beat_pde_set_timestep and beat_pde_guess_reset drop the history (call the latter when the potential is
+ * the flag.  order = -1 chooses between m = 3 and m = 4 per solve: it keeps a running mean of the iteration counts
+ * each of the two has been costing, uses the cheaper one and tries the other every 16th solve (the cubic wins on a
+ * travelling front, the quadratic where the increments are smooth; iteration counts are global, so all ranks of a
+ * decomposed solve decide alike).  beat_pde_set_timestep and beat_pde_guess_reset drop the history (call the latter when the potential is
  * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: max(m - 1, 1) + 1 more fields,
- * allocated when the order is set.  Default order: 0 (the Python layer's BaseModel asks for 3). */
+ * allocated when the order is set.  Default order: 0 (the Python layer's BaseModel asks for -1). */
 int beat_pde_set_guess_order(beat_pde* pde, int order);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);

@@ -237,7 +237,7 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, 
 
 
 @pytest.mark.parametrize("loop,order,per_node", [("lib", 0, False), ("lib", 2, False), ("lib", 1, False), ("stage", 0, False),
-                                                 ("lib", 2, True), ("lib", 0, True), ("lib", 3, False), ("lib", 4, True)])
+                                                 ("lib", 2, True), ("lib", 0, True), ("lib", 3, False), ("lib", 4, True), ("lib", "auto", False)])
 def test_split_steps_on_slabs_in_threads_match_one_rank(hip_ctx, loop, order, per_node):
     """bench.py's N > 1 step (TP06 ionic kernel applying the previous solve's pending directions on the slab's V row,
     then the slab-decomposed diffusion solve with the deferred last update) on 3 ranks played by threads: after 25 steps
