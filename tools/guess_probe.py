@@ -5,6 +5,7 @@
     x0 = v + 2 d1 - d2           (linear extrapolation of the increment)
     x0 = v + 3 d1 - 3 d2 + d3    (quadratic extrapolation)
     x0 = v + 4 d1 - 6 d2 + 4 d3 - d4   (cubic)
+    x0 = v + 5 d1 - 10 d2 + 10 d3 - 5 d4 + d5   (quartic)
 
 Same stopping test as the library (||r|| <= rtol ||b||).  Runs the bench workload (bump, then developed front) on
 one GPU at a reduced size with a PCG written in torch over beat_pde_apply, so no kernel has to exist before the
@@ -93,7 +94,7 @@ def main():
             rz = rzn
 
     def run(label, nsteps):
-        d1 = d2 = d3 = d4 = None
+        d1 = d2 = d3 = d4 = d5 = None
         t = 0.0
         rows = []
         for i in range(nsteps):
@@ -106,22 +107,23 @@ def main():
             ks, rs = [k0], [r0]
             for g in ((v0 + d1) if d1 is not None else None, (v0 + 2 * d1 - d2) if d2 is not None else None,
                       (v0 + 3 * d1 - 3 * d2 + d3) if d3 is not None else None,
-                      (v0 + 4 * d1 - 6 * d2 + 4 * d3 - d4) if d4 is not None else None):
+                      (v0 + 4 * d1 - 6 * d2 + 4 * d3 - d4) if d4 is not None else None,
+                      (v0 + 5 * d1 - 10 * d2 + 10 * d3 - 5 * d4 + d5) if d5 is not None else None):
                 if g is None:
                     ks.append(-1), rs.append(float("nan"))
                     continue
                 xg, kg, rg = pcg(b, g, bb)
                 ks.append(kg), rs.append(rg)
-            d4, d3, d2, d1 = d3, d2, d1, x - v0
+            d5, d4, d3, d2, d1 = d4, d3, d2, d1, x - v0
             v.data.copy_(x)
             rows.append(ks)
             t += bench.DT
             if i % 5 == 4 or i < 6:
-                print(f"{label} step {i:3d}: k(v)={ks[0]} k(v+d1)={ks[1]} k(v+2d1-d2)={ks[2]} k(quadratic)={ks[3]} k(cubic)={ks[4]}  r0/b: "
+                print(f"{label} step {i:3d}: k(v)={ks[0]} k(v+d1)={ks[1]} k(v+2d1-d2)={ks[2]} k(quadratic)={ks[3]} k(cubic)={ks[4]} k(quartic)={ks[5]}  r0/b: "
                       + " ".join(f"{np.sqrt(r / bb):.2e}" for r in rs), flush=True)
-        rows = np.array(rows[5:])
+        rows = np.array(rows[6:])
         print(f"{label}: mean iterations after 5 steps: v {rows[:, 0].mean():.2f}, v+d1 {rows[:, 1].mean():.2f}, "
-              f"v+2d1-d2 {rows[:, 2].mean():.2f}, quadratic {rows[:, 3].mean():.2f}, cubic {rows[:, 4].mean():.2f}", flush=True)
+              f"v+2d1-d2 {rows[:, 2].mean():.2f}, quadratic {rows[:, 3].mean():.2f}, cubic {rows[:, 4].mean():.2f}, quartic {rows[:, 5].mean():.2f}", flush=True)
 
     bench.init_states(ctx, states, ic, v_index, n, slab, 1234, n)
     run("bump", steps)
