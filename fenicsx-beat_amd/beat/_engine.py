@@ -516,7 +516,10 @@ class LibComm:
         peer_lo, peer_hi = peers if peers is not None else (-1 if slab.lo_phys else rank - 1, -1 if slab.hi_phys else rank + 1)
         self.peer_lo, self.peer_hi = int(peer_lo), int(peer_hi)
         handle = C.c_void_p()
+        self.handle = None
         self.transport = transport
+        if os.environ.get("BEAT_TEST_FAIL_LIBCOMM_RANK") == str(rank):  # tests: a rank whose communicator cannot be made
+            raise RuntimeError("simulated failure to create the library communicator (BEAT_TEST_FAIL_LIBCOMM_RANK)")
         if transport == "rccl":
             ids = C.create_string_buffer(2 * _hip.UNIQUE_ID_BYTES)
             if world > 1:
@@ -644,10 +647,33 @@ class DiffusionSolver:
             if dist.is_initialized() and not nccl and on_device:
                 self.dist = _HostStagedDist(dist)  # device fields on a host-only backend: rehearsal transport
             if self.libcomm is None and on_device and not stage_driven and isinstance(ops, HipOps):
-                if nccl or slab.world == 1:
-                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "rccl")
+                # The library's own communicator.  Should creating it fail on any rank (librccl missing, a refused
+                # ncclCommInitRank), ALL ranks fall back together to the stage-driven loop over torch.distributed -- slower
+                # (Python per iteration, no initial guess) but the same numbers -- instead of leaving the job half-connected.
+                err = None
+                try:
+                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "rccl" if (nccl or slab.world == 1) else "callbacks")
+                except Exception as exc:  # noqa: BLE001
+                    err = exc
+                if slab.world > 1 and dist.is_initialized():
+                    import torch
+
+                    flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64,
+                                        device=ops.st.device if nccl else "cpu")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                    failed = float(flag.item()) > 0.0
                 else:
-                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "callbacks")
+                    failed = err is not None
+                if failed:
+                    if slab.world == 1 and err is not None:
+                        raise err
+                    if self.libcomm is not None:
+                        self.libcomm.close()
+                        self.libcomm = None
+                    import warnings
+
+                    warnings.warn("in-library communicator unavailable" + (f" ({err})" if err is not None else " on another rank")
+                                  + ": using the stage-driven loop over torch.distributed", RuntimeWarning, stacklevel=2)
         else:
             self.dist = None
 

@@ -347,6 +347,17 @@ def test_bench_multi_process_rehearsal_on_one_gpu():
     assert r2["n_gpus"] == 2 and r2["config"]["nodes"] == 48**3 and r2["config"]["finite"] and r2["cpu_baseline"] is None
     assert abs(r2["config"]["pcg_iterations_per_step"] - r1["config"]["pcg_iterations_per_step"]) <= 0.5
     assert abs(r2["config"]["v_max"] - r1["config"]["v_max"]) < 1.0  # same bump; the gates' 1 % noise is seeded per rank
+    # one rank fails to create the library's communicator: both ranks fall back, together, to the stage-driven loop
+    # over torch.distributed (no initial guess there: more iterations, same answer) instead of hanging or crashing
+    env_fail = dict(env, BEAT_TEST_FAIL_LIBCOMM_RANK="1")
+    fb = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", *common],
+                        capture_output=True, text=True, timeout=300, cwd=root, env=env_fail)
+    assert fb.returncode == 0, fb.stderr[-2000:]
+    assert "stage-driven loop" in fb.stderr
+    r3 = json.loads([ln for ln in fb.stdout.splitlines() if ln.strip()][0])
+    assert r3["config"]["finite"] and abs(r3["config"]["v_max"] - r2["config"]["v_max"]) < 1e-4
+    assert r3["config"]["pcg_iterations_per_step"] >= r2["config"]["pcg_iterations_per_step"]
 
 
 @pytest.mark.parametrize("world", [2, 3])
