@@ -398,6 +398,10 @@ class HipOps:
         this operator on the multi-launch kernels (tests of those kernels on small grids, deferral semantics)."""
         _hip.check(self.lib.beat_pde_set_small_grid_solve(self.handle, int(bool(enable))))
 
+    def small_active(self) -> bool:
+        """True when solves of this operator run as one launch of one workgroup (and beat_split_steps accepts it)."""
+        return bool(self.lib.beat_pde_small_grid_solve_active(self.handle))
+
     def guess_reset(self) -> None:
         """Forget the recorded increments (the potential was overwritten: the next solve starts from x0 = v_)."""
         self.flush_pending()

@@ -25,6 +25,7 @@ MAX_STIM = 8
 ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON = range(11)
 ST_NUPD = 14
 ST_SIZE = 16
+MAX_BATCH = 1024  # BEAT_MAX_BATCH: steps per beat_split_steps call
 
 
 class BeatHipError(RuntimeError):
@@ -85,6 +86,9 @@ SIGNATURES = {
     "beat_pde_cg_next_oop": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "beat_pde_x_flush": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int]),
     "beat_pde_set_small_grid_solve": (_int, [_vp, _int]),
+    "beat_pde_small_grid_solve_active": (_int, [_vp]),
+    "beat_split_steps": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl,
+                                _int, _vp, _vp, _int, _vp, _vp]),
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
     "beat_pde_guess_reset": (_int, [_vp]),
     "beat_pde_guess_pending": (_int, [_vp]),

@@ -1284,6 +1284,17 @@ class ProbeRecorder:
                                                    self._wts.ctypes.data_as(C.c_void_p), self.npts, out))
         self._rows += 1
 
+    def _reserve(self, nrows: int):
+        """Device address of the next free row and how many rows (<= nrows) may be written there; the caller commits
+        them with ``_commit`` (MonodomainSplittingSolver.solve records a batch of steps in one library call)."""
+        if self._rows == self.capacity:
+            self._done.append(self._read())
+            self._rows = 0
+        return self._buf.data_ptr() + 8 * self._rows * self.npts, min(int(nrows), self.capacity - self._rows)
+
+    def _commit(self, nrows: int) -> None:
+        self._rows += int(nrows)
+
     def _read(self) -> np.ndarray:
         part = self._buf[: self._rows * self.npts].cpu().numpy().reshape(self._rows, self.npts).copy()
         if self._mesh.comm.size > 1:  # every rank holds the partial sums over the vertices it owns

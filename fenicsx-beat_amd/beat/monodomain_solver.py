@@ -47,16 +47,97 @@ class MonodomainSplittingSolver:
         self.ode.ode_to_pde()
         self.pde.assign_previous()
 
-    def solve(self, interval, dt):
+    def solve(self, interval, dt, recorder=None):
+        """The reference's loop (monodomain_solver.py:53-66).  ``recorder`` (a ``grid.ProbeRecorder`` on ``pde.state``;
+        not part of the reference's signature) gets one row per step.  On a grid small enough for the one-launch
+        diffusion solve, with a device cell model, theta = 1, stimuli whose time dependence is a scalar factor and no
+        monitor attached, the steps are handed to the library in batches (beat_split_steps): same kernels, same
+        values, no host round trip between steps."""
         T0, T = interval
         if dt is None:
             dt = T - T0
+        steps = []
         t0 = T0
         t1 = T0 + dt
         while t1 < T + EPS:
-            self.step((t0, t1))
+            steps.append((t0, t1))
             t0 = t1
             t1 = t0 + dt
+        if steps and self._can_batch(recorder):
+            self._batched_steps(steps, recorder)
+            return
+        for iv in steps:
+            self.step(iv)
+            if recorder is not None:
+                recorder.record()
+
+    def _can_batch(self, recorder) -> bool:
+        if not (self._can_fuse() and np.isclose(self.theta, 1.0)):
+            return False
+        ode, pde = self.ode, self.pde
+        ops = getattr(pde, "_ops", None)
+        if ops is None or not hasattr(ops, "small_active") or not ops.small_active():
+            return False
+        if not all(type(m) is NullMonitor for m in (self.monitor, pde.monitor, getattr(ode._dev, "monitor", NullMonitor()))):
+            return False  # someone wants per-step timings / KSP records
+        if any(getattr(s, "general", None) is not None or hasattr(s, "cellfun") for s in pde._stimuli):
+            return False  # weights that change from step to step
+        if recorder is not None and recorder._f is not pde.state:
+            return False
+        ode._dev.parameters = ode.parameters
+        return ode._dev._param_args()[2] is None  # uniform parameters
+
+    def _batched_steps(self, steps, recorder) -> None:
+        import ctypes as C
+
+        from . import _hip
+        from ._engine import KspResult
+
+        ode, pde = self.ode, self.pde
+        ops, dev, row = pde._ops, ode._dev, ode._v_row
+        dt = steps[0][1] - steps[0][0]
+        ops.flush_pending()
+        if not abs(dt - float(pde._timestep)) < 1.0e-12:
+            pde._timestep.value = dt
+            pde._update_matrices()
+        theta_pde = pde.parameters["theta"]
+        stims = [s for s in pde._stimuli if s.field is not None]
+        rtol, atol, max_it = pde._solver_tolerances()
+        hp, npar, _, _ = dev._param_args()
+        w_ptrs = (C.c_void_p * max(1, len(stims)))(*[s.field.ptr for s in stims])
+        done = 0
+        while done < len(steps):
+            nb = min(len(steps) - done, _hip.MAX_BATCH)
+            probe = (None, None, 0, None)
+            if recorder is not None:
+                ptr, nb = recorder._reserve(nb)
+                probe = (recorder._idx.ctypes.data_as(C.c_void_p), recorder._wts.ctypes.data_as(C.c_void_p), recorder.npts,
+                         C.c_void_p(ptr))
+            chunk = steps[done : done + nb]
+            t_start = np.ascontiguousarray([a for a, _ in chunk], dtype=np.float64)
+            dts = np.ascontiguousarray([self.theta * (b - a) for a, b in chunk], dtype=np.float64)
+            amps = np.zeros((nb, max(1, len(stims))))
+            for k, (a, _) in enumerate(chunk):  # the stimulus expressions are evaluated at t0 + theta dt, as step() does
+                pde.time.value = a + theta_pde * (chunk[k][1] - a)
+                for j, s in enumerate(stims):
+                    amps[k, j] = s.amplitude()
+            infos = (_hip.KspInfo * nb)()
+            rc = dev.ctx.lib.beat_split_steps(
+                dev.ctx.handle, dev.model.model_id, dev.states.ptr, dev.n, dev.states.ld, hp, npar, int(ode.v_index), ops.handle,
+                nb, t_start.ctypes.data_as(C.c_void_p), dts.ctypes.data_as(C.c_void_p), w_ptrs, amps.ctypes.data_as(C.c_void_p), len(stims),
+                rtol, atol, max_it, *probe, infos)
+            _hip.check(rc, allow_not_converged=True)
+            if recorder is not None:
+                recorder._commit(nb)
+            bad = [i for i in range(nb) if infos[i].converged_reason < 0]
+            last = infos[bad[0]] if bad else infos[nb - 1]
+            pde.ksp = KspResult(last.iterations, last.residual_norm, last.converged_reason, last.rhs_norm)
+            pde._check_converged()
+            done += nb
+        ode._pending_ops = ops
+        for f in (pde.state, pde.v_, ode.v_ode):
+            f.alias_to(row, sync=ops.flush_pending)
+        ode._aliases = [pde.state, pde.v_, ode.v_ode]
 
     # ---------------------------------------------------------------------------------------
     def _can_fuse(self) -> bool:

@@ -6,8 +6,10 @@
 #include "beat_pde_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <vector>
 #include "ionic_models.h"
 #include "torord_dyncl.h"
 
@@ -332,4 +334,63 @@ extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_st
   }
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
                            t, dt, v_index, dev_v_copy, pend);
+}
+
+
+// Many split steps of a SMALL grid in one call (theta = 1: ionic step of dt, then the diffusion step of dt in place on
+// the potential row; src/beat/monodomain_solver.py:33-79 run n_steps times): per step one ionic launch, the
+// one-workgroup solve (beat_pde_small.hip) and, optionally, a probe record -- nothing else, in particular no host
+// round trip: the scalar results of every solve are read back once at the end.  A grid of a few thousand nodes is
+// otherwise bound by exactly that: the Niederer slab at dx = 0.5 mm spends 0.10 of its 0.15 ms per step on the GPU.
+extern "C" int beat_split_steps(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                                const double* host_params, int num_params, int v_index, beat_pde* pde, int n_steps,
+                                const double* host_t0, const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp,
+                                int n_stim, double rtol, double atol, int max_it, const int64_t* host_probe_idx,
+                                const double* host_probe_w, int n_probe, double* dev_probe_out, beat_ksp_info* host_info) {
+  BEAT_REQUIRE(ctx != nullptr && pde != nullptr && dev_states != nullptr && ((host_t0 != nullptr && host_dt != nullptr) || n_steps == 0), "null argument");
+  BEAT_REQUIRE(pde->ctx == ctx, "operator and states belong to different contexts");
+  BEAT_REQUIRE(n_steps >= 0 && n_steps <= BEAT_MAX_BATCH, "at most %d steps per call, got %d", BEAT_MAX_BATCH, n_steps);
+  BEAT_REQUIRE(pde->n == n, "the operator has %lld nodes, the state array %lld", (long long)pde->n, (long long)n);
+  BEAT_REQUIRE(beat_small_available(pde), "beat_split_steps is for grids the one-launch solve takes "
+               "(beat_pde_small_grid_solve_active)");
+  BEAT_REQUIRE(!pde->guess_pending, "a deferred update of the potential is pending: apply it first");
+  BEAT_REQUIRE(n_stim == 0 || (host_dev_stim_w != nullptr && host_stim_amp != nullptr), "null stimulus arrays");
+  BEAT_REQUIRE(n_probe == 0 || (host_probe_idx && host_probe_w && dev_probe_out), "null probe arrays");
+  if (n_steps == 0) return BEAT_OK;
+  if (pde->d_batch_st == nullptr) BEAT_HIP_CHECK(hipMalloc(&pde->d_batch_st, sizeof(double) * 16 * BEAT_MAX_BATCH));
+  double* v_row = dev_states + (int64_t)v_index * ld;
+  for (int s = 0; s < n_steps; ++s) {
+    if (int rc = ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, nullptr, 0, host_t0[s], host_dt[s],
+                                   v_index, nullptr, PendingV{nullptr, 0, nullptr, 0, {}}))
+      return rc;
+    if (int rc = beat_small_launch(pde, v_row, host_dev_stim_w, host_stim_amp ? host_stim_amp + (size_t)s * n_stim : nullptr,
+                                   n_stim, v_row, rtol, atol, max_it, pde->d_batch_st + 16 * s))
+      return rc;
+    if (pde->guess.d != nullptr) beat_guess_advance(pde);  // (the adaptive order keeps its last choice through a batch)
+    if (n_probe > 0)
+      if (int rc = beat_field_probe_record(ctx, v_row, host_probe_idx, host_probe_w, n_probe, dev_probe_out + (size_t)s * n_probe))
+        return rc;
+  }
+  pde->auto_e_order = 0;
+  std::vector<double> h((size_t)16 * n_steps);
+  BEAT_HIP_CHECK(hipMemcpyAsync(h.data(), pde->d_batch_st, sizeof(double) * 16 * n_steps, hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  int worst = BEAT_OK;
+  for (int s = 0; s < n_steps; ++s) {
+    const double* hs = h.data() + 16 * s;
+    const int reason = (int)hs[beat_pde_detail::REASON];
+    if (host_info) {
+      host_info[s].iterations = (int)hs[beat_pde_detail::ITERS];
+      host_info[s].converged_reason = reason;
+      host_info[s].residual_norm = std::sqrt(hs[beat_pde_detail::RR]);
+      host_info[s].rhs_norm = std::sqrt(hs[beat_pde_detail::BB]);
+    }
+    if (reason < 0 && worst == BEAT_OK) {
+      beat_set_error("PCG did not converge in step %d of the batch (%d iterations, ||r|| = %.3e, ||b|| = %.3e)", s,
+                     (int)hs[beat_pde_detail::ITERS], std::sqrt(hs[beat_pde_detail::RR]), std::sqrt(hs[beat_pde_detail::BB]));
+      worst = BEAT_ENOTCONV;
+    }
+  }
+  pde->last_iters = (int)h[(size_t)16 * (n_steps - 1) + beat_pde_detail::ITERS];
+  return worst;
 }

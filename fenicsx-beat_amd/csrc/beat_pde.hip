@@ -644,6 +644,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->d_tabs);
   (void)hipFree(pde->d_st);
   (void)hipFree(pde->d_alphas);
+  (void)hipFree(pde->d_batch_st);
   (void)hipFree(pde->d_hist_alloc);
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
@@ -987,6 +988,11 @@ extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev
     pde->guess_pending = false;
   }
   return beat_pde_x_flush_terms(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
+}
+
+// 1 when beat_pde_solve[_ex] takes the one-launch path for this operator (and beat_split_steps accepts it)
+extern "C" int beat_pde_small_grid_solve_active(const beat_pde* pde) {
+  return pde != nullptr && beat_small_available(pde) ? 1 : 0;
 }
 
 extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {

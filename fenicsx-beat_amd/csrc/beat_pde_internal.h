@@ -45,6 +45,7 @@ struct beat_pde {
   int last_iters = -1;
   unsigned vec_grid = 1;
   double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
+  double* d_batch_st = nullptr;  // scalar states of the solves of a beat_split_steps batch (BEAT_MAX_BATCH x 16)
   // z node type of the ghost planes (the neighbouring slabs' boundary planes): 1 unless that plane is a face of the
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
@@ -130,6 +131,9 @@ void beat_guess_observe(beat_pde* pde, int iterations);  // of the solve that ju
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);
+int beat_small_launch(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                      const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
+                      double* dev_st);
 int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                      const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
                      beat_ksp_info* info);

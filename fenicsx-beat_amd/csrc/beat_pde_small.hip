@@ -274,9 +274,12 @@ bool beat_small_available(const beat_pde* pde) {
   return small_lds_bytes(pde, small_margin(pde)) <= (size_t)150 * 1024;
 }
 
-int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
-                     const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
-                     beat_ksp_info* info) {
+// Enqueue one solve (initial-guess terms taken with beat_guess_begin, scalar results to dev_st[0..16)); no
+// synchronisation: the caller reads dev_st back when it wants to and calls beat_guess_advance (after
+// beat_guess_observe, if it has the iteration count by then).
+int beat_small_launch(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                      const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
+                      double* dev_st) {
   BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
   BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
   BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
@@ -306,7 +309,7 @@ int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* cons
   a.max_it = max_it;
   beat_guess_begin(pde);
   a.gt = pde->guess;
-  a.st = pde->d_st;
+  a.st = dev_st;
   const size_t lds = small_lds_bytes(pde, a.margin);
   const int per_thread = (a.n + SMALL_THREADS - 1) / SMALL_THREADS;
   hipStream_t s = pde->ctx->stream;
@@ -336,6 +339,15 @@ int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* cons
     BEAT_SMALL_LAUNCH(16);
 #undef BEAT_SMALL_LAUNCH
   BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                     const double* host_stim_amp, int n_stim, double* dev_x, double rtol, double atol, int max_it,
+                     beat_ksp_info* info) {
+  if (int rc = beat_small_launch(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, rtol, atol, max_it, pde->d_st))
+    return rc;
+  hipStream_t s = pde->ctx->stream;
   double* h = pde->ctx->h_pinned;
   BEAT_HIP_CHECK(hipMemcpyAsync(h, pde->d_st, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
   BEAT_HIP_CHECK(hipStreamSynchronize(s));

@@ -310,6 +310,26 @@ int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, 
  * summation order in the dot products; nothing is ever left pending (host_pending = {0, 0}).  On by default
  * (BEAT_SMALL=0 disables it for the process), per operator: */
 int beat_pde_set_small_grid_solve(beat_pde* pde, int enable);
+int beat_pde_small_grid_solve_active(const beat_pde* pde);
+
+/* n_steps whole split steps of such a grid in ONE call (src/beat/monodomain_solver.py:33-79 with theta = 1, n_steps
+ * times: the ionic step on the (S, ld) state array, then the diffusion step in place on row
+ * v_index; uniform parameters).  Per step the library enqueues the ionic kernel, the one-launch solve and -- with
+ * n_probe > 0 -- one row of point values (beat_field_probe_record: dev_probe_out is (n_steps, n_probe)); the host is
+ * not consulted between steps and synchronises once at the end to fill host_info[0..n_steps) (NULL: not wanted).
+ * host_t0[s], host_dt[s]: start time and length of step s as the ionic step is given them (t1 - t0 of the caller's
+ * loop, which may differ from step to step in the last bit; the diffusion step uses the operator's dt,
+ * beat_pde_set_timestep); host_stim_amp is (n_steps, n_stim): the amplitudes at host_t0[s] + theta_pde dt, which the caller knows in advance
+ * (base_model.py:196-201 evaluates the stimulus expression at that time).  The initial guess of each solve follows
+ * beat_pde_set_guess_order; the adaptive order keeps its current choice through a batch.  Returns BEAT_ENOTCONV if a
+ * solve of the batch ran out of iterations (the later steps have run on its last iterate, as the reference's loop
+ * would without ksp_error_if_not_converged).  At most BEAT_MAX_BATCH steps per call. */
+#define BEAT_MAX_BATCH 1024
+int beat_split_steps(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                     const double* host_params, int num_params, int v_index, beat_pde* pde, int n_steps,
+                     const double* host_t0, const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                     double rtol, double atol, int max_it, const int64_t* host_probe_idx, const double* host_probe_w,
+                     int n_probe, double* dev_probe_out, beat_ksp_info* host_info);
 
 int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                       const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,

@@ -911,3 +911,71 @@ def test_pde_solve_reports_non_convergence_as_status():
                                   params={"petsc_options": {"ksp_rtol": 1e-14, "ksp_max_it": 2, "ksp_error_if_not_converged": True}})
     with pytest.raises(RuntimeError, match="did not converge"):
         strict.step((0.0, 0.1))
+
+
+@pytest.mark.parametrize("order", [3, "auto"])
+def test_batched_solve_equals_the_step_loop(order):
+    """MonodomainSplittingSolver.solve on a grid small enough for the one-launch diffusion solve hands its steps to the
+    library in one call (beat_split_steps: no host round trip between steps).  Same kernels in the same order as the
+    step() loop: with a fixed guess order the states are identical bit for bit, the recorded probe values are the
+    values evaluate_function returns after each step, the last KSP record is the last step's; with the adaptive order
+    (frozen through a batch) the trajectories agree to the solver tolerance.  A monitor or a non-uniform parameter set
+    keeps solve() on the step loop."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    pts = np.array([[0.0, 0.0, 0.0], [2.0, 1.0, 0.5], [4.0, 2.0, 1.0]])
+
+    def build(monitor=None):
+        geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=4.0, Ly=2.0, Lz=1.0, dx=0.25)
+        mesh = geo.mesh
+        time = g.Constant(mesh, 0.0)
+        cond = beat.conductivities.default_conductivities("Niederer")
+        cells = g.locate_entities(mesh, 3, lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+        tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+        I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                               mesh_unit="mm", amplitude=50_000.0, duration=1.0)
+        M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+        C_m = (1.0 * beat.units.ureg("uF/cm**2")).to("uF/mm**2").magnitude
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, dx=I_s.dZ,
+                                   params={"petsc_options": {"ksp_type": "cg", "ksp_rtol": 1e-10, "ksp_guess_order": order}})
+        ode = beat.odesolver.DolfinODESolver(
+            v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+            init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+            num_states=19, v_index=tp06.state_index("V"))
+        kw = {} if monitor is None else {"monitor": monitor}
+        return beat.MonodomainSplittingSolver(pde=pde, ode=ode, **kw)
+
+    dt, nsteps = 0.05, 45  # the stimulus switches off at t = 1 ms, inside the run
+    a = build()
+    assert a._can_batch(None)
+    rec = g.ProbeRecorder(a.pde.state, pts, capacity=32)  # smaller than the run: the record spills to the host once
+    a.solve((0.0, nsteps * dt), dt, recorder=rec)
+    b = build()
+    vals, t0 = [], 0.0
+    for i in range(nsteps):  # the intervals solve() generates (t1 = t0 + dt, accumulated)
+        b.step((t0, t0 + dt))
+        t0 = t0 + dt
+        vals.append(g.evaluate_function(b.pde.state, pts).ravel())
+    assert b.ode.values[17].max() > 0.0
+    if order == 3:
+        np.testing.assert_array_equal(a.ode.values, b.ode.values)
+        np.testing.assert_array_equal(rec.values(), np.array(vals))
+        assert a.pde.ksp.iterations == b.pde.ksp.iterations and a.pde.ksp.converged_reason > 0
+    else:
+        # (different guess orders leave different rtol-sized errors, which the upstroke amplifies)
+        np.testing.assert_allclose(a.ode.values, b.ode.values, rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(rec.values(), np.array(vals), rtol=0, atol=1e-5)
+    assert len(rec) == nsteps
+    np.testing.assert_array_equal(np.asarray(a.pde.state.x.array), a.ode.values[17])
+    np.testing.assert_array_equal(np.asarray(a.pde.v_.x.array), a.ode.values[17])
+    # a second call continues where the first one ended (the step loop too)
+    a.solve((t0, t0 + 5 * dt), dt)
+    for i in range(5):
+        b.step((t0, t0 + dt))
+        t0 = t0 + dt
+    if order == 3:
+        np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    # with a monitor attached the caller wants per-step records: no batching
+    assert not build(beat.telemetry.PerformanceMonitor())._can_batch(None)
