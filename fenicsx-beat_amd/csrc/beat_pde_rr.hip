@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
         Cp[r] = c;
         if (GUESS) {
           constexpr int q = GUESS ? 1 : 0;
-          Ep[r * q] = (zok && row_in[r]) ? re1[u][r * q] : 0.0;
+          Ep[r * q] = (zok && row_in[r]) ? c + re1[u][r * q] : 0.0;  // x0 = v_ + e
         }
         if (MODE == RR_PDOT) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
@@ -296,9 +296,14 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
 #pragma unroll
         for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
         if (MODE == RR_RHS) {
+          // without a guess: tab / tab2 = Mass / K, b = C_m Mass v - (1 - theta) dt K v + dt stim, r = dt (stim - K v);
+          // with one: tab = B, the second window holds x0 = v + e, b = B v + dt stim, r = b - A x0 (the textbook form:
+          // its rounding error is ~1e-16 |b|, far below any stopping threshold rtol |b|) -- two stencils instead of three
           double s2 = 0.0;
+          if (!GUESS) {
 #pragma unroll
-          for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+            for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+          }
           double di = s_dinv[13];
           if (type != 13) {
             s = 0.0;
@@ -306,15 +311,15 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
 #pragma unroll
             for (int k = 0; k < 15; ++k) {
               s = fma(s_tab[type * TABW + k], v[k], s);
-              s2 = fma(s_tab2[type * TABW + k], v[k], s2);
+              if (!GUESS) s2 = fma(s_tab2[type * TABW + k], v[k], s2);
             }
             di = s_dinv[type];
           }
           double stim = 0.0;
           for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
-          const double b = a.cm * s - a.omt_dt * s2 + a.dt * stim;
-          double rr = a.dt * (stim - s2);
-          if (GUESS) {  // - A e
+          const double b = GUESS ? fma(a.dt, stim, s) : a.cm * s - a.omt_dt * s2 + a.dt * stim;
+          double rr = GUESS ? b : a.dt * (stim - s2);
+          if (GUESS) {  // - A x0
             constexpr int q = GUESS ? 1 : 0;  // (keeps the indices in range in the instantiations without a window)
             const int re_ = r * q, rp = (r + 1) * q, rm = (r - 1) * q;
             double ev[15];
@@ -559,7 +564,9 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   }
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
-  if (guess) {  // r = b - A (v_ + e): the second register window
+  if (guess) {  // r = b - A (v_ + e): the second register window holds x0; tab = B
+    a.tab = pde->d_tab(1);
+    a.ci = interior_row(pde->h_B);
     a.e = gt.e;
     a.taba = pde->d_tab(0);
     a.cia = interior_row(pde->h_A);
