@@ -149,7 +149,13 @@ class BaseModel:
         # steps, the cubic on a developed front)
         order = (self.parameters.get("petsc_options") or {}).get("ksp_guess_order", os.environ.get("BEAT_GUESS_ORDER", "auto"))
         if hasattr(self._ops, "set_guess_order"):
-            self._ops.set_guess_order("auto" if order in ("auto", "-1", -1) else int(order))
+            from ._hip import BeatHipError
+
+            try:
+                self._ops.set_guess_order("auto" if order in ("auto", "-1", -1) else int(order))
+            except BeatHipError as exc:  # e.g. no memory for the history fields on a grid that fills the GPU
+                logger.warning("initial guess from previous steps disabled (%s): solves start from x0 = v_", exc)
+                self._ops.set_guess_order(0)
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
         self.ksp = None  # KSP-like record of the last solve

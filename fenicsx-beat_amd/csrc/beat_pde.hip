@@ -1023,7 +1023,14 @@ extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
     (void)hipFree(pde->d_hist_alloc);
     pde->d_hist_alloc = nullptr;
     pde->hist_fields = 0;
-    BEAT_HIP_CHECK(hipMalloc(&pde->d_hist_alloc, sizeof(double) * need * fld));
+    pde->d_hist[0] = pde->d_hist[1] = pde->d_hist[2] = pde->d_guess = nullptr;
+    if (hipMalloc(&pde->d_hist_alloc, sizeof(double) * need * fld) != hipSuccess) {
+      (void)hipGetLastError();
+      pde->d_hist_alloc = nullptr;
+      pde->guess_order = 0;  // no room for the history: the solves keep starting from x0 = v_
+      beat_set_error("no device memory for the %d fields of the initial guess (%.1f GB)", need, 8e-9 * need * fld);
+      return BEAT_EHIP;
+    }
     BEAT_HIP_CHECK(hipMemsetAsync(pde->d_hist_alloc, 0, sizeof(double) * need * fld, pde->ctx->stream));
     pde->hist_fields = need;
     for (int j = 0; j < need - 1; ++j) pde->d_hist[j] = pde->d_hist_alloc + pde->g.plane + (int64_t)j * fld;
