@@ -19,6 +19,6 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n=r['Name']
     if any(k in n for k in ('rr_kernel','stencil_kernel','cg_','x_flush')):
-        print(f"   {float(r['AverageNs'])/1e3:9.1f} us x{r['Calls']:>5}  {n[:60]}")
+        print("   avg %9.1f max %9.1f us x%5s  %s" % (float(r['AverageNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Calls'], n[:60]))
 PY
 done
