@@ -321,7 +321,8 @@ int beat_pde_small_grid_solve_active(const beat_pde* pde);
  * loop, which may differ from step to step in the last bit; the diffusion step uses the operator's dt,
  * beat_pde_set_timestep); host_stim_amp is (n_steps, n_stim): the amplitudes at host_t0[s] + theta_pde dt, which the caller knows in advance
  * (base_model.py:196-201 evaluates the stimulus expression at that time).  The initial guess of each solve follows
- * beat_pde_set_guess_order; the adaptive order keeps its current choice through a batch.  Returns BEAT_ENOTCONV if a
+ * beat_pde_set_guess_order; the adaptive order keeps its choice through a batch and is
+ * re-decided between batches from the batch's mean iteration count.  Returns BEAT_ENOTCONV if a
  * solve of the batch ran out of iterations (the later steps have run on its last iterate, as the reference's loop
  * would without ksp_error_if_not_converged).  At most BEAT_MAX_BATCH steps per call. */
 #define BEAT_MAX_BATCH 1024
