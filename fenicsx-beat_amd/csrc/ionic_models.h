@@ -326,6 +326,8 @@ struct NodeIOPending {
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
           if (j < npend) inc = fma(pa[j], pp[j], inc);
+        // (recorded here, where the increment is formed: doing it with the potential's own store near the end of the
+        // step keeps five more values alive through the step and measured no faster)
         beat_pde_detail::beat_guess_record(gt, gt.d + i, gt.e + i, inc, gd, gp0, gp1, ge);
         return x + inc;
       }
@@ -569,6 +571,14 @@ struct Tp06Grl1 {
     const double gKs = p[g_Ks] * (oXs * oXs);
     const double gto = p[g_to] * orr * os;
     const double gates_CaL = q.cCaL * od * of * of2 * ofCass;
+    // The concentrations are not needed before the gates are done, but their loads are issued HERE, ahead of the
+    // gates' stores: on gfx9 loads and stores retire through one in-order counter, so a load issued behind the twelve
+    // gate stores could only be waited for together with them (s_waitcnt vmcnt: ~2-4 k cycles for stores to reach HBM,
+    // once per tile and wave) -- 12 more VGPRs through the gate section, which the three-wave budget has.  512^3, same
+    // box, runs in pairs: 10.34-10.43 against 10.50-10.55 ms.  (Loading V after the gates, so that the two stores a
+    // pending update makes at V's load precede no other load, added nothing to that: 10.34-10.39.)
+    const double vCai = io.load(Ca_i), vCaSR = io.load(Ca_SR), vCass = io.load(Ca_ss), vNai = io.load(Na_i),
+                 vKi = io.load(K_i), vR = io.load(R_prime);
 
     // ---- shared exponentials of V ----------------------------------------------------------------------
     const double E20 = fm.exp(0.05 * v), E7 = fm.exp(v * (1.0 / 7.0));
@@ -663,8 +673,6 @@ struct Tp06Grl1 {
     }
     BEAT_FENCE();
 
-    const double vCai = io.load(Ca_i), vCaSR = io.load(Ca_SR), vCass = io.load(Ca_ss), vNai = io.load(Na_i),
-                 vKi = io.load(K_i), vR = io.load(R_prime);
     {  // fCass (.ode:261-264): depends on Ca_ss only
       const double c2 = 1.0 + (vCass * 20.0) * (vCass * 20.0);                // 1 + (Ca_ss/0.05)^2
       double rc2, rt;
