@@ -272,6 +272,12 @@ struct TorordDynClGrl1 {
     constexpr unsigned DV = 1u, D1 = 2u, D2 = 4u;
 
     const double v = io.load(S_v);
+    // Loads and stores retire through one in-order counter on gfx9: a load issued behind a store can only be waited for
+    // together with that store (thousands of cycles to reach HBM).  So (1) the eight concentrations several blocks
+    // read are loaded once, here, and (2) every block's gates are loaded before the previous block's stores are
+    // issued ("pf_" values below) -- no load of this step follows a store of this step.
+    const double nai = io.load(S_nai), ki = io.load(S_ki), cai = io.load(S_cai), cass = io.load(S_cass);
+    const double nass = io.load(S_nass), kss = io.load(S_kss), cli = io.load(S_cli), clss = io.load(S_clss);
     // The Goldman-Hodgkin-Katz fluxes are 0/0 at v = 0: everything that sees the potential through vF/RT is evaluated
     // at a potential kept 1e-4 mV away from it (beat_guard, derivative 1), as the generated kernel did
     const double vg = beat_guard(v);
@@ -288,7 +294,6 @@ struct TorordDynClGrl1 {
     // tangents each), and at this point nothing but the potential and the first running sums is live.
     // ---- INaK (.ode:418-444): directions 0 = v, 1 = nai, 2 = ki --------------------------------------------------------
     {
-      const double nai = io.load(S_nai), ki = io.load(S_ki);
       const Du<DV> Knai = dexp(fm, mk<DV>(p[delta_] * vfrt * (1.0 / 3.0), p[delta_] * q.FRT * (1.0 / 3.0))) * p[Knai0_];
       const Du<DV> Knao = dexp(fm, mk<DV>(vfrt * (1.0 - p[delta_]) * (1.0 / 3.0), (1.0 - p[delta_]) * q.FRT * (1.0 / 3.0))) * p[Knao0_];
       const Du<D1> Nai = mk<D1>(nai, 0.0, 1.0);
@@ -335,7 +340,6 @@ struct TorordDynClGrl1 {
 
     // ---- INaCa, myoplasm and subspace (.ode:446-525): directions 0 = v, 1 = Na, 2 = Ca --------------------------------
     {
-      const double nai = io.load(S_nai), cai = io.load(S_cai), nass = io.load(S_nass), cass = io.load(S_cass);
       const Du<DV> hca = dexp(fm, mk<DV>(p[qca_] * vfrt, p[qca_] * q.FRT));
       const Du<DV> hna = dexp(fm, mk<DV>(p[qna_] * vfrt, p[qna_] * q.FRT));
       // v-only part, shared by both compartments
@@ -405,8 +409,10 @@ struct TorordDynClGrl1 {
 
     // ---- CaMK (.ode:413-416): phosphorylated fraction fp = 1/(1 + KmCaMK/CaMKa), shared by INa, INaL, Ito, ICaL, Jup,
     //      Jrel (the specification writes it out six times) ---------------------------------------------------------
-    const double cass = io.load(S_cass);
     double fp, dfp_dcass;
+    double pf_m, pf_h, pf_hp, pf_j, pf_jp, pf_mL, pf_hL, pf_hLp, pf_a, pf_ap, pf_iF, pf_iFp, pf_iS, pf_iSp;
+    double pf_d, pf_ff, pf_fs, pf_fcaf, pf_fcas, pf_jca, pf_ffp, pf_fcafp, pf_nca_i, pf_nca_ss;
+    double pf_O, pf_C1, pf_C2, pf_C3, pf_I, pf_xs1, pf_xs2, pf_cajsr, pf_cansr, pf_Jrel_np, pf_Jrel_p;
     {
       const double CaMKt = io.load(S_CaMKt);
       const double rk = beat_rcp(cass + p[KmCaM_]);
@@ -420,12 +426,12 @@ struct TorordDynClGrl1 {
       dfp_dcass = p[KmCaMK_] * ra * ra * dCaMKb_dcass;
       const double f = -CaMKt * p[bCaMK_] + (CaMKb * p[aCaMK_]) * (CaMKb + CaMKt);
       const double J = -p[bCaMK_] + p[aCaMK_] * (dCaMKb_dCaMKt * (CaMKb + CaMKt) + CaMKb * (dCaMKb_dCaMKt + 1.0));
+      pf_m = io.load(S_m), pf_h = io.load(S_h), pf_hp = io.load(S_hp), pf_j = io.load(S_j), pf_jp = io.load(S_jp);
       io.store(S_CaMKt, advance(fm, CaMKt, f, J, dt));
     }
     BEAT_TFENCE();
 
     // ---- reversal potentials (.ode:527-532) ---------------------------------------------------------------------------
-    const double nai = io.load(S_nai), ki = io.load(S_ki);
     const double rnai = beat_rcp(nai), rki = beat_rcp(ki);
     const double ENa = q.RTFna * fm.log(p[nao_] * rnai);
     const double EK = q.RTFk * fm.log(p[ko_] * rki);
@@ -438,7 +444,7 @@ struct TorordDynClGrl1 {
     const double tm_rate = beat_rcp(0.06487 * fm.exp(-((v - 4.823) * (1.0 / 51.12)) * ((v - 4.823) * (1.0 / 51.12))) +
                                     0.1292 * fm.exp(-((v + 45.79) * (1.0 / 15.54)) * ((v + 45.79) * (1.0 / 15.54))));
     {
-      const double m = io.load(S_m), h = io.load(S_h), hp = io.load(S_hp), j = io.load(S_j), jp = io.load(S_jp);
+      const double m = pf_m, h = pf_h, hp = pf_hp, j = pf_j, jp = pf_jp;
       const double gNa = (m * m * m) * p[GNa_] * (j * (h * (1.0 - fp)) + jp * (fp * hp));
       const double INa = gNa * (v - ENa);
       Iv += INa;
@@ -464,6 +470,7 @@ struct TorordDynClGrl1 {
         rate_j = aj + bj;
       }
       BEAT_TFENCE();
+      pf_mL = io.load(S_mL), pf_hL = io.load(S_hL), pf_hLp = io.load(S_hLp);
       io.store(S_m, gate(fm, m, rm * rm, tm_rate, dt));
       io.store(S_h, gate(fm, h, rh * rh, rate_h, dt));
       io.store(S_hp, gate(fm, hp, rhp * rhp, rate_h, dt));
@@ -475,7 +482,7 @@ struct TorordDynClGrl1 {
 
     // ---- INaL (.ode:561-575) ------------------------------------------------------------------------------------------
     {
-      const double mL = io.load(S_mL), hL = io.load(S_hL), hLp = io.load(S_hLp);
+      const double mL = pf_mL, hL = pf_hL, hLp = pf_hLp;
       const double gNaL = mL * q.GNaL * (fp * hLp + hL * (1.0 - fp));
       const double INaL = gNaL * (v - ENa);
       Iv += INaL;
@@ -485,6 +492,8 @@ struct TorordDynClGrl1 {
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai);
       BEAT_TFENCE();
       const double ehL = fm.exp((v + 87.61) * (1.0 / 7.488));
+      pf_a = io.load(S_a), pf_ap = io.load(S_ap), pf_iF = io.load(S_iF), pf_iFp = io.load(S_iFp), pf_iS = io.load(S_iS),
+      pf_iSp = io.load(S_iSp);
       io.store(S_mL, gate(fm, mL, beat_rcp(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0), tm_rate, dt));
       io.store(S_hL, gate(fm, hL, beat_rcp(ehL + 1.0), beat_rcp(p[thL_]), dt));
       io.store(S_hLp, gate(fm, hLp, beat_rcp(ehL * 2.288717124596482 + 1.0), beat_rcp(3.0 * p[thL_]), dt));  // exp(6.2/7.488)
@@ -494,8 +503,7 @@ struct TorordDynClGrl1 {
     // ---- Ito (.ode:379-403) -------------------------------------------------------------------------------------------
     {
       const double ve = p[EKshift_] + v;
-      const double a = io.load(S_a), ap = io.load(S_ap), iF = io.load(S_iF), iFp = io.load(S_iFp), iS = io.load(S_iS),
-                   iSp = io.load(S_iSp);
+      const double a = pf_a, ap = pf_ap, iF = pf_iF, iFp = pf_iFp, iS = pf_iS, iSp = pf_iSp;
       const double AiF = beat_rcp(fm.exp((ve - 213.6) * (1.0 / 151.2)) + 1.0);
       const double dAiF = -AiF * (1.0 - AiF) * (1.0 / 151.2);
       const double i_ = AiF * iF + (1.0 - AiF) * iS, ip = AiF * iFp + (1.0 - AiF) * iSp;
@@ -529,6 +537,9 @@ struct TorordDynClGrl1 {
       BEAT_TFENCE();
       const double rdd = beat_rcp(dti_develop * dti_recover);
       const double rtiF = beat_rcp(tiF), rtiS = beat_rcp(tiS);
+      pf_d = io.load(S_d), pf_ff = io.load(S_ff_), pf_fs = io.load(S_fs), pf_fcaf = io.load(S_fcaf), pf_fcas = io.load(S_fcas);
+      pf_jca = io.load(S_jca), pf_ffp = io.load(S_ffp), pf_fcafp = io.load(S_fcafp), pf_nca_i = io.load(S_nca_i);
+      pf_nca_ss = io.load(S_nca_ss);
       io.store(S_a, gate(fm, a, ass, ta_rate, dt));
       io.store(S_ap, gate(fm, ap, assp, ta_rate, dt));
       BEAT_TFENCE();
@@ -542,12 +553,10 @@ struct TorordDynClGrl1 {
 
     // ---- ICaL gates and the common gate factors of ICaL / ICaNa / ICaK (.ode:312-377) ---------------------------------
     //   I_X_c = frac_c * scale_X * Gc * Phi_X_c,  Gc = d [ (1 - fp) (f (1 - nca) + nca fca jca) PCa + fp (fp_ (1 - nca) + nca fcap jca) PCap ]
-    const double cai = io.load(S_cai);
     double G_i, dG_i_dv, G_ss, dG_ss_dv, dG_ss_dfp;
     {
-      const double d = io.load(S_d), ff = io.load(S_ff_), fs = io.load(S_fs), fcaf = io.load(S_fcaf), fcas = io.load(S_fcas),
-                   jca = io.load(S_jca), ffp = io.load(S_ffp), fcafp = io.load(S_fcafp);
-      const double nca_i = io.load(S_nca_i), nca_ss = io.load(S_nca_ss);
+      const double d = pf_d, ff = pf_ff, fs = pf_fs, fcaf = pf_fcaf, fcas = pf_fcas, jca = pf_jca, ffp = pf_ffp, fcafp = pf_fcafp;
+      const double nca_i = pf_nca_i, nca_ss = pf_nca_ss;
       const double sA = beat_rcp(fm.exp((v - 10.0) * (1.0 / 10.0)) + 1.0);
       const double Afcaf = 0.3 + 0.6 * sA, dAfcaf = -0.06 * sA * (1.0 - sA);
       const double Afs = 1.0 - p[Aff_];
@@ -585,6 +594,7 @@ struct TorordDynClGrl1 {
       const double jcass = beat_rcp(fm.exp((v + 18.08) * (1.0 / 2.7916)) + 1.0);
       BEAT_TFENCE();
       const double rtff = beat_rcp(tff), rtfcaf = beat_rcp(tfcaf);
+      pf_O = io.load(S_O_), pf_C1 = io.load(S_C1), pf_C2 = io.load(S_C2), pf_C3 = io.load(S_C3), pf_I = io.load(S_I_);
       io.store(S_d, gate(fm, d, dss, beat_rcp(td), dt));
       io.store(S_ff_, gate(fm, ff, fss, rtff, dt));
       BEAT_TFENCE();
@@ -612,7 +622,6 @@ struct TorordDynClGrl1 {
     // ---- Goldman-Hodgkin-Katz fluxes of the L-type channel, background Ca and Na (.ode:326-347, 600-602, 610) ----------
     double ICaL_ss;  // needed again by the ryanodine receptor
     {
-      const double cli = io.load(S_cli), clss = io.load(S_clss), nass = io.load(S_nass), kss = io.load(S_kss);
       // dual directions: 0 = v, 1 = the ion the flux carries (cai / nai / ki, cass / nass / kss)
       const Du<DV> Ve1 = mk<DV>(e1, e1 * q.FRT), Ve2 = mk<DV>(e2, 2.0 * e2 * q.FRT);
       const Du<DV> Vff = mk<DV>(vffrt, q.FFRT);
@@ -725,7 +734,7 @@ struct TorordDynClGrl1 {
       const double dIKb_dv = q.GKb * (xkb * (1.0 - xkb) * (1.0 / 23.9871)) * uK + gKb;
       BEAT_TFENCE();
       // IKr
-      const double O_ = io.load(S_O_);
+      const double O_ = pf_O;
       const double gKr = O_ * q.GKrs;
       const double Iu = (gK1 + gKb + gKr + q.gKatp) * uK;  // IK1 + IKb + IKr + I_katp
       Iv += Iu;
@@ -734,7 +743,7 @@ struct TorordDynClGrl1 {
       dIki += (dIK1_du + gKb + gKr + q.gKatp) * (-dEK);
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
       {
-        const double C1 = io.load(S_C1), C2 = io.load(S_C2), C3 = io.load(S_C3), I_ = io.load(S_I_);
+        const double C1 = pf_C1, C2 = pf_C2, C3 = pf_C3, I_ = pf_I;
         const double alpha = 0.1161 * fm.exp(0.299 * vfrt), alpha_2 = 0.0578 * fm.exp(0.971 * vfrt);
         BEAT_TFENCE();
         const double alpha_C2ToI = 5.2e-5 * fm.exp(1.525 * vfrt), alpha_i = 0.2533 * fm.exp(0.5953 * vfrt);
@@ -744,6 +753,7 @@ struct TorordDynClGrl1 {
         BEAT_TFENCE();
         const double beta_ItoC2 = (alpha_C2ToI * (beta_2 * beta_i)) * beat_rcp(alpha_2 * alpha_i);
         const double a1_ = p[alpha_1_], b1_ = p[beta_1_];
+        pf_xs1 = io.load(S_xs1), pf_xs2 = io.load(S_xs2);
         io.store(S_C1, advance(fm, C1, -C1 * (alpha_C2ToI + (alpha_2 + b1_)) + (I_ * beta_ItoC2 + (C2 * a1_ + O_ * beta_2)),
                                -(alpha_C2ToI + (alpha_2 + b1_)), dt));
         BEAT_TFENCE();
@@ -757,7 +767,7 @@ struct TorordDynClGrl1 {
     BEAT_TFENCE();
     {
       // IKs: reversal potential with the Na permeability; KsCa depends on cai (no state's self-derivative sees that)
-      const double xs1 = io.load(S_xs1), xs2 = io.load(S_xs2);
+      const double xs1 = pf_xs1, xs2 = pf_xs2;
       const double rks = beat_rcp(p[PKNa_] * nai + ki);
       const double EKs = q.RTFk * fm.log((p[PKNa_] * p[nao_] + p[ko_]) * rks);
       const double KsCa = 1.0 + 0.6 * beat_rcp(fm.exp(1.4 * fm.log(3.8e-5 * beat_rcp(cai))) + 1.0);
@@ -772,6 +782,7 @@ struct TorordDynClGrl1 {
       const double xsss = beat_rcp(fm.exp(-(v + 11.6) * (1.0 / 8.932)) + 1.0);
       const double txs1 = 817.3 + beat_rcp(0.0002326 * fm.exp((v + 48.28) * (1.0 / 17.8)) + 0.001292 * fm.exp(-(v + 210.0) * (1.0 / 230.0)));
       const double rtxs2 = 0.01 * fm.exp((v - 50.0) * (1.0 / 20.0)) + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
+      pf_cajsr = io.load(S_cajsr), pf_cansr = io.load(S_cansr), pf_Jrel_np = io.load(S_Jrel_np), pf_Jrel_p = io.load(S_Jrel_p);
       io.store(S_xs1, gate(fm, xs1, xsss, beat_rcp(txs1), dt));
       io.store(S_xs2, gate(fm, xs2, xsss, rtxs2, dt));
     }
@@ -779,7 +790,6 @@ struct TorordDynClGrl1 {
 
     // ---- chloride currents and concentrations (.ode:604-608, 403-404) ---------------------------------------------------
     {
-      const double cli = io.load(S_cli), clss = io.load(S_clss);
       const double ECl = q.RTFcl * fm.log(p[clo_] * beat_rcp(cli)), EClss = q.RTFcl * fm.log(p[clo_] * beat_rcp(clss));
       const double g_junc = (p[Fjunc_] * p[GClCa_]) * cass * beat_rcp(cass + p[KdClCa_]);
       const double g_sl = (p[GClCa_] * (1.0 - p[Fjunc_])) * cai * beat_rcp(cai + p[KdClCa_]);
@@ -815,7 +825,6 @@ struct TorordDynClGrl1 {
 
     // ---- sodium and potassium (.ode:405-411) --------------------------------------------------------------------------
     {
-      const double nass = io.load(S_nass), kss = io.load(S_kss);
       const double rtNa = beat_rcp(p[tauNa_]), rtK = beat_rcp(p[tauK_]);
       const double JdiffNa = (nass - nai) * rtNa, JdiffK = (kss - ki) * rtK;
       io.store(S_nai, advance(fm, nai, -q.cAF_myo * Inai + JdiffNa * q.vss_vmyo, -q.cAF_myo * dInai - q.vss_vmyo * rtNa, dt));
@@ -828,8 +837,7 @@ struct TorordDynClGrl1 {
 
     // ---- calcium: SERCA, ryanodine receptor, translocation, buffers (.ode:398-402, 617-633) -----------------------------
     {
-      const double cajsr = io.load(S_cajsr), cansr = io.load(S_cansr);
-      const double Jrel_np = io.load(S_Jrel_np), Jrel_p = io.load(S_Jrel_p);
+      const double cajsr = pf_cajsr, cansr = pf_cansr, Jrel_np = pf_Jrel_np, Jrel_p = pf_Jrel_p;
       const double rtCa = beat_rcp(p[tauCa_]);
       const double Jdiff = (cass - cai) * rtCa;
       // SERCA
