@@ -240,7 +240,7 @@ def main():
                     "solve instead of inside the next ionic kernel")
     ap.add_argument("--guess-order", type=int, default=int(os.environ.get("BEAT_GUESS_ORDER", "-1")), choices=[-1, 0, 1, 2, 3, 4],
                     help="initial guess of each diffusion solve: 0 = the ionic step's potential, m = plus the degree-(m-1) "
-                    "extrapolation in time of the last m diffusion increments, -1 = quadratic or cubic chosen per solve by the "
+                    "extrapolation in time of the last m diffusion increments, -1 = order 1-4 chosen per solve by the "
                     "iteration counts seen (beat_pde_set_guess_order; -1 is the package default)")
     ap.add_argument("--no-front", action="store_true", help="skip the second, developed-front measurement")
     ap.add_argument("--direct", action="store_true", help="drive the kernels by bare C-ABI calls (beat_ode_step_pending + "
@@ -533,7 +533,7 @@ def main():
                             f"PCG rtol={args.rtol:g} (x0 = " + ("previous v", "previous v + last increment", "previous v + linear extrapolation of the last two increments",
                                                           "previous v + quadratic extrapolation of the last three increments",
                                                           "previous v + cubic extrapolation of the last four increments",
-                                                          "previous v + quadratic or cubic extrapolation of the last increments, chosen per solve")[args.guess_order] + "), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
+                                                          "previous v + extrapolation of the last increments, order 1-4 chosen per solve")[args.guess_order] + "), " + ("Jacobi" if args.pc_degree <= 1 else f"Chebyshev-Jacobi polynomial preconditioner, {args.pc_degree} terms"),
                 "nodes": n_total,
                 "states_per_node": S,
                 "driver": ("public API: beat.MonodomainSplittingSolver.step on MonodomainModel + DolfinODESolver" if use_api

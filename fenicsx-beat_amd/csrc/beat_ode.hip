@@ -394,25 +394,16 @@ extern "C" int beat_split_steps(beat_ctx* ctx, int model_id, double* dev_states,
   pde->last_iters = (int)h[(size_t)16 * (n_steps - 1) + beat_pde_detail::ITERS];
   if (pde->guess_order < 0 && n_steps >= 4) {
     // adaptive order, batch-wise: the whole batch ran with one order (its first solves on the guess the previous
-    // batch left); score it by the mean iteration count of the later steps, then use the cheaper order for the next
-    // batch -- the one not yet seen first, and the other one again every 8th batch
+    // batch left); score it by the mean iteration count of the later steps and let the policy move (beat_guess_policy:
+    // here one "solve" is one batch)
     double sum = 0.0;
     for (int s = 2; s < n_steps; ++s) sum += h[(size_t)16 * s + beat_pde_detail::ITERS];
-    const int k = pde->auto_next - 3;
+    const int k = pde->auto_next - 1;
     const double mean = sum / (n_steps - 2);
     pde->auto_score[k] = pde->auto_seen[k] ? 0.5 * pde->auto_score[k] + 0.5 * mean : mean;
     pde->auto_seen[k] = 1;
-    int best = pde->auto_next;
-    if (!pde->auto_seen[1 - k]) {
-      best = 3 + (1 - k);
-    } else {
-      best = pde->auto_score[1] < pde->auto_score[0] - 0.05 ? 4 : 3;
-      if (++pde->auto_since_probe >= 8) {
-        pde->auto_since_probe = 0;
-        best = best == 3 ? 4 : 3;
-      }
-    }
-    pde->auto_next = best;
+    pde->auto_since_probe += 5;  // (a batch stands for many solves: look at a neighbour every second or third batch)
+    pde->auto_next = beat_guess_policy(pde);
   }
   return worst;
 }

@@ -1010,9 +1010,9 @@ extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   pde->guess_order = order;
   pde->hist_n = 0;
   pde->guess = GuessTerms{};
-  pde->auto_next = 3;
+  pde->auto_cur = pde->auto_next = 3;
   pde->auto_e_order = 0;
-  pde->auto_seen[0] = pde->auto_seen[1] = 0;
+  for (int k = 0; k < 4; ++k) pde->auto_seen[k] = 0;
   pde->auto_since_probe = 0;
   if (order < 0) order = BEAT_GUESS_MAX_ORDER;  // adaptive: the fields the cubic needs
   // fields: the max(order - 1, 1) increments kept + the guess (1024^3: 8.6 GB each -- only what the order needs)
@@ -1116,26 +1116,43 @@ void beat_guess_advance(beat_pde* pde) {
 // costs more iterations, because what is left is the amplified noise of the recorded increments, rough, and Jacobi-PCG
 // takes longer over it than over the smooth truncation error of the quadratic) -- and picks the order of the guess
 // after next (the next one is being prepared by this solve's x update, whose coefficients were fixed when it began).
+// beat_guess_policy is the move itself (hill climbing over the orders 1..4, see beat_pde_internal.h).
+int beat_guess_policy(beat_pde* pde) {
+  constexpr int LO = 1, HI = BEAT_GUESS_MAX_ORDER;
+  int& cur = pde->auto_cur;
+  // a neighbour that has been looked at and costs fewer iterations takes over (ties stay)
+  for (int nb = cur - 1; nb <= cur + 1; nb += 2) {
+    if (nb < LO || nb > HI || !pde->auto_seen[nb - 1] || !pde->auto_seen[cur - 1]) continue;
+    if (pde->auto_score[nb - 1] < pde->auto_score[cur - 1] - 0.05) {
+      cur = nb;
+      pde->auto_since_probe = 0;  // look around from the new position soon
+      break;
+    }
+  }
+  int next = cur;
+  if (pde->auto_seen[cur - 1] && ++pde->auto_since_probe >= 12) {
+    pde->auto_since_probe = 0;
+    int nb = cur + (pde->auto_probe_up ? 1 : -1);
+    if (nb < LO || nb > HI) nb = cur - (pde->auto_probe_up ? 1 : -1);
+    pde->auto_probe_up = !pde->auto_probe_up;
+    if (nb >= LO && nb <= HI) next = nb;
+  }
+  return next;
+}
+
 void beat_guess_observe(beat_pde* pde, int iterations) {
   if (pde->guess_order >= 0) return;
   const int used = pde->auto_e_order;  // order behind the e this solve started from (0: none yet, or fewer increments)
-  if (used >= 3) {
-    const int k = used - 3;
+  if (used >= 1) {
+    const int k = used - 1;
     pde->auto_score[k] = pde->auto_seen[k] ? 0.5 * pde->auto_score[k] + 0.5 * iterations : (double)iterations;
     pde->auto_seen[k] = 1;
   }
   // the e the x update of THIS solve prepares has order min(auto_next, increments on record): remember it for the
   // next observation, then choose for the one after
   const int prepared = std::min(pde->auto_next, pde->hist_n + 1);
-  pde->auto_e_order = prepared >= 3 && prepared == pde->auto_next ? prepared : 0;
-  int best = 3;
-  if (pde->auto_seen[0] && pde->auto_seen[1]) best = pde->auto_score[1] < pde->auto_score[0] - 0.05 ? 4 : 3;
-  else if (pde->auto_seen[0]) best = 4;  // the cubic has not been looked at yet
-  if (pde->auto_seen[0] && pde->auto_seen[1] && ++pde->auto_since_probe >= 16) {
-    pde->auto_since_probe = 0;
-    best = best == 3 ? 4 : 3;  // one solve with the other order keeps its score current
-  }
-  pde->auto_next = best;
+  pde->auto_e_order = prepared == pde->auto_next ? prepared : 0;
+  pde->auto_next = beat_guess_policy(pde);
 }
 
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {

@@ -51,16 +51,19 @@ struct beat_pde {
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
   // initial guess from the previous solves' increments (0: x0 = v_; m: + the degree-(m-1) extrapolation of the last m), see GuessTerms
   int guess_order = 0;                     // as configured: 0..4, or -1 = choose between 3 and 4 per solve (below)
-  // adaptive choice (guess_order = -1).  The cubic extrapolation wins where the increments change fast (a travelling
-  // front), the quadratic where they are smooth and the rtol-sized noise of the recorded increments, amplified by the
-  // sum of |coefficients| (7 vs 15), sets the initial residual: keep a running mean of the iteration count per
-  // order, use the better one, look at the other one every 16th solve.  Iteration counts are global: every rank of a
-  // decomposed solve takes the same decisions.
-  int auto_next = 3;                       // order of the guess the NEXT x update prepares
+  // adaptive choice (guess_order = -1).  No order is right everywhere: each recorded increment carries an rtol-sized
+  // error, which an extrapolation of order m amplifies by the sum of its |coefficients| (1, 3, 7, 15) -- where the
+  // increments are smooth in time (plateau, repolarisation, rest) that noise sets the initial residual and the lowest
+  // order wins (0.3 iterations per step against 1.6), on a travelling front the truncation error does and the cubic
+  // wins (3.6 against 8).  Hill climbing on the order: a running mean of the iteration count per order, the current
+  // order used, one of its neighbours tried every 12th solve (up and down in turn), the move made when the neighbour
+  // has been costing fewer iterations.  Iteration counts are global: every rank of a decomposed solve decides alike.
+  int auto_cur = 3;                        // order the policy currently favours
+  int auto_next = 3;                       // order of the guess the NEXT x update prepares (auto_cur or a probe)
   int auto_e_order = 0;                    // order the guess now in e was built with (0: none / not adaptive)
-  double auto_score[2] = {0.0, 0.0};       // running mean of the iterations per solve for orders 3, 4
-  int auto_seen[2] = {0, 0};
-  int auto_since_probe = 0;
+  double auto_score[4] = {0.0, 0.0, 0.0, 0.0};  // running mean of the iterations per solve for orders 1..4
+  int auto_seen[4] = {0, 0, 0, 0};
+  int auto_since_probe = 0, auto_probe_up = 1;
   double* d_hist[3] = {nullptr, nullptr, nullptr};  // fields with ghost planes: the last increments, newest first
   double* d_guess = nullptr;               // the guess increment e prepared for the next solve
   double* d_hist_alloc = nullptr;
@@ -127,7 +130,8 @@ int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, c
                            int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);
 
 void beat_guess_advance(beat_pde* pde);
-void beat_guess_observe(beat_pde* pde, int iterations);  // of the solve that just ended (adaptive order)  // this solve's increment has been recorded: it is the most recent one now
+void beat_guess_observe(beat_pde* pde, int iterations);  // of the solve that just ended (adaptive order)
+int beat_guess_policy(beat_pde* pde);                     // hill-climbing move; returns the order to prepare next  // this solve's increment has been recorded: it is the most recent one now
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

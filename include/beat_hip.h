@@ -289,9 +289,10 @@ int beat_pde_work_fields(beat_pde* pde);
  * p_j), which also records the new increment and prepares the next e in place.  Consequences for callers that
  * defer (defer_flush != 0): the update may be due even when host_pending[1] == 0 -- ask beat_pde_guess_pending --
  * and it must be applied through this operator (beat_ode_step_pending with `pde`, or beat_pde_x_flush), which clears
- * the flag.  order = -1 chooses between m = 3 and m = 4 per solve: it keeps a running mean of the iteration counts
- * each of the two has been costing, uses the cheaper one and tries the other every 16th solve (the cubic wins on a
- * travelling front, the quadratic where the increments are smooth; iteration counts are global, so all ranks of a
+ * the flag.  order = -1 chooses m per solve by hill climbing over 1..4: it keeps a running mean of the iteration
+ * counts each order has been costing, uses the current one, tries one of its neighbours every 12th solve and moves
+ * when the neighbour is cheaper (the cubic wins on a travelling front, m = 1 once the increments are smooth and the
+ * rtol-sized noise they carry is all an extrapolation amplifies; iteration counts are global, so all ranks of a
  * decomposed solve decide alike).  beat_pde_set_timestep and beat_pde_guess_reset drop the history (call the latter when the potential is
  * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: max(m - 1, 1) + 1 more fields,
  * allocated when the order is set.  Default order: 0 (the Python layer's BaseModel asks for -1). */
