@@ -979,3 +979,45 @@ def test_batched_solve_equals_the_step_loop(order):
         np.testing.assert_array_equal(a.ode.values, b.ode.values)
     # with a monitor attached the caller wants per-step records: no batching
     assert not build(beat.telemetry.PerformanceMonitor())._can_batch(None)
+
+
+def test_split_steps_entry_refuses_what_it_does_not_cover(hip_ctx):
+    """beat_split_steps is for grids the one-launch solve takes: a larger grid, an operator switched to the multi-launch
+    kernels or more steps than BEAT_MAX_BATCH are refused with an error text (and MonodomainSplittingSolver.solve
+    falls back to its step loop for them: _can_batch)."""
+    import ctypes as C
+
+    from beat import _hip, _stencil
+    from beat._device import StateArray
+    from beat._engine import HipOps
+    from beat.models import tp06
+
+    lib = hip_ctx.lib
+    ic = tp06.init_state_values()
+    p = np.ascontiguousarray(tp06.init_parameter_values(stim_amplitude=0.0))
+    vi = tp06.state_index("V")
+
+    def call(nn, nsteps, small=True):
+        n = int(np.prod(nn))
+        ops = HipOps(hip_ctx, nn, True, True, *_stencil.stencil_tables(3, (0.1,) * 3, 1e-3))
+        ops.set_small(small)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        states = StateArray(hip_ctx, len(ic), n, nn[0] * nn[1])
+        states.set(np.repeat(ic[:, None], n, axis=1))
+        t0 = np.arange(nsteps, dtype=np.float64) * 0.05
+        dts = np.full(nsteps, 0.05)
+        infos = (_hip.KspInfo * max(1, nsteps))()
+        rc = lib.beat_split_steps(hip_ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n, states.ld, p.ctypes.data_as(C.c_void_p), len(p),
+                                  vi, ops.handle, nsteps, t0.ctypes.data_as(C.c_void_p), dts.ctypes.data_as(C.c_void_p), None, None, 0,
+                                  1e-10, 1e-50, 100, None, None, 0, None, infos)
+        return rc, lib.beat_last_error().decode(), infos, states
+
+    rc, _, infos, states = call((12, 10, 8), 5)
+    assert rc == 0 and all(infos[k].converged_reason > 0 for k in range(5))
+    assert np.isfinite(states.numpy()).all()
+    rc, msg, _, _ = call((40, 40, 40), 2)
+    assert rc != 0 and "one-launch" in msg
+    rc, msg, _, _ = call((12, 10, 8), 2, small=False)
+    assert rc != 0 and "one-launch" in msg
+    rc, msg, _, _ = call((12, 10, 8), _hip.MAX_BATCH + 1)
+    assert rc != 0 and "steps per call" in msg
