@@ -6,6 +6,7 @@ tensor, BASELINE.json configs[3]) -- where no CPU oracle finishes in seconds:
   * a theta-step solved by the PCG satisfies its own stopping test when the residual is recomputed from scratch
     with the operator kernels (b - A x from beat_pde_apply, not the recurrence);
   * deferring the last update of the potential to the ionic kernel changes nothing;
+  * with the extrapolated initial guess every solve still meets that stopping test, in fewer iterations;
   * one TP06 step keeps every gate in [0, 1] and leaves a resting cell at rest.
 """
 
@@ -98,6 +99,51 @@ def test_pcg_meets_its_stopping_test_at_full_size_and_deferral_is_exact(hip_ctx)
     assert not torch.equal(x1.data, x2.data)
     ops.flush_pending()
     assert torch.equal(x1.data, x2.data)
+
+
+@pytest.mark.parametrize("order", [2, "auto"])
+def test_extrapolated_guess_keeps_the_stopping_test_at_full_size(hip_ctx, order):
+    """A depolarised blob that moves 0.02 mm per solve on the 512^3 grid, solved with the extrapolated initial guess
+    (beat_pde_set_guess_order): every solve -- the ones the guess shortens and the ones it already satisfies -- ends at
+    ||b - A x|| <= rtol ||b|| with the residual recomputed from scratch by the operator kernels, whether the last update
+    (which carries the guess) was applied by the solver or deferred and flushed, and the iteration count falls against
+    the x0 = v_ iteration of the same right-hand sides."""
+    import torch
+
+    ctx = hip_ctx
+    n = N**3
+    idx = torch.arange(n, device=ctx.device, dtype=torch.float64)
+    xs, ys, zs = idx % N, torch.div(idx, N, rounding_mode="floor") % N, torch.div(idx, N * N, rounding_mode="floor")
+    del idx
+
+    def blob(step):
+        cx = 200.0 + 0.2 * step
+        return -85.0 + 100.0 * torch.exp(-(((xs - cx) ** 2 + (ys - 256.0) ** 2 + (zs - 300.0) ** 2) * H * H) / 0.5)
+
+    rtol = 1e-8
+    its = {}
+    for o in (0, order):
+        ops = _ops(ctx)
+        ops.set_guess_order(o)
+        ops.set_timestep(0.01, 0.5, 0.01)
+        v, x, b, ax = (ops.new_field() for _ in range(4))
+        its[o] = []
+        for step in range(8):
+            v.data.copy_(blob(step))
+            res = ops.solve_single(v, [], [], x, rtol, 1e-50, 200, defer_flush=(step % 2 == 1))
+            assert res.converged_reason > 0
+            if step % 2 == 1:
+                ops.flush_pending()
+            ops.apply(1, v, b)
+            ops.apply(0, x, ax)
+            rnorm = float(torch.linalg.vector_norm(b.data - ax.data))
+            bnorm = float(torch.linalg.vector_norm(b.data))
+            assert np.isclose(bnorm, res.rhs_norm, rtol=1e-12)
+            assert rnorm <= 1.05 * rtol * bnorm, (o, step, rnorm / bnorm)
+            its[o].append(res.iterations)
+        del ops, v, x, b, ax
+        torch.cuda.empty_cache()
+    assert sum(its[order][3:]) < sum(its[0][3:]), its
 
 
 def test_tp06_step_invariants_at_full_size(hip_ctx):
