@@ -19,6 +19,7 @@ MODEL_FHN_DEMO = 1
 MODEL_FHN_README = 2
 MODEL_TP06_GRL1 = 3
 MODEL_TORORD_DYNCL_GRL1 = 4
+MODEL_TORORD_LAND_GRL1 = 5
 MAX_STIM = 8
 
 # slots of the PCG scalar state (see include/beat_hip.h)

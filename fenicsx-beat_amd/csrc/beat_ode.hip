@@ -228,6 +228,7 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
     case BEAT_MODEL_FHN_README: BEAT_RUN(FhnReadme);
     case BEAT_MODEL_TP06_GRL1: BEAT_RUN(Tp06Grl1);
     case BEAT_MODEL_TORORD_DYNCL_GRL1: BEAT_RUN(TorordDynClGrl1);
+    case BEAT_MODEL_TORORD_LAND_GRL1: BEAT_RUN(TorordLandGrl1);
     default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
 #undef BEAT_RUN
@@ -281,6 +282,7 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
     case BEAT_MODEL_FHN_README: ns = FhnReadme::NS; np = FhnReadme::NP; break;
     case BEAT_MODEL_TP06_GRL1: ns = Tp06Grl1::NS; np = Tp06Grl1::NP; break;
     case BEAT_MODEL_TORORD_DYNCL_GRL1: ns = TorordDynClGrl1::NS; np = TorordDynClGrl1::NP; break;
+    case BEAT_MODEL_TORORD_LAND_GRL1: ns = TorordLandGrl1::NS; np = TorordLandGrl1::NP; break;
     default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
   if (num_states) *num_states = ns;
@@ -306,6 +308,7 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
     case BEAT_MODEL_FHN_README: BEAT_STEP(FhnReadme);
     case BEAT_MODEL_TP06_GRL1: BEAT_STEP(Tp06Grl1);
     case BEAT_MODEL_TORORD_DYNCL_GRL1: BEAT_STEP(TorordDynClGrl1);
+    case BEAT_MODEL_TORORD_LAND_GRL1: BEAT_STEP(TorordLandGrl1);
     default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
   }
 #undef BEAT_STEP

@@ -154,8 +154,13 @@ BEAT_DV Du<A> cube(const Du<A>& a) {
 
 }  // namespace torord_detail
 
-struct TorordDynClGrl1 {
-  static constexpr int NS = 45, NP = 112, V_INDEX = 42;  // V_INDEX: membrane potential
+// LAND = true: the same cell with the Land contraction model (odes/torord/ToRORd_dynCl_endo_Land.ode): 7 more states
+// (cross-bridges XS / XW, troponin-bound calcium CaTrpn, blocked tropomyosin TmB, distortions Zetas / Zetaw, dashpot Cd),
+// 28 more parameters, troponin buffering as a flux of the calcium equation instead of a term of Bcai; in that file cai
+// is declared with the mechanics states, so its row is 44 and the rows of cajsr .. xs2 are one lower (slot()).
+template <bool LAND>
+struct TorordGrl1T {
+  static constexpr int NS = LAND ? 52 : 45, NP = LAND ? 140 : 112, V_INDEX = LAND ? 41 : 42;  // V_INDEX: membrane potential
   // ode_run_kernel keeps the states of hand-written models in registers across steps (the generated kernel of round 1
   // spilled so heavily that this miscompiled and had to go through memory)
   static constexpr bool REGISTER_LOOP = true;
@@ -163,7 +168,16 @@ struct TorordDynClGrl1 {
   enum S {
     S_C1, S_C2, S_C3, S_I_, S_O_, S_CaMKt, S_Jrel_np, S_Jrel_p, S_a, S_ap, S_iF, S_iFp, S_iS, S_iSp, S_cai,
     S_cajsr, S_cansr, S_cass, S_cli, S_clss, S_ki, S_kss, S_nai, S_nass, S_d, S_fcaf, S_fcafp, S_fcas, S_ff_,
-    S_ffp, S_fs, S_jca, S_nca_i, S_nca_ss, S_h, S_hp, S_j, S_jp, S_m, S_hL, S_hLp, S_mL, S_v, S_xs1, S_xs2
+    S_ffp, S_fs, S_jca, S_nca_i, S_nca_ss, S_h, S_hp, S_j, S_jp, S_m, S_hL, S_hLp, S_mL, S_v, S_xs1, S_xs2,
+    S_XS, S_XW, S_CaTrpn, S_TmB, S_Zetas, S_Zetaw, S_Cd  // LAND only
+  };
+  // row of a state in the (NS, N) array
+  BEAT_HD static constexpr int slot(int s) { return !LAND ? s : (s == S_cai ? 44 : (s > S_cai && s < 45) ? s - 1 : s); }
+  template <class IO>
+  struct Rows {
+    const IO& io;
+    BEAT_DV double load(int s) const { return io.load(slot(s)); }
+    BEAT_DV void store(int s, double x) const { io.store(slot(s), x); }
   };
   enum P {
     A_atp_, K_atp_, K_o_n_, fkatp_, gkatp_, Aff_, ICaL_fractionSS_, Kmn_, PCa_b_, dielConstant_, k2n_,
@@ -174,7 +188,10 @@ struct TorordDynClGrl1 {
     qna_, wca_, wna_, wnaca_, GpCa_, KmCap_, H_, Khp_, Kki_, Kko_, Kmgatp_, Knai0_, Knao0_, Knap_, Kxkur_,
     MgADP_, MgATP_, Pnak_b_, delta_, eP_, k1m_, k1p_, k2m_, k2p_, k3m_, k3p_, k4m_, k4p_, Jrel_b_, bt_,
     cajsr_half_, Jup_b_, L_, rad__, PCab_, PKNa_, PNab_, cao_, clo_, ko_, nao_, celltype_, i_Stim_Amplitude_,
-    i_Stim_End_, i_Stim_Period_, i_Stim_PulseDuration_, i_Stim_Start_, tauCa_, tauCl_, tauK_, tauNa_
+    i_Stim_End_, i_Stim_Period_, i_Stim_PulseDuration_, i_Stim_Start_, tauCa_, tauCl_, tauK_, tauNa_,
+    // LAND only (.ode:648-679)
+    emcoupling_, lmbda_, dLambda_, mode_, isacs_, calib_, ktrpn_, ntrpn_, Trpn50_, rw_, rs_, gammas_, gammaw_, phi_,
+    Tot_A_, Beta0_, Beta1_, cat50_ref_, Tref_, kuw_, kws_, ku_, ntm_, p_a_, p_b_, p_k_, etal_, etas_
   };
 
   // parameter-only sub-expressions (celltype switches resolved: .ode PCa, Gto, Pnak, Gncx, GK1, GKb, GKr, GKs, GNaL,
@@ -188,6 +205,7 @@ struct TorordDynClGrl1 {
     double nk_a2, nk_a4, nk_b1, nk_cb3, nk_koK2, nk_1koK2, nk_Pden0;  // INaK
     double nc_k1, nc_h11, nc_cao;              // INaCa
     double a_rel, a_relp, btp;
+    double ksu, kwu_kws_kuw, Aw_dL, cw, cs, ca_scale, kb, Cdash;  // LAND
   };
   BEAT_HD static Derived derive(const double* p) {
     Derived q;
@@ -249,6 +267,19 @@ struct TorordDynClGrl1 {
     q.a_rel = 0.5 * p[bt_];
     q.btp = 1.25 * p[bt_];
     q.a_relp = 0.5 * q.btp;
+    if constexpr (LAND) {  // .ode:682-717, parameter-only
+      const double lam12 = p[lmbda_] < 1.2 ? p[lmbda_] : 1.2;
+      const double rw = p[rw_], rs = p[rs_];
+      q.ksu = p[kws_] * rw * (1.0 / rs - 1.0);
+      const double kwu = p[kuw_] * (1.0 / rw - 1.0) - p[kws_];
+      q.kwu_kws_kuw = kwu + p[kws_] + p[kuw_];
+      q.Aw_dL = (p[Tot_A_] * rs / ((1.0 - rs) * rw + rs)) * p[dLambda_];
+      q.cw = p[phi_] * p[kuw_] * ((1.0 - rs) * (1.0 - rw)) / ((1.0 - rs) * rw);
+      q.cs = p[phi_] * p[kws_] * ((1.0 - rs) * rw) / rs;
+      q.ca_scale = 1000.0 / (p[cat50_ref_] + p[Beta1_] * (lam12 - 1.0));
+      q.kb = p[ku_] * pow(p[Trpn50_], p[ntm_]) / (1.0 - rs - (1.0 - rs) * rw);
+      q.Cdash = lam12 - 1.0;
+    }
     return q;
   }
 
@@ -266,8 +297,9 @@ struct TorordDynClGrl1 {
   }
 
   template <class IO, class FM>
-  BEAT_DV static void step(const IO& io, const double* p, const Derived& q, const FM& fm, double t, double dt) {
+  BEAT_DV static void step(const IO& io_, const double* p, const Derived& q, const FM& fm, double t, double dt) {
     using namespace torord_detail;
+    const Rows<IO> io{io_};
     // directions of the dual numbers, per block: 0 = v always; 1, 2 = the block's ion concentrations
     constexpr unsigned DV = 1u, D1 = 2u, D2 = 4u;
 
@@ -352,7 +384,7 @@ struct TorordDynClGrl1 {
       const Du<DV> k8 = (p[wna_] * q.nc_h11) * h8;
       const Du<DV> rhca = inv(hca);
       const double k1 = q.nc_k1, k2 = p[kcaoff_], k5 = p[kcaoff_];
-#define BEAT_NCX(NA, CA, GN, IV, DIV, INA, DINA, ICA, DICA)                                                          \
+#define BEAT_NCX(NA, CA, GN, IV, DIV, INA, DINA, ICA, DICA, CAF)                                                        \
   {                                                                                                                  \
     const Du<D1> Na = mk<D1>(NA, 0.0, 1.0);                                                                          \
     const Du<D2> Ca = mk<D2>(CA, 0.0, 0.0, 1.0);                                                                     \
@@ -396,13 +428,14 @@ struct TorordDynClGrl1 {
     DIV += I.d[0];                                                                                                   \
     INA += 3.0 * I.v;                                                                                                \
     DINA += 3.0 * I.d[1];                                                                                            \
-    ICA += -2.0 * I.v;                                                                                               \
-    DICA += -2.0 * I.d[2];                                                                                           \
+    ICA += (CAF) * I.v;                                                                                              \
+    DICA += (CAF) * I.d[2];                                                                                          \
     BEAT_PIN(IV); BEAT_PIN(DIV); BEAT_PIN(INA); BEAT_PIN(DINA); BEAT_PIN(ICA); BEAT_PIN(DICA);                       \
   }
-      BEAT_NCX(nai, cai, q.Gncx_i, Iv, dIv, Inai, dInai, Icai, dIcai)
+      // (the Land file's calcium equation has INaCa_i / 3)
+      BEAT_NCX(nai, cai, q.Gncx_i, Iv, dIv, Inai, dInai, Icai, dIcai, (LAND ? -2.0 / 3.0 : -2.0))
       BEAT_TFENCE();
-      BEAT_NCX(nass, cass, q.Gncx_ss, Iv, dIv, Inass, dInass, Icass, dIcass)
+      BEAT_NCX(nass, cass, q.Gncx_ss, Iv, dIv, Inass, dInass, Icass, dIcass, -2.0)
 #undef BEAT_NCX
     }
     BEAT_TFENCE();
@@ -413,6 +446,7 @@ struct TorordDynClGrl1 {
     double pf_m, pf_h, pf_hp, pf_j, pf_jp, pf_mL, pf_hL, pf_hLp, pf_a, pf_ap, pf_iF, pf_iFp, pf_iS, pf_iSp;
     double pf_d, pf_ff, pf_fs, pf_fcaf, pf_fcas, pf_jca, pf_ffp, pf_fcafp, pf_nca_i, pf_nca_ss;
     double pf_O, pf_C1, pf_C2, pf_C3, pf_I, pf_xs1, pf_xs2, pf_cajsr, pf_cansr, pf_Jrel_np, pf_Jrel_p;
+    double pf_XS = 0.0, pf_XW = 0.0, pf_CaTrpn = 0.0, pf_TmB = 0.0, pf_Zetas = 0.0, pf_Zetaw = 0.0, pf_Cd = 0.0;
     {
       const double CaMKt = io.load(S_CaMKt);
       const double rk = beat_rcp(cass + p[KmCaM_]);
@@ -644,8 +678,13 @@ struct TorordDynClGrl1 {
           const Du<DV | D1> ICab = p[PCab_] * Phi;
           Iv += ICaL_i.v + ICab.v;
           dIv += ICaL_i.d[0] + ICab.d[0];
-          Icai += ICaL_i.v + ICab.v;
-          dIcai += ICaL_i.d[1] + ICab.d[1];
+          if constexpr (LAND) {  // the Land file's calcium equation has no ICaL_i term
+            Icai += ICab.v;
+            dIcai += ICab.d[1];
+          } else {
+            Icai += ICaL_i.v + ICab.v;
+            dIcai += ICaL_i.d[1] + ICab.d[1];
+          }
           BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Icai); BEAT_PIN(dIcai);
         }
         {  // Na: d I / d nai = 0.5/1000
@@ -783,6 +822,10 @@ struct TorordDynClGrl1 {
       const double txs1 = 817.3 + beat_rcp(0.0002326 * fm.exp((v + 48.28) * (1.0 / 17.8)) + 0.001292 * fm.exp(-(v + 210.0) * (1.0 / 230.0)));
       const double rtxs2 = 0.01 * fm.exp((v - 50.0) * (1.0 / 20.0)) + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
       pf_cajsr = io.load(S_cajsr), pf_cansr = io.load(S_cansr), pf_Jrel_np = io.load(S_Jrel_np), pf_Jrel_p = io.load(S_Jrel_p);
+      if constexpr (LAND) {
+        pf_XS = io.load(S_XS), pf_XW = io.load(S_XW), pf_CaTrpn = io.load(S_CaTrpn), pf_TmB = io.load(S_TmB);
+        pf_Zetas = io.load(S_Zetas), pf_Zetaw = io.load(S_Zetaw), pf_Cd = io.load(S_Cd);
+      }
       io.store(S_xs1, gate(fm, xs1, xsss, beat_rcp(txs1), dt));
       io.store(S_xs2, gate(fm, xs2, xsss, rtxs2, dt));
     }
@@ -863,7 +906,46 @@ struct TorordDynClGrl1 {
         io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, beat_rcp(tau_relp), dt));
       }
       BEAT_TFENCE();
-      {  // cai: d/dt = Bcai * inner
+      if constexpr (LAND) {
+        // ---- Land contraction model (ToRORd_dynCl_endo_Land.ode:682-722) ------------------------------------------------
+        const double XS = pf_XS, XW = pf_XW, CaTrpn = pf_CaTrpn, TmB = pf_TmB, Zetas = pf_Zetas, Zetaw = pf_Zetaw, Cd = pf_Cd;
+        // troponin: d CaTrpn/dt = ktrpn ((1000 cai / cat50)^ntrpn (1 - CaTrpn) - CaTrpn)
+        const double pw = fm.exp(p[ntrpn_] * fm.log(cai * q.ca_scale));
+        const double fTrpn = p[ktrpn_] * (pw * (1.0 - CaTrpn) - CaTrpn);
+        io.store(S_CaTrpn, advance(fm, CaTrpn, fTrpn, -p[ktrpn_] * (pw + 1.0), dt));
+        {  // cai: calmodulin buffering in Bcai, troponin as the flux J_TRPN = trpnmax dCaTrpn/dt
+          const double rm = beat_rcp(cai + p[kmcmdn_]);
+          const double bm = q.cmdnmax * p[kmcmdn_] * rm * rm;
+          const double B = beat_rcp(1.0 + bm);
+          const double dB = B * B * (2.0 * bm * rm);
+          const double inner = ((-q.cA2F_myo * Icai - Jup * q.vnsr_vmyo) + Jdiff * q.vss_vmyo) - p[trpnmax_] * fTrpn;
+          const double dinner = ((-q.cA2F_myo * dIcai - dJup_dcai * q.vnsr_vmyo) - q.vss_vmyo * rtCa) -
+                                p[trpnmax_] * p[ktrpn_] * (1.0 - CaTrpn) * p[ntrpn_] * pw * beat_rcp(cai);
+          io.store(S_cai, advance(fm, cai, B * inner, dB * inner + B * dinner, dt));
+        }
+        BEAT_TFENCE();
+        const double XU = ((1.0 - TmB) - XS) - XW;
+        {  // tropomyosin: kb min(CaTrpn^(-ntm/2), 100) XU - ku CaTrpn^(ntm/2) TmB
+          const double chalf = fm.exp((0.5 * p[ntm_]) * fm.log(CaTrpn));
+          const double cinv = beat_rcp(chalf);
+          const double cm = cinv < 100.0 ? cinv : 100.0;
+          io.store(S_TmB, advance(fm, TmB, q.kb * cm * XU - p[ku_] * chalf * TmB, -q.kb * cm - p[ku_] * chalf, dt));
+        }
+        {  // cross-bridges; the distortion-dependent unbinding rates use relations as numbers (.ode:689-690)
+          const double zp = Zetas > 0.0 ? Zetas : 0.0, zn = Zetas < -1.0 ? -Zetas - 1.0 : 0.0;
+          const double gsu = p[gammas_] * (zp > zn ? zp : zn), gwu = p[gammaw_] * fabs(Zetaw);
+          io.store(S_XS, advance(fm, XS, (p[kws_] * XW - q.ksu * XS) - gsu * XS, -q.ksu - gsu, dt));
+          // kuw XU - (kwu + kws + gwu) XW; the self-derivative also sees XU = 1 - TmB - XS - XW
+          io.store(S_XW, advance(fm, XW, p[kuw_] * XU - ((q.kwu_kws_kuw - p[kuw_]) + gwu) * XW, -q.kwu_kws_kuw - gwu, dt));
+        }
+        io.store(S_Zetas, advance(fm, Zetas, q.Aw_dL - q.cs * Zetas, -q.cs, dt));
+        io.store(S_Zetaw, advance(fm, Zetaw, q.Aw_dL - q.cw * Zetaw, -q.cw, dt));
+        {  // dashpot: p_k (C - Cd) / eta, eta by the sign of C - Cd
+          const double dCd = q.Cdash - Cd;
+          const double re = p[p_k_] * beat_rcp(dCd < 0.0 ? p[etas_] : p[etal_]);
+          io.store(S_Cd, advance(fm, Cd, re * dCd, -re, dt));
+        }
+      } else {  // cai: d/dt = Bcai * inner
         const double rt = beat_rcp(cai + p[kmtrpn_]), rm = beat_rcp(cai + p[kmcmdn_]);
         const double bt_ = p[kmtrpn_] * p[trpnmax_] * rt * rt, bm = q.cmdnmax * p[kmcmdn_] * rm * rm;
         const double B = beat_rcp(bt_ + (bm + 1.0));
@@ -898,3 +980,6 @@ struct TorordDynClGrl1 {
     }
   }
 };
+using TorordDynClGrl1 = TorordGrl1T<false>;
+using TorordLandGrl1 = TorordGrl1T<true>;
+

@@ -47,6 +47,7 @@ extern "C" {
 #define BEAT_MODEL_TP06_GRL1 3  /* odes/tentusscher_panfilov_2006 (.ode) + gotranx GRL1 (demos/niederer_benchmark.py:82-99) */
 
 #define BEAT_MODEL_TORORD_DYNCL_GRL1 4 /* odes/torord/ToRORd_dynCl_endo.ode + gotranx GRL1 (demos/biv_endocardial.py:124); 45 states, 112 parameters */
+#define BEAT_MODEL_TORORD_LAND_GRL1 5  /* odes/torord/ToRORd_dynCl_endo_Land.ode (the same cell + Land contraction model) + GRL1; 52 states, 140 parameters */
 
 #define BEAT_STENCIL_POINTS 15
 #define BEAT_NODE_TYPES 27

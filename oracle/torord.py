@@ -223,6 +223,12 @@ def _sqrt(x):
     return np.sqrt(x)
 
 
+def _abs(x):
+    if isinstance(x, Dual):
+        return Dual(np.abs(x.a), np.sign(x.a) * x.b)
+    return np.abs(x)
+
+
 def _where(c, a, b):
     if isinstance(a, Dual) or isinstance(b, Dual):
         aa, ab = Dual._split(a)
@@ -234,9 +240,11 @@ def _where(c, a, b):
 # ------------------------------------------------------------------------------------------------
 # right-hand side (.ode:303-633), written once for floats / arrays / Dual numbers
 # ------------------------------------------------------------------------------------------------
-def torord_rhs(states, t, parameters):
+def torord_rhs(states, t, parameters, land=None):
     """dy/dt of the 45 states in TORORD_STATES order.  ``states``: sequence of 45 arrays or Dual numbers;
-    ``parameters``: sequence of 112 floats or arrays (per-node parameters broadcast against the states)."""
+    ``parameters``: sequence of 112 floats or arrays (per-node parameters broadcast against the states).
+    ``land``: None, or the 7 extra states followed by the 28 extra parameters of the Land variant (see
+    torord_land_rhs): the calcium equation changes and the 7 extra derivatives are appended."""
     exp, log, sqrt, where = _exp, _log, _sqrt, _where
     (C1, C2, C3, I_, O_, CaMKt, Jrel_np, Jrel_p, a, ap, iF, iFp, iS, iSp, cai, cajsr, cansr, cass, cli, clss, ki,
      kss, nai, nass, d, fcaf, fcafp, fcas, ff_, ffp, fs, jca, nca_i, nca_ss, h, hp, j, jp, m, hL, hLp, mL, v, xs1,
@@ -573,6 +581,43 @@ def torord_rhs(states, t, parameters):
     Bcass = 1.0 / ((BSLmax * KmBSL) / ((KmBSL + cass) ** 2.0) + ((BSRmax * KmBSR) / ((KmBSR + cass) ** 2.0) + 1.0))
     dcai_dt = Bcai * (((Acap * (-(-2.0 * INaCa_i + (ICab_ICab + (ICaL_i + IpCa_IpCa))))) / ((2.0 * F) * vmyo)
                        - Jup * vnsr / vmyo) + (Jdiff * vss) / vmyo)
+    mechanics = []
+    if land is not None:
+        # ---- ToRORd_dynCl_endo_Land.ode:632-722: troponin buffering leaves Bcai and becomes the flux J_TRPN; the
+        # calcium equation is the file's own (no ICaL_i term, INaCa_i / 3), restated as written ------------------------
+        (XS, XW, CaTrpn, TmB, Zetas, Zetaw, Cd, emcoupling, lmbda, dLambda, mode, isacs, calib, ktrpn, ntrpn, Trpn50,
+         rw, rs, gammas, gammaw, phi, Tot_A, Beta0, Beta1, cat50_ref, Tref, kuw, kws, ku, ntm, p_a, p_b, p_k, etal,
+         etas) = land
+        lambda_min12 = where(lmbda < 1.2, lmbda, 1.2)
+        kwu = kuw * (1.0 / rw - 1.0) - kws
+        ksu = kws * rw * (1.0 / rs - 1.0)
+        Aw = Tot_A * rs / ((1.0 - rs) * rw + rs)
+        As = Aw
+        cw = phi * kuw * ((1.0 - rs) * (1.0 - rw)) / ((1.0 - rs) * rw)
+        cs = phi * kws * ((1.0 - rs) * rw) / rs
+        XU = (1.0 - TmB) - XS - XW
+        gammawu = gammaw * _abs(Zetaw)
+        zs_pos = (Zetas > 0) * Zetas                   # relations used as numbers (.ode:690)
+        zs_neg = (Zetas < -1) * (-Zetas - 1.0)
+        gammasu = gammas * where(zs_pos > zs_neg, zs_pos, zs_neg)
+        dXS_dt = kws * XW - ksu * XS - gammasu * XS
+        dXW_dt = kuw * XU - kwu * XW - kws * XW - gammawu * XW
+        cat50 = cat50_ref + Beta1 * (lambda_min12 - 1.0)
+        dCaTrpn_dt = ktrpn * (((cai * 1000.0 / cat50) ** ntrpn) * (1.0 - CaTrpn) - CaTrpn)
+        kb = ku * Trpn50**ntm / (1.0 - rs - (1.0 - rs) * rw)
+        ctm = CaTrpn ** (-ntm / 2.0)
+        dTmB_dt = kb * where(ctm < 100.0, ctm, 100.0) * XU - ku * CaTrpn ** (ntm / 2.0) * TmB
+        Bcai = 1.0 / (1.0 + cmdnmax * kmcmdn / (kmcmdn + cai) ** 2.0)
+        J_TRPN = dCaTrpn_dt * trpnmax
+        dcai_dt = Bcai * (-(IpCa_IpCa + ICab_ICab - 2.0 * INaCa_i / 3.0) * Acap / (2.0 * F * vmyo) - Jup * vnsr / vmyo
+                          + Jdiff * vss / vmyo - J_TRPN)
+        dZetas_dt = As * dLambda - cs * Zetas
+        dZetaw_dt = Aw * dLambda - cw * Zetaw
+        C = lambda_min12 - 1.0
+        dCd = C - Cd
+        eta = where(dCd < 0, etas, etal)
+        dCd_dt = p_k * (C - Cd) / eta
+        mechanics = [dXS_dt, dXW_dt, dCaTrpn_dt, dTmB_dt, dZetas_dt, dZetaw_dt, dCd_dt]
     dcajsr_dt = Bcajsr * (-Jrel + Jtr)
     dcansr_dt = Jup - Jtr * vjsr / vnsr
     dcass_dt = Bcass * (-Jdiff + ((Acap * (-(ICaL_ss - 2.0 * INaCa_ss))) / ((2.0 * F) * vss) + (Jrel * vjsr) / vss))
@@ -588,38 +633,101 @@ def torord_rhs(states, t, parameters):
     return [dC1_dt, dC2_dt, dC3_dt, dI__dt, dO__dt, dCaMKt_dt, dJrel_np_dt, dJrel_p_dt, da_dt, dap_dt, diF_dt, diFp_dt,
             diS_dt, diSp_dt, dcai_dt, dcajsr_dt, dcansr_dt, dcass_dt, dcli_dt, dclss_dt, dki_dt, dkss_dt, dnai_dt,
             dnass_dt, dd_dt, dfcaf_dt, dfcafp_dt, dfcas_dt, dff__dt, dffp_dt, dfs_dt, djca_dt, dnca_i_dt, dnca_ss_dt,
-            dh_dt, dhp_dt, dj_dt, djp_dt, dm_dt, dhL_dt, dhLp_dt, dmL_dt, dv_dt, dxs1_dt, dxs2_dt]
+            dh_dt, dhp_dt, dj_dt, djp_dt, dm_dt, dhL_dt, dhLp_dt, dmL_dt, dv_dt, dxs1_dt, dxs2_dt] + mechanics
 
 
-def _params(parameters, shape):
-    """112 parameter entries, each a float (uniform) or an array broadcastable to the nodes (per-node (P, N))."""
+def _params(parameters, shape, names=None):
+    """Parameter entries, each a float (uniform) or an array broadcastable to the nodes (per-node (P, N))."""
+    names = TORORD_PARAMETERS if names is None else names
     parameters = np.asarray(parameters, dtype=np.float64)
-    if parameters.shape[0] != len(TORORD_PARAMETERS):
-        raise ValueError(f"expected {len(TORORD_PARAMETERS)} parameters, got {parameters.shape[0]}")
+    if parameters.shape[0] != len(names):
+        raise ValueError(f"expected {len(names)} parameters, got {parameters.shape[0]}")
     return [parameters[k] for k in range(parameters.shape[0])]
+
+
+def _rhs_and_linearized(rhs, names, states, t, parameters):
+    states = np.asarray(states, dtype=np.float64)
+    ns = states.shape[0]
+    ps = _params(parameters, states.shape[1:], names)
+    tail = (1,) * (states.ndim - 1)
+    eye = np.eye(ns)
+    seeded = [Dual(states[k], eye[k].reshape((ns,) + tail)) for k in range(ns)]
+    with np.errstate(all="ignore"):
+        out = rhs(seeded, t, ps)
+    out = [o if isinstance(o, Dual) else Dual(o, 0.0) for o in out]
+    f = np.array([np.broadcast_to(np.asarray(o.a, dtype=np.float64), states.shape[1:]) for o in out])
+    J = np.array([np.broadcast_to(np.asarray(o.b, dtype=np.float64), (ns,) + states.shape[1:])[i] for i, o in enumerate(out)])
+    return f, J
 
 
 def torord_rhs_and_linearized(states, t, parameters):
     """(f, J): f[i] = dy_i/dt and the total self-derivative J[i] = d f_i / d y_i, both (45, ...) arrays.  One
     forward-mode pass with a 45-component derivative part (state k is seeded with the k-th unit vector, so the pass
     carries every d f_i / d y_k); the diagonal is what generalized Rush-Larsen uses."""
-    states = np.asarray(states, dtype=np.float64)
-    ns = states.shape[0]
-    ps = _params(parameters, states.shape[1:])
-    tail = (1,) * (states.ndim - 1)
-    eye = np.eye(ns)
-    seeded = [Dual(states[k], eye[k].reshape((ns,) + tail)) for k in range(ns)]
-    with np.errstate(all="ignore"):
-        out = torord_rhs(seeded, t, ps)
-    f = np.array([np.broadcast_to(np.asarray(o.a, dtype=np.float64), states.shape[1:]) for o in out])
-    J = np.array([np.broadcast_to(np.asarray(o.b, dtype=np.float64), (ns,) + states.shape[1:])[i] for i, o in enumerate(out)])
-    return f, J
+    return _rhs_and_linearized(torord_rhs, TORORD_PARAMETERS, states, t, parameters)
 
 
 def torord_generalized_rush_larsen(states, t, dt, parameters, delta=1e-8):
     """One GRL1 step of all 45 states (every state has a structurally non-zero self-derivative)."""
     states = np.asarray(states, dtype=np.float64)
     f, J = torord_rhs_and_linearized(states, t, parameters)
+    with np.errstate(all="ignore"):
+        return states + np.where(np.abs(J) > delta, f * (np.exp(J * dt) - 1) / J, f * dt)
+
+
+# ------------------------------------------------------------------------------------------------
+# ToR-ORd-dynCl + Land contraction model (odes/torord/ToRORd_dynCl_endo_Land.ode; no demo of the reference
+# advances it, the file ships next to the one above): 52 states, 140 parameters
+# ------------------------------------------------------------------------------------------------
+_LAND_EXTRA_STATES = dict(cai=0.0001, XS=0.0, XW=0.0, CaTrpn=1e-8, TmB=1.0, Zetas=0.0, Zetaw=0.0, Cd=0.0)  # .ode:634-646
+_LAND_EXTRA_PARAMETERS = dict(  # .ode:648-679
+    emcoupling=1.0, lmbda=1.0, dLambda=0.0, mode=1.0, isacs=0.0, calib=1.0, ktrpn=0.1, ntrpn=2.0, Trpn50=0.35, rw=0.5,
+    rs=0.25, gammas=0.0085, gammaw=0.615, phi=2.23, Tot_A=25.0, Beta0=2.3, Beta1=-2.4, cat50_ref=0.805, Tref=120.0,
+    kuw=0.182, kws=0.012, ku=0.04, ntm=2.4, p_a=2.1, p_b=9.1, p_k=7.0, etal=200.0, etas=20.0,
+)
+# cai leaves the "intracellular ions" group and is declared with the mechanics states at the end of the file
+TORORD_LAND_STATE_DEFAULTS = {k: v for k, v in TORORD_STATE_DEFAULTS.items() if k != "cai"} | _LAND_EXTRA_STATES
+TORORD_LAND_STATES = tuple(TORORD_LAND_STATE_DEFAULTS)
+TORORD_LAND_PARAMETER_DEFAULTS = TORORD_PARAMETER_DEFAULTS | _LAND_EXTRA_PARAMETERS
+TORORD_LAND_PARAMETERS = tuple(TORORD_LAND_PARAMETER_DEFAULTS)
+_CAI = TORORD_STATES.index("cai")
+
+
+def torord_land_init_state_values(**values) -> np.ndarray:
+    d = dict(TORORD_LAND_STATE_DEFAULTS)
+    for k, v in values.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return np.array([d[k] for k in TORORD_LAND_STATES], dtype=np.float64)
+
+
+def torord_land_init_parameter_values(**values) -> np.ndarray:
+    d = dict(TORORD_LAND_PARAMETER_DEFAULTS)
+    for k, v in values.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return np.array([d[k] for k in TORORD_LAND_PARAMETERS], dtype=np.float64)
+
+
+def torord_land_rhs(states, t, parameters):
+    """dy/dt of the 52 states in TORORD_LAND_STATES order (the 44 electrophysiology states without cai, then cai,
+    XS, XW, CaTrpn, TmB, Zetas, Zetaw, Cd)."""
+    states, parameters = list(states), list(parameters)
+    base = states[:_CAI] + [states[44]] + states[_CAI:44]
+    out = torord_rhs(base, t, parameters[:112], land=states[45:] + parameters[112:])
+    return out[:_CAI] + out[_CAI + 1:45] + [out[_CAI]] + out[45:]
+
+
+def torord_land_rhs_and_linearized(states, t, parameters):
+    return _rhs_and_linearized(torord_land_rhs, TORORD_LAND_PARAMETERS, states, t, parameters)
+
+
+def torord_land_generalized_rush_larsen(states, t, dt, parameters, delta=1e-8):
+    """One GRL1 step of the 52 states."""
+    states = np.asarray(states, dtype=np.float64)
+    f, J = torord_land_rhs_and_linearized(states, t, parameters)
     with np.errstate(all="ignore"):
         return states + np.where(np.abs(J) > delta, f * (np.exp(J * dt) - 1) / J, f * dt)
 

@@ -3,8 +3,9 @@
 
 Two sources, both the reference itself:
 
-1. ``tp06_spec.npz`` / ``torord_spec.npz`` -- the reference's TP06 / ToR-ORd-dynCl ``.ode`` specifications
-   (odes/tentusscher_panfilov_2006/tentusscher_panfilov_2006_epi_cell.ode) evaluated by the
+1. ``tp06_spec.npz`` / ``torord_spec.npz`` / ``torord_land_spec.npz`` -- the reference's TP06 / ToR-ORd-dynCl
+   (+ Land) ``.ode`` specifications (odes/tentusscher_panfilov_2006/tentusscher_panfilov_2006_epi_cell.ode,
+   odes/torord/ToRORd_dynCl_endo.ode, odes/torord/ToRORd_dynCl_endo_Land.ode) evaluated by the
    independent evaluator in ``ode_spec.py``: right-hand sides, total self-derivatives and one
    GRL1 step at seeded random states.
 2. ``splitting_reference.npz`` / ``.json`` -- the reference's OWN ``src/beat/odesolver.py`` and
@@ -141,6 +142,90 @@ def make_torord_spec():
     np.savez_compressed(HERE / "torord_spec.npz", **out)
     print("torord_spec.npz:", n, "points,", len(names), "states, 3 cell types;", traj.shape[1], "trajectory states, V range",
           traj[names.index("v")].min(), traj[names.index("v")].max())
+
+
+def make_torord_land_spec():
+    """ToR-ORd-dynCl with the Land contraction model (odes/torord/ToRORd_dynCl_endo_Land.ode, 52 states, 140
+    parameters): RHS, total self-derivatives and one GRL1 step at seeded states, for the three cell types at the
+    file's parameters and for a stretched, lengthening cell (lmbda = 1.1 / 1.25 / 0.85, dLambda != 0) so that both
+    branches of every condition of the mechanics part are taken; plus states along one paced action potential."""
+    from ode_spec import OdeSpec
+
+    import sympy
+
+    spec = OdeSpec(REF / "odes/torord/ToRORd_dynCl_endo_Land.ode")
+    rng = np.random.default_rng(20261005)
+    n = 48
+    names = spec.state_names
+    st = {k: spec.states[k] * (1.0 + 0.05 * rng.uniform(-1, 1, n)) for k in names}
+    st["v"] = rng.uniform(-90.0, 40.0, n)
+    st["cai"] = 10 ** rng.uniform(-4.2, -2.9, n)
+    st["XS"] = rng.uniform(0.0, 0.05, n)
+    st["XW"] = rng.uniform(0.0, 0.05, n)
+    st["CaTrpn"] = 10 ** rng.uniform(-4.0, -0.4, n)  # both sides of CaTrpn**(-ntm/2) = 100 (CaTrpn = 0.0215)
+    st["TmB"] = rng.uniform(0.2, 1.0, n)
+    st["Zetas"] = rng.uniform(-1.6, 0.6, n)          # the three branches of gammasu
+    st["Zetaw"] = rng.uniform(-0.3, 0.3, n)
+    st["Cd"] = rng.uniform(-0.2, 0.4, n)             # both signs of C - Cd
+    for k in names:
+        st[k][0] = spec.states[k]
+    t, dt = 0.3, 0.05
+    psets = []
+    for celltype in (0.0, 1.0, 2.0):
+        psets.append(dict(spec.parameters, celltype=celltype))
+    psets.append(dict(spec.parameters, lmbda=1.1, dLambda=0.002))
+    psets.append(dict(spec.parameters, lmbda=1.25, dLambda=-0.001, celltype=1.0, ntrpn=1.7, ntm=2.2))
+    psets.append(dict(spec.parameters, lmbda=0.85, dLambda=0.0005, celltype=2.0))
+    out = dict(state_names=np.array(names), parameter_names=np.array(spec.parameter_names),
+               state_defaults=np.array([spec.states[k] for k in names]),
+               parameter_defaults=np.array([spec.parameters[k] for k in spec.parameter_names]),
+               states=np.array([st[k] for k in names]), t=t, dt=dt,
+               parameter_sets=np.array([[ps[k] for k in spec.parameter_names] for ps in psets]))
+    rhs_all, jac_all, new_all = [], [], []
+    for ps in psets:
+        rhs, J, new = spec.grl1(st, ps, t, dt, total=True)
+        rhs_all.append([rhs[k] for k in names])
+        jac_all.append([J[k] for k in names])
+        new_all.append([new[k] for k in names])
+    out["rhs"], out["jac"], out["grl1"] = np.array(rhs_all), np.array(jac_all), np.array(new_all)
+    # one paced action potential (endo, dt = 0.02 ms) with the calcium transient driving troponin and the cross-bridges
+    lin = spec.linearized(total=True)
+    fns = {}
+    for s in names:
+        syms = sorted(lin[s].free_symbols, key=lambda x: x.name)
+        fns[s] = (syms, sympy.lambdify(syms, lin[s], "numpy", cse=True))
+    par = dict(spec.parameters)
+    cur = {k: np.array([v]) for k, v in spec.states.items()}
+    hdt, tt = 0.02, 0.0
+    keep_at = sorted(set(list(range(0, 150, 5)) + list(range(150, 15000, 500))))
+    traj = []
+    for i in range(15000):
+        if i in keep_at:
+            traj.append(np.array([cur[k][0] for k in names]))
+        vals = spec.evaluate(cur, par, tt)
+        env = dict(par)
+        env.update(cur)
+        env["time"] = tt
+        new = {}
+        for s in names:
+            f = np.asarray(vals[f"d{s}_dt"], dtype=float) + 0.0 * cur[s]
+            syms, fn = fns[s]
+            args = [np.broadcast_to(np.asarray(env[x.name], dtype=float), f.shape) for x in syms]
+            with np.errstate(all="ignore"):
+                Jv = np.asarray(fn(*args), dtype=float) + 0.0 * f
+                new[s] = cur[s] + np.where(np.abs(Jv) > 1e-8, f * (np.exp(Jv * hdt) - 1) / Jv, f * hdt)
+        cur, tt = new, tt + hdt
+    traj = np.array(traj).T
+    out["traj_states"] = traj
+    out["traj_dt"] = hdt
+    stt = {k: traj[i] for i, k in enumerate(names)}
+    _, _, new = spec.grl1(stt, par, 5.0, hdt, total=True)
+    out["traj_grl1"] = np.array([new[k] for k in names])
+    out["traj_step_t"] = 5.0
+    np.savez_compressed(HERE / "torord_land_spec.npz", **out)
+    print("torord_land_spec.npz:", n, "points,", len(names), "states,", len(psets), "parameter sets;", traj.shape[1],
+          "trajectory states, V range", traj[names.index("v")].min(), traj[names.index("v")].max(), "max CaTrpn",
+          traj[names.index("CaTrpn")].max(), "max XS", traj[names.index("XS")].max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -342,10 +427,12 @@ def make_splitting_reference():
 if __name__ == "__main__":
     if not REF.is_dir():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
-    which = sys.argv[1:] or ["tp06", "torord", "splitting"]
+    which = sys.argv[1:] or ["tp06", "torord", "torord_land", "splitting"]
     if "tp06" in which:
         make_tp06_spec()
     if "torord" in which:
         make_torord_spec()
+    if "torord_land" in which:
+        make_torord_land_spec()
     if "splitting" in which:
         make_splitting_reference()

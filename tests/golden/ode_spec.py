@@ -84,7 +84,7 @@ class OdeSpec:
             return np.where(c, a, b)
 
         ns = {
-            "exp": np.exp, "log": np.log, "sqrt": np.sqrt, "floor": np.floor, "abs": np.abs,
+            "exp": np.exp, "log": np.log, "sqrt": np.sqrt, "floor": np.floor, "abs": np.abs, "Abs": np.abs,
             "Conditional": conditional, "Lt": np.less, "Le": np.less_equal, "Gt": np.greater,
             "Ge": np.greater_equal, "Eq": np.equal, "And": np.logical_and, "Or": np.logical_or,
             "time": t, "pi": np.pi,
@@ -104,13 +104,36 @@ class OdeSpec:
         """d(dX_dt)/dX of each state derivative.  ``total=True``: every intermediate expression is
         resolved first (total self-derivative, the variant the Niederer table pins); ``total=False``:
         intermediates are held as opaque symbols (derivative of the expression as written)."""
-        sym = {n: sympy.Symbol(n) for n in list(self.states) + list(self.parameters)}
+        sym = {n: sympy.Symbol(n, real=True) for n in list(self.states) + list(self.parameters)}
+
+        class Rel:
+            """A relation that may also be used as a number (``Gt(x, 0)*x``, ToRORd_dynCl_endo_Land.ode): 1 where it
+            holds, 0 elsewhere."""
+
+            def __init__(self, rel):
+                self.rel = rel
+
+            def number(self):
+                return sympy.Piecewise((1, self.rel), (0, True))
+
+            def __mul__(self, other):
+                return self.number() * other
+
+            __rmul__ = __mul__
+
+        def rel(fn):
+            return lambda a, b: Rel(fn(*(x.number() if isinstance(x, Rel) else x for x in (a, b))))
+
+        def cond(x):
+            return x.rel if isinstance(x, Rel) else x
+
         ns = {
             "exp": sympy.exp, "log": sympy.log, "sqrt": sympy.sqrt, "floor": sympy.floor,
-            "abs": sympy.Abs,
-            "Conditional": lambda c, a, b: sympy.Piecewise((a, c), (b, True)),
-            "Lt": sympy.Lt, "Le": sympy.Le, "Gt": sympy.Gt, "Ge": sympy.Ge, "Eq": sympy.Eq,
-            "And": sympy.And, "Or": sympy.Or, "time": sympy.Symbol("time"), "pi": sympy.pi,
+            "abs": sympy.Abs, "Abs": sympy.Abs,
+            "Conditional": lambda c, a, b: sympy.Piecewise((a, cond(c)), (b, True)),
+            "Lt": rel(sympy.Lt), "Le": rel(sympy.Le), "Gt": rel(sympy.Gt), "Ge": rel(sympy.Ge), "Eq": rel(sympy.Eq),
+            "And": lambda *a: sympy.And(*map(cond, a)), "Or": lambda *a: sympy.Or(*map(cond, a)),
+            "time": sympy.Symbol("time", real=True), "pi": sympy.pi,
         }
         ns.update(sym)
         out = {}
@@ -140,8 +163,11 @@ class OdeSpec:
                 continue
             syms = sorted(e.free_symbols, key=lambda x: x.name)
             fn = sympy.lambdify(syms, e, "numpy", cse=True)
+            # arguments of one shape: conditions on parameters alone sit next to conditions on states in the
+            # lambdified select() lists
+            args = [np.broadcast_to(np.asarray(env[x.name], dtype=float), np.shape(f)) for x in syms]
             with np.errstate(all="ignore"):
-                Jv = np.asarray(fn(*[env[x.name] for x in syms]), dtype=float) + 0.0 * f
+                Jv = np.asarray(fn(*args), dtype=float) + 0.0 * f
                 J[s] = Jv
                 new[s] = states[s] + np.where(np.abs(Jv) > delta, f * (np.exp(Jv * dt) - 1) / Jv, f * dt)
         return rhs, J, new

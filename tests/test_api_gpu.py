@@ -334,10 +334,12 @@ def test_monodomain_splitting_temporal_convergence(odespace):
     assert sum(rates) / len(rates) > 1.0, (errors, rates)
 
 
-def _tp06_slab(fused, theta=1.0, nsteps=40, stim=True, ksp_rtol=None):
+def _tp06_slab(fused, theta=1.0, nsteps=40, stim=True, ksp_rtol=None, model=None, v_name="V", model_stimulus="stim_amplitude"):
     import beat
     from beat import grid as g
     from beat.models import tp06
+
+    tp06 = tp06 if model is None else model  # (any built-in cell model with the same module interface)
 
     geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=4.0, Ly=2.0, Lz=1.0, dx=0.25)
     mesh = geo.mesh
@@ -353,8 +355,8 @@ def _tp06_slab(fused, theta=1.0, nsteps=40, stim=True, ksp_rtol=None):
     pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, dx=I_s.dZ, params=params)
     ode = beat.odesolver.DolfinODESolver(
         v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
-        init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
-        num_states=19, v_index=tp06.state_index("V"))
+        init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(**{model_stimulus: 0.0}),
+        num_states=len(tp06.init_state_values()), v_index=tp06.state_index(v_name))
     solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta, fused=fused)
     dt = 0.05
     for i in range(nsteps):
@@ -414,6 +416,41 @@ def test_strang_splitting_against_oracle():
     out = s.ode.values
     err = np.abs(out - S) / np.maximum(np.abs(S), 1e-3)
     assert err.max() < 1e-7, err.max()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_land_cell_model_in_the_split_step_against_oracle(fused):
+    """The 52-state ToR-ORd + Land model (beat.models.torord_land, odes/torord/ToRORd_dynCl_endo_Land.ode) as ``fun`` of
+    the splitting solver on the slab of the tests above: 40 steps of 0.05 ms with a corner stimulus against the oracle
+    (oracle/torord.py ionic step + sparse-LU diffusion), PCG at rtol 1e-13 so that the arithmetic is compared; the
+    potential lives in row 41 and calcium in row 44 of this model."""
+    from beat.models import torord_land as tl
+    from oracle import fem
+    from oracle import torord as otor
+
+    nsteps, dt = 40, 0.05
+    s = _tp06_slab(fused, nsteps=nsteps, ksp_rtol=1e-13, model=tl, v_name="v", model_stimulus="i_Stim_Amplitude")
+    mesh = fem.BoxMesh((16, 8, 4), (4.0, 2.0, 1.0))
+    M = np.diag([0.0009529837251356239, 0.00012575841147269718, 0.00012575841147269718])
+    cells = mesh.locate_cells(lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+    w = fem.stimulus_weights(mesh, cells)
+    amp = 50000.0 / 1400.0 / 100.0
+    model = fem.OracleMonodomainModel(mesh, M, [fem.OracleStimulus(fem.window(0.0, 2.0, amp), w)], C_m=0.01, theta=0.5)
+    S = np.repeat(otor.torord_land_init_state_values()[:, None], mesh.num_nodes, axis=1)
+    P = otor.torord_land_init_parameter_values(i_Stim_Amplitude=0.0)
+    vi = otor.TORORD_LAND_STATES.index("v")
+    assert vi == tl.state_index("v") == 41
+    for i in range(nsteps):
+        t0 = i * dt
+        S = otor.torord_land_generalized_rush_larsen(S, t0, dt, P)
+        model.state[:] = S[vi]
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        S[vi] = model.state
+    out = s.ode.values
+    assert S[vi].max() > 0.0 and np.array_equal(out[vi], np.asarray(s.pde.state.x.array))
+    err = np.abs(out - S) / np.maximum(np.abs(S), 1e-6 * np.abs(S[:, :1]) + 1e-12)
+    assert err.max() < 1e-7, (err.max(), otor.TORORD_LAND_STATES[np.unravel_index(err.argmax(), err.shape)[0]])
 
 
 _POINTS = ("P1", "P2", "P3", "P4", "P5", "P6", "P7", "P8", "P9")

@@ -233,13 +233,79 @@ def test_torord_kernel_along_an_action_potential():
     assert len(bad) == 0, [(g["state_names"][i], float(g["traj_times"][j]), float(err[i, j])) for i, j in bad[:12]]
 
 
-@pytest.mark.parametrize("model", ["tp06", "torord", "fhn"])
+def test_torord_land_kernel_matches_the_ode_spec_golden_and_the_oracle():
+    """The Land instance of the ToR-ORd kernel (beat.models.torord_land: odes/torord/ToRORd_dynCl_endo_Land.ode, 52
+    states, 140 parameters): one GRL1 step vs the specification fixture for six parameter sets (cell types, stretch,
+    stretch rate, troponin / tropomyosin exponents) at states on every branch of the mechanics part and along a paced
+    action potential (1e-10 / 1e-9 relative to the state scale), and vs oracle/torord.py with per-node parameters."""
+    from beat.models import torord_land as tl
+
+    from oracle import torord as otor
+
+    g = np.load(GOLD / "torord_land_spec.npz")
+    m = tl.generalized_rush_larsen
+    assert tuple(g["state_names"]) == m.state_names and tuple(g["parameter_names"]) == m.parameter_names
+    np.testing.assert_array_equal(g["state_defaults"], tl.init_state_values())
+    np.testing.assert_array_equal(g["parameter_defaults"], tl.init_parameter_values())
+    assert m.num_states == 52 and m.num_parameters == 140 and tl.state_index("v") == 41 and tl.state_index("cai") == 44
+
+    def err(out, ref):
+        return np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6 * np.abs(g["state_defaults"])[:, None] + 1e-12)
+
+    for k, P in enumerate(g["parameter_sets"]):
+        out = m(states=g["states"], t=float(g["t"]), parameters=P, dt=float(g["dt"]))
+        assert np.isfinite(out).all()
+        e = err(out, g["grl1"][k])
+        assert e.max() < 1e-10, (k, e.max(), g["state_names"][np.unravel_index(e.argmax(), e.shape)[0]])
+    out = m(states=g["traj_states"], t=float(g["traj_step_t"]), parameters=g["parameter_defaults"], dt=float(g["traj_dt"]))
+    assert err(out, g["traj_grl1"]).max() < 1e-9
+    # per-node parameters
+    S = g["traj_states"]
+    n = S.shape[1]
+    P = np.repeat(tl.init_parameter_values()[:, None], n, axis=1)
+    P[tl.parameter_index("celltype")] = np.arange(n) % 3
+    P[tl.parameter_index("i_Stim_Amplitude")] = np.where(np.arange(n) % 2, -53.0, 0.0)
+    P[tl.parameter_index("lmbda")] = 0.8 + 0.5 * np.arange(n) / n
+    P[tl.parameter_index("dLambda")] = 0.001 * ((np.arange(n) % 5) - 2)
+    for t in (0.5, 7.0):
+        out = m(states=S, t=t, parameters=P, dt=0.02)
+        assert err(out, otor.torord_land_generalized_rush_larsen(S, t, 0.02, P)).max() < 1e-9
+
+
+def test_torord_land_beat_follows_the_oracle_and_develops_tension():
+    """One paced beat of the Land cell with the in-kernel loop: the electrophysiology is an ordinary ToR-ORd action
+    potential, troponin binds calcium and the cross-bridge states rise and fall again (active tension
+    Ta = h(lambda) Tref / rs (XS (Zetas + 1) + XW Zetaw), .ode:706, at lambda = 1); the first 300 steps equal the NumPy
+    oracle's within 1e-8."""
+    from beat.models import torord_land as tl
+
+    from oracle import torord as otor
+
+    m = tl.generalized_rush_larsen
+    y0, P = tl.init_state_values(), tl.init_parameter_values()
+    ix = [tl.state_index(k) for k in ("v", "cai", "CaTrpn", "XS", "XW", "TmB")]
+    y, tr = m.run(y0, P, dt=0.02, nsteps=25000, nbeats=1, track_indices=ix, save_freq=50)
+    v, cai, catrpn, xs = tr[:, 0], tr[:, 1], tr[:, 2], tr[:, 3]
+    assert np.isfinite(y).all() and 5.0 < v.max() < 60.0 and v[-1] < -80.0
+    assert 2e-4 < cai.max() < 2e-3 and cai[-1] < 1.5e-4
+    assert 0.05 < catrpn.max() < 0.9 and catrpn.argmax() > cai.argmax()      # troponin follows the calcium transient
+    ta = 120.0 / 0.25 * xs                                                     # Zetas = Zetaw = 0 at dLambda = 0
+    assert 5.0 < ta.max() < 150.0 and xs.argmax() > catrpn.argmax() and ta[-1] < 0.2 * ta.max()
+    ys, tr2 = m.run(y0, P, dt=0.02, nsteps=300, nbeats=1, track_indices=ix, save_freq=300)
+    yo = y0[:, None].copy()
+    for i in range(300):
+        yo = otor.torord_land_generalized_rush_larsen(yo, i * 0.02, 0.02, P)
+    scale = np.maximum(np.abs(yo[:, 0]), 1e-6 * np.abs(y0) + 1e-12)
+    assert (np.abs(ys.reshape(-1) - yo[:, 0]) / scale).max() < 1e-8
+
+
+@pytest.mark.parametrize("model", ["tp06", "torord", "torord_land", "fhn"])
 def test_run_kernel_equals_repeated_steps(model):
     """beat_ode_run (in-kernel time loop) gives bit-for-bit what repeated beat_ode_step launches give."""
-    from beat.models import fhn, torord, tp06
+    from beat.models import fhn, torord, torord_land, tp06
 
     m = {"tp06": tp06.generalized_rush_larsen, "torord": torord.generalized_rush_larsen,
-         "fhn": fhn.forward_euler_readme}[model]
+         "torord_land": torord_land.generalized_rush_larsen, "fhn": fhn.forward_euler_readme}[model]
     rng = np.random.default_rng(4)
     y0 = np.repeat(m.init_state_values()[:, None], 70, axis=1)
     y0[m.state_index(m.v_name)] += rng.uniform(0, 20, 70)

@@ -96,6 +96,44 @@ def test_torord_hand_restatement_along_an_action_potential():
         np.testing.assert_array_equal(per_node[:, ct == c], ref)
 
 
+def test_torord_land_hand_restatement_matches_the_ode_spec():
+    """The Land variant (odes/torord/ToRORd_dynCl_endo_Land.ode, 52 states / 140 parameters) of oracle/torord.py against
+    tests/golden/torord_land_spec.npz: names, defaults, RHS, total self-derivatives and one GRL1 step for six parameter
+    sets (three cell types; stretched / lengthening / shortening cells with non-default troponin and tropomyosin
+    exponents) at states that take every branch of the mechanics part, and one step from each of 60 states along a
+    paced action potential."""
+    g = np.load(GOLD / "torord_land_spec.npz")
+    assert tuple(g["state_names"]) == torord.TORORD_LAND_STATES
+    assert tuple(g["parameter_names"]) == torord.TORORD_LAND_PARAMETERS
+    np.testing.assert_array_equal(g["state_defaults"], torord.torord_land_init_state_values())
+    np.testing.assert_array_equal(g["parameter_defaults"], torord.torord_land_init_parameter_values())
+    S, t, dt = g["states"], float(g["t"]), float(g["dt"])
+    names = list(g["state_names"])
+    zs, cd, ct = S[names.index("Zetas")], S[names.index("Cd")], S[names.index("CaTrpn")]
+    assert (zs > 0).any() and (zs < -1).any() and ((zs > -1) & (zs < 0)).any()   # the three branches of gammasu
+    assert (ct ** -1.2 < 100).any() and (ct ** -1.2 > 100).any() and (cd > 0).any() and (cd < -0.2 + 0.25).any()
+    for k, P in enumerate(g["parameter_sets"]):
+        f, J = torord.torord_land_rhs_and_linearized(S, t, P)
+        np.testing.assert_allclose(f, g["rhs"][k], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(J, g["jac"][k], rtol=1e-11, atol=1e-300)
+        assert (np.abs(J) > 0).all()
+        out = torord.torord_land_generalized_rush_larsen(S, t, dt, P)
+        np.testing.assert_allclose(out, g["grl1"][k], rtol=1e-12, atol=1e-300)
+    assert not np.allclose(g["grl1"][0], g["grl1"][3], rtol=1e-9)  # stretch matters
+    out = torord.torord_land_generalized_rush_larsen(g["traj_states"], float(g["traj_step_t"]), float(g["traj_dt"]),
+                                                     g["parameter_defaults"])
+    np.testing.assert_allclose(out, g["traj_grl1"], rtol=1e-11, atol=1e-300)
+    # the electrophysiology states follow the 45-state model except through the calcium equation: with the same
+    # states, every derivative but cai's (and the mechanics rows) equals the base model's
+    base_names = list(torord.TORORD_STATES)
+    Sb = np.array([S[names.index(n)] for n in base_names])
+    fb, _ = torord.torord_rhs_and_linearized(Sb, t, g["parameter_sets"][1][:112])
+    fl, _ = torord.torord_land_rhs_and_linearized(S, t, g["parameter_sets"][1])
+    for i, n in enumerate(base_names):
+        if n != "cai":
+            np.testing.assert_array_equal(fb[i], fl[names.index(n)])
+
+
 def test_torord_single_cell_action_potential_is_physiological():
     """The model's own stimulus (-53 A/F for 1 ms at t = 0) fires one endocardial cell: overshoot 20-60 mV, APD90
     in the human ventricular range, back at rest after 450 ms (dt = 0.1 ms keeps the CPU suite short;

@@ -6,6 +6,9 @@ table-driven ones) and checked against
   for endo / epi / mid and along a paced action potential, 1e-11 relative to the state scale;
 * the independent NumPy oracle (oracle/torord.py) on per-node parameters and over a 400-step trajectory.
 
+The Land instance of the same source (52 states: ToRORd_dynCl_endo_Land.ode) is checked the same way against
+tests/golden/torord_land_spec.npz and the oracle.
+
 The arithmetic organisation of the kernel (blocks, running sums, sparse dual numbers) is therefore verified without a
 GPU; the GPU suite then checks the device build of the same source."""
 import shutil
@@ -21,13 +24,13 @@ ROOT = Path(__file__).resolve().parents[1]
 GOLD = ROOT / "tests" / "golden"
 
 
-@pytest.fixture(scope="module")
-def host_step(tmp_path_factory):
+def _host_step(tmp_path_factory, flags):
     if shutil.which("g++") is None:
         pytest.skip("no g++ on this machine")
     d = tmp_path_factory.mktemp("torord_host")
     exe = d / "torord_host"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "torord_host_harness.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", *flags, "-o", str(exe), str(ROOT / "tests" / "torord_host_harness.cpp")],
+                   check=True)
 
     def run(S, P, t, dt):
         S = np.ascontiguousarray(S, dtype=np.float64)
@@ -38,6 +41,16 @@ def host_step(tmp_path_factory):
         return np.fromfile(d / "o.bin").reshape(S.shape)
 
     return run
+
+
+@pytest.fixture(scope="module")
+def host_step(tmp_path_factory):
+    return _host_step(tmp_path_factory, [])
+
+
+@pytest.fixture(scope="module")
+def host_step_land(tmp_path_factory):
+    return _host_step(tmp_path_factory, ["-DBEAT_HOST_LAND=1"])
 
 
 def _err(out, ref, defaults):
@@ -74,4 +87,42 @@ def test_hand_kernel_source_matches_the_numpy_oracle(host_step):
         y = host_step(y, P1, i * 0.01, 0.01)
         yo = torord.torord_generalized_rush_larsen(yo, i * 0.01, 0.01, P1)
     assert yo[torord.torord_state_index("v"), 0] > 0.0  # fired
+    assert _err(y, yo, g["state_defaults"]).max() < 1e-9
+
+
+def test_land_instance_matches_the_ode_spec_fixture(host_step_land):
+    """Six parameter sets (three cell types; stretched / lengthening / shortening cells with other troponin and
+    tropomyosin exponents) at states that take every branch of the mechanics part, and one step from every state of a
+    paced action potential."""
+    g = np.load(GOLD / "torord_land_spec.npz")
+    for k, P in enumerate(g["parameter_sets"]):
+        out = host_step_land(g["states"], P, float(g["t"]), float(g["dt"]))
+        assert _err(out, g["grl1"][k], g["state_defaults"]).max() < 1e-11, k
+    out = host_step_land(g["traj_states"], g["parameter_defaults"], float(g["traj_step_t"]), float(g["traj_dt"]))
+    assert _err(out, g["traj_grl1"], g["state_defaults"]).max() < 1e-11
+
+
+def test_land_instance_matches_the_numpy_oracle(host_step_land):
+    """Per-node parameters (cell type, stimulus and stretch differ from node to node) and a 400-step trajectory
+    through the upstroke and the start of the calcium transient, against oracle/torord.py."""
+    g = np.load(GOLD / "torord_land_spec.npz")
+    S = g["traj_states"]
+    n = S.shape[1]
+    names = list(torord.TORORD_LAND_PARAMETERS)
+    P = np.repeat(torord.torord_land_init_parameter_values()[:, None], n, axis=1)
+    P[names.index("celltype")] = np.arange(n) % 3
+    P[names.index("i_Stim_Amplitude")] = np.where(np.arange(n) % 2, -53.0, 0.0)
+    P[names.index("lmbda")] = 0.8 + 0.5 * np.arange(n) / n
+    P[names.index("dLambda")] = 0.001 * ((np.arange(n) % 5) - 2)
+    for t in (0.5, 7.0):
+        out = host_step_land(S, P, t, 0.02)
+        ref = torord.torord_land_generalized_rush_larsen(S, t, 0.02, P)
+        assert _err(out, ref, g["state_defaults"]).max() < 1e-11
+    y = torord.torord_land_init_state_values()[:, None].copy()
+    yo = y.copy()
+    P1 = torord.torord_land_init_parameter_values()
+    for i in range(400):
+        y = host_step_land(y, P1, i * 0.01, 0.01)
+        yo = torord.torord_land_generalized_rush_larsen(yo, i * 0.01, 0.01, P1)
+    assert yo[torord.TORORD_LAND_STATES.index("v"), 0] > 0.0
     assert _err(y, yo, g["state_defaults"]).max() < 1e-9

@@ -1,6 +1,7 @@
 // Host build of the hand-organised ToR-ORd-dynCl step (fenicsx-beat_amd/csrc/torord_dyncl.h) for the CPU test suite:
 // the same source the HIP kernel compiles, with exp / log / reciprocal from libm.
 //   torord_host <states.bin> <params.bin> <out.bin> n t dt     (states: (45, n) doubles row-major; params: (112,) or (112, n))
+// Built with -DBEAT_HOST_LAND=1 it runs the Land instance of the same source (52 states, 140 parameters).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,12 @@ using std::pow;
 using std::sqrt;
 #include "../fenicsx-beat_amd/csrc/torord_dyncl.h"
 
+#ifdef BEAT_HOST_LAND
+using Model = TorordLandGrl1;
+#else
+using Model = TorordDynClGrl1;
+#endif
+
 struct HostIO {
   const double* in;
   double* out;
@@ -39,24 +46,24 @@ int main(int argc, char** argv) {
   if (argc < 7) return 2;
   const long n = std::atol(argv[4]);
   const double t = std::atof(argv[5]), dt = std::atof(argv[6]);
-  std::vector<double> S(45 * n), O(45 * n, 0.0);
+  std::vector<double> S(Model::NS * n), O(Model::NS * n, 0.0);
   FILE* f = std::fopen(argv[1], "rb");
   if (!f || std::fread(S.data(), 8, S.size(), f) != S.size()) return 3;
   std::fclose(f);
   f = std::fopen(argv[2], "rb");
   if (!f) return 3;
-  std::vector<double> P(112 * n);
+  std::vector<double> P(Model::NP * n);
   const size_t got = std::fread(P.data(), 8, P.size(), f);
   std::fclose(f);
   const bool per_node = got == P.size() && n > 1;
-  if (!per_node && got < 112) return 3;
+  if (!per_node && got < (size_t)Model::NP) return 3;
   const HostMath fm;
   for (long i = 0; i < n; ++i) {
-    double pl[112];
-    for (int k = 0; k < 112; ++k) pl[k] = per_node ? P[(long)k * n + i] : P[k];
-    const TorordDynClGrl1::Derived q = TorordDynClGrl1::derive(pl);
+    double pl[Model::NP];
+    for (int k = 0; k < Model::NP; ++k) pl[k] = per_node ? P[(long)k * n + i] : P[k];
+    const Model::Derived q = Model::derive(pl);
     const HostIO io{S.data(), O.data(), n, i};
-    TorordDynClGrl1::step(io, pl, q, fm, t, dt);
+    Model::step(io, pl, q, fm, t, dt);
   }
   f = std::fopen(argv[3], "wb");
   if (!f) return 4;

@@ -105,6 +105,24 @@ def main():
                                      len(P2), None, 0, 0.0, 0.01, vi, None))
 
     timeit("ode_step torord", ode2, 16 * len(ic), reps=4)
+    del sb
+
+    from beat.models import torord_land
+
+    ic = torord_land.init_state_values()
+    P3 = np.ascontiguousarray(torord_land.init_parameter_values())
+    vi3 = torord_land.state_index("v")
+    sc = StateArray(ctx, len(ic), N, plane)
+    for k in range(len(ic)):
+        sc.rows[k].fill_(float(ic[k]))
+    sc.rows[vi3].add_(torch.rand(N, dtype=torch.float64, device=ctx.device) * 100.0)
+    sc.rows[torord_land.state_index("CaTrpn")].fill_(0.05)
+
+    def ode3():
+        _hip.check(lib.beat_ode_step(ctx.handle, _hip.MODEL_TORORD_LAND_GRL1, sc.ptr, N, sc.ld, P3.ctypes.data_as(C.c_void_p),
+                                     len(P3), None, 0, 0.0, 0.01, vi3, None))
+
+    timeit("ode_step torord_land", ode3, 16 * len(ic), reps=4)
 
 
 if __name__ == "__main__":
