@@ -490,6 +490,21 @@ def main():
             "v_max": fmax,
         }
 
+    # What a trivial in-place kernel reaches on the very array the ionic kernel walks (every state read once and written
+    # back once: x *= 1.0, bit-preserving), measured here, after the timed regions: the practical ceiling next to which
+    # the 8 TB/s of "roofline.peak" should be read (on this pool: write-only 6.7, read-only 6.1, in-place 5.6, copy 4.8 TB/s;
+    # tools/bw_probe.py)
+    stream_ms = None
+    flat = states.buf[states.base: states.base + states.S * states.ld]  # the rows with their ghost-plane padding, contiguous
+    if finite:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+        for a, b in evs:
+            a.record()
+            flat.mul_(1.0)
+            b.record()
+        torch.cuda.synchronize()
+        stream_ms = sorted(a.elapsed_time(b) for a, b in evs[1:])[2]
+
     if rank == 0:
         n_total = n * n * nz_glob
         # HBM bytes and VALU counters per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
@@ -550,9 +565,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                # the yardstick above is the HBM roofline (the path is bandwidth-shaped); what actually limits THIS
-                # kernel is fp64 VALU issue: see "valu"
-                "limiter": "valu_fp64_issue",
+                # the yardstick above is the HBM roofline (the path is bandwidth-shaped); THIS kernel sits close to three
+                # ceilings at once
+                "limiter": "co-limited: fp64 VALU issue (see valu), the in-place streaming rate of HBM (see inplace_stream) and the package power limit (profiles/r02_power.md)",
                 "kernel": "ode_step_kernel<Tp06Grl1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -571,6 +586,12 @@ def main():
                     "frac_of_issue_peak": valu["valu_instr_per_wave"] * valu.get("waves", n_local / 64.0) * 4.0 / (1024.0 * 2.4e9) / (ode_ms * 1e-3),
                     "effective_clock_GHz": valu["gui_cycles_per_xcd"] / (valu["avg_us"] * 1e-6) / 1e9,
                     "source": "profiles/r02_512_pmc.json (rocprofv3 SQ/GRBM pass of this command, tools/measure_round2.sh)",
+                },
+                "inplace_stream": None if stream_ms is None else {
+                    "what": "x *= 1.0 over the same state array (torch), 16 B per value, median of 5 launches after the timed region",
+                    "rate": 16.0 * flat.numel() / (stream_ms * 1e-3) / 1e9,
+                    "unit": "GB/s",
+                    "kernel_frac_of_it": achieved / (16.0 * flat.numel() / (stream_ms * 1e-3) / 1e9),
                 },
                 "whole_step": {
                     "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dt", type=float, default=0.05)
+    ap.add_argument("--trace", type=int, default=0, help="print mean PCG iterations and ms/step per window of this many steps")
     ap.add_argument("--save", default="", help="directory for rank<r>.npz (potential, layer markers, slab) after the run")
     args = ap.parse_args()
     import os
@@ -127,10 +128,17 @@ def main():
         t += dt
     torch.cuda.synchronize()
     tic = time.perf_counter()
-    for _ in range(args.steps):
+    tw = tic
+    for i in range(args.steps):
         solver.step((t, t + dt))
         its.append(pde.ksp.iterations)
         t += dt
+        if args.trace and (i + 1) % args.trace == 0 and mesh.comm.rank == 0:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            print(f"  steps {i + 1 - args.trace:5d}-{i + 1:5d} (t = {t:7.2f} ms): {np.mean(its[-args.trace:]):5.2f} its/step, "
+                  f"{(now - tw) / args.trace * 1e3:6.2f} ms/step", flush=True)
+            tw = now
     torch.cuda.synchronize()
     wall = time.perf_counter() - tic
     vmin, vmax = pde.state.field.minmax()
