@@ -280,3 +280,44 @@ def test_comm_allreduce_honours_the_reduction_op():
 
     with pytest.raises(ValueError):
         comm.allreduce(1.0, op="xor")
+
+
+def test_single_cell_pacing_of_a_host_callable(tmp_path):
+    """beat.single_cell.get_steady_state with an ordinary Python step function (the reference's convention:
+    fun(states=, t=, parameters=, dt=), src/beat/single_cell.py:86-156): nbeats repetitions of the times arange(0, BCL, dt),
+    tracked states recorded before every save_freq-th step of a beat, result cached under a key of function, inputs and
+    protocol -- against a literal double loop."""
+    import beat
+
+    calls = []
+
+    def fun(states, t, parameters, dt):
+        calls.append(t)
+        a, b = parameters
+        v, s = states
+        return np.array([v + dt * (-a * s + (1.0 if t < 0.25 else 0.0)), s + dt * b * v])
+
+    y0, P = np.array([1.0, 0.0]), np.array([2.0, 0.5])
+    dt, BCL, nbeats, every = 0.1, 1, 3, 0.3
+    y = beat.single_cell.get_steady_state(fun, y0, P, tmp_path / "cache", nbeats=nbeats, BCL=BCL, save_every_ms=every, dt=dt,
+                                          track_indices=[1, 0])
+    times = np.arange(0.0, BCL, dt)
+    assert len(calls) == nbeats * len(times) and np.allclose(calls[: len(times)], times) and calls[len(times)] == 0.0
+    ref, rows = y0.copy(), []
+    for _ in range(nbeats):
+        for j, t in enumerate(times):
+            if j % 3 == 0:
+                rows.append([ref[1], ref[0]])
+            ref = np.array([ref[0] + dt * (-2.0 * ref[1] + (1.0 if t < 0.25 else 0.0)), ref[1] + dt * 0.5 * ref[0]])
+    np.testing.assert_allclose(y, ref, rtol=1e-15)
+    tracked = np.load(next((tmp_path / "cache").glob("tracked_values_*.npy")))
+    assert tracked.shape == (nbeats * 4, 2)
+    np.testing.assert_allclose(tracked, np.array(rows), rtol=1e-15)
+    # second call: served from the cache (the function is not called again); other inputs: another key
+    n = len(calls)
+    y2 = beat.single_cell.get_steady_state(fun, y0, P, tmp_path / "cache", nbeats=nbeats, BCL=BCL, save_every_ms=every, dt=dt)
+    assert len(calls) == n and np.array_equal(y2, y)
+    k = beat.single_cell.compute_hash(fun, y0, P, nbeats, BCL, dt)
+    assert k != beat.single_cell.compute_hash(fun, y0 + 1e-12, P, nbeats, BCL, dt)
+    assert k != beat.single_cell.compute_hash(fun, y0, P, nbeats + 1, BCL, dt)
+    assert k != beat.single_cell.compute_hash(lambda states, t, parameters, dt: states * 2.0, y0, P, nbeats, BCL, dt)
