@@ -2,7 +2,7 @@
 # Round-2 measurement on the GPU box (run through gpurun from the repo root): the default bench line, then the SAME
 # bench command under rocprofv3 -- kernel trace + stats, and three PMC passes (FETCH_SIZE | WRITE_SIZE | SQ / GRBM
 # counters), each in its own run with the kernel trace only.  Results land in gpurun_out/prof_r02/; condense them with
-#   python tools/summarize_prof.py gpurun_out/prof_r02 profiles/r02_512.md "..." --json profiles/r02_512_pmc.json
+#   python tools/copy_round2_profiles.py     (-> profiles/r02_512.md, _pmc.json, _kernel_stats.csv, _bench.json)
 set -e
 R=$PWD
 O=$R/gpurun_out/prof_r02
