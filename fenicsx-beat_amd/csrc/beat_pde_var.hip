@@ -137,6 +137,91 @@ __device__ __forceinline__ double var_readlane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+// (helpers of var_rhs_kernel.  The SpMV below keeps its own, branchy form: rebuilt on these helpers it ran 0.65 instead of
+// 0.58 ms on a 401^3 shell -- 14.1 against 13.3 ms per step, alternated on one box.)
+// x at the 15 stencil points of node seg0 + lane, for all lanes of a 64-node segment at once (every lane of the wave
+// must call this).  nz[k]: this lane uses slot k; own0: the lane's node is an active node (slot 0).  A row value is
+// loaded from where it lives if the lane itself or the lane it is shifted to uses it, and from `safe` (an index inside
+// the slab) otherwise: every lane loads, so the loads of a segment are issued back to back instead of one branch and one
+// wait per row -- and what an unused lane loaded is never selected, so no address outside the box is formed and a
+// stale ghost plane cannot leak a NaN.
+__device__ __forceinline__ void var_row_values(const double* __restrict__ x, int64_t seg0, int lane, bool own0,
+                                               int64_t safe, int edge_off, const bool (&nz)[15], const int (&doff)[15],
+                                               double (&xk)[15]) {
+  // rows of the stencil: slot of the dx = 0 point, of the dx = +1 point and of the dx = -1 point (-1: none)
+  constexpr int kBase[7] = {0, 3, 4, 5, 6, 9, 10};
+  constexpr int kPlus[7] = {1, 7, -1, 11, -1, 13, -1};
+  constexpr int kMinus[7] = {2, -1, 8, -1, 12, -1, 14};
+  const int64_t i = seg0 + lane;
+  unsigned long long bp[7], bm[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    bp[r] = kPlus[r] >= 0 ? __ballot(nz[kPlus[r] >= 0 ? kPlus[r] : 0]) : 0ull;
+    bm[r] = kMinus[r] >= 0 ? __ballot(nz[kMinus[r] >= 0 ? kMinus[r] : 0]) : 0ull;
+  }
+  // values just outside the segment: lanes 0..3 fetch lane 63's +1 taps (rows 0, 1, 3, 5), lanes 4..7 lane 0's
+  // -1 taps (rows 0, 2, 4, 6); bit l of `edges`: lane l's value is wanted
+  const unsigned edges = (unsigned)(bp[0] >> 63) | (unsigned)(bp[1] >> 63) << 1 | (unsigned)(bp[3] >> 63) << 2 |
+                         (unsigned)(bp[5] >> 63) << 3 | (unsigned)(bm[0] & 1ull) << 4 | (unsigned)(bm[2] & 1ull) << 5 |
+                         (unsigned)(bm[4] & 1ull) << 6 | (unsigned)(bm[6] & 1ull) << 7;
+  const bool want_edge = lane < 8 && ((edges >> (lane & 7)) & 1u);
+  const double edge = x[want_edge ? seg0 + edge_off : safe];
+  // the seven row loads, issued together
+  double X[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int kb = kBase[r];
+    const bool own = kb == 0 ? own0 : nz[kb];
+    const unsigned long long wanted = (bp[r] << 1) | (bm[r] >> 1);  // lane l-1 wants its +1, lane l+1 its -1 tap
+    const bool take = own | (((wanted >> lane) & 1ull) != 0ull);
+    X[r] = x[take ? i + doff[kb] : safe];
+    xk[kb] = own ? X[r] : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    if (kPlus[r] >= 0) {
+      const int kp = kPlus[r] >= 0 ? kPlus[r] : 0;
+      const int e = r == 0 ? 0 : r == 1 ? 1 : r == 3 ? 2 : 3;
+      const double shifted = __shfl_down(X[r], 1, VAR_SEG);
+      const double v = lane == VAR_SEG - 1 ? var_readlane(edge, e) : shifted;
+      xk[kp] = nz[kp] ? v : 0.0;
+    }
+    if (kMinus[r] >= 0) {
+      const int km = kMinus[r] >= 0 ? kMinus[r] : 0;
+      const int e = r == 0 ? 4 : r == 2 ? 5 : r == 4 ? 6 : 7;
+      const double shifted = __shfl_up(X[r], 1, VAR_SEG);
+      const double v = lane == 0 ? var_readlane(edge, e) : shifted;
+      xk[km] = nz[km] ? v : 0.0;
+    }
+  }
+}
+
+// offset (from the first node of a segment) of the value lane `lane` < 8 fetches for var_row_values' segment edges
+__device__ __forceinline__ int var_edge_offset(int lane, const int (&doff)[15]) {
+  const int e = lane & 7;
+  const int off = e == 0 || e == 4 ? doff[0] : e == 1 ? doff[3] : e == 2 ? doff[5] : e == 3 ? doff[9]
+                  : e == 5 ? doff[4] : e == 6 ? doff[6] : doff[10];
+  return (e < 4 ? VAR_SEG : -1) + off;
+}
+
+// coefficient row of node i (0.0 on inactive lanes, which load the row of node `safe` instead of branching around the
+// loads); symmetric operator: the coefficient towards a backward neighbour is that neighbour's forward coefficient (see
+// var_stencil_kernel)
+__device__ __forceinline__ void var_row_coefficients(const double* __restrict__ T, int64_t ld, int64_t i, bool active,
+                                                     int64_t safe, const int (&doff)[15], double (&c)[15]) {
+  const int64_t ii = active ? i : safe;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    int64_t src = (int64_t)k * ld + ii;
+    if (k >= 2 && (k & 1) == 0) {
+      const int64_t jn = ii + doff[k];
+      if (jn >= 0) src = (int64_t)(k - 1) * ld + jn;
+    }
+    const double v = T[src];
+    c[k] = active ? v : 0.0;
+  }
+}
+
 __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
   __shared__ double red[4];
   if (a.st[STOP] != 0.0) return;
@@ -214,6 +299,65 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
   }
   const double s0 = beat_block_sum(acc0, red);
   if (threadIdx.x == 0) a.partials[a.part_off + blockIdx.x] = s0;
+}
+
+// The right-hand side of a step (what var_stencil_kernel<MODE_RHS> computes, same sums in the same order, so the
+// same bits) with the rows of v_ -- and of the guess increment e -- loaded once and shifted across the wave like the
+// SpMV's: T1 = A, T2 = K;  r0 = dt (stim - K v_),  b = A v_ + r0,  r = r0 - A e,  z = D^-1 r,  partials of b.b, r.z, r.r.
+// The 2 x 15 gathers per node of the plain kernel made it cost three SpMVs (1.82 against 0.58 ms on a 401^3 shell).
+__global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a) {
+  __shared__ double red[4];
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
+  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  const int edge_off = var_edge_offset(lane, a.doff);
+  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+    const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
+    const int64_t i = seg0 + lane;
+    const bool active = i >= a.i_lo && i < a.i_hi && (!a.seg || ((a.segmask[w] >> lane) & 1ull));
+    const int64_t safe = i < a.i_hi ? (i < a.i_lo ? a.i_lo : i) : a.i_hi - 1;
+    double cA[15], cK[15], xk[15];
+    bool nz[15];
+    var_row_coefficients(a.T1, a.ld, i, active, safe, a.doff, cA);
+    var_row_coefficients(a.T2, a.ld, i, active, safe, a.doff, cK);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) nz[k] = (cA[k] != 0.0) | (cK[k] != 0.0);
+    var_row_values(a.x, seg0, lane, active, safe, edge_off, nz, a.doff, xk);
+    double s1 = 0.0, s2 = 0.0, se = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      s1 = fma(cA[k], xk[k], s1);
+      s2 = fma(cK[k], xk[k], s2);
+    }
+    if (a.x2 != nullptr) {  // A e: only where A itself has an entry
+#pragma unroll
+      for (int k = 0; k < 15; ++k) nz[k] = cA[k] != 0.0;
+      var_row_values(a.x2, seg0, lane, active, safe, edge_off, nz, a.doff, xk);
+#pragma unroll
+      for (int k = 0; k < 15; ++k) se = fma(cA[k], xk[k], se);
+    }
+    if (active) {
+      double stim = 0.0;
+      for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][i], stim);
+      const double r0 = a.dt * (stim - s2);
+      const double b = s1 + r0;
+      const double r = r0 - se;
+      const double zz = a.dinv[i] * r;
+      a.y[i] = r;
+      a.y2[i] = zz;
+      acc0 = fma(b, b, acc0);
+      acc1 = fma(r, zz, acc1);
+      acc2 = fma(r, r, acc2);
+    }
+  }
+  const double s0 = beat_block_sum(acc0, red);
+  const double s1 = beat_block_sum(acc1, red);
+  const double s2 = beat_block_sum(acc2, red);
+  if (threadIdx.x == 0) {
+    a.partials[a.part_off + blockIdx.x] = s0;
+    a.partials[BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s1;
+    a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
+  }
 }
 
 // PCG vector updates over the active segments (per-node 1/diag)
@@ -492,6 +636,16 @@ static unsigned var_stencil_grid(unsigned wanted) {
   return std::min(wanted, resident);
 }
 
+// BEAT_VAR_RHS_GATHER=1: the right-hand side with one gather per stencil point (var_stencil_kernel<MODE_RHS>, the kernel
+// the row-shifting var_rhs_kernel is checked against bit for bit)
+static bool var_rhs_by_gathers() {
+  static const bool on = [] {
+    const char* e = getenv("BEAT_VAR_RHS_GATHER");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return on;
+}
+
 // launches over planes [z_lo, z_hi); returns the number of block partials written from part_off on.
 // `dense` ignores the segment list (APPLY must write every node of y).
 template <int MODE>
@@ -506,7 +660,12 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.nseg = r.nseg;
   if constexpr (MODE == MODE_SPMV_DOT)
     hipLaunchKernelGGL(var_spmv_kernel, dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
-  else
+  else if (MODE == MODE_RHS && !var_rhs_by_gathers()) {
+    static const unsigned resident = resident_blocks(var_rhs_kernel);
+    const unsigned grid = std::min(r.grid, resident);
+    hipLaunchKernelGGL(var_rhs_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+    return (int)grid;
+  } else
     hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0,
                        pde->ctx->stream, a);
   return (int)var_stencil_grid<MODE>(r.grid);

@@ -179,6 +179,26 @@ def test_per_node_theta_step_matches_direct_solve(hip_ctx, cells, L):
     np.testing.assert_allclose(fv.numpy(), out, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
+def test_row_shifting_rhs_kernel_equals_the_gather_kernel_bit_for_bit():
+    """var_rhs_kernel (rows of v_ and of the guess increment loaded once and shifted across the wave) against
+    var_stencil_kernel<RHS> (one gather per stencil point, BEAT_VAR_RHS_GATHER=1): identical bits in r, p, the reduced
+    scalars and every solution of two four-step sequences (without and with the extrapolated guess) on a masked shell with
+    a random fibre field.  Two fresh interpreters, since the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    script = Path(__file__).with_name("_var_rhs_script.py")
+    digests = []
+    for gather in ("1", "0"):
+        env = dict(os.environ, BEAT_VAR_RHS_GATHER=gather)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
+
+
 @pytest.mark.parametrize("lo_phys,hi_phys,nzl", [(0, 0, 5), (1, 0, 4), (0, 1, 3), (0, 0, 1), (0, 0, 2)])
 def test_per_node_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl):
     """Slab rows cut out of a larger masked grid: interior part with poisoned ghosts + boundary part equals the
