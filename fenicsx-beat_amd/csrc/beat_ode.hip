@@ -11,6 +11,10 @@
 #include <cstdlib>
 #include <vector>
 #include "ionic_models.h"
+
+#ifndef BEAT_ODE_PROBE
+#define BEAT_ODE_PROBE 0  // 1 / 2: probe builds of the plain step kernel (memory only / arithmetic only), tools/ode_probe.sh
+#endif
 #include "torord_dyncl.h"
 
 template <int NP>
@@ -103,7 +107,30 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
     } else {
+#if BEAT_ODE_PROBE == 1
+      // probe build (never shipped: -DBEAT_ODE_PROBE=1): the kernel's memory traffic alone -- every state read and
+      // written back, same grid and tile loop
+      double tmp[Model::NS];
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tmp[k] = io.load(k);
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) io.store(k, tmp[k] * 1.0000000001);
+#elif BEAT_ODE_PROBE == 2
+      // probe build (-DBEAT_ODE_PROBE=2): the kernel's arithmetic alone -- states of the block's first tile (cache hits),
+      // stores behind a condition that never holds
+      struct ProbeIO {
+        double* __restrict__ base;
+        int64_t ld, i, j;
+        __device__ __forceinline__ double load(int k) const { return base[(int64_t)k * ld + j]; }
+        __device__ __forceinline__ void store(int k, double v) const {
+          if (v == 1.2345e300) base[(int64_t)k * ld + i] = v;
+        }
+      };
+      const ProbeIO pio{states, ld, i, (int64_t)threadIdx.x};
+      Model::step(pio, p_uni, d_uni, fm, t, dt);
+#else
       Model::step(io, p_uni, d_uni, fm, t, dt);
+#endif
     }
   }
   }
