@@ -223,6 +223,115 @@ def cpu_baseline(n_side: int, steps: int, rtol: float):
     return out
 
 
+def progress(msg: str) -> None:
+    """One line on stderr per phase: what the launching parent's watchdog (launch_ranks) listens for."""
+    print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """``python bench.py --gpus N`` called directly (no launcher around it, as the driver calls it; the reference's CI
+    starts its parallel job itself too: .github/workflows/main-mpi.yml:33): this process never touches a GPU -- it
+    starts N fresh rank processes (``python -m torch.distributed.run --nproc-per-node N bench.py ...``), relays rank
+    0's one JSON line and their return code, and watches them: a job that prints nothing for longer than the watchdog
+    allows is killed (whole process group), and ONE more attempt is made in fresh children with the deadlock-proof
+    communication order (``BEAT_DIST_SERIAL=1``: ghost planes and all-reduces on one RCCL communicator, one stream).
+    Returns the exit code."""
+    import signal
+    import subprocess
+    import threading
+
+    n = args.gpus
+    backend = os.environ.get("BEAT_DIST_BACKEND", "nccl")
+    if backend == "nccl":  # one device per rank; counting devices does not initialise the GPU
+        try:
+            import torch
+
+            ndev = torch.cuda.device_count()
+        except Exception as exc:  # noqa: BLE001
+            print(f"bench.py: cannot count GPUs ({exc})", file=sys.stderr)
+            return 2
+        if ndev < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this host shows {ndev} "
+                  "(BEAT_DIST_BACKEND=gloo rehearses N ranks on fewer devices; its numbers mean nothing)", file=sys.stderr)
+            return 2
+    t_start = float(os.environ.get("BEAT_BENCH_WATCHDOG_START_S", "420"))  # first output: N x `import torch` on a cold box
+    t_phase = float(os.environ.get("BEAT_BENCH_WATCHDOG_S", str(max(180.0, 0.5 * (args.steps + args.warmup)))))
+    attempts = [{}]
+    if os.environ.get("BEAT_DIST_SERIAL", "0") != "1" and os.environ.get("BEAT_BENCH_NO_RETRY", "0") != "1":
+        attempts.append({"BEAT_DIST_SERIAL": "1"})
+    history = []
+    for k, extra in enumerate(attempts):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *argv]
+        env = dict(os.environ, **extra)
+        env.setdefault("OMP_NUM_THREADS", "4")
+        print(f"[bench launcher] attempt {k + 1}/{len(attempts)}: {n} ranks" + (f" with {extra}" if extra else ""), file=sys.stderr, flush=True)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        state = {"last": time.monotonic(), "seen": False}
+        out_lines = []
+
+        def pump(stream, sink, relay):
+            for line in stream:
+                state["last"] = time.monotonic()
+                state["seen"] = True
+                if relay:
+                    sys.stderr.write(line)
+                    sys.stderr.flush()
+                else:
+                    sink.append(line)
+
+        threads = [threading.Thread(target=pump, args=(proc.stdout, out_lines, False), daemon=True),
+                   threading.Thread(target=pump, args=(proc.stderr, None, True), daemon=True)]
+        for th in threads:
+            th.start()
+        timed_out = False
+        tic = time.monotonic()
+        while proc.poll() is None:
+            time.sleep(0.25)
+            silent = time.monotonic() - state["last"]
+            if silent > (t_phase if state["seen"] else t_start):
+                timed_out = True
+                print(f"[bench launcher] no output for {silent:.0f} s: killing the ranks", file=sys.stderr, flush=True)
+                for sig in (signal.SIGTERM, signal.SIGKILL):
+                    try:
+                        os.killpg(proc.pid, sig)  # the launcher and every rank (own session = own process group)
+                    except ProcessLookupError:
+                        break
+                    try:
+                        proc.wait(timeout=10)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                break
+        rc = proc.wait()
+        for th in threads:
+            th.join(timeout=5)
+        lines = [ln for ln in out_lines if ln.strip()]
+        history.append({"attempt": k + 1, "env": extra, "rc": rc, "timed_out": timed_out, "wall_s": round(time.monotonic() - tic, 1)})
+        if rc == 0 and not timed_out and len(lines) == 1:
+            try:
+                out = json.loads(lines[0])
+                out.setdefault("config", {})["launch"] = {"by": "bench.py --gpus N (self-launched ranks)", "attempts": history}
+                print(json.dumps(out), flush=True)
+            except ValueError:
+                print(lines[0], end="", flush=True)
+            return 0
+        print(f"[bench launcher] attempt {k + 1} failed: rc {rc}" + (", watchdog" if timed_out else "")
+              + (f", {len(lines)} stdout lines" if len(lines) != 1 else ""), file=sys.stderr, flush=True)
+    return history[-1]["rc"] or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,12 +359,18 @@ def main():
     args = ap.parse_args()
     global ISOTROPIC
     ISOTROPIC = args.iso
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # called without a launcher (``python bench.py --gpus N``): start the ranks as fresh children of a parent that
+        # stays away from the GPU, watch them, relay rank 0's line
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     # stdout carries exactly one line, the JSON result: libraries that write to file descriptor 1 themselves (RCCL
     # prints a five-line version banner when its communicator is created) are sent to stderr instead
     sys.stdout.flush()
     result_stream = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    if os.environ.get("BEAT_BENCH_TEST_HANG") == "1" and args.gpus > 1:  # tests of the launcher's watchdog: a rank that never reports
+        time.sleep(3600)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -286,6 +401,7 @@ def main():
 
     from beat import _hip
 
+    progress(f"process group up ({backend}, world {world})" if (world > 1 or force_dist) else "started")
     # a checkout without the built artefacts (the .so is not tracked): rank 0 builds, everybody waits -- the barrier is
     # unconditional, so a rank that only looks once the file is already there cannot skip it and leave rank 0 waiting
     if rank == 0 and not _hip.library_path().is_file():
@@ -392,6 +508,7 @@ def main():
         ev_pde_end = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         if mon is not None:
             mon.events.clear()
+        guess_fields, guess_orders = [], []
         iters, pend_counts = [], []  # pend: search directions the timed ionic launches applied for the previous solve
 
         def step(t, i=None):
@@ -399,6 +516,9 @@ def main():
             pend = ops.pending
             if i is not None:
                 pend_counts.append(pend[2] if pend else 0)
+                gt = ops.guess_traffic()  # increments this launch reads / writes for the initial guess (only if it applies the update)
+                guess_fields.append(gt["reads"] + gt["writes"] if (pend and gt["pending"]) else 0)
+                guess_orders.append(gt["order"])
             if use_api:
                 mon.armed = i
                 api_solver.step((t, t + DT))
@@ -438,11 +558,14 @@ def main():
             w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w.item())
-        return dict(t=t, wall=wall, iters=iters, pend_counts=pend_counts,
+        return dict(t=t, wall=wall, iters=iters, pend_counts=pend_counts, guess_fields=guess_fields, guess_orders=guess_orders,
                     ode_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_ode])),
                     pde_ms=float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(steps)])))
 
+    progress(f"set-up done ({n_local} nodes on this rank, transport "
+             f"{solver.libcomm.info()['transport'] if getattr(solver, 'libcomm', None) is not None else 'none'}); timing")
     run = timed_run(0.0, args.warmup, args.steps)
+    progress(f"headline timed: {run['wall'] / args.steps * 1e3:.3f} ms/step")
     wall, iters, pend_counts, ode_ms, pde_ms = run["wall"], run["iters"], run["pend_counts"], run["ode_ms"], run["pde_ms"]
     vmin, vmax = v_field.minmax()
     if world > 1:  # extrema over all slabs (NaN-propagating: a non-finite value on any rank shows)
@@ -466,7 +589,9 @@ def main():
         del prof
         ops.guess_reset()  # the recorded increments belong to the overwritten state
         setup_s = time.perf_counter() - tic
+        progress("developed front prepared; timing")
         fr = timed_run(0.0, max(args.warmup, 5), args.steps)
+        progress(f"developed front timed: {fr['wall'] / args.steps * 1e3:.3f} ms/step")
         fmin, fmax = v_field.minmax()
         if world > 1:
             ext = torch.tensor([-fmin, fmax, 0.0 if np.isfinite(fmin) and np.isfinite(fmax) else 1.0], dtype=torch.float64,
@@ -489,6 +614,51 @@ def main():
             "v_min": fmin,
             "v_max": fmax,
         }
+
+    # N > 1: what each rank did, and what the communication inside the solve costs.  Profiled on a few EXTRA steps after
+    # the timed regions (timing events around every exchange and all-reduce are not free): ms per step the ghost-plane
+    # transfers took on their stream, the all-reduces on the compute stream (waiting for the slowest rank included), and
+    # the compute stream stood waiting for ghost planes (= the part of the exchange the interior stencil did not hide).
+    ranks_info, comm_info = None, None
+    libcomm = getattr(solver, "libcomm", None)
+    if (world > 1 or force_dist) and finite:
+        prof = None
+        if libcomm is not None:
+            comm_info = libcomm.info()
+            if comm_info["transport"] != "callbacks":
+                nprof = 5
+                libcomm.profile(True)
+                t_prof = (fr if front else run)["t"]
+                for _ in range(nprof):
+                    if use_api:
+                        api_solver.step((t_prof, t_prof + DT))
+                    else:
+                        pend = ops.pending
+                        ops.pending = None
+                        _hip.check(lib.beat_ode_step_pending(ctx.handle, _hip.MODEL_TP06_GRL1, states.ptr, n_local, states.ld, p_ptr,
+                                                             len(p_host), None, 0, t_prof, DT, v_index, None, ops.handle, ops.ring[0].ptr,
+                                                             ops.fld, pend[2] if pend else 0))
+                        solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
+                    t_prof += DT
+                ops.flush_pending()
+                libcomm.profile(False)
+                raw = libcomm.profile_read()
+                prof = {"steps": nprof, "halo_ms_per_step": raw["halo_ms"] / nprof, "halo_exchanges_per_step": raw["halo_count"] / nprof,
+                        "allreduce_ms_per_step": raw["allreduce_ms"] / nprof, "allreduces_per_step": raw["allreduce_count"] / nprof,
+                        "halo_stall_ms_per_step": raw["halo_stall_ms"] / nprof}
+        k_pend_r = float(np.mean(run["pend_counts"])) if run["pend_counts"] else 0.0
+        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "planes": int(slab.nz), "nodes": int(n_local),
+                "ode_ms": run["ode_ms"], "pde_ms": run["pde_ms"], "comm": prof,
+                "roofline_ode": {"achieved": (16.0 * len(ic) + 8.0 * k_pend_r) * n_local / (run["ode_ms"] * 1e-3) / 1e9, "unit": "GB/s",
+                                 "note": "state rows + pending directions only (the guess's increments are added on rank 0's line)"}}
+        if front:
+            mine["front_ode_ms"], mine["front_pde_ms"] = fr["ode_ms"], fr["pde_ms"]
+        if world > 1:
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, mine)
+        else:
+            ranks_info = [mine]
+        progress("per-rank figures gathered")
 
     # What a trivial in-place kernel reaches on the very array the ionic kernel walks (every state read once and written
     # back once: x *= 1.0, bit-preserving), measured here, after the timed regions: the practical ceiling next to which
@@ -525,7 +695,8 @@ def main():
         # diffusion solve (the launch applies that solve's x += sum alpha_j p_j)
         k_pend = float(np.mean(pend_counts)) if pend_counts else 0.0
         # ... and, with an extrapolated initial guess, the increments it is built from (read) and the new one (written)
-        g_bytes = 8.0 * ((args.guess_order if args.guess_order > 0 else 4) + 2) if args.guess_order else 0.0  # reads e, d.., writes d, e
+        # (counted per launch from the terms of the update it applies, beat_pde_guess_traffic: the adaptive policy moves between orders)
+        g_bytes = 8.0 * float(np.mean(run["guess_fields"])) if run["guess_fields"] else 0.0
         ode_bytes = (16.0 * S + 8.0 * k_pend + g_bytes) * n_local
         achieved = ode_bytes / (ode_ms * 1e-3) / 1e9
         step_bytes = (16.0 * S + 16.0 + 88.0 * k_avg) * n_total
@@ -557,6 +728,7 @@ def main():
                                + ("" if backend == "nccl" else f" (REHEARSAL on {backend}, ranks share a GPU: not a measurement)"),
                 "pcg_iterations_per_step": k_avg,
                 "guess_order": args.guess_order,
+                "guess_order_used": (float(np.mean(run["guess_orders"])) if run["guess_orders"] else None),
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
                 "v_min": vmin,
@@ -574,6 +746,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else "profiles/r02_512_pmc.json (rocprofv3 PMC passes of this command at this size, committed; not re-measured in this run)",
                 "algorithmic_bytes_per_launch": ode_bytes,
                 "bytes_per_node": 16.0 * S + 8.0 * k_pend + g_bytes,
                 "pending_directions_per_launch": k_pend,
@@ -602,10 +775,69 @@ def main():
             },
         }
         out["developed_front"] = front
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+            out["config"]["comm"] = comm_info
+            if comm_info is not None:
+                out["config"]["rccl_ranks"] = comm_info["rccl_ranks"]
         if world == 1 and args.cpu_sample > 0:
+            progress("CPU baseline (oracle port on the host cores)")
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, args.rtol)
         else:
             out["cpu_baseline"] = None
+    else:
+        out = None
+
+    # N > 1: the same steps over the OTHER transports of the library (ghost planes as interprocess device copies instead
+    # of RCCL send/recv; everything on one communicator and one stream), a few steps each, so that one run on a multi-GPU
+    # node says what each costs.  Best effort under a deadline: the headline above is already measured, and if an
+    # alternative stops making progress every rank leaves (rank 0 printing the headline line first) instead of hanging.
+    if world > 1 and finite and libcomm is not None and os.environ.get("BEAT_BENCH_ALT", "1") == "1":
+        import threading
+
+        from beat._engine import LibComm, LibCommUnavailable
+
+        main_name = comm_info["transport"] if comm_info else "?"
+        transports = {main_name: {"ms_per_step": wall / args.steps * 1e3, "pcg_iterations_per_step": float(np.mean(iters)), "role": "headline"}}
+        deadline = float(os.environ.get("BEAT_BENCH_ALT_DEADLINE_S", "90"))
+
+        def give_up():
+            if rank == 0:
+                transports["error"] = f"an alternative transport made no progress for {deadline:.0f} s; abandoned"
+                out["transports"] = transports
+                print(json.dumps(out), file=result_stream, flush=True)
+            print(f"[bench rank {rank}] alternative transports abandoned at the deadline", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        alts = [("ipc", False)] if main_name != "ipc" else []
+        if backend == "nccl":
+            alts += [("rccl", True)] if main_name != "rccl-serial" else [("rccl", False)]
+        t_alt = (fr if front else run)["t"] + 10 * DT
+        for name, serial in alts:
+            label = name + ("-serial" if serial else "")
+            timer = threading.Timer(deadline, give_up)
+            timer.daemon = True
+            timer.start()
+            try:
+                progress(f"alternative transport {label}")
+                alt = LibComm(ctx, slab, dist, None, name, serial=serial, plane_doubles=plane)
+                solver.libcomm = alt
+                ar = timed_run(t_alt, 2, args.steps)
+                t_alt = ar["t"]
+                transports[label] = {"ms_per_step": ar["wall"] / args.steps * 1e3, "pcg_iterations_per_step": float(np.mean(ar["iters"])),
+                                     "ode_ms": ar["ode_ms"], "pde_ms": ar["pde_ms"], "comm": alt.info()}
+                ops.flush_pending()
+                torch.cuda.synchronize()
+                solver.libcomm = libcomm
+                alt.close()
+            except LibCommUnavailable as exc:  # raised on every rank alike
+                transports[label] = {"error": str(exc)}
+                solver.libcomm = libcomm
+            finally:
+                timer.cancel()
+        if rank == 0:
+            out["transports"] = transports
+    if rank == 0:
         print(json.dumps(out), file=result_stream, flush=True)
     if world > 1 or force_dist:
         dist.barrier()

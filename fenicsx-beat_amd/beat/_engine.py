@@ -402,6 +402,12 @@ class HipOps:
         """True when solves of this operator run as one launch of one workgroup (and beat_split_steps accepts it)."""
         return bool(self.lib.beat_pde_small_grid_solve_active(self.handle))
 
+    def guess_traffic(self) -> dict:
+        """Fields the last solve's x update reads / writes for the initial guess (beat_pde_guess_traffic)."""
+        out = (C.c_int * 4)()
+        _hip.check(self.lib.beat_pde_guess_traffic(self.handle, out))
+        return {"reads": int(out[0]), "writes": int(out[1]), "order": int(out[2]), "pending": bool(out[3])}
+
     def guess_reset(self) -> None:
         """Forget the recorded increments (the potential was overwritten: the next solve starts from x0 = v_)."""
         self.flush_pending()
@@ -503,17 +509,30 @@ class _HostStagedDist:
         t.copy_(host)
 
 
+class LibCommUnavailable(RuntimeError):
+    """Raised by LibComm on EVERY rank when any rank could not set its side up (agreed collectively)."""
+
+
 class LibComm:
     """``beat_comm`` of this rank (include/beat_hip.h): the transport the in-library decomposed solve uses.
 
     ``transport="rccl"``: RCCL communicators created by the library (ghost planes on its side stream, all-reduces
-    on the compute stream); rank 0's unique id reaches the other ranks through ``torch.distributed`` (any backend) --
-    that broadcast at set-up is all PyTorch contributes.  ``transport="callbacks"``: both operations are handed back
-    to Python and staged through the host over ``dist`` (gloo) -- the rehearsal transport for several ranks sharing
-    one GPU, where RCCL (one rank per device) cannot run.  ``peers``: override of (peer_lo, peer_hi), used by the
-    one-rank periodic self-exchange test."""
+    on the compute stream; ``serial=True`` / env ``BEAT_DIST_SERIAL=1``: one communicator, one stream); rank 0's
+    unique id reaches the other ranks through ``torch.distributed`` (any backend) -- that broadcast at set-up is all
+    PyTorch contributes.  ``transport="ipc"``: ghost planes as interprocess device-to-device copies (mailboxes mapped
+    with hipIpc*, interprocess events), all-reduces by RCCL when ``torch.distributed`` runs on nccl, handed back to
+    Python otherwise -- the transport that lets several processes sharing ONE GPU exchange planes on the device.
+    ``transport="callbacks"``: both operations are handed back to Python and staged through the host over ``dist``
+    (gloo) -- the rehearsal transport.  ``peers``: override of (peer_lo, peer_hi), used by the one-rank periodic
+    self-exchange tests.
 
-    def __init__(self, ctx, slab: Slab, dist=None, group=None, transport: str = "rccl", peers=None):
+    Set-up is collective and fails collectively: every step that can fail on one rank (rank 0's unique id, the
+    library calls, ``BEAT_TEST_FAIL_LIBCOMM_RANK``) is followed by an agreement over ``dist``, and no rank enters a
+    collective create (``ncclCommInitRank``) unless all are ready to -- otherwise every rank raises
+    :class:`LibCommUnavailable` (a rank failing alone would leave the others blocked in the next collective)."""
+
+    def __init__(self, ctx, slab: Slab, dist=None, group=None, transport: str = "rccl", peers=None, serial: bool | None = None,
+                 plane_doubles: int | None = None):
         self.ctx, self.slab, self.dist, self.group = ctx, slab, dist, group
         lib = ctx.lib
         rank, world = slab.rank, slab.world
@@ -522,29 +541,115 @@ class LibComm:
         handle = C.c_void_p()
         self.handle = None
         self.transport = transport
+        if serial is None:
+            serial = os.environ.get("BEAT_DIST_SERIAL", "0") == "1"
+        self.serial = bool(serial) and transport == "rccl"
+        if transport not in ("rccl", "ipc", "callbacks"):
+            raise ValueError(f"unknown transport {transport!r}")
+        collective = world > 1 and dist is not None and getattr(dist, "is_initialized", lambda: False)()
+        nccl = collective and dist.get_backend(group) == "nccl"
+        err = None
         if os.environ.get("BEAT_TEST_FAIL_LIBCOMM_RANK") == str(rank):  # tests: a rank whose communicator cannot be made
-            raise RuntimeError("simulated failure to create the library communicator (BEAT_TEST_FAIL_LIBCOMM_RANK)")
-        if transport == "rccl":
+            err = RuntimeError("simulated failure to create the library communicator (BEAT_TEST_FAIL_LIBCOMM_RANK)")
+
+        def agree(stage):
+            """Collective: raise on every rank if any rank holds an error."""
+            nonlocal err
+            failed = err is not None
+            if collective:
+                import torch
+
+                flag = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=ctx.device if nccl else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                failed = float(flag.item()) > 0.0
+            if failed:
+                if handle:
+                    lib.beat_comm_destroy(handle)
+                if err is not None and not collective:
+                    raise err
+                raise LibCommUnavailable(f"{transport} transport, {stage}: " + (str(err) if err is not None else "failed on another rank")) from err
+
+        ids = None
+        use_rccl = transport == "rccl" or (transport == "ipc" and (nccl or not collective) and os.environ.get("BEAT_IPC_ALLREDUCE", "rccl") == "rccl")
+        if use_rccl:
             ids = C.create_string_buffer(2 * _hip.UNIQUE_ID_BYTES)
-            if world > 1:
-                box = [None]
-                if rank == 0:
-                    _hip.check(lib.beat_comm_unique_id(ids))
-                    box[0] = ids.raw
+            box = [None]
+            if rank == 0 or not collective:
+                try:
+                    if err is None:
+                        _hip.check(lib.beat_comm_unique_id(ids))
+                        box[0] = ids.raw
+                except Exception as exc:  # noqa: BLE001
+                    err = exc
+            if collective:  # always runs, whatever happened on rank 0: the others are waiting in it
                 src = 0 if group is None else dist.get_global_rank(group, 0)
                 dist.broadcast_object_list(box, src=src, group=group)
-                ids = C.create_string_buffer(box[0], 2 * _hip.UNIQUE_ID_BYTES)
-            else:
-                _hip.check(lib.beat_comm_unique_id(ids))
-            _hip.check(lib.beat_comm_create_rccl(ctx.handle, rank, world, self.peer_lo, self.peer_hi, ids, C.byref(handle)))
-        elif transport == "callbacks":
+                if box[0] is None and err is None:
+                    err = RuntimeError("rank 0 could not produce the RCCL unique id")
+                elif box[0] is not None:
+                    ids = C.create_string_buffer(box[0], 2 * _hip.UNIQUE_ID_BYTES)
+            agree("unique id")
+        if transport == "rccl":
+            try:  # collective inside RCCL: entered only after every rank agreed it can
+                _hip.check(lib.beat_comm_create_rccl_ex(ctx.handle, rank, world, self.peer_lo, self.peer_hi, ids,
+                                                        _hip.COMM_SERIAL if self.serial else 0, C.byref(handle)))
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            agree("communicator")
+        elif transport == "ipc":
+            if plane_doubles is None:
+                raise ValueError("the ipc transport needs plane_doubles (size of one ghost plane)")
+            mine = C.create_string_buffer(_hip.IPC_HANDLE_BYTES)
+            self._allreduce_cb = None
+            cb = None
+            if not use_rccl:
+                self._allreduce_cb = _hip.ALLREDUCE_FN(self._allreduce)
+                cb = C.cast(self._allreduce_cb, C.c_void_p)
+            try:
+                if err is None:
+                    _hip.check(lib.beat_comm_create_ipc(ctx.handle, rank, world, self.peer_lo, self.peer_hi, int(plane_doubles),
+                                                        ids if use_rccl else None, cb, None, mine, C.byref(handle)))
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            agree("mailbox")
+            handles = {rank: mine.raw}
+            if collective:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, mine.raw, group=group)
+                handles = dict(enumerate(gathered))
+            try:
+                lo = handles.get(self.peer_lo) if self.peer_lo >= 0 and self.peer_lo != rank else None
+                hi = handles.get(self.peer_hi) if self.peer_hi >= 0 and self.peer_hi != rank else None
+                _hip.check(lib.beat_comm_ipc_connect(handle, lo, hi))
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            agree("connect")
+        else:
             self._halo_cb = _hip.HALO_FN(self._halo)          # keep the thunks alive with the object
             self._allreduce_cb = _hip.ALLREDUCE_FN(self._allreduce)
-            _hip.check(lib.beat_comm_create_callbacks(ctx.handle, rank, world, self.peer_lo, self.peer_hi, self._halo_cb,
-                                                      self._allreduce_cb, None, C.byref(handle)))
-        else:
-            raise ValueError(f"unknown transport {transport!r}")
+            try:
+                if err is None:
+                    _hip.check(lib.beat_comm_create_callbacks(ctx.handle, rank, world, self.peer_lo, self.peer_hi, self._halo_cb,
+                                                              self._allreduce_cb, None, C.byref(handle)))
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            agree("callbacks")
         self.handle = handle
+
+    def info(self) -> dict:
+        out = (C.c_int * 4)()
+        _hip.check(self.ctx.lib.beat_comm_info(self.handle, out))
+        return {"transport": _hip.TRANSPORT_NAMES.get(out[0], str(out[0])), "rccl_ranks": int(out[1]), "world": int(out[2]),
+                "allreduce": "rccl" if out[3] else "caller"}
+
+    def profile(self, enable: bool) -> None:
+        _hip.check(self.ctx.lib.beat_comm_profile(self.handle, int(bool(enable))))
+
+    def profile_read(self) -> dict:
+        out = (C.c_double * 6)()
+        _hip.check(self.ctx.lib.beat_comm_profile_read(self.handle, out))
+        return {"halo_ms": out[0], "halo_count": int(out[1]), "allreduce_ms": out[2], "allreduce_count": int(out[3]),
+                "halo_stall_ms": out[4], "halo_stall_count": int(out[5])}
 
     # -- host-staged callbacks (rehearsal transport) ------------------------------------------------------------
     def _d2h(self, ptr, count):
@@ -654,30 +759,15 @@ class DiffusionSolver:
                 # The library's own communicator.  Should creating it fail on any rank (librccl missing, a refused
                 # ncclCommInitRank), ALL ranks fall back together to the stage-driven loop over torch.distributed -- slower
                 # (Python per iteration, no initial guess) but the same numbers -- instead of leaving the job half-connected.
-                err = None
+                # LibComm's set-up fails on all ranks or on none (LibCommUnavailable).
+                transport = os.environ.get("BEAT_DIST_TRANSPORT") or ("rccl" if (nccl or slab.world == 1) else "callbacks")
                 try:
-                    self.libcomm = LibComm(ops.ctx, slab, dist, group, "rccl" if (nccl or slab.world == 1) else "callbacks")
-                except Exception as exc:  # noqa: BLE001
-                    err = exc
-                if slab.world > 1 and dist.is_initialized():
-                    import torch
-
-                    flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64,
-                                        device=ops.st.device if nccl else "cpu")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-                    failed = float(flag.item()) > 0.0
-                else:
-                    failed = err is not None
-                if failed:
-                    if slab.world == 1 and err is not None:
-                        raise err
-                    if self.libcomm is not None:
-                        self.libcomm.close()
-                        self.libcomm = None
+                    self.libcomm = LibComm(ops.ctx, slab, dist, group, transport, plane_doubles=ops.plane)
+                except LibCommUnavailable as exc:
                     import warnings
 
-                    warnings.warn("in-library communicator unavailable" + (f" ({err})" if err is not None else " on another rank")
-                                  + ": using the stage-driven loop over torch.distributed", RuntimeWarning, stacklevel=2)
+                    warnings.warn(f"in-library communicator unavailable ({exc}): using the stage-driven loop over torch.distributed",
+                                  RuntimeWarning, stacklevel=2)
         else:
             self.dist = None
 

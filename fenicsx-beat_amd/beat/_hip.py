@@ -94,6 +94,7 @@ SIGNATURES = {
     "beat_pde_guess_reset": (_int, [_vp]),
     "beat_pde_guess_pending": (_int, [_vp]),
     "beat_pde_guess_history": (_int, [_vp, _vp, _vp, _vp]),
+    "beat_pde_guess_traffic": (_int, [_vp, C.POINTER(_int)]),
     "beat_pde_set_preconditioner": (_int, [_vp, _int, _vp]),
     "beat_pde_pc_num_passes": (_int, [_vp]),
     "beat_pde_pc_pass": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
@@ -117,13 +118,23 @@ SIGNATURES = {
 # callbacks of a beat_comm whose transport is supplied by the caller (include/beat_hip.h)
 HALO_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _i64)
 ALLREDUCE_FN = C.CFUNCTYPE(_int, _vp, _vp, _int)
+ALLREDUCE_FN_OR_NULL = _vp  # an ALLREDUCE_FN cast to void* (ctypes function types do not accept None)
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 2048
+COMM_SERIAL = 1
+TRANSPORT_NAMES = {0: "callbacks", 1: "rccl", 2: "rccl-serial", 3: "ipc"}
 E_NOT_CONVERGED = -3
 
 SIGNATURES.update({
     "beat_pde_set_ghost_types": (_int, [_vp, _int, _int]),
     "beat_comm_unique_id": (_int, [_vp]),
     "beat_comm_create_rccl": (_int, [_vp, _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
+    "beat_comm_create_rccl_ex": (_int, [_vp, _int, _int, _int, _int, _vp, _int, C.POINTER(_vp)]),
+    "beat_comm_create_ipc": (_int, [_vp, _int, _int, _int, _int, _i64, _vp, ALLREDUCE_FN_OR_NULL, _vp, _vp, C.POINTER(_vp)]),
+    "beat_comm_ipc_connect": (_int, [_vp, _vp, _vp]),
+    "beat_comm_info": (_int, [_vp, C.POINTER(_int)]),
+    "beat_comm_profile": (_int, [_vp, _int]),
+    "beat_comm_profile_read": (_int, [_vp, C.POINTER(_dbl)]),
     "beat_comm_create_callbacks": (_int, [_vp, _int, _int, _int, _int, HALO_FN, ALLREDUCE_FN, _vp, C.POINTER(_vp)]),
     "beat_comm_destroy": (_int, [_vp]),
     "beat_comm_halo_exchange": (_int, [_vp, _vp, _i64, _i64]),

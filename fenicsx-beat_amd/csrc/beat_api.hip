@@ -8,6 +8,8 @@
 
 static thread_local std::string g_last_error;
 
+thread_local bool beat_tls_launched = false;
+
 void beat_set_error(const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -134,10 +136,10 @@ extern "C" int beat_copy(beat_ctx* ctx, double* dev_dst, const double* dev_src, 
   if (n == 0 || dev_dst == dev_src) return BEAT_OK;
   const bool aligned = (((uintptr_t)dev_dst | (uintptr_t)dev_src) & 15) == 0 && (n % 2 == 0);
   if (aligned)
-    hipLaunchKernelGGL(copy2_kernel, dim3(stream_grid(n / 2)), dim3(BEAT_BLOCK), 0, ctx->stream,
+    BEAT_KERNEL(copy2_kernel, dim3(stream_grid(n / 2)), dim3(BEAT_BLOCK), 0, ctx->stream,
                        (double2*)dev_dst, (const double2*)dev_src, n / 2);
   else
-    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
+    BEAT_KERNEL(copy_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
                        dev_src, n);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -146,7 +148,7 @@ extern "C" int beat_copy(beat_ctx* ctx, double* dev_dst, const double* dev_src, 
 extern "C" int beat_fill(beat_ctx* ctx, double* dev_dst, double value, int64_t n) {
   BEAT_REQUIRE(ctx != nullptr && dev_dst != nullptr && n >= 0, "bad argument");
   if (n == 0) return BEAT_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst, value, n);
+  BEAT_KERNEL(fill_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst, value, n);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -155,7 +157,7 @@ extern "C" int beat_gather(beat_ctx* ctx, double* dev_dst, const double* dev_src
                            const int64_t* dev_idx, int64_t n) {
   BEAT_REQUIRE(ctx != nullptr && dev_dst && dev_src && dev_idx && n >= 0, "bad argument");
   if (n == 0) return BEAT_OK;
-  hipLaunchKernelGGL(gather_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
+  BEAT_KERNEL(gather_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
                      dev_src, dev_idx, n);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -165,7 +167,7 @@ extern "C" int beat_scatter(beat_ctx* ctx, double* dev_dst, const double* dev_sr
                             const int64_t* dev_idx, int64_t n) {
   BEAT_REQUIRE(ctx != nullptr && dev_dst && dev_src && dev_idx && n >= 0, "bad argument");
   if (n == 0) return BEAT_OK;
-  hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
+  BEAT_KERNEL(scatter_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst,
                      dev_src, dev_idx, n);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -201,7 +203,7 @@ extern "C" int beat_field_probe(beat_ctx* ctx, const double* dev_field, const in
       b.idx[k] = host_idx[4 * base + k];
       b.w[k] = host_w[4 * base + k];
     }
-    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, ctx->d_small);
+    BEAT_KERNEL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, ctx->d_small);
     BEAT_LAUNCH_CHECK();
     BEAT_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * b.n, hipMemcpyDeviceToHost,
                                   ctx->stream));
@@ -223,7 +225,7 @@ extern "C" int beat_field_probe_record(beat_ctx* ctx, const double* dev_field, c
       b.idx[k] = host_idx[4 * base + k];
       b.w[k] = host_w[4 * base + k];
     }
-    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, dev_out + base);
+    BEAT_KERNEL(probe_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_field, b, dev_out + base);
     BEAT_LAUNCH_CHECK();
   }
   return BEAT_OK;
@@ -271,7 +273,7 @@ extern "C" int beat_interp2(beat_ctx* ctx, double* dev_dst, const double* dev_sr
                             const double* dev_w, int64_t n) {
   BEAT_REQUIRE(ctx != nullptr && dev_dst && dev_src && dev_idx && dev_w && n >= 0, "bad argument");
   if (n == 0) return BEAT_OK;
-  hipLaunchKernelGGL(interp2_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst, dev_src, dev_idx,
+  BEAT_KERNEL(interp2_kernel, dim3(stream_grid(n)), dim3(BEAT_BLOCK), 0, ctx->stream, dev_dst, dev_src, dev_idx,
                      dev_w, n);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void dot_partial_kernel(const double* _
 extern "C" int beat_field_dot(beat_ctx* ctx, const double* dev_x, const double* dev_y, int64_t n, double* host_out) {
   BEAT_REQUIRE(ctx != nullptr && dev_x && dev_y && host_out && n > 0, "bad argument");
   const unsigned grid = stream_grid(n) > 1024 ? 1024 : stream_grid(n);
-  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, dev_x, dev_y, n,
+  BEAT_KERNEL(dot_partial_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, dev_x, dev_y, n,
                      ctx->d_partials);
   BEAT_LAUNCH_CHECK();
   std::vector<double> h(grid);
@@ -309,7 +311,7 @@ extern "C" int beat_field_minmax(beat_ctx* ctx, const double* dev_field, int64_t
                                  double* host_max) {
   BEAT_REQUIRE(ctx != nullptr && dev_field && host_min && host_max && n > 0, "bad argument");
   const unsigned grid = stream_grid(n) > 1024 ? 1024 : stream_grid(n);
-  hipLaunchKernelGGL(minmax_partial_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, dev_field, n,
+  BEAT_KERNEL(minmax_partial_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, dev_field, n,
                      ctx->d_partials);
   BEAT_LAUNCH_CHECK();
   std::vector<double> h(2 * grid);

@@ -43,7 +43,25 @@ void beat_set_error(const char* fmt, ...);
     }                              \
   } while (0)
 
-#define BEAT_LAUNCH_CHECK() BEAT_HIP_CHECK(hipGetLastError())
+// A launch is checked with hipGetLastError, which (HIP 7) returns the last error of ANY runtime call this host thread has
+// made, however long ago -- another library's harmless probe included (seen: "invalid device ordinal" surfacing at the
+// check behind a launch helper that had nothing to launch, in a thread that had torn down an RCCL communicator).
+// BEAT_KERNEL drops whatever is pending before the launch, and BEAT_LAUNCH_CHECK only looks when a launch has been
+// made since the last check, so that it reads the launches' own verdict and nothing else.
+extern thread_local bool beat_tls_launched;
+#define BEAT_KERNEL(...)                         \
+  do {                                           \
+    if (!beat_tls_launched) (void)hipGetLastError(); \
+    beat_tls_launched = true;                    \
+    hipLaunchKernelGGL(__VA_ARGS__);             \
+  } while (0)
+#define BEAT_LAUNCH_CHECK()               \
+  do {                                    \
+    if (beat_tls_launched) {              \
+      beat_tls_launched = false;          \
+      BEAT_HIP_CHECK(hipGetLastError());  \
+    }                                     \
+  } while (0)
 
 // ---- wave / block reductions (fixed summation order => run-to-run deterministic) -------------
 __device__ __forceinline__ double beat_wave_sum(double v) {

@@ -5,11 +5,18 @@
 #include "beat_pde_internal.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace {
 using namespace beat_pde_detail;
@@ -21,6 +28,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -55,6 +63,7 @@ int load_rccl() {
   BEAT_SYM(GetUniqueId, "ncclGetUniqueId");
   BEAT_SYM(CommInitRank, "ncclCommInitRank");
   BEAT_SYM(CommDestroy, "ncclCommDestroy");
+  BEAT_SYM(CommCount, "ncclCommCount");
   BEAT_SYM(GroupStart, "ncclGroupStart");
   BEAT_SYM(GroupEnd, "ncclGroupEnd");
   BEAT_SYM(Send, "ncclSend");
@@ -76,10 +85,111 @@ int load_rccl() {
   } while (0)
 }  // namespace
 
+namespace {
+// ---- "ipc" transport: ghost planes as device-to-device copies between processes, no RCCL ------------------------
+// Every rank owns a mailbox in fine-grained device memory (exported with hipIpcGetMemHandle, peer-mapped by its two
+// neighbours): per direction IPC_SLOTS slots of IPC_FIELDS planes, and four sequence flags the neighbours write.  One
+// exchange (number s, the same on every rank: all ranks issue their exchanges in the same order) is two launches per
+// neighbour on the side stream, ordered ON THE DEVICE by those flags -- the hosts never wait for each other:
+//   send kernel:     [spin until the neighbour has emptied slot s % IPC_SLOTS: my freed[d] > s - IPC_SLOTS]  copy the
+//                    boundary plane(s) into the neighbour's mailbox; the last workgroup raises the neighbour's
+//                    arrived[1 - d] to s + 1 (system-scope release)
+//   receive kernel:  spin until my arrived[d] > s (acquire), copy mailbox -> ghost plane(s); the last workgroup
+//                    raises the neighbour's freed[1 - d] to s + 1
+// Every spin is bounded (BEAT_IPC_TIMEOUT_S, default 30 s on the GPU's 100 MHz wall clock): a wave that gives up
+// raises an error word in pinned host memory, which the solve reports after its next synchronisation -- no kernel
+// waits forever for a peer that died.  This is what RCCL's point-to-point does over xGMI, minus its channels and
+// proxy threads, and three processes sharing ONE GPU can run it -- which RCCL (one rank per device) cannot.
+// (A first version ordered plain hipMemcpyAsync copies with interprocess events, hipEventInterprocess: fine between
+// two processes, "invalid argument" from hipStreamWaitEvent on the middle one of three; tools/ipc_probe.cpp.)
+constexpr int IPC_SLOTS = 4;   // exchanges in flight per direction before a mailbox slot is reused
+constexpr int IPC_FIELDS = 2;  // fields per exchange (v_ and the guess increment travel together)
+constexpr uint32_t IPC_MAGIC = 0xbea71bc1u;
+constexpr int IPC_BLOCKS = 64;  // workgroups of a transfer kernel
+
+struct IpcFlags {  // in the mailbox, written by the neighbours (peer_lo's side: [0], peer_hi's: [1])
+  unsigned long long arrived[2];  // messages from that neighbour that have landed in this rank's mailbox
+  unsigned long long freed[2];    // messages this rank sent to that neighbour that it has taken out of its mailbox
+};
+
+struct IpcHandle {  // what beat_comm_create_ipc exports (BEAT_IPC_HANDLE_BYTES)
+  uint32_t magic, rank;
+  int64_t plane_max;
+  hipIpcMemHandle_t inbox;
+};
+static_assert(sizeof(IpcHandle) <= BEAT_IPC_HANDLE_BYTES, "ipc handle size");
+
+struct IpcPeer {  // a neighbour as this rank sees it
+  char* box = nullptr;  // its mailbox, peer-mapped (the local one when the neighbour is this rank itself)
+  bool connected = false, self = false;
+};
+
+struct IpcXfer {
+  const double* src[IPC_FIELDS];
+  double* dst[IPC_FIELDS];
+  int nf;
+  int64_t plane;
+  const unsigned long long* wait_flag;  // nullptr: nothing to wait for
+  unsigned long long wait_need;
+  unsigned long long* signal_flag;
+  unsigned long long signal_value;
+  unsigned int* counter;  // local, zero between launches: workgroups that have finished their share
+  long long ticks;
+  int* err;
+};
+
+// One direction of one exchange: wait for the flag, copy nf planes, the last workgroup to finish raises the other
+// side's flag.  Every workgroup polls the flag itself (thread 0; no workgroup depends on another one being scheduled).
+__global__ __launch_bounds__(256) void ipc_xfer_kernel(IpcXfer a) {
+  if (a.wait_flag != nullptr) {
+    if (threadIdx.x == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wait_need) {
+        if (wall_clock64() - t0 > a.ticks) {  // the peer is gone: say so and carry on (the data are wrong, the host will know)
+          __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int k = 0; k < a.nf; ++k)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.plane; i += stride) a.dst[k][i] = a.src[k][i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(a.signal_flag, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+inline size_t ipc_data_bytes(int64_t plane_max) {
+  return ((sizeof(double) * 2 * IPC_SLOTS * IPC_FIELDS * (size_t)plane_max + 255) / 256) * 256;
+}
+inline double* ipc_slot(char* box, int64_t plane_max, int dir, int slot, int field) {
+  return (double*)box + (((int64_t)dir * IPC_SLOTS + slot) * IPC_FIELDS + field) * plane_max;
+}
+inline IpcFlags* ipc_flags(char* box, int64_t plane_max) { return (IpcFlags*)(box + ipc_data_bytes(plane_max)); }
+
+struct ProfSpan {
+  hipEvent_t a, b;
+  int kind;  // 0: ghost-plane transfer (side stream), 1: all-reduce (compute stream), 2: compute stream stalled on the ghost planes
+};
+
+}  // namespace
+
 struct beat_comm {
   beat_ctx* ctx = nullptr;
   int rank = 0, world = 1, peer_lo = -1, peer_hi = -1;
-  bool rccl = false;
+  bool rccl = false;    // RCCL send/recv for the ghost planes
+  bool serial = false;  // ... on the compute stream, on the all-reduce communicator (one stream, one communicator)
+  bool ipc = false;     // ghost planes by interprocess device copies
   ncclComm_t p2p = nullptr, coll = nullptr;
   hipStream_t side = nullptr;          // ghost-plane traffic (non-blocking stream owned by the communicator)
   hipEvent_t ev_ready = nullptr;       // compute -> side: the planes to send are final
@@ -87,7 +197,90 @@ struct beat_comm {
   beat_halo_fn halo = nullptr;
   beat_allreduce_fn allreduce = nullptr;
   void* user = nullptr;
+  // ipc transport
+  int64_t ipc_plane_max = 0;
+  char* ipc_box = nullptr;             // this rank's mailbox: [2 directions][IPC_SLOTS][IPC_FIELDS][plane_max] doubles, then IpcFlags
+  unsigned int* ipc_counters = nullptr;  // device, local: [send lo, send hi, recv lo, recv hi]
+  int* ipc_err = nullptr;              // pinned host memory: set by a transfer kernel that gave up waiting
+  IpcPeer ipc_peer[2];
+  uint64_t ipc_seq = 0;
+  long long ipc_ticks = 30LL * 100000000LL;
+  // profiling (beat_comm_profile)
+  bool profiling = false;
+  std::vector<ProfSpan> spans;
 };
+
+namespace {
+void prof_clear(beat_comm* c) {
+  for (ProfSpan& s : c->spans) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  c->spans.clear();
+}
+
+// open a span on `stream`; returns its index or -1 (profiling off / no events to be had: profiling never fails a solve)
+int prof_begin(beat_comm* c, int kind, hipStream_t stream) {
+  if (!c->profiling || c->spans.size() >= 200000) return -1;
+  ProfSpan s{nullptr, nullptr, kind};
+  if (hipEventCreate(&s.a) != hipSuccess) return -1;
+  if (hipEventCreate(&s.b) != hipSuccess) {
+    (void)hipEventDestroy(s.a);
+    return -1;
+  }
+  (void)hipEventRecord(s.a, stream);
+  c->spans.push_back(s);
+  return (int)c->spans.size() - 1;
+}
+void prof_end(beat_comm* c, int idx, hipStream_t stream) {
+  if (idx >= 0) (void)hipEventRecord(c->spans[idx].b, stream);
+}
+
+void ipc_disconnect(beat_comm* c, IpcPeer& P) {
+  if (P.connected && !P.self && P.box) (void)hipIpcCloseMemHandle(P.box);
+  P = IpcPeer();
+}
+
+// releases whatever a (possibly half-built) communicator holds
+void comm_free(beat_comm* c) {
+  if (c == nullptr) return;
+  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->ctx && (c->rccl || c->ipc || c->coll)) (void)hipStreamSynchronize(c->ctx->stream);
+  prof_clear(c);
+  if (c->p2p) (void)g_rccl.CommDestroy(c->p2p);
+  if (c->coll) (void)g_rccl.CommDestroy(c->coll);
+  if (c->ipc) {
+    ipc_disconnect(c, c->ipc_peer[0]);
+    ipc_disconnect(c, c->ipc_peer[1]);
+    if (c->ipc_box) (void)hipFree(c->ipc_box);
+    if (c->ipc_counters) (void)hipFree(c->ipc_counters);
+    if (c->ipc_err) (void)hipHostFree(c->ipc_err);
+  }
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  (void)hipGetLastError();  // whatever the teardown left behind (RCCL's included) is not the next launch's business
+  delete c;
+}
+
+struct CommGuard {  // destroys a half-built communicator on every early return of a create function
+  beat_comm* c;
+  ~CommGuard() { comm_free(c); }
+  beat_comm* release() {
+    beat_comm* r = c;
+    c = nullptr;
+    return r;
+  }
+};
+
+int side_stream_and_events(beat_comm* c) {
+  BEAT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  return BEAT_OK;
+}
+}  // namespace
 
 extern "C" int beat_comm_unique_id(void* host_id_out) {
   BEAT_REQUIRE(host_id_out != nullptr, "null argument");
@@ -106,39 +299,47 @@ static int check_peers(int rank, int world, int peer_lo, int peer_hi) {
   return BEAT_OK;
 }
 
-extern "C" int beat_comm_create_rccl(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, const void* host_id,
-                                     beat_comm** out) {
-  BEAT_REQUIRE(ctx != nullptr && host_id != nullptr && out != nullptr, "null argument");
-  if (int rc = check_peers(rank, world, peer_lo, peer_hi)) return rc;
-  if (int rc = load_rccl()) return rc;
-  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
+static beat_comm* new_comm(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi) {
   beat_comm* c = new beat_comm();
   c->ctx = ctx;
   c->rank = rank;
   c->world = world;
   c->peer_lo = peer_lo;
   c->peer_hi = peer_hi;
+  return c;
+}
+
+extern "C" int beat_comm_create_rccl_ex(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi,
+                                        const void* host_id, int flags, beat_comm** out) {
+  BEAT_REQUIRE(ctx != nullptr && host_id != nullptr && out != nullptr, "null argument");
+  BEAT_REQUIRE((flags & ~BEAT_COMM_SERIAL) == 0, "unknown flags %d", flags);
+  if (int rc = check_peers(rank, world, peer_lo, peer_hi)) return rc;
+  if (int rc = load_rccl()) return rc;
+  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
+  CommGuard g{new_comm(ctx, rank, world, peer_lo, peer_hi)};
+  beat_comm* c = g.c;
   c->rccl = true;
+  c->serial = (flags & BEAT_COMM_SERIAL) != 0;
   const ncclUniqueId* ids = (const ncclUniqueId*)host_id;
-  BEAT_RCCL_CHECK(g_rccl.CommInitRank(&c->p2p, world, ids[0], rank));
+  // serial: ONE communicator carries the ghost planes and the all-reduces, all on the compute stream -- every rank
+  // enqueues the same operations in the same order on one stream, the ordering RCCL guarantees free of deadlock
+  if (!c->serial) BEAT_RCCL_CHECK(g_rccl.CommInitRank(&c->p2p, world, ids[0], rank));
   BEAT_RCCL_CHECK(g_rccl.CommInitRank(&c->coll, world, ids[1], rank));
-  BEAT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-  *out = c;
+  if (int rc = side_stream_and_events(c)) return rc;
+  *out = g.release();
   return BEAT_OK;
+}
+
+extern "C" int beat_comm_create_rccl(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, const void* host_id,
+                                     beat_comm** out) {
+  return beat_comm_create_rccl_ex(ctx, rank, world, peer_lo, peer_hi, host_id, 0, out);
 }
 
 extern "C" int beat_comm_create_callbacks(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi,
                                           beat_halo_fn halo, beat_allreduce_fn allreduce, void* user, beat_comm** out) {
   BEAT_REQUIRE(ctx != nullptr && halo != nullptr && allreduce != nullptr && out != nullptr, "null argument");
   if (int rc = check_peers(rank, world, peer_lo, peer_hi)) return rc;
-  beat_comm* c = new beat_comm();
-  c->ctx = ctx;
-  c->rank = rank;
-  c->world = world;
-  c->peer_lo = peer_lo;
-  c->peer_hi = peer_hi;
+  beat_comm* c = new_comm(ctx, rank, world, peer_lo, peer_hi);
   c->halo = halo;
   c->allreduce = allreduce;
   c->user = user;
@@ -146,21 +347,202 @@ extern "C" int beat_comm_create_callbacks(beat_ctx* ctx, int rank, int world, in
   return BEAT_OK;
 }
 
-extern "C" int beat_comm_destroy(beat_comm* c) {
-  if (c == nullptr) return BEAT_OK;
-  if (c->rccl) {
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->side);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->p2p) (void)g_rccl.CommDestroy(c->p2p);
-    if (c->coll) (void)g_rccl.CommDestroy(c->coll);
-    (void)hipEventDestroy(c->ev_ready);
-    (void)hipEventDestroy(c->ev_halo);
-    (void)hipStreamDestroy(c->side);
+extern "C" int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, int64_t max_plane_doubles,
+                                    const void* host_rccl_id, beat_allreduce_fn allreduce, void* user, void* host_handle_out,
+                                    beat_comm** out) {
+  BEAT_REQUIRE(ctx != nullptr && out != nullptr && host_handle_out != nullptr, "null argument");
+  BEAT_REQUIRE(max_plane_doubles > 0, "max_plane_doubles must be positive");
+  BEAT_REQUIRE((host_rccl_id != nullptr) != (allreduce != nullptr),
+               "exactly one of host_rccl_id (all-reduces by RCCL) and allreduce (by the caller) must be given");
+  if (int rc = check_peers(rank, world, peer_lo, peer_hi)) return rc;
+  BEAT_REQUIRE(!(peer_lo >= 0 && peer_lo == peer_hi && peer_lo != rank),
+               "both neighbours are rank %d: the ipc transport opens a neighbour's handle once", peer_lo);
+  BEAT_HIP_CHECK(hipSetDevice(ctx->device));
+  CommGuard g{new_comm(ctx, rank, world, peer_lo, peer_hi)};
+  beat_comm* c = g.c;
+  c->ipc = true;
+  c->ipc_plane_max = max_plane_doubles;
+  if (const char* e = std::getenv("BEAT_IPC_TIMEOUT_S")) c->ipc_ticks = (long long)(std::max(0.1, std::atof(e)) * 1.0e8);
+  if (host_rccl_id) {
+    if (int rc = load_rccl()) return rc;
+    const ncclUniqueId* ids = (const ncclUniqueId*)host_rccl_id;
+    BEAT_RCCL_CHECK(g_rccl.CommInitRank(&c->coll, world, ids[1], rank));
+  } else {
+    c->allreduce = allreduce;
+    c->user = user;
   }
-  delete c;
+  if (int rc = side_stream_and_events(c)) return rc;
+  const size_t bytes = ipc_data_bytes(max_plane_doubles) + sizeof(IpcFlags);
+  // fine-grained: what a neighbouring GPU writes over xGMI must be seen by this GPU's caches (coarse-grained memory is
+  // only coherent at kernel boundaries of the writing device).  BEAT_IPC_COARSE=1: plain hipMalloc (A/B on one GPU)
+  const char* coarse = std::getenv("BEAT_IPC_COARSE");
+  if (coarse && coarse[0] == '1')
+    BEAT_HIP_CHECK(hipMalloc((void**)&c->ipc_box, bytes));
+  else
+    BEAT_HIP_CHECK(hipExtMallocWithFlags((void**)&c->ipc_box, bytes, hipDeviceMallocFinegrained));
+  BEAT_HIP_CHECK(hipMemsetAsync(c->ipc_box, 0, bytes, c->side));
+  BEAT_HIP_CHECK(hipMalloc((void**)&c->ipc_counters, 4 * sizeof(unsigned int)));
+  BEAT_HIP_CHECK(hipMemsetAsync(c->ipc_counters, 0, 4 * sizeof(unsigned int), c->side));
+  BEAT_HIP_CHECK(hipHostMalloc((void**)&c->ipc_err, sizeof(int)));
+  *c->ipc_err = 0;
+  BEAT_HIP_CHECK(hipStreamSynchronize(c->side));
+  IpcHandle h;
+  std::memset(&h, 0, sizeof(h));
+  h.magic = IPC_MAGIC;
+  h.rank = (uint32_t)rank;
+  h.plane_max = max_plane_doubles;
+  BEAT_HIP_CHECK(hipIpcGetMemHandle(&h.inbox, c->ipc_box));
+  std::memset(host_handle_out, 0, BEAT_IPC_HANDLE_BYTES);
+  std::memcpy(host_handle_out, &h, sizeof(h));
+  *out = g.release();
   return BEAT_OK;
 }
+
+static int ipc_open_peer(beat_comm* c, IpcPeer& P, int peer, const void* host_handle) {
+  if (peer < 0) return BEAT_OK;
+  if (peer == c->rank) {  // a rank that is its own neighbour (periodic one-rank tests): no handle to open
+    P.self = true;
+    P.box = c->ipc_box;
+    P.connected = true;
+    return BEAT_OK;
+  }
+  BEAT_REQUIRE(host_handle != nullptr, "no handle given for neighbour %d", peer);
+  IpcHandle h;
+  std::memcpy(&h, host_handle, sizeof(h));
+  BEAT_REQUIRE(h.magic == IPC_MAGIC && (int)h.rank == peer, "handle is not rank %d's ipc handle", peer);
+  BEAT_REQUIRE(h.plane_max == c->ipc_plane_max, "neighbour %d sized its mailbox for planes of %lld doubles, this rank for %lld",
+               peer, (long long)h.plane_max, (long long)c->ipc_plane_max);
+  BEAT_HIP_CHECK(hipIpcOpenMemHandle((void**)&P.box, h.inbox, hipIpcMemLazyEnablePeerAccess));
+  P.connected = true;
+  return BEAT_OK;
+}
+
+extern "C" int beat_comm_ipc_connect(beat_comm* c, const void* host_handle_lo, const void* host_handle_hi) {
+  BEAT_REQUIRE(c != nullptr && c->ipc, "not an ipc communicator");
+  BEAT_REQUIRE(!c->ipc_peer[0].connected && !c->ipc_peer[1].connected, "already connected");
+  BEAT_HIP_CHECK(hipSetDevice(c->ctx->device));
+  if (int rc = ipc_open_peer(c, c->ipc_peer[0], c->peer_lo, host_handle_lo)) return rc;
+  if (int rc = ipc_open_peer(c, c->ipc_peer[1], c->peer_hi, host_handle_hi)) return rc;
+  return BEAT_OK;
+}
+
+extern "C" int beat_comm_destroy(beat_comm* c) {
+  comm_free(c);
+  return BEAT_OK;
+}
+
+extern "C" int beat_comm_info(beat_comm* c, int* host_out) {
+  BEAT_REQUIRE(c != nullptr && host_out != nullptr, "null argument");
+  host_out[0] = c->ipc ? BEAT_TRANSPORT_IPC : c->rccl ? (c->serial ? BEAT_TRANSPORT_RCCL_SERIAL : BEAT_TRANSPORT_RCCL)
+                                                      : BEAT_TRANSPORT_CALLBACKS;
+  int count = 0;
+  if (c->coll) BEAT_RCCL_CHECK(g_rccl.CommCount(c->coll, &count));  // ranks as RCCL itself counts them
+  host_out[1] = count;
+  host_out[2] = c->world;
+  host_out[3] = c->coll != nullptr;  // all-reduces by RCCL (1) or handed back to the caller (0)
+  return BEAT_OK;
+}
+
+extern "C" int beat_comm_profile(beat_comm* c, int enable) {
+  BEAT_REQUIRE(c != nullptr, "null argument");
+  if (enable) {
+    if (c->side) BEAT_HIP_CHECK(hipStreamSynchronize(c->side));
+    BEAT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    prof_clear(c);
+  }
+  c->profiling = enable != 0;
+  return BEAT_OK;
+}
+
+extern "C" int beat_comm_profile_read(beat_comm* c, double* host_out) {
+  BEAT_REQUIRE(c != nullptr && host_out != nullptr, "null argument");
+  if (c->side) BEAT_HIP_CHECK(hipStreamSynchronize(c->side));
+  BEAT_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+  for (int k = 0; k < 6; ++k) host_out[k] = 0.0;
+  for (const ProfSpan& s : c->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;  // a span whose end was never recorded
+    host_out[2 * s.kind] += ms;
+    host_out[2 * s.kind + 1] += 1.0;
+  }
+  return BEAT_OK;
+}
+
+namespace {
+int ipc_check(beat_comm* c) {
+  if (c->ipc && c->ipc_err && *(volatile int*)c->ipc_err) {
+    beat_set_error("ipc transport: rank %d gave up waiting for a neighbour (peers %d, %d): the exchanged planes are not valid",
+                   c->rank, c->peer_lo, c->peer_hi);
+    return BEAT_EHIP;
+  }
+  return BEAT_OK;
+}
+
+int ipc_halo_start(beat_comm* c, double* const* fields, int nf, int64_t n, int64_t plane) {
+  BEAT_REQUIRE(plane <= c->ipc_plane_max, "plane of %lld doubles, the mailboxes hold %lld", (long long)plane,
+               (long long)c->ipc_plane_max);
+  BEAT_REQUIRE(nf <= IPC_FIELDS, "at most %d fields per exchange", IPC_FIELDS);
+  const int peers[2] = {c->peer_lo, c->peer_hi};
+  for (int d = 0; d < 2; ++d)
+    BEAT_REQUIRE(peers[d] < 0 || c->ipc_peer[d].connected, "beat_comm_ipc_connect has not been called");
+  if (int rc = ipc_check(c)) return rc;
+  const uint64_t s = c->ipc_seq++;
+  const int slot = (int)(s % IPC_SLOTS);
+  const int64_t pm = c->ipc_plane_max;
+  IpcFlags* mine = ipc_flags(c->ipc_box, pm);
+  BEAT_HIP_CHECK(hipEventRecord(c->ev_ready, c->ctx->stream));
+  BEAT_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  const int span = prof_begin(c, 0, c->side);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(IPC_BLOCKS, (plane + 1023) / 1024));
+  // all sends first (to either neighbour), then the receives: no rank waits for a message before it has posted its own
+  for (int d = 0; d < 2; ++d) {
+    if (peers[d] < 0) continue;
+    IpcPeer& P = c->ipc_peer[d];
+    const int od = 1 - d;  // this rank is the neighbour's neighbour in the opposite direction
+    IpcXfer x{};
+    x.nf = nf;
+    x.plane = plane;
+    for (int k = 0; k < nf; ++k) {
+      x.src[k] = d == 0 ? fields[k] : fields[k] + n - plane;
+      x.dst[k] = ipc_slot(P.box, pm, od, slot, k);
+    }
+    if (s >= (uint64_t)IPC_SLOTS) {  // the slot's previous message must have left the neighbour's mailbox
+      x.wait_flag = &mine->freed[d];
+      x.wait_need = s - IPC_SLOTS + 1;
+    }
+    x.signal_flag = &ipc_flags(P.box, pm)->arrived[od];
+    x.signal_value = s + 1;
+    x.counter = c->ipc_counters + d;
+    x.ticks = c->ipc_ticks;
+    x.err = c->ipc_err;
+    BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks), dim3(256), 0, c->side, x);
+  }
+  for (int d = 0; d < 2; ++d) {
+    if (peers[d] < 0) continue;
+    IpcPeer& P = c->ipc_peer[d];
+    const int od = 1 - d;
+    IpcXfer x{};
+    x.nf = nf;
+    x.plane = plane;
+    for (int k = 0; k < nf; ++k) {
+      x.src[k] = ipc_slot(c->ipc_box, pm, d, slot, k);
+      x.dst[k] = d == 0 ? fields[k] - plane : fields[k] + n;
+    }
+    x.wait_flag = &mine->arrived[d];
+    x.wait_need = s + 1;
+    x.signal_flag = &ipc_flags(P.box, pm)->freed[od];
+    x.signal_value = s + 1;
+    x.counter = c->ipc_counters + 2 + d;
+    x.ticks = c->ipc_ticks;
+    x.err = c->ipc_err;
+    BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks), dim3(256), 0, c->side, x);
+  }
+  BEAT_LAUNCH_CHECK();
+  prof_end(c, span, c->side);
+  BEAT_HIP_CHECK(hipEventRecord(c->ev_halo, c->side));
+  return BEAT_OK;
+}
+}  // namespace
 
 // Start the exchange of the boundary planes of `f` (interior pointer, n doubles, ghost planes around it) -- and of a
 // second field `f2` in the same RCCL group when given (one group latency for both) -- on the side stream once the
@@ -169,6 +551,7 @@ static int halo_start(beat_comm* c, double* f, int64_t n, int64_t plane, double*
   if (c->peer_lo < 0 && c->peer_hi < 0) return BEAT_OK;
   double* fields[2] = {f, f2};
   const int nf = f2 ? 2 : 1;
+  if (c->ipc) return ipc_halo_start(c, fields, nf, n, plane);
   if (!c->rccl) {
     for (int k = 0; k < nf; ++k) {
       double* g = fields[k];
@@ -181,8 +564,13 @@ static int halo_start(beat_comm* c, double* f, int64_t n, int64_t plane, double*
     }
     return BEAT_OK;
   }
-  BEAT_HIP_CHECK(hipEventRecord(c->ev_ready, c->ctx->stream));
-  BEAT_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  hipStream_t stream = c->serial ? c->ctx->stream : c->side;
+  ncclComm_t comm = c->serial ? c->coll : c->p2p;
+  if (!c->serial) {
+    BEAT_HIP_CHECK(hipEventRecord(c->ev_ready, c->ctx->stream));
+    BEAT_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  }
+  const int span = prof_begin(c, 0, stream);
   // posting order: both sends, then the receives in the opposite order -- between two different ranks messages of
   // one direction are matched in the order posted (field by field on both sides); on a one-rank communicator whose
   // two peers are the rank itself (tests) it makes the exchange periodic (ghost_hi <- first plane, ghost_lo <- last)
@@ -193,26 +581,35 @@ static int halo_start(beat_comm* c, double* f, int64_t n, int64_t plane, double*
     double* ghost_lo = c->peer_lo >= 0 ? g - plane : nullptr;
     const double* last = c->peer_hi >= 0 ? g + n - plane : nullptr;
     double* ghost_hi = c->peer_hi >= 0 ? g + n : nullptr;
-    if (first) BEAT_RCCL_CHECK(g_rccl.Send(first, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
-    if (last) BEAT_RCCL_CHECK(g_rccl.Send(last, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
-    if (ghost_hi) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_hi, (size_t)plane, ncclDouble, c->peer_hi, c->p2p, c->side));
-    if (ghost_lo) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_lo, (size_t)plane, ncclDouble, c->peer_lo, c->p2p, c->side));
+    if (first) BEAT_RCCL_CHECK(g_rccl.Send(first, (size_t)plane, ncclDouble, c->peer_lo, comm, stream));
+    if (last) BEAT_RCCL_CHECK(g_rccl.Send(last, (size_t)plane, ncclDouble, c->peer_hi, comm, stream));
+    if (ghost_hi) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_hi, (size_t)plane, ncclDouble, c->peer_hi, comm, stream));
+    if (ghost_lo) BEAT_RCCL_CHECK(g_rccl.Recv(ghost_lo, (size_t)plane, ncclDouble, c->peer_lo, comm, stream));
   }
   BEAT_RCCL_CHECK(g_rccl.GroupEnd());
-  BEAT_HIP_CHECK(hipEventRecord(c->ev_halo, c->side));
+  prof_end(c, span, stream);
+  if (!c->serial) BEAT_HIP_CHECK(hipEventRecord(c->ev_halo, c->side));
   return BEAT_OK;
 }
 
 // Make the compute stream wait for the ghost planes of the exchange started last.
 static int halo_wait(beat_comm* c) {
-  if (!c->rccl || (c->peer_lo < 0 && c->peer_hi < 0)) return BEAT_OK;
+  if (!(c->rccl || c->ipc) || c->serial || (c->peer_lo < 0 && c->peer_hi < 0)) return BEAT_OK;
+  const int span = prof_begin(c, 2, c->ctx->stream);
   BEAT_HIP_CHECK(hipStreamWaitEvent(c->ctx->stream, c->ev_halo, 0));
+  prof_end(c, span, c->ctx->stream);
   return BEAT_OK;
 }
 
+// In-place sum over the ranks.  Inside beat_pde_solve_dist the all-reduces of iterations enqueued beyond the one that
+// latched STOP still run (the stage kernels around them exit at once): they re-sum slots that were already reduced
+// (PQ, RZN, RRN grow by a factor `world` per such iteration); nothing reads those slots afterwards -- ITERS, RR, BB,
+// REASON and NUPD are written by the scalar step, which the latch stops.
 static int allreduce_sum(beat_comm* c, double* dev, int count) {
-  if (c->rccl) {
+  if (c->coll) {
+    const int span = prof_begin(c, 1, c->ctx->stream);
     BEAT_RCCL_CHECK(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, c->coll, c->ctx->stream));
+    prof_end(c, span, c->ctx->stream);
     return BEAT_OK;
   }
   const int rc = c->allreduce(c->user, dev, count);
@@ -257,26 +654,42 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   int rc;
   const bool rr = beat_rr_available(pde);  // constant coefficients: the kernels that never store q = A p
   // ghost planes of v_ for the right-hand side (the reference's scatter_forward after the previous solve) and, in the
-  // same exchange, of the guess increment e (written by the x update of the previous solve)
+  // same exchange, of the guess increment e (written by the x update of the previous solve): they travel while the
+  // right-hand side is built on the planes that need neither, the one or two boundary planes follow
   const bool guess_path = (rr || pde->var) && pde->guess_order != 0 && pde->d_guess != nullptr && pde->hist_n >= 1;
+  if (rr || pde->var) {
+    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+    beat_guess_begin(pde);
+    BEAT_REQUIRE(!pde->guess.use_e || guess_path, "guess increment without ghost planes");
+  }
   if ((rc = halo_start(comm, const_cast<double*>(dev_v_prev), n, plane, guess_path ? pde->d_guess : nullptr))) return rc;
-  if ((rc = halo_wait(comm))) return rc;
+  static const bool split_rhs = [] {  // BEAT_DIST_RHS_SPLIT=0: wait for the planes first, one launch (A/B runs)
+    const char* e = std::getenv("BEAT_DIST_RHS_SPLIT");
+    return !(e && e[0] == '0');
+  }();
   if (rr) {
-    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
-    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
-    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
-    beat_guess_begin(pde);
-    BEAT_REQUIRE(!pde->guess.use_e || guess_path, "guess increment without ghost planes");
-    rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+    if (split_rhs) {
+      if ((rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st, 0))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st, 1);
+    } else {
+      if ((rc = halo_wait(comm))) return rc;
+      rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+    }
   } else if (pde->var) {
-    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
-    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
-    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
-    beat_guess_begin(pde);
-    BEAT_REQUIRE(!pde->guess.use_e || guess_path, "guess increment without ghost planes");
-    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
-                      pde->guess.use_e ? pde->guess.e : nullptr);
+    const double* e = pde->guess.use_e ? pde->guess.e : nullptr;
+    if (split_rhs) {
+      if ((rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, e, 0))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, e, 1);
+    } else {
+      if ((rc = halo_wait(comm))) return rc;
+      rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, e);
+    }
   } else {
+    if ((rc = halo_wait(comm))) return rc;
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }
   if (rc) return rc;
@@ -328,6 +741,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     launched += chunk;
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
     BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if ((rc = ipc_check(comm))) return rc;
     if (h[STOP] != 0.0 || launched >= max_it) break;
     chunk = 2;
   }

@@ -229,10 +229,10 @@ static int launch_ode_run(beat_ctx* ctx, double* states, int64_t n, int64_t ld, 
   const unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
-    hipLaunchKernelGGL((ode_run_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld, prm,
+    BEAT_KERNEL((ode_run_kernel<Model, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld, prm,
                        drv, ppn, pld, t0, dt, nsteps, nbeats, save_freq, tr, trace);
   } else {
-    hipLaunchKernelGGL((ode_run_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld,
+    BEAT_KERNEL((ode_run_kernel<Model, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, states, n, ld,
                        prm, drv, ppn, pld, t0, dt, nsteps, nbeats, save_freq, tr, trace);
   }
   BEAT_LAUNCH_CHECK();
@@ -282,7 +282,7 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   if (grid_cap > 0) grid = std::min(grid, (unsigned)grid_cap);
   const dim3 g3(grid), b3(BEAT_BLOCK);
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
-  hipLaunchKernelGGL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
+  BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
                      dt, v_index, v_copy, pend)
   if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);

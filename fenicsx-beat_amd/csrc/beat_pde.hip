@@ -555,9 +555,9 @@ using namespace beat_pde_detail;
 #define BEAT_LAUNCH_VEC(pde, kernel, ...)                                   \
   do {                                                                      \
     if ((pde)->var)                                                         \
-      hipLaunchKernelGGL((kernel<true>), __VA_ARGS__);                      \
+      BEAT_KERNEL((kernel<true>), __VA_ARGS__);                      \
     else                                                                    \
-      hipLaunchKernelGGL((kernel<false>), __VA_ARGS__);                     \
+      BEAT_KERNEL((kernel<false>), __VA_ARGS__);                     \
   } while (0)
 
 static Coef15 interior(const double* tab) {
@@ -717,9 +717,9 @@ static void launch_stencil(const beat_pde* pde, const StencilArgs& a, const Geom
   const dim3 grid(stencil_grid(g)), block(BEAT_BLOCK);
   hipStream_t s = pde->ctx->stream;
   switch (g.tile_tx) {
-    case 256: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<256, 4>>), grid, block, 0, s, g, a); break;
-    case 128: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<128, 8>>), grid, block, 0, s, g, a); break;
-    default: hipLaunchKernelGGL((stencil_kernel<MODE, Tile<64, 16>>), grid, block, 0, s, g, a); break;
+    case 256: BEAT_KERNEL((stencil_kernel<MODE, Tile<256, 4>>), grid, block, 0, s, g, a); break;
+    case 128: BEAT_KERNEL((stencil_kernel<MODE, Tile<128, 8>>), grid, block, 0, s, g, a); break;
+    default: BEAT_KERNEL((stencil_kernel<MODE, Tile<64, 16>>), grid, block, 0, s, g, a); break;
   }
 }
 
@@ -741,7 +741,7 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
 }
 
 int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+  BEAT_KERNEL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const double*)pde->ctx->d_partials, count, nsum, out, st, counter);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -787,7 +787,7 @@ extern "C" int beat_pde_rhs(beat_pde* pde, const double* dev_v_prev, const doubl
 
 extern "C" int beat_pde_cg_begin(beat_pde* pde, double* dev_st, double rtol, double atol, int max_it) {
   BEAT_REQUIRE(pde != nullptr && dev_st, "null argument");
-  hipLaunchKernelGGL(pcg_begin_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st, rtol, atol,
+  BEAT_KERNEL(pcg_begin_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st, rtol, atol,
                      (double)max_it);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -902,10 +902,10 @@ extern "C" int beat_pde_pc_pass(beat_pde* pde, int j, const double* dev_r, doubl
 // p = z + beta p after the scalar roll (polynomial-preconditioned variant of beat_pde_cg_next)
 extern "C" int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_z && dev_p, "null argument");
-  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
+  BEAT_KERNEL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
                      (const double*)dev_st, dev_z, dev_p);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -915,7 +915,7 @@ extern "C" int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* d
 extern "C" int beat_pde_cg_first_z(beat_pde* pde, double* dev_st, const double* dev_z, double* dev_p) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_z && dev_p, "null argument");
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
+  BEAT_KERNEL(cg_pupdate_z_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n,
                      (const double*)dev_st, dev_z, dev_p);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -923,7 +923,7 @@ extern "C" int beat_pde_cg_first_z(beat_pde* pde, double* dev_st, const double* 
 
 extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_p) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p, "null argument");
-  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
   BEAT_LAUNCH_VEC(pde, cg_pupdate_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_p, pde->dinv_arg(), pde->h_dinv[13]);
@@ -956,7 +956,7 @@ extern "C" int beat_pde_cg_next_oop(beat_pde* pde, double* dev_st, const double*
                                     double* dev_p_next) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_p_cur && dev_p_next, "null argument");
   BEAT_REQUIRE(dev_p_cur != dev_p_next, "the p-update is out of place");
-  hipLaunchKernelGGL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
   if (pde->var) return beat_var_pupdate_oop(pde, dev_st, dev_r, dev_p_cur, dev_p_next);
   BEAT_LAUNCH_VEC(pde, cg_pupdate_oop_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
@@ -972,7 +972,7 @@ int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, c
   if (dev_st == nullptr) dev_st = pde->d_st;  // the scalar state of beat_pde_solve[_ex]
   if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
+  BEAT_KERNEL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
                      dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full, gt);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -1058,6 +1058,23 @@ extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_d, doubl
   if (dev_d) *dev_d = pde->d_hist[0];
   if (dev_e) *dev_e = pde->d_guess;
   if (count) *count = pde->hist_n;
+  return BEAT_OK;
+}
+
+extern "C" int beat_pde_guess_traffic(const beat_pde* pde, int* host_out) {
+  BEAT_REQUIRE(pde != nullptr && host_out != nullptr, "null argument");
+  const GuessTerms& g = pde->guess_pending ? pde->guess_final : pde->guess;
+  int reads = 0, writes = 0;
+  if (g.d != nullptr) {
+    reads += (g.accumulate || g.use_e) ? 1 : 0;          // e
+    reads += (g.accumulate || g.cd != 0.0) ? 1 : 0;      // the oldest increment kept
+    for (int j = 0; j < BEAT_GUESS_MAX_ORDER - 2; ++j) reads += (!g.accumulate && g.cp[j] != 0.0) ? 1 : 0;
+    writes = 2;                                          // d, e
+  }
+  host_out[0] = reads;
+  host_out[1] = writes;
+  host_out[2] = pde->guess_order < 0 ? pde->auto_cur : pde->guess_order;
+  host_out[3] = pde->guess_pending ? 1 : 0;
   return BEAT_OK;
 }
 

@@ -72,6 +72,7 @@ struct beat_pde {
   beat_pde_detail::GuessTerms guess{};     // terms of the solve in progress (out == nullptr: not in use)
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
   beat_pde_detail::GuessTerms guess_final{};  // ... with these terms
+  int rhs_part_blocks = 0;  // block partials written by part 0 of a right-hand side built in two parts
   bool small_enabled = true;  // grids of a few thousand nodes: whole solve in one launch (beat_pde_small.hip)
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
@@ -110,7 +111,8 @@ int beat_var_form_A(beat_pde* pde);
 int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y);
 int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                  const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red,
-                 const double* dev_e = nullptr);  // dev_e: initial-guess increment (r = b - A (v_ + e)) or nullptr
+                 const double* dev_e = nullptr,  // dev_e: initial-guess increment (r = b - A (v_ + e)) or nullptr
+                 int part = -1);  // decomposed grids: 0 = the planes that need no ghost data, 1 = the boundary planes + the sums; -1: all
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);
@@ -145,7 +147,7 @@ int beat_small_solve(beat_pde* pde, const double* dev_v_prev, const double* cons
 // register-row kernels of the constant-coefficient Jacobi-PCG that never stores q = A p (beat_pde_rr.hip)
 bool beat_rr_available(const beat_pde* pde);
 int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
-                int n_stim, double* dev_x, double* dev_r, double* dev_st);
+                int n_stim, double* dev_x, double* dev_r, double* dev_st, int part = -1);  // part: as beat_var_rhs
 int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new);
 int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
                       int part);

@@ -509,7 +509,7 @@ void launch_rr(const beat_pde* pde, const RGeom& g, const RArgs& a) {
   const dim3 grid((unsigned)grid_blocks(g)), block(BEAT_BLOCK);  // xcd_block() deals whole runs to the 8 XCDs
   hipStream_t s = pde->ctx->stream;
 #define BEAT_RR_LAUNCH(RYV, PDV) \
-  hipLaunchKernelGGL((rr_kernel<MODE, RYV, PDV, GUESS>), grid, block, 0, s, g, a, a.x, GUESS ? a.e : a.x2, a.y, a.y2)
+  BEAT_KERNEL((rr_kernel<MODE, RYV, PDV, GUESS>), grid, block, 0, s, g, a, a.x, GUESS ? a.e : a.x2, a.y, a.y2)
   const int pd = rr_prefetch();
   if (g.ry == 2) {
     if (pd == 2) BEAT_RR_LAUNCH(2, 2); else if (pd == 3) BEAT_RR_LAUNCH(2, 3); else BEAT_RR_LAUNCH(2, 1);
@@ -532,7 +532,7 @@ bool beat_rr_available(const beat_pde* pde) {
 
 // Right-hand side in residual form (see beat_pde_rhs) without the p output.
 int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp,
-                int n_stim, double* dev_x, double* dev_r, double* dev_st) {
+                int n_stim, double* dev_x, double* dev_r, double* dev_st, int part) {
   const GuessTerms& gt = pde->guess;
   const bool guess = gt.d != nullptr && gt.use_e;
   // with a guess the kernel holds two register windows (v_ and e): 2 rows per wave keep it at the other kernels' occupancy
@@ -541,7 +541,7 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
     const int v = e ? std::atoi(e) : 2;
     return v == 4 ? 4 : 2;
   }();
-  const RGeom g = guess ? make_geom(pde, 0, pde->g.nz, 0, guess_rows) : make_geom(pde);
+  const int rows = guess ? guess_rows : 0;
   RArgs a{};
   a.x = dev_v_prev;
   a.y = dev_r;
@@ -570,12 +570,35 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
     a.e = gt.e;
     a.taba = pde->d_tab(0);
     a.cia = interior_row(pde->h_A);
-    launch_rr<RR_RHS, true>(pde, g, a);
-  } else {
-    launch_rr<RR_RHS>(pde, g, a);
   }
+  auto launch = [&](const RGeom& g) {
+    if (guess)
+      launch_rr<RR_RHS, true>(pde, g, a);
+    else
+      launch_rr<RR_RHS>(pde, g, a);
+    return g.total_blocks > 0 ? grid_blocks(g) : 0;
+  };
+  const Geom& f = pde->g;
+  if (part < 0) {
+    const int nb = launch(make_geom(pde, 0, f.nz, 0, rows));
+    BEAT_LAUNCH_CHECK();
+    return beat_pde_launch_reduce(pde, nb, 3, dev_st, nullptr);
+  }
+  // in two parts on a decomposed grid (as beat_rr_pdot_part): the planes whose stencil needs no ghost plane of v_ / e
+  // while those travel, then the one or two slab-boundary planes and the reduction over all block partials
+  const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0, rows);
+  if (part == 0) {
+    launch(gi);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
+  int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
+  if (!f.z_lo_phys) off += launch(make_geom(pde, 0, 1, off, rows));
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch(make_geom(pde, f.nz - 1, f.nz, off, rows));
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, grid_blocks(g), 3, dev_st, nullptr);
+  BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+  return beat_pde_launch_reduce(pde, off, 3, dev_st, nullptr);
 }
 
 // p_new = D^-1 r + st[BETA] p_old (p_old unread while beta = 0), LOCAL p_new . A p_new -> dev_st[PQ].
@@ -649,7 +672,7 @@ int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev
 }
 
 int beat_rr_next(beat_pde* pde, double* dev_st) {
-  hipLaunchKernelGGL(rr_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
+  BEAT_KERNEL(rr_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }

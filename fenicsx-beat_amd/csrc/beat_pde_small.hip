@@ -321,7 +321,7 @@ int beat_small_launch(beat_pde* pde, const double* dev_v_prev, const double* con
                                          160 * 1024));                                                                  \
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
-    hipLaunchKernelGGL((pcg_small_kernel<MV>), dim3(1), dim3(SMALL_THREADS), lds, s, a);                                \
+    BEAT_KERNEL((pcg_small_kernel<MV>), dim3(1), dim3(SMALL_THREADS), lds, s, a);                                \
   } while (0)
   if (per_thread <= 2)
     BEAT_SMALL_LAUNCH(2);

@@ -659,14 +659,14 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.segmask = r.segmask;
   a.nseg = r.nseg;
   if constexpr (MODE == MODE_SPMV_DOT)
-    hipLaunchKernelGGL(var_spmv_kernel, dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+    BEAT_KERNEL(var_spmv_kernel, dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
   else if (MODE == MODE_RHS && !var_rhs_by_gathers()) {
     static const unsigned resident = resident_blocks(var_rhs_kernel);
     const unsigned grid = std::min(r.grid, resident);
-    hipLaunchKernelGGL(var_rhs_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+    BEAT_KERNEL(var_rhs_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
     return (int)grid;
   } else
-    hipLaunchKernelGGL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0,
+    BEAT_KERNEL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0,
                        pde->ctx->stream, a);
   return (int)var_stencil_grid<MODE>(r.grid);
 }
@@ -679,7 +679,7 @@ static unsigned var_vec_grid(const beat_pde* pde) {
 
 int beat_var_form_A(beat_pde* pde) {
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
+  BEAT_KERNEL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
                      pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, pde->v_A, pde->v_dinv);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -710,7 +710,7 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
   std::vector<unsigned long long> flags((size_t)nsegs), masks;
   hipError_t e = hipMalloc(&d_flags, sizeof(unsigned long long) * (size_t)nsegs);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, (nsegs + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK)),
+    BEAT_KERNEL(var_segment_flags_kernel, dim3((unsigned)std::min<int64_t>(4096, (nsegs + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK)),
                        dim3(BEAT_BLOCK), 0, ctx->stream, p->n, dev_mass, d_flags);
     e = hipGetLastError();
   }
@@ -749,7 +749,7 @@ extern "C" int beat_rows_apply_dirichlet(beat_ctx* ctx, const int64_t n[3], doub
   for (int k = 0; k < 15; ++k)
     offs.doff[k] = kOffsets[3 * k] + (int)n[0] * kOffsets[3 * k + 1] + (int)(n[0] * n[1]) * kOffsets[3 * k + 2];
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  hipLaunchKernelGGL(rows_dirichlet_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, nn, ld, dev_rows, dev_flag,
+  BEAT_KERNEL(rows_dirichlet_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, nn, ld, dev_rows, dev_flag,
                      dev_g, dev_f, offs);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
@@ -798,7 +798,7 @@ extern "C" int beat_pde_assemble_rows(beat_ctx* ctx, const int64_t n[3], const i
     a.Me = d_t + 8 * 8 * 9;
     const int64_t nn = n[0] * n[1] * n[2];
     const unsigned grid = (unsigned)std::min<int64_t>(8192, (nn + BEAT_BLOCK - 1) / BEAT_BLOCK);
-    hipLaunchKernelGGL(assemble_rows_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, a);
+    BEAT_KERNEL(assemble_rows_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, a);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host tensors and d_t go out of scope
   }
@@ -834,7 +834,7 @@ int beat_var_apply(beat_pde* pde, int which, const double* dev_x, double* dev_y)
 
 int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                  const double* host_stim_amp, int n_stim, double* dev_x, double* dev_r, double* dev_p, double* dev_red,
-                 const double* dev_e) {
+                 const double* dev_e, int part) {
   VarArgs a{};
   var_offsets(pde, a);
   a.T1 = pde->v_A;
@@ -844,7 +844,7 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
   a.y = dev_r;
   a.y2 = dev_p;
   a.y3 = nullptr;
-  if (dev_x != dev_v_prev)  // nodes outside the tissue keep their value: copy everything first
+  if (dev_x != dev_v_prev && part <= 0)  // nodes outside the tissue keep their value: copy everything first
     BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice,
                                   pde->ctx->stream));
   a.dinv = pde->v_dinv;
@@ -856,9 +856,26 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
     ++a.nstim;
   }
   a.partials = pde->ctx->d_partials;
-  const int nb = launch_var<MODE_RHS>(pde, a, 0, pde->g.nz, 0);
+  if (part < 0) {
+    const int nb = launch_var<MODE_RHS>(pde, a, 0, pde->g.nz, 0);
+    BEAT_LAUNCH_CHECK();
+    return beat_pde_launch_reduce(pde, nb, 3, dev_red, nullptr);
+  }
+  // in two parts on a decomposed grid (as beat_var_spmv_dot_part): the planes that need no ghost plane of v_ / e while
+  // those travel, then the slab-boundary planes and the reduction over all block partials
+  const Geom& f = pde->g;
+  const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
+  if (part == 0) {
+    pde->rhs_part_blocks = launch_var<MODE_RHS>(pde, a, lo, std::max(lo, hi), 0);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
+  int off = pde->rhs_part_blocks;
+  if (!f.z_lo_phys) off += launch_var<MODE_RHS>(pde, a, 0, 1, off);
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch_var<MODE_RHS>(pde, a, f.nz - 1, f.nz, off);
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, nb, 3, dev_red, nullptr);
+  BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+  return beat_pde_launch_reduce(pde, off, 3, dev_red, nullptr);
 }
 
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
@@ -900,7 +917,7 @@ int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, do
 
 int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   const unsigned grid = var_vec_grid(pde);
-  hipLaunchKernelGGL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask,
+  BEAT_KERNEL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask,
                      (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_q, (const double*)pde->v_dinv,
                      pde->ctx->d_partials, pde->d_alphas, slot);
   BEAT_LAUNCH_CHECK();
@@ -908,7 +925,7 @@ int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double
 }
 
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next) {
-  hipLaunchKernelGGL(var_pupdate_oop_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+  BEAT_KERNEL(var_pupdate_oop_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_p_cur,
                      dev_p_next, (const double*)pde->v_dinv);
   BEAT_LAUNCH_CHECK();
@@ -917,7 +934,7 @@ int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, con
 
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                    int ring_base, int only_if_full, const GuessTerms& gt) {
-  hipLaunchKernelGGL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
+  BEAT_KERNEL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
                      (const double*)pde->d_alphas, ring_base, only_if_full, gt);
   BEAT_LAUNCH_CHECK();

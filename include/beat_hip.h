@@ -303,6 +303,11 @@ int beat_pde_guess_pending(const beat_pde* pde);
 /* the last recorded increment, the guess increment prepared for the next solve, and the number of solves on record
  * since the history was dropped, capped at 4 (tests, checkpoints) */
 int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, int* count);
+/* What the x update of the last solve (the pending one, if it was deferred to the next ionic kernel) moves for the
+ * guess's bookkeeping: host_out[4] = {fields it reads (e, the increments its extrapolation uses), fields it writes
+ * (d, e: 2, or 0 without a guess), the order in use (the adaptive policy's current one for order -1), 1 if that
+ * update is still pending}.  8 bytes per node each: what bench.py charges the ionic kernel for. */
+int beat_pde_guess_traffic(const beat_pde* pde, int* host_out);
 
 /* Small grids (constant coefficients, Jacobi, undivided, <= 8192 nodes -- the reference's own CPU-sized cases, e.g.
  * the Niederer slab at dx = 0.5 mm): beat_pde_solve[_ex] runs the whole solve -- right-hand side, every iteration,
@@ -363,6 +368,13 @@ typedef struct beat_comm beat_comm;
 int beat_comm_unique_id(void* host_id_out /* 2 * BEAT_UNIQUE_ID_BYTES: ids of the two communicators */);
 int beat_comm_create_rccl(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, const void* host_id,
                           beat_comm** out);
+/* flags = BEAT_COMM_SERIAL: ONE communicator carries ghost planes and all-reduces, everything on the compute stream
+ * -- no overlap, but every rank enqueues the same RCCL operations in the same order on one stream, the ordering
+ * that cannot deadlock whatever the GPUs' schedulers do with two concurrent RCCL kernels (bench.py's launcher
+ * falls back to it when a run with the two-communicator transport stops making progress). */
+#define BEAT_COMM_SERIAL 1
+int beat_comm_create_rccl_ex(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, const void* host_id,
+                             int flags, beat_comm** out);
 /* Exchange the slab-boundary planes of one field: the first interior plane goes to peer_lo and the plane
  * received from it lands in the ghost plane below the field; likewise the last plane / upper ghost plane with
  * peer_hi.  dev_* point at the four planes (each plane_doubles long); a side without a peer passes NULL. */
@@ -371,7 +383,38 @@ typedef int (*beat_halo_fn)(void* user, const double* dev_first, double* dev_gho
 typedef int (*beat_allreduce_fn)(void* user, double* dev_values, int count); /* in-place sum over the ranks */
 int beat_comm_create_callbacks(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, beat_halo_fn halo,
                                beat_allreduce_fn allreduce, void* user, beat_comm** out);
+/*  - ipc: ghost planes as device-to-device copies between processes, without RCCL: every rank owns a mailbox in
+ *    fine-grained device memory that its two neighbours map (hipIpcGetMemHandle / hipIpcOpenMemHandle); a transfer
+ *    kernel on the side stream copies the boundary planes into the neighbour's mailbox and raises a sequence flag
+ *    there, the neighbour's transfer kernel spins (bounded) on that flag and moves the planes into its ghost planes --
+ *    ordering is done on the device, the hosts never wait for each other.  Over xGMI between the GPUs of one node,
+ *    inside one GPU when several ranks share it (where RCCL, one rank per device, cannot run: that is how the overlap
+ *    of the exchange with the interior stencil is measured on a one-GPU box).  The all-reduces go through RCCL
+ *    (host_rccl_id = the 2 x 128-byte id of beat_comm_unique_id; its second communicator is created) or through the
+ *    caller (allreduce / user).  Set-up is two steps: every rank creates its side and gets BEAT_IPC_HANDLE_BYTES to
+ *    publish; once it holds its neighbours' handles it connects (pass NULL for an absent neighbour; a rank that is
+ *    its own neighbour needs none).  All ranks must issue their exchanges in the same order (the decomposed solve
+ *    does).  A neighbour that stops responding is reported (BEAT_IPC_TIMEOUT_S, default 30 s), not waited for. */
+#define BEAT_IPC_HANDLE_BYTES 2048
+int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, int64_t max_plane_doubles,
+                         const void* host_rccl_id, beat_allreduce_fn allreduce, void* user, void* host_handle_out,
+                         beat_comm** out);
+int beat_comm_ipc_connect(beat_comm* comm, const void* host_handle_lo, const void* host_handle_hi);
 int beat_comm_destroy(beat_comm* comm);
+/* host_out[4]: transport (BEAT_TRANSPORT_*), ranks of the all-reduce communicator as RCCL itself counts them
+ * (ncclCommCount; 0 without RCCL), world as given at creation, 1 if the all-reduces are RCCL's. */
+#define BEAT_TRANSPORT_CALLBACKS 0
+#define BEAT_TRANSPORT_RCCL 1
+#define BEAT_TRANSPORT_RCCL_SERIAL 2
+#define BEAT_TRANSPORT_IPC 3
+int beat_comm_info(beat_comm* comm, int* host_out);
+/* Event timing of the communication inside the decomposed solve (RCCL and ipc transports): enable = 1 drops what
+ * was collected and starts, 0 stops.  beat_comm_profile_read synchronises and fills host_out[6] = {ms the ghost-plane
+ * transfers took on their stream, their number, ms the all-reduces took on the compute stream (waiting for the
+ * slowest rank included), their number, ms the compute stream stood waiting for ghost planes, number of waits}.  The
+ * events cost a few microseconds each: profile a few extra steps, not the timed region. */
+int beat_comm_profile(beat_comm* comm, int enable);
+int beat_comm_profile_read(beat_comm* comm, double* host_out);
 /* The two operations on their own (set-up code, tests): complete in stream order on the context's stream. */
 int beat_comm_halo_exchange(beat_comm* comm, double* dev_field, int64_t n, int64_t plane_doubles);
 int beat_comm_allreduce_sum(beat_comm* comm, double* dev_values, int count);

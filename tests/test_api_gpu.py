@@ -418,6 +418,53 @@ def test_strang_splitting_against_oracle():
     assert err.max() < 1e-7, err.max()
 
 
+def test_isotropic_slab_tp06_trajectory_against_oracle():
+    """BASELINE.json configs[2] in small: the benchmark's own isotropic set-up (bench.py --iso: M = 9.5301e-4 I, h = 0.1 mm,
+    C_m = 0.01, theta_pde = 0.5, Godunov splitting, dt = 0.01, TP06 GRL1 at the Niederer initial values, a 60 mV Gaussian
+    bump on V and 1 % noise on the other states, no stimulus) through the public API -- fused split step, default
+    adaptive initial guess -- against the oracle (NumPy TP06 + literally assembled P1 matrices + sparse LU) over 40
+    steps: every state of every node to 1e-8 relative."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+    from oracle import fem, ionic
+
+    cells, h, dt, nsteps = (20, 16, 12), 0.1, 0.01, 40
+    L = tuple(c * h for c in cells)
+    M = 9.5301e-4 * np.eye(3)
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array(L)], list(cells))
+    time = g.Constant(mesh, 0.0)
+    pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, C_m=0.01, params={"theta": 0.5, "petsc_options": {"ksp_rtol": 1e-13, "ksp_atol": 1e-50}})
+    ic = tp06.init_state_values()
+    vi = tp06.state_index("V")
+    om = fem.BoxMesh(cells, L)
+    rng = np.random.default_rng(1234)
+    S0 = np.repeat(ic[:, None], om.num_nodes, axis=1) * (1.0 + 0.01 * rng.uniform(-1.0, 1.0, (19, om.num_nodes)))
+    S0[vi] = ic[vi] + 60.0 * np.exp(-((om.x - 0.5 * np.array(L)) ** 2).sum(axis=1) / (2.0 * 0.4**2))
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(g.functionspace(mesh, ("P", 1))), v_pde=pde.state,
+                                         fun=tp06.generalized_rush_larsen, init_states=S0,
+                                         parameters=tp06.init_parameter_values(stim_amplitude=0.0), num_states=19, v_index=vi)
+    solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+    model = fem.OracleMonodomainModel(om, M, [], C_m=0.01, theta=0.5)
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    S = S0.copy()
+    its = []
+    for i in range(nsteps):
+        t0 = i * dt
+        solver.step((t0, t0 + dt))
+        its.append(pde.ksp.getIterationNumber())
+        S = ionic.tp06_generalized_rush_larsen(S, t0, dt, P)
+        model.state[:] = S[vi]
+        model.assign_previous()
+        model.step((t0, t0 + dt))
+        S[vi] = model.state
+    out = np.asarray(ode.values)
+    err = np.abs(out - S) / np.maximum(np.abs(S), 1e-3)
+    assert err.max() < 1e-8, err.max()
+    assert out[vi].max() > -40.0 and out[vi].min() < -80.0  # the bump is still up, the far field at rest
+    assert all(k <= 40 for k in its) and np.mean(its[10:]) < np.mean(its[:3])  # the extrapolated guess took over
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_land_cell_model_in_the_split_step_against_oracle(fused):
     """The 52-state ToR-ORd + Land model (beat.models.torord_land, odes/torord/ToRORd_dynCl_endo_Land.ode) as ``fun`` of

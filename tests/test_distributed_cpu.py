@@ -205,3 +205,24 @@ def test_voxel_mask_per_node_rows_slab_decomposed(world, tmp_path):
     A = model.A.tocsr()
     _, its_ref, _ = fem.pcg_jacobi(A, model.rhs(THETA * DT, DT), v_prev, rtol=1e-12)
     assert abs(int(parts[0]["its"]) - its_ref) <= 1
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """``python bench.py --gpus 8`` on a host that shows fewer devices: one clear line, non-zero exit, within seconds,
+    before any rank process is started (counting devices does not initialise a GPU)."""
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    import torch
+
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this host has 8 GPUs")
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BEAT_DIST_BACKEND")}
+    tic = time.perf_counter()
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=120,
+                         cwd=root, env=env)
+    assert res.returncode != 0 and time.perf_counter() - tic < 30
+    assert "needs 8 visible GPUs" in res.stderr and not res.stdout.strip()

@@ -358,11 +358,64 @@ def test_bench_multi_process_rehearsal_on_one_gpu():
     r3 = json.loads([ln for ln in fb.stdout.splitlines() if ln.strip()][0])
     assert r3["config"]["finite"] and abs(r3["config"]["v_max"] - r2["config"]["v_max"]) < 1e-4
     assert r3["config"]["pcg_iterations_per_step"] >= r2["config"]["pcg_iterations_per_step"]
+    # the same on the RCCL transport's set-up path (forced here on gloo; its collective create is never reached): whether
+    # rank 0 fails before it has a unique id to broadcast or rank 1 fails after receiving it, every rank learns of it in
+    # the agreement that follows the broadcast and none enters ncclCommInitRank alone
+    for failing in ("0", "1"):
+        fr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                             "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", *common],
+                            capture_output=True, text=True, timeout=300, cwd=root,
+                            env=dict(env, BEAT_TEST_FAIL_LIBCOMM_RANK=failing, BEAT_DIST_TRANSPORT="rccl", BEAT_BENCH_ALT="0"))
+        assert fr.returncode == 0, fr.stderr[-2000:]
+        assert fr.stderr.count("stage-driven loop") >= 2, fr.stderr[-2000:]  # both ranks fell back
+        r4 = json.loads([ln for ln in fr.stdout.splitlines() if ln.strip()][0])
+        assert r4["config"]["finite"] and abs(r4["config"]["v_max"] - r3["config"]["v_max"]) < 1e-9
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
-    """The reference's own call sequence (geometry, stimulus, MonodomainModel, DolfinODESolver, splitting solver,
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no launcher around it (how the driver calls it): the parent starts two fresh
+    rank processes, relays rank 0's ONE JSON line and returns 0; the line reports both ranks (per-rank stage times, the
+    transport in use) and the same steps over the ipc transport -- two processes exchanging ghost planes on the device
+    through each other's mailboxes (hipIpc*).  A job that stops printing is killed by the parent's watchdog and tried once
+    more in fresh children with BEAT_DIST_SERIAL=1; when that fails too the return code is non-zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["BEAT_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--size", "64", "--steps", "4", "--warmup", "1"]
+    two = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, two.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["nodes"] == 64**3 and r["config"]["finite"]
+    assert r["config"]["launch"]["attempts"][-1]["rc"] == 0 and len(r["config"]["launch"]["attempts"]) == 1
+    assert [x["rank"] for x in r["ranks"]] == [0, 1] and sum(x["nodes"] for x in r["ranks"]) == 64**3
+    assert all(x["ode_ms"] > 0 and x["pde_ms"] > 0 for x in r["ranks"])
+    assert r["config"]["comm"]["transport"] == "callbacks"
+    ipc = r["transports"]["ipc"]
+    assert "error" not in ipc and ipc["comm"]["transport"] == "ipc" and ipc["ms_per_step"] > 0
+    assert abs(ipc["pcg_iterations_per_step"] - r["config"]["pcg_iterations_per_step"]) <= 1.5
+    # a job that never prints: the watchdog kills it, the serial retry is made, the parent reports failure
+    tic = time.perf_counter()
+    hung = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root,
+                          env=dict(env, BEAT_BENCH_TEST_HANG="1", BEAT_BENCH_WATCHDOG_START_S="20", BEAT_BENCH_WATCHDOG_S="20"))
+    assert hung.returncode != 0 and time.perf_counter() - tic < 200
+    assert hung.stderr.count("killing the ranks") == 2 and "BEAT_DIST_SERIAL" in hung.stderr and not hung.stdout.strip()
+
+
+@pytest.mark.parametrize("world,transport", [(2, "callbacks"), (3, "callbacks"), (3, "ipc")])
+def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_path):
+    """(transport "ipc": the three processes exchange their ghost planes ON THE DEVICE -- each maps its neighbours' mailboxes
+    with hipIpcOpenMemHandle and copies its boundary planes into them on the library's side stream, ordered by
+    interprocess events; only the all-reduces go through gloo.)
+    The reference's own call sequence (geometry, stimulus, MonodomainModel, DolfinODESolver, splitting solver,
     evaluate_function, x.array) run by `world` processes, the communicator cutting the mesh into z-slabs
     (tests/_api_ranks_script.py; ranks share this box's GPU over the host-staged gloo transport): after 60 TP06 steps
     the concatenated potential, every state row and the probe values equal the one-process run to 1e-10, with the
@@ -382,7 +435,8 @@ def test_public_api_on_several_ranks_matches_one_process(world, tmp_path):
     assert one.returncode == 0, one.stderr[-3000:]
     many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, str(dn)],
-                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+                          capture_output=True, text=True, timeout=300, cwd=root,
+                          env=dict(env, BEAT_DIST_BACKEND="gloo", BEAT_DIST_TRANSPORT=transport))
     assert many.returncode == 0, many.stderr[-3000:]
     a = np.load(d1 / "rank0.npz")
     parts = [np.load(dn / f"rank{r}.npz") for r in range(world)]
@@ -507,9 +561,13 @@ class _PeriodicSelf:
         return []
 
 
+@pytest.mark.parametrize("transport", ["rccl", "rccl-serial", "ipc"])
 @pytest.mark.parametrize("per_node", [False, True])
-def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_node):
-    """The in-library solve with REAL RCCL point-to-point traffic on its side stream: a one-rank communicator whose
+def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_node, transport):
+    """(transport "rccl-serial": the same exchange on the all-reduce communicator and the compute stream, BEAT_COMM_SERIAL;
+    "ipc": the ghost planes as device copies through the rank's own mailbox, ordered by its interprocess events -- every
+    slot and event of the ring reused many times over the solves below.)
+    The in-library solve with REAL RCCL point-to-point traffic on its side stream: a one-rank communicator whose
     lower and upper peers are the rank itself (the only multi-message topology a one-GPU box can host) makes the slab
     periodic in z -- ghost planes live on both faces, ncclSend/ncclRecv pairs in a group per SpMV, events between the
     side and the compute stream, boundary planes computed after the receive.  The stage-driven Python loop with the
@@ -535,8 +593,11 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
     rng = np.random.default_rng(11)
     v = -85.0 + 30.0 * rng.random(plane * nz)
     w = rng.random(plane * nz) * 1e-3
-    comm = LibComm(ctx, Interior(), transport="rccl", peers=(0, 0))
+    comm = LibComm(ctx, Interior(), transport=transport.split("-")[0], peers=(0, 0), serial=transport.endswith("serial"),
+                   plane_doubles=plane)
     try:
+        info = comm.info()
+        assert info["transport"] == transport and info["rccl_ranks"] == 1 and info["allreduce"] == "rccl"
         # the exchange on its own
         states = StateArray(ctx, 3, plane * nz, plane)
         for field in (ctx.field(plane * nz, plane), states.row_field(1)):
@@ -618,6 +679,15 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
         for a, b in zip(its[0][1], its[3][1]):
             np.testing.assert_allclose(b, a, rtol=0, atol=1e-8 * np.abs(a).max())
         assert sum(its[3][0][2:]) < sum(its[0][0][2:])
+        # event timing of the communication inside the solve (beat_comm_profile): one exchange per iteration + the one
+        # before the right-hand side, two all-reduces per iteration + one; every span has a non-negative duration
+        comm.profile(True)
+        res = solver.solve(fv, [], [], fx, rtol=1e-10, atol=1e-50, max_it=200)
+        comm.profile(False)
+        prof = comm.profile_read()
+        assert prof["allreduce_count"] >= 2 * res.iterations + 1 and prof["halo_count"] >= res.iterations + 1
+        assert prof["halo_ms"] > 0.0 and prof["allreduce_ms"] > 0.0 and prof["halo_stall_ms"] >= 0.0
+        assert (prof["halo_stall_count"] > 0) == (transport != "rccl-serial")
     finally:
         comm.close()
 

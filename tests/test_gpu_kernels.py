@@ -175,6 +175,7 @@ GRIDS = [
     ((70, 37, 9), (7.0, 3.7, 0.9), "aniso3"),
     ((40, 14, 6), (20.0, 7.0, 3.0), "niederer"),
     ((4, 1, 2), (2.0, 0.5, 1.0), "aniso3"),
+    ((24, 20, 12), (2.4, 2.0, 1.2), "iso3"),  # BASELINE.json configs[2]: M = s I, h = 0.1 mm (7-point stiffness inside the 15-point row)
     ((130, 33), (1.0, 1.0), "aniso2"),
     ((10,), (1.0,), 1.0),
 ]
@@ -186,6 +187,8 @@ def _conductivity(kind, dim):
         return 9.5e-4 * np.outer(f0, f0) + 1.25e-4 * (np.eye(3) - np.outer(f0, f0))
     if kind == "niederer":
         return np.diag([9.5301e-4, 1.2576e-4, 1.2576e-4])
+    if kind == "iso3":
+        return 9.5301e-4 * np.eye(3)
     if kind == "aniso2":
         return np.array([[2.0, 0.3], [0.3, 1.0]])
     return kind
@@ -282,7 +285,7 @@ def test_stencil_slab_ghost_planes(hip_ctx):
         _hip.check(ctx.lib.beat_pde_destroy(handle))
 
 
-@pytest.mark.parametrize("cells,L,Mk", GRIDS[:2] + GRIDS[3:])
+@pytest.mark.parametrize("cells,L,Mk", GRIDS[:2] + GRIDS[3:])  # (all but the 5 x 2 x 3-node grid)
 def test_pde_solve_matches_direct_solve(hip_ctx, cells, L, Mk):
     """One theta-step: rhs build + Jacobi-PCG (rtol 1e-12) vs the oracle's sparse-LU solve of
     (C_m Mass + theta dt K) v = (C_m Mass - (1-theta) dt K) v_ + dt b_stim: <= 1e-9 * max|v|."""
