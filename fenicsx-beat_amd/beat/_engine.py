@@ -128,9 +128,9 @@ def spectrum_bounds(A_tab: np.ndarray, ratio: float = 5.0) -> tuple[float, float
 
 
 class HipOps:
-    default_small = True  # small grids: whole solve in one launch (tests flip this to exercise the multi-launch kernels)
-
     """The product compute backend: every method is one C-ABI call into libbeat_hip.so."""
+
+    default_small = True  # small grids: whole solve in one launch (tests flip this to exercise the multi-launch kernels)
 
     def __init__(self, ctx, shape_local, lo_phys, hi_phys, mass_tab, stiff_tab, per_node: bool = False):
         """mass_tab / stiff_tab: the (27, 15) tables of _stencil.stencil_tables, or with ``per_node`` the

@@ -39,8 +39,12 @@ def write_mesh(filename, mesh: grid.Mesh, **kw) -> None:
     if mesh.comm.rank == 0:
         root = Path(filename)
         root.mkdir(parents=True, exist_ok=True)
-        for old in root.glob("*_r*.npy"):
-            old.unlink()
+        # only the files the previous checkpoint itself recorded (its meta.json): <name>_<k>_r<rank>.npy per function,
+        # time stamp and slab -- anything else the caller keeps in this directory is not ours to delete
+        for name, entry in _load_meta(filename).get("functions", {}).items():
+            for k, slabs in enumerate(entry.get("slabs", [])):
+                for r in range(len(slabs)):
+                    (root / f"{name}_{k}_r{r}.npy").unlink(missing_ok=True)
         meta = {"mesh": _mesh_meta(mesh), "functions": {}}
         _meta_path(filename).write_text(json.dumps(meta))
     mesh.comm.Barrier()

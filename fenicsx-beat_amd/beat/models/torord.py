@@ -3,7 +3,7 @@
 Specification: odes/torord/ToRORd_dynCl_endo.ode of the reference (state / parameter order = order of
 appearance there; ``celltype`` selects endo / epi / mid as in demos/biv_endocardial.py:124-173).
 ``generalized_rush_larsen`` is the drop-in for the gotranx-generated function of the same name; its kernel
-(csrc/torord_dyncl.h) is hand-organised; the names / defaults module was written by tools/gen_cell_model.py from the
+(csrc/torord_dyncl.h) is hand-organised; the names / defaults module was written by tools/gen_model_data.py from the
 model specification."""
 
 from .. import _hip

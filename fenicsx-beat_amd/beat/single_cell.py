@@ -62,6 +62,30 @@ def pace_on_host(fun: Callable, states: np.ndarray, parameters: np.ndarray, dt: 
     return y, tracked
 
 
+def _pace_over_times(fun, nbeats, times, y, p, dt, save_freq=1, track_values=None, track_indices=None):
+    """The pacing loop over explicit step times (the two reference entry points below share it)."""
+    row = 0
+    for _beat in range(int(nbeats)):
+        for j, t in enumerate(times):
+            if track_values is not None and j % save_freq == 0:
+                for i, index in enumerate(track_indices):
+                    track_values[row, i] = y[index]
+                row += 1
+            y[:] = fun(states=y, t=t, parameters=p, dt=dt)
+    return y
+
+
+def solve_with_save(fun, nbeats, times, y, p, dt, save_freq, track_values, track_indices):
+    """Reference signature (src/beat/single_cell.py:40-57): ``nbeats`` passes over ``times``, ``y`` advanced in place,
+    the tracked states written to ``track_values`` every ``save_freq`` steps.  Returns (y, track_values)."""
+    return _pace_over_times(fun, nbeats, times, y, p, dt, save_freq, track_values, track_indices), track_values
+
+
+def solve_without_save(fun, nbeats, times, y, p, dt):
+    """Reference signature (src/beat/single_cell.py:60-65)."""
+    return _pace_over_times(fun, nbeats, times, y, p, dt)
+
+
 def get_steady_state(fun: Callable, init_states: np.ndarray, parameters: np.ndarray, outdir: Path, nbeats: int = 200,
                      BCL: int = 1000, save_every_ms: float = 1.0, dt: float = 0.05,
                      track_indices: list[int] | None = None):

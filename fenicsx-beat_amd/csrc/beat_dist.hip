@@ -105,7 +105,7 @@ namespace {
 constexpr int IPC_SLOTS = 4;   // exchanges in flight per direction before a mailbox slot is reused
 constexpr int IPC_FIELDS = 2;  // fields per exchange (v_ and the guess increment travel together)
 constexpr uint32_t IPC_MAGIC = 0xbea71bc1u;
-constexpr int IPC_BLOCKS = 64;  // workgroups of a transfer kernel
+constexpr int IPC_BLOCKS = 64;  // workgroups per direction of a transfer kernel (tools/xfer_bench.cpp: 32-64 is the sweet spot)
 
 struct IpcFlags {  // in the mailbox, written by the neighbours (peer_lo's side: [0], peer_hi's: [1])
   unsigned long long arrived[2];  // messages from that neighbour that have landed in this rank's mailbox
@@ -124,29 +124,35 @@ struct IpcPeer {  // a neighbour as this rank sees it
   bool connected = false, self = false;
 };
 
-struct IpcXfer {
+struct IpcXfer {  // one direction of one phase (send or receive) of an exchange
   const double* src[IPC_FIELDS];
   double* dst[IPC_FIELDS];
-  int nf;
-  int64_t plane;
   const unsigned long long* wait_flag;  // nullptr: nothing to wait for
   unsigned long long wait_need;
-  unsigned long long* signal_flag;
+  unsigned long long* signal_flag;      // nullptr: this direction has no neighbour (its workgroups exit)
   unsigned long long signal_value;
   unsigned int* counter;  // local, zero between launches: workgroups that have finished their share
+};
+struct IpcXferArgs {
+  IpcXfer dir[2];  // blockIdx.y: towards / from peer_lo, peer_hi
+  int nf;
+  int64_t plane;
   long long ticks;
   int* err;
 };
 
-// One direction of one exchange: wait for the flag, copy nf planes, the last workgroup to finish raises the other
-// side's flag.  Every workgroup polls the flag itself (thread 0; no workgroup depends on another one being scheduled).
-__global__ __launch_bounds__(256) void ipc_xfer_kernel(IpcXfer a) {
+// One phase of one exchange, both directions in one launch (blockIdx.y): wait for the flag, copy nf planes, the last
+// workgroup of the direction to finish raises the other side's flag.  Every workgroup polls the flag itself (thread
+// 0; no workgroup depends on another one being scheduled).
+__global__ __launch_bounds__(256) void ipc_xfer_kernel(IpcXferArgs args) {
+  const IpcXfer& a = args.dir[blockIdx.y];
+  if (a.signal_flag == nullptr) return;
   if (a.wait_flag != nullptr) {
     if (threadIdx.x == 0) {
       const long long t0 = wall_clock64();
       while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wait_need) {
-        if (wall_clock64() - t0 > a.ticks) {  // the peer is gone: say so and carry on (the data are wrong, the host will know)
-          __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (wall_clock64() - t0 > args.ticks) {  // the peer is gone: say so and carry on (the data are wrong, the host will know)
+          __hip_atomic_store(args.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -154,10 +160,33 @@ __global__ __launch_bounds__(256) void ipc_xfer_kernel(IpcXfer a) {
     }
     __syncthreads();
   }
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int k = 0; k < a.nf; ++k)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.plane; i += stride) a.dst[k][i] = a.src[k][i];
-  __threadfence_system();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < args.nf; ++k) {
+    const double* __restrict__ src = a.src[k];
+    double* __restrict__ dst = a.dst[k];
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {  // 16 bytes per lane where the planes allow it, 4 loads in flight
+      const int64_t pairs = args.plane >> 1;
+      const double2* __restrict__ s2 = (const double2*)src;
+      double2* __restrict__ d2 = (double2*)dst;
+      int64_t i = first;
+      for (; i + 3 * stride < pairs; i += 4 * stride) {
+        const double2 v0 = s2[i], v1 = s2[i + stride], v2 = s2[i + 2 * stride], v3 = s2[i + 3 * stride];
+        d2[i] = v0;
+        d2[i + stride] = v1;
+        d2[i + 2 * stride] = v2;
+        d2[i + 3 * stride] = v3;
+      }
+      for (; i < pairs; i += stride) d2[i] = s2[i];
+      if ((args.plane & 1) && first == 0) dst[args.plane - 1] = src[args.plane - 1];
+    } else {
+      for (int64_t i = first; i < args.plane; i += stride) dst[i] = src[i];
+    }
+  }
+  // Every wave waits for its own stores to be acknowledged, the barrier collects the workgroup, and ONE release per
+  // workgroup (the counter's, agent scope) publishes them; the last workgroup adds the system-scope release in front
+  // of the flag.  (A fence in every wave is what made the first version slow: 256 workgroups fencing at agent or
+  // system scope take 26 us for a 2 MiB plane, this form 5-8 us, alone or beside a streaming kernel -- tools/xfer_bench.cpp.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int done = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -275,7 +304,17 @@ struct CommGuard {  // destroys a half-built communicator on every early return 
 };
 
 int side_stream_and_events(beat_comm* c) {
-  BEAT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  // BEAT_DIST_SIDE_PRIORITY=1: a high-priority stream (hipStreamCreateWithPriority).  Measured on the 512 x 512 x 64
+  // slab with a self-neighbour, same box: every cross-stream dependency then costs 150-300 us instead of ~10 (an RCCL
+  // exchange alone 178 us against 12 on the compute stream; 3.5 against 1.85 ms per solve) -- not the default.
+  const char* pe = std::getenv("BEAT_DIST_SIDE_PRIORITY");
+  if (pe && pe[0] == '1') {
+    int least = 0, greatest = 0;
+    BEAT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    BEAT_HIP_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, greatest));
+  } else {
+    BEAT_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  }
   BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   BEAT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   return BEAT_OK;
@@ -493,15 +532,19 @@ int ipc_halo_start(beat_comm* c, double* const* fields, int nf, int64_t n, int64
   BEAT_HIP_CHECK(hipEventRecord(c->ev_ready, c->ctx->stream));
   BEAT_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
   const int span = prof_begin(c, 0, c->side);
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(IPC_BLOCKS, (plane + 1023) / 1024));
-  // all sends first (to either neighbour), then the receives: no rank waits for a message before it has posted its own
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(IPC_BLOCKS, (plane + 2047) / 2048));
+  // all sends first (to either neighbour, one launch), then the receives (one launch): no rank waits for a message
+  // before it has posted its own
+  IpcXferArgs snd{}, rcv{};
+  snd.nf = rcv.nf = nf;
+  snd.plane = rcv.plane = plane;
+  snd.ticks = rcv.ticks = c->ipc_ticks;
+  snd.err = rcv.err = c->ipc_err;
   for (int d = 0; d < 2; ++d) {
     if (peers[d] < 0) continue;
     IpcPeer& P = c->ipc_peer[d];
     const int od = 1 - d;  // this rank is the neighbour's neighbour in the opposite direction
-    IpcXfer x{};
-    x.nf = nf;
-    x.plane = plane;
+    IpcXfer& x = snd.dir[d];
     for (int k = 0; k < nf; ++k) {
       x.src[k] = d == 0 ? fields[k] : fields[k] + n - plane;
       x.dst[k] = ipc_slot(P.box, pm, od, slot, k);
@@ -513,30 +556,19 @@ int ipc_halo_start(beat_comm* c, double* const* fields, int nf, int64_t n, int64
     x.signal_flag = &ipc_flags(P.box, pm)->arrived[od];
     x.signal_value = s + 1;
     x.counter = c->ipc_counters + d;
-    x.ticks = c->ipc_ticks;
-    x.err = c->ipc_err;
-    BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks), dim3(256), 0, c->side, x);
-  }
-  for (int d = 0; d < 2; ++d) {
-    if (peers[d] < 0) continue;
-    IpcPeer& P = c->ipc_peer[d];
-    const int od = 1 - d;
-    IpcXfer x{};
-    x.nf = nf;
-    x.plane = plane;
+    IpcXfer& y = rcv.dir[d];
     for (int k = 0; k < nf; ++k) {
-      x.src[k] = ipc_slot(c->ipc_box, pm, d, slot, k);
-      x.dst[k] = d == 0 ? fields[k] - plane : fields[k] + n;
+      y.src[k] = ipc_slot(c->ipc_box, pm, d, slot, k);
+      y.dst[k] = d == 0 ? fields[k] - plane : fields[k] + n;
     }
-    x.wait_flag = &mine->arrived[d];
-    x.wait_need = s + 1;
-    x.signal_flag = &ipc_flags(P.box, pm)->freed[od];
-    x.signal_value = s + 1;
-    x.counter = c->ipc_counters + 2 + d;
-    x.ticks = c->ipc_ticks;
-    x.err = c->ipc_err;
-    BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks), dim3(256), 0, c->side, x);
+    y.wait_flag = &mine->arrived[d];
+    y.wait_need = s + 1;
+    y.signal_flag = &ipc_flags(P.box, pm)->freed[od];
+    y.signal_value = s + 1;
+    y.counter = c->ipc_counters + 2 + d;
   }
+  BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks, 2), dim3(256), 0, c->side, snd);
+  BEAT_KERNEL(ipc_xfer_kernel, dim3(blocks, 2), dim3(256), 0, c->side, rcv);
   BEAT_LAUNCH_CHECK();
   prof_end(c, span, c->side);
   BEAT_HIP_CHECK(hipEventRecord(c->ev_halo, c->side));

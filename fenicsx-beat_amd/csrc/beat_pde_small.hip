@@ -315,11 +315,12 @@ int beat_small_launch(beat_pde* pde, const double* dev_v_prev, const double* con
   hipStream_t s = pde->ctx->stream;
 #define BEAT_SMALL_LAUNCH(MV)                                                                                           \
   do {                                                                                                                  \
-    static bool attr_set = false;                                                                                       \
-    if (!attr_set) {                                                                                                    \
+    static bool attr_set[64] = {}; /* per device: the attribute belongs to the function on ONE device */              \
+    const int dev_ = pde->ctx->device & 63;                                                                             \
+    if (!attr_set[dev_]) {                                                                                              \
       BEAT_HIP_CHECK(hipFuncSetAttribute((const void*)pcg_small_kernel<MV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          160 * 1024));                                                                  \
-      attr_set = true;                                                                                                  \
+      attr_set[dev_] = true;                                                                                            \
     }                                                                                                                   \
     BEAT_KERNEL((pcg_small_kernel<MV>), dim3(1), dim3(SMALL_THREADS), lds, s, a);                                \
   } while (0)

@@ -285,7 +285,7 @@ struct FastMath {
 };
 
 // The generated models' Goldman-Hodgkin-Katz fluxes  v g / (exp(c v) - 1)  are 0/0 at v = 0 and their v-derivative
-// loses all accuracy next to it (relative error ~ ulp / (c v F/RT)^2; see tools/gen_cell_model.py): the intermediates
+// loses all accuracy next to it (relative error ~ ulp / (c v F/RT)^2; round-1 notes in DESIGN.md): the intermediates
 // they go through are evaluated at a potential kept at least 1e-4 mV away from the singular value.  That leaves the
 // derivative five correct digits; on the rare step a node spends inside the window its rates are evaluated up to
 // 1e-4 mV off, which moves an increment by |d increment / dv| * 1e-4 mV (~2e-5 of the increment).

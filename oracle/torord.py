@@ -13,7 +13,7 @@ reference's ventricular demos advance with gotranx's first-order generalized Rus
 
 This file is written by hand from the specification, in dependency order, and is deliberately
 independent of tests/golden/ode_spec.py (the ``ast`` walker that produced the committed fixture
-tests/golden/torord_spec.npz and that the kernel generator tools/gen_cell_model.py shares): it does
+tests/golden/torord_spec.npz and that tools/gen_model_data.py shares): it does
 not parse the ``.ode`` file, it does not use SymPy, and its self-derivatives come from forward-mode
 automatic differentiation with NumPy dual numbers (one pass per state), not from symbolic
 differentiation.  tests/test_oracle_pins.py checks it against that fixture (names, defaults, RHS,
