@@ -21,6 +21,7 @@ MODEL_TP06_GRL1 = 3
 MODEL_TORORD_DYNCL_GRL1 = 4
 MODEL_TORORD_LAND_GRL1 = 5
 MAX_STIM = 8
+MAX_CLASSES = 32
 
 # slots of the PCG scalar state (see include/beat_hip.h)
 ST_BB, ST_RZ, ST_RR, ST_PQ, ST_RZN, ST_RRN, ST_TOL2, ST_BETA, ST_STOP, ST_ITERS, ST_REASON = range(11)
@@ -62,6 +63,9 @@ SIGNATURES = {
     "beat_ode_model_info": (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
     "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
     "beat_ode_step_pending": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
+    "beat_ode_class_table_doubles": (_int, [_int, C.POINTER(_int)]),
+    "beat_ode_class_table_fill": (_int, [_vp, _int, _vp, _int, _int, _vp]),
+    "beat_ode_step_classes": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
     "beat_ode_run": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _i64, _int, _int, _vp, _int, _vp]),
     "beat_copy": (_int, [_vp, _vp, _vp, _i64]),
     "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),

@@ -72,7 +72,9 @@ class MonodomainSplittingSolver:
                 recorder.record()
 
     def _can_batch(self, recorder) -> bool:
-        if not (self._can_fuse() and np.isclose(self.theta, 1.0)):
+        from .odesolver import DolfinODESolver
+
+        if not (isinstance(self.ode, DolfinODESolver) and self._can_fuse() and np.isclose(self.theta, 1.0)):
             return False
         ode, pde = self.ode, self.pde
         ops = getattr(pde, "_ops", None)
@@ -85,7 +87,7 @@ class MonodomainSplittingSolver:
         if recorder is not None and recorder._f is not pde.state:
             return False
         ode._dev.parameters = ode.parameters
-        return ode._dev._param_args()[2] is None  # uniform parameters
+        return ode._dev._param_args()[0] is not None  # uniform parameters (one host vector)
 
     def _batched_steps(self, steps, recorder) -> None:
         import ctypes as C
@@ -141,9 +143,13 @@ class MonodomainSplittingSolver:
 
     # ---------------------------------------------------------------------------------------
     def _can_fuse(self) -> bool:
-        from .odesolver import DolfinODESolver
+        from .odesolver import DolfinMultiODESolver, DolfinODESolver
 
         ode, pde = self.ode, self.pde
+        if isinstance(ode, DolfinMultiODESolver):
+            # markers that share one device model live in one state array advanced by one launch: the single-model route
+            return (self.fused and 0.0 < self.theta <= 1.0 and getattr(ode, "_marked", False) and isinstance(pde, MonodomainModel)
+                    and ode.v_pde is pde.state and ode.v_ode.x.array.size == pde.state.x.array.size)
         return (
             self.fused
             and 0.0 < self.theta <= 1.0
@@ -154,6 +160,15 @@ class MonodomainSplittingSolver:
             and ode.num_points == pde.state.x.array.size
         )
 
+    def _fused_prepare(self) -> int:
+        """Parameters as they are now (the reference hands the live arrays to ``fun`` every step); returns the row of
+        the potential."""
+        ode = self.ode
+        if hasattr(ode, "_fused_prepare"):
+            return ode._fused_prepare()
+        ode._dev.parameters = ode.parameters
+        return ode.v_index
+
     def _fused_step(self, t0, t1):
         ode, pde, mon = self.ode, self.pde, self.monitor
         dt = t1 - t0
@@ -161,9 +176,9 @@ class MonodomainSplittingSolver:
         with mon.track_time("total_step"):
             with mon.track_time("ode_step"):
                 # functions aliasing the row are re-aliased below, so no materialisation here
-                ode._dev.parameters = ode.parameters
+                v_index = self._fused_prepare()
                 # a deferred x += sum alpha_j p_j of the previous solve is applied by this kernel
-                ode._dev.step(t0, self.theta * dt, v_index=ode.v_index, pending_ops=ode._pending_ops, v_row=row)
+                ode._dev.step(t0, self.theta * dt, v_index=v_index, pending_ops=ode._pending_ops, v_row=row)
             with mon.track_time("pde_step"):
                 theta_pde = pde.parameters["theta"]
                 with pde.monitor.track_time("pde_total_step"):
@@ -186,7 +201,7 @@ class MonodomainSplittingSolver:
             if not np.isclose(self.theta, 1.0):
                 # corrective ionic step of length (1 - theta) dt from t0 + theta dt (monodomain_solver.py:98-113)
                 with mon.track_time("corrective_ode_step"):
-                    ode._dev.step(t0 + self.theta * dt, (1.0 - self.theta) * dt, v_index=ode.v_index,
+                    ode._dev.step(t0 + self.theta * dt, (1.0 - self.theta) * dt, v_index=v_index,
                                   pending_ops=ode._pending_ops, v_row=row)
             with mon.track_time("pde_assign_previous_after"):
                 for f in (pde.state, pde.v_, ode.v_ode):

@@ -104,6 +104,32 @@ class _DeviceODE:
         self.monitor = monitor
         self._ppn = None
         self._ppn_host = None  # what the device copy was uploaded from
+        self.classes = None    # (marker bytes on the device, class table, number of classes): see set_classes
+        self.explicit_classes = False  # the owner set the classes itself (DolfinMultiODESolver); else they follow the parameters
+        self._class_host = None
+
+    def set_classes(self, markers_dev, param_sets) -> None:
+        """One launch for several uniform parameter sets (beat_ode_step_classes): ``markers_dev`` = a byte per node naming
+        its set (255: none, the node is not advanced), ``param_sets`` = the sets in class order.  Calling it again with
+        the same byte row only refreshes the table, and only if a set changed (the reference hands ``fun`` the live
+        parameter arrays every step, odesolver.py:70-76)."""
+        P = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in param_sets]))
+        if P.ndim != 2 or P.shape[1] != self.model.num_parameters or not 1 <= P.shape[0] <= _hip.MAX_CLASSES:
+            raise ValueError(f"{self.model.name}: {P.shape[0]} parameter sets of {P.shape[1:]} values "
+                             f"(expected 1..{_hip.MAX_CLASSES} sets of {self.model.num_parameters})")
+        lib = self.ctx.lib
+        if self.classes is None or self.classes[2] != P.shape[0]:
+            stride = C.c_int()
+            _hip.check(lib.beat_ode_class_table_doubles(self.model.model_id, C.byref(stride)))
+            table = self.ctx.zeros(stride.value * P.shape[0])
+            self._class_host = None
+        else:
+            table = self.classes[1]
+        if self._class_host is None or not np.array_equal(self._class_host, P):
+            _hip.check(lib.beat_ode_class_table_fill(self.ctx.handle, self.model.model_id, P.ctypes.data_as(C.c_void_p), P.shape[1],
+                                                     P.shape[0], C.c_void_p(table.data_ptr())))
+            self._class_host = P.copy()
+        self.classes = (markers_dev, table, P.shape[0])
 
     def set_initial(self, values) -> None:
         if values.ndim == 1:
@@ -112,17 +138,58 @@ class _DeviceODE:
         else:
             self.states.set(values)
 
+    def _classify(self, t):
+        """Per-node parameters (P, N) that are piecewise constant -- demos/pace_train.py:133-167 zeroes two conductances
+        in half of the cable -- are a handful of uniform parameter sets: the distinct columns become classes, a byte per
+        node names its class, and the step runs the class kernel (uniform parameters in scalar registers, no per-node
+        rows to load: 424 B/node for TP06, 896 for ToR-ORd) instead of the per-node one.  Returns (marker bytes on the
+        device, (classes, P) host array) or None when the columns are not few (a smooth gradient: per-node kernel).
+        BEAT_PARAM_CLASSES=0 turns the analysis off."""
+        import os
+
+        if os.environ.get("BEAT_PARAM_CLASSES", "1") == "0":
+            return None
+        torch = self.ctx.torch
+        varying = (t != t[:, :1]).any(dim=1)
+        n = t.shape[1]
+        if not bool(varying.any()):
+            return torch.zeros(n, dtype=torch.uint8, device=t.device), t[:, :1].T.cpu().numpy()
+        cols = t[varying]
+        stride = max(1, n // 65536)  # a sample first: a smooth field shows at once
+        if torch.unique(cols[:, ::stride], dim=1).shape[1] > _hip.MAX_CLASSES:
+            return None
+        uniq, inv = torch.unique(cols, dim=1, return_inverse=True)
+        if uniq.shape[1] > _hip.MAX_CLASSES:
+            return None
+        first = torch.full((uniq.shape[1],), n, dtype=torch.int64, device=t.device)
+        first.scatter_reduce_(0, inv, torch.arange(n, device=t.device), reduce="amin")
+        return inv.to(torch.uint8), t[:, first].T.contiguous().cpu().numpy()
+
+    def _per_node_or_classes(self, tensor, num_rows):
+        """(host params, P, device rows, ld) for per-node parameters held in ``tensor``: the class route if they allow it."""
+        found = self._classify(tensor)
+        if found is not None:
+            self.set_classes(found[0], list(found[1]))
+            return None, num_rows, None, 0
+        self.classes = None
+        return None, num_rows, C.c_void_p(tensor.data_ptr()), self.n
+
     def _param_args(self):
         p = self.parameters
         if p is None:
             return None, 0, None, 0
         if isinstance(p, DeviceParameters):  # resident handle: nothing to check or move per step
             _, dev, ld = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
-            return None, p.shape[0], C.c_void_p(dev.data_ptr()), ld
+            key = (id(p), p.version)
+            if getattr(self, "_dp_key", None) != key:  # new values: look at them once
+                self._dp_args = self._per_node_or_classes(dev, p.shape[0])
+                self._dp_key = key
+            return self._dp_args
         p = np.asarray(p, dtype=np.float64)
         if p.ndim == 1:
             hp = np.ascontiguousarray(p)
             self._keep = hp
+            self.classes = None
             return hp.ctypes.data_as(C.c_void_p), len(hp), None, 0
         # per-node NumPy parameters: the reference hands the live array to ``fun`` every step (odesolver.py:70-76),
         # so any in-place edit must reach the kernel.  Exact comparison with the copy that was uploaded (one host
@@ -130,12 +197,14 @@ class _DeviceODE:
         if self._ppn is None or self._ppn_host.shape != p.shape or not np.array_equal(self._ppn_host, p):
             _, self._ppn, _ = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
             self._ppn_host = p.copy()
-        return None, p.shape[0], C.c_void_p(self._ppn.data_ptr()), self.n
+            self._ppn_args = self._per_node_or_classes(self._ppn, p.shape[0])
+        return self._ppn_args
 
     def step(self, t0, dt, v_index=0, v_copy=None, pending_ops=None, v_row=None):
         """``pending_ops``: diffusion operators whose last solve deferred its update of ``v_row`` (row v_index of
         these states): the kernel adds it while loading the potential (beat_ode_step_pending)."""
-        hp, npar, ppn, pld = self._param_args()
+        # (classes set explicitly -- one model for several markers -- stay; otherwise the parameters decide the route)
+        hp, npar, ppn, pld = (None, 0, None, 0) if self.explicit_classes else self._param_args()
         pend = None
         if pending_ops is not None and pending_ops.pending is not None:
             model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
@@ -147,7 +216,16 @@ class _DeviceODE:
                 pending_ops.flush_pending()
         with self.monitor.track_time("ode_total_step"):
             with self.monitor.track_time("ode_function_call"):
-                if pend is not None:
+                if self.classes is not None:
+                    mk, table, ncls = self.classes
+                    if int(v_index) != self.model.state_index(self.model.v_name) and pend is not None:
+                        raise ValueError("a pending update needs the model's own potential row")
+                    _hip.check(self.ctx.lib.beat_ode_step_classes(
+                        self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, C.c_void_p(table.data_ptr()),
+                        ncls, C.c_void_p(mk.data_ptr()), float(t0), float(dt), int(v_index), None if v_copy is None else v_copy.ptr,
+                        pending_ops.handle if pend is not None else None, pending_ops.ring[0].ptr if pend is not None else None,
+                        pending_ops.fld if pend is not None else 0, int(pend[2]) if pend is not None else 0))
+                elif pend is not None:
                     _hip.check(
                         self.ctx.lib.beat_ode_step_pending(
                             self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, hp, npar, ppn,
@@ -352,6 +430,13 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
         self._ctx = ctx
         self.on_device = all(isinstance(f, DeviceModel) for f in self.fun.values())
         self._initialize_full_values()
+        self._aliases: list[grid.Function] = []
+        self._pending_ops = None
+        self._marked = self.on_device and self._one_launch_possible()
+        if self._marked:
+            self._setup_one_launch(marker_arr)
+            self._initialize_metadata()
+            return
         for marker in self._marker_values:
             where = marker_arr == marker
             n_m = int(where.sum())
@@ -370,6 +455,89 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
                                                      parameters=self.parameters[marker], monitor=self.monitor)
         self._initialize_metadata()
 
+    # ---- one launch for all markers (the markers share one device model: cell types, parameter regions) ----------------
+    def _one_launch_possible(self) -> bool:
+        """All markers run the same built-in model with uniform (1-D) parameter sets on the PDE's P1 space: then the
+        nodes live in ONE (S, N) state array with a byte per node naming the node's parameter set, and a step is one
+        kernel launch (beat_ode_step_classes) instead of one per marker plus a scatter and a gather of the potential
+        (BEAT_MULTI_ONE_LAUNCH=0 keeps the per-marker arrays: the reference's literal data layout)."""
+        import os
+
+        if os.environ.get("BEAT_MULTI_ONE_LAUNCH", "1") == "0":
+            return False
+        ms = self._marker_values
+        funs = [self.fun[m] for m in ms]
+        return (
+            1 <= len(ms) <= _hip.MAX_CLASSES
+            and all(f.model_id == funs[0].model_id for f in funs)
+            and len({int(self.num_states[m]) for m in ms}) == 1
+            and len({int(self.v_index[m]) for m in ms}) == 1
+            and all(not isinstance(self.parameters[m], DeviceParameters) and np.ndim(self.parameters[m]) == 1 for m in ms)
+            and self.v_ode.function_space.is_p1
+        )
+
+    def _setup_one_launch(self, marker_arr) -> None:
+        ctx, ms = self._ctx, self._marker_values
+        model, S, vi = self.fun[ms[0]], int(self.num_states[ms[0]]), int(self.v_index[ms[0]])
+        n = marker_arr.size
+        mesh = self.v_ode.function_space.mesh
+        self._dev = _DeviceODE(ctx, model, S, n, mesh.plane, None, self.monitor)
+        rows = self._dev.states.rows  # (S, n) view of the device array: filled there (a 141 M-node box: 51 GB, not a host array)
+        rows[vi].copy_(self.v_ode.field.data)  # nodes outside every marker keep the potential they have
+        cls = np.full(n, 255, dtype=np.uint8)
+        self._idx_dev = {}
+        for k, marker in enumerate(ms):
+            where = marker_arr == marker
+            self._inds[marker] = where
+            self._num_points[marker] = int(where.sum())
+            cls[where] = k
+            idx = ctx.from_numpy(np.nonzero(where)[0].astype(np.int64))
+            self._idx_dev[marker] = idx
+            init = np.asarray(self.init_states[marker], dtype=np.float64)
+            if init.ndim == 1:  # (S,) broadcast to the marker's nodes (odesolver.py:149-153)
+                for r in range(S):
+                    rows[r].index_fill_(0, idx, float(init[r]))
+            else:
+                if init.shape != self.shape(marker):
+                    raise ValueError(f"init_states[{marker}] has shape {init.shape}, expected {self.shape(marker)}")
+                rows.index_copy_(1, idx, ctx.from_numpy(np.ascontiguousarray(init)))
+        self._cls_dev = ctx.from_numpy(cls)
+        self._dev.explicit_classes = True
+        self._dev.set_classes(self._cls_dev, [self.parameters[m] for m in ms])
+        self._v_row = self._dev.states.row_field(vi)
+        self._vi = vi
+        self._marked_any = cls != 255
+        self._all_marked = bool(self._marked_any.all())
+        self._idx_all = None if self._all_marked else ctx.from_numpy(np.nonzero(self._marked_any)[0].astype(np.int64))
+        self._odes = {}
+
+    def _sync_v(self):
+        if self._pending_ops is not None:
+            self._pending_ops.flush_pending()
+
+    def _release_aliases(self):
+        self._sync_v()
+        for f in self._aliases:
+            if f._alias is self._v_row:
+                f.materialize()
+        self._aliases = []
+
+    def _fused_prepare(self) -> int:
+        """Called by the fused split step before the ionic launch: refresh the class table if a parameter set was
+        edited; returns the potential's row."""
+        self._dev.set_classes(self._cls_dev, [self.parameters[m] for m in self._marker_values])
+        return self._vi
+
+    def _masked_copy(self, dst, src) -> None:
+        """dst[i] = src[i] on the nodes that carry a marker (all of them: a plain copy)."""
+        if self._all_marked:
+            dst.copy_from(src)
+            return
+        lib, n_m = self._ctx.lib, int(self._idx_all.numel())
+        tmp = self._ctx.zeros(n_m)
+        _hip.check(lib.beat_gather(self._ctx.handle, C.c_void_p(tmp.data_ptr()), src.ptr, C.c_void_p(self._idx_all.data_ptr()), n_m))
+        _hip.check(lib.beat_scatter(self._ctx.handle, dst.ptr, C.c_void_p(tmp.data_ptr()), C.c_void_p(self._idx_all.data_ptr()), n_m))
+
     def _initialize_full_values(self):
         ns = tuple(self.num_states.values())
         self._all_states_equal_size = bool((np.array(ns) == ns[0]).all())
@@ -377,7 +545,13 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
             self._full_values = np.zeros((ns[0], self.markers.x.array.size))
 
     def to_dolfin(self) -> None:
-        if self.on_device:
+        if self._marked:
+            if self.v_ode._alias is self._v_row:
+                return
+            self._sync_v()
+            self._masked_copy(self.v_ode.writable_field(overwrite_all=False), self._v_row)
+            self.v_ode._touch()
+        elif self.on_device:
             dst = self.v_ode.writable_field(overwrite_all=False)
             for marker in self._marker_values:
                 row = self._odes[marker].states.row_field(self.v_index[marker])
@@ -392,6 +566,9 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
 
     def scatter_v(self, dst) -> None:
         """Potentials of every marker's states -> field ``dst`` (fused split step)."""
+        if self._marked:
+            self._sync_v()
+            return self._masked_copy(dst, self._v_row)
         for marker in self._marker_values:
             row = self._odes[marker].states.row_field(self.v_index[marker])
             _hip.check(self._ctx.lib.beat_scatter(self._ctx.handle, dst.ptr, row.ptr,
@@ -399,13 +576,21 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
 
     def gather_v(self, src) -> None:
         """Field ``src`` -> the potential rows of every marker's states (fused split step)."""
+        if self._marked:
+            self._release_aliases()
+            return self._masked_copy(self._v_row, src)
         for marker in self._marker_values:
             row = self._odes[marker].states.row_field(self.v_index[marker])
             _hip.check(self._ctx.lib.beat_gather(self._ctx.handle, row.ptr, src.ptr,
                                                  C.c_void_p(self._idx_dev[marker].data_ptr()), row.n))
 
     def from_dolfin(self) -> None:
-        if self.on_device:
+        if self._marked:
+            if self.v_ode._alias is self._v_row:
+                return
+            self._release_aliases()
+            self._masked_copy(self._v_row, self.v_ode.field)
+        elif self.on_device:
             src = self.v_ode.field
             for marker in self._marker_values:
                 row = self._odes[marker].states.row_field(self.v_index[marker])
@@ -417,7 +602,21 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
                 self._values[marker][self.v_index[marker], :] = arr[self._inds[marker]]
 
     def values(self, marker: int):
+        if self._marked:  # the marker's columns of the one state array, (S, N_marker) as the reference keeps them
+            self._sync_v()
+            return self._dev.states.rows.index_select(1, self._idx_dev[marker]).cpu().numpy()
         return self._odes[marker].states.numpy() if self.on_device else self._values[marker]
+
+    def set_values(self, marker: int, values) -> None:
+        """Overwrite the (S, N_marker) states of one marker (e.g. with a pre-paced steady state)."""
+        values = np.broadcast_to(np.asarray(values, dtype=np.float64).reshape(self.num_states[marker], -1), self.shape(marker))
+        if self._marked:
+            self._release_aliases()
+            self._dev.states.rows.index_copy_(1, self._idx_dev[marker], self._ctx.from_numpy(np.ascontiguousarray(values)))
+        elif self.on_device:
+            self._odes[marker].states.set(np.ascontiguousarray(values))
+        else:
+            self._values[marker][:] = values
 
     def num_parameters(self, marker: int) -> int:
         return len(self.parameters[marker])
@@ -429,6 +628,11 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
         return self._num_points[marker]
 
     def step(self, t0: float, dt: float):
+        if self._marked:
+            with self.monitor.track_time("total_ode_step"):
+                self._release_aliases()
+                self._dev.step(t0, dt, v_index=self._fused_prepare())
+            return
         with self.monitor.track_time("total_ode_step"):
             for marker, ode in self._odes.items():
                 with self.monitor.track_time(f"marker_{marker}_ode_step"):

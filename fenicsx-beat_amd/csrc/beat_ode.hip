@@ -46,11 +46,30 @@ struct OdeStepKernArgHead {
   typename Model::Derived drv;
 };
 
-template <class Model, bool PER_NODE, bool PEND>
-__global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
+// Cell types / parameter classes in ONE launch (MARKED): a byte per node selects one of up to BEAT_MAX_CLASSES
+// parameter sets (uniform parameters + their Derived constants, a table in device memory laid out as TableEntry);
+// 255 = the node belongs to no class and is not advanced.  A wavefront whose nodes all carry the same marker -- the rule
+// when the classes are layers or regions -- reads its set with scalar loads exactly as the uniform kernel reads the
+// kernel-argument segment; a wavefront that straddles a boundary runs the step once per class present, lanes masked.
+// Replaces one launch per marker + scatter / gather of the potential (src/beat/odesolver.py:306-310 loops the markers).
+struct MarkedArgs {
+  const unsigned char* markers;  // (n) or nullptr
+  const double* table;           // classes x (NP + sizeof(Derived) / 8) doubles
+  int stride;                    // doubles per table entry
+  int dephase;                   // experiments (BEAT_ODE_DEPHASE): 1 = start the blocks of a CU a third of a tile apart
+};
+
+template <class Model>
+struct OdeTableEntry {
+  double p[Model::NP];
+  typename Model::Derived d;
+};
+
+template <class Model, bool PER_NODE, bool PEND, bool MARKED = false>
+__global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
-    int v_index, double* __restrict__ v_copy, PendingV pend) {
+    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk) {
   __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
@@ -58,12 +77,86 @@ __global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_step_kernel(
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
   const FastMath fm{etab, ltab};
+  if (mk.dephase == 1) {  // experiment: the three blocks that share a CU at launch start a third of a tile (~5 us) apart
+    const int ph = (blockIdx.x >> 8) % 3;
+    for (int k = 0; k < ph; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   // a block walks over several tiles of 256 nodes (stride gridDim.x) and pays its launch and the table set-up once:
   // at 512^3, 24 576 blocks of ~21 tiles each measured 10.5-10.6 ms against 10.9-11.3 for one block per tile on the
   // same box (768 blocks, i.e. exactly the resident number: 11.5; 3 072: 10.7; 196 608: 10.9)
   for (int64_t tile = blockIdx.x; tile * BEAT_BLOCK < n; tile += gridDim.x) {
   const int64_t i = tile * BEAT_BLOCK + threadIdx.x;
   if (i >= n) break;
+  if (MARKED) {
+    const int m_lane = mk.markers[i];
+    if (PEND) {
+      // all loads issued together (they overlap with the state loads that follow)
+      NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+#pragma unroll
+      for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
+        io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
+        io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+      }
+      if (pend.gt.d != nullptr) {
+        io.gt = pend.gt;
+        io.ge = beat_pde_detail::beat_guess_needs_e(pend.gt) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
+        io.gd = beat_pde_detail::beat_guess_needs_d(pend.gt) ? __builtin_nontemporal_load(pend.gt.d + i) : 0.0;
+        io.gp0 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 0) ? __builtin_nontemporal_load(pend.gt.dp[0] + i) : 0.0;
+        io.gp1 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 1) ? __builtin_nontemporal_load(pend.gt.dp[1] + i) : 0.0;
+      }
+      // the potential with the pending update applied (and the guess's bookkeeping done), once, ahead of the passes: the
+      // pending values die here instead of staying live through every pass (-30 VGPRs, no scratch)
+      const double v_now = io.load(Model::V_INDEX);
+      struct NodeIOWithV {
+        double* __restrict__ base;
+        int64_t ld, i;
+        double* __restrict__ v_copy;
+        double v;
+        __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : base[(int64_t)k * ld + i]; }
+        __device__ __forceinline__ void store(int k, double x) const {
+          base[(int64_t)k * ld + i] = x;
+          if (k == Model::V_INDEX && v_copy != nullptr) v_copy[i] = x;
+        }
+      };
+      unsigned long long todo = __ballot(m_lane != 255);
+      while (todo) {
+        const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);  // wave-uniform
+        // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
+        // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
+        typedef const __attribute__((address_space(4))) char* TabPtr;
+        TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
+        asm volatile("" : "+s"(tb));
+        const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
+        const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
+        // (the node index is made opaque per pass: otherwise the address of every state row is hoisted out of this loop
+        // and kept in registers, +38 VGPRs)
+        NodeIOWithV iol{states, ld, i, v_copy, v_now};
+        asm volatile("" : "+v"(iol.i), "+v"(iol.v));  // (nor may anything that depends on the potential alone leave the loop)
+        if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
+        todo &= ~__ballot(m_lane == m);
+      }
+      // a node outside every class still takes part in the diffusion: its potential gets the pending update
+      if (m_lane == 255) io.store(Model::V_INDEX, v_now);
+    } else {
+      const NodeIO io{states, ld, i, v_copy, v_index};
+      unsigned long long todo = __ballot(m_lane != 255);
+      while (todo) {
+        const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);
+        // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
+        // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
+        typedef const __attribute__((address_space(4))) char* TabPtr;
+        TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
+        asm volatile("" : "+s"(tb));
+        const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
+        const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
+        NodeIO iol = io;
+        asm volatile("" : "+v"(iol.i));
+        if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
+        todo &= ~__ballot(m_lane == m);
+      }
+    }
+    continue;
+  }
   // The ~90 uniform doubles (parameters, per-launch derived constants) are scalar loads from the kernel-argument
   // segment.  Left to itself the compiler hoists all of them out of the tile loop, runs out of SGPRs and parks them in
   // VGPR lanes: 640 v_readlane / v_writelane per node on the VALU that is this kernel's bottleneck.  Reading them
@@ -144,8 +237,10 @@ struct TrackSpec {
   int n;
 };
 
+// (one wave per SIMD asked of the register allocator: the states of a node stay in registers through the time loop,
+// and these launches are a few hundred to a few thousand cells -- occupancy buys nothing, scratch traffic costs)
 template <class Model, bool PER_NODE>
-__global__ __launch_bounds__(BEAT_BLOCK, Model::WAVES) void ode_run_kernel(
+__global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
     const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
     TrackSpec track, double* __restrict__ trace) {
@@ -264,8 +359,8 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
-                      int v_index, double* v_copy, const PendingV& pend) {
-  BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2),
+                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, 0}) {
+  BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
   const bool have_pend = pend.count > 0 || pend.gt.d != nullptr;
@@ -281,10 +376,23 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   }();
   if (grid_cap > 0) grid = std::min(grid, (unsigned)grid_cap);
   const dim3 g3(grid), b3(BEAT_BLOCK);
+  static const int dephase = [] {
+    const char* e = std::getenv("BEAT_ODE_DEPHASE");
+    return e ? std::atoi(e) : 0;
+  }();
+  mk.dephase = dephase;
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
-                     dt, v_index, v_copy, pend)
-  if (ppn != nullptr) {
+                     dt, v_index, v_copy, pend, mk)
+  if (mk.markers != nullptr) {
+    BEAT_REQUIRE(ppn == nullptr && mk.table != nullptr, "parameter classes come with a table, not with per-node rows");
+    if (have_pend)
+      BEAT_KERNEL((ode_step_kernel<Model, false, true, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
+                  v_index, v_copy, pend, mk);
+    else
+      BEAT_KERNEL((ode_step_kernel<Model, false, false, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
+                  v_index, v_copy, pend, mk);
+  } else if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
     if (have_pend)
       BEAT_LAUNCH_ODE(true, true);
@@ -320,7 +428,7 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
 static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                              const double* host_params, int num_params, const double* dev_params_per_node,
                              int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
-                             const PendingV& pend) {
+                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, 0}) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
@@ -328,7 +436,7 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
   if (n == 0) return BEAT_OK;
 #define BEAT_STEP(M)                                                                                             \
   return launch_ode<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, \
-                       v_index, dev_v_copy, pend)
+                       v_index, dev_v_copy, pend, mk)
   switch (model_id) {
     case BEAT_MODEL_SIMPLE_ODE: BEAT_STEP(SimpleOde);
     case BEAT_MODEL_FHN_DEMO: BEAT_STEP(FhnDemo);
@@ -364,6 +472,78 @@ extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_st
   }
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld,
                            t, dt, v_index, dev_v_copy, pend);
+}
+
+
+template <class Model>
+static int fill_table(const double* host_params, int num_params, int classes, std::vector<double>& out) {
+  BEAT_REQUIRE(num_params == Model::NP, "model expects %d parameters, got %d", Model::NP, num_params);
+  static_assert(sizeof(OdeTableEntry<Model>) % sizeof(double) == 0, "table entry is a whole number of doubles");
+  const size_t stride = sizeof(OdeTableEntry<Model>) / sizeof(double);
+  out.assign(stride * (size_t)classes, 0.0);
+  for (int c = 0; c < classes; ++c) {
+    OdeTableEntry<Model>* e = (OdeTableEntry<Model>*)(out.data() + stride * c);
+    for (int k = 0; k < Model::NP; ++k) e->p[k] = host_params[(size_t)c * Model::NP + k];
+    e->d = Model::derive(e->p);
+  }
+  return BEAT_OK;
+}
+
+template <class Model>
+static int table_doubles() { return (int)(sizeof(OdeTableEntry<Model>) / sizeof(double)); }
+
+extern "C" int beat_ode_class_table_doubles(int model_id, int* doubles_per_class) {
+  BEAT_REQUIRE(doubles_per_class != nullptr, "null argument");
+  switch (model_id) {
+    case BEAT_MODEL_SIMPLE_ODE: *doubles_per_class = table_doubles<SimpleOde>(); break;
+    case BEAT_MODEL_FHN_DEMO: *doubles_per_class = table_doubles<FhnDemo>(); break;
+    case BEAT_MODEL_FHN_README: *doubles_per_class = table_doubles<FhnReadme>(); break;
+    case BEAT_MODEL_TP06_GRL1: *doubles_per_class = table_doubles<Tp06Grl1>(); break;
+    case BEAT_MODEL_TORORD_DYNCL_GRL1: *doubles_per_class = table_doubles<TorordDynClGrl1>(); break;
+    case BEAT_MODEL_TORORD_LAND_GRL1: *doubles_per_class = table_doubles<TorordLandGrl1>(); break;
+    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+  }
+  return BEAT_OK;
+}
+
+extern "C" int beat_ode_class_table_fill(beat_ctx* ctx, int model_id, const double* host_params, int num_params, int classes,
+                                         double* dev_table) {
+  BEAT_REQUIRE(ctx != nullptr && host_params != nullptr && dev_table != nullptr, "null argument");
+  BEAT_REQUIRE(classes >= 1 && classes <= BEAT_MAX_CLASSES, "1..%d parameter classes, got %d", BEAT_MAX_CLASSES, classes);
+  std::vector<double> tab;
+  int rc;
+  switch (model_id) {
+    case BEAT_MODEL_SIMPLE_ODE: rc = fill_table<SimpleOde>(host_params, num_params, classes, tab); break;
+    case BEAT_MODEL_FHN_DEMO: rc = fill_table<FhnDemo>(host_params, num_params, classes, tab); break;
+    case BEAT_MODEL_FHN_README: rc = fill_table<FhnReadme>(host_params, num_params, classes, tab); break;
+    case BEAT_MODEL_TP06_GRL1: rc = fill_table<Tp06Grl1>(host_params, num_params, classes, tab); break;
+    case BEAT_MODEL_TORORD_DYNCL_GRL1: rc = fill_table<TorordDynClGrl1>(host_params, num_params, classes, tab); break;
+    case BEAT_MODEL_TORORD_LAND_GRL1: rc = fill_table<TorordLandGrl1>(host_params, num_params, classes, tab); break;
+    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+  }
+  if (rc) return rc;
+  BEAT_HIP_CHECK(hipMemcpyAsync(dev_table, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `tab` goes out of scope
+  return BEAT_OK;
+}
+
+extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                                     const double* dev_table, int classes, const unsigned char* dev_markers, double t, double dt,
+                                     int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
+                                     int64_t field_stride, int pending) {
+  BEAT_REQUIRE(dev_table != nullptr && dev_markers != nullptr, "null argument");
+  BEAT_REQUIRE(classes >= 1 && classes <= BEAT_MAX_CLASSES, "1..%d parameter classes, got %d", BEAT_MAX_CLASSES, classes);
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
+  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
+  if (pde != nullptr && pde->guess_pending) {
+    pend.gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
+  int stride = 0;
+  if (int rc = beat_ode_class_table_doubles(model_id, &stride)) return rc;
+  return ode_step_dispatch(ctx, model_id, dev_states, n, ld, nullptr, 0, nullptr, 0, t, dt, v_index, dev_v_copy, pend,
+                           MarkedArgs{dev_markers, dev_table, stride, 0});
 }
 
 

@@ -241,6 +241,9 @@ __device__ const LogEntry kLogTab[128] = {
 #ifndef BEAT_ODE_WAVES
 #define BEAT_ODE_WAVES 2
 #endif
+#ifndef BEAT_ODE_WAVES_PER_NODE
+#define BEAT_ODE_WAVES_PER_NODE 2  // kernels whose parameters are per-node rows (TP06: 53 more doubles per lane)
+#endif
 
 // exp() argument of a rate * dt product, kept inside the range FastMath::exp handles (below -746 the result is 0,
 // above 710 it is inf: the clamp changes no finite value)
@@ -358,6 +361,7 @@ struct SimpleOde {
   static constexpr int NS = 2, NP = 2, V_INDEX = 0;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
+  static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -377,6 +381,7 @@ struct FhnDemo {
   static constexpr int NS = 2, NP = 10, V_INDEX = 1;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
+  static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -405,6 +410,7 @@ struct FhnReadme {
   static constexpr int NS = 2, NP = 11, V_INDEX = 1;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
+  static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   struct Derived {};
   __host__ __device__ static Derived derive(const double*) { return {}; }
   template <class IO>
@@ -449,6 +455,7 @@ struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53, V_INDEX = 17;
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
+  static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
     P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,

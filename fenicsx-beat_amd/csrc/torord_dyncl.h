@@ -165,6 +165,7 @@ struct TorordGrl1T {
   // spilled so heavily that this miscompiled and had to go through memory)
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = 2;  // waves per SIMD the kernels are compiled for
+  static constexpr int WAVES_PER_NODE = 1;  // with 112 (140) per-node parameters in registers: one wave per SIMD, no scratch
   enum S {
     S_C1, S_C2, S_C3, S_I_, S_O_, S_CaMKt, S_Jrel_np, S_Jrel_p, S_a, S_ap, S_iF, S_iFp, S_iS, S_iSp, S_cai,
     S_cajsr, S_cansr, S_cass, S_cli, S_clss, S_ki, S_kss, S_nai, S_nass, S_d, S_fcaf, S_fcafp, S_fcas, S_ff_,

@@ -108,6 +108,25 @@ int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64
                           int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
                           beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
 
+/* Cell types / parameter classes in ONE launch (src/beat/odesolver.py:306-310 loops over the markers and calls `fun`
+ * once per marker; demos/biv_endocardial.py:187-282: endo / mid / epi): one (S, n) state array, a byte per node that
+ * names the node's class (0 .. classes-1; 255: the node belongs to none and is not advanced), and a device table with
+ * one uniform parameter set per class.  beat_ode_class_table_doubles gives the size of a table entry (the parameters
+ * followed by the model's per-launch constants), beat_ode_class_table_fill builds `classes` entries from
+ * host_params (classes x num_params, row-major) into dev_table (synchronises).  beat_ode_step_classes is
+ * beat_ode_step_pending with the class table in place of the parameters: wavefronts whose nodes share a class read
+ * their set with scalar loads, as the uniform kernel does; a wavefront on a class boundary runs the step once per class
+ * present.  Piecewise-constant per-node parameters (demos/pace_train.py:133-167: two conductances zeroed in half of the
+ * cable) are the same thing: the distinct parameter columns are the classes. */
+#define BEAT_MAX_CLASSES 32
+int beat_ode_class_table_doubles(int model_id, int* doubles_per_class);
+int beat_ode_class_table_fill(beat_ctx* ctx, int model_id, const double* host_params, int num_params, int classes,
+                              double* dev_table);
+int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                          const double* dev_table, int classes, const unsigned char* dev_markers, double t, double dt,
+                          int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
+                          int64_t field_stride, int pending);
+
 /* nbeats x nsteps updates in ONE launch with the node's states held in registers: replaces the Python
  * loops of src/beat/single_cell.py:42-65 (solve_with_save / solve_without_save; t restarts at t0 for every
  * beat and is t0 + j*dt within it) and of src/beat/odesolver.py:24-43.  Optionally records `ntrack` (<= 8)

@@ -800,15 +800,21 @@ def test_deferred_potential_update_is_bit_identical():
 
 
 @pytest.mark.parametrize("theta", [1.0, 0.5])
-def test_fused_multi_celltype_step_equals_reference_sequence(theta):
-    """DolfinMultiODESolver through the fused route (potentials scattered straight into the PDE unknown, in-place
-    solve, gathered back) vs the literal reference sequence: bit-identical states, v_ / v_ode / state agree."""
+def test_fused_multi_celltype_step_equals_reference_sequence(theta, monkeypatch):
+    """DolfinMultiODESolver whose markers share one device model, four ways: (a) ONE state array with a class byte per
+    node, one ionic launch per step (beat_ode_step_classes) and the single-model fused route -- in-place solve on the V
+    row, the deferred potential update applied by the next ionic launch; (b) the same array driven through the literal
+    reference sequence; (c) per-marker arrays (the reference's data layout, BEAT_MULTI_ONE_LAUNCH=0) through the fused
+    multi route (potentials scattered into the PDE unknown, solved in place, gathered back); (d) per-marker arrays, literal
+    sequence.  Bit-identical states everywhere; v_ / v_ode / state agree.  A strip of nodes carries a marker no model is
+    defined for: it only diffuses (its potential still receives the deferred update)."""
     import beat
     from beat import grid as g
     from beat.models import tp06
 
     out = []
-    for fused in (True, False):
+    for one_launch, fused in ((True, True), (True, False), (False, True), (False, False)):
+        monkeypatch.setenv("BEAT_MULTI_ONE_LAUNCH", "1" if one_launch else "0")
         mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([3.0, 2.0, 1.0])], [12, 8, 4])
         time = g.Constant(mesh, 0.0)
         cells = g.locate_entities(mesh, 3, lambda x: x[0] <= 0.75 + 1e-10)
@@ -820,25 +826,106 @@ def test_fused_multi_celltype_step_equals_reference_sequence(theta):
         V = g.functionspace(mesh, ("P", 1))
         markers = g.Function(V)
         xs = mesh.node_coordinates(pad3=True)[:, 0]
-        markers.x.array[:] = np.where(xs < 1.0, 0.0, np.where(xs < 2.0, 1.0, 2.0))
+        markers.x.array[:] = np.where(xs < 1.0, 0.0, np.where(xs < 2.0, 1.0, np.where(xs < 2.7, 2.0, 7.0)))
+        v_ode = g.Function(V)
+        v_ode.x.array[:] = -80.0  # what the strip without a model starts from
         keys = (0, 1, 2)
         params = {0: tp06.init_parameter_values(stim_amplitude=0.0), 1: tp06.init_parameter_values(stim_amplitude=0.0, g_Ks=0.098),
                   2: tp06.init_parameter_values(stim_amplitude=0.0, g_to=0.073)}
         ode = beat.odesolver.DolfinMultiODESolver(
-            v_ode=g.Function(V), v_pde=pde.state, markers=markers, num_states={k: 19 for k in keys},
+            v_ode=v_ode, v_pde=pde.state, markers=markers, num_states={k: 19 for k in keys},
             fun={k: tp06.generalized_rush_larsen for k in keys}, init_states={k: tp06.init_state_values() for k in keys},
             parameters=params, v_index={k: tp06.state_index("V") for k in keys})
+        assert ode._marked == one_launch
         solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta, fused=fused)
-        assert solver._can_fuse_multi() == fused
+        assert solver._can_fuse() == (fused and one_launch) and solver._can_fuse_multi() == fused
         for i in range(25):
+            if i == 12:  # an edit of a live parameter array between steps reaches the kernels (odesolver.py:70-76)
+                params[1][tp06.parameter_index("g_Kr")] *= 0.5
             solver.step((i * 0.05, (i + 1) * 0.05))
+        if one_launch and fused:
+            assert getattr(pde._ops, "flushes", 0) == 0  # no separate pass ever applied the potential's update
         v = np.asarray(pde.state.x.array).copy()
         np.testing.assert_array_equal(v, np.asarray(pde.v_.x.array))
         np.testing.assert_array_equal(v, np.asarray(ode.v_ode.x.array))
-        out.append((v, ode.full_values.copy()))
-        assert v.max() > -60.0
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
+        per_marker = {k: ode.values(k).copy() for k in keys}
+        assert all(per_marker[k].shape == (19, int((np.asarray(markers.x.array) == k).sum())) for k in keys)
+        out.append((v, ode.full_values.copy(), per_marker))
+        assert v.max() > -60.0 and v[xs >= 2.7].max() < -60.0 and not np.array_equal(v[xs >= 2.7], np.full((xs >= 2.7).sum(), -80.0))
+    for other in out[1:]:
+        np.testing.assert_array_equal(out[0][0], other[0])
+        np.testing.assert_array_equal(out[0][1], other[1])
+        for k in (0, 1, 2):
+            np.testing.assert_array_equal(out[0][2][k], other[2][k])
+
+
+def test_piecewise_constant_per_node_parameters_run_as_classes():
+    """(P, N) per-node parameters of which two rows are piecewise constant -- demos/pace_train.py:133-167: g_Kr and g_Ks
+    zeroed in the right half of the cable -- are recognised as two uniform parameter sets and run through the class
+    kernel (scalar-register parameters, no per-node rows loaded), as NumPy array and as resident DeviceParameters handle,
+    with edits seen; the states equal those of the per-node kernel (BEAT_PARAM_CLASSES=0) to rounding of the per-launch
+    constants and the oracle's to 1e-11.  A smoothly varying row is left to the per-node kernel."""
+    import os
+
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+    from beat.odesolver import DeviceParameters
+    from oracle import ionic
+
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([4.0, 1.0, 1.0])], [32, 8, 8])
+    V = g.functionspace(mesh, ("P", 1))
+    n = V.dofmap.index_map.size_local
+    xs = mesh.node_coordinates(pad3=True)[:, 0]
+    P0 = tp06.init_parameter_values(stim_amplitude=0.0)
+    P = np.zeros((len(P0), n))
+    P.T[:] = P0
+    for name in ("g_Kr", "g_Ks"):
+        P[tp06.parameter_index(name)] = np.where(xs >= 2.0, 0.0, P0[tp06.parameter_index(name)])
+    rng = np.random.default_rng(2)
+    S0 = np.repeat(tp06.init_state_values()[:, None], n, axis=1)
+    S0[tp06.state_index("V")] = rng.uniform(-90.0, 30.0, n)
+
+    def run(parameters, steps=6, classes_env="1"):
+        os.environ["BEAT_PARAM_CLASSES"] = classes_env
+        try:
+            ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=g.Function(V), fun=tp06.generalized_rush_larsen,
+                                                 init_states=S0, parameters=parameters, num_states=19, v_index=tp06.state_index("V"))
+            for i in range(steps):
+                ode.step(0.02 * i, 0.02)
+            return ode, np.asarray(ode.values).copy()
+        finally:
+            os.environ.pop("BEAT_PARAM_CLASSES", None)
+
+    ode_c, out_c = run(P)
+    assert ode_c._dev.classes is not None and ode_c._dev.classes[2] == 2
+    ode_h, out_h = run(DeviceParameters(P))
+    assert ode_h._dev.classes is not None and ode_h._dev.classes[2] == 2
+    ode_n, out_n = run(P, classes_env="0")
+    assert ode_n._dev.classes is None
+    np.testing.assert_array_equal(out_c, out_h)
+    np.testing.assert_allclose(out_c, out_n, rtol=1e-13, atol=1e-300)
+    ref = S0.copy()
+    for i in range(6):
+        ref = ionic.tp06_generalized_rush_larsen(ref, 0.02 * i, 0.02, P)
+    err = np.abs(out_c - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-10
+    # an edit of the live array is seen: a third class appears
+    P[tp06.parameter_index("g_to"), xs < 1.0] *= 0.3
+    ode_c.step(0.12, 0.02)
+    assert ode_c._dev.classes[2] == 3
+    ref = ionic.tp06_generalized_rush_larsen(ref, 0.12, 0.02, P)
+    err = np.abs(np.asarray(ode_c.values) - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-10
+    # a smooth field has as many distinct columns as nodes: per-node kernel
+    Pg = P.copy()
+    Pg[tp06.parameter_index("g_Na")] *= np.linspace(0.8, 1.2, n)
+    ode_g, out_g = run(Pg)
+    assert ode_g._dev.classes is None
+    ref = S0.copy()
+    for i in range(6):
+        ref = ionic.tp06_generalized_rush_larsen(ref, 0.02 * i, 0.02, Pg)
+    assert (np.abs(out_g - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
 
 
 @pytest.mark.parametrize("dim,theta_split,theta_pde", [(2, 1.0, 0.5), (2, 0.5, 1.0), (3, 1.0, 1.0), (3, 0.5, 0.5), (3, 1.0, 0.75)])
