@@ -106,6 +106,7 @@ class _DeviceODE:
         self._ppn_host = None  # what the device copy was uploaded from
         self.classes = None    # (marker bytes on the device, class table, number of classes): see set_classes
         self.explicit_classes = False  # the owner set the classes itself (DolfinMultiODESolver); else they follow the parameters
+        self.node_map = None   # (int32 node of the PDE grid per entry, the field holding the potential): compact layout
         self._class_host = None
 
     def set_classes(self, markers_dev, param_sets) -> None:
@@ -209,7 +210,8 @@ class _DeviceODE:
         if pending_ops is not None and pending_ops.pending is not None:
             model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
             if (v_row is not None and int(v_index) == model_v
-                    and pending_ops.pending[0].ptr.value == v_row.ptr.value):
+                    and pending_ops.pending[0].ptr.value == v_row.ptr.value
+                    and (self.node_map is None or self.node_map[1].ptr.value == v_row.ptr.value)):
                 pend = pending_ops.pending
                 pending_ops.pending = None
             else:
@@ -220,9 +222,11 @@ class _DeviceODE:
                     mk, table, ncls = self.classes
                     if int(v_index) != self.model.state_index(self.model.v_name) and pend is not None:
                         raise ValueError("a pending update needs the model's own potential row")
+                    nmap, vfield = (None, None) if self.node_map is None else (C.c_void_p(self.node_map[0].data_ptr()), self.node_map[1].ptr)
                     _hip.check(self.ctx.lib.beat_ode_step_classes(
                         self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, C.c_void_p(table.data_ptr()),
                         ncls, C.c_void_p(mk.data_ptr()), float(t0), float(dt), int(v_index), None if v_copy is None else v_copy.ptr,
+                        nmap, vfield,
                         pending_ops.handle if pend is not None else None, pending_ops.ring[0].ptr if pend is not None else None,
                         pending_ops.fld if pend is not None else 0, int(pend[2]) if pend is not None else 0))
                 elif pend is not None:
@@ -477,21 +481,79 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
         )
 
     def _setup_one_launch(self, marker_arr) -> None:
+        import os
+
         ctx, ms = self._ctx, self._marker_values
         model, S, vi = self.fun[ms[0]], int(self.num_states[ms[0]]), int(self.v_index[ms[0]])
         n = marker_arr.size
         mesh = self.v_ode.function_space.mesh
-        self._dev = _DeviceODE(ctx, model, S, n, mesh.plane, None, self.monitor)
-        rows = self._dev.states.rows  # (S, n) view of the device array: filled there (a 141 M-node box: 51 GB, not a host array)
-        rows[vi].copy_(self.v_ode.field.data)  # nodes outside every marker keep the potential they have
-        cls = np.full(n, 255, dtype=np.uint8)
-        self._idx_dev = {}
+        cls_full = np.full(n, 255, dtype=np.uint8)
         for k, marker in enumerate(ms):
             where = marker_arr == marker
             self._inds[marker] = where
             self._num_points[marker] = int(where.sum())
-            cls[where] = k
-            idx = ctx.from_numpy(np.nonzero(where)[0].astype(np.int64))
+            cls_full[where] = k
+        self._marked_any = cls_full != 255
+        self._all_marked = bool(self._marked_any.all())
+        self._idx_all = None if self._all_marked else ctx.from_numpy(np.nonzero(self._marked_any)[0].astype(np.int64))
+        # Layout.  The ionic kernels are bound by fp64 issue: a lane without a cell costs what a busy one does.  When the
+        # nodes that carry a model are a fraction of the grid (the wall of a voxelised geometry inside its box: 26 %) the
+        # state array holds only those -- plus any other node of the tissue, which still diffuses -- and a node map
+        # tells the kernel where each one's potential lives in the PDE's field; otherwise the array spans the grid and
+        # its potential row IS that field.  BEAT_MULTI_COMPACT = 0 | 1 forces one or the other.
+        tissue = mesh.node_active() if mesh.active is not None else np.ones(n, dtype=bool)
+        held = self._marked_any | tissue
+        # wavefronts (64 consecutive nodes) that would meet more than one class: each costs one pass per class
+        seg = np.full(((n + 63) // 64) * 64, 255, dtype=np.uint8)
+        seg[:n] = cls_full
+        seg = seg.reshape(-1, 64)
+        present = np.zeros(len(seg), dtype=np.int64)
+        for k in range(len(ms)):
+            present += (seg == k).any(axis=1)
+        mixed = float((present > 1).sum()) / max(1, int((present > 0).sum()))
+        want = os.environ.get("BEAT_MULTI_COMPACT")
+        compact = (held.mean() < 0.9 or mixed > 0.05) if want is None else (want == "1")
+        self._vi = vi
+        if compact:
+            # one run of whole 256-node tiles per class (then the tissue nodes without a model), nodes ascending inside a run
+            tile = 256
+            runs = [(k, np.nonzero(self._inds[m])[0]) for k, m in enumerate(ms)]
+            rest = np.nonzero(held & ~self._marked_any)[0]
+            if rest.size:
+                runs.append((255, rest))
+            node_parts, cls_parts, pos, real_pos, off = [], [], {}, [], 0
+            for k, nodes in runs:
+                pad = (-nodes.size) % tile
+                node_parts += [nodes, np.zeros(pad, dtype=np.int64)]
+                cls_parts += [np.full(nodes.size, k, dtype=np.uint8), np.full(pad, 254, dtype=np.uint8)]
+                if k != 255:
+                    pos[ms[k]] = off + np.arange(nodes.size)
+                real_pos.append(off + np.arange(nodes.size))
+                off += nodes.size + pad
+            node_idx = np.concatenate(node_parts)
+            cls = np.concatenate(cls_parts)
+            real_pos = np.concatenate(real_pos)
+            if node_idx.size == 0 or node_idx.max() >= 2**31:
+                raise ValueError("the node map holds 32-bit indices")
+            n_c = int(node_idx.size)
+            self._dev = _DeviceODE(ctx, model, S, n_c, 0, None, self.monitor)
+            self._v_row = ctx.field(n, mesh.plane)  # the potential's home: a field of the PDE grid
+            self._v_row.copy_from(self.v_ode.field)  # nodes outside every marker keep the potential they have
+            self._real_pos = ctx.from_numpy(real_pos.astype(np.int64))       # entries of the array that are nodes ...
+            self._real_nodes = ctx.from_numpy(node_idx[real_pos].astype(np.int64))  # ... and the nodes they are
+            self._node_idx = self._real_nodes
+            self._dev.node_map = (ctx.from_numpy(node_idx.astype(np.int32)), self._v_row)
+        else:
+            self._dev = _DeviceODE(ctx, model, S, n, mesh.plane, None, self.monitor)
+            self._v_row = self._dev.states.row_field(vi)
+            self._v_row.copy_from(self.v_ode.field)
+            self._node_idx = None
+            cls = cls_full
+            pos = {m: np.nonzero(self._inds[m])[0] for m in ms}
+        rows = self._dev.states.rows  # (S, n) view of the device array: filled there (tens of GB at full size, not a host array)
+        self._idx_dev = {}
+        for marker in ms:
+            idx = ctx.from_numpy(pos[marker].astype(np.int64))
             self._idx_dev[marker] = idx
             init = np.asarray(self.init_states[marker], dtype=np.float64)
             if init.ndim == 1:  # (S,) broadcast to the marker's nodes (odesolver.py:149-153)
@@ -501,19 +563,24 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
                 if init.shape != self.shape(marker):
                     raise ValueError(f"init_states[{marker}] has shape {init.shape}, expected {self.shape(marker)}")
                 rows.index_copy_(1, idx, ctx.from_numpy(np.ascontiguousarray(init)))
+        if compact:  # the marked nodes' initial potential goes to its home (the others keep what v_ode held)
+            for marker in ms:
+                nodes = ctx.from_numpy(np.nonzero(self._inds[marker])[0].astype(np.int64))
+                self._v_row.data.index_copy_(0, nodes, rows[vi].index_select(0, self._idx_dev[marker]))
         self._cls_dev = ctx.from_numpy(cls)
         self._dev.explicit_classes = True
         self._dev.set_classes(self._cls_dev, [self.parameters[m] for m in ms])
-        self._v_row = self._dev.states.row_field(vi)
-        self._vi = vi
-        self._marked_any = cls != 255
-        self._all_marked = bool(self._marked_any.all())
-        self._idx_all = None if self._all_marked else ctx.from_numpy(np.nonzero(self._marked_any)[0].astype(np.int64))
         self._odes = {}
 
     def _sync_v(self):
         if self._pending_ops is not None:
             self._pending_ops.flush_pending()
+
+    def _refresh_compact_v(self) -> None:
+        """Compact layout: the potential row of the state array mirrors the field only as of the last ionic launch."""
+        if self._marked and self._node_idx is not None:
+            self._sync_v()
+            self._dev.states.rows[self._vi].index_copy_(0, self._real_pos, self._v_row.data.index_select(0, self._real_nodes))
 
     def _release_aliases(self):
         self._sync_v()
@@ -604,6 +671,7 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
     def values(self, marker: int):
         if self._marked:  # the marker's columns of the one state array, (S, N_marker) as the reference keeps them
             self._sync_v()
+            self._refresh_compact_v()
             return self._dev.states.rows.index_select(1, self._idx_dev[marker]).cpu().numpy()
         return self._odes[marker].states.numpy() if self.on_device else self._values[marker]
 
@@ -613,6 +681,9 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
         if self._marked:
             self._release_aliases()
             self._dev.states.rows.index_copy_(1, self._idx_dev[marker], self._ctx.from_numpy(np.ascontiguousarray(values)))
+            if self._node_idx is not None:  # the potential's home is the field
+                nodes = self._ctx.from_numpy(np.nonzero(self._inds[marker])[0].astype(np.int64))
+                self._v_row.data.index_copy_(0, nodes, self._ctx.from_numpy(np.ascontiguousarray(values[self._vi])))
         elif self.on_device:
             self._odes[marker].states.set(np.ascontiguousarray(values))
         else:

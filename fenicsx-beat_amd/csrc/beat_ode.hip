@@ -56,6 +56,8 @@ struct MarkedArgs {
   const unsigned char* markers;  // (n) or nullptr
   const double* table;           // classes x (NP + sizeof(Derived) / 8) doubles
   int stride;                    // doubles per table entry
+  const int* vmap;               // (n) node of the PDE grid each entry of the state array belongs to, or nullptr (identity)
+  double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
   int dephase;                   // experiments (BEAT_ODE_DEPHASE): 1 = start the blocks of a CU a third of a tile apart
 };
 
@@ -89,71 +91,75 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
   if (i >= n) break;
   if (MARKED) {
     const int m_lane = mk.markers[i];
-    if (PEND) {
-      // all loads issued together (they overlap with the state loads that follow)
-      NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+    // where the node's potential lives: row V_INDEX of the state array, or -- when the array holds only the nodes that
+    // carry a cell model (a voxelised wall inside its box) -- the PDE's field at node vmap[i]: the kernel then reads the
+    // potential there (pending update included) and writes the new one to both, which is the scatter and the gather of
+    // the potential the per-marker route spends two launches per marker on
+    const int64_t jn = mk.vmap != nullptr ? (int64_t)mk.vmap[i] : i;
+    double* const vptr = mk.vmap != nullptr ? mk.vfield + jn : states + (int64_t)Model::V_INDEX * ld + i;
+    struct NodeIOWithV {
+      double* __restrict__ base;
+      int64_t ld, i;
+      double* vout;  // the field entry that mirrors the potential (or nullptr)
+      double v;
+      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : base[(int64_t)k * ld + i]; }
+      __device__ __forceinline__ void store(int k, double x) const {
+        base[(int64_t)k * ld + i] = x;
+        if (k == Model::V_INDEX && vout != nullptr) *vout = x;
+      }
+    };
+    // 254: a padding entry (the compact layout keeps each class in its own run of whole tiles, so that a wavefront
+    // meets one class): nothing is read or written for it
+    double v_now = m_lane != 254 ? *vptr : 0.0;
+    if (PEND && m_lane != 254) {
+      // the potential with the pending update applied (and the guess's bookkeeping done) once, ahead of the passes --
+      // same expressions and order as NodeIOPending::load / x_flush_kernel: the pending values die here instead of
+      // staying live through every pass (-30 VGPRs, no scratch)
+      double pp[BEAT_MAX_PENDING], pa[BEAT_MAX_PENDING];
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-        io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
-        io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+        pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + jn) : 0.0;
+        pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
       }
       if (pend.gt.d != nullptr) {
-        io.gt = pend.gt;
-        io.ge = beat_pde_detail::beat_guess_needs_e(pend.gt) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
-        io.gd = beat_pde_detail::beat_guess_needs_d(pend.gt) ? __builtin_nontemporal_load(pend.gt.d + i) : 0.0;
-        io.gp0 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 0) ? __builtin_nontemporal_load(pend.gt.dp[0] + i) : 0.0;
-        io.gp1 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 1) ? __builtin_nontemporal_load(pend.gt.dp[1] + i) : 0.0;
+        const beat_pde_detail::GuessTerms& gt = pend.gt;
+        const double ge = beat_pde_detail::beat_guess_needs_e(gt) ? __builtin_nontemporal_load(gt.e + jn) : 0.0;
+        const double gd = beat_pde_detail::beat_guess_needs_d(gt) ? __builtin_nontemporal_load(gt.d + jn) : 0.0;
+        const double gp0 = beat_pde_detail::beat_guess_needs_dp(gt, 0) ? __builtin_nontemporal_load(gt.dp[0] + jn) : 0.0;
+        const double gp1 = beat_pde_detail::beat_guess_needs_dp(gt, 1) ? __builtin_nontemporal_load(gt.dp[1] + jn) : 0.0;
+        double inc = gt.accumulate ? 0.0 : ge;
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+          if (j < pend.count) inc = fma(pa[j], pp[j], inc);
+        beat_pde_detail::beat_guess_record(gt, gt.d + jn, gt.e + jn, inc, gd, gp0, gp1, ge);
+        v_now += inc;
+      } else {
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+          if (j < pend.count) v_now = fma(pa[j], pp[j], v_now);
       }
-      // the potential with the pending update applied (and the guess's bookkeeping done), once, ahead of the passes: the
-      // pending values die here instead of staying live through every pass (-30 VGPRs, no scratch)
-      const double v_now = io.load(Model::V_INDEX);
-      struct NodeIOWithV {
-        double* __restrict__ base;
-        int64_t ld, i;
-        double* __restrict__ v_copy;
-        double v;
-        __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : base[(int64_t)k * ld + i]; }
-        __device__ __forceinline__ void store(int k, double x) const {
-          base[(int64_t)k * ld + i] = x;
-          if (k == Model::V_INDEX && v_copy != nullptr) v_copy[i] = x;
-        }
-      };
-      unsigned long long todo = __ballot(m_lane != 255);
-      while (todo) {
-        const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);  // wave-uniform
-        // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
-        // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
-        typedef const __attribute__((address_space(4))) char* TabPtr;
-        TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
-        asm volatile("" : "+s"(tb));
-        const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
-        const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
-        // (the node index is made opaque per pass: otherwise the address of every state row is hoisted out of this loop
-        // and kept in registers, +38 VGPRs)
-        NodeIOWithV iol{states, ld, i, v_copy, v_now};
-        asm volatile("" : "+v"(iol.i), "+v"(iol.v));  // (nor may anything that depends on the potential alone leave the loop)
-        if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
-        todo &= ~__ballot(m_lane == m);
-      }
-      // a node outside every class still takes part in the diffusion: its potential gets the pending update
-      if (m_lane == 255) io.store(Model::V_INDEX, v_now);
-    } else {
-      const NodeIO io{states, ld, i, v_copy, v_index};
-      unsigned long long todo = __ballot(m_lane != 255);
-      while (todo) {
-        const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);
-        // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
-        // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
-        typedef const __attribute__((address_space(4))) char* TabPtr;
-        TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
-        asm volatile("" : "+s"(tb));
-        const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
-        const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
-        NodeIO iol = io;
-        asm volatile("" : "+v"(iol.i));
-        if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
-        todo &= ~__ballot(m_lane == m);
-      }
+    }
+    unsigned long long todo = __ballot(m_lane < 254);
+    while (todo) {
+      const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);  // wave-uniform
+      // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
+      // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
+      typedef const __attribute__((address_space(4))) char* TabPtr;
+      TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
+      asm volatile("" : "+s"(tb));
+      const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
+      const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
+      // (node index and potential are made opaque per pass: otherwise the address of every state row and everything
+      // that depends on the potential alone is hoisted out of this loop and kept in registers, +38 VGPRs and scratch)
+      NodeIOWithV iol{states, ld, i, mk.vmap != nullptr ? vptr : (v_copy != nullptr ? v_copy + i : nullptr), v_now};
+      asm volatile("" : "+v"(iol.i), "+v"(iol.v));
+      if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
+      todo &= ~__ballot(m_lane == m);
+    }
+    // a node outside every class still takes part in the diffusion: its potential gets the pending update
+    if (PEND && m_lane == 255) {
+      *vptr = v_now;
+      if (mk.vmap != nullptr) states[(int64_t)Model::V_INDEX * ld + i] = v_now;
     }
     continue;
   }
@@ -359,7 +365,7 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
-                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, 0}) {
+                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr, 0}) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
@@ -428,7 +434,7 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
 static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                              const double* host_params, int num_params, const double* dev_params_per_node,
                              int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
-                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, 0}) {
+                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr, 0}) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
@@ -529,12 +535,15 @@ extern "C" int beat_ode_class_table_fill(beat_ctx* ctx, int model_id, const doub
 
 extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                                      const double* dev_table, int classes, const unsigned char* dev_markers, double t, double dt,
-                                     int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
-                                     int64_t field_stride, int pending) {
+                                     int v_index, double* dev_v_copy, const int* dev_node_map, double* dev_v_field,
+                                     beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending) {
   BEAT_REQUIRE(dev_table != nullptr && dev_markers != nullptr, "null argument");
+  BEAT_REQUIRE((dev_node_map == nullptr) == (dev_v_field == nullptr), "dev_node_map and dev_v_field come together");
+  BEAT_REQUIRE(dev_node_map == nullptr || dev_v_copy == nullptr, "with a node map the field IS the mirror of the potential");
   BEAT_REQUIRE(classes >= 1 && classes <= BEAT_MAX_CLASSES, "1..%d parameter classes, got %d", BEAT_MAX_CLASSES, classes);
   BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
-  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && (field_stride >= n || dev_node_map != nullptr)),
+               "bad pending update");
   PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
   if (pde != nullptr && pde->guess_pending) {
     pend.gt = pde->guess_final;
@@ -543,7 +552,7 @@ extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_st
   int stride = 0;
   if (int rc = beat_ode_class_table_doubles(model_id, &stride)) return rc;
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, nullptr, 0, nullptr, 0, t, dt, v_index, dev_v_copy, pend,
-                           MarkedArgs{dev_markers, dev_table, stride, 0});
+                           MarkedArgs{dev_markers, dev_table, stride, dev_node_map, dev_v_field, 0});
 }
 
 

@@ -110,22 +110,28 @@ int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64
 
 /* Cell types / parameter classes in ONE launch (src/beat/odesolver.py:306-310 loops over the markers and calls `fun`
  * once per marker; demos/biv_endocardial.py:187-282: endo / mid / epi): one (S, n) state array, a byte per node that
- * names the node's class (0 .. classes-1; 255: the node belongs to none and is not advanced), and a device table with
+ * names the node's class (0 .. classes-1; 255: the node belongs to none and is not advanced -- its potential still
+ * receives a pending update; 254: a padding entry, nothing is read or written for it), and a device table with
  * one uniform parameter set per class.  beat_ode_class_table_doubles gives the size of a table entry (the parameters
  * followed by the model's per-launch constants), beat_ode_class_table_fill builds `classes` entries from
  * host_params (classes x num_params, row-major) into dev_table (synchronises).  beat_ode_step_classes is
  * beat_ode_step_pending with the class table in place of the parameters: wavefronts whose nodes share a class read
  * their set with scalar loads, as the uniform kernel does; a wavefront on a class boundary runs the step once per class
  * present.  Piecewise-constant per-node parameters (demos/pace_train.py:133-167: two conductances zeroed in half of the
- * cable) are the same thing: the distinct parameter columns are the classes. */
+ * cable) are the same thing: the distinct parameter columns are the classes.
+ * dev_node_map / dev_v_field (both or neither): the state array holds only the n nodes that carry a cell model (the
+ * wall of a voxelised geometry inside its box -- an ionic kernel is bound by fp64 issue, so idle lanes cost what busy ones
+ * do); entry i belongs to node dev_node_map[i] of the PDE grid, the potential is READ from dev_v_field there (with the
+ * pending update of that field applied) and the new one written to the state array's row and to the field: the
+ * reference's to_dolfin / from_dolfin for every marker (odesolver.py:280-292) inside the one launch. */
 #define BEAT_MAX_CLASSES 32
 int beat_ode_class_table_doubles(int model_id, int* doubles_per_class);
 int beat_ode_class_table_fill(beat_ctx* ctx, int model_id, const double* host_params, int num_params, int classes,
                               double* dev_table);
 int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                           const double* dev_table, int classes, const unsigned char* dev_markers, double t, double dt,
-                          int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
-                          int64_t field_stride, int pending);
+                          int v_index, double* dev_v_copy, const int* dev_node_map, double* dev_v_field,
+                          beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
 
 /* nbeats x nsteps updates in ONE launch with the node's states held in registers: replaces the Python
  * loops of src/beat/single_cell.py:42-65 (solve_with_save / solve_without_save; t restarts at t0 for every

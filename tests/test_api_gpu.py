@@ -813,8 +813,12 @@ def test_fused_multi_celltype_step_equals_reference_sequence(theta, monkeypatch)
     from beat.models import tp06
 
     out = []
-    for one_launch, fused in ((True, True), (True, False), (False, True), (False, False)):
+    # (compact: the state array holds only the nodes of the tissue and reaches the potential through a node map -- what a
+    # voxelised wall gets by itself; forced here on a full box, where the map is the identity)
+    for one_launch, fused, compact in ((True, True, "0"), (True, True, "1"), (True, False, "0"), (True, False, "1"),
+                                       (False, True, "0"), (False, False, "0")):
         monkeypatch.setenv("BEAT_MULTI_ONE_LAUNCH", "1" if one_launch else "0")
+        monkeypatch.setenv("BEAT_MULTI_COMPACT", compact)
         mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([3.0, 2.0, 1.0])], [12, 8, 4])
         time = g.Constant(mesh, 0.0)
         cells = g.locate_entities(mesh, 3, lambda x: x[0] <= 0.75 + 1e-10)
@@ -836,7 +840,7 @@ def test_fused_multi_celltype_step_equals_reference_sequence(theta, monkeypatch)
             v_ode=v_ode, v_pde=pde.state, markers=markers, num_states={k: 19 for k in keys},
             fun={k: tp06.generalized_rush_larsen for k in keys}, init_states={k: tp06.init_state_values() for k in keys},
             parameters=params, v_index={k: tp06.state_index("V") for k in keys})
-        assert ode._marked == one_launch
+        assert ode._marked == one_launch and (not one_launch or (ode._node_idx is not None) == (compact == "1"))
         solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode, theta=theta, fused=fused)
         assert solver._can_fuse() == (fused and one_launch) and solver._can_fuse_multi() == fused
         for i in range(25):
