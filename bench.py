@@ -678,17 +678,19 @@ def main():
     if rank == 0:
         n_total = n * n * nz_glob
         # HBM bytes and VALU counters per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-        # very command (tools/measure_round2.sh -> profiles/r02_512_pmc.json); only quoted when this run has the
+        # very command (tools/measure_round3.sh -> profiles/r03_<tag>_pmc.json); only quoted when this run has the
         # configuration the counters were collected on
-        traffic, valu = None, None
-        tfile = ROOT / "profiles" / "r02_512_pmc.json"
-        if tfile.is_file():
+        traffic, valu, pmc_source = None, None, None
+        for tfile in sorted((ROOT / "profiles").glob("r0*_pmc.json"), reverse=True):  # the newest round's file that fits
             tj = json.loads(tfile.read_text())
             cfg = tj.get("config", {})
-            kern = tj.get("kernels", {}).get("ode_step_kernel<Tp06Grl1, false, true>")
-            if cfg.get("n") == n and nz_glob == n and cfg.get("n_gpus") == world and kern:
+            kern = next((v for k, v in tj.get("kernels", {}).items() if k.startswith("ode_step_kernel<Tp06Grl1, false, true")), None)
+            if (cfg.get("n") == n and nz_glob == n and cfg.get("n_gpus") == world and bool(cfg.get("isotropic", False)) == ISOTROPIC
+                    and kern and "hbm_read_bytes" in kern):
                 traffic = kern.get("hbm_read_bytes", 0.0) + kern.get("hbm_write_bytes", 0.0)
                 valu = kern
+                pmc_source = f"profiles/{tfile.name}"
+                break
         k_avg = float(np.mean(iters)) if iters else 0.0
         S = len(ic)
         # every state row read once + written once, plus one read per pending search direction of the previous
@@ -746,7 +748,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": None if traffic is None else "profiles/r02_512_pmc.json (rocprofv3 PMC passes of this command at this size, committed; not re-measured in this run)",
+                "traffic_source": None if traffic is None else f"{pmc_source} (rocprofv3 PMC passes of this command at this size, committed; not re-measured in this run)",
                 "algorithmic_bytes_per_launch": ode_bytes,
                 "bytes_per_node": 16.0 * S + 8.0 * k_pend + g_bytes,
                 "pending_directions_per_launch": k_pend,
@@ -758,7 +760,7 @@ def main():
                     # VALU op on a SIMD16) over the kernel time measured live in this run
                     "frac_of_issue_peak": valu["valu_instr_per_wave"] * valu.get("waves", n_local / 64.0) * 4.0 / (1024.0 * 2.4e9) / (ode_ms * 1e-3),
                     "effective_clock_GHz": valu["gui_cycles_per_xcd"] / (valu["avg_us"] * 1e-6) / 1e9,
-                    "source": "profiles/r02_512_pmc.json (rocprofv3 SQ/GRBM pass of this command, tools/measure_round2.sh)",
+                    "source": f"{pmc_source} (rocprofv3 SQ/GRBM pass of this command, committed; kernel time measured live)",
                 },
                 "inplace_stream": None if stream_ms is None else {
                     "what": "x *= 1.0 over the same state array (torch), 16 B per value, median of 5 launches after the timed region",

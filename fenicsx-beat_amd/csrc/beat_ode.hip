@@ -58,7 +58,6 @@ struct MarkedArgs {
   int stride;                    // doubles per table entry
   const int* vmap;               // (n) node of the PDE grid each entry of the state array belongs to, or nullptr (identity)
   double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
-  int dephase;                   // experiments (BEAT_ODE_DEPHASE): 1 = start the blocks of a CU a third of a tile apart
 };
 
 template <class Model>
@@ -79,10 +78,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
   const FastMath fm{etab, ltab};
-  if (mk.dephase == 1) {  // experiment: the three blocks that share a CU at launch start a third of a tile (~5 us) apart
-    const int ph = (blockIdx.x >> 8) % 3;
-    for (int k = 0; k < ph; ++k) __builtin_amdgcn_s_sleep(127);
-  }
+  // (Round 3, measured and removed: starting the three blocks that share a CU a third of a tile apart -- s_sleep by
+  // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
+  // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
+  // the first round.)
   // a block walks over several tiles of 256 nodes (stride gridDim.x) and pays its launch and the table set-up once:
   // at 512^3, 24 576 blocks of ~21 tiles each measured 10.5-10.6 ms against 10.9-11.3 for one block per tile on the
   // same box (768 blocks, i.e. exactly the resident number: 11.5; 3 072: 10.7; 196 608: 10.9)
@@ -365,7 +364,7 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
-                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr, 0}) {
+                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
@@ -382,11 +381,6 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   }();
   if (grid_cap > 0) grid = std::min(grid, (unsigned)grid_cap);
   const dim3 g3(grid), b3(BEAT_BLOCK);
-  static const int dephase = [] {
-    const char* e = std::getenv("BEAT_ODE_DEPHASE");
-    return e ? std::atoi(e) : 0;
-  }();
-  mk.dephase = dephase;
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
                      dt, v_index, v_copy, pend, mk)
@@ -434,7 +428,7 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
 static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                              const double* host_params, int num_params, const double* dev_params_per_node,
                              int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
-                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr, 0}) {
+                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
@@ -552,7 +546,7 @@ extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_st
   int stride = 0;
   if (int rc = beat_ode_class_table_doubles(model_id, &stride)) return rc;
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, nullptr, 0, nullptr, 0, t, dt, v_index, dev_v_copy, pend,
-                           MarkedArgs{dev_markers, dev_table, stride, dev_node_map, dev_v_field, 0});
+                           MarkedArgs{dev_markers, dev_table, stride, dev_node_map, dev_v_field});
 }
 
 
