@@ -650,6 +650,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->v_dinv);
   (void)hipFree(pde->v_seg);
   (void)hipFree(pde->v_segmask);
+  beat_vrr_destroy(pde);
   delete pde;
   return BEAT_OK;
 }

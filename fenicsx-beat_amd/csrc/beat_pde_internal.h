@@ -73,6 +73,8 @@ struct beat_pde {
   bool guess_pending = false;              // the last solve left x += e + sum alpha_j p_j to its caller ...
   beat_pde_detail::GuessTerms guess_final{};  // ... with these terms
   int rhs_part_blocks = 0;  // block partials written by part 0 of a right-hand side built in two parts
+  void* vrr = nullptr;      // work lists of the z-marching per-node SpMV (beat_pde_vrr.hip), or nullptr
+  int vrr_part_blocks = 0;
   bool small_enabled = true;  // grids of a few thousand nodes: whole solve in one launch (beat_pde_small.hip)
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
@@ -134,6 +136,12 @@ int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, c
 void beat_guess_advance(beat_pde* pde);
 void beat_guess_observe(beat_pde* pde, int iterations);  // of the solve that just ended (adaptive order)
 int beat_guess_policy(beat_pde* pde);                     // hill-climbing move; returns the order to prepare next  // this solve's increment has been recorded: it is the most recent one now
+
+// per-node-coefficient SpMV that marches along z and loads only the forward half of each row (beat_pde_vrr.hip)
+int beat_vrr_setup(beat_pde* pde, const std::vector<unsigned long long>& host_tissue_flags);
+void beat_vrr_destroy(beat_pde* pde);
+bool beat_vrr_available(const beat_pde* pde);
+int beat_vrr_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

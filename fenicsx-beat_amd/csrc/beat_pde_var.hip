@@ -736,6 +736,10 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
     return BEAT_EHIP;
   }
+  if ((rc = beat_vrr_setup(p, flags))) {
+    beat_pde_destroy(p);
+    return rc;
+  }
   *out = p;
   return BEAT_OK;
 }
@@ -879,6 +883,7 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
 }
 
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
+  if (beat_vrr_available(pde)) return beat_vrr_spmv_dot(pde, dev_p, dev_q, dev_st, -1);
   VarArgs a{};
   var_offsets(pde, a);
   a.T1 = pde->v_A;
@@ -892,6 +897,7 @@ int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double*
 }
 
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part) {
+  if (beat_vrr_available(pde)) return beat_vrr_spmv_dot(pde, dev_p, dev_q, dev_st, part);
   const Geom& f = pde->g;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);  // planes that need no ghost data
   VarArgs a{};

@@ -261,6 +261,54 @@ def test_per_node_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl)
     assert np.isclose(float(ops.st[3]), pq, rtol=1e-13)
 
 
+@pytest.mark.parametrize("cells,L", CASES + [((70, 9, 40), (7.0, 0.9, 4.0))])
+def test_marching_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, cells, L, monkeypatch):
+    """vrr_spmv_kernel (csrc/beat_pde_vrr.hip: marches along z, loads the forward half of each row and takes the backward
+    coefficients from the neighbouring lane / row / plane) against var_spmv_kernel (all 15 coefficients gathered, BEAT_VRR=0)
+    on masked grids with per-cell tensors, 3-D / 2-D, with 2 and 4 rows per wave: q identical bit for bit on every tissue
+    node, nothing written elsewhere, p.q equal to the rounding of its summation order -- and a whole PCG solve agrees."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    ctx = hip_ctx
+    d = len(cells)
+    h = tuple(l / c for l, c in zip(L, cells))
+    active, M = _shell_case(cells, L, 7)
+    nn = tuple(c + 1 for c in cells) + (1,) * (3 - d)
+    mf, kf = _stencil.stencil_fields(d, cells, h, M, active)
+    rng = np.random.default_rng(3)
+    n = int(np.prod(nn))
+    x = rng.standard_normal(n)
+    tissue = mf[0] != 0.0
+    out = {}
+    for key, env in (("rows", {"BEAT_VRR": "0"}), ("march2", {"BEAT_VRR": "1", "BEAT_VRR_RY": "2"}), ("march4", {"BEAT_VRR": "1", "BEAT_VRR_RY": "4"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ops = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        ops.ring[0].set(np.where(tissue, x, 0.0))
+        ops.ring[0].ghost_lo.fill_(float("nan"))
+        ops.ring[0].ghost_hi.fill_(float("nan"))
+        ops.q.fill(float("nan"))
+        ops.st.zero_()
+        ops.spmv_dot()
+        ctx.synchronize()
+        q = ops.q.numpy().copy()
+        fv, fx = ops.new_field(), ops.new_field()
+        fv.set(np.where(tissue, -80.0 + 20.0 * x, 0.0))
+        res = ops.solve_single(fv, [], [], fx, 1e-11, 1e-50, 300)
+        out[key] = (q, float(ops.st[3]), fx.numpy().copy(), res.iterations)
+    q0, pq0, x0, it0 = out["rows"]
+    assert np.isfinite(q0[tissue]).all() and np.isnan(q0[~tissue]).all() and abs(pq0) > 0.0
+    for key in ("march2", "march4"):
+        q1, pq1, x1, it1 = out[key]
+        np.testing.assert_array_equal(q1[tissue], q0[tissue])
+        assert np.isnan(q1[~tissue]).all()
+        assert np.isclose(pq1, pq0, rtol=1e-12)
+        assert abs(it1 - it0) <= 1
+        np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-9 * np.abs(x0).max())
+
+
 # ---- API level: voxelised shell, per-cell fibres, transmural cell types (BASELINE configs[4] in small) ---------
 def _shell_geometry(n=(26, 22, 18), h=0.5):
     """Truncated ellipsoidal shell voxelised on a box: active voxels, transmural depth in [0, 1] per voxel

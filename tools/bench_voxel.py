@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=256, help="voxels per axis of the bounding box")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--dense", action="store_true", help="every voxel active (a box with a fibre field): per-node rows without a mask")
     args = ap.parse_args()
     import torch
 
@@ -28,6 +29,8 @@ def main():
     ro = np.sqrt((X / 0.48) ** 2 + (Y / 0.44) ** 2 + (Z / 0.48) ** 2)
     ri = np.sqrt((X / 0.30) ** 2 + (Y / 0.27) ** 2 + (Z / 0.30) ** 2)
     mask = (ro < 1.0) & (ri > 1.0) & (Z < 0.3)
+    if args.dense:
+        mask = np.ones_like(mask)
     ang = np.pi * (ri - 1.0)
     f0 = np.stack([np.cos(ang), np.sin(ang), 0.0 * ang], axis=-1).reshape(-1, 3)
     M = 1.25e-4 * np.eye(3)[None] + (9.5e-4 - 1.25e-4) * f0[:, :, None] * f0[:, None, :]
