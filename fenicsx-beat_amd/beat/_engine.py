@@ -509,6 +509,28 @@ class _HostStagedDist:
         t.copy_(host)
 
 
+def exchange_ghost_planes(field, slab: Slab, group=None) -> None:
+    """Fill the ghost planes of ``field`` with the neighbouring slabs' boundary planes over ``torch.distributed`` (device
+    tensors on nccl = RCCL, host-staged on any other backend): the reference's ``scatter_forward`` for a function that
+    something other than the diffusion solve is about to read across the slab boundary (the interpolation of the
+    potential onto a P2 / DG1 ODE space, utils.local_project)."""
+    if slab.world <= 1:
+        return
+    import torch.distributed as dist
+
+    d = dist if dist.get_backend(group) == "nccl" else _HostStagedDist(dist)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    plane, ops = field.plane, []
+    if not slab.lo_phys:
+        ops.append(d.P2POp(d.isend, field.data[:plane], peer(slab.rank - 1), group))
+        ops.append(d.P2POp(d.irecv, field.ghost_lo, peer(slab.rank - 1), group))
+    if not slab.hi_phys:
+        ops.append(d.P2POp(d.isend, field.data[field.n - plane:], peer(slab.rank + 1), group))
+        ops.append(d.P2POp(d.irecv, field.ghost_hi, peer(slab.rank + 1), group))
+    for req in (d.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+
+
 class LibCommUnavailable(RuntimeError):
     """Raised by LibComm on EVERY rank when any rank could not set its side up (agreed collectively)."""
 

@@ -801,8 +801,6 @@ class FunctionSpace:
             fam = "DG"  # degree 0: host-side cell data (CellFunction); degree 1: ODE space
         elif fam is None or degree not in (1, 2):
             raise NotImplementedError(f"function space {family} {degree} is not implemented on the HIP backend")
-        if (fam, degree) != ("Lagrange", 1) and mesh.comm.size > 1 and degree != 0:
-            raise NotImplementedError("P2 / DG1 ODE spaces are implemented on one rank only")
         self.mesh = mesh
         self.family = fam
         self.degree = degree
@@ -829,11 +827,14 @@ class FunctionSpace:
 
     # -- degrees of freedom of the non-P1 spaces ------------------------------------------------------------------
     def _edges(self):
-        """(first vertex, second vertex) of every edge of the simplicial mesh: node i and i + o for the forward
-        stencil offsets o that stay inside the box (every such pair shares a box cell, hence an edge)."""
+        """(first vertex, second vertex) of every edge of the simplicial mesh whose FIRST vertex this rank owns: node i
+        and i + o for the forward stencil offsets o that stay inside the box (every such pair shares a box cell, hence an
+        edge); GLOBAL node ids -- on a decomposed mesh the second vertex of an edge that points upwards out of the slab
+        is a node of the upper neighbour's first plane (this rank's upper ghost plane)."""
         mesh = self.mesh
         nx, ny, nz = mesh.shape_global
-        iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        z0, z1 = (mesh.slab.z0, mesh.slab.z1) if mesh.comm.size > 1 else (0, nz)
+        iz, iy, ix = np.meshgrid(np.arange(z0, z1), np.arange(ny), np.arange(nx), indexing="ij")
         node = (ix + nx * (iy + ny * iz)).ravel()
         ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
         a, b = [], []
@@ -849,19 +850,39 @@ class FunctionSpace:
         """(from_p1, to_p1): from_p1 = (idx (n, 2), w (n, 2)) expressing every dof as a combination of P1 vertex
         values (the P1 interpolant evaluated at the dof's point); to_p1 = for every vertex one dof located there."""
         if self._layout is None:
+            # Node ids are LOCAL to the rank's slab: 0 .. n_local-1 its own nodes (plane by plane), n_local .. n_local +
+            # plane - 1 the upper ghost plane, -plane .. -1 the lower one -- the positions of those values in a field.  On a
+            # decomposed mesh a P2 space holds the vertices of the slab and the edges that start at them; a DG1 space the
+            # cells that touch one of the slab's node planes (the layer between two slabs is held by both ranks, as
+            # DOLFINx holds ghost cells: the ODE is pointwise, both compute the same values there).
             mesh = self.mesh
-            nv = mesh.num_nodes_global
+            plane = mesh.plane
+            multi = mesh.comm.size > 1
+            base = mesh.slab.z0 * plane if multi else 0
+            nv = mesh.num_nodes if multi else mesh.num_nodes_global
             if self.family == "Lagrange" and self.degree == 2:
                 ea, eb = self._edges()
+                ea, eb = ea - base, eb - base
                 idx = np.concatenate([np.stack([np.arange(nv), np.arange(nv)], axis=1), np.stack([ea, eb], axis=1)])
                 w = np.concatenate([np.tile([1.0, 0.0], (nv, 1)), np.full((len(ea), 2), 0.5)])
                 to_p1 = np.arange(nv, dtype=np.int64)
             elif self.family == "DG" and self.degree == 1:
-                verts = mesh.cell_vertices(mesh.all_cells()).ravel()
+                cells = mesh.all_cells()
+                if multi:
+                    per_layer = mesh.n[0] * mesh.n[1] * mesh.simplices_per_cell  # cell id = box cell (x fastest) * simplices + k
+                    layer = cells // per_layer
+                    cells = cells[(layer >= mesh.slab.z0 - 1) & (layer <= mesh.slab.z1 - 1)]
+                verts = mesh.cell_vertices(cells).ravel() - base
                 idx = np.stack([verts, verts], axis=1)
                 w = np.tile([1.0, 0.0], (len(verts), 1))
-                to_p1 = np.zeros(nv, dtype=np.int64)
-                to_p1[verts[::-1]] = np.arange(len(verts))[::-1]  # first dof sitting at each vertex
+                own = (verts >= 0) & (verts < nv)
+                to_p1 = np.full(nv, -1, dtype=np.int64)
+                pos = np.nonzero(own)[0]
+                to_p1[verts[pos][::-1]] = pos[::-1]  # first dof sitting at each vertex
+                if (to_p1 < 0).any():
+                    if mesh.active is None:
+                        raise RuntimeError("a vertex of the slab belongs to no cell of the DG1 space")
+                    to_p1[to_p1 < 0] = 0  # vertices outside the tissue: any dof (their potential is not part of the system)
             else:
                 raise NotImplementedError("layout is only needed for P2 / DG1 spaces")
             self._layout = ((np.ascontiguousarray(idx, dtype=np.int64), np.ascontiguousarray(w)), to_p1)
@@ -882,7 +903,8 @@ class FunctionSpace:
             return self.mesh.node_coordinates(pad3=True)
         (idx, w), _ = self.layout()
         xyz = self.mesh.node_coordinates(pad3=True, local=False)
-        return w[:, :1] * xyz[idx[:, 0]] + w[:, 1:] * xyz[idx[:, 1]]
+        base = self.mesh.slab.z0 * self.mesh.plane if self.mesh.comm.size > 1 else 0
+        return w[:, :1] * xyz[idx[:, 0] + base] + w[:, 1:] * xyz[idx[:, 1] + base]
 
 
 class VectorFunctionSpace:
@@ -892,8 +914,8 @@ class VectorFunctionSpace:
     assembled."""
 
     def __init__(self, mesh: Mesh, value_size: int):
-        if mesh.comm.size > 1:
-            raise NotImplementedError("nodal vector fields are implemented on one rank (pass the fibres per cell on several)")
+        # (on a decomposed mesh every rank holds the whole nodal field on the host -- it is input data, reduced to one
+        # tensor per simplex of the rank's slab when the operators are assembled; x.array is therefore the GLOBAL vector)
         self.mesh = mesh
         self.value_size = int(value_size)
         self.family, self.degree = "Lagrange", 1
@@ -909,7 +931,7 @@ class VectorFunctionSpace:
         return self.mesh.num_nodes_global * self.value_size
 
     def tabulate_dof_coordinates(self) -> np.ndarray:
-        return self.mesh.node_coordinates(pad3=True)
+        return self.mesh.node_coordinates(pad3=True, local=False)
 
 
 class VectorFunction:

@@ -38,6 +38,11 @@ def local_project(v: grid.Function, V: grid.FunctionSpace, u: grid.Function | No
         return U
     if src_space.is_p1 and not V.is_p1:
         idx, w = _interp_maps(V)["from_p1"]
+        mesh = src_space.mesh
+        if mesh.comm.size > 1:  # dofs on the slab's faces interpolate between this rank's and its neighbour's vertices
+            from ._engine import exchange_ghost_planes
+
+            exchange_ghost_planes(v.field, mesh.slab, mesh.comm.group)
     elif V.is_p1 and not src_space.is_p1:
         idx, w = _interp_maps(src_space)["to_p1"]
     else:

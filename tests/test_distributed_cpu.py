@@ -226,3 +226,87 @@ def test_bench_refuses_more_ranks_than_visible_gpus():
                          cwd=root, env=env)
     assert res.returncode != 0 and time.perf_counter() - tic < 30
     assert "needs 8 visible GPUs" in res.stderr and not res.stdout.strip()
+
+
+def _layout_worker(rank, world, port, out_dir):
+    for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from beat import grid as g
+
+        mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([1.0, 0.8, 1.2])], [5, 4, 7])
+        assert mesh.comm.size == world and mesh.slab.rank == rank
+        out = {"z0": mesh.slab.z0, "z1": mesh.slab.z1, "plane": mesh.plane}
+        for name, space in (("p2", ("P", 2)), ("dg1", ("DG", 1))):
+            V = g.functionspace(mesh, space)
+            (idx, w), to_p1 = V.layout()
+            out[name + "_idx"], out[name + "_w"], out[name + "_to_p1"] = idx, w, to_p1
+            out[name + "_xyz"] = V.tabulate_dof_coordinates()
+            assert V.num_dofs == len(idx) == V.dofmap.index_map.size_local
+        # nodal vector fields (fibres): the whole field on every rank, reduced per simplex of the slab at assembly
+        W = g.functionspace(mesh, ("P", 1, (3,)))
+        f = g.Function(W)
+        f.interpolate(lambda x: np.stack([np.cos(x[2]), np.sin(x[2]), 0.0 * x[0]]))
+        out["fibre"] = np.asarray(f.x.array).copy()
+        np.savez(Path(out_dir) / f"rank{rank}.npz", **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2_and_dg1_layouts_and_nodal_fibres_on_two_slabs(tmp_path):
+    """The ODE spaces the reference's splitting tests parametrise over (tests/test_monodomain_solver.py:33-216, run under
+    ``mpirun -n 2`` by .github/workflows/main-mpi.yml:33) and the nodal fibre field of its geometries, on a mesh cut into
+    two z-slabs (gloo, world 2; layouts are host logic, no GPU): every P2 dof -- a vertex of the slab or an edge starting
+    at one -- is the same two-term combination of the same GLOBAL vertices as on one rank, every edge and vertex is held
+    exactly once; every DG1 dof sits on a vertex of one of its cells, the layer of cells between the slabs is held by both
+    ranks, the others by one; an edge or cell that reaches across the cut refers to the neighbour's plane through the ghost
+    plane (local index >= n_local or < 0); ``to_p1`` picks, for every vertex of the slab, a dof located there."""
+    from beat import grid as g
+
+    port = _free_port()
+    mp.spawn(_layout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    one = g.create_box(g.Comm(), [np.zeros(3), np.array([1.0, 0.8, 1.2])], [5, 4, 7])
+    assert one.comm.size == 1
+    xyz = one.node_coordinates(pad3=True, local=False)
+    plane = int(parts[0]["plane"])
+    n_glob = one.num_nodes_global
+    assert int(parts[0]["z0"]) == 0 and int(parts[0]["z1"]) == int(parts[1]["z0"]) and int(parts[1]["z1"]) == 8
+    # P2: union over the ranks == the one-rank layout, as sets of (global a, global b, weights)
+    (idx1, w1), _ = g.functionspace(one, ("P", 2)).layout()
+    ref = sorted(map(tuple, np.column_stack([idx1, w1]).tolist()))
+    got = []
+    for p in parts:
+        base, nloc = int(p["z0"]) * plane, (int(p["z1"]) - int(p["z0"])) * plane
+        idx = p["p2_idx"]
+        assert idx.min() >= 0 and idx.max() < nloc + plane  # an upward edge of the top plane ends in the upper ghost plane
+        got += list(map(tuple, np.column_stack([idx + base, p["p2_w"]]).tolist()))
+        np.testing.assert_array_equal(p["p2_to_p1"], np.arange(nloc))
+        np.testing.assert_allclose(p["p2_xyz"], p["p2_w"][:, :1] * xyz[idx[:, 0] + base] + p["p2_w"][:, 1:] * xyz[idx[:, 1] + base])
+    assert sorted(got) == ref
+    assert any((p["p2_idx"].max() >= (int(p["z1"]) - int(p["z0"])) * plane) for p in parts[:1])  # rank 0 does reach across
+    # DG1: cells as vertex tuples
+    (idxd, _), _ = g.functionspace(one, ("DG", 1)).layout()
+    cells_ref = sorted(map(tuple, idxd[:, 0].reshape(-1, 4).tolist()))
+    seen = {}
+    for r, p in enumerate(parts):
+        base, nloc = int(p["z0"]) * plane, (int(p["z1"]) - int(p["z0"])) * plane
+        idx = p["dg1_idx"][:, 0]
+        assert idx.min() >= -plane and idx.max() < nloc + plane
+        for c in map(tuple, (idx + base).reshape(-1, 4).tolist()):
+            seen.setdefault(c, []).append(r)
+        to_p1 = p["dg1_to_p1"]
+        np.testing.assert_array_equal(idx[to_p1], np.arange(nloc))  # the chosen dof sits on that vertex
+        np.testing.assert_allclose(p["dg1_xyz"], xyz[idx + base])
+    assert sorted(seen) == cells_ref
+    cut = int(parts[0]["z1"])  # cells between node planes cut-1 and cut are held by both ranks
+    for c, ranks in seen.items():
+        zs = {v // plane for v in c}
+        assert ranks == ([0, 1] if zs == {cut - 1, cut} else [0] if max(zs) < cut else [1]), (c, ranks)
+    # the nodal fibre field is the global one on both ranks
+    for p in parts:
+        assert p["fibre"].shape == (3 * n_glob,)
+        np.testing.assert_allclose(p["fibre"].reshape(-1, 3), np.stack([np.cos(xyz[:, 2]), np.sin(xyz[:, 2]), 0 * xyz[:, 0]], axis=1))

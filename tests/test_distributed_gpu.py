@@ -455,6 +455,39 @@ def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_p
         assert bool(p["roundtrip_ok"]) and abs(float(a["leads"][0])) > 0.0
 
 
+@pytest.mark.parametrize("odespace", ["CG_2", "DG_1"])
+def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, tmp_path):
+    """tests/_ode_space_ranks_script.py -- the reference's split test system (tests/test_monodomain_solver.py:33-216, which
+    its CI also runs under ``mpirun -n 2``) in 3-D with the ODE on a P2 / DG1 space and the conductivity from a nodal
+    fibre function -- on two processes (z-slabs; dofs on the cut interpolate across it through the exchanged ghost plane)
+    against one: potential and second state at the vertices equal to 1e-11, same PCG iteration count."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    script = str(root / "tests" / "_ode_space_ranks_script.py")
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir()
+    d2.mkdir()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, script, str(d1), odespace], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), script, str(d2), odespace],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    a = np.load(d1 / "rank0.npz")
+    parts = [np.load(d2 / f"rank{r}.npz") for r in range(2)]
+    assert int(parts[0]["z1"]) == int(parts[1]["z0"]) and int(parts[1]["z1"]) == 10
+    assert abs(a["v"]).max() > 0.05
+    np.testing.assert_allclose(np.concatenate([p["v"] for p in parts]), a["v"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.concatenate([p["s"] for p in parts]), a["s"], rtol=0, atol=1e-11)
+    assert sum(int(p["dofs"]) for p in parts) >= int(a["dofs"])  # DG1: the layer of cells on the cut is held twice
+    assert all(int(p["its"]) == int(a["its"]) for p in parts)
+
+
 def test_voxel_shell_pipeline_on_three_ranks_matches_one_process(tmp_path):
     """BASELINE configs[4] in small (tools/bench_biv.py: voxelised shell, per-voxel fibres, expand_layer markers from the
     Laplace solve, ToR-ORd endo/mid/epi through DolfinMultiODESolver, endocardial surface stimulus) on 3 processes --
