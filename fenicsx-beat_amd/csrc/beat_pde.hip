@@ -650,6 +650,8 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->v_dinv);
   (void)hipFree(pde->v_seg);
   (void)hipFree(pde->v_segmask);
+  (void)hipFree(pde->v_seg_tiled);
+  (void)hipFree(pde->v_segmask_tiled);
   beat_vrr_destroy(pde);
   delete pde;
   return BEAT_OK;

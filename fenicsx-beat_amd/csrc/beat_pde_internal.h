@@ -88,6 +88,8 @@ struct beat_pde {
   int* v_seg = nullptr;        // device: indices of the 64-node segments that hold tissue nodes (ascending)
   std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
   unsigned long long* v_segmask = nullptr;  // device: per list entry, bit l set = node 64 seg + l is a tissue node
+  int* v_seg_tiled = nullptr;               // the same list (and masks) ordered by tiles of T rows x T planes (BEAT_VAR_TILE, experiments)
+  unsigned long long* v_segmask_tiled = nullptr;
   const double* d_tab(int which) const { return d_tabs + (size_t)which * 27 * beat_pde_detail::TABW; }
   const double* d_dinv() const { return d_tabs + (size_t)4 * 27 * beat_pde_detail::TABW; }
   const double* dinv_arg() const { return var ? v_dinv : d_dinv(); }

@@ -49,7 +49,28 @@ struct VarArgs {
   const int* seg;      // active segments (VAR_SEG nodes each) covering [i_lo, i_hi) (nullptr: every node of the range)
   const unsigned long long* segmask;  // per list entry: which of its nodes are tissue nodes
   int nseg;
+  int tiled;  // the list is in tile order (runs of 8 x 8 rows): every XCD takes one contiguous eighth of it, in order
 };
+
+// The list entries a wave visits.  Plain: entry 4 b + wave of block b, stride 4 gridDim -- consecutive entries land on
+// consecutive blocks, i.e. on all eight XCDs.  Tiled (whole-slab launches of the solver's kernels): the list is ordered
+// by tiles of 8 rows x 8 planes (all x segments of a row together), XCD x (blocks b with b % 8 == x) walks the x-th eighth
+// of it front to back, so that the ~640 entries an XCD has in flight are one or two tiles: the rows of p around a node and
+// the neighbours' forward coefficients it reads as its backward ones are lines that XCD's L2 has just fetched.
+struct VarWalk {
+  int64_t w, end, stride;
+};
+__device__ __forceinline__ VarWalk var_walk(const VarArgs& a, int64_t nwork, int wave) {
+  if (a.tiled) {
+    const int nbx = gridDim.x >> 3;
+    const int64_t per = (nwork + 7) >> 3;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int64_t start = xcd * per;
+    const int64_t end = lb < nbx ? (start + per < nwork ? start + per : nwork) : 0;
+    return VarWalk{start + (int64_t)lb * VAR_SEGS_PER_BLOCK + wave, end, (int64_t)nbx * VAR_SEGS_PER_BLOCK};
+  }
+  return VarWalk{(int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave, nwork, (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK};
+}
 
 template <int MODE>
 __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
@@ -60,7 +81,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
   // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
   const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
-  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+  const VarWalk walk = var_walk(a, nwork, wave);
+  for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
     const int64_t i = (a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG) + lane;
     if (i < a.i_lo || i >= a.i_hi) continue;
     // lanes on nodes outside the tissue issue no loads or stores: lines without a tissue node are never fetched
@@ -232,7 +254,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
   double acc0 = 0.0;
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
   const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
-  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+  const VarWalk walk = var_walk(a, nwork, wave);
+  for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
     const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
     const int64_t i = seg0 + lane;
     const bool active = i >= a.i_lo && i < a.i_hi && (!a.seg || ((a.segmask[w] >> lane) & 1ull));
@@ -311,7 +334,8 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a) {
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
   const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
   const int edge_off = var_edge_offset(lane, a.doff);
-  for (int64_t w = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; w < nwork; w += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
+  const VarWalk walk = var_walk(a, nwork, wave);
+  for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
     const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
     const int64_t i = seg0 + lane;
     const bool active = i >= a.i_lo && i < a.i_hi && (!a.seg || ((a.segmask[w] >> lane) & 1ull));
@@ -606,10 +630,26 @@ struct VarRange {
   const unsigned long long* segmask;
   int nseg;
   unsigned grid;
+  int tiled;
 };
+static int var_tile_edge() {  // BEAT_VAR_TILE = rows and planes per tile of the tile-ordered list (0: node order everywhere)
+  static const int t = [] {
+    const char* e = getenv("BEAT_VAR_TILE");
+    return e != nullptr ? std::max(0, atoi(e)) : 0;
+  }();
+  return t;
+}
 static VarRange var_range(const beat_pde* pde, int z_lo, int z_hi, bool dense) {
-  VarRange r{nullptr, nullptr, 0, 0};
+  VarRange r{nullptr, nullptr, 0, 0, 0};
   if (z_hi <= z_lo) return r;
+  if (!dense && z_lo == 0 && z_hi == pde->g.nz && pde->v_seg_tiled != nullptr && pde->h_seg.size() >= 4096) {
+    r.seg = pde->v_seg_tiled;
+    r.segmask = pde->v_segmask_tiled;
+    r.nseg = (int)pde->h_seg.size();
+    r.grid = (unsigned)std::max<int64_t>(8, (r.nseg + VAR_SEGS_PER_BLOCK - 1) / VAR_SEGS_PER_BLOCK);
+    r.tiled = 1;
+    return r;
+  }
   const int64_t i_lo = (int64_t)z_lo * pde->g.plane, i_hi = (int64_t)z_hi * pde->g.plane;
   int64_t nwork = (i_hi - i_lo + VAR_SEG - 1) / VAR_SEG;
   if (!dense) {
@@ -658,17 +698,24 @@ static int launch_var(const beat_pde* pde, VarArgs& a, int z_lo, int z_hi, int p
   a.seg = r.seg;
   a.segmask = r.segmask;
   a.nseg = r.nseg;
-  if constexpr (MODE == MODE_SPMV_DOT)
-    BEAT_KERNEL(var_spmv_kernel, dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
-  else if (MODE == MODE_RHS && !var_rhs_by_gathers()) {
+  a.tiled = r.tiled;
+  auto whole_xcds = [&](unsigned grid) { return r.tiled ? std::max(8u, grid & ~7u) : grid; };  // tiled: blocks in eights
+  if constexpr (MODE == MODE_SPMV_DOT) {
+    const unsigned grid = whole_xcds(var_stencil_grid<MODE>(r.grid));
+    BEAT_KERNEL(var_spmv_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+    return (int)grid;
+  } else if (MODE == MODE_RHS && !var_rhs_by_gathers()) {
     static const unsigned resident = resident_blocks(var_rhs_kernel);
-    const unsigned grid = std::min(r.grid, resident);
+    const unsigned grid = whole_xcds(std::min(r.grid, resident));
     BEAT_KERNEL(var_rhs_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
     return (int)grid;
-  } else
-    BEAT_KERNEL((var_stencil_kernel<MODE>), dim3(var_stencil_grid<MODE>(r.grid)), dim3(BEAT_BLOCK), 0,
-                       pde->ctx->stream, a);
-  return (int)var_stencil_grid<MODE>(r.grid);
+  }
+  if constexpr (MODE != MODE_SPMV_DOT) {
+    const unsigned grid = whole_xcds(var_stencil_grid<MODE>(r.grid));
+    BEAT_KERNEL((var_stencil_kernel<MODE>), dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, a);
+    return (int)grid;
+  }
+  return 0;
 }
 
 static unsigned var_vec_grid(const beat_pde* pde) {
@@ -731,6 +778,31 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     e = hipMemcpy(p->v_seg, p->h_seg.data(), sizeof(int) * p->h_seg.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && !masks.empty())
     e = hipMemcpy(p->v_segmask, masks.data(), sizeof(unsigned long long) * masks.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && p->g.nz > 1 && !p->h_seg.empty() && var_tile_edge() > 0) {
+    // the same list in tile order: tiles of T rows x T planes (keyed by the segment's first node), node order inside
+    const int TY = var_tile_edge(), TZ = var_tile_edge();
+    const int64_t nyb = (p->g.ny + TY - 1) / TY;
+    std::vector<int64_t> key(p->h_seg.size());
+    std::vector<int> order(p->h_seg.size());
+    for (size_t k = 0; k < p->h_seg.size(); ++k) {
+      const int64_t i0 = (int64_t)p->h_seg[k] * VAR_SEG;
+      const int64_t z = i0 / p->g.plane, y = (i0 % p->g.plane) / p->g.nx;
+      key[k] = (z / TZ) * nyb + y / TY;
+      order[k] = (int)k;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return key[(size_t)u] < key[(size_t)v]; });
+    std::vector<int> seg_t(order.size());
+    std::vector<unsigned long long> mask_t(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+      seg_t[k] = p->h_seg[(size_t)order[k]];
+      mask_t[k] = masks[(size_t)order[k]];
+    }
+    e = hipMalloc(&p->v_seg_tiled, sizeof(int) * seg_t.size());
+    if (e == hipSuccess) e = hipMalloc(&p->v_segmask_tiled, sizeof(unsigned long long) * mask_t.size());
+    if (e == hipSuccess) e = hipMemcpy(p->v_seg_tiled, seg_t.data(), sizeof(int) * seg_t.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(p->v_segmask_tiled, mask_t.data(), sizeof(unsigned long long) * mask_t.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     beat_pde_destroy(p);
     beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
