@@ -379,7 +379,18 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
     const char* e = std::getenv("BEAT_ODE_GRID");
     return e ? std::atoi(e) : 24576;
   }();
-  if (grid_cap > 0) grid = std::min(grid, (unsigned)grid_cap);
+  static const bool balance = [] {  // BEAT_ODE_BALANCE=0: plain cap (A/B runs)
+    const char* e = std::getenv("BEAT_ODE_BALANCE");
+    return !(e && e[0] == '0');
+  }();
+  if (grid_cap > 0 && grid > (unsigned)grid_cap) {
+    // a few tiles per block: give every block the same number (the last one aside).  With 2.67 tiles per block -- 256^3, or
+    // the slab one of 8 ranks owns at 512^3, on 24 576 blocks -- two thirds of the blocks are on a third tile while the
+    // others have finished: 1.36-1.47 ms against 1.25-1.32 with 3 tiles each (A B A B A B on one box, round 3).  With
+    // 21.3 tiles per block (512^3) the plain cap measures the same or better (9.80 against 9.83 ms) and stays.
+    const unsigned per_block = (grid + (unsigned)grid_cap - 1) / (unsigned)grid_cap;
+    grid = (balance && per_block <= 8) ? (grid + per_block - 1) / per_block : (unsigned)grid_cap;
+  }
   const dim3 g3(grid), b3(BEAT_BLOCK);
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
