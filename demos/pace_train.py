@@ -23,6 +23,9 @@ def main(argv=None):
     ap.add_argument("--dt", type=float, default=0.05)
     ap.add_argument("--s1", type=int, default=3)
     ap.add_argument("--bcl", type=float, default=200.0)
+    ap.add_argument("--block", action="store_true", help="the reference demo's own heterogeneity (demos/pace_train.py:133-167): "
+                    "g_Kr and g_Ks set to zero in the right half of the cable instead of the g_CaL gradient -- piecewise "
+                    "constant parameters, which run as two parameter classes at the uniform kernel's speed")
     args = ap.parse_args(argv)
     Lx, Ly, Lz = 12.0, 3.0, 1.0
     geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=Lx, Ly=Ly, Lz=Lz, dx=args.dx)
@@ -40,7 +43,11 @@ def main(argv=None):
     V = g.functionspace(mesh, ("Lagrange", 1))
     x = V.tabulate_dof_coordinates()[:, 0]
     P = np.repeat(tp06.init_parameter_values(stim_amplitude=0.0)[:, None], len(x), axis=1)
-    P[tp06.parameter_index("g_CaL")] *= 1.0 - 0.5 * x / Lx          # action potentials shorten towards the far end
+    if args.block:
+        for name in ("g_Kr", "g_Ks"):
+            P[tp06.parameter_index(name)] = np.where(x >= Lx / 2, 0.0, P[tp06.parameter_index(name)])
+    else:
+        P[tp06.parameter_index("g_CaL")] *= 1.0 - 0.5 * x / Lx      # action potentials shorten towards the far end
     params = DeviceParameters(P)
     y0 = tp06.init_state_values()
     ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, fun=tp06.generalized_rush_larsen, init_states=y0,
@@ -52,7 +59,9 @@ def main(argv=None):
     solver.solve((0.0, T), dt=args.dt, recorder=rec)
     tr = rec.values()                                              # (steps, 2)
     t = args.dt * (1 + np.arange(len(tr)))
-    print(f"{mesh.num_nodes} nodes, {len(tr)} steps of {args.dt} ms, g_CaL x 1.0 at x = 0 .. x 0.5 at x = {Lx} mm")
+    route = "parameter classes: %d uniform sets" % ode._dev.classes[2] if ode._dev.classes is not None else "per-node parameter rows"
+    what = "g_Kr = g_Ks = 0 for x >= %g mm" % (Lx / 2) if args.block else f"g_CaL x 1.0 at x = 0 .. x 0.5 at x = {Lx} mm"
+    print(f"{mesh.num_nodes} nodes, {len(tr)} steps of {args.dt} ms, {what} ({route})")
     report = []
     for b in range(args.s1):
         win = (t >= b * args.bcl) & (t < (b + 1) * args.bcl)

@@ -49,3 +49,14 @@ def test_pace_train_demo():
         assert far[1] < near[1]                                    # less I_CaL there: shorter action potential
     assert report[0][0][1] - report[0][1][1] > 10.0                # by tens of ms on the first, rested beat
     assert report[1][0][1] < report[0][0][1] - 30.0                # restitution: the beat 320 ms later is shorter
+
+
+def test_pace_train_demo_with_the_reference_heterogeneity(capsys):
+    """demos/pace_train.py --block: g_Kr = g_Ks = 0 in the right half of the cable, as the reference's demo sets them
+    (demos/pace_train.py:133-167) -- the (P, N) parameters are recognised as two classes; without the two repolarising
+    currents the far end stays depolarised far longer than the near end."""
+    report = _demo("pace_train").main(["--dx", "0.5", "--s1", "1", "--bcl", "450", "--block"])
+    assert "parameter classes: 2 uniform sets" in capsys.readouterr().out
+    near, far = report[0]
+    assert 0.0 < near[0] < 3.0 and 10.0 < far[0] < 40.0
+    assert np.isfinite(near[1]) and (np.isnan(far[1]) or far[1] > near[1] + 50.0)
