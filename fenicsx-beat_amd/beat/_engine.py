@@ -455,7 +455,12 @@ def build_ops(ctx, mesh, M: np.ndarray) -> "HipOps":
     slab = mesh.slab
     if M.ndim == 2 and mesh.active is None:
         mass_tab, stiff_tab = _stencil.stencil_tables(mesh.dim, mesh.h, M)
+        if getattr(mesh, "kernel_y_as_z", False):  # a 2-D mesh cut into slabs of rows: the kernels see (nx, 1, ny_local)
+            mass_tab, stiff_tab = _stencil.tables_y_as_z(mass_tab), _stencil.tables_y_as_z(stiff_tab)
         return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
+    if getattr(mesh, "kernel_y_as_z", False):
+        raise NotImplementedError("per-cell conductivities and cell masks on a decomposed 2-D mesh (constant tensors only; "
+                                  "3-D meshes take both on any number of ranks)")
     per_voxel = (M.ndim == 2 or M.shape[0] == mesh.num_box_cells) and (mesh.active is None or mesh.active_box is not None)
     if per_voxel:
         return HipOps.from_voxels(ctx, mesh.dim, mesh.n, mesh.h, M, mesh.active_box, mesh.shape_local, slab.z0,

@@ -103,6 +103,21 @@ def stencil_tables(dim: int, h, M) -> tuple[np.ndarray, np.ndarray]:
     return mass_tab, stiff_tab
 
 
+def tables_y_as_z(tab: np.ndarray) -> np.ndarray:
+    """A 2-D (27, 15) table re-expressed for a grid stored as (nx, 1, ny): the kernels decompose along their slowest
+    axis, so a 2-D mesh that is cut into slabs of rows is handed to them with y in the place of z -- node numbering
+    unchanged (x fastest, then the rows).  Type tx + 3 ty + 9 (interior z) -> tx + 3 (collapsed y) + 9 ty, offset
+    (dx, dy, 0) -> (dx, 0, dy); every 2-D offset has its slot in the 15-point set."""
+    out = np.zeros_like(tab)
+    for tx in range(3):
+        for ty in range(3):
+            for k, (dx, dy, dz) in enumerate(OFFSETS):
+                if dz != 0 or tab[tx + 3 * ty + 9, k] == 0.0:
+                    continue
+                out[tx + 3 + 9 * ty, _OFFSET_INDEX[(dx, 0, dy)]] = tab[tx + 3 * ty + 9, k]
+    return out
+
+
 def stencil_fields(dim: int, cells: tuple[int, ...], h, M, active=None, z_range=None) -> tuple[np.ndarray, np.ndarray]:
     """Per-node rows of the same operators for voxel-masked domains and spatially varying conductivity:
     returns (mass, stiff), each (15, n_local) with n_local = nx*ny*(z1-z0) nodes, x fastest.

@@ -401,8 +401,14 @@ class Mesh:
         from ._engine import Slab
 
         world = self.comm.size
-        if world > 1 and self.dim < 3:
-            raise NotImplementedError("slab decomposition is implemented for 3-D boxes only")
+        if world > 1 and self.dim < 2:
+            raise NotImplementedError("slab decomposition is implemented for 2-D and 3-D boxes")
+        # The mesh is cut along its slowest axis: z-slabs in 3-D, slabs of rows in 2-D (the reference's own tests run their
+        # unit squares under ``mpirun -n 2``: .github/workflows/main-mpi.yml:33).  The kernels decompose along THEIR
+        # slowest axis, so a decomposed 2-D mesh is handed to them as the grid (nx, 1, ny_local) -- same node numbering,
+        # a "plane" is one row of nodes -- with its operator tables re-expressed accordingly (_stencil.tables_y_as_z).
+        self.split_axis = self.dim - 1 if world > 1 else 2
+        self.kernel_y_as_z = world > 1 and self.dim == 2
         weights = None
         if active is not None and world > 1 and np.asarray(active).size == int(np.prod(self.n)):
             # voxel mask: balance the slabs by tissue per node plane (a plane touches the voxel layers on both sides)
@@ -410,11 +416,15 @@ class Mesh:
             weights = np.zeros(nodes[2])
             weights[:-1] += per_layer
             weights[1:] += per_layer
-        self.slab = Slab(nodes[2], self.comm.rank, world, weights)
-        self.shape_local = (nodes[0], nodes[1], self.slab.nz)
-        self.plane = nodes[0] * nodes[1]
+        self.slab = Slab(nodes[self.split_axis], self.comm.rank, world, weights)
+        if self.kernel_y_as_z:
+            self.shape_local = (nodes[0], 1, self.slab.nz)
+            self.plane = nodes[0]
+        else:
+            self.shape_local = (nodes[0], nodes[1], self.slab.nz)
+            self.plane = nodes[0] * nodes[1]
         self.num_nodes = self.plane * self.slab.nz
-        self.num_nodes_global = self.plane * nodes[2]
+        self.num_nodes_global = nodes[0] * nodes[1] * nodes[2]
         self.simplices_per_cell = {1: 1, 2: 2, 3: 6}[self.dim]
         self.num_box_cells = int(np.prod(self.n))
         self.active = None  # bool per simplex (global numbering) or None = every cell
@@ -438,7 +448,7 @@ class Mesh:
         if axis >= self.dim:
             return np.zeros(1)
         c = self.lower[axis] + self.h[axis] * np.arange(self.n[axis] + 1)
-        if axis == 2 and local:
+        if axis == self.split_axis and local:
             c = c[self.slab.z0 : self.slab.z1]
         return c
 
@@ -833,8 +843,10 @@ class FunctionSpace:
         is a node of the upper neighbour's first plane (this rank's upper ghost plane)."""
         mesh = self.mesh
         nx, ny, nz = mesh.shape_global
-        z0, z1 = (mesh.slab.z0, mesh.slab.z1) if mesh.comm.size > 1 else (0, nz)
-        iz, iy, ix = np.meshgrid(np.arange(z0, z1), np.arange(ny), np.arange(nx), indexing="ij")
+        ranges = [np.arange(nx), np.arange(ny), np.arange(nz)]
+        if mesh.comm.size > 1:
+            ranges[mesh.split_axis] = np.arange(mesh.slab.z0, mesh.slab.z1)
+        iz, iy, ix = np.meshgrid(ranges[2], ranges[1], ranges[0], indexing="ij")
         node = (ix + nx * (iy + ny * iz)).ravel()
         ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
         a, b = [], []
@@ -869,7 +881,8 @@ class FunctionSpace:
             elif self.family == "DG" and self.degree == 1:
                 cells = mesh.all_cells()
                 if multi:
-                    per_layer = mesh.n[0] * mesh.n[1] * mesh.simplices_per_cell  # cell id = box cell (x fastest) * simplices + k
+                    # cell id = box cell (x fastest) * simplices + k: cells per layer along the axis the mesh is cut along
+                    per_layer = int(np.prod(mesh.n[: mesh.split_axis])) * mesh.simplices_per_cell
                     layer = cells // per_layer
                     cells = cells[(layer >= mesh.slab.z0 - 1) & (layer <= mesh.slab.z1 - 1)]
                 verts = mesh.cell_vertices(cells).ravel() - base

@@ -22,20 +22,27 @@ import beat  # noqa: E402
 from beat import grid as g  # noqa: E402
 
 out_dir, odespace = Path(sys.argv[1]), sys.argv[2]
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 comm = g.COMM_WORLD
-mesh = g.create_box(comm, [np.zeros(3), np.array([1.0, 1.0, 0.75])], [12, 10, 9])
+if dim == 3:
+    mesh = g.create_box(comm, [np.zeros(3), np.array([1.0, 1.0, 0.75])], [12, 10, 9])
+else:  # the reference's own test mesh (tests/test_monodomain_solver.py: unit square), cut into slabs of rows
+    mesh = g.create_unit_square(comm, 24, 20)
 time = g.Constant(mesh, 0.0)
 x = g.SpatialCoordinate(mesh)
 I_s = 8 * g.pi**2 * g.cos(2 * g.pi * x[0]) * g.cos(2 * g.pi * x[1]) * g.sin(time)
-# fibres as a vector P1 function (src/beat/conductivities.py:101-118): rotating with height
-W = g.functionspace(mesh, ("P", 1, (3,)))
-f0 = g.Function(W)
-f0.interpolate(lambda p: np.stack([np.cos(1.3 * p[2]), np.sin(1.3 * p[2]), 0.0 * p[0]]))
-M = beat.conductivities.define_conductivity_tensor(f0=f0, chi=1.0, g_il=1.0, g_it=0.4, g_el=1.0, g_et=0.4)
+if dim == 3:
+    # fibres as a vector P1 function (src/beat/conductivities.py:101-118): rotating with height
+    W = g.functionspace(mesh, ("P", 1, (3,)))
+    f0 = g.Function(W)
+    f0.interpolate(lambda p: np.stack([np.cos(1.3 * p[2]), np.sin(1.3 * p[2]), 0.0 * p[0]]))
+    M = beat.conductivities.define_conductivity_tensor(f0=f0, chi=1.0, g_il=1.0, g_it=0.4, g_el=1.0, g_et=0.4)
+else:
+    M = np.array([[1.0, 0.2], [0.2, 0.6]])
 pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, params={"petsc_options": {"ksp_rtol": 1e-12}})
 V_ode = beat.utils.space_from_string(odespace, mesh, dim=1)
 s = g.Function(V_ode)
-s.interpolate(lambda p: -np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * (1.0 + 0.3 * p[2]))
+s.interpolate(lambda p: -np.cos(2 * np.pi * p[0]) * np.cos(2 * np.pi * p[1]) * (1.0 + 0.3 * p[dim - 1]))
 init_states = np.zeros((2, s.x.array.size))
 init_states[1, :] = np.asarray(s.x.array)
 ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V_ode), v_pde=pde.state, fun=beat.models.simple.forward_euler,

@@ -228,6 +228,82 @@ def test_bench_refuses_more_ranks_than_visible_gpus():
     assert "needs 8 visible GPUs" in res.stderr and not res.stdout.strip()
 
 
+def _layout2d_worker(rank, world, port, out_dir):
+    for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from beat import _stencil
+        from beat import grid as g
+
+        mesh = g.create_unit_square(g.COMM_WORLD, 6, 9)
+        out = {"z0": mesh.slab.z0, "z1": mesh.slab.z1, "plane": mesh.plane, "shape_local": np.array(mesh.shape_local),
+               "xyz": mesh.node_coordinates(pad3=True), "nodes": mesh.num_nodes}
+        for name, space in (("p2", ("P", 2)), ("dg1", ("DG", 1))):
+            V = g.functionspace(mesh, space)
+            (idx, w), to_p1 = V.layout()
+            out[name + "_idx"], out[name + "_w"], out[name + "_to_p1"] = idx, w, to_p1
+        np.savez(Path(out_dir) / f"rank{rank}.npz", **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_dimensional_mesh_is_cut_into_slabs_of_rows(tmp_path):
+    """The reference's unit-square tests run under ``mpirun -n 2``: a 2-D mesh on several ranks is cut along y.  Host
+    logic on gloo (world 3): every rank owns whole rows, ``plane`` is one row of nodes, the kernels' grid is (nx, 1,
+    rows), local coordinates are those of the owned rows; the P2 / DG1 layouts of the slabs add up to the one-rank
+    layouts; and the operator tables handed to the kernels (y in the place of z) describe the same matrix: applying
+    them row by row on the (nx, 1, ny) grid reproduces the assembled 2-D operator of the oracle."""
+    from beat import _stencil
+    from beat import grid as g
+    from oracle import fem
+
+    port = _free_port()
+    mp.spawn(_layout2d_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(3)]
+    one = g.create_unit_square(g.Comm(), 6, 9)
+    xyz = one.node_coordinates(pad3=True, local=False)
+    assert [int(p["plane"]) for p in parts] == [7, 7, 7] and sum(int(p["nodes"]) for p in parts) == 70
+    assert all(tuple(p["shape_local"]) == (7, 1, int(p["z1"]) - int(p["z0"])) for p in parts)
+    np.testing.assert_allclose(np.concatenate([p["xyz"] for p in parts]), xyz)
+    (idx1, w1), _ = g.functionspace(one, ("P", 2)).layout()
+    got = []
+    for p in parts:
+        base = int(p["z0"]) * 7
+        got += list(map(tuple, np.column_stack([p["p2_idx"] + base, p["p2_w"]]).tolist()))
+        nloc = int(p["nodes"])
+        idx = p["dg1_idx"][:, 0]
+        np.testing.assert_array_equal(idx[p["dg1_to_p1"]], np.arange(nloc))
+        assert idx.min() >= -7 and idx.max() < nloc + 7
+    assert sorted(got) == sorted(map(tuple, np.column_stack([idx1, w1]).tolist()))
+    # the remapped tables: y-as-z stencil applied with plain NumPy on the (nx, 1, ny) grid == the oracle's assembled matrix
+    M = np.array([[1.0, 0.2], [0.2, 0.6]])
+    mt, kt = _stencil.stencil_tables(2, one.h, M)
+    m2, k2 = _stencil.tables_y_as_z(mt), _stencil.tables_y_as_z(kt)
+    om = fem.BoxMesh((6, 9), (1.0, 1.0))
+    K = fem.assemble_stiffness(om, M)
+    Mass = fem.assemble_mass(om)
+    nx, ny = 7, 10
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(nx * ny)
+    for tab, mat in ((m2, Mass), (k2, K)):
+        y = np.zeros_like(x)
+        for iz in range(ny):  # the kernels' z = the mesh's y
+            for ix in range(nx):
+                tx = 0 if ix == 0 else 2 if ix == nx - 1 else 1
+                tz = 0 if iz == 0 else 2 if iz == ny - 1 else 1
+                row = tab[tx + 3 + 9 * tz]
+                acc = 0.0
+                for k, (dx, dy, dz) in enumerate(_stencil.OFFSETS):
+                    if row[k] != 0.0:
+                        acc += row[k] * x[(ix + dx) + nx * (iz + dz)]
+                        assert dy == 0
+                y[ix + nx * iz] = acc
+        np.testing.assert_allclose(y, mat @ x, rtol=0, atol=1e-12 * np.abs(mat @ x).max())
+
+
 def _layout_worker(rank, world, port, out_dir):
     for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
         if p not in sys.path:

@@ -455,8 +455,8 @@ def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_p
         assert bool(p["roundtrip_ok"]) and abs(float(a["leads"][0])) > 0.0
 
 
-@pytest.mark.parametrize("odespace", ["CG_2", "DG_1"])
-def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, tmp_path):
+@pytest.mark.parametrize("odespace,dim,world", [("CG_2", 3, 2), ("DG_1", 3, 2), ("CG_1", 2, 2), ("CG_2", 2, 3), ("DG_1", 2, 2)])
+def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, dim, world, tmp_path):
     """tests/_ode_space_ranks_script.py -- the reference's split test system (tests/test_monodomain_solver.py:33-216, which
     its CI also runs under ``mpirun -n 2``) in 3-D with the ODE on a P2 / DG1 space and the conductivity from a nodal
     fibre function -- on two processes (z-slabs; dofs on the cut interpolate across it through the exchanged ghost plane)
@@ -472,15 +472,16 @@ def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(o
     d1.mkdir()
     d2.mkdir()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    one = subprocess.run([sys.executable, script, str(d1), odespace], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    # (dim = 2: the reference's own unit-square mesh cut into slabs of ROWS -- the kernels see it as the grid (nx, 1, ny_local))
+    one = subprocess.run([sys.executable, script, str(d1), odespace, str(dim)], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert one.returncode == 0, one.stderr[-3000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(_free_port()), script, str(d2), odespace],
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), script, str(d2), odespace, str(dim)],
                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
     assert two.returncode == 0, two.stderr[-3000:]
     a = np.load(d1 / "rank0.npz")
-    parts = [np.load(d2 / f"rank{r}.npz") for r in range(2)]
-    assert int(parts[0]["z1"]) == int(parts[1]["z0"]) and int(parts[1]["z1"]) == 10
+    parts = [np.load(d2 / f"rank{r}.npz") for r in range(world)]
+    assert all(int(parts[r]["z1"]) == int(parts[r + 1]["z0"]) for r in range(world - 1)) and int(parts[-1]["z1"]) == (10 if dim == 3 else 21)
     assert abs(a["v"]).max() > 0.05
     np.testing.assert_allclose(np.concatenate([p["v"] for p in parts]), a["v"], rtol=0, atol=1e-11)
     np.testing.assert_allclose(np.concatenate([p["s"] for p in parts]), a["s"], rtol=0, atol=1e-11)
