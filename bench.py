@@ -837,8 +837,67 @@ def main():
                 solver.libcomm = libcomm
             finally:
                 timer.cancel()
+        # If an alternative beat the transport the headline was measured on by more than 3 % -- in the regime both were timed
+        # in: the alternatives continue from the state of the last timed region -- the headline regime is measured again on
+        # it (state re-initialised, same warm-up, same K steps, same barriers) and THAT becomes `value`: the line reports
+        # the best this build does on this node, and says so.  Same deadline rule.
+        ref_ms = (fr["wall"] if front else wall) / args.steps * 1e3
+        timed = {k: v["ms_per_step"] for k, v in transports.items() if isinstance(v, dict) and "ms_per_step" in v and k != main_name}
+        best = min(timed, key=timed.get) if timed else None
+        choice = {"headline_measured_on": main_name, "compared_in": "developed_front" if front else "headline",
+                  "reference_ms_per_step": ref_ms, "adopted": None}
+        if best is not None and timed[best] < 0.97 * ref_ms and os.environ.get("BEAT_BENCH_ADOPT", "1") == "1":
+            timer = threading.Timer(deadline, give_up)
+            timer.daemon = True
+            timer.start()
+            try:
+                progress(f"{best} was {100 * (1 - timed[best] / ref_ms):.0f} % faster: measuring the headline regime on it")
+                name, serial = (best[:-7], True) if best.endswith("-serial") else (best, False)
+                alt = LibComm(ctx, slab, dist, None, name, serial=serial, plane_doubles=plane)
+                solver.libcomm = alt
+                ops.flush_pending()
+                init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
+                ops.guess_reset()
+                solver.exchange_halo(v_field)
+                hr = timed_run(0.0, args.warmup, args.steps)
+                hmin, hmax = v_field.minmax()
+                ext = torch.tensor([-hmin, hmax, 0.0 if np.isfinite(hmin) and np.isfinite(hmax) else 1.0], dtype=torch.float64,
+                                   device=ctx.device if backend == "nccl" else "cpu")
+                dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+                ok = float(ext[2]) == 0.0
+                if ok and hr["wall"] < wall:
+                    choice["adopted"] = best
+                    if rank == 0:
+                        transports[main_name]["role"] = "first measurement of the headline"
+                        k_new = float(np.mean(hr["iters"]))
+                        kp = float(np.mean(hr["pend_counts"])) if hr["pend_counts"] else 0.0
+                        gb = 8.0 * float(np.mean(hr["guess_fields"])) if hr["guess_fields"] else 0.0
+                        ob = (16.0 * len(ic) + 8.0 * kp + gb) * n_local
+                        out.update(value=n * n * nz_glob * args.steps / hr["wall"], ms_per_step=hr["wall"] / args.steps * 1e3)
+                        out["config"].update(pcg_iterations_per_step=k_new, ode_ms=hr["ode_ms"], pde_ms=hr["pde_ms"],
+                                             v_min=-float(ext[0]), v_max=float(ext[1]), comm=alt.info())
+                        out["roofline"].update(achieved=ob / (hr["ode_ms"] * 1e-3) / 1e9, frac=ob / (hr["ode_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               algorithmic_bytes_per_launch=ob, bytes_per_node=16.0 * len(ic) + 8.0 * kp + gb,
+                                               pending_directions_per_launch=kp)
+                        sb = (16.0 * len(ic) + 16.0 + 88.0 * k_new) * n * n * nz_glob
+                        out["roofline"]["whole_step"].update(bytes_per_node_update=16.0 * len(ic) + 16.0 + 88.0 * k_new,
+                                                             achieved=sb * args.steps / hr["wall"] / 1e9 / world,
+                                                             frac_of_8TBs_per_gpu=sb * args.steps / hr["wall"] / 1e9 / world / HBM_PEAK_GBS)
+                        out["roofline"]["whole_step"]["frac_of_6.29TBs_per_gpu"] = sb * args.steps / hr["wall"] / 1e9 / world / HBM_COPY_GBS
+                        transports[best + " (headline)"] = {"ms_per_step": hr["wall"] / args.steps * 1e3, "pcg_iterations_per_step": k_new,
+                                                           "ode_ms": hr["ode_ms"], "pde_ms": hr["pde_ms"], "role": "headline"}
+                ops.flush_pending()
+                torch.cuda.synchronize()
+                solver.libcomm = libcomm
+                alt.close()
+            except LibCommUnavailable as exc:
+                choice["error"] = str(exc)
+                solver.libcomm = libcomm
+            finally:
+                timer.cancel()
         if rank == 0:
             out["transports"] = transports
+            out["config"]["transport_choice"] = choice
     if rank == 0:
         print(json.dumps(out), file=result_stream, flush=True)
     if world > 1 or force_dist:

@@ -398,7 +398,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert r["config"]["launch"]["attempts"][-1]["rc"] == 0 and len(r["config"]["launch"]["attempts"]) == 1
     assert [x["rank"] for x in r["ranks"]] == [0, 1] and sum(x["nodes"] for x in r["ranks"]) == 64**3
     assert all(x["ode_ms"] > 0 and x["pde_ms"] > 0 for x in r["ranks"])
-    assert r["config"]["comm"]["transport"] == "callbacks"
+    choice = r["config"]["transport_choice"]
+    assert choice["headline_measured_on"] == "callbacks" and choice["adopted"] in (None, "ipc")
+    # (an alternative that is > 3 % faster in the regime both were timed in gets the headline regime re-measured on it, and
+    # that measurement becomes `value`: host-staged callbacks against device-to-device copies -- ipc usually wins here)
+    assert r["config"]["comm"]["transport"] == ("ipc" if choice["adopted"] else "callbacks")
+    if choice["adopted"]:
+        assert r["transports"]["ipc (headline)"]["ms_per_step"] == r["ms_per_step"] < r["transports"]["callbacks"]["ms_per_step"]
     ipc = r["transports"]["ipc"]
     assert "error" not in ipc and ipc["comm"]["transport"] == "ipc" and ipc["ms_per_step"] > 0
     assert abs(ipc["pcg_iterations_per_step"] - r["config"]["pcg_iterations_per_step"]) <= 1.5
