@@ -37,7 +37,7 @@ outside the timed steps.
 (P / f"r03_{tag}.md").write_text(head + (O / "summary.md").read_text().split("\n", 1)[1])
 pmc = json.loads((O / "summary.json").read_text())
 pmc["config"] = {
-    "n": n, "n_gpus": 1, "isotropic": "isotropic" in d["config"]["workload"],
+    "n": n, "n_gpus": 1, "isotropic": " isotropic slab" in d["config"]["workload"],
     "command": f"bench.py (tools/measure_round3.sh {tag}), package defaults: ksp_guess_order auto, 24576 blocks per ionic launch",
     "note": "per-launch means over launches that did real work; HBM bytes: FETCH_SIZE x2 (gfx950 correction) and WRITE_SIZE; an ionic-kernel wave walks over ~21 tiles of 64 nodes (valu_instr_per_wave x waves x 64 / nodes = instructions per node)",
 }
