@@ -547,8 +547,9 @@ class LibComm:
     on the compute stream; ``serial=True`` / env ``BEAT_DIST_SERIAL=1``: one communicator, one stream); rank 0's
     unique id reaches the other ranks through ``torch.distributed`` (any backend) -- that broadcast at set-up is all
     PyTorch contributes.  ``transport="ipc"``: ghost planes as interprocess device-to-device copies (mailboxes mapped
-    with hipIpc*, interprocess events), all-reduces by RCCL when ``torch.distributed`` runs on nccl, handed back to
-    Python otherwise -- the transport that lets several processes sharing ONE GPU exchange planes on the device.
+    with hipIpc*, ordered by sequence flags in device memory) and all-reduces through the same mailboxes (up to
+    ``IPC_MAX_RANKS`` ranks; ``BEAT_IPC_ALLREDUCE=rccl|caller``: by RCCL / handed back to Python) -- no RCCL at all,
+    and the transport that lets several processes sharing ONE GPU exchange planes on the device.
     ``transport="callbacks"``: both operations are handed back to Python and staged through the host over ``dist``
     (gloo) -- the rehearsal transport.  ``peers``: override of (peer_lo, peer_hi), used by the one-rank periodic
     self-exchange tests.
@@ -597,7 +598,15 @@ class LibComm:
                 raise LibCommUnavailable(f"{transport} transport, {stage}: " + (str(err) if err is not None else "failed on another rank")) from err
 
         ids = None
-        use_rccl = transport == "rccl" or (transport == "ipc" and (nccl or not collective) and os.environ.get("BEAT_IPC_ALLREDUCE", "rccl") == "rccl")
+        # who sums the dot products of the ipc transport: "ipc" (the mailboxes, no RCCL at all), "rccl", "caller" (dist)
+        ipc_sum = os.environ.get("BEAT_IPC_ALLREDUCE", "ipc") if transport == "ipc" else None
+        if ipc_sum == "ipc" and world > _hip.IPC_MAX_RANKS:
+            ipc_sum = "rccl"
+        if ipc_sum == "rccl" and collective and not nccl:
+            ipc_sum = "caller"  # several processes on one GPU (gloo rehearsal): RCCL cannot run there
+        if ipc_sum not in (None, "ipc", "rccl", "caller"):
+            raise ValueError(f"BEAT_IPC_ALLREDUCE={ipc_sum!r}: ipc, rccl or caller")
+        use_rccl = transport == "rccl" or ipc_sum == "rccl"
         if use_rccl:
             ids = C.create_string_buffer(2 * _hip.UNIQUE_ID_BYTES)
             box = [None]
@@ -629,7 +638,7 @@ class LibComm:
             mine = C.create_string_buffer(_hip.IPC_HANDLE_BYTES)
             self._allreduce_cb = None
             cb = None
-            if not use_rccl:
+            if ipc_sum == "caller":
                 self._allreduce_cb = _hip.ALLREDUCE_FN(self._allreduce)
                 cb = C.cast(self._allreduce_cb, C.c_void_p)
             try:
@@ -645,9 +654,12 @@ class LibComm:
                 dist.all_gather_object(gathered, mine.raw, group=group)
                 handles = dict(enumerate(gathered))
             try:
-                lo = handles.get(self.peer_lo) if self.peer_lo >= 0 and self.peer_lo != rank else None
-                hi = handles.get(self.peer_hi) if self.peer_hi >= 0 and self.peer_hi != rank else None
-                _hip.check(lib.beat_comm_ipc_connect(handle, lo, hi))
+                if ipc_sum == "ipc":  # every rank maps every mailbox: the all-reduce writes into all of them
+                    _hip.check(lib.beat_comm_ipc_connect_all(handle, b"".join(handles[r] for r in range(world)), world))
+                else:
+                    lo = handles.get(self.peer_lo) if self.peer_lo >= 0 and self.peer_lo != rank else None
+                    hi = handles.get(self.peer_hi) if self.peer_hi >= 0 and self.peer_hi != rank else None
+                    _hip.check(lib.beat_comm_ipc_connect(handle, lo, hi))
             except Exception as exc:  # noqa: BLE001
                 err = exc
             agree("connect")
@@ -667,7 +679,7 @@ class LibComm:
         out = (C.c_int * 4)()
         _hip.check(self.ctx.lib.beat_comm_info(self.handle, out))
         return {"transport": _hip.TRANSPORT_NAMES.get(out[0], str(out[0])), "rccl_ranks": int(out[1]), "world": int(out[2]),
-                "allreduce": "rccl" if out[3] else "caller"}
+                "allreduce": {0: "caller", 1: "rccl", 2: "ipc"}[int(out[3])]}
 
     def profile(self, enable: bool) -> None:
         _hip.check(self.ctx.lib.beat_comm_profile(self.handle, int(bool(enable))))

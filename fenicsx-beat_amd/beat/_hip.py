@@ -125,6 +125,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(_int, _vp, _vp, _int)
 ALLREDUCE_FN_OR_NULL = _vp  # an ALLREDUCE_FN cast to void* (ctypes function types do not accept None)
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 2048
+IPC_MAX_RANKS = 16
 COMM_SERIAL = 1
 TRANSPORT_NAMES = {0: "callbacks", 1: "rccl", 2: "rccl-serial", 3: "ipc"}
 E_NOT_CONVERGED = -3
@@ -136,6 +137,7 @@ SIGNATURES.update({
     "beat_comm_create_rccl_ex": (_int, [_vp, _int, _int, _int, _int, _vp, _int, C.POINTER(_vp)]),
     "beat_comm_create_ipc": (_int, [_vp, _int, _int, _int, _int, _i64, _vp, ALLREDUCE_FN_OR_NULL, _vp, _vp, C.POINTER(_vp)]),
     "beat_comm_ipc_connect": (_int, [_vp, _vp, _vp]),
+    "beat_comm_ipc_connect_all": (_int, [_vp, _vp, _int]),
     "beat_comm_info": (_int, [_vp, C.POINTER(_int)]),
     "beat_comm_profile": (_int, [_vp, _int]),
     "beat_comm_profile_read": (_int, [_vp, C.POINTER(_dbl)]),

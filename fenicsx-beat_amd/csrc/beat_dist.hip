@@ -112,6 +112,55 @@ struct IpcFlags {  // in the mailbox, written by the neighbours (peer_lo's side:
   unsigned long long freed[2];    // messages this rank sent to that neighbour that it has taken out of its mailbox
 };
 
+// All-reduce of the PCG's 1-3 dot products without RCCL (connect_all): every rank stores its values into EVERY rank's
+// mailbox (slot s % IPC_AR_SLOTS of all-reduce number s, its own column) and raises that column's sequence flag; every
+// rank then waits for all columns of its own mailbox and adds them IN RANK ORDER -- one small kernel on the compute
+// stream, the same bits on every rank (the convergence latch must come out alike everywhere), a store and a flag over
+// xGMI instead of an RCCL kernel launch with its channel set-up per call.  A rank can be at most one all-reduce ahead of
+// the slowest (it needs everybody's contribution to finish one), so four slots never collide.
+constexpr int IPC_AR_SLOTS = 4;
+constexpr int IPC_AR_VALUES = 4;
+struct IpcAr {
+  unsigned long long flag[IPC_AR_SLOTS][BEAT_IPC_MAX_RANKS];
+  double val[IPC_AR_SLOTS][BEAT_IPC_MAX_RANKS][IPC_AR_VALUES];
+};
+
+struct IpcArArgs {
+  char* box[BEAT_IPC_MAX_RANKS];  // every rank's mailbox as this rank sees it
+  size_t ar_offset;               // of the IpcAr block inside a mailbox
+  int rank, world, count;
+  unsigned long long seq;
+  double* values;                 // in: this rank's partial sums, out: the sums over the ranks
+  long long ticks;
+  int* err;
+};
+
+__global__ __launch_bounds__(64) void ipc_allreduce_kernel(IpcArArgs a) {
+  const int j = threadIdx.x;
+  const int slot = (int)(a.seq % IPC_AR_SLOTS);
+  IpcAr* mine = (IpcAr*)(a.box[a.rank] + a.ar_offset);
+  if (j < a.world) {
+    IpcAr* dst = (IpcAr*)(a.box[j] + a.ar_offset);
+    for (int c = 0; c < a.count; ++c) dst->val[slot][a.rank][c] = a.values[c];
+    __threadfence_system();
+    __hip_atomic_store(&dst->flag[slot][a.rank], a.seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&mine->flag[slot][j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq + 1) {
+      if (wall_clock64() - t0 > a.ticks) {
+        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (j < a.count) {  // one lane per value, ranks added in order
+    double s = 0.0;
+    for (int r = 0; r < a.world; ++r) s += __hip_atomic_load(&mine->val[slot][r][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.values[j] = s;
+  }
+}
+
 struct IpcHandle {  // what beat_comm_create_ipc exports (BEAT_IPC_HANDLE_BYTES)
   uint32_t magic, rank;
   int64_t plane_max;
@@ -205,6 +254,8 @@ inline double* ipc_slot(char* box, int64_t plane_max, int dir, int slot, int fie
   return (double*)box + (((int64_t)dir * IPC_SLOTS + slot) * IPC_FIELDS + field) * plane_max;
 }
 inline IpcFlags* ipc_flags(char* box, int64_t plane_max) { return (IpcFlags*)(box + ipc_data_bytes(plane_max)); }
+inline size_t ipc_ar_offset(int64_t plane_max) { return ipc_data_bytes(plane_max) + 256; }
+inline size_t ipc_box_bytes(int64_t plane_max) { return ipc_ar_offset(plane_max) + sizeof(IpcAr); }
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -232,6 +283,9 @@ struct beat_comm {
   unsigned int* ipc_counters = nullptr;  // device, local: [send lo, send hi, recv lo, recv hi]
   int* ipc_err = nullptr;              // pinned host memory: set by a transfer kernel that gave up waiting
   IpcPeer ipc_peer[2];
+  char* ipc_all[BEAT_IPC_MAX_RANKS] = {};  // every rank's mailbox (connect_all): the all-reduce goes through them
+  bool ipc_all_connected = false;
+  uint64_t ipc_ar_seq = 0;
   uint64_t ipc_seq = 0;
   long long ipc_ticks = 30LL * 100000000LL;
   // profiling (beat_comm_profile)
@@ -280,6 +334,12 @@ void comm_free(beat_comm* c) {
   if (c->p2p) (void)g_rccl.CommDestroy(c->p2p);
   if (c->coll) (void)g_rccl.CommDestroy(c->coll);
   if (c->ipc) {
+    if (c->ipc_all_connected) {  // the neighbours' mappings are among these: closed once, here
+      for (int r = 0; r < c->world && r < BEAT_IPC_MAX_RANKS; ++r)
+        if (r != c->rank && c->ipc_all[r]) (void)hipIpcCloseMemHandle(c->ipc_all[r]);
+      c->ipc_peer[0] = IpcPeer();
+      c->ipc_peer[1] = IpcPeer();
+    }
     ipc_disconnect(c, c->ipc_peer[0]);
     ipc_disconnect(c, c->ipc_peer[1]);
     if (c->ipc_box) (void)hipFree(c->ipc_box);
@@ -391,8 +451,10 @@ extern "C" int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer
                                     beat_comm** out) {
   BEAT_REQUIRE(ctx != nullptr && out != nullptr && host_handle_out != nullptr, "null argument");
   BEAT_REQUIRE(max_plane_doubles > 0, "max_plane_doubles must be positive");
-  BEAT_REQUIRE((host_rccl_id != nullptr) != (allreduce != nullptr),
-               "exactly one of host_rccl_id (all-reduces by RCCL) and allreduce (by the caller) must be given");
+  BEAT_REQUIRE(!(host_rccl_id != nullptr && allreduce != nullptr),
+               "at most one of host_rccl_id (all-reduces by RCCL) and allreduce (by the caller); neither: by the mailboxes (beat_comm_ipc_connect_all)");
+  BEAT_REQUIRE(world <= BEAT_IPC_MAX_RANKS || host_rccl_id != nullptr || allreduce != nullptr, "the ipc all-reduce takes at most %d ranks",
+               BEAT_IPC_MAX_RANKS);
   if (int rc = check_peers(rank, world, peer_lo, peer_hi)) return rc;
   BEAT_REQUIRE(!(peer_lo >= 0 && peer_lo == peer_hi && peer_lo != rank),
                "both neighbours are rank %d: the ipc transport opens a neighbour's handle once", peer_lo);
@@ -411,7 +473,8 @@ extern "C" int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer
     c->user = user;
   }
   if (int rc = side_stream_and_events(c)) return rc;
-  const size_t bytes = ipc_data_bytes(max_plane_doubles) + sizeof(IpcFlags);
+  static_assert(sizeof(IpcFlags) <= 256, "flags fit their slot");
+  const size_t bytes = ipc_box_bytes(max_plane_doubles);
   // fine-grained: what a neighbouring GPU writes over xGMI must be seen by this GPU's caches (coarse-grained memory is
   // only coherent at kernel boundaries of the writing device).  BEAT_IPC_COARSE=1: plain hipMalloc (A/B on one GPU)
   const char* coarse = std::getenv("BEAT_IPC_COARSE");
@@ -465,6 +528,35 @@ extern "C" int beat_comm_ipc_connect(beat_comm* c, const void* host_handle_lo, c
   return BEAT_OK;
 }
 
+extern "C" int beat_comm_ipc_connect_all(beat_comm* c, const void* host_handles, int count) {
+  BEAT_REQUIRE(c != nullptr && c->ipc && host_handles != nullptr, "not an ipc communicator");
+  BEAT_REQUIRE(count == c->world && c->world <= BEAT_IPC_MAX_RANKS, "%d handles for %d ranks (at most %d)", count, c->world,
+               BEAT_IPC_MAX_RANKS);
+  BEAT_REQUIRE(!c->ipc_peer[0].connected && !c->ipc_peer[1].connected && !c->ipc_all_connected, "already connected");
+  BEAT_HIP_CHECK(hipSetDevice(c->ctx->device));
+  c->ipc_all_connected = true;  // from here on comm_free closes what has been opened
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) {
+      c->ipc_all[r] = c->ipc_box;
+      continue;
+    }
+    IpcHandle h;
+    std::memcpy(&h, (const char*)host_handles + (size_t)r * BEAT_IPC_HANDLE_BYTES, sizeof(h));
+    BEAT_REQUIRE(h.magic == IPC_MAGIC && (int)h.rank == r, "handle %d is not rank %d's ipc handle", r, r);
+    BEAT_REQUIRE(h.plane_max == c->ipc_plane_max, "rank %d sized its mailbox for planes of %lld doubles, this rank for %lld", r,
+                 (long long)h.plane_max, (long long)c->ipc_plane_max);
+    BEAT_HIP_CHECK(hipIpcOpenMemHandle((void**)&c->ipc_all[r], h.inbox, hipIpcMemLazyEnablePeerAccess));
+  }
+  const int peers[2] = {c->peer_lo, c->peer_hi};
+  for (int d = 0; d < 2; ++d) {
+    if (peers[d] < 0) continue;
+    c->ipc_peer[d].box = c->ipc_all[peers[d]];
+    c->ipc_peer[d].self = peers[d] == c->rank;
+    c->ipc_peer[d].connected = true;
+  }
+  return BEAT_OK;
+}
+
 extern "C" int beat_comm_destroy(beat_comm* c) {
   comm_free(c);
   return BEAT_OK;
@@ -478,7 +570,7 @@ extern "C" int beat_comm_info(beat_comm* c, int* host_out) {
   if (c->coll) BEAT_RCCL_CHECK(g_rccl.CommCount(c->coll, &count));  // ranks as RCCL itself counts them
   host_out[1] = count;
   host_out[2] = c->world;
-  host_out[3] = c->coll != nullptr;  // all-reduces by RCCL (1) or handed back to the caller (0)
+  host_out[3] = c->coll != nullptr ? 1 : (c->ipc && c->allreduce == nullptr) ? 2 : 0;  // all-reduces: RCCL, mailboxes, the caller
   return BEAT_OK;
 }
 
@@ -638,12 +730,32 @@ static int halo_wait(beat_comm* c) {
 // (PQ, RZN, RRN grow by a factor `world` per such iteration); nothing reads those slots afterwards -- ITERS, RR, BB,
 // REASON and NUPD are written by the scalar step, which the latch stops.
 static int allreduce_sum(beat_comm* c, double* dev, int count) {
+  if (c->ipc && c->ipc_all_connected && c->coll == nullptr && c->allreduce == nullptr) {
+    BEAT_REQUIRE(count >= 1 && count <= IPC_AR_VALUES, "the ipc all-reduce takes 1..%d values", IPC_AR_VALUES);
+    if (int rc = ipc_check(c)) return rc;
+    IpcArArgs a{};
+    for (int r = 0; r < c->world; ++r) a.box[r] = c->ipc_all[r];
+    a.ar_offset = ipc_ar_offset(c->ipc_plane_max);
+    a.rank = c->rank;
+    a.world = c->world;
+    a.count = count;
+    a.seq = c->ipc_ar_seq++;
+    a.values = dev;
+    a.ticks = c->ipc_ticks;
+    a.err = c->ipc_err;
+    const int span = prof_begin(c, 1, c->ctx->stream);
+    BEAT_KERNEL(ipc_allreduce_kernel, dim3(1), dim3(64), 0, c->ctx->stream, a);
+    BEAT_LAUNCH_CHECK();
+    prof_end(c, span, c->ctx->stream);
+    return BEAT_OK;
+  }
   if (c->coll) {
     const int span = prof_begin(c, 1, c->ctx->stream);
     BEAT_RCCL_CHECK(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, c->coll, c->ctx->stream));
     prof_end(c, span, c->ctx->stream);
     return BEAT_OK;
   }
+  BEAT_REQUIRE(c->allreduce != nullptr, "this ipc communicator reduces through the mailboxes: connect it with beat_comm_ipc_connect_all");
   const int rc = c->allreduce(c->user, dev, count);
   if (rc) {
     beat_set_error("all-reduce callback failed (%d)", rc);

@@ -415,19 +415,26 @@ int beat_comm_create_callbacks(beat_ctx* ctx, int rank, int world, int peer_lo, 
  *    ordering is done on the device, the hosts never wait for each other.  Over xGMI between the GPUs of one node,
  *    inside one GPU when several ranks share it (where RCCL, one rank per device, cannot run: that is how the overlap
  *    of the exchange with the interior stencil is measured on a one-GPU box).  The all-reduces go through RCCL
- *    (host_rccl_id = the 2 x 128-byte id of beat_comm_unique_id; its second communicator is created) or through the
- *    caller (allreduce / user).  Set-up is two steps: every rank creates its side and gets BEAT_IPC_HANDLE_BYTES to
- *    publish; once it holds its neighbours' handles it connects (pass NULL for an absent neighbour; a rank that is
- *    its own neighbour needs none).  All ranks must issue their exchanges in the same order (the decomposed solve
- *    does).  A neighbour that stops responding is reported (BEAT_IPC_TIMEOUT_S, default 30 s), not waited for. */
+ *    (host_rccl_id = the 2 x 128-byte id of beat_comm_unique_id; its second communicator is created), through the
+ *    caller (allreduce / user), or -- both NULL, at most BEAT_IPC_MAX_RANKS ranks -- through the mailboxes as well:
+ *    one small kernel per all-reduce stores the rank's 1-4 values and a sequence flag into every rank's mailbox, waits
+ *    (bounded) for every rank's flag in its own and adds the values in rank order, so all ranks hold the same bits; no
+ *    RCCL at all then.  Set-up is two steps: every rank creates its side and gets BEAT_IPC_HANDLE_BYTES to publish;
+ *    once it holds its neighbours' handles it connects (beat_comm_ipc_connect: pass NULL for an absent neighbour; a
+ *    rank that is its own neighbour needs none) -- or, for the mailbox all-reduce, the handles of ALL ranks in rank
+ *    order, world x BEAT_IPC_HANDLE_BYTES (beat_comm_ipc_connect_all; the rank's own entry is not opened).  All ranks
+ *    must issue their exchanges and all-reduces in the same order (the decomposed solve does).  A rank that stops
+ *    responding is reported (BEAT_IPC_TIMEOUT_S, default 30 s), not waited for. */
 #define BEAT_IPC_HANDLE_BYTES 2048
+#define BEAT_IPC_MAX_RANKS 16
 int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer_lo, int peer_hi, int64_t max_plane_doubles,
                          const void* host_rccl_id, beat_allreduce_fn allreduce, void* user, void* host_handle_out,
                          beat_comm** out);
 int beat_comm_ipc_connect(beat_comm* comm, const void* host_handle_lo, const void* host_handle_hi);
+int beat_comm_ipc_connect_all(beat_comm* comm, const void* host_handles, int count);
 int beat_comm_destroy(beat_comm* comm);
 /* host_out[4]: transport (BEAT_TRANSPORT_*), ranks of the all-reduce communicator as RCCL itself counts them
- * (ncclCommCount; 0 without RCCL), world as given at creation, 1 if the all-reduces are RCCL's. */
+ * (ncclCommCount; 0 without RCCL), world as given at creation, who sums: 1 RCCL, 2 the ipc mailboxes, 0 the caller. */
 #define BEAT_TRANSPORT_CALLBACKS 0
 #define BEAT_TRANSPORT_RCCL 1
 #define BEAT_TRANSPORT_RCCL_SERIAL 2

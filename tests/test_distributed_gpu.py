@@ -420,7 +420,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
 def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_path):
     """(transport "ipc": the three processes exchange their ghost planes ON THE DEVICE -- each maps its neighbours' mailboxes
     with hipIpcOpenMemHandle and copies its boundary planes into them on the library's side stream, ordered by
-    interprocess events; only the all-reduces go through gloo.)
+    sequence flags in device memory, and the dot products are summed through all three mailboxes (rank order, the same
+    bits on every rank): nothing of the solve goes through gloo or RCCL.)
     The reference's own call sequence (geometry, stimulus, MonodomainModel, DolfinODESolver, splitting solver,
     evaluate_function, x.array) run by `world` processes, the communicator cutting the mesh into z-slabs
     (tests/_api_ranks_script.py; ranks share this box's GPU over the host-staged gloo transport): after 60 TP06 steps
@@ -601,12 +602,13 @@ class _PeriodicSelf:
         return []
 
 
-@pytest.mark.parametrize("transport", ["rccl", "rccl-serial", "ipc"])
+@pytest.mark.parametrize("transport", ["rccl", "rccl-serial", "ipc", "ipc+rccl"])
 @pytest.mark.parametrize("per_node", [False, True])
-def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_node, transport):
+def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_node, transport, monkeypatch):
     """(transport "rccl-serial": the same exchange on the all-reduce communicator and the compute stream, BEAT_COMM_SERIAL;
-    "ipc": the ghost planes as device copies through the rank's own mailbox, ordered by its interprocess events -- every
-    slot and event of the ring reused many times over the solves below.)
+    "ipc": the ghost planes as device copies through the rank's own mailbox, ordered by its sequence flags -- every
+    slot of the ring reused many times over the solves below -- and the dot products summed through the mailbox too,
+    no RCCL anywhere; "ipc+rccl": those planes with RCCL's all-reduce, BEAT_IPC_ALLREDUCE=rccl.)
     The in-library solve with REAL RCCL point-to-point traffic on its side stream: a one-rank communicator whose
     lower and upper peers are the rank itself (the only multi-message topology a one-GPU box can host) makes the slab
     periodic in z -- ghost planes live on both faces, ncclSend/ncclRecv pairs in a group per SpMV, events between the
@@ -633,11 +635,23 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
     rng = np.random.default_rng(11)
     v = -85.0 + 30.0 * rng.random(plane * nz)
     w = rng.random(plane * nz) * 1e-3
+    summed_by = "ipc" if transport == "ipc" else "rccl"
+    if transport.startswith("ipc"):
+        monkeypatch.setenv("BEAT_IPC_ALLREDUCE", summed_by)
+        transport = "ipc"
     comm = LibComm(ctx, Interior(), transport=transport.split("-")[0], peers=(0, 0), serial=transport.endswith("serial"),
                    plane_doubles=plane)
     try:
         info = comm.info()
-        assert info["transport"] == transport and info["rccl_ranks"] == 1 and info["allreduce"] == "rccl"
+        assert info["transport"] == transport and info["rccl_ranks"] == (0 if summed_by == "ipc" else 1) and info["allreduce"] == summed_by
+        # the all-reduce on its own: 1..3 values, many times over (every slot of the mailbox's ring reused)
+        import torch
+
+        for k in range(11):
+            t = torch.arange(1.0, 2.0 + k % 3, dtype=torch.float64, device=ctx.device) * (k + 1)
+            want = t.cpu().numpy().copy()
+            comm.allreduce_sum(t)
+            np.testing.assert_array_equal(t.cpu().numpy(), want)
         # the exchange on its own
         states = StateArray(ctx, 3, plane * nz, plane)
         for field in (ctx.field(plane * nz, plane), states.row_field(1)):
