@@ -44,6 +44,12 @@ struct OdeStepKernArgHead {
   int64_t n, ld;
   ParamPack<Model::NP> prm;
   typename Model::Derived drv;
+  const double* ppn;
+  int64_t pld;
+  double t, dt;
+  int v_index;
+  double* v_copy;
+  PendingV pend;  // (MarkedArgs follows)
 };
 
 // Cell types / parameter classes in ONE launch (MARKED): a byte per node selects one of up to BEAT_MAX_CLASSES
@@ -88,6 +94,18 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
   for (int64_t tile = blockIdx.x; tile * BEAT_BLOCK < n; tile += gridDim.x) {
   const int64_t i = tile * BEAT_BLOCK + threadIdx.x;
   if (i >= n) break;
+  // The row stride, opaque per tile: the base address of each of the NS state rows (states + k ld) is uniform and
+  // loop-invariant, so the compiler forms all of them ahead of the tile loop, runs out of SGPRs and parks them in VGPR
+  // lanes -- one v_readlane per half address per tile on the VALU this kernel is bound by (144 of 4756 VALU
+  // instructions per ToR-ORd node, 58 of 1928 per TP06 node).  Recomputed where used they cost SALU cycles only.
+  int64_t ldl = ld;
+  asm volatile("" : "+s"(ldl));
+  // the kernel-argument segment through a pointer the optimiser cannot see through (see below, at the uniform parameters);
+  // the pending-update arguments are read through it too: kept in SGPRs across the tile loop they were spilled as well
+  typedef const __attribute__((address_space(4))) char* KArgPtr;
+  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const PendingV& pendl = *(const PendingV*)(ka + offsetof(OdeStepKernArgHead<Model>, pend));
   if (MARKED) {
     const int m_lane = mk.markers[i];
     // where the node's potential lives: row V_INDEX of the state array, or -- when the array holds only the nodes that
@@ -117,11 +135,11 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       double pp[BEAT_MAX_PENDING], pa[BEAT_MAX_PENDING];
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-        pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + jn) : 0.0;
-        pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+        pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + jn) : 0.0;
+        pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
       }
-      if (pend.gt.d != nullptr) {
-        const beat_pde_detail::GuessTerms& gt = pend.gt;
+      if (pendl.gt.d != nullptr) {
+        const beat_pde_detail::GuessTerms& gt = pendl.gt;
         const double ge = beat_pde_detail::beat_guess_needs_e(gt) ? __builtin_nontemporal_load(gt.e + jn) : 0.0;
         const double gd = beat_pde_detail::beat_guess_needs_d(gt) ? __builtin_nontemporal_load(gt.d + jn) : 0.0;
         const double gp0 = beat_pde_detail::beat_guess_needs_dp(gt, 0) ? __builtin_nontemporal_load(gt.dp[0] + jn) : 0.0;
@@ -129,13 +147,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
         double inc = gt.accumulate ? 0.0 : ge;
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
-          if (j < pend.count) inc = fma(pa[j], pp[j], inc);
+          if (j < pendl.count) inc = fma(pa[j], pp[j], inc);
         beat_pde_detail::beat_guess_record(gt, gt.d + jn, gt.e + jn, inc, gd, gp0, gp1, ge);
         v_now += inc;
       } else {
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
-          if (j < pend.count) v_now = fma(pa[j], pp[j], v_now);
+          if (j < pendl.count) v_now = fma(pa[j], pp[j], v_now);
       }
     }
     unsigned long long todo = __ballot(m_lane < 254);
@@ -150,7 +168,8 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
       // (node index and potential are made opaque per pass: otherwise the address of every state row and everything
       // that depends on the potential alone is hoisted out of this loop and kept in registers, +38 VGPRs and scratch)
-      NodeIOWithV iol{states, ld, i, mk.vmap != nullptr ? vptr : (v_copy != nullptr ? v_copy + i : nullptr), v_now};
+      asm volatile("" : "+s"(ldl));
+      NodeIOWithV iol{states, ldl, i, mk.vmap != nullptr ? vptr : (v_copy != nullptr ? v_copy + i : nullptr), v_now};
       asm volatile("" : "+v"(iol.i), "+v"(iol.v));
       if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
       todo &= ~__ballot(m_lane == m);
@@ -166,26 +185,23 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
   // segment.  Left to itself the compiler hoists all of them out of the tile loop, runs out of SGPRs and parks them in
   // VGPR lanes: 640 v_readlane / v_writelane per node on the VALU that is this kernel's bottleneck.  Reading them
   // through a pointer the optimiser cannot see through keeps the loads where they are used (SALU, scalar cache).
-  typedef const __attribute__((address_space(4))) char* KArgPtr;
-  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
   const double* p_uni = (const double*)(ka + offsetof(OdeStepKernArgHead<Model>, prm));
   const typename Model::Derived& d_uni =
       *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    NodeIOPending<Model::V_INDEX> io{states, ld, i, v_copy, pend.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+    NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, pendl.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-      io.pp[j] = j < pend.count ? __builtin_nontemporal_load(pend.ring + (int64_t)j * pend.fld + i) : 0.0;
-      io.pa[j] = j < pend.count ? pend.alphas[j] : 0.0;
+      io.pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + i) : 0.0;
+      io.pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
     }
-    if (pend.gt.d != nullptr) {
-      io.gt = pend.gt;
-      io.ge = beat_pde_detail::beat_guess_needs_e(pend.gt) ? __builtin_nontemporal_load(pend.gt.e + i) : 0.0;
-      io.gd = beat_pde_detail::beat_guess_needs_d(pend.gt) ? __builtin_nontemporal_load(pend.gt.d + i) : 0.0;
-      io.gp0 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 0) ? __builtin_nontemporal_load(pend.gt.dp[0] + i) : 0.0;
-      io.gp1 = beat_pde_detail::beat_guess_needs_dp(pend.gt, 1) ? __builtin_nontemporal_load(pend.gt.dp[1] + i) : 0.0;
+    if (pendl.gt.d != nullptr) {
+      io.gt = pendl.gt;
+      io.ge = beat_pde_detail::beat_guess_needs_e(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.e + i) : 0.0;
+      io.gd = beat_pde_detail::beat_guess_needs_d(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.d + i) : 0.0;
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 0) ? __builtin_nontemporal_load(pendl.gt.dp[0] + i) : 0.0;
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 1) ? __builtin_nontemporal_load(pendl.gt.dp[1] + i) : 0.0;
     }
     if (PER_NODE) {
       double pl[Model::NP];
@@ -197,7 +213,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       Model::step(io, p_uni, d_uni, fm, t, dt);
     }
   } else {
-    const NodeIO io{states, ld, i, v_copy, v_index};
+    // (the mirror of row v_index -- any row here, unlike in the pending-update form -- is written after the step from
+    // the row itself: a store-time test "k == v_index" for each of the NS rows is NS uniform conditions kept, and spilled)
+    const NodeIO io{states, ldl, i, nullptr, -1};
     if (PER_NODE) {
       double pl[Model::NP];
 #pragma unroll
@@ -224,12 +242,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
           if (v == 1.2345e300) base[(int64_t)k * ld + i] = v;
         }
       };
-      const ProbeIO pio{states, ld, i, (int64_t)threadIdx.x};
+      const ProbeIO pio{states, ldl, i, (int64_t)threadIdx.x};
       Model::step(pio, p_uni, d_uni, fm, t, dt);
 #else
       Model::step(io, p_uni, d_uni, fm, t, dt);
 #endif
     }
+    if (v_copy != nullptr) v_copy[i] = states[(int64_t)v_index * ldl + i];
   }
   }
 }

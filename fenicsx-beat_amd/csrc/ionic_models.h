@@ -451,6 +451,9 @@ struct FhnReadme {
 //    normal denominators that occur here) instead of the ~12-instruction IEEE division sequence.
 //  * parameter-only sub-expressions are evaluated once per launch on the host (Derived).
 // ------------------------------------------------------------------------------------------------
+#if defined(__clang__) && !defined(BEAT_TP06_NO_CONTRACT)
+#pragma clang fp contract(fast)  // a * b + c as one fma inside the step (the library as a whole is built with contraction off)
+#endif
 struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53, V_INDEX = 17;
   static constexpr bool REGISTER_LOOP = true;
@@ -850,3 +853,6 @@ struct Tp06Grl1 {
   }
 #undef BEAT_FENCE
 };
+#if defined(__clang__) && !defined(BEAT_TP06_NO_CONTRACT)
+#pragma clang fp contract(off)
+#endif

@@ -37,6 +37,10 @@
 #define BEAT_PIN(x) asm volatile("" : "+v"(x))
 #endif
 
+#if defined(__clang__) && !defined(BEAT_TORORD_NO_CONTRACT)
+#pragma clang fp contract(fast)
+#endif
+
 namespace torord_detail {
 
 // value + up to three tangents; bit k of M set <=> tangent k is structurally non-zero
@@ -158,13 +162,16 @@ BEAT_DV Du<A> cube(const Du<A>& a) {
 // (cross-bridges XS / XW, troponin-bound calcium CaTrpn, blocked tropomyosin TmB, distortions Zetas / Zetaw, dashpot Cd),
 // 28 more parameters, troponin buffering as a flux of the calcium equation instead of a term of Bcai; in that file cai
 // is declared with the mechanics states, so its row is 44 and the rows of cajsr .. xs2 are one lower (slot()).
+#ifndef BEAT_TORORD_WAVES
+#define BEAT_TORORD_WAVES 2
+#endif
 template <bool LAND>
 struct TorordGrl1T {
   static constexpr int NS = LAND ? 52 : 45, NP = LAND ? 140 : 112, V_INDEX = LAND ? 41 : 42;  // V_INDEX: membrane potential
   // ode_run_kernel keeps the states of hand-written models in registers across steps (the generated kernel of round 1
   // spilled so heavily that this miscompiled and had to go through memory)
   static constexpr bool REGISTER_LOOP = true;
-  static constexpr int WAVES = 2;  // waves per SIMD the kernels are compiled for
+  static constexpr int WAVES = BEAT_TORORD_WAVES;  // waves per SIMD the kernels are compiled for
   static constexpr int WAVES_PER_NODE = 1;  // with 112 (140) per-node parameters in registers: one wave per SIMD, no scratch
   enum S {
     S_C1, S_C2, S_C3, S_I_, S_O_, S_CaMKt, S_Jrel_np, S_Jrel_p, S_a, S_ap, S_iF, S_iFp, S_iS, S_iSp, S_cai,
@@ -207,6 +214,15 @@ struct TorordGrl1T {
     double nc_k1, nc_h11, nc_cao;              // INaCa
     double a_rel, a_relp, btp;
     double ksu, kwu_kws_kuw, Aw_dL, cw, cs, ca_scale, kb, Cdash;  // LAND
+    // Products, quotients and reciprocals of parameters alone that the step used to form per node: there is no scalar
+    // fp64 unit, so every one of them was a VALU instruction per wavefront and tile -- an IEEE division (1.0 / p[..],
+    // ~13 instructions) nine times over, seven reciprocals, some forty products.
+    double nk_sKnai, nk_dKnai, nk_sKnao, nk_dKnao, nk_iKnap, nk_iKxkur, nk_iKki, nk_a3n, nk_cK, nk_cN, nk_cKb1;  // INaK
+    double nc_sca, nc_sna, nc_nao_kna3, nc_wna_h11, nc_ikna3, nc_ikna1, nc_ikna2, nc_ikna12, nc_3zna, nc_km2;    // INaCa
+    double r_thL, r_3thL, r_tjca, r_tauNa, r_tauK, r_tauCa, Afs, td0;
+    double fi, fi_na, fi_k, fs, fs_na, fs_k, m4cA;
+    double g_junc0, g_sl0, cu, cup, Jleak_c, J_cansr, GpCa_Km, nao_ko_ks;
+    double b_trpn, b_cmdn, b_bsl, b_bsr, b_csqn;
   };
   BEAT_HD static Derived derive(const double* p) {
     Derived q;
@@ -268,6 +284,55 @@ struct TorordGrl1T {
     q.a_rel = 0.5 * p[bt_];
     q.btp = 1.25 * p[bt_];
     q.a_relp = 0.5 * q.btp;
+    q.nk_sKnai = p[delta_] * (1.0 / 3.0);
+    q.nk_dKnai = p[delta_] * q.FRT * (1.0 / 3.0);
+    q.nk_sKnao = (1.0 - p[delta_]) * (1.0 / 3.0);
+    q.nk_dKnao = (1.0 - p[delta_]) * q.FRT * (1.0 / 3.0);
+    q.nk_iKnap = 1.0 / p[Knap_];
+    q.nk_iKxkur = 1.0 / p[Kxkur_];
+    q.nk_iKki = 1.0 / p[Kki_];
+    q.nk_a3n = p[k3p_] * q.nk_koK2;
+    q.nk_cK = 2.0 * p[zk_];
+    q.nk_cN = 3.0 * p[zna_];
+    q.nk_cKb1 = q.nk_cK * q.nk_b1;
+    q.nc_sca = p[qca_] * q.FRT;
+    q.nc_sna = p[qna_] * q.FRT;
+    q.nc_nao_kna3 = p[nao_] / p[kna3_];
+    q.nc_wna_h11 = p[wna_] * q.nc_h11;
+    q.nc_ikna3 = 1.0 / p[kna3_];
+    q.nc_ikna1 = 1.0 / p[kna1_];
+    q.nc_ikna2 = 1.0 / p[kna2_];
+    q.nc_ikna12 = 1.0 / (p[kna2_] * p[kna1_]);
+    q.nc_3zna = 3.0 * p[zna_];
+    q.nc_km2 = p[KmCaAct_] * p[KmCaAct_];
+    q.r_thL = 1.0 / p[thL_];
+    q.r_3thL = 1.0 / (3.0 * p[thL_]);
+    q.r_tjca = 1.0 / p[tjca_];
+    q.r_tauNa = 1.0 / p[tauNa_];
+    q.r_tauK = 1.0 / p[tauK_];
+    q.r_tauCa = 1.0 / p[tauCa_];
+    q.Afs = 1.0 - p[Aff_];
+    q.td0 = p[offset_] + 0.6;
+    q.fi = 1.0 - p[ICaL_fractionSS_];
+    q.fs = p[ICaL_fractionSS_];
+    q.fi_na = q.fi * 0.00125;
+    q.fi_k = q.fi * 0.0003574;
+    q.fs_na = q.fs * 0.00125;
+    q.fs_k = q.fs * 0.0003574;
+    q.m4cA = -4.0 * q.cA;
+    q.g_junc0 = p[Fjunc_] * p[GClCa_];
+    q.g_sl0 = p[GClCa_] * (1.0 - p[Fjunc_]);
+    q.cu = q.upScale * 0.005425;
+    q.cup = (q.upScale * 2.75) * 0.005425;
+    q.Jleak_c = 0.0048825 * (1.0 / 15.0);
+    q.J_cansr = -p[Jup_b_] * (0.0048825 * (1.0 / 15.0)) - (1.0 / 60.0) * q.vjsr_vnsr;
+    q.GpCa_Km = p[GpCa_] * p[KmCap_];
+    q.nao_ko_ks = p[PKNa_] * p[nao_] + p[ko_];
+    q.b_trpn = p[kmtrpn_] * p[trpnmax_];
+    q.b_cmdn = q.cmdnmax * p[kmcmdn_];
+    q.b_bsl = p[BSLmax_] * p[KmBSL_];
+    q.b_bsr = p[BSRmax_] * p[KmBSR_];
+    q.b_csqn = p[csqnmax_] * p[kmcsqn_];
     if constexpr (LAND) {  // .ode:682-717, parameter-only
       const double lam12 = p[lmbda_] < 1.2 ? p[lmbda_] : 1.2;
       const double rw = p[rw_], rs = p[rs_];
@@ -287,14 +352,38 @@ struct TorordGrl1T {
   BEAT_DV static double grl1(double y, double f, double J, double expm1Jdt, double dt) {
     return y + ((fabs(J) > 1e-8) ? f * beat_rcp(J) * expm1Jdt : f * dt);
   }
+  // phi(z) = (exp(z) - 1) / z for |z| <= 1/16 by its Taylor polynomial of degree 8 (first omitted term z^9/10! < 5e-18).
+  // The GRL1 increment f (exp(J dt) - 1) / J is f dt phi(J dt); at dt = 0.01 ms nearly every state of nearly every node
+  // has |J dt| below 1/16 (time constants above 0.16 ms), and the polynomial is 8 fma against an exp() (13) and, for
+  // the non-gate states, a reciprocal (7) and the |J| > 1e-8 selection (phi(0) = 1 is that limit).  It is also the more
+  // accurate form: exp(z) - 1 loses log2(1/|z|) bits to cancellation.  The branch is per lane (a node's result does not
+  // depend on which nodes share its wavefront); lanes outside the window take the general form below it.
+#ifndef BEAT_GRL1_PHI
+#define BEAT_GRL1_PHI 1  // 0: the general form for every lane (A/B builds)
+#endif
+  static constexpr double PHI_WINDOW = 0.0625;
+  BEAT_DV static double phi_small(double z) {
+    double ph = fma(z, 1.0 / 362880.0, 1.0 / 40320.0);
+    ph = fma(z, ph, 1.0 / 5040.0);
+    ph = fma(z, ph, 1.0 / 720.0);
+    ph = fma(z, ph, 1.0 / 120.0);
+    ph = fma(z, ph, 1.0 / 24.0);
+    ph = fma(z, ph, 1.0 / 6.0);
+    ph = fma(z, ph, 0.5);
+    return fma(z, ph, 1.0);
+  }
   // gate with f = (inf - y) * rate, J = -rate  =>  y += (inf - y) (1 - exp(-dt rate))
   template <class FM>
   BEAT_DV static double gate(const FM& fm, double y, double inf, double rate, double dt) {
-    return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rate, -746.0)));  // rates reach 1e21/ms at +350 mV: see FastMath::exp
+    const double z = -dt * rate;
+    if (BEAT_GRL1_PHI > 1 && fabs(z) <= PHI_WINDOW) return fma(inf - y, -z * phi_small(z), y);  // (measured: no gain for gates)
+    return y + (inf - y) * (1.0 - fm.exp(fmax(z, -746.0)));  // rates reach 1e21/ms at +350 mV: see FastMath::exp
   }
   template <class FM>
   BEAT_DV static double advance(const FM& fm, double y, double f, double J, double dt) {
-    return grl1(y, f, J, fm.exp(fmin(fmax(J * dt, -746.0), 710.0)) - 1.0, dt);
+    const double z = J * dt;
+    if (BEAT_GRL1_PHI && fabs(z) <= PHI_WINDOW) return fma(f * dt, phi_small(z), y);
+    return grl1(y, f, J, fm.exp(fmin(fmax(z, -746.0), 710.0)) - 1.0, dt);
   }
 
   template <class IO, class FM>
@@ -327,27 +416,27 @@ struct TorordGrl1T {
     // tangents each), and at this point nothing but the potential and the first running sums is live.
     // ---- INaK (.ode:418-444): directions 0 = v, 1 = nai, 2 = ki --------------------------------------------------------
     {
-      const Du<DV> Knai = dexp(fm, mk<DV>(p[delta_] * vfrt * (1.0 / 3.0), p[delta_] * q.FRT * (1.0 / 3.0))) * p[Knai0_];
-      const Du<DV> Knao = dexp(fm, mk<DV>(vfrt * (1.0 - p[delta_]) * (1.0 / 3.0), (1.0 - p[delta_]) * q.FRT * (1.0 / 3.0))) * p[Knao0_];
+      const Du<DV> Knai = dexp(fm, mk<DV>(vfrt * q.nk_sKnai, q.nk_dKnai)) * p[Knai0_];
+      const Du<DV> Knao = dexp(fm, mk<DV>(vfrt * q.nk_sKnao, q.nk_dKnao)) * p[Knao0_];
       const Du<D1> Nai = mk<D1>(nai, 0.0, 1.0);
       const Du<D2> Ki = mk<D2>(ki, 0.0, 0.0, 1.0);
-      const Du<D1 | D2> P = p[eP_] / ((Nai * (1.0 / p[Knap_]) + q.nk_Pden0) + Ki * (1.0 / p[Kxkur_]));
+      const Du<D1 | D2> P = p[eP_] / ((Nai * q.nk_iKnap + q.nk_Pden0) + Ki * q.nk_iKxkur);
       const Du<DV | D1> xn = Nai / Knai;
-      const Du<D2> xk = Ki * (1.0 / p[Kki_]);
+      const Du<D2> xk = Ki * q.nk_iKki;
       const Du<DV | D1 | D2> rD1 = inv((sq(1.0 + xk) + cube(1.0 + xn)) - 1.0);
       const Du<DV | D1 | D2> a1 = (p[k1p_] * cube(xn)) * rD1;
       const Du<DV | D1 | D2> b4 = (p[k4m_] * sq(xk)) * rD1;
       BEAT_TFENCE();
       const Du<DV> yo = p[nao_] / Knao;
       const Du<DV> rD3 = inv((cube(1.0 + yo) + q.nk_1koK2) - 1.0);
-      const Du<DV> a3 = (p[k3p_] * q.nk_koK2) * rD3;
+      const Du<DV> a3 = q.nk_a3n * rD3;
       const Du<DV> b2 = (p[k2m_] * cube(yo)) * rD3;
       const Du<D1 | D2> b3 = q.nk_cb3 * P;
       const double a2 = q.nk_a2, a4 = q.nk_a4, b1 = q.nk_b1;
       BEAT_TFENCE();
       // INaK = Pnak (zk JnakK + zna JnakNa), JnakK = 2 (E4 b1 - E3 a1), JnakNa = 3 (E1 a3 - E2 b3), E_k = x_k / sum x:
       // the x_k are formed one after the other and folded into the numerator and the sum (not kept, nor the E_k)
-      const double cK = 2.0 * p[zk_], cN = 3.0 * p[zna_];
+      const double cK = q.nk_cK, cN = q.nk_cN;
       auto x = a2 * (a1 * b3) + (b3 * (a2 * b4) + (a2 * (a1 * a4) + b3 * (b2 * b4)));   // x1
       auto S = x;
       auto N = cN * (x * a3);
@@ -359,7 +448,7 @@ struct TorordGrl1T {
       N = N - cK * (x * a1);
       x = a1 * (b2 * b3) + (a1 * (a4 * b2) + (a1 * (a3 * a4) + b2 * (b3 * b4)));        // x4
       S = S + x;
-      N = N + (cK * b1) * x;
+      N = N + q.nk_cKb1 * x;
       const auto INaK = q.Pnak * (N * inv(S));
       Iv += INaK.v;
       dIv += INaK.d[0];
@@ -373,28 +462,28 @@ struct TorordGrl1T {
 
     // ---- INaCa, myoplasm and subspace (.ode:446-525): directions 0 = v, 1 = Na, 2 = Ca --------------------------------
     {
-      const Du<DV> hca = dexp(fm, mk<DV>(p[qca_] * vfrt, p[qca_] * q.FRT));
-      const Du<DV> hna = dexp(fm, mk<DV>(p[qna_] * vfrt, p[qna_] * q.FRT));
+      const Du<DV> hca = dexp(fm, mk<DV>(p[qca_] * vfrt, q.nc_sca));
+      const Du<DV> hna = dexp(fm, mk<DV>(p[qna_] * vfrt, q.nc_sna));
       // v-only part, shared by both compartments
       const Du<DV> rhna = inv(hna);
-      const Du<DV> h7 = (p[nao_] / p[kna3_]) * (1.0 + rhna) + 1.0;
+      const Du<DV> h7 = q.nc_nao_kna3 * (1.0 + rhna) + 1.0;
       const Du<DV> h9 = inv(h7);
-      const Du<DV> h8 = (p[nao_] / p[kna3_]) * (rhna * h9);
+      const Du<DV> h8 = q.nc_nao_kna3 * (rhna * h9);
       const Du<DV> k3pp = h8 * p[wnaca_];
       const Du<DV> k3 = h9 * p[wca_] + k3pp;
-      const Du<DV> k8 = (p[wna_] * q.nc_h11) * h8;
+      const Du<DV> k8 = q.nc_wna_h11 * h8;
       const Du<DV> rhca = inv(hca);
       const double k1 = q.nc_k1, k2 = p[kcaoff_], k5 = p[kcaoff_];
 #define BEAT_NCX(NA, CA, GN, IV, DIV, INA, DINA, ICA, DICA, CAF)                                                        \
   {                                                                                                                  \
     const Du<D1> Na = mk<D1>(NA, 0.0, 1.0);                                                                          \
     const Du<D2> Ca = mk<D2>(CA, 0.0, 0.0, 1.0);                                                                     \
-    const Du<DV | D1> h1 = (Na * (1.0 / p[kna3_])) * (hna + 1.0) + 1.0;                                              \
+    const Du<DV | D1> h1 = (Na * q.nc_ikna3) * (hna + 1.0) + 1.0;                                                    \
     const Du<DV | D1> h3 = inv(h1);                                                                                  \
-    const Du<DV | D1> h2 = ((hna * Na) * (1.0 / p[kna3_])) * h3;                                                     \
-    const Du<D1> h4 = (Na * (1.0 / p[kna1_])) * (1.0 + Na * (1.0 / p[kna2_])) + 1.0;                                 \
+    const Du<DV | D1> h2 = ((hna * Na) * q.nc_ikna3) * h3;                                                           \
+    const Du<D1> h4 = (Na * q.nc_ikna1) * (1.0 + Na * q.nc_ikna2) + 1.0;                                             \
     const Du<D1> h6 = inv(h4);                                                                                       \
-    const Du<D1> h5 = ((Na * Na) * (1.0 / (p[kna2_] * p[kna1_]))) * h6;                                              \
+    const Du<D1> h5 = ((Na * Na) * q.nc_ikna12) * h6;                                                                \
     const Du<DV | D1> k4pp = h2 * p[wnaca_];                                                                         \
     const Du<DV | D1> k4 = (h3 * p[wca_]) * rhca + k4pp;                                                             \
     const Du<D1 | D2> k6 = p[kcaon_] * (Ca * h6);                                                                    \
@@ -405,7 +494,7 @@ struct TorordGrl1T {
     {                                                                                                                  \
       const auto x1 = (k2 * k4) * (k6 + k7) + (k5 * k7) * (k2 + k3);                                                   \
       S = x1;                                                                                                          \
-      N = x1 * (k8 * (-3.0 * p[zna_]) - p[zca_] * k1);                                                                 \
+      N = x1 * (k8 * (-q.nc_3zna) - p[zca_] * k1);                                                                     \
     }                                                                                                                  \
     {                                                                                                                  \
       const auto x2 = (k1 * k7) * (k4 + k5) + (k4 * k6) * (k1 + k8);                                                   \
@@ -420,9 +509,9 @@ struct TorordGrl1T {
     {                                                                                                                  \
       const auto x4 = (k2 * k8) * (k4 + k5) + (k3 * k5) * (k1 + k8);                                                   \
       S = S + x4;                                                                                                      \
-      N = N + x4 * ((3.0 * p[zna_]) * k7);                                                                             \
+      N = N + x4 * (q.nc_3zna * k7);                                                                                   \
     }                                                                                                                  \
-    const double km2 = p[KmCaAct_] * p[KmCaAct_];                                                                      \
+    const double km2 = q.nc_km2;                                                                                       \
     const Du<D2> allo = (Ca * Ca) * inv(Ca * Ca + km2);                                                                \
     const auto I = (allo * (GN)) * (N * inv(S));                                                                       \
     IV += I.v;                                                                                                       \
@@ -530,8 +619,8 @@ struct TorordGrl1T {
       pf_a = io.load(S_a), pf_ap = io.load(S_ap), pf_iF = io.load(S_iF), pf_iFp = io.load(S_iFp), pf_iS = io.load(S_iS),
       pf_iSp = io.load(S_iSp);
       io.store(S_mL, gate(fm, mL, beat_rcp(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0), tm_rate, dt));
-      io.store(S_hL, gate(fm, hL, beat_rcp(ehL + 1.0), beat_rcp(p[thL_]), dt));
-      io.store(S_hLp, gate(fm, hLp, beat_rcp(ehL * 2.288717124596482 + 1.0), beat_rcp(3.0 * p[thL_]), dt));  // exp(6.2/7.488)
+      io.store(S_hL, gate(fm, hL, beat_rcp(ehL + 1.0), q.r_thL, dt));
+      io.store(S_hLp, gate(fm, hLp, beat_rcp(ehL * 2.288717124596482 + 1.0), q.r_3thL, dt));  // exp(6.2/7.488)
     }
     BEAT_TFENCE();
 
@@ -594,7 +683,7 @@ struct TorordGrl1T {
       const double nca_i = pf_nca_i, nca_ss = pf_nca_ss;
       const double sA = beat_rcp(fm.exp((v - 10.0) * (1.0 / 10.0)) + 1.0);
       const double Afcaf = 0.3 + 0.6 * sA, dAfcaf = -0.06 * sA * (1.0 - sA);
-      const double Afs = 1.0 - p[Aff_];
+      const double Afs = q.Afs;
       const double f = p[Aff_] * ff + Afs * fs, fpx = p[Aff_] * ffp + Afs * fs;
       const double fca = Afcaf * fcaf + (1.0 - Afcaf) * fcas, fcap = Afcaf * fcafp + (1.0 - Afcaf) * fcas;
       const double dfca = dAfcaf * (fcaf - fcas), dfcap = dAfcaf * (fcafp - fcas);
@@ -614,7 +703,7 @@ struct TorordGrl1T {
       // gates
       const double dss = (v >= 31.4978) ? 1.0 : 1.0763 * fm.exp(-1.007 * fm.exp(-0.0829 * v));
       const double vs = v + p[vShift_];
-      const double td = (p[offset_] + 0.6) + beat_rcp(fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0)));
+      const double td = q.td0 + beat_rcp(fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0)));
       BEAT_TFENCE();
       const double fss = beat_rcp(fm.exp((v + 19.58) * (1.0 / 3.696)) + 1.0);
       const double e20 = fm.exp((v + 20.0) * (1.0 / 10.0));
@@ -640,7 +729,7 @@ struct TorordGrl1T {
       io.store(S_fcafp, gate(fm, fcafp, fss, rtfcaf * (1.0 / 2.5), dt));
       BEAT_TFENCE();
       io.store(S_fcas, gate(fm, fcas, fss, beat_rcp(tfcas), dt));
-      io.store(S_jca, gate(fm, jca, jcass, beat_rcp(p[tjca_]), dt));
+      io.store(S_jca, gate(fm, jca, jcass, q.r_tjca, dt));
       BEAT_TFENCE();
       // nca: f = anca k2n - km2n nca, km2n = jca, anca = 1/(k2n/km2n + (Kmn/ca + 1)^4): J = -jca
       {
@@ -661,7 +750,7 @@ struct TorordGrl1T {
       const Du<DV> Ve1 = mk<DV>(e1, e1 * q.FRT), Ve2 = mk<DV>(e2, 2.0 * e2 * q.FRT);
       const Du<DV> Vff = mk<DV>(vffrt, q.FFRT);
       const Du<DV> R1 = inv(Ve1 - 1.0), R2 = inv(Ve2 - 1.0);
-      const double fi = 1.0 - p[ICaL_fractionSS_], fs_ = p[ICaL_fractionSS_];
+      const double fi = q.fi, fs_ = q.fs;
       // myoplasm: activity coefficients gamma = exp(-cA z^2 g(I)), g = sqrt(I)/(1 + sqrt(I)) - 0.3 I, I = ionic strength
       {
         const double Ii = (0.5 * (4.0 * cai + (cli + (ki + nai)))) * (1.0 / 1000.0);
@@ -670,7 +759,7 @@ struct TorordGrl1T {
         const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;          // dg/dI
         const double g1 = fm.exp(-q.cA * g);                              // z = 1
         const double g2 = (g1 * g1) * (g1 * g1);                          // z = 2: exp(-4 cA g)
-        const double dg1_dI = -q.cA * dg * g1, dg2_dI = -4.0 * q.cA * dg * g2;
+        const double dg1_dI = -q.cA * dg * g1, dg2_dI = q.m4cA * dg * g2;
         const Du<DV> Gi = mk<DV>(G_i, dG_i_dv);
         {  // Ca: d I / d cai = 2/1000
           const Du<D1> act = mk<D1>(g2 * cai, 0.0, g2 + cai * dg2_dI * 0.002);
@@ -690,7 +779,7 @@ struct TorordGrl1T {
         }
         {  // Na: d I / d nai = 0.5/1000
           const Du<D1> act = mk<D1>(g1 * nai, 0.0, g1 + nai * dg1_dI * 0.0005);
-          const Du<DV | D1> ICaNa_i = (fi * 0.00125) * (Gi * (Vff * (act * Ve1 - q.gnao_nao) * R1));
+          const Du<DV | D1> ICaNa_i = q.fi_na * (Gi * (Vff * (act * Ve1 - q.gnao_nao) * R1));
           const Du<DV | D1> INab = p[PNab_] * (Vff * (mk<D1>(nai, 0.0, 1.0) * Ve1 - p[nao_]) * R1);
           Iv += ICaNa_i.v + INab.v;
           dIv += ICaNa_i.d[0] + INab.d[0];
@@ -700,7 +789,7 @@ struct TorordGrl1T {
         }
         {  // K
           const Du<D1> act = mk<D1>(g1 * ki, 0.0, g1 + ki * dg1_dI * 0.0005);
-          const Du<DV | D1> ICaK_i = (fi * 0.0003574) * (Gi * (Vff * (act * Ve1 - q.gko_ko) * R1));
+          const Du<DV | D1> ICaK_i = q.fi_k * (Gi * (Vff * (act * Ve1 - q.gko_ko) * R1));
           Iv += ICaK_i.v;
           dIv += ICaK_i.d[0];
           Iki += ICaK_i.v;
@@ -717,7 +806,7 @@ struct TorordGrl1T {
         const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;
         const double g1 = fm.exp(-q.cA * g);
         const double g2 = (g1 * g1) * (g1 * g1);
-        const double dg1_dI = -q.cA * dg * g1, dg2_dI = -4.0 * q.cA * dg * g2;
+        const double dg1_dI = -q.cA * dg * g1, dg2_dI = q.m4cA * dg * g2;
         {
           const Du<DV | D1> Gs = mk<DV | D1>(G_ss, dG_ss_dv, dG_ss_dfp * dfp_dcass);
           const Du<D1> act = mk<D1>(g2 * cass, 0.0, g2 + cass * dg2_dI * 0.002);
@@ -732,7 +821,7 @@ struct TorordGrl1T {
         const Du<DV> Gs = mk<DV>(G_ss, dG_ss_dv);
         {
           const Du<D1> act = mk<D1>(g1 * nass, 0.0, g1 + nass * dg1_dI * 0.0005);
-          const Du<DV | D1> I = (fs_ * 0.00125) * (Gs * (Vff * (act * Ve1 - q.gnao_nao) * R1));
+          const Du<DV | D1> I = q.fs_na * (Gs * (Vff * (act * Ve1 - q.gnao_nao) * R1));
           Iv += I.v;
           dIv += I.d[0];
           Inass += I.v;
@@ -741,7 +830,7 @@ struct TorordGrl1T {
         }
         {
           const Du<D1> act = mk<D1>(g1 * kss, 0.0, g1 + kss * dg1_dI * 0.0005);
-          const Du<DV | D1> I = (fs_ * 0.0003574) * (Gs * (Vff * (act * Ve1 - q.gko_ko) * R1));
+          const Du<DV | D1> I = q.fs_k * (Gs * (Vff * (act * Ve1 - q.gko_ko) * R1));
           Iv += I.v;
           dIv += I.d[0];
           Ikss += I.v;
@@ -809,7 +898,7 @@ struct TorordGrl1T {
       // IKs: reversal potential with the Na permeability; KsCa depends on cai (no state's self-derivative sees that)
       const double xs1 = pf_xs1, xs2 = pf_xs2;
       const double rks = beat_rcp(p[PKNa_] * nai + ki);
-      const double EKs = q.RTFk * fm.log((p[PKNa_] * p[nao_] + p[ko_]) * rks);
+      const double EKs = q.RTFk * fm.log(q.nao_ko_ks * rks);
       const double KsCa = 1.0 + 0.6 * beat_rcp(fm.exp(1.4 * fm.log(3.8e-5 * beat_rcp(cai))) + 1.0);
       const double gKs = xs2 * (xs1 * (q.GKs * KsCa));
       const double IKs = gKs * (v - EKs);
@@ -835,13 +924,13 @@ struct TorordGrl1T {
     // ---- chloride currents and concentrations (.ode:604-608, 403-404) ---------------------------------------------------
     {
       const double ECl = q.RTFcl * fm.log(p[clo_] * beat_rcp(cli)), EClss = q.RTFcl * fm.log(p[clo_] * beat_rcp(clss));
-      const double g_junc = (p[Fjunc_] * p[GClCa_]) * cass * beat_rcp(cass + p[KdClCa_]);
-      const double g_sl = (p[GClCa_] * (1.0 - p[Fjunc_])) * cai * beat_rcp(cai + p[KdClCa_]);
+      const double g_junc = q.g_junc0 * cass * beat_rcp(cass + p[KdClCa_]);
+      const double g_sl = q.g_sl0 * cai * beat_rcp(cai + p[KdClCa_]);
       const double IClCa_junc = g_junc * (v - EClss), IClCa_sl = g_sl * (v - ECl), IClb = p[GClb_] * (v - ECl);
       Iv += IClCa_junc + IClCa_sl + IClb;
       dIv += g_junc + g_sl + p[GClb_];
-      const double JdiffCl = (clss - cli) * beat_rcp(p[tauNa_]);  // the specification divides by tauNa, not tauCl
-      const double rt = beat_rcp(p[tauNa_]);
+      const double rt = q.r_tauNa;
+      const double JdiffCl = (clss - cli) * rt;  // the specification divides by tauNa, not tauCl
       // d ECl / d cli = -RTFcl / cli
       const double f_cli = q.cAF_myo * (IClCa_sl + IClb) + JdiffCl * q.vss_vmyo;
       const double J_cli = q.cAF_myo * (g_sl + p[GClb_]) * (q.RTFcl * beat_rcp(cli)) - q.vss_vmyo * rt;
@@ -862,14 +951,14 @@ struct TorordGrl1T {
       const double IpCa = p[GpCa_] * cai * rp;
       Iv += IpCa;
       Icai += IpCa;
-      dIcai += p[GpCa_] * p[KmCap_] * rp * rp;
+      dIcai += q.GpCa_Km * rp * rp;
       io.store(S_v, advance(fm, v, -(Istim + Iv), -dIv, dt));
     }
     BEAT_TFENCE();
 
     // ---- sodium and potassium (.ode:405-411) --------------------------------------------------------------------------
     {
-      const double rtNa = beat_rcp(p[tauNa_]), rtK = beat_rcp(p[tauK_]);
+      const double rtNa = q.r_tauNa, rtK = q.r_tauK;
       const double JdiffNa = (nass - nai) * rtNa, JdiffK = (kss - ki) * rtK;
       io.store(S_nai, advance(fm, nai, -q.cAF_myo * Inai + JdiffNa * q.vss_vmyo, -q.cAF_myo * dInai - q.vss_vmyo * rtNa, dt));
       io.store(S_nass, advance(fm, nass, -JdiffNa - q.cAF_ss * Inass, -rtNa - q.cAF_ss * dInass, dt));
@@ -882,13 +971,13 @@ struct TorordGrl1T {
     // ---- calcium: SERCA, ryanodine receptor, translocation, buffers (.ode:398-402, 617-633) -----------------------------
     {
       const double cajsr = pf_cajsr, cansr = pf_cansr, Jrel_np = pf_Jrel_np, Jrel_p = pf_Jrel_p;
-      const double rtCa = beat_rcp(p[tauCa_]);
+      const double rtCa = q.r_tauCa;
       const double Jdiff = (cass - cai) * rtCa;
       // SERCA
       const double ru = beat_rcp(cai + 0.00092), rup = beat_rcp((cai + 0.00092) - 0.00017);
-      const double cu = q.upScale * 0.005425, cup = (q.upScale * 2.75) * 0.005425;
+      const double cu = q.cu, cup = q.cup;
       const double Jupnp = cai * cu * ru, Jupp = cai * cup * rup;
-      const double Jleak = (0.0048825 * cansr) * (1.0 / 15.0);
+      const double Jleak = q.Jleak_c * cansr;
       const double Jup = p[Jup_b_] * (-Jleak + (Jupnp * (1.0 - fp) + Jupp * fp));
       const double dJup_dcai = p[Jup_b_] * ((1.0 - fp) * cu * 0.00092 * ru * ru + fp * cup * (0.00092 - 0.00017) * rup * rup);
       // release
@@ -916,7 +1005,7 @@ struct TorordGrl1T {
         io.store(S_CaTrpn, advance(fm, CaTrpn, fTrpn, -p[ktrpn_] * (pw + 1.0), dt));
         {  // cai: calmodulin buffering in Bcai, troponin as the flux J_TRPN = trpnmax dCaTrpn/dt
           const double rm = beat_rcp(cai + p[kmcmdn_]);
-          const double bm = q.cmdnmax * p[kmcmdn_] * rm * rm;
+          const double bm = q.b_cmdn * rm * rm;
           const double B = beat_rcp(1.0 + bm);
           const double dB = B * B * (2.0 * bm * rm);
           const double inner = ((-q.cA2F_myo * Icai - Jup * q.vnsr_vmyo) + Jdiff * q.vss_vmyo) - p[trpnmax_] * fTrpn;
@@ -948,7 +1037,7 @@ struct TorordGrl1T {
         }
       } else {  // cai: d/dt = Bcai * inner
         const double rt = beat_rcp(cai + p[kmtrpn_]), rm = beat_rcp(cai + p[kmcmdn_]);
-        const double bt_ = p[kmtrpn_] * p[trpnmax_] * rt * rt, bm = q.cmdnmax * p[kmcmdn_] * rm * rm;
+        const double bt_ = q.b_trpn * rt * rt, bm = q.b_cmdn * rm * rm;
         const double B = beat_rcp(bt_ + (bm + 1.0));
         const double dB = B * B * (2.0 * bt_ * rt + 2.0 * bm * rm);
         const double inner = (-q.cA2F_myo * Icai - Jup * q.vnsr_vmyo) + Jdiff * q.vss_vmyo;
@@ -958,7 +1047,7 @@ struct TorordGrl1T {
       BEAT_TFENCE();
       {  // cass
         const double rl = beat_rcp(p[KmBSL_] + cass), rr = beat_rcp(p[KmBSR_] + cass);
-        const double bl = p[BSLmax_] * p[KmBSL_] * rl * rl, br = p[BSRmax_] * p[KmBSR_] * rr * rr;
+        const double bl = q.b_bsl * rl * rl, br = q.b_bsr * rr * rr;
         const double B = beat_rcp(bl + (br + 1.0));
         const double dB = B * B * (2.0 * bl * rl + 2.0 * br * rr);
         const double inner = -Jdiff + (-q.cA2F_ss * Icass + Jrel * q.vjsr_vss);
@@ -968,7 +1057,7 @@ struct TorordGrl1T {
       BEAT_TFENCE();
       {  // cajsr
         const double rq = beat_rcp(cajsr + p[kmcsqn_]);
-        const double bq = p[csqnmax_] * p[kmcsqn_] * rq * rq;
+        const double bq = q.b_csqn * rq * rq;
         const double B = beat_rcp(bq + 1.0);
         const double dB = B * B * (2.0 * bq * rq);
         const double inner = -Jrel + Jtr;
@@ -976,11 +1065,14 @@ struct TorordGrl1T {
       }
       BEAT_TFENCE();
       // cansr
-      io.store(S_cansr, advance(fm, cansr, Jup - Jtr * q.vjsr_vnsr,
-                                -p[Jup_b_] * (0.0048825 * (1.0 / 15.0)) - (1.0 / 60.0) * q.vjsr_vnsr, dt));
+      io.store(S_cansr, advance(fm, cansr, Jup - Jtr * q.vjsr_vnsr, q.J_cansr, dt));
     }
   }
 };
 using TorordDynClGrl1 = TorordGrl1T<false>;
 using TorordLandGrl1 = TorordGrl1T<true>;
+
+#if defined(__clang__) && !defined(BEAT_TORORD_NO_CONTRACT)
+#pragma clang fp contract(off)
+#endif
 

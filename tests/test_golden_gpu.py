@@ -301,7 +301,10 @@ def test_torord_land_beat_follows_the_oracle_and_develops_tension():
 
 @pytest.mark.parametrize("model", ["tp06", "torord", "torord_land", "fhn"])
 def test_run_kernel_equals_repeated_steps(model):
-    """beat_ode_run (in-kernel time loop) gives bit-for-bit what repeated beat_ode_step launches give."""
+    """beat_ode_run (in-kernel time loop) gives what repeated beat_ode_step launches give: bit for bit for the models
+    compiled without contraction; the TP06 and ToR-ORd steps are compiled with a * b + c contracted to fma (round 3: -5 %
+    VALU instructions on kernels bound by them), which the compiler decides per kernel instantiation -- the register loop
+    and the step kernel may then round an expression differently (seen: 3 of 3640 values one ulp apart after 25 steps)."""
     from beat.models import fhn, torord, torord_land, tp06
 
     m = {"tp06": tp06.generalized_rush_larsen, "torord": torord.generalized_rush_larsen,
@@ -314,7 +317,10 @@ def test_run_kernel_equals_repeated_steps(model):
     for j in range(25):
         ys = m(states=ys, t=j * 0.02, parameters=P, dt=0.02)
     yr, tr = m.run(y0, P, dt=0.02, nsteps=25, track_indices=[m.state_index(m.v_name)], save_freq=5)
-    np.testing.assert_array_equal(yr, ys)
+    if model == "fhn":
+        np.testing.assert_array_equal(yr, ys)
+    else:
+        np.testing.assert_allclose(yr, ys, rtol=1e-13, atol=1e-300)
     assert tr.shape == (5, 1, 70)
     np.testing.assert_array_equal(tr[0, 0], y0[m.state_index(m.v_name)])
 
