@@ -256,6 +256,13 @@ __device__ __forceinline__ double beat_rcp(double x) {
   return fma(r, fma(e, e, e), r);
 }
 
+// 1/sqrt(x): hardware estimate + one third-order step r (1 + e/2 + 3 e^2/8), e = 1 - x r^2 (9 issue slots; sqrt(x) = x r)
+__device__ __forceinline__ double beat_rsqrt(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * r), r, 1.0);
+  return fma(r * fma(e, 0.375, 0.5), e, r);
+}
+
 struct FastMath {
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
   const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab

@@ -147,6 +147,50 @@ BEAT_DV Du<A> dexp(const FM& fm, const Du<A>& a) {
   BEAT_DU_FOR(k, A) r.d[k] = r.v * a.d[k];
   return r;
 }
+// Several reciprocals from ONE v_rcp_f64 (quarter rate) + Newton step: 1/a = b c (1/(a b c)), ...  A reciprocal is 7 issue
+// slots, a pair 10 instead of 14, a triple 13 instead of 21, a quadruple 16 instead of 28.  The callers' products stay
+// far inside the double range (each factor is 1 + exp(.) or a sum of exponentials of the potential: < 1e60 each for
+// -135 .. +500 mV) -- where a factor can reach 1e304 (Ito's development term) it keeps its own reciprocal.
+BEAT_DV void rcp2(double a, double b, double& ia, double& ib) {
+  const double r = beat_rcp(a * b);
+  ia = r * b;
+  ib = r * a;
+}
+BEAT_DV void rcp3(double a, double b, double c, double& ia, double& ib, double& ic) {
+  const double ab = a * b;
+  const double r = beat_rcp(ab * c);
+  const double rc = r * c;
+  ic = r * ab;
+  ia = rc * b;
+  ib = rc * a;
+}
+BEAT_DV void rcp4(double a, double b, double c, double d, double& ia, double& ib, double& ic, double& id) {
+  const double ab = a * b, cd = c * d;
+  const double r = beat_rcp(ab * cd);
+  const double rab = r * cd, rcd = r * ab;
+  ia = rab * b;
+  ib = rab * a;
+  ic = rcd * d;
+  id = rcd * c;
+}
+// 1 / a given r = 1 / a.v
+template <unsigned A>
+BEAT_DV Du<A> inv_with(const Du<A>& a, double r) {
+  Du<A> o;
+  o.v = r;
+  const double m = -r * r;
+  BEAT_DU_FOR(k, A) o.d[k] = m * a.d[k];
+  return o;
+}
+template <unsigned A, unsigned B, unsigned C>
+BEAT_DV void inv3(const Du<A>& a, const Du<B>& b, const Du<C>& c, Du<A>& ia, Du<B>& ib, Du<C>& ic) {
+  double ra, rb, rc;
+  rcp3(a.v, b.v, c.v, ra, rb, rc);
+  ia = inv_with(a, ra);
+  ib = inv_with(b, rb);
+  ic = inv_with(c, rc);
+}
+
 template <unsigned A>
 BEAT_DV Du<A> sq(const Du<A>& a) {
   return a * a;
@@ -223,6 +267,7 @@ struct TorordGrl1T {
     double fi, fi_na, fi_k, fs, fs_na, fs_k, m4cA;
     double g_junc0, g_sl0, cu, cup, Jleak_c, J_cansr, GpCa_Km, nao_ko_ks;
     double b_trpn, b_cmdn, b_bsl, b_bsr, b_csqn;
+    double nk_iKnai0, nk_nao_iKnao0, nk_cb3eP, half8, r_bt, r_btp;
   };
   BEAT_HD static Derived derive(const double* p) {
     Derived q;
@@ -333,6 +378,15 @@ struct TorordGrl1T {
     q.b_bsl = p[BSLmax_] * p[KmBSL_];
     q.b_bsr = p[BSRmax_] * p[KmBSR_];
     q.b_csqn = p[csqnmax_] * p[kmcsqn_];
+    q.nk_iKnai0 = 1.0 / p[Knai0_];
+    q.nk_nao_iKnao0 = p[nao_] / p[Knao0_];
+    q.nk_cb3eP = q.nk_cb3 * p[eP_];
+    {
+      const double h2 = p[cajsr_half_] * p[cajsr_half_], h4 = h2 * h2;
+      q.half8 = h4 * h4;
+    }
+    q.r_bt = 1.0 / p[bt_];
+    q.r_btp = 1.0 / q.btp;
     if constexpr (LAND) {  // .ode:682-717, parameter-only
       const double lam12 = p[lmbda_] < 1.2 ? p[lmbda_] : 1.2;
       const double rw = p[rw_], rs = p[rs_];
@@ -416,22 +470,24 @@ struct TorordGrl1T {
     // tangents each), and at this point nothing but the potential and the first running sums is live.
     // ---- INaK (.ode:418-444): directions 0 = v, 1 = nai, 2 = ki --------------------------------------------------------
     {
-      const Du<DV> Knai = dexp(fm, mk<DV>(vfrt * q.nk_sKnai, q.nk_dKnai)) * p[Knai0_];
-      const Du<DV> Knao = dexp(fm, mk<DV>(vfrt * q.nk_sKnao, q.nk_dKnao)) * p[Knao0_];
+      // 1 / Knai and nao / Knao as exponentials of the negated argument (the specification divides by exp(.) Knai0)
+      const Du<DV> iKnai = dexp(fm, mk<DV>(-(vfrt * q.nk_sKnai), -q.nk_dKnai)) * q.nk_iKnai0;
+      const Du<DV> yo = dexp(fm, mk<DV>(-(vfrt * q.nk_sKnao), -q.nk_dKnao)) * q.nk_nao_iKnao0;
       const Du<D1> Nai = mk<D1>(nai, 0.0, 1.0);
       const Du<D2> Ki = mk<D2>(ki, 0.0, 0.0, 1.0);
-      const Du<D1 | D2> P = p[eP_] / ((Nai * q.nk_iKnap + q.nk_Pden0) + Ki * q.nk_iKxkur);
-      const Du<DV | D1> xn = Nai / Knai;
+      const Du<DV | D1> xn = Nai * iKnai;
       const Du<D2> xk = Ki * q.nk_iKki;
-      const Du<DV | D1 | D2> rD1 = inv((sq(1.0 + xk) + cube(1.0 + xn)) - 1.0);
+      Du<D1 | D2> rP;
+      Du<DV | D1 | D2> rD1;
+      Du<DV> rD3;
+      inv3((Nai * q.nk_iKnap + q.nk_Pden0) + Ki * q.nk_iKxkur, (sq(1.0 + xk) + cube(1.0 + xn)) - 1.0,
+           (cube(1.0 + yo) + q.nk_1koK2) - 1.0, rP, rD1, rD3);
       const Du<DV | D1 | D2> a1 = (p[k1p_] * cube(xn)) * rD1;
       const Du<DV | D1 | D2> b4 = (p[k4m_] * sq(xk)) * rD1;
       BEAT_TFENCE();
-      const Du<DV> yo = p[nao_] / Knao;
-      const Du<DV> rD3 = inv((cube(1.0 + yo) + q.nk_1koK2) - 1.0);
       const Du<DV> a3 = q.nk_a3n * rD3;
       const Du<DV> b2 = (p[k2m_] * cube(yo)) * rD3;
-      const Du<D1 | D2> b3 = q.nk_cb3 * P;
+      const Du<D1 | D2> b3 = q.nk_cb3eP * rP;
       const double a2 = q.nk_a2, a4 = q.nk_a4, b1 = q.nk_b1;
       BEAT_TFENCE();
       // INaK = Pnak (zk JnakK + zna JnakNa), JnakK = 2 (E4 b1 - E3 a1), JnakNa = 3 (E1 a3 - E2 b3), E_k = x_k / sum x:
@@ -462,7 +518,7 @@ struct TorordGrl1T {
 
     // ---- INaCa, myoplasm and subspace (.ode:446-525): directions 0 = v, 1 = Na, 2 = Ca --------------------------------
     {
-      const Du<DV> hca = dexp(fm, mk<DV>(p[qca_] * vfrt, q.nc_sca));
+      const Du<DV> rhca = dexp(fm, mk<DV>(-(p[qca_] * vfrt), -q.nc_sca));  // 1 / hca: the only form it is used in
       const Du<DV> hna = dexp(fm, mk<DV>(p[qna_] * vfrt, q.nc_sna));
       // v-only part, shared by both compartments
       const Du<DV> rhna = inv(hna);
@@ -472,17 +528,19 @@ struct TorordGrl1T {
       const Du<DV> k3pp = h8 * p[wnaca_];
       const Du<DV> k3 = h9 * p[wca_] + k3pp;
       const Du<DV> k8 = q.nc_wna_h11 * h8;
-      const Du<DV> rhca = inv(hca);
       const double k1 = q.nc_k1, k2 = p[kcaoff_], k5 = p[kcaoff_];
 #define BEAT_NCX(NA, CA, GN, IV, DIV, INA, DINA, ICA, DICA, CAF)                                                        \
   {                                                                                                                  \
     const Du<D1> Na = mk<D1>(NA, 0.0, 1.0);                                                                          \
     const Du<D2> Ca = mk<D2>(CA, 0.0, 0.0, 1.0);                                                                     \
     const Du<DV | D1> h1 = (Na * q.nc_ikna3) * (hna + 1.0) + 1.0;                                                    \
-    const Du<DV | D1> h3 = inv(h1);                                                                                  \
-    const Du<DV | D1> h2 = ((hna * Na) * q.nc_ikna3) * h3;                                                           \
     const Du<D1> h4 = (Na * q.nc_ikna1) * (1.0 + Na * q.nc_ikna2) + 1.0;                                             \
-    const Du<D1> h6 = inv(h4);                                                                                       \
+    const Du<D2> Ca2 = Ca * Ca;                                                                                      \
+    Du<DV | D1> h3;                                                                                                  \
+    Du<D1> h6;                                                                                                       \
+    Du<D2> rallo;                                                                                                    \
+    inv3(h1, h4, Ca2 + q.nc_km2, h3, h6, rallo);                                                                     \
+    const Du<DV | D1> h2 = ((hna * Na) * q.nc_ikna3) * h3;                                                           \
     const Du<D1> h5 = ((Na * Na) * q.nc_ikna12) * h6;                                                                \
     const Du<DV | D1> k4pp = h2 * p[wnaca_];                                                                         \
     const Du<DV | D1> k4 = (h3 * p[wca_]) * rhca + k4pp;                                                             \
@@ -511,8 +569,7 @@ struct TorordGrl1T {
       S = S + x4;                                                                                                      \
       N = N + x4 * (q.nc_3zna * k7);                                                                                   \
     }                                                                                                                  \
-    const double km2 = q.nc_km2;                                                                                       \
-    const Du<D2> allo = (Ca * Ca) * inv(Ca * Ca + km2);                                                                \
+    const Du<D2> allo = Ca2 * rallo;                                                                                   \
     const auto I = (allo * (GN)) * (N * inv(S));                                                                       \
     IV += I.v;                                                                                                       \
     DIV += I.d[0];                                                                                                   \
@@ -556,7 +613,8 @@ struct TorordGrl1T {
     BEAT_TFENCE();
 
     // ---- reversal potentials (.ode:527-532) ---------------------------------------------------------------------------
-    const double rnai = beat_rcp(nai), rki = beat_rcp(ki);
+    double rnai, rki, rcai, rcass;  // (rcai, rcass: the nca states and IKs below)
+    rcp4(nai, ki, cai, cass, rnai, rki, rcai, rcass);
     const double ENa = q.RTFna * fm.log(p[nao_] * rnai);
     const double EK = q.RTFk * fm.log(p[ko_] * rki);
     const double uK = v - EK;                                        // driving force of the K currents
@@ -564,9 +622,7 @@ struct TorordGrl1T {
     BEAT_TFENCE();
 
     // ---- INa (.ode:577-599) -------------------------------------------------------------------------------------------
-    // shared with INaL: tm = tmL
-    const double tm_rate = beat_rcp(0.06487 * fm.exp(-((v - 4.823) * (1.0 / 51.12)) * ((v - 4.823) * (1.0 / 51.12))) +
-                                    0.1292 * fm.exp(-((v + 45.79) * (1.0 / 15.54)) * ((v + 45.79) * (1.0 / 15.54))));
+    double tm_rate;  // shared with INaL: tm = tmL
     {
       const double m = pf_m, h = pf_h, hp = pf_hp, j = pf_j, jp = pf_jp;
       const double gNa = (m * m * m) * p[GNa_] * (j * (h * (1.0 - fp)) + jp * (fp * hp));
@@ -577,20 +633,27 @@ struct TorordGrl1T {
       dInai += -gNa * dENa;
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Inai); BEAT_PIN(dInai);
       BEAT_TFENCE();
+      const double tm_den = 0.06487 * fm.exp(-((v - 4.823) * (1.0 / 51.12)) * ((v - 4.823) * (1.0 / 51.12))) +
+                            0.1292 * fm.exp(-((v + 45.79) * (1.0 / 15.54)) * ((v + 45.79) * (1.0 / 15.54)));
+      BEAT_TFENCE();
       const double em = fm.exp(-(v + 56.86) * (1.0 / 9.03));
       const double eh = fm.exp((v + 71.55) * (1.0 / 7.43));
-      const double rm = beat_rcp(em + 1.0), rh = beat_rcp(eh + 1.0), rhp = beat_rcp(eh * 2.2423782291926058 + 1.0);  // exp(6/7.43)
+      double rm, rh, rhp;
+      rcp4(tm_den, em + 1.0, eh + 1.0, eh * 2.2423782291926058 + 1.0, tm_rate, rm, rh, rhp);  // exp(6/7.43)
       BEAT_TFENCE();
       double rate_h, rate_j;
       if (v > -40.0) {
         const double ea = fm.exp(0.0900900900900901 * v);
-        rate_h = 0.77 * ea * beat_rcp(0.13 * ea + 0.0497581410839387);
-        rate_j = 0.6 * fm.exp(0.157 * v) * beat_rcp(1.0 * fm.exp(0.1 * v) + 0.0407622039783662);
+        double r1, r2;
+        rcp2(0.13 * ea + 0.0497581410839387, 1.0 * fm.exp(0.1 * v) + 0.0407622039783662, r1, r2);
+        rate_h = 0.77 * ea * r1;
+        rate_j = 0.6 * fm.exp(0.157 * v) * r2;
       } else {
         rate_h = 4.43126792958051e-7 * fm.exp(-0.147058823529412 * v) + (2.7 * fm.exp(0.079 * v) + 310000.0 * fm.exp(0.3485 * v));
-        const double aj = -(v + 37.78) * (25428.0 * fm.exp(0.28831 * v) + 6.948e-6) * fm.exp(-0.04391 * v) *
-                          beat_rcp(50262745825.954 * fm.exp(0.311 * v) + 1.0);
-        const double bj = 0.02424 * fm.exp(0.12728 * v) * beat_rcp(1.0 * fm.exp(0.1378 * v) + 0.00396086833990426);
+        double r1, r2;
+        rcp2(50262745825.954 * fm.exp(0.311 * v) + 1.0, 1.0 * fm.exp(0.1378 * v) + 0.00396086833990426, r1, r2);
+        const double aj = -(v + 37.78) * (25428.0 * fm.exp(0.28831 * v) + 6.948e-6) * fm.exp(-0.04391 * v) * r1;
+        const double bj = 0.02424 * fm.exp(0.12728 * v) * r2;
         rate_j = aj + bj;
       }
       BEAT_TFENCE();
@@ -618,9 +681,11 @@ struct TorordGrl1T {
       const double ehL = fm.exp((v + 87.61) * (1.0 / 7.488));
       pf_a = io.load(S_a), pf_ap = io.load(S_ap), pf_iF = io.load(S_iF), pf_iFp = io.load(S_iFp), pf_iS = io.load(S_iS),
       pf_iSp = io.load(S_iSp);
-      io.store(S_mL, gate(fm, mL, beat_rcp(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0), tm_rate, dt));
-      io.store(S_hL, gate(fm, hL, beat_rcp(ehL + 1.0), q.r_thL, dt));
-      io.store(S_hLp, gate(fm, hLp, beat_rcp(ehL * 2.288717124596482 + 1.0), q.r_3thL, dt));  // exp(6.2/7.488)
+      double mLss, hLss, hLpss;
+      rcp3(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0, ehL + 1.0, ehL * 2.288717124596482 + 1.0, mLss, hLss, hLpss);  // exp(6.2/7.488)
+      io.store(S_mL, gate(fm, mL, mLss, tm_rate, dt));
+      io.store(S_hL, gate(fm, hL, hLss, q.r_thL, dt));
+      io.store(S_hLp, gate(fm, hLp, hLpss, q.r_3thL, dt));
     }
     BEAT_TFENCE();
 
@@ -641,26 +706,34 @@ struct TorordGrl1T {
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
       BEAT_TFENCE();
       const double ea = fm.exp(-(ve - 14.34) * (1.0 / 14.82));
-      const double ass = beat_rcp(ea + 1.0), assp = beat_rcp(ea * 1.9635691902911017 + 1.0);  // exp(10/14.82)
       const double et = fm.exp(-(ve - 18.4099) * (1.0 / 29.3814));
-      // 3.5/(exp((ve + 100)/29.3814) + 1): exp((ve + 100)/29.3814) = exp(118.4099/29.3814) / et
-      const double ta_rate = (beat_rcp(1.2089 * (et + 1.0)) + 3.5 * et * beat_rcp(56.266384148520984 + et)) * (1.0 / 1.0515);
+      // ta = 1.0515 / (1/(1.2089 (et + 1)) + 3.5/(exp((ve + 100)/29.3814) + 1)), exp((ve + 100)/29.3814) = exp(118.4099/29.3814) / et:
+      // 1/ta over the common denominator -- one reciprocal, shared with the two steady states
+      double ass, assp, ta_rate;
+      {
+        const double c = 56.266384148520984 + et;
+        rcp3(ea + 1.0, ea * 1.9635691902911017 + 1.0, (1.2089 * 1.0515) * ((et + 1.0) * c), ass, assp, ta_rate);  // exp(10/14.82)
+        ta_rate *= c + (3.5 * 1.2089) * (et * (et + 1.0));
+      }
       BEAT_TFENCE();
-      const double iss = beat_rcp(fm.exp((ve + 43.94) * (1.0 / 5.711)) + 1.0);
+      const double iss_den = fm.exp((ve + 43.94) * (1.0 / 5.711)) + 1.0;
       double delta_epi = 1.0;
       if (q.is_epi != 0.0) delta_epi = 1.0 - 0.95 * beat_rcp(fm.exp((ve + 70.0) * (1.0 / 5.0)) + 1.0);
-      const double tiF = delta_epi * (4.562 + beat_rcp(0.3933 * fm.exp(-(ve + 100.0) * (1.0 / 100.0)) +
-                                                       0.08004 * fm.exp((ve + 50.0) * (1.0 / 16.59))));
+      // tiF = delta_epi (4.562 + 1/sF): 1/tiF = sF / (delta_epi (4.562 sF + 1)); tiS likewise
+      const double sF = 0.3933 * fm.exp(-(ve + 100.0) * (1.0 / 100.0)) + 0.08004 * fm.exp((ve + 50.0) * (1.0 / 16.59));
       BEAT_TFENCE();
-      const double tiS = delta_epi * (23.62 + beat_rcp(0.001416 * fm.exp(-(ve + 96.52) * (1.0 / 59.05)) +
-                                                       1.78e-8 * fm.exp((ve + 114.1) * (1.0 / 8.079))));
+      const double sS = 0.001416 * fm.exp(-(ve + 96.52) * (1.0 / 59.05)) + 1.78e-8 * fm.exp((ve + 114.1) * (1.0 / 8.079));
+      double iss, rtiF, rtiS;
+      rcp3(iss_den, delta_epi * (4.562 * sF + 1.0), delta_epi * (23.62 * sS + 1.0), iss, rtiF, rtiS);
+      rtiF *= sF;
+      rtiS *= sS;
       BEAT_TFENCE();
       const double xdev = fmin(-(ve - 12.23) * (1.0 / 0.2154), 700.0);  // exp() of it overflows below -138 mV
-      const double dti_develop = 1.354 + 0.0001 * beat_rcp(fm.exp(xdev) + fm.exp((ve - 167.4) * (1.0 / 15.89)));
-      const double dti_recover = 1.0 - 0.5 * beat_rcp(fm.exp((ve + 70.0) * (1.0 / 20.0)) + 1.0);
+      const double dti_develop = 1.354 + 0.0001 * beat_rcp(fm.exp(xdev) + fm.exp((ve - 167.4) * (1.0 / 15.89)));  // (up to 1e304: alone)
+      // dti_recover = 1 - 0.5/(er + 1) = (er + 0.5)/(er + 1): 1/(develop recover) with one reciprocal
+      const double er = fm.exp((ve + 70.0) * (1.0 / 20.0));
       BEAT_TFENCE();
-      const double rdd = beat_rcp(dti_develop * dti_recover);
-      const double rtiF = beat_rcp(tiF), rtiS = beat_rcp(tiS);
+      const double rdd = (er + 1.0) * beat_rcp(dti_develop * (er + 0.5));
       pf_d = io.load(S_d), pf_ff = io.load(S_ff_), pf_fs = io.load(S_fs), pf_fcaf = io.load(S_fcaf), pf_fcas = io.load(S_fcas);
       pf_jca = io.load(S_jca), pf_ffp = io.load(S_ffp), pf_fcafp = io.load(S_fcafp), pf_nca_i = io.load(S_nca_i);
       pf_nca_ss = io.load(S_nca_ss);
@@ -701,41 +774,54 @@ struct TorordGrl1T {
       BEAT_PIN(G_i); BEAT_PIN(dG_i_dv); BEAT_PIN(G_ss); BEAT_PIN(dG_ss_dv); BEAT_PIN(dG_ss_dfp);
       BEAT_TFENCE();
       // gates
+      // Every time constant of the form  tau = c + 1/s  enters as its rate  1/tau = s / (c s + 1): one reciprocal instead
+      // of two (three where s itself held a 1/exp: 0.0045/e + 0.0045 e = 0.0045 (1 + e^2)/e), and the seven
+      // denominators of the block share two v_rcp_f64.
       const double dss = (v >= 31.4978) ? 1.0 : 1.0763 * fm.exp(-1.007 * fm.exp(-0.0829 * v));
       const double vs = v + p[vShift_];
-      const double td = q.td0 + beat_rcp(fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0)));
+      const double sd = fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0));          // td = td0 + 1/sd
       BEAT_TFENCE();
-      const double fss = beat_rcp(fm.exp((v + 19.58) * (1.0 / 3.696)) + 1.0);
+      const double fss_den = fm.exp((v + 19.58) * (1.0 / 3.696)) + 1.0;
       const double e20 = fm.exp((v + 20.0) * (1.0 / 10.0));
-      const double tff = 7.0 + beat_rcp(0.0045 * beat_rcp(e20) + 0.0045 * e20);
+      const double w20 = 0.0045 * (1.0 + e20 * e20);                                       // tff = 7 + e20 / w20
       BEAT_TFENCE();
-      const double tfs = 1000.0 + beat_rcp(3.5e-5 * fm.exp(-(v + 5.0) * (1.0 / 4.0)) + 3.5e-5 * fm.exp((v + 5.0) * (1.0 / 6.0)));
+      const double sfs = 3.5e-5 * fm.exp(-(v + 5.0) * (1.0 / 4.0)) + 3.5e-5 * fm.exp((v + 5.0) * (1.0 / 6.0));  // tfs = 1000 + 1/sfs
+      double rtd, fss, rtff, rtfs;
+      rcp4(q.td0 * sd + 1.0, fss_den, 7.0 * w20 + e20, 1000.0 * sfs + 1.0, rtd, fss, rtff, rtfs);
+      rtd *= sd;
+      rtff *= w20;
+      rtfs *= sfs;
       BEAT_TFENCE();
       const double e4 = fm.exp((v - 4.0) * (1.0 / 7.0));
-      const double tfcaf = 7.0 + beat_rcp(0.04 * beat_rcp(e4) + 0.04 * e4);
+      const double w4 = 0.04 * (1.0 + e4 * e4);                                            // tfcaf = 7 + e4 / w4
       BEAT_TFENCE();
-      const double tfcas = 100.0 + beat_rcp(0.00012 * fm.exp(-v * (1.0 / 3.0)) + 0.00012 * fm.exp(v * (1.0 / 7.0)));
-      const double jcass = beat_rcp(fm.exp((v + 18.08) * (1.0 / 2.7916)) + 1.0);
+      const double sfcas = 0.00012 * fm.exp(-v * (1.0 / 3.0)) + 0.00012 * fm.exp(v * (1.0 / 7.0));  // tfcas = 100 + 1/sfcas
+      const double jcass_den = fm.exp((v + 18.08) * (1.0 / 2.7916)) + 1.0;
+      double rtfcaf, rtfcas, jcass;
+      rcp3(7.0 * w4 + e4, 100.0 * sfcas + 1.0, jcass_den, rtfcaf, rtfcas, jcass);
+      rtfcaf *= w4;
+      rtfcas *= sfcas;
       BEAT_TFENCE();
-      const double rtff = beat_rcp(tff), rtfcaf = beat_rcp(tfcaf);
       pf_O = io.load(S_O_), pf_C1 = io.load(S_C1), pf_C2 = io.load(S_C2), pf_C3 = io.load(S_C3), pf_I = io.load(S_I_);
-      io.store(S_d, gate(fm, d, dss, beat_rcp(td), dt));
+      io.store(S_d, gate(fm, d, dss, rtd, dt));
       io.store(S_ff_, gate(fm, ff, fss, rtff, dt));
       BEAT_TFENCE();
       io.store(S_ffp, gate(fm, ffp, fss, rtff * (1.0 / 2.5), dt));
-      io.store(S_fs, gate(fm, fs, fss, beat_rcp(tfs), dt));
+      io.store(S_fs, gate(fm, fs, fss, rtfs, dt));
       BEAT_TFENCE();
       io.store(S_fcaf, gate(fm, fcaf, fss, rtfcaf, dt));
       io.store(S_fcafp, gate(fm, fcafp, fss, rtfcaf * (1.0 / 2.5), dt));
       BEAT_TFENCE();
-      io.store(S_fcas, gate(fm, fcas, fss, beat_rcp(tfcas), dt));
+      io.store(S_fcas, gate(fm, fcas, fss, rtfcas, dt));
       io.store(S_jca, gate(fm, jca, jcass, q.r_tjca, dt));
       BEAT_TFENCE();
-      // nca: f = anca k2n - km2n nca, km2n = jca, anca = 1/(k2n/km2n + (Kmn/ca + 1)^4): J = -jca
+      // nca: f = anca k2n - km2n nca, km2n = jca, anca = 1/(k2n/km2n + (Kmn/ca + 1)^4) = jca / (k2n + jca (Kmn/ca + 1)^4): J = -jca
       {
-        const double xi = p[Kmn_] * beat_rcp(cai) + 1.0, xs = p[Kmn_] * beat_rcp(cass) + 1.0;
-        const double k2j = p[k2n_] * beat_rcp(jca);
-        const double anca_i = beat_rcp(k2j + (xi * xi) * (xi * xi)), anca_ss = beat_rcp(k2j + (xs * xs) * (xs * xs));
+        const double xi = p[Kmn_] * rcai + 1.0, xs = p[Kmn_] * rcass + 1.0;
+        double anca_i, anca_ss;
+        rcp2(p[k2n_] + jca * ((xi * xi) * (xi * xi)), p[k2n_] + jca * ((xs * xs) * (xs * xs)), anca_i, anca_ss);
+        anca_i *= jca;
+        anca_ss *= jca;
         const double em1 = fm.exp(fmax(-jca * dt, -746.0)) - 1.0;
         io.store(S_nca_i, grl1(nca_i, anca_i * p[k2n_] - jca * nca_i, -jca, em1, dt));
         io.store(S_nca_ss, grl1(nca_ss, anca_ss * p[k2n_] - jca * nca_ss, -jca, em1, dt));
@@ -749,14 +835,21 @@ struct TorordGrl1T {
       // dual directions: 0 = v, 1 = the ion the flux carries (cai / nai / ki, cass / nass / kss)
       const Du<DV> Ve1 = mk<DV>(e1, e1 * q.FRT), Ve2 = mk<DV>(e2, 2.0 * e2 * q.FRT);
       const Du<DV> Vff = mk<DV>(vffrt, q.FFRT);
-      const Du<DV> R1 = inv(Ve1 - 1.0), R2 = inv(Ve2 - 1.0);
+      Du<DV> R1, R2;
+      {
+        double r1v, r2v;
+        rcp2(e1 - 1.0, e2 - 1.0, r1v, r2v);
+        R1 = inv_with(Ve1, r1v);
+        R2 = inv_with(Ve2, r2v);
+      }
       const double fi = q.fi, fs_ = q.fs;
       // myoplasm: activity coefficients gamma = exp(-cA z^2 g(I)), g = sqrt(I)/(1 + sqrt(I)) - 0.3 I, I = ionic strength
       {
         const double Ii = (0.5 * (4.0 * cai + (cli + (ki + nai)))) * (1.0 / 1000.0);
-        const double sI = sqrt(Ii), r1s = beat_rcp(1.0 + sI);
+        const double rsI = beat_rsqrt(Ii);                              // 1/sqrt(I) serves sqrt(I) = I/sqrt(I) too
+        const double sI = Ii * rsI, r1s = beat_rcp(1.0 + sI);
         const double g = sI * r1s - 0.3 * Ii;
-        const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;          // dg/dI
+        const double dg = 0.5 * rsI * r1s * r1s - 0.3;                    // dg/dI
         const double g1 = fm.exp(-q.cA * g);                              // z = 1
         const double g2 = (g1 * g1) * (g1 * g1);                          // z = 2: exp(-4 cA g)
         const double dg1_dI = -q.cA * dg * g1, dg2_dI = q.m4cA * dg * g2;
@@ -801,9 +894,10 @@ struct TorordGrl1T {
       // subspace: the gate factor also depends on cass through fp
       {
         const double Is = (0.5 * (4.0 * cass + (clss + (kss + nass)))) * (1.0 / 1000.0);
-        const double sI = sqrt(Is), r1s = beat_rcp(1.0 + sI);
+        const double rsI = beat_rsqrt(Is);
+        const double sI = Is * rsI, r1s = beat_rcp(1.0 + sI);
         const double g = sI * r1s - 0.3 * Is;
-        const double dg = 0.5 * beat_rcp(sI) * r1s * r1s - 0.3;
+        const double dg = 0.5 * rsI * r1s * r1s - 0.3;
         const double g1 = fm.exp(-q.cA * g);
         const double g2 = (g1 * g1) * (g1 * g1);
         const double dg1_dI = -q.cA * dg * g1, dg2_dI = q.m4cA * dg * g2;
@@ -844,21 +938,24 @@ struct TorordGrl1T {
     // ---- K currents: IK1, IKb, IKr (+ Markov states), IKs (+ gates), I_katp (.ode:534-575, 612-615) --------------------
     {
       // IK1: aK1, bK1 functions of u = v - EK
+      // K1ss = aK1/(aK1 + bK1) with aK1 = 4.094/A, bK1 = E/B (A = ea + 1, B = eb3 + 1, E = eb1 + eb2) is N/D, N = 4.094 B,
+      // D = N + E A, and its derivative (N' - K1ss D')/D: one reciprocal (shared with IKb's) instead of three
       const double ea = fm.exp(0.1217 * (uK - 49.934));
-      const double aK1 = 4.094 * beat_rcp(ea + 1.0), daK1 = -aK1 * 0.1217 * ea * beat_rcp(ea + 1.0);
       const double eb1 = 15.72 * fm.exp(0.0674 * (uK - 3.257)), eb2 = fm.exp(0.0618 * (uK - 594.31));
       const double eb3 = fm.exp(-0.1629 * (uK + 14.207));
-      const double rb = beat_rcp(eb3 + 1.0);
-      const double bK1 = (eb1 + eb2) * rb;
-      const double dbK1 = (0.0674 * eb1 + 0.0618 * eb2) * rb + bK1 * 0.1629 * eb3 * rb;
-      const double rab = beat_rcp(aK1 + bK1);
-      const double K1ss = aK1 * rab, dK1ss = (daK1 * bK1 - aK1 * dbK1) * rab * rab;
+      BEAT_TFENCE();
+      const double ekb = fm.exp(-(v - 10.8968) * (1.0 / 23.9871));
+      const double A1 = ea + 1.0, E1 = eb1 + eb2;
+      const double N1 = 4.094 * (eb3 + 1.0), D1_ = N1 + E1 * A1;
+      const double dN1 = (4.094 * -0.1629) * eb3;
+      const double dD1 = dN1 + ((0.0674 * eb1 + 0.0618 * eb2) * A1 + E1 * (0.1217 * ea));
+      double rD1_, xkb;
+      rcp2(D1_, ekb + 1.0, rD1_, xkb);
+      const double K1ss = N1 * rD1_, dK1ss = (dN1 - K1ss * dD1) * rD1_;
       const double gK1 = q.GK1s * K1ss;
       const double dIK1_du = q.GK1s * dK1ss * uK + gK1;
       BEAT_TFENCE();
       // IKb
-      const double ekb = fm.exp(-(v - 10.8968) * (1.0 / 23.9871));
-      const double xkb = beat_rcp(ekb + 1.0);
       const double gKb = q.GKb * xkb;
       const double dIKb_dv = q.GKb * (xkb * (1.0 - xkb) * (1.0 / 23.9871)) * uK + gKb;
       BEAT_TFENCE();
@@ -897,9 +994,15 @@ struct TorordGrl1T {
     {
       // IKs: reversal potential with the Na permeability; KsCa depends on cai (no state's self-derivative sees that)
       const double xs1 = pf_xs1, xs2 = pf_xs2;
-      const double rks = beat_rcp(p[PKNa_] * nai + ki);
+      // the four reciprocals of the block from one: 1/(PKNa nai + ki), KsCa's, the steady state's, and 1/txs1 = s/(817.3 s + 1)
+      const double sx1 = 0.0002326 * fm.exp((v + 48.28) * (1.0 / 17.8)) + 0.001292 * fm.exp(-(v + 210.0) * (1.0 / 230.0));
+      double rks, rKsCa, xsss, rtxs1;
+      rcp4(p[PKNa_] * nai + ki, fm.exp(1.4 * fm.log(3.8e-5 * rcai)) + 1.0, fm.exp(-(v + 11.6) * (1.0 / 8.932)) + 1.0,
+           817.3 * sx1 + 1.0, rks, rKsCa, xsss, rtxs1);
+      rtxs1 *= sx1;
+      BEAT_TFENCE();
       const double EKs = q.RTFk * fm.log(q.nao_ko_ks * rks);
-      const double KsCa = 1.0 + 0.6 * beat_rcp(fm.exp(1.4 * fm.log(3.8e-5 * beat_rcp(cai))) + 1.0);
+      const double KsCa = 1.0 + 0.6 * rKsCa;
       const double gKs = xs2 * (xs1 * (q.GKs * KsCa));
       const double IKs = gKs * (v - EKs);
       Iv += IKs;
@@ -908,24 +1011,24 @@ struct TorordGrl1T {
       dIki += gKs * (q.RTFk * rks);
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
       BEAT_TFENCE();
-      const double xsss = beat_rcp(fm.exp(-(v + 11.6) * (1.0 / 8.932)) + 1.0);
-      const double txs1 = 817.3 + beat_rcp(0.0002326 * fm.exp((v + 48.28) * (1.0 / 17.8)) + 0.001292 * fm.exp(-(v + 210.0) * (1.0 / 230.0)));
       const double rtxs2 = 0.01 * fm.exp((v - 50.0) * (1.0 / 20.0)) + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
       pf_cajsr = io.load(S_cajsr), pf_cansr = io.load(S_cansr), pf_Jrel_np = io.load(S_Jrel_np), pf_Jrel_p = io.load(S_Jrel_p);
       if constexpr (LAND) {
         pf_XS = io.load(S_XS), pf_XW = io.load(S_XW), pf_CaTrpn = io.load(S_CaTrpn), pf_TmB = io.load(S_TmB);
         pf_Zetas = io.load(S_Zetas), pf_Zetaw = io.load(S_Zetaw), pf_Cd = io.load(S_Cd);
       }
-      io.store(S_xs1, gate(fm, xs1, xsss, beat_rcp(txs1), dt));
+      io.store(S_xs1, gate(fm, xs1, xsss, rtxs1, dt));
       io.store(S_xs2, gate(fm, xs2, xsss, rtxs2, dt));
     }
     BEAT_TFENCE();
 
     // ---- chloride currents and concentrations (.ode:604-608, 403-404) ---------------------------------------------------
     {
-      const double ECl = q.RTFcl * fm.log(p[clo_] * beat_rcp(cli)), EClss = q.RTFcl * fm.log(p[clo_] * beat_rcp(clss));
-      const double g_junc = q.g_junc0 * cass * beat_rcp(cass + p[KdClCa_]);
-      const double g_sl = q.g_sl0 * cai * beat_rcp(cai + p[KdClCa_]);
+      double rcli, rclss, rjn, rsl;
+      rcp4(cli, clss, cass + p[KdClCa_], cai + p[KdClCa_], rcli, rclss, rjn, rsl);
+      const double ECl = q.RTFcl * fm.log(p[clo_] * rcli), EClss = q.RTFcl * fm.log(p[clo_] * rclss);
+      const double g_junc = q.g_junc0 * cass * rjn;
+      const double g_sl = q.g_sl0 * cai * rsl;
       const double IClCa_junc = g_junc * (v - EClss), IClCa_sl = g_sl * (v - ECl), IClb = p[GClb_] * (v - ECl);
       Iv += IClCa_junc + IClCa_sl + IClb;
       dIv += g_junc + g_sl + p[GClb_];
@@ -933,9 +1036,9 @@ struct TorordGrl1T {
       const double JdiffCl = (clss - cli) * rt;  // the specification divides by tauNa, not tauCl
       // d ECl / d cli = -RTFcl / cli
       const double f_cli = q.cAF_myo * (IClCa_sl + IClb) + JdiffCl * q.vss_vmyo;
-      const double J_cli = q.cAF_myo * (g_sl + p[GClb_]) * (q.RTFcl * beat_rcp(cli)) - q.vss_vmyo * rt;
+      const double J_cli = q.cAF_myo * (g_sl + p[GClb_]) * (q.RTFcl * rcli) - q.vss_vmyo * rt;
       const double f_clss = -JdiffCl + q.cAF_ss * IClCa_junc;
-      const double J_clss = -rt + q.cAF_ss * g_junc * (q.RTFcl * beat_rcp(clss));
+      const double J_clss = -rt + q.cAF_ss * g_junc * (q.RTFcl * rclss);
       io.store(S_cli, advance(fm, cli, f_cli, J_cli, dt));
       io.store(S_clss, advance(fm, clss, f_clss, J_clss, dt));
     }
@@ -943,11 +1046,13 @@ struct TorordGrl1T {
 
     // ---- membrane potential (.ode:600-604) ----------------------------------------------------------------------------
     double Istim = 0.0;
+    double ru, rup;  // SERCA's reciprocals, formed with IpCa's (all three are functions of cai)
     {
       const double since = -p[i_Stim_Period_] * floor(-(p[i_Stim_Start_] - t) / p[i_Stim_Period_]) - p[i_Stim_Start_] + t;
       if (p[i_Stim_Start_] <= t && p[i_Stim_PulseDuration_] >= since) Istim = p[i_Stim_Amplitude_];
       // IpCa: sarcolemmal Ca pump
-      const double rp = beat_rcp(p[KmCap_] + cai);
+      double rp;
+      rcp3(p[KmCap_] + cai, cai + 0.00092, (cai + 0.00092) - 0.00017, rp, ru, rup);
       const double IpCa = p[GpCa_] * cai * rp;
       Iv += IpCa;
       Icai += IpCa;
@@ -974,7 +1079,6 @@ struct TorordGrl1T {
       const double rtCa = q.r_tauCa;
       const double Jdiff = (cass - cai) * rtCa;
       // SERCA
-      const double ru = beat_rcp(cai + 0.00092), rup = beat_rcp((cai + 0.00092) - 0.00017);
       const double cu = q.cu, cup = q.cup;
       const double Jupnp = cai * cu * ru, Jupp = cai * cup * rup;
       const double Jleak = q.Jleak_c * cansr;
@@ -984,16 +1088,19 @@ struct TorordGrl1T {
       const double Jrel = p[Jrel_b_] * (Jrel_np * (1.0 - fp) + Jrel_p * fp);
       const double dJrel_dcass = p[Jrel_b_] * (Jrel_p - Jrel_np) * dfp_dcass;
       const double Jtr = (cansr - cajsr) * (1.0 / 60.0);
+      double rq;  // 1/(cajsr + kmcsqn), for the cajsr equation below
       {
-        const double hr = p[cajsr_half_] * beat_rcp(cajsr);
-        const double h2 = hr * hr, h4 = h2 * h2;
-        const double rh8 = beat_rcp(h4 * h4 + 1.0);
+        // 1/((cajsr_half/cajsr)^8 + 1) = cajsr^8/(cajsr_half^8 + cajsr^8);  tau_rel = max(bt/(1 + 0.0123/cajsr), 0.001):
+        // 1/tau_rel = min((cajsr + 0.0123)/(bt cajsr), 1000) -- one reciprocal for the block instead of six
+        const double c2 = cajsr * cajsr, c4 = c2 * c2, c8 = c4 * c4;
+        double rcajsr, rh;
+        rcp3(cajsr, q.half8 + c8, cajsr + p[kmcsqn_], rcajsr, rh, rq);
+        const double rh8 = c8 * rh;
         const double Jrel_inf = q.relScale * ((ICaL_ss * (-q.a_rel)) * rh8);
         const double Jrel_infp = q.relScale * ((ICaL_ss * (-q.a_relp)) * rh8);
-        const double rc = beat_rcp(1.0 + 0.0123 * beat_rcp(cajsr));
-        const double tau_rel = fmax(p[bt_] * rc, 0.001), tau_relp = fmax(q.btp * rc, 0.001);
-        io.store(S_Jrel_np, gate(fm, Jrel_np, Jrel_inf, beat_rcp(tau_rel), dt));
-        io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, beat_rcp(tau_relp), dt));
+        const double irc = (cajsr + 0.0123) * rcajsr;
+        io.store(S_Jrel_np, gate(fm, Jrel_np, Jrel_inf, fmin(irc * q.r_bt, 1000.0), dt));
+        io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, fmin(irc * q.r_btp, 1000.0), dt));
       }
       BEAT_TFENCE();
       if constexpr (LAND) {
@@ -1036,7 +1143,8 @@ struct TorordGrl1T {
           io.store(S_Cd, advance(fm, Cd, re * dCd, -re, dt));
         }
       } else {  // cai: d/dt = Bcai * inner
-        const double rt = beat_rcp(cai + p[kmtrpn_]), rm = beat_rcp(cai + p[kmcmdn_]);
+        double rt, rm;
+        rcp2(cai + p[kmtrpn_], cai + p[kmcmdn_], rt, rm);
         const double bt_ = q.b_trpn * rt * rt, bm = q.b_cmdn * rm * rm;
         const double B = beat_rcp(bt_ + (bm + 1.0));
         const double dB = B * B * (2.0 * bt_ * rt + 2.0 * bm * rm);
@@ -1046,7 +1154,8 @@ struct TorordGrl1T {
       }
       BEAT_TFENCE();
       {  // cass
-        const double rl = beat_rcp(p[KmBSL_] + cass), rr = beat_rcp(p[KmBSR_] + cass);
+        double rl, rr;
+        rcp2(p[KmBSL_] + cass, p[KmBSR_] + cass, rl, rr);
         const double bl = q.b_bsl * rl * rl, br = q.b_bsr * rr * rr;
         const double B = beat_rcp(bl + (br + 1.0));
         const double dB = B * B * (2.0 * bl * rl + 2.0 * br * rr);
@@ -1056,7 +1165,6 @@ struct TorordGrl1T {
       }
       BEAT_TFENCE();
       {  // cajsr
-        const double rq = beat_rcp(cajsr + p[kmcsqn_]);
         const double bq = q.b_csqn * rq * rq;
         const double B = beat_rcp(bq + 1.0);
         const double dB = B * B * (2.0 * bq * rq);
