@@ -268,6 +268,8 @@ struct TorordGrl1T {
     double g_junc0, g_sl0, cu, cup, Jleak_c, J_cansr, GpCa_Km, nao_ko_ks;
     double b_trpn, b_cmdn, b_bsl, b_bsr, b_csqn;
     double nk_iKnai0, nk_nao_iKnao0, nk_cb3eP, half8, r_bt, r_btp;
+    double e_er, e_sd;  // exp((EKshift + 70)/20), exp(-(vShift + 6)/20)
+    double gate_bound, ito_bound;  // upper bounds of the rates of the gates whose time constant has a floor (see gate_b)
   };
   BEAT_HD static Derived derive(const double* p) {
     Derived q;
@@ -387,6 +389,19 @@ struct TorordGrl1T {
     }
     q.r_bt = 1.0 / p[bt_];
     q.r_btp = 1.0 / q.btp;
+    q.e_er = exp((p[EKshift_] + 70.0) * (1.0 / 20.0));
+    q.e_sd = exp(-0.05 * (p[vShift_] + 6.0));
+    {
+      // d: 1/td <= 1/td0; ff, fcaf: 1/7; fs, fcas, xs1: smaller; jca: 1/tjca; hL, hLp: 1/thL; nca: km2n = jca <= 1
+      double b = 1.0;
+      b = fmax(b, q.td0 > 0.0 ? 1.0 / q.td0 : 1.0e300);
+      b = fmax(b, fabs(q.r_tjca));
+      b = fmax(b, fabs(q.r_thL));
+      q.gate_bound = b;
+      // iF, iS: 1/(delta_epi (4.562 + ..)), delta_epi >= 0.05 for epi cells, 1 otherwise; iFp, iSp: times
+      // 1/(dti_develop dti_recover) <= 1/(1.354 * 0.5)
+      q.ito_bound = (1.0 / (1.354 * 0.5)) / (4.562 * (epi ? 0.05 : 1.0));
+    }
     if constexpr (LAND) {  // .ode:682-717, parameter-only
       const double lam12 = p[lmbda_] < 1.2 ? p[lmbda_] : 1.2;
       const double rw = p[rw_], rs = p[rs_];
@@ -433,6 +448,27 @@ struct TorordGrl1T {
     if (BEAT_GRL1_PHI > 1 && fabs(z) <= PHI_WINDOW) return fma(inf - y, -z * phi_small(z), y);  // (measured: no gain for gates)
     return y + (inf - y) * (1.0 - fm.exp(fmax(z, -746.0)));  // rates reach 1e21/ms at +350 mV: see FastMath::exp
   }
+  // The same update for a gate whose rate has an upper bound B known per parameter set (a time constant c + 1/s has the
+  // floor c): when dt B <= 1/32 -- `small`, uniform over the launch, so the branch is a scalar one -- 1 - exp(z), z = -dt rate,
+  // is -z phi(z) by the Taylor polynomial of degree 7 (first omitted term z^8/9! < 3e-18): 7 fma in place of the exp().
+  static constexpr double GATE_WINDOW = 1.0 / 32.0;
+  BEAT_DV static double phi7(double z) {
+    double ph = fma(z, 1.0 / 40320.0, 1.0 / 5040.0);
+    ph = fma(z, ph, 1.0 / 720.0);
+    ph = fma(z, ph, 1.0 / 120.0);
+    ph = fma(z, ph, 1.0 / 24.0);
+    ph = fma(z, ph, 1.0 / 6.0);
+    ph = fma(z, ph, 0.5);
+    return fma(z, ph, 1.0);
+  }
+  template <class FM>
+  BEAT_DV static double gate_b(const FM& fm, double y, double inf, double rate, double dt, bool small) {
+    if (small) {
+      const double z = -dt * rate;
+      return fma(inf - y, -z * phi7(z), y);
+    }
+    return gate(fm, y, inf, rate, dt);
+  }
   template <class FM>
   BEAT_DV static double advance(const FM& fm, double y, double f, double J, double dt) {
     const double z = J * dt;
@@ -459,6 +495,10 @@ struct TorordGrl1T {
     const double vg = beat_guard(v);
     const double vfrt = vg * q.FRT, vffrt = vg * q.FFRT;
     const double e1 = fm.exp(vfrt), e2 = e1 * e1;
+    // Exponentials of the potential with slope 1/20, 1/10 and 1/5 mV (INa, Ito, ICaL, IKs: seven of them) are E20 = exp(v/20)
+    // times or squared times a constant.
+    const double E20 = fm.exp(0.05 * v), E10 = E20 * E20;
+    const bool small_g = BEAT_GRL1_PHI && dt * q.gate_bound <= GATE_WINDOW, small_i = BEAT_GRL1_PHI && dt * q.ito_bound <= GATE_WINDOW;
 
     // running sums: total current seen by the state and its derivative w.r.t. the state
     double Iv = 0.0, dIv = 0.0;
@@ -645,7 +685,7 @@ struct TorordGrl1T {
       if (v > -40.0) {
         const double ea = fm.exp(0.0900900900900901 * v);
         double r1, r2;
-        rcp2(0.13 * ea + 0.0497581410839387, 1.0 * fm.exp(0.1 * v) + 0.0407622039783662, r1, r2);
+        rcp2(0.13 * ea + 0.0497581410839387, E10 + 0.0407622039783662, r1, r2);
         rate_h = 0.77 * ea * r1;
         rate_j = 0.6 * fm.exp(0.157 * v) * r2;
       } else {
@@ -684,8 +724,8 @@ struct TorordGrl1T {
       double mLss, hLss, hLpss;
       rcp3(fm.exp(-(v + 42.85) * (1.0 / 5.264)) + 1.0, ehL + 1.0, ehL * 2.288717124596482 + 1.0, mLss, hLss, hLpss);  // exp(6.2/7.488)
       io.store(S_mL, gate(fm, mL, mLss, tm_rate, dt));
-      io.store(S_hL, gate(fm, hL, hLss, q.r_thL, dt));
-      io.store(S_hLp, gate(fm, hLp, hLpss, q.r_3thL, dt));
+      io.store(S_hL, gate_b(fm, hL, hLss, q.r_thL, dt, small_g));
+      io.store(S_hLp, gate_b(fm, hLp, hLpss, q.r_3thL, dt, small_g));
     }
     BEAT_TFENCE();
 
@@ -717,8 +757,9 @@ struct TorordGrl1T {
       }
       BEAT_TFENCE();
       const double iss_den = fm.exp((ve + 43.94) * (1.0 / 5.711)) + 1.0;
+      const double er = E20 * q.e_er;  // exp((ve + 70)/20), ve = v + EKshift
       double delta_epi = 1.0;
-      if (q.is_epi != 0.0) delta_epi = 1.0 - 0.95 * beat_rcp(fm.exp((ve + 70.0) * (1.0 / 5.0)) + 1.0);
+      if (q.is_epi != 0.0) delta_epi = 1.0 - 0.95 * beat_rcp((er * er) * (er * er) + 1.0);  // exp((ve + 70)/5)
       // tiF = delta_epi (4.562 + 1/sF): 1/tiF = sF / (delta_epi (4.562 sF + 1)); tiS likewise
       const double sF = 0.3933 * fm.exp(-(ve + 100.0) * (1.0 / 100.0)) + 0.08004 * fm.exp((ve + 50.0) * (1.0 / 16.59));
       BEAT_TFENCE();
@@ -731,7 +772,6 @@ struct TorordGrl1T {
       const double xdev = fmin(-(ve - 12.23) * (1.0 / 0.2154), 700.0);  // exp() of it overflows below -138 mV
       const double dti_develop = 1.354 + 0.0001 * beat_rcp(fm.exp(xdev) + fm.exp((ve - 167.4) * (1.0 / 15.89)));  // (up to 1e304: alone)
       // dti_recover = 1 - 0.5/(er + 1) = (er + 0.5)/(er + 1): 1/(develop recover) with one reciprocal
-      const double er = fm.exp((ve + 70.0) * (1.0 / 20.0));
       BEAT_TFENCE();
       const double rdd = (er + 1.0) * beat_rcp(dti_develop * (er + 0.5));
       pf_d = io.load(S_d), pf_ff = io.load(S_ff_), pf_fs = io.load(S_fs), pf_fcaf = io.load(S_fcaf), pf_fcas = io.load(S_fcas);
@@ -740,11 +780,11 @@ struct TorordGrl1T {
       io.store(S_a, gate(fm, a, ass, ta_rate, dt));
       io.store(S_ap, gate(fm, ap, assp, ta_rate, dt));
       BEAT_TFENCE();
-      io.store(S_iF, gate(fm, iF, iss, rtiF, dt));
-      io.store(S_iFp, gate(fm, iFp, iss, rtiF * rdd, dt));
+      io.store(S_iF, gate_b(fm, iF, iss, rtiF, dt, small_i));
+      io.store(S_iFp, gate_b(fm, iFp, iss, rtiF * rdd, dt, small_i));
       BEAT_TFENCE();
-      io.store(S_iS, gate(fm, iS, iss, rtiS, dt));
-      io.store(S_iSp, gate(fm, iSp, iss, rtiS * rdd, dt));
+      io.store(S_iS, gate_b(fm, iS, iss, rtiS, dt, small_i));
+      io.store(S_iSp, gate_b(fm, iSp, iss, rtiS * rdd, dt, small_i));
     }
     BEAT_TFENCE();
 
@@ -754,7 +794,7 @@ struct TorordGrl1T {
     {
       const double d = pf_d, ff = pf_ff, fs = pf_fs, fcaf = pf_fcaf, fcas = pf_fcas, jca = pf_jca, ffp = pf_ffp, fcafp = pf_fcafp;
       const double nca_i = pf_nca_i, nca_ss = pf_nca_ss;
-      const double sA = beat_rcp(fm.exp((v - 10.0) * (1.0 / 10.0)) + 1.0);
+      const double sA = beat_rcp(E10 * 0.36787944117144233 + 1.0);  // exp((v - 10)/10) = exp(v/10) exp(-1)
       const double Afcaf = 0.3 + 0.6 * sA, dAfcaf = -0.06 * sA * (1.0 - sA);
       const double Afs = q.Afs;
       const double f = p[Aff_] * ff + Afs * fs, fpx = p[Aff_] * ffp + Afs * fs;
@@ -779,23 +819,25 @@ struct TorordGrl1T {
       // denominators of the block share two v_rcp_f64.
       const double dss = (v >= 31.4978) ? 1.0 : 1.0763 * fm.exp(-1.007 * fm.exp(-0.0829 * v));
       const double vs = v + p[vShift_];
-      const double sd = fm.exp(-0.05 * (vs + 6.0)) + fm.exp(0.09 * (vs + 14.0));          // td = td0 + 1/sd
+      // td = td0 + 1/sd, sd = exp(-(vs + 6)/20) + exp(0.09 (vs + 14)) = Wd / E20, Wd = exp(-(vShift + 6)/20) + exp(0.09 (vs + 14)) E20:
+      // 1/td = Wd / (td0 Wd + E20)
+      const double Wd = q.e_sd + fm.exp(0.09 * (vs + 14.0)) * E20;
       BEAT_TFENCE();
       const double fss_den = fm.exp((v + 19.58) * (1.0 / 3.696)) + 1.0;
-      const double e20 = fm.exp((v + 20.0) * (1.0 / 10.0));
+      const double e20 = E10 * 7.38905609893065;  // exp((v + 20)/10) = exp(v/10) exp(2)
       const double w20 = 0.0045 * (1.0 + e20 * e20);                                       // tff = 7 + e20 / w20
       BEAT_TFENCE();
       const double sfs = 3.5e-5 * fm.exp(-(v + 5.0) * (1.0 / 4.0)) + 3.5e-5 * fm.exp((v + 5.0) * (1.0 / 6.0));  // tfs = 1000 + 1/sfs
       double rtd, fss, rtff, rtfs;
-      rcp4(q.td0 * sd + 1.0, fss_den, 7.0 * w20 + e20, 1000.0 * sfs + 1.0, rtd, fss, rtff, rtfs);
-      rtd *= sd;
+      rcp4(q.td0 * Wd + E20, fss_den, 7.0 * w20 + e20, 1000.0 * sfs + 1.0, rtd, fss, rtff, rtfs);
+      rtd *= Wd;
       rtff *= w20;
       rtfs *= sfs;
       BEAT_TFENCE();
       const double e4 = fm.exp((v - 4.0) * (1.0 / 7.0));
       const double w4 = 0.04 * (1.0 + e4 * e4);                                            // tfcaf = 7 + e4 / w4
       BEAT_TFENCE();
-      const double sfcas = 0.00012 * fm.exp(-v * (1.0 / 3.0)) + 0.00012 * fm.exp(v * (1.0 / 7.0));  // tfcas = 100 + 1/sfcas
+      const double sfcas = 0.00012 * fm.exp(-v * (1.0 / 3.0)) + (0.00012 * 1.770794952435155) * e4;  // tfcas = 100 + 1/sfcas; exp(v/7) = e4 exp(4/7)
       const double jcass_den = fm.exp((v + 18.08) * (1.0 / 2.7916)) + 1.0;
       double rtfcaf, rtfcas, jcass;
       rcp3(7.0 * w4 + e4, 100.0 * sfcas + 1.0, jcass_den, rtfcaf, rtfcas, jcass);
@@ -803,17 +845,17 @@ struct TorordGrl1T {
       rtfcas *= sfcas;
       BEAT_TFENCE();
       pf_O = io.load(S_O_), pf_C1 = io.load(S_C1), pf_C2 = io.load(S_C2), pf_C3 = io.load(S_C3), pf_I = io.load(S_I_);
-      io.store(S_d, gate(fm, d, dss, rtd, dt));
-      io.store(S_ff_, gate(fm, ff, fss, rtff, dt));
+      io.store(S_d, gate_b(fm, d, dss, rtd, dt, small_g));
+      io.store(S_ff_, gate_b(fm, ff, fss, rtff, dt, small_g));
       BEAT_TFENCE();
-      io.store(S_ffp, gate(fm, ffp, fss, rtff * (1.0 / 2.5), dt));
-      io.store(S_fs, gate(fm, fs, fss, rtfs, dt));
+      io.store(S_ffp, gate_b(fm, ffp, fss, rtff * (1.0 / 2.5), dt, small_g));
+      io.store(S_fs, gate_b(fm, fs, fss, rtfs, dt, small_g));
       BEAT_TFENCE();
-      io.store(S_fcaf, gate(fm, fcaf, fss, rtfcaf, dt));
-      io.store(S_fcafp, gate(fm, fcafp, fss, rtfcaf * (1.0 / 2.5), dt));
+      io.store(S_fcaf, gate_b(fm, fcaf, fss, rtfcaf, dt, small_g));
+      io.store(S_fcafp, gate_b(fm, fcafp, fss, rtfcaf * (1.0 / 2.5), dt, small_g));
       BEAT_TFENCE();
-      io.store(S_fcas, gate(fm, fcas, fss, rtfcas, dt));
-      io.store(S_jca, gate(fm, jca, jcass, q.r_tjca, dt));
+      io.store(S_fcas, gate_b(fm, fcas, fss, rtfcas, dt, small_g));
+      io.store(S_jca, gate_b(fm, jca, jcass, q.r_tjca, dt, small_g));
       BEAT_TFENCE();
       // nca: f = anca k2n - km2n nca, km2n = jca, anca = 1/(k2n/km2n + (Kmn/ca + 1)^4) = jca / (k2n + jca (Kmn/ca + 1)^4): J = -jca
       {
@@ -822,9 +864,16 @@ struct TorordGrl1T {
         rcp2(p[k2n_] + jca * ((xi * xi) * (xi * xi)), p[k2n_] + jca * ((xs * xs) * (xs * xs)), anca_i, anca_ss);
         anca_i *= jca;
         anca_ss *= jca;
-        const double em1 = fm.exp(fmax(-jca * dt, -746.0)) - 1.0;
-        io.store(S_nca_i, grl1(nca_i, anca_i * p[k2n_] - jca * nca_i, -jca, em1, dt));
-        io.store(S_nca_ss, grl1(nca_ss, anca_ss * p[k2n_] - jca * nca_ss, -jca, em1, dt));
+        const double f_i = anca_i * p[k2n_] - jca * nca_i, f_ss = anca_ss * p[k2n_] - jca * nca_ss;
+        if (small_g) {  // the increment f (exp(J dt) - 1)/J as f dt phi(J dt), J = -jca (a gate: <= 1)
+          const double dph = dt * phi7(-jca * dt);
+          io.store(S_nca_i, fma(f_i, dph, nca_i));
+          io.store(S_nca_ss, fma(f_ss, dph, nca_ss));
+        } else {
+          const double em1 = fm.exp(fmax(-jca * dt, -746.0)) - 1.0;
+          io.store(S_nca_i, grl1(nca_i, f_i, -jca, em1, dt));
+          io.store(S_nca_ss, grl1(nca_ss, f_ss, -jca, em1, dt));
+        }
       }
     }
     BEAT_TFENCE();
@@ -1011,13 +1060,13 @@ struct TorordGrl1T {
       dIki += gKs * (q.RTFk * rks);
       BEAT_PIN(Iv); BEAT_PIN(dIv); BEAT_PIN(Iki); BEAT_PIN(dIki);
       BEAT_TFENCE();
-      const double rtxs2 = 0.01 * fm.exp((v - 50.0) * (1.0 / 20.0)) + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
+      const double rtxs2 = (0.01 * 0.0820849986238988) * E20 + 0.0193 * fm.exp(-(v + 66.54) * (1.0 / 31.0));
       pf_cajsr = io.load(S_cajsr), pf_cansr = io.load(S_cansr), pf_Jrel_np = io.load(S_Jrel_np), pf_Jrel_p = io.load(S_Jrel_p);
       if constexpr (LAND) {
         pf_XS = io.load(S_XS), pf_XW = io.load(S_XW), pf_CaTrpn = io.load(S_CaTrpn), pf_TmB = io.load(S_TmB);
         pf_Zetas = io.load(S_Zetas), pf_Zetaw = io.load(S_Zetaw), pf_Cd = io.load(S_Cd);
       }
-      io.store(S_xs1, gate(fm, xs1, xsss, rtxs1, dt));
+      io.store(S_xs1, gate_b(fm, xs1, xsss, rtxs1, dt, small_g));
       io.store(S_xs2, gate(fm, xs2, xsss, rtxs2, dt));
     }
     BEAT_TFENCE();

@@ -126,3 +126,39 @@ def test_land_instance_matches_the_numpy_oracle(host_step_land):
         yo = torord.torord_land_generalized_rush_larsen(yo, i * 0.01, 0.01, P1)
     assert yo[torord.TORORD_LAND_STATES.index("v"), 0] > 0.0
     assert _err(y, yo, g["state_defaults"]).max() < 1e-9
+
+
+def _perturbed_parameters(P0, names, n, seed):
+    """Every parameter moved per node: non-zero ones scaled by 0.9 .. 1.1, the voltage shifts and offsets that default to
+    zero (EKshift, vShift, offset) set to a few mV / ms; switches (celltype, mode, isacs) and the stimulus protocol cycled."""
+    rng = np.random.default_rng(seed)
+    P = np.repeat(P0[:, None], n, axis=1) * rng.uniform(0.9, 1.1, (len(P0), n))
+    for name, lo, hi in (("EKshift", -4.0, 4.0), ("vShift", -3.0, 3.0), ("offset", 0.0, 0.5)):
+        P[names.index(name)] = rng.uniform(lo, hi, n)
+    for name in ("celltype", "mode", "isacs"):
+        if name in names:
+            P[names.index(name)] = P0[names.index(name)]
+    P[names.index("celltype")] = np.arange(n) % 3
+    for name in ("i_Stim_Start", "i_Stim_End", "i_Stim_Period", "i_Stim_PulseDuration"):
+        P[names.index(name)] = P0[names.index(name)]
+    return P
+
+
+def test_every_parameter_reaches_the_step_as_the_specification_has_it(host_step, host_step_land):
+    """The kernel forms products, quotients and reciprocals of parameters once per parameter set (Derived) and shares
+    exponentials whose arguments differ by a parameter-dependent constant (exp((v + EKshift + 70)/20) = exp(v/20) *
+    const): with ALL parameters perturbed per node -- the shifts that default to zero included -- one step from the
+    action-potential samples still equals the NumPy oracle, which evaluates the specification literally."""
+    g = np.load(GOLD / "torord_spec.npz")
+    S = g["traj_states"]
+    n = S.shape[1]
+    P = _perturbed_parameters(torord.torord_init_parameter_values(), list(torord.TORORD_PARAMETERS), n, 5)
+    out = host_step(S, P, 0.4, 0.01)
+    ref = torord.torord_generalized_rush_larsen(S, 0.4, 0.01, P)
+    assert _err(out, ref, g["state_defaults"]).max() < 1e-10
+    gl = np.load(GOLD / "torord_land_spec.npz")
+    Sl = gl["traj_states"]
+    Pl = _perturbed_parameters(torord.torord_land_init_parameter_values(), list(torord.TORORD_LAND_PARAMETERS), Sl.shape[1], 6)
+    outl = host_step_land(Sl, Pl, 0.4, 0.01)
+    refl = torord.torord_land_generalized_rush_larsen(Sl, 0.4, 0.01, Pl)
+    assert _err(outl, refl, gl["state_defaults"]).max() < 1e-10

@@ -24,9 +24,20 @@ for f in glob.glob('gpurun_out/prof_ode2/*counter_collection.csv'):
         n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
         if n.startswith('ode_step_kernel'):
             agg[n][r['Counter_Name']].append(float(r['Counter_Value']))
+dur = collections.defaultdict(list)
+for f in glob.glob('gpurun_out/prof_ode2/*kernel_trace.csv'):
+    for r in csv.DictReader(open(f)):
+        n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        if n.startswith('ode_step_kernel'):
+            dur[n].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
 for k, c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     print(k)
+    if dur[k]:
+        ms = sorted(dur[k])[len(dur[k]) // 2]
+        print('   median duration under the counters %.3f ms' % ms)
+        if 'GRBM_GUI_ACTIVE' in m:
+            print('   clock %.2f GHz' % (m['GRBM_GUI_ACTIVE'] / 8 / ms / 1e6))
     for n in sorted(m):
         print('   %-28s %.4g' % (n, m[n]))
     if 'GRBM_GUI_ACTIVE' in m:
