@@ -37,6 +37,7 @@ static inline double __hiloint2double(int hi, int lo) {
   return x;
 }
 static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 #include "../fenicsx-beat_amd/csrc/ionic_models.h"
 
