@@ -7,6 +7,7 @@ goes through ``libbeat_hip.so``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -124,6 +125,14 @@ class StateArray:
         self.plane = int(plane)
         ld = self.n + 2 * self.plane
         self.ld = (ld + 31) // 32 * 32  # 256-byte aligned rows
+        # Rows a multiple of 4 KiB apart (512^3 + 2 * 512^2 doubles are 2^30 + 2^22 bytes) put node i of EVERY row on the
+        # same memory channels: the ionic kernel's 19 .. 52 row streams then queue on a few channels at a time.  17 * 256 B
+        # of padding per row spreads them: the kernel's memory traffic alone (probe build, 256^3) 4.5 -> 5.1 TB/s for 45
+        # rows, 4.8 -> 5.3 for 19 (profiles/r03_ode_probes.md).  BEAT_STATE_SKEW=<doubles> overrides (0: none).
+        skew = os.environ.get("BEAT_STATE_SKEW", "auto")
+        if skew == "auto":
+            skew = 544 if (self.ld * 8) % 4096 == 0 and self.n >= 65536 else 0
+        self.ld += int(skew) // 32 * 32
         self.base = self.plane  # leading ghost plane of row 0
         self.buf = ctx.zeros(self.base + self.S * self.ld + 32)
         self.rows = self.buf[self.base : self.base + self.S * self.ld].view(self.S, self.ld)[:, : self.n]

@@ -231,6 +231,15 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       for (int k = 0; k < Model::NS; ++k) tmp[k] = io.load(k);
 #pragma unroll
       for (int k = 0; k < Model::NS; ++k) io.store(k, tmp[k] * 1.0000000001);
+#elif BEAT_ODE_PROBE == 3
+      // probe build (-DBEAT_ODE_PROBE=3): the traffic of probe 1 with the array addressed tile-major -- the NS rows of a
+      // tile's 256 nodes next to each other (NS * 2 KB contiguous per tile) instead of NS streams ld apart
+      double tmp[Model::NS];
+      double* tb = states + tile * (int64_t)(Model::NS * BEAT_BLOCK) + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tmp[k] = tb[k * BEAT_BLOCK];
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tb[k * BEAT_BLOCK] = tmp[k] * 1.0000000001;
 #elif BEAT_ODE_PROBE == 2
       // probe build (-DBEAT_ODE_PROBE=2): the kernel's arithmetic alone -- states of the block's first tile (cache hits),
       // stores behind a condition that never holds

@@ -263,6 +263,14 @@ __device__ __forceinline__ double beat_rsqrt(double x) {
   return fma(r * fma(e, 0.375, 0.5), e, r);
 }
 
+// a double constant through a scalar register pair (see torord_dyncl.h: phi_small)
+__device__ __forceinline__ double beat_sconst(double c) {
+#ifdef __AMDGCN__  // (tests/tp06_host_harness.cpp builds this header with g++)
+  asm volatile("" : "+s"(c));
+#endif
+  return c;
+}
+
 struct FastMath {
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
   const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab
@@ -287,9 +295,12 @@ struct FastMath {
     r = fma(k, -6.327543041662719e-14, r);                              // low part
     const int ki = __double2loint(kb);
     const double t = tab[ki & (BEAT_EXP_TAB - 1)];
-    double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-    p = fma(r, p, 0.5);
-    p = fma(r * r, p, r);                                               // exp(r) - 1
+    // exp(r) - 1 = r + r^2 (1/2 + r/6 + r^2/24), every fma with at most ONE constant that is not an inline one (an fma
+    // with two takes the second from VGPRs: two v_mov_b32 per use)
+    const double r2 = r * r;
+    double p = fma(r, beat_sconst(1.0 / 6.0), 0.5);
+    p = fma(r2, beat_sconst(1.0 / 24.0), p);
+    p = fma(r2, p, r);
     return ldexp(fma(t, p, t), ki >> 8);
   }
 };

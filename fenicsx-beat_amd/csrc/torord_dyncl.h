@@ -35,6 +35,7 @@
 // and a block whose results merely flow into sums that are consumed at the very end (the pumps, the GHK fluxes) would
 // otherwise be emitted down there, where everything else is live too.
 #define BEAT_PIN(x) asm volatile("" : "+v"(x))
+#define BEAT_SCONST(c) beat_sconst(c)
 #endif
 
 #if defined(__clang__) && !defined(BEAT_TORORD_NO_CONTRACT)
@@ -431,13 +432,16 @@ struct TorordGrl1T {
 #define BEAT_GRL1_PHI 1  // 0: the general form for every lane (A/B builds)
 #endif
   static constexpr double PHI_WINDOW = 0.0625;
+  // (BEAT_SCONST: the coefficient through a scalar register.  A 64-bit literal cannot be an operand; left alone the
+  // compiler materialises each one in a VGPR pair -- two v_mov_b32 ahead of every fma of the Horner scheme, three VALU
+  // instructions per step instead of one.  Opaque in an SGPR pair it costs two s_mov on the scalar unit.)
   BEAT_DV static double phi_small(double z) {
-    double ph = fma(z, 1.0 / 362880.0, 1.0 / 40320.0);
-    ph = fma(z, ph, 1.0 / 5040.0);
-    ph = fma(z, ph, 1.0 / 720.0);
-    ph = fma(z, ph, 1.0 / 120.0);
-    ph = fma(z, ph, 1.0 / 24.0);
-    ph = fma(z, ph, 1.0 / 6.0);
+    double ph = z * BEAT_SCONST(1.0 / 362880.0) + BEAT_SCONST(1.0 / 40320.0);  // (two constants in one fma: one of them in VGPRs)
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 5040.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 720.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 120.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 24.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 6.0));
     ph = fma(z, ph, 0.5);
     return fma(z, ph, 1.0);
   }
@@ -453,11 +457,11 @@ struct TorordGrl1T {
   // is -z phi(z) by the Taylor polynomial of degree 7 (first omitted term z^8/9! < 3e-18): 7 fma in place of the exp().
   static constexpr double GATE_WINDOW = 1.0 / 32.0;
   BEAT_DV static double phi7(double z) {
-    double ph = fma(z, 1.0 / 40320.0, 1.0 / 5040.0);
-    ph = fma(z, ph, 1.0 / 720.0);
-    ph = fma(z, ph, 1.0 / 120.0);
-    ph = fma(z, ph, 1.0 / 24.0);
-    ph = fma(z, ph, 1.0 / 6.0);
+    double ph = z * BEAT_SCONST(1.0 / 40320.0) + BEAT_SCONST(1.0 / 5040.0);
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 720.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 120.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 24.0));
+    ph = fma(z, ph, BEAT_SCONST(1.0 / 6.0));
     ph = fma(z, ph, 0.5);
     return fma(z, ph, 1.0);
   }

@@ -12,6 +12,7 @@
 #define BEAT_DV inline
 #define BEAT_TFENCE() ((void)0)
 #define BEAT_PIN(x) ((void)0)
+#define BEAT_SCONST(c) (c)
 static inline double beat_rcp(double x) { return 1.0 / x; }
 static inline double beat_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 static inline double beat_guard(double v) { return std::fabs(v) < 1.0e-4 ? std::copysign(1.0e-4, v) : v; }
