@@ -57,6 +57,12 @@ struct VarArgs {
 // by tiles of 8 rows x 8 planes (all x segments of a row together), XCD x (blocks b with b % 8 == x) walks the x-th eighth
 // of it front to back, so that the ~640 entries an XCD has in flight are one or two tiles: the rows of p around a node and
 // the neighbours' forward coefficients it reads as its backward ones are lines that XCD's L2 has just fetched.
+// The wave's index in its block as a SCALAR: everything derived from it -- the list entry w, seg[w], segmask[w] -- is
+// then wave-uniform for the compiler too and read with scalar loads.  Derived from threadIdx.x alone those two reads were
+// vector loads, each followed by s_waitcnt vmcnt(0): two more dependent trips to memory per segment ahead of the
+// coefficients and the rows of p, and a wait that any load issued earlier had to share.
+__device__ __forceinline__ int var_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / VAR_SEG)); }
+
 struct VarWalk {
   int64_t w, end, stride;
 };
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_stencil_kernel(VarArgs a) {
   // Work items: the wavefront-sized segments that hold at least one tissue node (list built at create time); segments
   // entirely outside the tissue are never read or written (their r, p, q stay zero, x keeps its value).
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
-  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  const int wave = var_wave(), lane = threadIdx.x % VAR_SEG;
   const VarWalk walk = var_walk(a, nwork, wave);
   for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
     const int64_t i = (a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG) + lane;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
   constexpr int kMinus[7] = {2, -1, 8, -1, 12, -1, 14};
   double acc0 = 0.0;
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
-  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  const int wave = var_wave(), lane = threadIdx.x % VAR_SEG;
   const VarWalk walk = var_walk(a, nwork, wave);
   for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
     const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
@@ -289,13 +295,22 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
                                         : e == 3 ? bp[5] >> 63 : e == 4 ? bm[0] : e == 5 ? bm[2] : e == 6 ? bm[4] : bm[6];
       if (lane < 8 && (wanted & 1ull)) edge = a.x[seg0 + (plus ? VAR_SEG : -1) + off];
     }
-    double xk[15];
+    // all seven rows of p requested before the first of them is used: written as one loop -- load a row, shift it across
+    // the wave, load the next -- every load sat in its own predicated block behind the shuffles of the row before it and
+    // was waited for (s_waitcnt vmcnt(0)) before the next one was issued: seven trips to memory in a row per segment
+    double xk[15], Xr[7];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
       const int kb = kBase[r];
       const bool own = kb == 0 ? active : c[kb] != 0.0;
       const unsigned long long wanted = (bp[r] << 1) | (bm[r] >> 1);  // lane l-1 wants its +1, lane l+1 its -1 tap
-      const double X = (own || ((wanted >> lane) & 1ull)) ? a.x[i + a.doff[kb]] : 0.0;
+      Xr[r] = (own || ((wanted >> lane) & 1ull)) ? a.x[i + a.doff[kb]] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int kb = kBase[r];
+      const bool own = kb == 0 ? active : c[kb] != 0.0;
+      const double X = Xr[r];
       xk[kb] = own ? X : 0.0;
       if (kPlus[r] >= 0) {
         const int kp = kPlus[r] >= 0 ? kPlus[r] : 0;
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a) {
   __shared__ double red[4];
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
-  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  const int wave = var_wave(), lane = threadIdx.x % VAR_SEG;
   const int edge_off = var_edge_offset(lane, a.doff);
   const VarWalk walk = var_walk(a, nwork, wave);
   for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_update_r_kernel(const int* __r
   const double alpha = st[RZ] / st[PQ];
   if (blockIdx.x == 0 && threadIdx.x == 0) alphas[slot] = alpha;
   double s_rz = 0.0, s_rr = 0.0;
-  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + var_wave(); w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     const double ri = fma(-alpha, q[i], r[i]);
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_pupdate_oop_kernel(const int* 
                                                                      const double* __restrict__ dinv) {
   if (st[STOP] != 0.0) return;
   const double beta = st[BETA];
-  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + var_wave(); w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     p_new[i] = fma(beta, p_old[i], dinv[i] * r[i]);
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
   double a[PRING];
 #pragma unroll
   for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
-  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + threadIdx.x / VAR_SEG; w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
+  for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + var_wave(); w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
     if (gt.d != nullptr) {  // inc = e + sum alpha_j P_j;  x += inc;  (d, e) updated  (see x_flush_kernel)
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
 __global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n, const double* __restrict__ mass_diag,
                                                                        unsigned long long* __restrict__ flags) {
   const int64_t nsegs = (n + VAR_SEG - 1) / VAR_SEG;
-  const int wave = threadIdx.x / VAR_SEG, lane = threadIdx.x % VAR_SEG;
+  const int wave = var_wave(), lane = threadIdx.x % VAR_SEG;
   for (int64_t s = (int64_t)blockIdx.x * VAR_SEGS_PER_BLOCK + wave; s < nsegs; s += (int64_t)gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = s * VAR_SEG + lane;
     const bool mine = i < n && mass_diag[i] != 0.0;
@@ -632,10 +647,15 @@ struct VarRange {
   unsigned grid;
   int tiled;
 };
-static int var_tile_edge() {  // BEAT_VAR_TILE = rows and planes per tile of the tile-ordered list (0: node order everywhere)
+// BEAT_VAR_TILE = rows and planes per tile of the tile-ordered list (0: node order everywhere).  On since the kernels
+// stopped serialising their loads (round 3): either change alone bought 0 - 2 % on the 17 M-node shell, both together 5 %
+// of the step (tools/bench_biv.py --n 400: 13.2 -> 12.6 ms) -- the trips to memory and the L2 misses bounded the SpMV at
+// the same level.  (A software pipeline over the list -- the next entry's coefficients requested behind the current
+// entry's rows of p -- on top of both: 12.09 against 12.11 ms, not kept.)
+static int var_tile_edge() {
   static const int t = [] {
     const char* e = getenv("BEAT_VAR_TILE");
-    return e != nullptr ? std::max(0, atoi(e)) : 0;
+    return e != nullptr ? std::max(0, atoi(e)) : 8;
   }();
   return t;
 }

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O -o sq --output-format csv -- python3 $R/tools/bench_voxel.py --n 400 --reps 4 > $O/sq.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $O -o tcc --output-format csv -- python3 $R/tools/bench_voxel.py --n 400 --reps 4 > $O/tcc.log 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O -o sq2 --output-format csv -- python3 $R/tools/bench_voxel.py --n 400 --reps 4 > $O/sq2.log 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace -d $O -o sq3 --output-format csv -- python3 $R/tools/bench_voxel.py --n 400 --reps 4 > $O/sq3.log 2>&1 || true
 cd $R
 python3 - <<'PY'
 import csv, collections, glob

@@ -1,6 +1,6 @@
 #!/bin/bash
 # L2 hit / miss counts and time of the per-node SpMV on the 401^3 shell for several tile sizes of the tile-ordered
-# segment list (BEAT_VAR_TILE; 0 = node order, the default)
+# segment list (BEAT_VAR_TILE; 0 = node order; default 8 since round 3)
 R=$PWD
 O=$R/gpurun_out/prof_spmv_tiles
 rm -rf $O && mkdir -p $O
