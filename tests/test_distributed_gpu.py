@@ -770,3 +770,55 @@ def test_non_convergence_is_reported_not_raised(hip_ctx):
         assert np.isfinite(x2).all() and not np.array_equal(x2, v)
         res = solver.solve(fv, [], [], fx, rtol=1e-11, atol=1e-50, max_it=200)
         assert res.converged_reason > 0
+
+
+def test_ipc_communicator_set_up_errors_are_reported(hip_ctx):
+    """The two-step set-up of the ipc transport through the C ABI (include/beat_hip.h): a communicator that sums through the
+    mailboxes refuses to reduce before beat_comm_ipc_connect_all has been called; connect_all wants one handle per rank, each
+    from the rank at its position; connecting twice, an all-reduce of more than four values and both RCCL id and callback
+    at creation are errors -- reported through beat_last_error, nothing left half-built."""
+    import ctypes as C
+
+    import torch
+
+    from beat import _hip
+
+    ctx = hip_ctx
+    lib = ctx.lib
+    plane = 64
+    mine = C.create_string_buffer(_hip.IPC_HANDLE_BYTES)
+    h = C.c_void_p()
+    _hip.check(lib.beat_comm_create_ipc(ctx.handle, 0, 1, 0, 0, plane, None, None, None, mine, C.byref(h)))
+    try:
+        t = torch.ones(3, dtype=torch.float64, device=ctx.device)
+        with pytest.raises(RuntimeError, match="connect_all"):
+            _hip.check(lib.beat_comm_allreduce_sum(h, C.c_void_p(t.data_ptr()), 3))
+        with pytest.raises(RuntimeError, match="handles for 1 ranks"):
+            _hip.check(lib.beat_comm_ipc_connect_all(h, mine.raw + mine.raw, 2))
+        _hip.check(lib.beat_comm_ipc_connect_all(h, mine.raw, 1))
+        with pytest.raises(RuntimeError, match="already connected"):
+            _hip.check(lib.beat_comm_ipc_connect_all(h, mine.raw, 1))
+        with pytest.raises(RuntimeError, match="already connected"):
+            _hip.check(lib.beat_comm_ipc_connect(h, None, None))
+        _hip.check(lib.beat_comm_allreduce_sum(h, C.c_void_p(t.data_ptr()), 3))
+        ctx.synchronize()
+        assert t.cpu().tolist() == [1.0, 1.0, 1.0]  # a world of one rank
+        five = torch.ones(5, dtype=torch.float64, device=ctx.device)
+        with pytest.raises(RuntimeError, match=r"1\.\.4 values"):
+            _hip.check(lib.beat_comm_allreduce_sum(h, C.c_void_p(five.data_ptr()), 5))
+    finally:
+        _hip.check(lib.beat_comm_destroy(h))
+    # a handle that is not the rank's own at its position
+    other = C.create_string_buffer(_hip.IPC_HANDLE_BYTES)
+    h2 = C.c_void_p()
+    _hip.check(lib.beat_comm_create_ipc(ctx.handle, 1, 2, 0, -1, plane, None, None, None, other, C.byref(h2)))
+    try:
+        with pytest.raises(RuntimeError, match="not rank 0's ipc handle"):
+            _hip.check(lib.beat_comm_ipc_connect_all(h2, other.raw + other.raw, 2))
+    finally:
+        _hip.check(lib.beat_comm_destroy(h2))
+    ids = C.create_string_buffer(2 * _hip.UNIQUE_ID_BYTES)
+    cb = _hip.ALLREDUCE_FN(lambda user, values, count: 0)
+    h3 = C.c_void_p()
+    with pytest.raises(RuntimeError, match="at most one of"):
+        _hip.check(lib.beat_comm_create_ipc(ctx.handle, 0, 1, -1, -1, plane, ids, C.cast(cb, C.c_void_p), None, mine, C.byref(h3)))
