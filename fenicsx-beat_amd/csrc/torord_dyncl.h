@@ -20,6 +20,13 @@
 //  * exponentials with a common slope share one exp(); the total derivatives through the Debye-Hueckel activity
 //    coefficients and through the CaMK-dependent phosphorylation fraction are kept where a state sees them
 //    (cai, nai, ki, cass, nass, kss), as the reference's fully resolved self-derivative has them.
+//  * (round 3, profiles/r03_ode_probes.md: 4631 -> 3707 executed VALU instructions per node) there is no scalar fp64 unit,
+//    so EVERY product, quotient and reciprocal of parameters alone lives in Derived; reciprocals are batched (one
+//    v_rcp_f64 for two to four of them), a rate 1/(c + 1/s) is formed as s/(c s + 1), 1/exp(x) as exp(-x); exponentials
+//    of slope 1/20, 1/10, 1/5 mV come from one exp(v/20); the GRL1 increment f (exp(J dt) - 1)/J of a non-gate state is
+//    f dt phi(J dt) with phi by its Taylor polynomial when |J dt| <= 1/16 (per lane), and a gate whose time constant has
+//    a floor takes the polynomial behind a uniform branch on dt * bound; a * b + c is contracted to fma inside this header
+//    (the pragma below; the library as a whole is compiled with contraction off).
 // Compiles for the host too (tests/test_torord_host.py builds it with g++ against the golden fixture): everything it
 // needs from the device side comes through BEAT_HD / the FM template parameter / beat_rcp / beat_guard / BEAT_TFENCE.
 #pragma once
