@@ -2,6 +2,7 @@
 reference's own modules and model specification by tests/golden/make_golden.py)."""
 
 import json
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -231,6 +232,38 @@ def test_torord_kernel_along_an_action_potential():
     err = np.abs(out - ref) / scale
     bad = np.argwhere(err > 1e-9)
     assert len(bad) == 0, [(g["state_names"][i], float(g["traj_times"][j]), float(err[i, j])) for i, j in bad[:12]]
+
+
+@pytest.mark.parametrize("model", ["torord", "torord_land"])
+def test_torord_update_forms_agree_across_their_switch_points(model):
+    """The ToR-ORd step takes the GRL1 increment of a non-gate state as f dt phi(J dt) by polynomial when |J dt| <= 1/16 (per
+    lane) and updates the gates whose rate has a bound B by polynomial when dt B <= 1/32 (one uniform branch; B = 1/0.6 for
+    the default parameters, i.e. dt <= 0.01875 ms), otherwise through exp() (csrc/torord_dyncl.h: advance, gate_b).  From
+    the action-potential samples, with every parameter perturbed per node, one step at time steps on both sides of the gate
+    switch and spanning the per-lane window (dt = 0.002 .. 0.2 ms) equals the NumPy oracle -- which knows only the
+    exp() form -- to 1e-9 of the state scale."""
+    from beat.models import torord, torord_land
+
+    from oracle import torord as otor
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_torord_host import _perturbed_parameters
+
+    if model == "torord":
+        m, g = torord, np.load(GOLD / "torord_spec.npz")
+        names, P0, ref_fn = list(otor.TORORD_PARAMETERS), otor.torord_init_parameter_values(), otor.torord_generalized_rush_larsen
+    else:
+        m, g = torord_land, np.load(GOLD / "torord_land_spec.npz")
+        names, P0 = list(otor.TORORD_LAND_PARAMETERS), otor.torord_land_init_parameter_values()
+        ref_fn = otor.torord_land_generalized_rush_larsen
+    S = g["traj_states"]
+    P = _perturbed_parameters(P0, names, S.shape[1], 9)
+    scale0 = 1e-6 * np.abs(g["state_defaults"])[:, None] + 1e-12
+    for dt in (0.002, 0.01, 0.0187, 0.0188, 0.05, 0.2):
+        out = m.generalized_rush_larsen(states=S, t=0.4, parameters=P, dt=dt)
+        ref = ref_fn(S, 0.4, dt, P)
+        err = np.abs(out - ref) / np.maximum(np.abs(ref), scale0)
+        assert err.max() < 1e-9, (dt, float(err.max()), g["state_names"][int(np.unravel_index(err.argmax(), err.shape)[0])])
 
 
 def test_torord_land_kernel_matches_the_ode_spec_golden_and_the_oracle():
