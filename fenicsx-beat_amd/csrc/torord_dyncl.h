@@ -1150,17 +1150,24 @@ struct TorordGrl1T {
       const double Jtr = (cansr - cajsr) * (1.0 / 60.0);
       double rq;  // 1/(cajsr + kmcsqn), for the cajsr equation below
       {
-        // 1/((cajsr_half/cajsr)^8 + 1) = cajsr^8/(cajsr_half^8 + cajsr^8);  tau_rel = max(bt/(1 + 0.0123/cajsr), 0.001):
-        // 1/tau_rel = min((cajsr + 0.0123)/(bt cajsr), 1000) -- one reciprocal for the block instead of six
-        const double c2 = cajsr * cajsr, c4 = c2 * c2, c8 = c4 * c4;
+        // 1/((cajsr_half/cajsr)^8 + 1) = cajsr^8/(cajsr_half^8 + cajsr^8);  tau_rel = max(bt/(1 + 0.0123/cajsr), 0.001),
+        // 1/(1 + 0.0123/cajsr) = 1/irc with irc = (cajsr + 0.0123)/cajsr:  1/tau_rel = min(irc/bt, 1000) where irc > 0 and
+        // 1000 where it is not (a load that has run NEGATIVE -- perturbed parameter sets do that for a while -- makes the
+        // specification's quotient negative, and its max() then returns the floor) -- one reciprocal for the block
+        // instead of six.  (A load of exactly zero gives finite values in the specification: kept away from the
+        // reciprocal.)
+        const double cj = fabs(cajsr) < 1.0e-150 ? 1.0e-150 : cajsr;
+        const double c2 = cj * cj, c4 = c2 * c2, c8 = c4 * c4;
         double rcajsr, rh;
-        rcp3(cajsr, q.half8 + c8, cajsr + p[kmcsqn_], rcajsr, rh, rq);
+        rcp3(cj, q.half8 + c8, cajsr + p[kmcsqn_], rcajsr, rh, rq);
         const double rh8 = c8 * rh;
         const double Jrel_inf = q.relScale * ((ICaL_ss * (-q.a_rel)) * rh8);
         const double Jrel_infp = q.relScale * ((ICaL_ss * (-q.a_relp)) * rh8);
-        const double irc = (cajsr + 0.0123) * rcajsr;
-        io.store(S_Jrel_np, gate(fm, Jrel_np, Jrel_inf, fmin(irc * q.r_bt, 1000.0), dt));
-        io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, fmin(irc * q.r_btp, 1000.0), dt));
+        const double irc = (cj + 0.0123) * rcajsr;
+        const double rate_np = irc > 0.0 ? fmin(irc * q.r_bt, 1000.0) : 1000.0;
+        const double rate_p = irc > 0.0 ? fmin(irc * q.r_btp, 1000.0) : 1000.0;
+        io.store(S_Jrel_np, gate(fm, Jrel_np, Jrel_inf, rate_np, dt));
+        io.store(S_Jrel_p, gate(fm, Jrel_p, Jrel_infp, rate_p, dt));
       }
       BEAT_TFENCE();
       if constexpr (LAND) {

@@ -162,3 +162,34 @@ def test_every_parameter_reaches_the_step_as_the_specification_has_it(host_step,
     outl = host_step_land(Sl, Pl, 0.4, 0.01)
     refl = torord.torord_land_generalized_rush_larsen(Sl, 0.4, 0.01, Pl)
     assert _err(outl, refl, gl["state_defaults"]).max() < 1e-10
+
+
+def test_sarcoplasmic_load_at_zero_and_below(host_step, host_step_land):
+    """cajsr enters the release equations through 1/cajsr (ToRORd_dynCl_endo.ode: Jrel_inf, tau_rel = max(bt/(1 + 0.0123/cajsr),
+    0.001)).  Perturbed parameter sets drive it through zero and below for a while (tools/soak_cells.py); the
+    specification stays finite there -- its max() returns the floor when the quotient turns negative -- and the kernel,
+    which forms 1/tau_rel from one shared reciprocal, must do what the specification does: one step from the
+    action-potential samples with cajsr set to values around zero equals the NumPy oracle."""
+    import warnings
+
+    g = np.load(GOLD / "torord_spec.npz")
+    S = g["traj_states"].copy()
+    n = S.shape[1]
+    vals = np.array([-0.5, -0.1, -0.02, -0.012, -1e-3, -3.7e-4, -1e-9, 1e-12, 1e-9, 1.8e-5, 1e-3, 0.05])
+    S[torord.torord_state_index("cajsr")] = vals[np.arange(n) % len(vals)]
+    P = torord.torord_init_parameter_values()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = torord.torord_generalized_rush_larsen(S, 0.4, 0.01, P)
+    out = host_step(S, P, 0.4, 0.01)
+    assert np.isfinite(out).all() and np.isfinite(ref).all()
+    assert _err(out, ref, g["state_defaults"]).max() < 1e-9
+    gl = np.load(GOLD / "torord_land_spec.npz")
+    Sl = gl["traj_states"].copy()
+    Sl[list(torord.TORORD_LAND_STATES).index("cajsr")] = vals[np.arange(Sl.shape[1]) % len(vals)]
+    Pl = torord.torord_land_init_parameter_values()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        refl = torord.torord_land_generalized_rush_larsen(Sl, 0.4, 0.01, Pl)
+    outl = host_step_land(Sl, Pl, 0.4, 0.01)
+    assert _err(outl, refl, gl["state_defaults"]).max() < 1e-9
