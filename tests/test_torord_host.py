@@ -193,3 +193,37 @@ def test_sarcoplasmic_load_at_zero_and_below(host_step, host_step_land):
         refl = torord.torord_land_generalized_rush_larsen(Sl, 0.4, 0.01, Pl)
     outl = host_step_land(Sl, Pl, 0.4, 0.01)
     assert _err(outl, refl, gl["state_defaults"]).max() < 1e-9
+
+
+def test_unphysiological_states_agree_wherever_the_specification_is_finite(host_step):
+    """Differential run on 6000 states nobody should reach -- potentials in -135 .. 100 mV, gates in -0.1 .. 1.1, every
+    concentration, load and release flux scaled by -1 .. 10 (negative ones included) -- wherever the NumPy oracle, which
+    evaluates the specification literally, returns finite values (logarithms of negative quotients do not), the kernel
+    source returns the same ones: its rewrites (shared reciprocals, rates s/(c s + 1), cajsr^8/(half^8 + cajsr^8), ...)
+    assume no sign."""
+    import warnings
+
+    g = np.load(GOLD / "torord_spec.npz")
+    names = list(g["state_names"])
+    rng = np.random.default_rng(5)
+    n = 6000
+    base = g["traj_states"]
+    S = base[:, rng.integers(0, base.shape[1], n)].copy()
+    scaled = ("nai", "nass", "ki", "kss", "cai", "cass", "cansr", "cajsr", "cli", "clss", "CaMKt", "Jrel_np", "Jrel_p")
+    for k, name in enumerate(names):
+        if name == "v":
+            S[k] = rng.uniform(-135, 100, n)
+        elif name in scaled:
+            S[k] *= rng.choice([-1.0, -0.1, 0.05, 0.5, 1.0, 2.0, 10.0], n, p=[0.05, 0.05, 0.1, 0.2, 0.3, 0.2, 0.1])
+        else:
+            S[k] = rng.uniform(-0.1, 1.1, n)
+    P = torord.torord_init_parameter_values()
+    for dt in (0.01, 0.05):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = torord.torord_generalized_rush_larsen(S, 0.3, dt, P)
+        out = host_step(S, P, 0.3, dt)
+        cols = np.isfinite(ref).all(axis=0)
+        assert cols.sum() > n // 3
+        assert np.isfinite(out[:, cols]).all()
+        assert _err(out[:, cols], ref[:, cols], g["state_defaults"]).max() < 1e-7
