@@ -266,6 +266,44 @@ def test_torord_update_forms_agree_across_their_switch_points(model):
         assert err.max() < 1e-9, (dt, float(err.max()), g["state_names"][int(np.unravel_index(err.argmax(), err.shape)[0])])
 
 
+def test_torord_kernel_on_unphysiological_states_agrees_wherever_the_specification_is_finite():
+    """The differential run of tests/test_torord_host.py (6000 states nobody should reach: gates in -0.1 .. 1.1, every
+    concentration, load and flux scaled by -1 .. 10) on the device build: wherever the NumPy oracle returns finite values,
+    the kernel returns the same ones to 1e-7 of the state scale.  (A negative SR load is what perturbed parameter sets do
+    reach for a while: tools/soak_cells.py.)"""
+    import warnings
+
+    from beat.models import torord
+
+    from oracle import torord as otor
+
+    g = np.load(GOLD / "torord_spec.npz")
+    names = list(g["state_names"])
+    rng = np.random.default_rng(5)
+    n = 6000
+    base = g["traj_states"]
+    S = base[:, rng.integers(0, base.shape[1], n)].copy()
+    scaled = ("nai", "nass", "ki", "kss", "cai", "cass", "cansr", "cajsr", "cli", "clss", "CaMKt", "Jrel_np", "Jrel_p")
+    for k, name in enumerate(names):
+        if name == "v":
+            S[k] = rng.uniform(-135, 100, n)
+        elif name in scaled:
+            S[k] *= rng.choice([-1.0, -0.1, 0.05, 0.5, 1.0, 2.0, 10.0], n, p=[0.05, 0.05, 0.1, 0.2, 0.3, 0.2, 0.1])
+        else:
+            S[k] = rng.uniform(-0.1, 1.1, n)
+    P = otor.torord_init_parameter_values()
+    scale0 = 1e-6 * np.abs(g["state_defaults"])[:, None] + 1e-12
+    for dt in (0.01, 0.05):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = otor.torord_generalized_rush_larsen(S, 0.3, dt, P)
+        out = torord.generalized_rush_larsen(states=S, t=0.3, parameters=P, dt=dt)
+        cols = np.isfinite(ref).all(axis=0)
+        assert cols.sum() > n // 3 and np.isfinite(out[:, cols]).all()
+        err = np.abs(out[:, cols] - ref[:, cols]) / np.maximum(np.abs(ref[:, cols]), scale0)
+        assert err.max() < 1e-7, (dt, float(err.max()), names[int(np.unravel_index(err.argmax(), err.shape)[0])])
+
+
 def test_torord_land_kernel_matches_the_ode_spec_golden_and_the_oracle():
     """The Land instance of the ToR-ORd kernel (beat.models.torord_land: odes/torord/ToRORd_dynCl_endo_Land.ode, 52
     states, 140 parameters): one GRL1 step vs the specification fixture for six parameter sets (cell types, stretch,
