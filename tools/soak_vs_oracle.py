@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ms", type=float, default=1200.0)
     ap.add_argument("--dt", type=float, default=0.02)
     ap.add_argument("--land", action="store_true")
+    ap.add_argument("--tp06", action="store_true")
     args = ap.parse_args()
     from beat.models import torord, torord_land
 
@@ -29,15 +30,25 @@ def main():
 
     m = torord_land if args.land else torord
     step = otor.torord_land_generalized_rush_larsen if args.land else otor.torord_generalized_rush_larsen
+    if args.tp06:
+        from beat.models import tp06
+
+        from oracle import ionic
+
+        m, step = tp06, ionic.tp06_generalized_rush_larsen
     rng = np.random.default_rng(2)
     n = args.cells
     P0 = m.init_parameter_values()
     P = np.repeat(P0[:, None], n, axis=1) * rng.uniform(0.9, 1.1, (len(P0), n))
-    P[m.parameter_index("celltype")] = np.arange(n) % 3
-    for k in ("i_Stim_Start", "i_Stim_End", "i_Stim_Period", "i_Stim_PulseDuration") + (("mode", "isacs") if args.land else ()):
+    if args.tp06:
+        fixed = ("stim_start", "stim_period", "stim_duration")
+    else:
+        P[m.parameter_index("celltype")] = np.arange(n) % 3
+        fixed = ("i_Stim_Start", "i_Stim_End", "i_Stim_Period", "i_Stim_PulseDuration") + (("mode", "isacs") if args.land else ())
+    for k in fixed:
         P[m.parameter_index(k)] = P0[m.parameter_index(k)]
     y0 = np.repeat(m.init_state_values()[:, None], n, axis=1)
-    vi = m.state_index("v")
+    vi = m.state_index("V" if args.tp06 else "v")
     nsteps = int(round(args.ms / args.dt))
     every = int(round(1.0 / args.dt))
     y, tr = m.generalized_rush_larsen.run(y0, P, dt=args.dt, nsteps=nsteps, nbeats=1, track_indices=[vi], save_freq=every)
