@@ -818,12 +818,16 @@ def main():
         transports = {main_name: {"ms_per_step": wall / args.steps * 1e3, "pcg_iterations_per_step": float(np.mean(iters)), "role": "headline"}}
         deadline = float(os.environ.get("BEAT_BENCH_ALT_DEADLINE_S", "90"))
 
-        def give_up():
+        def give_up(reason=None):
+            """Leave with the headline that is already measured: rank 0 prints its line, every rank exits 0.  Called by the
+            deadline timer, and by a rank on which an alternative raised (a transfer that timed out, a failed HIP call):
+            the other ranks are then waiting for this one inside the alternative and leave at their own deadline."""
             if rank == 0:
-                transports["error"] = f"an alternative transport made no progress for {deadline:.0f} s; abandoned"
+                transports["error"] = reason or f"an alternative transport made no progress for {deadline:.0f} s; abandoned"
                 out["transports"] = transports
                 print(json.dumps(out), file=result_stream, flush=True)
-            print(f"[bench rank {rank}] alternative transports abandoned at the deadline", file=sys.stderr, flush=True)
+            print(f"[bench rank {rank}] alternative transports abandoned" + (f": {reason}" if reason else " at the deadline"),
+                  file=sys.stderr, flush=True)
             os._exit(0)
 
         alts = [("ipc", False)] if main_name != "ipc" else []
@@ -837,6 +841,8 @@ def main():
             timer.start()
             try:
                 progress(f"alternative transport {label}")
+                if os.environ.get("BEAT_BENCH_TEST_ALT_RAISE") == str(rank):  # tests: an alternative that fails on one rank only
+                    raise RuntimeError("simulated failure inside an alternative transport (BEAT_BENCH_TEST_ALT_RAISE)")
                 alt = LibComm(ctx, slab, dist, None, name, serial=serial, plane_doubles=plane)
                 solver.libcomm = alt
                 ar = timed_run(t_alt, 2, args.steps)
@@ -850,6 +856,9 @@ def main():
             except LibCommUnavailable as exc:  # raised on every rank alike
                 transports[label] = {"error": str(exc)}
                 solver.libcomm = libcomm
+            except Exception as exc:  # noqa: BLE001 -- on this rank only: the ranks are out of step from here on
+                transports[label] = {"error": repr(exc)}
+                give_up(f"{label} raised on rank {rank}: {exc!r}")
             finally:
                 timer.cancel()
         # If an alternative beat the transport the headline was measured on by more than 3 % -- in the regime both were timed
@@ -908,6 +917,10 @@ def main():
             except LibCommUnavailable as exc:
                 choice["error"] = str(exc)
                 solver.libcomm = libcomm
+            except Exception as exc:  # noqa: BLE001
+                choice["error"] = repr(exc)
+                out["config"]["transport_choice"] = choice
+                give_up(f"re-measuring on {best} raised on rank {rank}: {exc!r}")
             finally:
                 timer.cancel()
         if rank == 0:

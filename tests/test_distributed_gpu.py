@@ -416,6 +416,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert hung.stderr.count("killing the ranks") == 2 and "BEAT_DIST_SERIAL" in hung.stderr and not hung.stdout.strip()
 
 
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_bench_alternative_transport_failing_on_one_rank_keeps_the_headline(failing_rank):
+    """The alternative transports are timed after the headline (bench.py, `transports`).  One of them raising on ONE rank
+    -- a transfer that timed out, a failed HIP call: the ranks are out of step from there on -- must not cost the measurement:
+    that rank leaves with exit code 0 (rank 0 printing the headline line first), the others leave at the deadline, and the
+    job's line carries the headline and says what happened."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(BEAT_DIST_BACKEND="gloo", BEAT_BENCH_TEST_ALT_RAISE=str(failing_rank), BEAT_BENCH_ALT_DEADLINE_S="12")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--size", "48", "--steps", "3", "--warmup", "1"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["finite"]
+    # (rank 0 reports its own failure, or -- when the other rank left -- the broken connection it then meets, or the deadline)
+    assert "error" in r["transports"] and ("raised on rank" in r["transports"]["error"] or "no progress" in r["transports"]["error"])
+    assert "abandoned" in run.stderr
+
+
 @pytest.mark.parametrize("world,transport", [(2, "callbacks"), (3, "callbacks"), (3, "ipc")])
 def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_path):
     """(transport "ipc": the three processes exchange their ghost planes ON THE DEVICE -- each maps its neighbours' mailboxes
