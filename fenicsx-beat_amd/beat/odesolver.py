@@ -103,7 +103,9 @@ class _DeviceODE:
         self.parameters = parameters
         self.monitor = monitor
         self._ppn = None
-        self._ppn_host = None  # what the device copy was uploaded from
+        self._ppn_host = None  # what the device copy was uploaded from (None: the per-node route's cache is not current)
+        self._dp_key = None    # (id, version) of the DeviceParameters handle the cached route was derived from
+        self._per_node_args = None
         self.classes = None    # (marker bytes on the device, class table, number of classes): see set_classes
         self.explicit_classes = False  # the owner set the classes itself (DolfinMultiODESolver); else they follow the parameters
         self.node_map = None   # (int32 node of the PDE grid per entry, the field holding the potential): compact layout
@@ -168,21 +170,33 @@ class _DeviceODE:
 
     def _per_node_or_classes(self, tensor, num_rows):
         """(host params, P, device rows, ld) for per-node parameters held in ``tensor``: the class route if they allow it."""
+        per_node = (None, num_rows, C.c_void_p(tensor.data_ptr()), self.n)
         found = self._classify(tensor)
         if found is not None:
             self.set_classes(found[0], list(found[1]))
+            self._per_node_args = per_node  # for the caller the class kernel does not serve (a mirror of another row than V)
             return None, num_rows, None, 0
         self.classes = None
-        return None, num_rows, C.c_void_p(tensor.data_ptr()), self.n
+        return per_node
+
+    def _forget_routes(self) -> None:
+        """The parameters are no per-node rows (any more): no classes, and neither cached route may be taken for current
+        again -- a classified (P, N) array, then a vector, then the same array must classify again (the vector branch
+        cleared the classes the cached arguments rely on)."""
+        self.classes = None
+        self._ppn_host = None
+        self._dp_key = None
 
     def _param_args(self):
         p = self.parameters
         if p is None:
+            self._forget_routes()
             return None, 0, None, 0
         if isinstance(p, DeviceParameters):  # resident handle: nothing to check or move per step
             _, dev, ld = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
             key = (id(p), p.version)
-            if getattr(self, "_dp_key", None) != key:  # new values: look at them once
+            if self._dp_key != key:  # new values: look at them once
+                self._ppn_host = None  # (the classes now follow THIS handle: the NumPy route's cache is stale)
                 self._dp_args = self._per_node_or_classes(dev, p.shape[0])
                 self._dp_key = key
             return self._dp_args
@@ -190,14 +204,15 @@ class _DeviceODE:
         if p.ndim == 1:
             hp = np.ascontiguousarray(p)
             self._keep = hp
-            self.classes = None
+            self._forget_routes()
             return hp.ctypes.data_as(C.c_void_p), len(hp), None, 0
         # per-node NumPy parameters: the reference hands the live array to ``fun`` every step (odesolver.py:70-76),
         # so any in-place edit must reach the kernel.  Exact comparison with the copy that was uploaded (one host
         # pass over (P, N) per step; pass a DeviceParameters handle to avoid it on large grids).
-        if self._ppn is None or self._ppn_host.shape != p.shape or not np.array_equal(self._ppn_host, p):
+        if self._ppn is None or self._ppn_host is None or self._ppn_host.shape != p.shape or not np.array_equal(self._ppn_host, p):
             _, self._ppn, _ = host_and_device_parameters(self.ctx, p, self.model.num_parameters, self.n)
             self._ppn_host = p.copy()
+            self._dp_key = None  # (see above)
             self._ppn_args = self._per_node_or_classes(self._ppn, p.shape[0])
         return self._ppn_args
 
@@ -206,6 +221,13 @@ class _DeviceODE:
         these states): the kernel adds it while loading the potential (beat_ode_step_pending)."""
         # (classes set explicitly -- one model for several markers -- stay; otherwise the parameters decide the route)
         hp, npar, ppn, pld = (None, 0, None, 0) if self.explicit_classes else self._param_args()
+        use_classes = self.classes is not None
+        if use_classes and not self.explicit_classes and v_copy is not None and self.model.v_name \
+                and int(v_index) != self.model.state_index(self.model.v_name):
+            # the class kernel mirrors the model's own potential row only: per-node parameters that were routed to classes
+            # go back to the per-node kernel, which mirrors any row (what the reference's v_index means, odesolver.py:135-146)
+            use_classes = False
+            hp, npar, ppn, pld = self._per_node_args
         pend = None
         if pending_ops is not None and pending_ops.pending is not None:
             model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
@@ -218,7 +240,7 @@ class _DeviceODE:
                 pending_ops.flush_pending()
         with self.monitor.track_time("ode_total_step"):
             with self.monitor.track_time("ode_function_call"):
-                if self.classes is not None:
+                if use_classes:
                     mk, table, ncls = self.classes
                     if int(v_index) != self.model.state_index(self.model.v_name) and pend is not None:
                         raise ValueError("a pending update needs the model's own potential row")

@@ -395,7 +395,13 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
                       int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
+  // (with num_params == NP and neither a vector nor rows nor classes every parameter would silently be 1.0 -- what the
+  // two-parameter test ODE is called with on purpose and nothing else is)
+  BEAT_REQUIRE(host_params != nullptr || ppn != nullptr || mk.markers != nullptr || Model::NP == 2,
+               "no parameters given: a host vector, per-node rows or parameter classes");
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
+  BEAT_REQUIRE(mk.markers == nullptr || v_copy == nullptr || v_index == Model::V_INDEX,
+               "the class kernel mirrors the model's potential (row %d), not row %d", Model::V_INDEX, v_index);
   const bool have_pend = pend.count > 0 || pend.gt.d != nullptr;
   BEAT_REQUIRE(!have_pend || v_index == Model::V_INDEX,
                "a pending update needs v_index = %d (the model's membrane potential), got %d", Model::V_INDEX, v_index);

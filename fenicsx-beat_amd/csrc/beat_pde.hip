@@ -653,6 +653,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->v_seg_tiled);
   (void)hipFree(pde->v_segmask_tiled);
   beat_vrr_destroy(pde);
+  beat_vtl_destroy(pde);
   delete pde;
   return BEAT_OK;
 }

@@ -75,6 +75,7 @@ struct beat_pde {
   int rhs_part_blocks = 0;  // block partials written by part 0 of a right-hand side built in two parts
   void* vrr = nullptr;      // work lists of the z-marching per-node SpMV (beat_pde_vrr.hip), or nullptr
   int vrr_part_blocks = 0;
+  void* vtl = nullptr;      // tiles and lane masks of the workgroup-tile per-node SpMV (beat_pde_vtl.hip), or nullptr
   bool small_enabled = true;  // grids of a few thousand nodes: whole solve in one launch (beat_pde_small.hip)
   int pc_ncoef = 1;       // 1: Jacobi; m >= 2: Chebyshev polynomial of degree m-1 in D^-1 A (m-1 stencil passes)
   double pc_coef[8] = {1.0};
@@ -144,6 +145,13 @@ int beat_vrr_setup(beat_pde* pde, const std::vector<unsigned long long>& host_ti
 void beat_vrr_destroy(beat_pde* pde);
 bool beat_vrr_available(const beat_pde* pde);
 int beat_vrr_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
+
+// per-node-coefficient SpMV on workgroup tiles: forward coefficients and rows of p loaded once per tile, shared through
+// LDS and registers (beat_pde_vtl.hip); whole-slab launches only
+int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& host_tissue_flags);
+void beat_vtl_destroy(beat_pde* pde);
+bool beat_vtl_available(const beat_pde* pde);
+int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

@@ -828,7 +828,7 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
     beat_set_error("beat_pde_create_var: %s", hipGetErrorString(e));
     return BEAT_EHIP;
   }
-  if ((rc = beat_vrr_setup(p, flags))) {
+  if ((rc = beat_vrr_setup(p, flags)) || (rc = beat_vtl_setup(p, flags))) {
     beat_pde_destroy(p);
     return rc;
   }
@@ -976,6 +976,7 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
 
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
   if (beat_vrr_available(pde)) return beat_vrr_spmv_dot(pde, dev_p, dev_q, dev_st, -1);
+  if (beat_vtl_available(pde)) return beat_vtl_spmv_dot(pde, dev_p, dev_q, dev_st);
   VarArgs a{};
   var_offsets(pde, a);
   a.T1 = pde->v_A;

@@ -1,0 +1,580 @@
+// Per-node-coefficient SpMV of the PCG on workgroup tiles: q = A p with every stored forward coefficient and every row
+// of p loaded ONCE per tile, the rest shared on chip.
+//
+// The segment-list kernel (var_spmv_kernel, beat_pde_var.hip) issues 23 wave-level loads per 64 nodes -- 8 forward
+// coefficients, 7 backward ones read as the neighbours' forward coefficients a row or a plane away, 7 rows of p, the
+// segment's edge values -- and moves 121 B per tissue node from beyond the L2 on the 401^3 shell (PMC, round 3) against
+// the 80 B a node owns (8 coefficients, p, q).  The z-marching kernel of round 3 (beat_pde_vrr.hip) loads the forward
+// half only but keeps RY rows x 3 planes of p and two sets of coefficients per WAVE (180-240 VGPRs), loads its whole
+// footprint whether tissue or not, and reads the tissue bits with a vector load inside the march (a vmcnt(0) per plane
+// that drains its prefetch).  Here:
+//   * a WORKGROUP owns a tile of 62 x-nodes (lanes 1..62 of a wave; lanes 0 and 63 carry the x-halo) x RY rows, one row
+//     per wave, and marches along z over a run of planes that hold tissue;
+//   * per plane a wave loads its row's 8 forward coefficients and ONE row of p (the plane after next; both one step ahead
+//     of their use); its own row's three planes of p and the four slots that point to the plane above stay in registers;
+//   * what a row needs from the rows next to it -- p of the rows above and below, the four forward slots of the row
+//     below that point up (+y, +x+y, +y+z, +x+y+z: its backward -y, -x-y, -y-z, -x-y-z) -- goes through LDS: every wave
+//     publishes its row once per plane, one barrier per plane, two buffers; the two halo rows of the tile (p above and
+//     below, the four slots of the row below) are six more loads per plane, dealt to the waves;
+//   * x-neighbours by DPP wave shifts; lanes on nodes outside the tissue issue no loads (per-row 64-bit masks, a table
+//     laid out along z and read with scalar loads two steps ahead), so lines without tissue are never fetched.
+// Per plane and tile: 9 RY + 6 wave loads for 62 RY nodes (RY = 4: 10.5 per 62 nodes instead of 23 per 64).  The values
+// of q are those of var_spmv_kernel bit for bit (same coefficients, the same 15 fused multiply-adds in slot order);
+// the block partials of p.q are summed in another order.
+//
+// Replaces, like beat_pde_var.hip, PETSc's MatMult inside KSP.solve (src/beat/base_model.py:236) for operators assembled
+// from per-cell conductivity tensors (src/beat/conductivities.py:101-118, demos/biv_endocardial.py:187-282).
+#include "beat_pde_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+using namespace beat_pde_detail;
+
+constexpr int SEG = 62;  // x-nodes computed per wave (lanes 1..62)
+using u64 = unsigned long long;
+
+struct VtlItem {
+  int seg, rb, zb, ze;  // tile column (x segment, row block) and the planes [zb, ze) it computes
+};
+
+struct VtlArgs {
+  int64_t ld;
+  int nx, ny, nz;
+  int64_t plane;
+  int nsegx;  // x segments per row
+  int nzp;    // entries per (row, x segment) of the mask table: planes -1 .. nz + padding
+  double* partials;
+  int part_off;
+  const double* st;
+  const double* x;         // p
+  double* y;               // q
+  const double* rows;      // (15, ld) coefficient rows of A
+  const unsigned long long* mask;  // lane masks per (row, x segment) along z
+  const VtlItem* items;
+  const int* xcd_first;    // 9 entries: the part of the tile list each XCD walks
+  int* next;               // 8 counters (next tile of each part) + the number of workgroups done
+};
+
+__device__ __forceinline__ double vtl_from_left(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);  // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double vtl_from_right(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);  // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// One plane of a field (or of a coefficient row) as a raw buffer: a lane that wants nothing passes an offset beyond the
+// buffer's end -- its load returns 0 and fetches nothing, its store is dropped -- so neither needs a branch or a change
+// of the exec mask, and the compiler can count what is outstanding at every point of the march.
+typedef int vtl_v2i __attribute__((ext_vector_type(2)));
+constexpr unsigned VTL_OOB = 0x80000000u;
+__device__ __forceinline__ double vtl_buf_load(const double* base, unsigned bytes, unsigned off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  const vtl_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsigned off, double val) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  vtl_v2i v;
+  v.x = __double2loint(val);
+  v.y = __double2hiint(val);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0);
+}
+
+// forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
+// 13 +x+y+z; the backward slot k+1 pairs with the forward slot k.  F[] below holds them in that order.
+template <int RY, bool DYN>
+__global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
+  // one LDS array: p of plane z+1 for rows y0-1 .. y0+RY of the tile (two buffers), slots 3, 7, 9, 13 of plane z for rows
+  // y0-1 .. y0+RY-2 (two buffers), and a row per wave that absorbs the stores of a wave without a (second) halo load
+  constexpr int P_PAR = (RY + 2) * 64, C_PAR = RY * 4 * 64;
+  constexpr int P_BASE = 0, C_BASE = 2 * P_PAR, DUMMY = C_BASE + 2 * C_PAR;
+  constexpr bool TWO = RY < 6;  // six halo loads per plane: two per wave when a tile has fewer than six rows
+  __shared__ double lds[DUMMY + RY * 64];
+  __shared__ double red[RY];
+  __shared__ int next_item;
+  if (a_.st[STOP] != 0.0) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u64 lanebit = 1ull << lane;
+  // Every XCD (blocks b with b % 8 == x) walks one contiguous, equally heavy part of the tile list, front to back: the
+  // tiles its workgroups have in flight are neighbours, the halo rows and lanes they share are lines its L2 holds.  A
+  // workgroup that is done takes the part's next tile (one counter per XCD; tiles differ by a factor of ten in tissue,
+  // dealt round-robin the average wave was alive 75 % of the launch), and helps the other XCDs out once its own part is
+  // exhausted.  p.q is summed per TILE, the reduction adds the tiles in list order: the same bits whoever computed what.
+  // DYN = false (the default, see beat_vtl_setup): the tiles of a part dealt round-robin to the XCD's workgroups.
+  const int xcd = blockIdx.x & 7;
+  int static_it = a_.xcd_first[xcd] + (int)(blockIdx.x >> 3);
+  for (;;) {
+    // (taken by wave 0 as a whole, uniformly; only the atomic itself is one lane's.  Written as `if (threadIdx.x == 0)` at
+    // the head of the loop, the compiler split the loop by lanes and wave 0 executed the barrier below twice per round.)
+    if (w == 0) {
+      int got = -1;
+      if (DYN) {
+        for (int k = 0; k < 8 && got < 0; ++k) {
+          const int x = (xcd + k) & 7;
+          const int first = a_.xcd_first[x], end = a_.xcd_first[x + 1];
+          if (first < end) {
+            int n = 0;
+            if (lane == 0) n = atomicAdd(a_.next + x, 1);
+            n = __builtin_amdgcn_readfirstlane(n);
+            if (n < end - first) got = first + n;
+          }
+        }
+      } else {
+        if (static_it < a_.xcd_first[xcd + 1]) got = static_it;
+        static_it += (int)(gridDim.x >> 3);
+      }
+      if (lane == 0) next_item = got;
+    }
+    __syncthreads();  // (also: the previous tile's last reads of the LDS buffers are done)
+    const int it = __builtin_amdgcn_readfirstlane(next_item);
+    if (it < 0) break;
+    double acc = 0.0;
+    // the kernel arguments through a pointer the optimiser cannot see through, per tile: read where a tile needs them
+    // instead of being held in SGPRs from the top of the kernel on (the kernel has none to spare)
+    typedef const __attribute__((address_space(4))) char* KArgPtr;
+    KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const VtlArgs& a = *(const VtlArgs*)ka;
+    const double* __restrict__ X = a.x;
+    double* __restrict__ Y = a.y;
+    const double* __restrict__ A = a.rows;
+    const u64* __restrict__ MASK = a.mask;
+    const VtlItem item = a.items[it];  // wave-uniform
+    const int y0 = item.rb * RY, zb = item.zb, ze = item.ze;
+    const int gy = y0 + w;
+    const int gx = item.seg * SEG - 1 + lane;
+    const int cx = min(max(gx, 0), a.nx - 1);
+    // rows of the mask table: index y + 1 for y = -1 .. ny (both ends all zero); z + 1 for z = -1 .. nz
+    // (32-bit offsets into the table: the set-up refuses grids whose table has 2^31 entries)
+    const int ty = min(gy, a.ny), tyu = min(gy + 1, a.ny), tyd = min(gy - 1, a.ny);
+    const int mo_own = ((ty + 1) * a.nsegx + item.seg) * a.nzp + 1;
+    const unsigned roff = (unsigned)(min(gy, a.ny - 1) * a.nx + cx);
+    // Everything inside the march is data, not control flow: a load that is not wanted (a lane outside the tissue, a plane
+    // beyond the run, a halo load this wave does not have) gets an empty mask, i.e. out-of-range offsets in every lane.
+    // With branches around the loads and the store the compiler cannot count what is outstanding where the paths join
+    // and waits for everything (vmcnt(0) right behind the store of q, every plane).
+    const unsigned pbytes = (unsigned)a.plane * 8u;
+    auto lane_off = [&](u64 mk, unsigned ro) -> unsigned { return (mk & lanebit) ? ro * 8u : VTL_OOB; };
+    auto ldp = [&](u64 mk, int z, unsigned ro) -> double { return vtl_buf_load(X + (int64_t)z * a.plane, pbytes, lane_off(mk, ro)); };
+    auto ldc = [&](u64 mk, int slot, int z, unsigned ro) -> double {
+      return vtl_buf_load(A + (int64_t)slot * a.ld + (int64_t)z * a.plane, pbytes, lane_off(mk, ro));
+    };
+    // the halo rows of the tile: p of rows y0-1 and y0+RY (consumed like the waves' own p: loaded for plane z+2 at step
+    // z), slots 3, 7, 9, 13 of row y0-1 (like the own coefficients: plane z+1 at step z); wave w takes halo loads w and
+    // w + RY of the six (e: 0 = p below, 1 = p above, 2..5 = slot 3 / 7 / 9 / 13 of the row below).  What a halo load
+    // needs is re-derived from its number where it is used (a handful of scalar instructions per plane): kept as
+    // pointers, the descriptors cost the SGPRs the kernel does not have
+    const int ea = w, eb = w + RY;
+    auto halo_row = [&](int e) -> int { return e == 1 ? y0 + RY : y0 - 1; };
+    const unsigned roff_a = (unsigned)(min(max(halo_row(ea), 0), a.ny - 1) * a.nx + cx);
+    const unsigned roff_b = (unsigned)(min(max(halo_row(eb), 0), a.ny - 1) * a.nx + cx);
+    const int moff_a = ((min(max(halo_row(ea), -1), a.ny) + 1) * a.nsegx + item.seg) * a.nzp + 1;
+    const int moff_b = ((min(max(halo_row(eb), -1), a.ny) + 1) * a.nsegx + item.seg) * a.nzp + 1;
+    auto halo_plane = [&](int e, int z) -> int { return z + (e < 2 ? 2 : 1); };  // what step z loads (step z+1 publishes)
+    auto halo_mask = [&](int e, int moff, int z) -> u64 { return MASK[moff + halo_plane(e, z)]; };
+    auto halo_load = [&](int e, u64 mk, unsigned ro, int z) -> double {
+      const bool is_p = e < 2;
+      const int zz = halo_plane(e, z);
+      const bool want = e < 6 && zz <= (is_p ? ze : ze - 1);
+      const u64 m = want ? mk : 0ull;
+      int64_t ld = a.ld;
+      asm volatile("" : "+s"(ld));
+      const int slot = (0xD973 >> (4 * ((e - 2) & 3))) & 15;  // 3, 7, 9, 13
+      const double* base = is_p ? X : A + slot * ld;
+      return vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, lane_off(m, ro));
+    };
+    auto halo_lds = [&](int e, int z) -> int {  // where step z publishes it
+      const int par = (e < 2 ? z + 1 : z) & 1;
+      const int p_at = P_BASE + par * P_PAR + (e & 1) * (RY + 1) * 64, c_at = C_BASE + par * C_PAR + (e - 2) * 64;
+      const int at = e < 2 ? p_at : c_at;
+      return e >= 6 ? DUMMY + w * 64 : at;
+    };
+
+    // ---- prologue: the planes below the run, straight from memory ------------------------------------------------------
+    u64 M0 = MASK[mo_own + zb], M1 = MASK[mo_own + zb + 1], M2 = MASK[mo_own + zb + 2];
+    double Pm, P0, U0, D0, Dm, K5, K9, K11, K13;
+    bool direct = zb == 0;
+    {
+      const int mo_up = ((tyu + 1) * a.nsegx + item.seg) * a.nzp + 1;
+      const int mo_dn = ((tyd + 1) * a.nsegx + item.seg) * a.nzp + 1;
+      const unsigned roff_up = (unsigned)(min(gy + 1, a.ny - 1) * a.nx + cx);
+      const unsigned roff_dn = (unsigned)(max(gy - 1, 0) * a.nx + cx);
+      const u64 mo = MASK[mo_own + zb - 1], md = MASK[mo_dn + zb - 1];
+      Pm = ldp(mo, zb - 1, roff);
+      P0 = ldp(M0, zb, roff);
+      U0 = ldp(MASK[mo_up + zb], zb, roff_up);
+      D0 = ldp(MASK[mo_dn + zb], zb, roff_dn);
+      Dm = ldp(md, zb - 1, roff_dn);
+      // coefficients of the plane below towards this one: slots 5 / 11 of the own row, 9 / 13 of the row below.  Plane 0
+      // of a slab has no stored plane below it: its own backward slots 6, 10, 12, 14 are used as they are (what
+      // var_spmv_kernel does; zero on a physical face)
+      const int zc = direct ? 0 : zb - 1;
+      const u64 mk_o = direct ? M0 : mo, mk_d = direct ? M0 : md;
+      const unsigned ro_d = direct ? roff : roff_dn;
+      K5 = ldc(mk_o, direct ? 6 : 5, zc, roff);
+      K11 = ldc(mk_o, direct ? 12 : 11, zc, roff);
+      K9 = ldc(mk_d, direct ? 10 : 9, zc, ro_d);
+      K13 = ldc(mk_d, direct ? 14 : 13, zc, ro_d);
+    }
+    // in flight for the first step: this plane's coefficients, p of the next plane, the halo rows' share
+    double Fn[8];
+    auto load_coefs = [&](u64 mk, int z) {
+      const unsigned off = lane_off(mk & ~(1ull << 63), roff);  // lane 63 is the +x halo: nobody needs its coefficients
+      // the row stride opaque per plane: otherwise the seven products k ld are loop invariants, hoisted into SGPR pairs
+      // the kernel does not have (31 spilled to VGPR lanes)
+      int64_t ld = a.ld;
+      asm volatile("" : "+s"(ld));
+      const double* bc = A + (int64_t)z * a.plane;
+      Fn[0] = vtl_buf_load(bc, pbytes, off);
+      bc += ld;
+      Fn[1] = vtl_buf_load(bc, pbytes, off);
+      ld += ld;
+#pragma unroll
+      for (int k = 2; k < 8; ++k) {
+        bc += ld;
+        Fn[k] = vtl_buf_load(bc, pbytes, off);
+      }
+    };
+    load_coefs(M0, zb);
+    double Pn = ldp(M1, zb + 1, roff);
+    double Ean = halo_load(ea, halo_mask(ea, moff_a, zb - 1), roff_a, zb - 1);
+    double Ebn = 0.0;
+    if (TWO) Ebn = halo_load(eb, halo_mask(eb, moff_b, zb - 1), roff_b, zb - 1);
+    u64 HA = halo_mask(ea, moff_a, zb), HB = TWO ? halo_mask(eb, moff_b, zb) : 0ull;  // masks of the loads step zb issues
+    for (int z = zb; z < ze; ++z) {
+      double F[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) F[k] = Fn[k];
+      const double Pp = Pn, Ea = Ean, Eb = Ebn;
+      // masks: one step (the halo loads') and two steps (the own row's) ahead of their use
+      const u64 M3 = MASK[mo_own + z + 3];
+      const u64 HAn = halo_mask(ea, moff_a, z + 1);
+      const u64 HBn = TWO ? halo_mask(eb, moff_b, z + 1) : 0ull;
+      // next step's operands
+      load_coefs(z + 1 < ze ? M1 : 0ull, z + 1);
+      Pn = ldp(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
+      Ean = halo_load(ea, HA, roff_a, z);
+      if (TWO) Ebn = halo_load(eb, HB, roff_b, z);
+      // publish this row
+      lds[P_BASE + ((z + 1) & 1) * P_PAR + (w + 1) * 64 + lane] = Pp;
+      {
+        double* __restrict__ cw = lds + (w + 1 < RY ? C_BASE + (z & 1) * C_PAR + (w + 1) * 4 * 64 : DUMMY + w * 64) + lane;
+        const int cs = w + 1 < RY ? 64 : 0;
+        cw[0] = F[2];
+        cw[cs] = F[4];
+        cw[2 * cs] = F[5];
+        cw[3 * cs] = F[7];
+      }
+      lds[halo_lds(ea, z) + lane] = Ea;
+      if (TWO) lds[halo_lds(eb, z) + lane] = Eb;
+      __syncthreads();
+      const double* __restrict__ pr = lds + P_BASE + ((z + 1) & 1) * P_PAR + w * 64 + lane;
+      const double Dn = pr[0], Un = pr[128];
+      const double* __restrict__ cr = lds + C_BASE + (z & 1) * C_PAR + w * 4 * 64 + lane;
+      const double H3 = cr[0], H7 = cr[64], H9 = cr[128], H13 = cr[192];
+      double c[15], v[15];
+      c[0] = F[0];
+      c[1] = F[1];
+      c[2] = vtl_from_left(F[1]);  // -x: the left neighbour's +x
+      c[3] = F[2];
+      c[4] = H3;                   // -y: the lower row's +y
+      c[5] = F[3];
+      c[6] = K5;                   // -z: the lower plane's +z
+      c[7] = F[4];
+      c[8] = vtl_from_left(H7);    // -x-y
+      c[9] = F[5];
+      c[10] = K9;                  // -y-z
+      c[11] = F[6];
+      const double K11l = vtl_from_left(K11), K13l = vtl_from_left(K13);
+      c[12] = direct ? K11 : K11l;  // -x-z
+      c[13] = F[7];
+      c[14] = direct ? K13 : K13l;  // -x-y-z
+      v[0] = P0;
+      v[1] = vtl_from_right(P0);
+      v[2] = vtl_from_left(P0);
+      v[3] = U0;
+      v[4] = D0;
+      v[5] = Pp;
+      v[6] = Pm;
+      v[7] = vtl_from_right(U0);
+      v[8] = vtl_from_left(D0);
+      v[9] = Un;
+      v[10] = Dm;
+      v[11] = vtl_from_right(Pp);
+      v[12] = vtl_from_left(Pm);
+      v[13] = vtl_from_right(Un);
+      v[14] = vtl_from_left(Dm);
+      // values are selected, never multiplied by a zero coefficient: a stale ghost plane cannot leak a NaN
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s = fma(c[k], (k == 0 || c[k] != 0.0) ? v[k] : 0.0, s);
+      const bool out = (M0 & lanebit & (((1ull << SEG) - 1ull) << 1)) != 0ull;
+      acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
+      vtl_buf_store(Y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
+      // roll: this plane becomes the plane below
+      Pm = P0;
+      P0 = Pp;
+      U0 = Un;
+      Dm = D0;
+      D0 = Dn;
+      K5 = F[3];
+      K11 = F[6];
+      K9 = H9;
+      K13 = H13;
+      direct = false;
+      M0 = M1;
+      M1 = M2;
+      M2 = M3;
+      HA = HAn;
+      HB = HBn;
+    }
+    // the tile's share of p.q, summed in wave order
+    acc = beat_wave_sum(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (w == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < RY; ++k) t += red[k];
+      if (lane == 0) a.partials[a.part_off + it] = t;
+    }
+  }
+  // the last workgroup to leave rewinds the counters for the next launch
+  // (no fence: a __threadfence() here is an L2 write-back and invalidate per workgroup -- a thousand of them while the others
+  // still live off the lines they share; the counters are only ever touched by atomics, and a workgroup's last grab, whose
+  // result it had to see before it got here, precedes its tick)
+  if (DYN && w == 0 && lane == 0) {
+    if (atomicAdd(a_.next + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a_.next[k] = 0;
+    }
+  }
+}
+
+struct VtlData {
+  int ry = 4;
+  bool dyn = false;
+  VtlItem* d_items = nullptr;
+  int* d_xcd_first = nullptr;  // 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
+  u64* d_mask = nullptr;
+  int nitems = 0, nsegx = 0, nzp = 0;
+  unsigned resident = 0;
+};
+
+template <int RY>
+unsigned vtl_resident_blocks() {
+  auto kernel = vtl_spmv_kernel<RY, true>;
+  int dev = 0, cus = 256, per_cu = 1;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RY * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return (unsigned)std::min(cus * per_cu, BEAT_MAX_PARTIALS) & ~7u;
+}
+}  // namespace
+
+void beat_vtl_destroy(beat_pde* pde) {
+  VtlData* d = (VtlData*)pde->vtl;
+  if (d == nullptr) return;
+  if (d->d_items) (void)hipFree(d->d_items);
+  if (d->d_xcd_first) (void)hipFree(d->d_xcd_first);
+  if (d->d_mask) (void)hipFree(d->d_mask);
+  delete d;
+  pde->vtl = nullptr;
+}
+
+// flags: tissue bits per 64-node segment of the slab (host copy).  Builds the per-row lane masks along z and the list of
+// tiles (column x run of planes with tissue), in (z block, row block, x segment) order, cut into eight equally heavy parts.
+int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) {
+  // BEAT_VTL=0 keeps the segment-list kernel (var_spmv_kernel), which also serves every launch over part of a slab
+  const char* sw = std::getenv("BEAT_VTL");
+  if (sw != nullptr && sw[0] == '0') return BEAT_OK;
+  const Geom& f = pde->g;
+  if (f.nz < 2 || f.nx < 2 || f.ny < 2) return BEAT_OK;  // 1-D / 2-D grids and single planes: the segment list
+  if (f.plane >= ((int64_t)1 << 28)) return BEAT_OK;      // 32-bit byte offsets inside a plane
+  if ((int64_t)(f.ny + 2) * ((f.nx + SEG - 1) / SEG) * (f.nz + 6) >= ((int64_t)1 << 31)) return BEAT_OK;  // 32-bit mask offsets
+  VtlData* d = new VtlData();
+  {
+    const char* e = std::getenv("BEAT_VTL_RY");
+    // eight rows per tile halve the share of the halo rows; four keep thin slabs busy.  Measured on the 401^3 shell, one box,
+    // alternating (tools/vtl_ab.sh, rocprofv3 kernel times): 8 rows, runs of 16 planes, dynamic: 403 us; 8 / 32: 414-428;
+    // 4 / 32 dealt statically: 423-429, dynamic: 447; 4 / 16: 409-420; 4 / 64: 466 -- the segment-list kernel: 535
+    d->ry = e ? (std::atoi(e) == 8 ? 8 : 4) : (f.ny >= 16 ? 8 : 4);
+    // tiles dealt round-robin to an XCD's workgroups (default) or taken from a counter per XCD (BEAT_VTL_DYNAMIC=1).  The
+    // counter balances better on paper and measured the same on the SpMV alone (tools/bench_voxel.py: 403 against 409 us),
+    // but inside the shell's split step (tools/bench_biv.py --n 400, same box, alternating) the round trip of the atomic, with
+    // the whole workgroup waiting behind it once per tile, cost 560 against 375 us per launch: 12.85 against 11.24 ms/step
+    const char* dy = std::getenv("BEAT_VTL_DYNAMIC");
+    d->dyn = dy && dy[0] == '1';
+  }
+  int max_run = 16;
+  if (const char* e = std::getenv("BEAT_VTL_RUN")) max_run = std::max(1, std::atoi(e));
+  int aligned = 0;
+  if (const char* e = std::getenv("BEAT_VTL_ALIGN")) aligned = std::atoi(e);
+  const int RY = d->ry;
+  const int nsegx = (f.nx + SEG - 1) / SEG, nrb = (f.ny + RY - 1) / RY;
+  const int nzp = f.nz + 6;  // planes -1 .. nz, and what the march reads ahead of its last plane
+  d->nsegx = nsegx;
+  d->nzp = nzp;
+  auto tissue = [&](int64_t i) -> u64 { return (flags[(size_t)(i >> 6)] >> (i & 63)) & 1ull; };
+  // mask[(y + 1) nsegx + seg][z + 1]: bit l = node (62 seg - 1 + l, y, z) is a tissue node of this slab; on a ghost plane
+  // that another rank owns: the node is inside the box (its p is live; which of them are tissue is not known here)
+  std::vector<u64> mask((size_t)(f.ny + 2) * nsegx * nzp, 0ull);
+  for (int y = 0; y < f.ny; ++y)
+    for (int s = 0; s < nsegx; ++s) {
+      u64* row = mask.data() + ((size_t)(y + 1) * nsegx + s) * nzp + 1;
+      u64 box = 0ull;
+      for (int l = 0; l < 64; ++l) {
+        const int gx = s * SEG - 1 + l;
+        if (gx >= 0 && gx < f.nx) box |= 1ull << l;
+      }
+      if (!f.z_lo_phys) row[-1] = box;
+      if (!f.z_hi_phys) row[f.nz] = box;
+      for (int z = 0; z < f.nz; ++z) {
+        const int64_t base = (int64_t)z * f.plane + (int64_t)y * f.nx + (int64_t)s * SEG - 1;
+        u64 m = 0ull;
+        for (int l = 0; l < 64; ++l)
+          if (((box >> l) & 1ull) && tissue(base + l)) m |= 1ull << l;
+        row[z] = m;
+      }
+    }
+  const u64 out_lanes = ((1ull << SEG) - 1ull) << 1;  // lanes 1..62
+  std::vector<VtlItem> items;
+  std::vector<char> act((size_t)f.nz);
+  // (one partial sum of p.q per tile: longer runs if there would be more tiles than partial slots)
+  for (;; max_run *= 2) {
+  items.clear();
+  for (int rb = 0; rb < nrb; ++rb)
+    for (int seg = 0; seg < nsegx; ++seg) {
+      bool any = false;
+      for (int z = 0; z < f.nz; ++z) {
+        u64 m = 0ull;
+        for (int y = rb * RY; y < std::min(f.ny, rb * RY + RY); ++y) m |= mask[((size_t)(y + 1) * nsegx + seg) * nzp + 1 + z];
+        act[(size_t)z] = (m & out_lanes) != 0ull;
+        any |= act[(size_t)z] != 0;
+      }
+      if (!any) continue;
+      if (aligned) {
+        // every tile of a z block covers the block's tissue range as a whole (BEAT_VTL_ALIGN=2: the whole block): neighbouring
+        // tiles then march through the same planes at about the same time, and the lines they share -- the halo rows, the
+        // 128-byte lines a row segment shares with the segments left and right of it -- are fetched once per XCD
+        for (int b0 = 0; b0 < f.nz; b0 += max_run) {
+          const int b1 = std::min(f.nz, b0 + max_run);
+          int lo = b1, hi = b0;
+          for (int z = b0; z < b1; ++z)
+            if (act[(size_t)z]) {
+              lo = std::min(lo, z);
+              hi = std::max(hi, z + 1);
+            }
+          if (lo >= hi) continue;
+          items.push_back(aligned == 2 ? VtlItem{seg, rb, b0, b1} : VtlItem{seg, rb, lo, hi});
+        }
+        continue;
+      }
+      int z = 0;
+      while (z < f.nz) {
+        if (!act[(size_t)z]) {
+          ++z;
+          continue;
+        }
+        // a run never crosses a multiple of max_run: tiles of one z block are neighbours in the list
+        const int stop = std::min(f.nz, (z / max_run + 1) * max_run);
+        int e = z + 1, last = z + 1;  // grow the run over gaps of up to two planes
+        while (e < stop && (act[(size_t)e] || e - last < 2)) {
+          if (act[(size_t)e]) last = e + 1;
+          ++e;
+        }
+        items.push_back(VtlItem{seg, rb, z, last});
+        z = last;
+      }
+    }
+  if ((int64_t)items.size() <= BEAT_MAX_PARTIALS || max_run >= f.nz) break;
+  }
+  if ((int64_t)items.size() > BEAT_MAX_PARTIALS) {  // (a plane of more than 16384 tiles: the segment-list kernel)
+    delete d;
+    return BEAT_OK;
+  }
+  std::stable_sort(items.begin(), items.end(), [&](const VtlItem& p, const VtlItem& q) {
+    const int zp = p.zb / max_run, zq = q.zb / max_run;
+    if (zp != zq) return zp < zq;
+    if (p.rb != q.rb) return p.rb < q.rb;
+    return p.seg < q.seg;
+  });
+  // eight contiguous parts of equal weight (planes + a prologue's worth per tile)
+  std::vector<int64_t> cum(items.size() + 1, 0);
+  for (size_t k = 0; k < items.size(); ++k) cum[k + 1] = cum[k] + (items[k].ze - items[k].zb) + 2;
+  int first[9];
+  first[0] = 0;
+  for (int x = 1; x < 8; ++x) {
+    const int64_t want = cum.back() * x / 8;
+    first[x] = (int)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+    first[x] = std::max(first[x - 1], std::min(first[x], (int)items.size()));
+  }
+  first[8] = (int)items.size();
+  d->nitems = (int)items.size();
+  pde->vtl = d;
+  hipError_t e = hipMalloc(&d->d_items, sizeof(VtlItem) * std::max<size_t>(1, items.size()));
+  if (e == hipSuccess && !items.empty()) e = hipMemcpy(d->d_items, items.data(), sizeof(VtlItem) * items.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&d->d_xcd_first, 2 * sizeof(first));
+  if (e == hipSuccess) e = hipMemset(d->d_xcd_first, 0, 2 * sizeof(first));
+  if (e == hipSuccess) e = hipMemcpy(d->d_xcd_first, first, sizeof(first), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&d->d_mask, sizeof(u64) * mask.size());
+  if (e == hipSuccess) e = hipMemcpy(d->d_mask, mask.data(), sizeof(u64) * mask.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    beat_vtl_destroy(pde);
+    beat_set_error("beat_vtl_setup: %s", hipGetErrorString(e));
+    return BEAT_EHIP;
+  }
+  d->resident = RY == 8 ? vtl_resident_blocks<8>() : vtl_resident_blocks<4>();
+  if (std::getenv("BEAT_VTL_VERBOSE")) {
+    long planes = 0;
+    for (const VtlItem& it : items) planes += it.ze - it.zb;
+    std::fprintf(stderr, "vtl: RY %d, %d x %d columns, %d tiles, %.1f planes per tile, %u resident blocks, parts %d %d %d %d %d %d %d %d\n", RY,
+                 nsegx, nrb, d->nitems, d->nitems ? (double)planes / d->nitems : 0.0, d->resident, first[1] - first[0],
+                 first[2] - first[1], first[3] - first[2], first[4] - first[3], first[5] - first[4], first[6] - first[5],
+                 first[7] - first[6], first[8] - first[7]);
+  }
+  return BEAT_OK;
+}
+
+bool beat_vtl_available(const beat_pde* pde) { return pde->var && pde->vtl != nullptr && ((VtlData*)pde->vtl)->nitems > 0; }
+
+// whole-slab q = A p and the sum p.q
+int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
+  VtlData* d = (VtlData*)pde->vtl;
+  const Geom& f = pde->g;
+  VtlArgs a{};
+  a.ld = pde->v_ld;
+  a.nx = f.nx;
+  a.ny = f.ny;
+  a.nz = f.nz;
+  a.plane = f.plane;
+  a.nsegx = d->nsegx;
+  a.nzp = d->nzp;
+  a.partials = pde->ctx->d_partials;
+  a.part_off = 0;
+  a.st = dev_st;
+  // blocks in eights (one per XCD), at most the resident number, at least one tile per block on average
+  const unsigned grid = std::max(8u, std::min(d->resident, (unsigned)((d->nitems + 7) & ~7)));
+  a.x = dev_p;
+  a.y = dev_q;
+  a.rows = pde->v_A;
+  a.mask = d->d_mask;
+  a.items = d->d_items;
+  a.xcd_first = d->d_xcd_first;
+  a.next = d->d_xcd_first + 9;
+  auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
+  if (d->ry == 8)
+    d->dyn ? launch(vtl_spmv_kernel<8, true>, 8) : launch(vtl_spmv_kernel<8, false>, 8);
+  else
+    d->dyn ? launch(vtl_spmv_kernel<4, true>, 4) : launch(vtl_spmv_kernel<4, false>, 4);
+  BEAT_LAUNCH_CHECK();
+  return beat_pde_launch_reduce(pde, d->nitems, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
+}

@@ -932,6 +932,69 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     assert (np.abs(out_g - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
 
 
+def test_parameter_route_follows_the_parameters_through_every_change_of_kind():
+    """(round-3 review) The route a step takes -- uniform vector, per-node rows, parameter classes -- is re-derived whenever
+    the KIND of ``parameters`` changes: a classified (P, N) array, then a vector, then the SAME array again must classify
+    again (the vector branch cleared the classes, a cached "use the classes" must not survive it), likewise for a resident
+    DeviceParameters handle of one version, and for NumPy array <-> handle in either order.  Every step is checked against
+    the oracle with the parameters that were current; a mirror row other than the potential sends class-routed parameters
+    back to the per-node kernel; the library refuses a launch without any parameters."""
+    import ctypes as C
+
+    import beat
+    from beat import _hip
+    from beat import grid as g
+    from beat.models import tp06
+    from beat.odesolver import DeviceParameters
+    from oracle import ionic
+
+    mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([4.0, 1.0, 1.0])], [16, 4, 4])
+    V = g.functionspace(mesh, ("P", 1))
+    n = V.dofmap.index_map.size_local
+    xs = mesh.node_coordinates(pad3=True)[:, 0]
+    P0 = tp06.init_parameter_values(stim_amplitude=0.0)
+    Pn = np.zeros((len(P0), n))
+    Pn.T[:] = P0
+    Pn[tp06.parameter_index("g_Kr")] = np.where(xs >= 2.0, 0.0, P0[tp06.parameter_index("g_Kr")])
+    Pv = tp06.init_parameter_values(stim_amplitude=0.0, g_Na=9.0)
+    handle = DeviceParameters(Pn)
+    rng = np.random.default_rng(8)
+    S0 = np.repeat(tp06.init_state_values()[:, None], n, axis=1)
+    S0[tp06.state_index("V")] = rng.uniform(-90.0, 30.0, n)
+    ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=g.Function(V), fun=tp06.generalized_rush_larsen,
+                                         init_states=S0, parameters=Pn, num_states=19, v_index=tp06.state_index("V"))
+    ref, t, dt = S0.copy(), 0.0, 0.02
+    sequence = [("rows", Pn, 2), ("vector", Pv, None), ("rows", Pn, 2), ("handle", handle, 2), ("vector", Pv, None),
+                ("handle", handle, 2), ("rows", Pn, 2), ("handle", handle, 2), ("vector", Pv, None), ("rows", Pn, 2)]
+    for kind, prm, ncls in sequence:
+        ode.parameters = prm
+        ode.step(t, dt)
+        ref = ionic.tp06_generalized_rush_larsen(ref, t, dt, Pv if kind == "vector" else Pn)
+        t += dt
+        cls = ode._dev.classes
+        assert (cls is None) if ncls is None else (cls is not None and cls[2] == ncls), (kind, cls)
+        err = np.abs(np.asarray(ode.values) - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert err.max() < 1e-10, (kind, err.max())
+    # a mirror of another row than the potential: the class kernel does not write it, the per-node kernel does
+    dev = ode._dev
+    mirror = dev.ctx.zeros(n)
+
+    class _Row:
+        ptr = C.c_void_p(mirror.data_ptr())
+
+    k = 3  # the m gate
+    dev.parameters = Pn
+    dev.step(t, dt, v_index=k, v_copy=_Row)
+    ref = ionic.tp06_generalized_rush_larsen(ref, t, dt, Pn)
+    dev.ctx.synchronize()
+    np.testing.assert_allclose(mirror.cpu().numpy(), ref[k], rtol=1e-10)
+    np.testing.assert_array_equal(mirror.cpu().numpy(), np.asarray(ode.values)[k])
+    # no parameters at all for a model that has 53: refused, not run with every parameter at 1.0
+    rc = dev.ctx.lib.beat_ode_step(dev.ctx.handle, _hip.MODEL_TP06_GRL1, dev.states.ptr, n, dev.states.ld, None, 53, None, 0,
+                                   0.0, dt, tp06.state_index("V"), None)
+    assert rc != 0 and b"no parameters" in dev.ctx.lib.beat_last_error()
+
+
 @pytest.mark.parametrize("dim,theta_split,theta_pde", [(2, 1.0, 0.5), (2, 0.5, 1.0), (3, 1.0, 1.0), (3, 0.5, 0.5), (3, 1.0, 0.75)])
 def test_fused_route_equals_literal_route_over_options(dim, theta_split, theta_pde):
     """Fused vs literal stepping (the reference's sequence of copies) over what the other tests hold fixed: 2-D and 3-D

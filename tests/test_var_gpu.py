@@ -214,7 +214,7 @@ def test_tile_ordered_segment_list_gives_the_node_ordered_results(tmp_path):
     res = {}
     for tile in ("0", "8"):
         out = tmp_path / f"tile{tile}.npz"
-        run = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, BEAT_VAR_TILE=tile),
+        run = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, BEAT_VAR_TILE=tile, BEAT_VTL="0"),
                              capture_output=True, text=True, timeout=300)
         assert run.returncode == 0, run.stderr[-2000:]
         res[tile] = np.load(out)
@@ -310,6 +310,7 @@ def test_marching_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, cells, 
     x = rng.standard_normal(n)
     tissue = mf[0] != 0.0
     out = {}
+    monkeypatch.setenv("BEAT_VTL", "0")  # the baseline is the segment-list kernel
     for key, env in (("rows", {"BEAT_VRR": "0"}), ("march2", {"BEAT_VRR": "1", "BEAT_VRR_RY": "2"}), ("march4", {"BEAT_VRR": "1", "BEAT_VRR_RY": "4"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -336,6 +337,120 @@ def test_marching_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, cells, 
         assert np.isclose(pq1, pq0, rtol=1e-12)
         assert abs(it1 - it0) <= 1
         np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-9 * np.abs(x0).max())
+
+
+TILE_CASES = CASES + [((70, 9, 40), (7.0, 0.9, 4.0)), ((61, 12, 35), (6.1, 1.2, 3.5)), ((130, 21, 9), (13.0, 2.1, 0.9)), ((5, 3, 70), (0.5, 0.3, 7.0))]
+
+
+@pytest.mark.parametrize("cells,L", TILE_CASES)
+def test_workgroup_tile_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, cells, L, monkeypatch):
+    """vtl_spmv_kernel (csrc/beat_pde_vtl.hip: a workgroup owns 62 x-nodes x 4 or 8 rows and marches along z; forward
+    coefficients and rows of p loaded once per tile, shared through LDS and registers; raw-buffer loads with out-of-range
+    offsets on the lanes outside the tissue) against var_spmv_kernel (all 15 coefficients gathered per 64-node segment,
+    BEAT_VTL=0) on masked grids with per-cell tensors: q identical bit for bit on every tissue node, nothing written
+    elsewhere (NaN-filled q, NaN ghost planes), p.q equal to the rounding of its summation order, and a whole PCG solve takes
+    the same iterations to the same solution.  Grids with one and several x segments of 62 nodes, row blocks that end
+    inside the box, runs of planes longer and shorter than a tile run (BEAT_VTL_RUN=5 cuts them every 5 planes); tiles dealt
+    round-robin (the default) and taken from the per-XCD counters (BEAT_VTL_DYNAMIC=1: p.q is summed per tile in list order
+    either way, so even the sum is the same bits)."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    ctx = hip_ctx
+    d = len(cells)
+    h = tuple(l / c for l, c in zip(L, cells))
+    active, M = _shell_case(cells, L, 11)
+    nn = tuple(c + 1 for c in cells) + (1,) * (3 - d)
+    mf, kf = _stencil.stencil_fields(d, cells, h, M, active)
+    rng = np.random.default_rng(5)
+    n = int(np.prod(nn))
+    x = rng.standard_normal(n)
+    tissue = mf[0] != 0.0
+    out = {}
+    variants = (("rows", {"BEAT_VTL": "0"}), ("tile4", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "32", "BEAT_VTL_DYNAMIC": "0"}),
+                ("tile8", {"BEAT_VTL": "1", "BEAT_VTL_RY": "8", "BEAT_VTL_RUN": "32", "BEAT_VTL_DYNAMIC": "0"}),
+                ("tile4short", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "5", "BEAT_VTL_DYNAMIC": "0"}),
+                ("tile8counter", {"BEAT_VTL": "1", "BEAT_VTL_RY": "8", "BEAT_VTL_RUN": "16", "BEAT_VTL_DYNAMIC": "1"}),
+                ("tile4counter", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "7", "BEAT_VTL_DYNAMIC": "1"}))
+    monkeypatch.setenv("BEAT_VRR", "0")
+    for key, env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ops = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        ops.ring[0].set(np.where(tissue, x, 0.0))
+        ops.ring[0].ghost_lo.fill_(float("nan"))
+        ops.ring[0].ghost_hi.fill_(float("nan"))
+        ops.q.fill(float("nan"))
+        ops.st.zero_()
+        ops.spmv_dot()
+        ctx.synchronize()
+        q = ops.q.numpy().copy()
+        fv, fx = ops.new_field(), ops.new_field()
+        fv.set(np.where(tissue, -80.0 + 20.0 * x, 0.0))
+        res = ops.solve_single(fv, [], [], fx, 1e-11, 1e-50, 300)
+        out[key] = (q, float(ops.st[3]), fx.numpy().copy(), res.iterations)
+    q0, pq0, x0, it0 = out["rows"]
+    assert np.isfinite(q0[tissue]).all() and np.isnan(q0[~tissue]).all() and abs(pq0) > 0.0
+    for key, _ in variants[1:]:
+        q1, pq1, x1, it1 = out[key]
+        np.testing.assert_array_equal(q1[tissue], q0[tissue], err_msg=key)
+        assert np.isnan(q1[~tissue]).all(), key
+        assert np.isclose(pq1, pq0, rtol=1e-12), key
+        assert abs(it1 - it0) <= 1, key
+        np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-9 * np.abs(x0).max(), err_msg=key)
+
+
+def test_workgroup_tile_spmv_on_a_slab_with_live_ghost_planes(hip_ctx, monkeypatch):
+    """The tile kernel on slab rows cut out of a larger masked grid, ghost planes holding the neighbouring slabs' p: plane 0
+    takes its own stored backward coefficients (the plane below belongs to another rank), the last plane its forward ones;
+    q equals the rows of the global matrix and the segment-list kernel bit for bit."""
+    import scipy.sparse as sp
+
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    ctx = hip_ctx
+    cells, L = (70, 12, 19), (7.0, 1.2, 1.9)
+    h = tuple(l / c for l, c in zip(L, cells))
+    active, M = _shell_case(cells, L, 4)
+    mesh, Mass, K = _oracle_matrices(cells, L, active, M)
+    nx, ny, nz = (c + 1 for c in cells)
+    plane = nx * ny
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    touched = Mass.diagonal() > 0
+    A = (C_m * Mass + theta * dt * K + sp.diags(np.where(touched, 0.0, 1.0))).tocsr()
+    rng = np.random.default_rng(12)
+    xg = rng.standard_normal(mesh.num_nodes)
+    monkeypatch.setenv("BEAT_VRR", "0")
+    for z0, z1 in ((4, 13), (0, 7), (11, nz)):
+        mf, kf = _stencil.stencil_fields(3, cells, h, M, active, z_range=(z0, z1))
+        ref = (A @ xg)[z0 * plane : z1 * plane]
+        tl = touched[z0 * plane : z1 * plane]
+        qs = {}
+        for vtl in ("0", "1"):
+            monkeypatch.setenv("BEAT_VTL", vtl)
+            ops = HipOps(ctx, (nx, ny, z1 - z0), z0 == 0, z1 == nz, mf, kf, per_node=True)
+            ops.set_timestep(C_m, theta, dt)
+            p = ops.ring[0]
+            p.set(xg[z0 * plane : z1 * plane])
+            if z0 > 0:
+                p.ghost_lo.copy_(ctx.from_numpy(xg[(z0 - 1) * plane : z0 * plane]))
+            else:
+                p.ghost_lo.fill_(float("nan"))
+            if z1 < nz:
+                p.ghost_hi.copy_(ctx.from_numpy(xg[z1 * plane : (z1 + 1) * plane]))
+            else:
+                p.ghost_hi.fill_(float("nan"))
+            ops.q.fill(float("nan"))
+            ops.st.zero_()
+            ops.spmv_dot()
+            ctx.synchronize()
+            qs[vtl] = (ops.q.numpy().copy(), float(ops.st[3]))
+        np.testing.assert_allclose(qs["1"][0][tl], ref[tl], rtol=0, atol=1e-12 * np.abs(ref).max())
+        np.testing.assert_array_equal(qs["1"][0][tl], qs["0"][0][tl])
+        assert np.isnan(qs["1"][0][~tl]).all()
+        assert np.isclose(qs["1"][1], qs["0"][1], rtol=1e-12)
 
 
 # ---- API level: voxelised shell, per-cell fibres, transmural cell types (BASELINE configs[4] in small) ---------

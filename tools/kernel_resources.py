@@ -21,7 +21,7 @@ def demangle(names):
     if not tool:
         return names
     out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
-    return [re.sub(r"\(.*", "", n).replace("void ", "").replace("(anonymous namespace)::", "") for n in out]
+    return [re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("void ", "") for n in out]
 
 
 def main():
@@ -38,12 +38,12 @@ def main():
         def g(key):
             m = re.search(key + r": (\d+)", b)
             return int(m.group(1)) if m else -1
-        rows.append([b.split("\n")[0].strip(), g("VGPRs"), g("AGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
-                     g("SGPRs"), g(r"LDS Size \[bytes/block\]")])
+        rows.append([b.split("\n")[0].split(" [-R")[0].strip(), g("VGPRs"), g("AGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
+                     g("TotalSGPRs"), g("SGPRs Spill"), g(r"LDS Size \[bytes/block\]")])
     for r, n in zip(rows, demangle([r[0] for r in rows])):
         r[0] = n
     rows = [r for r in rows if args.filter in r[0]]
-    lines = ["| kernel | VGPRs | AGPRs | scratch B/lane | waves/SIMD | SGPRs | LDS B/block |", "|---|---:|---:|---:|---:|---:|---:|"]
+    lines = ["| kernel | VGPRs | AGPRs | scratch B/lane | waves/SIMD | SGPRs | spilled SGPRs | LDS B/block |", "|---|---:|---:|---:|---:|---:|---:|---:|"]
     lines += ["| `" + r[0] + "` | " + " | ".join(str(v) for v in r[1:]) + " |" for r in rows]
     text = "\n".join(lines)
     print(text)

@@ -25,7 +25,7 @@ title = argv[3] if len(argv) > 3 else d.name
 OURS = ("ode_step_kernel", "stencil_kernel", "cg_update_kernel", "cg_pupdate_kernel", "reduce_partials_kernel",
         "pcg_next_kernel", "pcg_begin_kernel", "minmax_partial_kernel", "copy", "fill_kernel", "fused", "cg_", "x_flush",
         "var_", "assemble_rows", "dot_partial", "rows_dirichlet", "ode_run_kernel", "gather_kernel", "scatter_kernel",
-        "rr_kernel", "rr_next_kernel")
+        "rr_kernel", "rr_next_kernel", "vtl_spmv")
 
 
 def short(name):
