@@ -239,10 +239,20 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def ordering_of(comm_info) -> str:
+    """``config.ordering`` of an N > 1 line: "overlapped" = ghost planes on a side stream behind the interior stencil (the
+    design of DESIGN section 5: transports rccl and ipc), "serial" = every communication operation on the compute stream
+    (rccl-serial; the host-staged callbacks; the stage-driven fallback without a library communicator)."""
+    if comm_info is None:
+        return "serial"
+    return "overlapped" if comm_info.get("transport") in ("rccl", "ipc") else "serial"
+
+
 def launch_ranks(args, argv) -> int:
     """``python bench.py --gpus N`` called directly (no launcher around it, as the driver calls it; the reference's CI
-    starts its parallel job itself too: .github/workflows/main-mpi.yml:33): this process never touches a GPU -- it
-    starts N fresh rank processes (``python -m torch.distributed.run --nproc-per-node N bench.py ...``), relays rank
+    starts its parallel job itself too: .github/workflows/main-mpi.yml:33): this process runs no GPU work -- it counts the
+    devices (which may initialise the HIP runtime here when torch has no amdsmi to ask; the ranks are fresh children
+    either way), starts N fresh rank processes (``python -m torch.distributed.run --nproc-per-node N bench.py ...``), relays rank
     0's one JSON line and their return code, and watches them: a job that prints nothing for longer than the watchdog
     allows is killed (whole process group), and ONE more attempt is made in fresh children with the deadlock-proof
     communication order (``BEAT_DIST_SERIAL=1``: ghost planes and all-reduces on one RCCL communicator, one stream).
@@ -791,6 +801,7 @@ def main():
         if ranks_info is not None:
             out["ranks"] = ranks_info
             out["config"]["comm"] = comm_info
+            out["config"]["ordering"] = ordering_of(comm_info)  # of the transport `value` was measured on
             if comm_info is not None:
                 out["config"]["rccl_ranks"] = comm_info["rccl_ranks"]
             if external_launch:
@@ -818,14 +829,20 @@ def main():
         transports = {main_name: {"ms_per_step": wall / args.steps * 1e3, "pcg_iterations_per_step": float(np.mean(iters)), "role": "headline"}}
         deadline = float(os.environ.get("BEAT_BENCH_ALT_DEADLINE_S", "90"))
 
+        # what give_up prints: a snapshot taken HERE, before the alternatives, so that the timer thread never serialises `out`
+        # or `transports` while the main thread is updating them (adoption of a faster transport rewrites half of `out`)
+        headline_snapshot = json.dumps(out) if rank == 0 else None
+
         def give_up(reason=None):
             """Leave with the headline that is already measured: rank 0 prints its line, every rank exits 0.  Called by the
             deadline timer, and by a rank on which an alternative raised (a transfer that timed out, a failed HIP call):
             the other ranks are then waiting for this one inside the alternative and leave at their own deadline."""
             if rank == 0:
-                transports["error"] = reason or f"an alternative transport made no progress for {deadline:.0f} s; abandoned"
-                out["transports"] = transports
-                print(json.dumps(out), file=result_stream, flush=True)
+                line = json.loads(headline_snapshot)
+                line["transports"] = {main_name: dict(transports[main_name]),
+                                      "error": reason or f"an alternative transport made no progress for {deadline:.0f} s; abandoned"}
+                line["alt_failed"] = True
+                print(json.dumps(line), file=result_stream, flush=True)
             print(f"[bench rank {rank}] alternative transports abandoned" + (f": {reason}" if reason else " at the deadline"),
                   file=sys.stderr, flush=True)
             os._exit(0)
@@ -899,7 +916,7 @@ def main():
                         ob = (16.0 * len(ic) + 8.0 * kp + gb) * n_local
                         out.update(value=n * n * nz_glob * args.steps / hr["wall"], ms_per_step=hr["wall"] / args.steps * 1e3)
                         out["config"].update(pcg_iterations_per_step=k_new, ode_ms=hr["ode_ms"], pde_ms=hr["pde_ms"],
-                                             v_min=-float(ext[0]), v_max=float(ext[1]), comm=alt.info())
+                                             v_min=-float(ext[0]), v_max=float(ext[1]), comm=alt.info(), ordering=ordering_of(alt.info()))
                         out["roofline"].update(achieved=ob / (hr["ode_ms"] * 1e-3) / 1e9, frac=ob / (hr["ode_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                algorithmic_bytes_per_launch=ob, bytes_per_node=16.0 * len(ic) + 8.0 * kp + gb,
                                                pending_directions_per_launch=kp)

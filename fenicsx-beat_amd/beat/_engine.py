@@ -459,8 +459,15 @@ def build_ops(ctx, mesh, M: np.ndarray) -> "HipOps":
             mass_tab, stiff_tab = _stencil.tables_y_as_z(mass_tab), _stencil.tables_y_as_z(stiff_tab)
         return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, mass_tab, stiff_tab)
     if getattr(mesh, "kernel_y_as_z", False):
-        raise NotImplementedError("per-cell conductivities and cell masks on a decomposed 2-D mesh (constant tensors only; "
-                                  "3-D meshes take both on any number of ranks)")
+        # a 2-D mesh cut into slabs of ROWS (the reference's unit-square tests under `mpirun -n 2`,
+        # .github/workflows/main-mpi.yml:33, tests/test_monodomain_solver.py:33-216) with per-cell tensors or a cell mask:
+        # the rows of the whole (small) 2-D operator, this rank's rows of nodes cut out of them, the coefficients moved to
+        # the slots the kernels' (nx, 1, ny_local) grid reads them from
+        mass, stiff = _stencil.stencil_fields(2, mesh.n, mesh.h, M, mesh.active)
+        nxn = mesh.shape_local[0]
+        cut = slice(slab.z0 * nxn, slab.z1 * nxn)
+        return HipOps(ctx, mesh.shape_local, slab.lo_phys, slab.hi_phys, _stencil.fields_y_as_z(mass[:, cut]),
+                      _stencil.fields_y_as_z(stiff[:, cut]), per_node=True)
     per_voxel = (M.ndim == 2 or M.shape[0] == mesh.num_box_cells) and (mesh.active is None or mesh.active_box is not None)
     if per_voxel:
         return HipOps.from_voxels(ctx, mesh.dim, mesh.n, mesh.h, M, mesh.active_box, mesh.shape_local, slab.z0,
@@ -674,6 +681,28 @@ class LibComm:
                 err = exc
             agree("callbacks")
         self.handle = handle
+
+    @classmethod
+    def ipc_in_process(cls, ctx, slab: Slab, plane_doubles: int, registry: dict, barrier) -> "LibComm":
+        """The ipc transport between ranks that are THREADS of this process (each with its own Context): every rank creates
+        its mailbox, `registry[rank]` collects the communicators, `barrier` (threading.Barrier(world)) separates creating
+        from connecting (beat_comm_ipc_connect_local: nothing is exported or opened).  The rehearsal of the target shape --
+        8 ranks, 16 for the all-reduce -- on a box that admits six GPU processes (tests/test_distributed_gpu.py)."""
+        self = cls.__new__(cls)
+        self.ctx, self.slab, self.dist, self.group = ctx, slab, None, None
+        rank, world = slab.rank, slab.world
+        self.peer_lo, self.peer_hi = (-1 if slab.lo_phys else rank - 1), (-1 if slab.hi_phys else rank + 1)
+        self.transport, self.serial, self._allreduce_cb, self.handle = "ipc", False, None, None
+        handle, mine = C.c_void_p(), C.create_string_buffer(_hip.IPC_HANDLE_BYTES)
+        _hip.check(ctx.lib.beat_comm_create_ipc(ctx.handle, rank, world, self.peer_lo, self.peer_hi, int(plane_doubles), None, None,
+                                                None, mine, C.byref(handle)))
+        registry[rank] = handle
+        barrier.wait(timeout=120)
+        arr = (C.c_void_p * world)(*[registry[r] for r in range(world)])
+        _hip.check(ctx.lib.beat_comm_ipc_connect_local(handle, arr, world))
+        barrier.wait(timeout=120)
+        self.handle = handle
+        return self
 
     def info(self) -> dict:
         out = (C.c_int * 4)()

@@ -138,6 +138,7 @@ SIGNATURES.update({
     "beat_comm_create_ipc": (_int, [_vp, _int, _int, _int, _int, _i64, _vp, ALLREDUCE_FN_OR_NULL, _vp, _vp, C.POINTER(_vp)]),
     "beat_comm_ipc_connect": (_int, [_vp, _vp, _vp]),
     "beat_comm_ipc_connect_all": (_int, [_vp, _vp, _int]),
+    "beat_comm_ipc_connect_local": (_int, [_vp, _vp, _int]),
     "beat_comm_info": (_int, [_vp, C.POINTER(_int)]),
     "beat_comm_profile": (_int, [_vp, _int]),
     "beat_comm_profile_read": (_int, [_vp, C.POINTER(_dbl)]),

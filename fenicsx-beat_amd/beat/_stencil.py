@@ -118,6 +118,18 @@ def tables_y_as_z(tab: np.ndarray) -> np.ndarray:
     return out
 
 
+def fields_y_as_z(rows: np.ndarray) -> np.ndarray:
+    """Per-node rows (15, n) of a 2-D operator re-expressed for a grid stored as (nx, 1, ny) -- tables_y_as_z for
+    stencil_fields: the coefficient of offset (dx, dy, 0) moves to the slot of (dx, 0, dy); node numbering unchanged."""
+    out = np.zeros_like(rows)
+    for k, (dx, dy, dz) in enumerate(OFFSETS):
+        if dz == 0:
+            out[_OFFSET_INDEX[(dx, 0, dy)]] = rows[k]
+        elif rows[k].any():
+            raise ValueError("fields_y_as_z: a 2-D operator has no coefficients out of its plane")
+    return out
+
+
 def stencil_fields(dim: int, cells: tuple[int, ...], h, M, active=None, z_range=None) -> tuple[np.ndarray, np.ndarray]:
     """Per-node rows of the same operators for voxel-masked domains and spatially varying conductivity:
     returns (mass, stiff), each (15, n_local) with n_local = nx*ny*(z1-z0) nodes, x fastest.

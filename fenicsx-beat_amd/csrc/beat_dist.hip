@@ -288,6 +288,7 @@ struct beat_comm {
   uint64_t ipc_ar_seq = 0;
   uint64_t ipc_seq = 0;
   long long ipc_ticks = 30LL * 100000000LL;
+  bool ipc_local = false;  // connected with beat_comm_ipc_connect_local: the other mailboxes are this process's own
   // profiling (beat_comm_profile)
   bool profiling = false;
   std::vector<ProfSpan> spans;
@@ -336,7 +337,7 @@ void comm_free(beat_comm* c) {
   if (c->ipc) {
     if (c->ipc_all_connected) {  // the neighbours' mappings are among these: closed once, here
       for (int r = 0; r < c->world && r < BEAT_IPC_MAX_RANKS; ++r)
-        if (r != c->rank && c->ipc_all[r]) (void)hipIpcCloseMemHandle(c->ipc_all[r]);
+        if (r != c->rank && c->ipc_all[r] && !c->ipc_local) (void)hipIpcCloseMemHandle(c->ipc_all[r]);
       c->ipc_peer[0] = IpcPeer();
       c->ipc_peer[1] = IpcPeer();
     }
@@ -552,6 +553,32 @@ extern "C" int beat_comm_ipc_connect_all(beat_comm* c, const void* host_handles,
     if (peers[d] < 0) continue;
     c->ipc_peer[d].box = c->ipc_all[peers[d]];
     c->ipc_peer[d].self = peers[d] == c->rank;
+    c->ipc_peer[d].connected = true;
+  }
+  return BEAT_OK;
+}
+
+// Ranks that live in ONE process (threads, each with its own context and streams: the rehearsal of 8 and 16 ranks on a box
+// that lets six processes at most onto its GPU): the mailboxes are this process's own allocations, so there is nothing
+// to export or open -- every rank is handed the other communicators themselves.  Same kernels, same flags, same slots.
+extern "C" int beat_comm_ipc_connect_local(beat_comm* c, beat_comm* const* host_comms, int count) {
+  BEAT_REQUIRE(c != nullptr && c->ipc && host_comms != nullptr, "not an ipc communicator");
+  BEAT_REQUIRE(count == c->world && c->world <= BEAT_IPC_MAX_RANKS, "%d communicators for %d ranks (at most %d)", count, c->world,
+               BEAT_IPC_MAX_RANKS);
+  BEAT_REQUIRE(!c->ipc_peer[0].connected && !c->ipc_peer[1].connected && !c->ipc_all_connected, "already connected");
+  for (int r = 0; r < c->world; ++r) {
+    const beat_comm* o = host_comms[r];
+    BEAT_REQUIRE(o != nullptr && o->ipc && o->rank == r && o->world == c->world && o->ipc_box != nullptr, "entry %d is not rank %d's ipc communicator", r, r);
+    BEAT_REQUIRE(o->ipc_plane_max == c->ipc_plane_max && o->ctx->device == c->ctx->device, "rank %d: another plane size or another device", r);
+    c->ipc_all[r] = o->ipc_box;
+  }
+  c->ipc_all_connected = true;
+  c->ipc_local = true;  // (nothing was opened: comm_free closes nothing; the owners free their mailboxes)
+  const int peers[2] = {c->peer_lo, c->peer_hi};
+  for (int d = 0; d < 2; ++d) {
+    if (peers[d] < 0) continue;
+    c->ipc_peer[d].box = c->ipc_all[peers[d]];
+    c->ipc_peer[d].self = true;  // never closed
     c->ipc_peer[d].connected = true;
   }
   return BEAT_OK;

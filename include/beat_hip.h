@@ -432,6 +432,11 @@ int beat_comm_create_ipc(beat_ctx* ctx, int rank, int world, int peer_lo, int pe
                          beat_comm** out);
 int beat_comm_ipc_connect(beat_comm* comm, const void* host_handle_lo, const void* host_handle_hi);
 int beat_comm_ipc_connect_all(beat_comm* comm, const void* host_handles, int count);
+/* The same for ranks that are THREADS of one process (each with its own beat_ctx; rehearsals of 8 and 16 ranks on one
+ * GPU, tests/_ipc_ranks_script.py): host_comms[r] = rank r's ipc communicator; nothing is exported or opened, every
+ * communicator must outlive the others' last use of it.  Reference analogue: the PETSc reductions and ghost updates inside
+ * KSP.solve / scatter_forward, src/beat/base_model.py:203-206,236,242, which the reference's CI runs under mpirun -n 2. */
+int beat_comm_ipc_connect_local(beat_comm* comm, beat_comm* const* host_comms, int count);
 int beat_comm_destroy(beat_comm* comm);
 /* host_out[4]: transport (BEAT_TRANSPORT_*), ranks of the all-reduce communicator as RCCL itself counts them
  * (ncclCommCount; 0 without RCCL), world as given at creation, who sums: 1 RCCL, 2 the ipc mailboxes, 0 the caller. */

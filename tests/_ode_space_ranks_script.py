@@ -1,7 +1,7 @@
 """Run through torch.distributed.run by tests/test_distributed_gpu.py: the split system of the reference's
 tests/test_monodomain_solver.py (forward-Euler test ODE, source term in the PDE) on a 3-D box, with the ODE on a P2 or
 DG1 space and the conductivity built from a NODAL fibre function -- on every rank of a z-slab decomposition.
-argv: out_dir odespace"""
+argv: out_dir odespace [dim [percell]]   (dim 2: the reference's unit square, cut into slabs of rows; percell: a tensor per cell)"""
 import os
 import sys
 from pathlib import Path
@@ -23,6 +23,7 @@ from beat import grid as g  # noqa: E402
 
 out_dir, odespace = Path(sys.argv[1]), sys.argv[2]
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+percell = len(sys.argv) > 4 and sys.argv[4] == "percell"  # 2-D: a tensor per cell (beat.grid.CellField) instead of a constant one
 comm = g.COMM_WORLD
 if dim == 3:
     mesh = g.create_box(comm, [np.zeros(3), np.array([1.0, 1.0, 0.75])], [12, 10, 9])
@@ -37,6 +38,13 @@ if dim == 3:
     f0 = g.Function(W)
     f0.interpolate(lambda p: np.stack([np.cos(1.3 * p[2]), np.sin(1.3 * p[2]), 0.0 * p[0]]))
     M = beat.conductivities.define_conductivity_tensor(f0=f0, chi=1.0, g_il=1.0, g_it=0.4, g_el=1.0, g_et=0.4)
+elif percell:
+    # a conductivity tensor per box cell (what define_conductivity_tensor gives for per-cell fibres; per-cell M is how the
+    # reference's ventricular demos build theirs, src/beat/conductivities.py:101-118): rotating with x, stiffer towards y = 1
+    cc = g.cell_centers(mesh)
+    ang = 0.9 * cc[:, 0] + 0.4 * cc[:, 1]
+    f = np.stack([np.cos(ang), np.sin(ang)], axis=-1)
+    M = g.CellField(mesh, (0.4 + 0.3 * cc[:, 1])[:, None, None] * np.eye(2)[None] + 0.6 * f[:, :, None] * f[:, None, :])
 else:
     M = np.array([[1.0, 0.2], [0.2, 0.6]])
 pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, params={"petsc_options": {"ksp_rtol": 1e-12}})

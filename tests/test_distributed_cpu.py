@@ -304,6 +304,80 @@ def test_two_dimensional_mesh_is_cut_into_slabs_of_rows(tmp_path):
         np.testing.assert_allclose(y, mat @ x, rtol=0, atol=1e-12 * np.abs(mat @ x).max())
 
 
+def _percell2d_problem():
+    from oracle import fem
+
+    cells, L = (14, 11), (1.4, 1.1)
+    mesh = fem.BoxMesh(cells, L)
+    rng = np.random.default_rng(4)
+    cc = np.stack(np.meshgrid((np.arange(cells[1]) + 0.5) / cells[1], (np.arange(cells[0]) + 0.5) / cells[0], indexing="ij"), -1)[..., ::-1].reshape(-1, 2)
+    ang = 2.0 * cc[:, 0] + 0.7 * cc[:, 1] + 0.2 * rng.standard_normal(len(cc))
+    f = np.stack([np.cos(ang), np.sin(ang)], axis=-1)
+    M = 2e-4 * np.eye(2)[None] + 8e-4 * f[:, :, None] * f[:, None, :]
+    active = ((cc - 0.5) ** 2).sum(axis=1) < 0.46**2  # a disc of active cells: rows of nodes without any tissue at the rim
+    v_prev = -80.0 + 50.0 * np.exp(-((mesh.x - np.array([0.5, 0.6])) ** 2).sum(axis=1) / 0.03)
+    return mesh, cells, tuple(l / c for l, c in zip(L, cells)), M, active, v_prev
+
+
+def _percell2d_worker(rank, world, port, out_dir):
+    for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle_ops import CpuField, OracleOps
+        from beat import _stencil
+        from beat import grid as g
+        from beat._engine import DiffusionSolver
+
+        mesh_o, cells, h, M, active, v_prev = _percell2d_problem()
+        mesh = g.create_rectangle(g.COMM_WORLD, [np.zeros(2), np.array([1.4, 1.1])], list(cells))
+        slab = mesh.slab
+        assert mesh.kernel_y_as_z and (slab.rank, slab.world) == (rank, world)
+        nxn = mesh.shape_local[0]
+        # what beat._engine.build_ops does for such a mesh (there with the HIP operators): the 2-D rows, this rank's rows of
+        # nodes, coefficients moved to the slots of the (nx, 1, rows) grid
+        mass, stiff = _stencil.stencil_fields(2, cells, h, M, active)
+        cut = slice(slab.z0 * nxn, slab.z1 * nxn)
+        ops = OracleOps(mesh.shape_local, slab.lo_phys, slab.hi_phys, _stencil.fields_y_as_z(mass[:, cut]),
+                        _stencil.fields_y_as_z(stiff[:, cut]), per_node=True)
+        ops.set_timestep(C_M, THETA, DT)
+        solver = DiffusionSolver(ops, slab, group=mesh.comm.group)
+        fv, fx = CpuField(ops.n, nxn), CpuField(ops.n, nxn)
+        tissue = mass[0, cut] != 0.0
+        fv.data.copy_(torch.from_numpy(np.where(tissue, v_prev[cut], 0.0)))
+        res = solver.solve(fv, [], [], fx, rtol=1e-12, atol=1e-50, max_it=500)
+        np.savez(Path(out_dir) / f"rank{rank}.npz", x=fx.numpy(), its=res.iterations, reason=res.converged_reason, z0=slab.z0, z1=slab.z1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_cell_tensors_and_mask_on_a_two_dimensional_mesh_cut_into_rows(world, tmp_path):
+    """The last NotImplementedError on a path the reference's parallel CI reaches (tests/test_monodomain_solver.py:33-216
+    under `mpirun -n 2`, .github/workflows/main-mpi.yml:33): a 2-D mesh on several ranks with a conductivity tensor per cell
+    and a cell mask.  Every rank cuts its rows of nodes out of the 2-D per-node operator and hands them to the kernels'
+    (nx, 1, rows) grid with the coefficients moved to the y-as-z slots (_stencil.fields_y_as_z); the theta-step solved by the
+    decomposed PCG on gloo equals the sparse-LU solve of the undivided masked problem assembled by the oracle."""
+    from oracle import fem
+
+    port = _free_port()
+    mp.spawn(_percell2d_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mesh, cells, h, M, active, v_prev = _percell2d_problem()
+    act_s = np.repeat(active, 2)
+    model = fem.OracleMonodomainModel(mesh, np.repeat(M, 2, axis=0), [], C_m=C_M, theta=THETA, default_timestep=DT, active_cells=act_s)
+    tissue = fem.assemble_mass(mesh, np.nonzero(act_s)[0]).diagonal() > 0
+    model.state[:] = np.where(tissue, v_prev, 0.0)
+    model.assign_previous()
+    model.step((0.0, DT))
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert [int(p["z0"]) for p in parts] == [0] + [int(p["z1"]) for p in parts[:-1]] and int(parts[-1]["z1"]) == cells[1] + 1
+    x = np.concatenate([p["x"] for p in parts])
+    assert np.abs(x - model.state)[tissue].max() <= 1e-9 * np.abs(model.state).max()
+    assert len({int(p["its"]) for p in parts}) == 1 and all(int(p["reason"]) > 0 for p in parts)
+
+
 def _layout_worker(rank, world, port, out_dir):
     for p in (str(ROOT), str(ROOT / "fenicsx-beat_amd"), str(ROOT / "tests")):
         if p not in sys.path:

@@ -159,7 +159,7 @@ def _thread_solver(ops, slab, dist_view, loop):
 
 @pytest.mark.parametrize("loop", ["lib", "stage"])
 @pytest.mark.parametrize("per_node,world,nz", [(False, 2, 19), (False, 3, 19), (True, 3, 19), (False, 4, 5), (True, 4, 6),
-                                               (False, 5, 5)])
+                                               (False, 5, 5), (False, 8, 19), (True, 8, 21)])
 def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, loop):
     """world ranks as threads, each with its own context, slab operators and DiffusionSolver: the assembled solution
     equals the undivided solve, iteration counts agree, and the deferred last update flushes to the same values --
@@ -403,6 +403,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     # (an alternative that is > 3 % faster in the regime both were timed in gets the headline regime re-measured on it, and
     # that measurement becomes `value`: host-staged callbacks against device-to-device copies -- ipc usually wins here)
     assert r["config"]["comm"]["transport"] == ("ipc" if choice["adopted"] else "callbacks")
+    # the ordering `value` was measured on is spelt out at the top of config, whichever branch produced the line
+    assert r["config"]["ordering"] == ("overlapped" if choice["adopted"] else "serial")
     if choice["adopted"]:
         assert r["transports"]["ipc (headline)"]["ms_per_step"] == r["ms_per_step"] < r["transports"]["callbacks"]["ms_per_step"]
     ipc = r["transports"]["ipc"]
@@ -414,6 +416,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
                           env=dict(env, BEAT_BENCH_TEST_HANG="1", BEAT_BENCH_WATCHDOG_START_S="20", BEAT_BENCH_WATCHDOG_S="20"))
     assert hung.returncode != 0 and time.perf_counter() - tic < 200
     assert hung.stderr.count("killing the ranks") == 2 and "BEAT_DIST_SERIAL" in hung.stderr and not hung.stdout.strip()
+
+
+def test_bench_with_four_ranks_sharing_one_gpu(tmp_path):
+    """``BEAT_DIST_BACKEND=gloo python bench.py --gpus 4 --size 80``: the launcher, four rank processes on this box's one GPU
+    (the pool's process guard admits six processes with the GPU open: the test runner and a launcher are two), slabs of 20
+    planes, the headline over the host-staged transport and the same steps over the mailboxes with four real processes: ONE
+    line, n_gpus 4, four `ranks` entries that add up to the grid, the ordering spelt out, finite potentials."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["BEAT_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "4", "--size", "80", "--steps", "4", "--warmup", "1"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 4 and r["config"]["nodes"] == 80**3 and r["config"]["finite"]
+    assert [x["rank"] for x in r["ranks"]] == [0, 1, 2, 3] and sum(x["nodes"] for x in r["ranks"]) == 80**3
+    assert r["config"]["ordering"] in ("serial", "overlapped") and r["config"]["comm"]["world"] == 4
+    ipc = r["transports"]["ipc"]
+    assert "error" not in ipc and ipc["comm"]["transport"] == "ipc" and ipc["comm"]["allreduce"] == "ipc" and ipc["ms_per_step"] > 0
 
 
 @pytest.mark.parametrize("failing_rank", [0, 1])
@@ -440,12 +469,72 @@ def test_bench_alternative_transport_failing_on_one_rank_keeps_the_headline(fail
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["finite"]
     # (rank 0 reports its own failure, or -- when the other rank left -- the broken connection it then meets, or the deadline)
     assert "error" in r["transports"] and ("raised on rank" in r["transports"]["error"] or "no progress" in r["transports"]["error"])
+    assert r["alt_failed"] is True and r["config"]["ordering"] == "serial"  # (the headline's transport: host-staged callbacks)
     assert "abandoned" in run.stderr
 
 
-@pytest.mark.parametrize("world,transport", [(2, "callbacks"), (3, "callbacks"), (3, "ipc")])
+def _ipc_ranks(tmp_path, *args, timeout=240):
+    """tests/_ipc_ranks_script.py in a fresh interpreter with enough hardware queues for 2 x world streams whose kernels wait
+    for each other (the runtime's default of four would put a waiting kernel in front of the one it waits for) and a short
+    leash on every wait (BEAT_IPC_TIMEOUT_S: a rank that gives up raises an error word, the script fails, nothing hangs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    out = tmp_path / "out.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GPU_MAX_HW_QUEUES="48", BEAT_IPC_TIMEOUT_S="20")
+    run = subprocess.run([sys.executable, str(root / "tests" / "_ipc_ranks_script.py"), *[str(a) for a in args], str(out)],
+                         capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    return json.loads(out.read_text())
+
+
+@pytest.mark.parametrize("world", [8, 16])
+def test_mailbox_allreduce_with_8_and_16_ranks_wraps_its_slot_ring_under_skew(world, tmp_path):
+    """The all-reduce of the ipc transport (csrc/beat_dist.hip: ipc_allreduce_kernel -- every rank stores its 1-3 values and a
+    sequence flag into EVERY rank's mailbox and adds what arrives in its own in rank order; four slots) with the rank counts
+    it is written for and had never run with: 8 (the target decomposition: 512^3 in 8 slabs of 64 planes) and 16
+    (BEAT_IPC_MAX_RANKS).  240 consecutive reductions of 1, 2, 3 values spanning 16 orders of magnitude, the ranks taking
+    turns at being held back on the host so that the others run ahead until the slot ring stops them: every result on every
+    rank equals the rank-ordered sum bit for bit (the convergence latch of the PCG relies on exactly that).  Ranks are
+    threads of one process, each with its own context and streams (beat_comm_ipc_connect_local): the boxes of this pool
+    admit at most six GPU processes.  Reference analogue: the reductions inside KSP.solve, src/beat/base_model.py:236, under
+    the reference's `mpirun -n 2` CI (.github/workflows/main-mpi.yml:33)."""
+    r = _ipc_ranks(tmp_path, "allreduce", world, 240)
+    assert r["world"] == world and r["rounds"] == 240 and r["bitwise_equal_on_every_rank"] is True
+
+
+def test_mailbox_ghost_plane_exchange_between_8_ranks(tmp_path):
+    """60 ghost-plane exchanges between 8 ranks (threads, see above) over the mailboxes -- transfer kernels on every rank's
+    side stream, sequence flags, four slots per direction, ranks held back in turn: every ghost plane holds the
+    neighbour's boundary plane of THAT round (src/beat/base_model.py:242: scatter_forward)."""
+    r = _ipc_ranks(tmp_path, "exchange", 8, 60)
+    assert r["world"] == 8 and r["wrong_ghost_planes"] == 0
+
+
+def test_decomposed_solve_on_8_ranks_over_the_mailboxes_matches_the_undivided_solve(tmp_path):
+    """beat_pde_solve_dist on 8 slabs of 2-3 planes (threads, mailboxes for ghost planes AND dot products; no RCCL, no
+    host in the loop) against the undivided solve: constant-coefficient rows (ghost planes of r, p formed on the ghost
+    planes) and per-node rows (split SpMV, exchange of p), three solves each so that the extrapolated guess and its ghost
+    planes take part; same values to 1e-9 of the scale, iteration counts within one of the undivided solve's and alike on
+    all eight ranks."""
+    r = _ipc_ranks(tmp_path, "solve", 8, timeout=400)
+    for kind in ("constant", "per_node"):
+        c = r[kind]
+        assert c["max_abs_diff"] <= 1e-9 * c["scale"], (kind, c)
+        assert all(its == c["iterations_ranks"][0] for its in c["iterations_ranks"]), (kind, c)
+        assert all(abs(a - b) <= 1 for a, b in zip(c["iterations_ranks"][0], c["iterations_whole"])), (kind, c)
+
+
+@pytest.mark.parametrize("world,transport", [(2, "callbacks"), (3, "callbacks"), (3, "ipc"), (4, "ipc")])
 def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_path):
-    """(transport "ipc": the three processes exchange their ghost planes ON THE DEVICE -- each maps its neighbours' mailboxes
+    """(world 4: what the boxes of this pool admit next to the test runner and the launcher -- six processes with the GPU open
+    in all, a run with five ranks was killed by the guard; 8 and 16 ranks run as threads, test_mailbox_* above.)
+    (transport "ipc": the processes exchange their ghost planes ON THE DEVICE -- each maps its neighbours' mailboxes
     with hipIpcOpenMemHandle and copies its boundary planes into them on the library's side stream, ordered by
     sequence flags in device memory, and the dot products are summed through all three mailboxes (rank order, the same
     bits on every rank): nothing of the solve goes through gloo or RCCL.)
@@ -489,12 +578,15 @@ def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_p
         assert bool(p["roundtrip_ok"]) and abs(float(a["leads"][0])) > 0.0
 
 
-@pytest.mark.parametrize("odespace,dim,world", [("CG_2", 3, 2), ("DG_1", 3, 2), ("CG_1", 2, 2), ("CG_2", 2, 3), ("DG_1", 2, 2)])
-def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, dim, world, tmp_path):
+@pytest.mark.parametrize("odespace,dim,world,percell", [("CG_2", 3, 2, False), ("DG_1", 3, 2, False), ("CG_1", 2, 2, False), ("CG_2", 2, 3, False),
+                                                        ("DG_1", 2, 2, False), ("CG_1", 2, 2, True), ("CG_2", 2, 3, True)])
+def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, dim, world, percell, tmp_path):
     """tests/_ode_space_ranks_script.py -- the reference's split test system (tests/test_monodomain_solver.py:33-216, which
     its CI also runs under ``mpirun -n 2``) in 3-D with the ODE on a P2 / DG1 space and the conductivity from a nodal
     fibre function -- on two processes (z-slabs; dofs on the cut interpolate across it through the exchanged ghost plane)
-    against one: potential and second state at the vertices equal to 1e-11, same PCG iteration count."""
+    against one: potential and second state at the vertices equal to 1e-11, same PCG iteration count.  ``percell``: the 2-D
+    mesh with a conductivity tensor PER CELL (per-node rows cut out of the 2-D operator per rank and re-expressed for the
+    kernels' (nx, 1, rows) grid, _stencil.fields_y_as_z; round 3 raised NotImplementedError here)."""
     import os
     import subprocess
     import sys
@@ -507,10 +599,11 @@ def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(o
     d2.mkdir()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     # (dim = 2: the reference's own unit-square mesh cut into slabs of ROWS -- the kernels see it as the grid (nx, 1, ny_local))
-    one = subprocess.run([sys.executable, script, str(d1), odespace, str(dim)], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    extra = ["percell"] if percell else []
+    one = subprocess.run([sys.executable, script, str(d1), odespace, str(dim), *extra], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert one.returncode == 0, one.stderr[-3000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-                          "127.0.0.1", "--master-port", str(_free_port()), script, str(d2), odespace, str(dim)],
+                          "127.0.0.1", "--master-port", str(_free_port()), script, str(d2), odespace, str(dim), *extra],
                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, BEAT_DIST_BACKEND="gloo"))
     assert two.returncode == 0, two.stderr[-3000:]
     a = np.load(d1 / "rank0.npz")

@@ -60,12 +60,23 @@ int main(int argc, char** argv) {
   const bool per_node = got == P.size() && n > 1;
   if (!per_node && got < (size_t)Model::NP) return 3;
   const HostMath fm;
+  // optional: <nsteps> <steps_per_beat> -- the in-kernel time loop of beat_ode_run on the host: nsteps steps in all, t restarts
+  // at the given t every steps_per_beat steps (src/beat/single_cell.py:86-156 paces a cell this way)
+  const long nsteps = argc > 7 ? std::atol(argv[7]) : 1;
+  const long per_beat = argc > 8 ? std::atol(argv[8]) : nsteps;
+  std::vector<typename Model::Derived> Q;
+  std::vector<double> PL((size_t)Model::NP * n);
   for (long i = 0; i < n; ++i) {
-    double pl[Model::NP];
-    for (int k = 0; k < Model::NP; ++k) pl[k] = per_node ? P[(long)k * n + i] : P[k];
-    const Model::Derived q = Model::derive(pl);
-    const HostIO io{S.data(), O.data(), n, i};
-    Model::step(io, pl, q, fm, t, dt);
+    for (int k = 0; k < Model::NP; ++k) PL[(size_t)i * Model::NP + k] = per_node ? P[(size_t)k * n + i] : P[k];
+    Q.push_back(Model::derive(&PL[(size_t)i * Model::NP]));
+  }
+  for (long j = 0; j < nsteps; ++j) {
+    const double tj = t + (double)(j % per_beat) * dt;
+    for (long i = 0; i < n; ++i) {
+      const HostIO io{S.data(), O.data(), n, i};
+      Model::step(io, &PL[(size_t)i * Model::NP], Q[(size_t)i], fm, tj, dt);
+    }
+    if (j + 1 < nsteps) S.swap(O);
   }
   f = std::fopen(argv[3], "wb");
   if (!f) return 4;
