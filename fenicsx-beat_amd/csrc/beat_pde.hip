@@ -1306,19 +1306,33 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     }
   } else {
     // Jacobi, deferred x: iteration i uses p_i = ring[i % PRING]
+    // per-node rows on one slab (round 4): the tile kernel forms p_i = D^-1 r + beta p_{i-1} while loading, stores it and
+    // q = A p_i in the same pass (beat_vtl_pdot) -- the direction update is no pass of its own any more (32 B/node and a
+    // launch per iteration); same expressions, same bits as the three-kernel iteration (BEAT_VTL_PDOT=0)
+    const bool pdot = pde->var && beat_vtl_pdot_available(pde);
     while (true) {
       chunk = std::min(chunk, max_it - launched);
       for (int it = 0; it < chunk; ++it) {
         const int i = launched + it, slot = i % PRING;
         double* p_cur = ring + (int64_t)slot * fld;
         double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
-        if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
+        if (pdot) {
+          const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+          if ((rc = beat_vtl_pdot(pde, st, r, p_old, p_cur, q, i == 0))) return rc;
+        } else if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) {
+          return rc;
+        }
         if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
         if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
           if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
             return rc;
         }
-        if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
+        if (pdot) {  // the scalar roll alone: beta for the next pass, the latch, the iteration count
+          BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, st);
+          BEAT_LAUNCH_CHECK();
+        } else if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) {
+          return rc;
+        }
       }
       launched += chunk;
       BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -152,6 +152,8 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& host_ti
 void beat_vtl_destroy(beat_pde* pde);
 bool beat_vtl_available(const beat_pde* pde);
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
+bool beat_vtl_pdot_available(const beat_pde* pde);
+int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q, int first);
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

@@ -56,6 +56,11 @@ struct VtlArgs {
   const VtlItem* items;
   const int* xcd_first;    // 9 entries: the part of the tile list each XCD walks
   int* next;               // 8 counters (next tile of each part) + the number of workgroups done
+  // PDOT (the solver's iteration): x = the PREVIOUS search direction, the new one is formed while loading --
+  // p = D^-1 r + beta p_old, D^-1 = 1 / the row's own centre coefficient -- and stored to pnew
+  const double* r;
+  double* pnew;
+  int first;               // iteration 0: p = D^-1 r (beta = 0, p_old not read)
 };
 
 __device__ __forceinline__ double vtl_from_left(double v) {
@@ -89,7 +94,7 @@ __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsi
 
 // forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
 // 13 +x+y+z; the backward slot k+1 pairs with the forward slot k.  F[] below holds them in that order.
-template <int RY, bool DYN>
+template <int RY, bool DYN, bool PDOT>
 __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
   // one LDS array: p of plane z+1 for rows y0-1 .. y0+RY of the tile (two buffers), slots 3, 7, 9, 13 of plane z for rows
   // y0-1 .. y0+RY-2 (two buffers), and a row per wave that absorbs the stores of a wave without a (second) halo load
@@ -167,6 +172,38 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     auto ldc = [&](u64 mk, int slot, int z, unsigned ro) -> double {
       return vtl_buf_load(A + (int64_t)slot * a.ld + (int64_t)z * a.plane, pbytes, lane_off(mk, ro));
     };
+    // PDOT: a value of p is formed from three loads -- the residual, the previous direction and the row's centre coefficient
+    // c0 (D^-1 = 1 / c0, rounded as var_form_A_kernel rounds the stored 1/diag; p = fma(beta, p_old, D^-1 r): the very
+    // expression of var_pupdate_oop_kernel, so the same bits) -- wherever the SpMV needs it: the own row, the rows above and
+    // below, the halo lanes.  Redundant arithmetic on the halo, no second pass over r, p_old and 1/diag (32 B/node).
+    const double* __restrict__ Rr = PDOT ? a.r : nullptr;
+    const double beta = PDOT ? a.st[BETA] : 0.0;
+    const bool first = PDOT && a.first != 0;
+    struct Trio {
+      double r, q, c0;
+    };
+    auto form = [&](const Trio& t) -> double {
+      const double di = 1.0 / t.c0;
+      const double zz = di * t.r;
+      const double pv = first ? zz : fma(beta, t.q, zz);
+      return t.c0 != 0.0 ? pv : 0.0;  // (a lane that loaded nothing: c0 = 0)
+    };
+    auto ld3 = [&](u64 mk, int z, unsigned ro) -> Trio {
+      const unsigned off = lane_off(mk, ro);
+      Trio t;
+      t.r = vtl_buf_load(Rr + (int64_t)z * a.plane, pbytes, off);
+      t.q = vtl_buf_load(X + (int64_t)z * a.plane, pbytes, first ? VTL_OOB : off);
+      t.c0 = vtl_buf_load(A + (int64_t)z * a.plane, pbytes, off);
+      return t;
+    };
+    // (a ghost plane of a physical face: its mask is empty, nothing is loaded, p = 0; the decomposed solve does not come here)
+    auto ldpv = [&](u64 mk, int z, unsigned ro) -> double {  // p at (row ro, plane z), straight from memory
+      if constexpr (PDOT) {
+        return form(ld3(mk, z, ro));
+      } else {
+        return ldp(mk, z, ro);
+      }
+    };
     // the halo rows of the tile: p of rows y0-1 and y0+RY (consumed like the waves' own p: loaded for plane z+2 at step
     // z), slots 3, 7, 9, 13 of row y0-1 (like the own coefficients: plane z+1 at step z); wave w takes halo loads w and
     // w + RY of the six (e: 0 = p below, 1 = p above, 2..5 = slot 3 / 7 / 9 / 13 of the row below).  What a halo load
@@ -180,7 +217,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     const int moff_b = ((min(max(halo_row(eb), -1), a.ny) + 1) * a.nsegx + item.seg) * a.nzp + 1;
     auto halo_plane = [&](int e, int z) -> int { return z + (e < 2 ? 2 : 1); };  // what step z loads (step z+1 publishes)
     auto halo_mask = [&](int e, int moff, int z) -> u64 { return MASK[moff + halo_plane(e, z)]; };
-    auto halo_load = [&](int e, u64 mk, unsigned ro, int z) -> double {
+    auto halo_load = [&](int e, u64 mk, unsigned ro, int z) -> Trio {
       const bool is_p = e < 2;
       const int zz = halo_plane(e, z);
       const bool want = e < 6 && zz <= (is_p ? ze : ze - 1);
@@ -188,8 +225,26 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       int64_t ld = a.ld;
       asm volatile("" : "+s"(ld));
       const int slot = (0xD973 >> (4 * ((e - 2) & 3))) & 15;  // 3, 7, 9, 13
-      const double* base = is_p ? X : A + slot * ld;
-      return vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, lane_off(m, ro));
+      Trio t{0.0, 0.0, 0.0};
+      if constexpr (PDOT) {
+        // a p entry is three loads (r, p_old, c0), a coefficient entry one: the two others run with every lane out of range
+        const double* base = is_p ? Rr : A + slot * ld;
+        const unsigned off = lane_off(m, ro), offp = is_p ? off : VTL_OOB;
+        t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, off);
+        t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, first ? VTL_OOB : offp);
+        t.c0 = vtl_buf_load(A + (int64_t)zz * a.plane, pbytes, offp);
+      } else {
+        const double* base = is_p ? X : A + slot * ld;
+        t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, lane_off(m, ro));
+      }
+      return t;
+    };
+    auto halo_value = [&](int e, const Trio& t) -> double {  // what is published: p of the halo row, or the coefficient
+      if constexpr (PDOT) {
+        return e < 2 ? form(t) : t.r;
+      } else {
+        return t.r;
+      }
     };
     auto halo_lds = [&](int e, int z) -> int {  // where step z publishes it
       const int par = (e < 2 ? z + 1 : z) & 1;
@@ -201,6 +256,8 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     // ---- prologue: the planes below the run, straight from memory ------------------------------------------------------
     u64 M0 = MASK[mo_own + zb], M1 = MASK[mo_own + zb + 1], M2 = MASK[mo_own + zb + 2];
     double Pm, P0, U0, D0, Dm, K5, K9, K11, K13;
+    double C0keep = 0.0;  // PDOT: the centre coefficient of the plane after this one's p was formed from, until it is F[0]
+    const u64 out_lanes = ((1ull << SEG) - 1ull) << 1;
     bool direct = zb == 0;
     {
       const int mo_up = ((tyu + 1) * a.nsegx + item.seg) * a.nzp + 1;
@@ -208,11 +265,19 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       const unsigned roff_up = (unsigned)(min(gy + 1, a.ny - 1) * a.nx + cx);
       const unsigned roff_dn = (unsigned)(max(gy - 1, 0) * a.nx + cx);
       const u64 mo = MASK[mo_own + zb - 1], md = MASK[mo_dn + zb - 1];
-      Pm = ldp(mo, zb - 1, roff);
-      P0 = ldp(M0, zb, roff);
-      U0 = ldp(MASK[mo_up + zb], zb, roff_up);
-      D0 = ldp(MASK[mo_dn + zb], zb, roff_dn);
-      Dm = ldp(md, zb - 1, roff_dn);
+      Pm = ldpv(mo, zb - 1, roff);
+      if constexpr (PDOT) {
+        const Trio t0 = ld3(M0, zb, roff);
+        P0 = form(t0);
+        C0keep = t0.c0;
+        // this tile's first plane of the new direction (the later ones are stored as they are formed, one plane ahead)
+        vtl_buf_store(a.pnew + (int64_t)zb * a.plane, pbytes, (M0 & lanebit & out_lanes) ? roff * 8u : VTL_OOB, P0);
+      } else {
+        P0 = ldp(M0, zb, roff);
+      }
+      U0 = ldpv(MASK[mo_up + zb], zb, roff_up);
+      D0 = ldpv(MASK[mo_dn + zb], zb, roff_dn);
+      Dm = ldpv(md, zb - 1, roff_dn);
       // coefficients of the plane below towards this one: slots 5 / 11 of the own row, 9 / 13 of the row below.  Plane 0
       // of a slab has no stored plane below it: its own backward slots 6, 10, 12, 14 are used as they are (what
       // var_spmv_kernel does; zero on a physical face)
@@ -233,7 +298,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       int64_t ld = a.ld;
       asm volatile("" : "+s"(ld));
       const double* bc = A + (int64_t)z * a.plane;
-      Fn[0] = vtl_buf_load(bc, pbytes, off);
+      Fn[0] = PDOT ? 0.0 : vtl_buf_load(bc, pbytes, off);  // (PDOT: the centre coefficient comes with r and p_old, a plane earlier)
       bc += ld;
       Fn[1] = vtl_buf_load(bc, pbytes, off);
       ld += ld;
@@ -244,23 +309,40 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       }
     };
     load_coefs(M0, zb);
-    double Pn = ldp(M1, zb + 1, roff);
-    double Ean = halo_load(ea, halo_mask(ea, moff_a, zb - 1), roff_a, zb - 1);
-    double Ebn = 0.0;
+    double Pn = 0.0;
+    Trio Tn{0.0, 0.0, 0.0};
+    if constexpr (PDOT) {
+      Tn = ld3(M1, zb + 1, roff);
+    } else {
+      Pn = ldp(M1, zb + 1, roff);
+    }
+    Trio Ean = halo_load(ea, halo_mask(ea, moff_a, zb - 1), roff_a, zb - 1);
+    Trio Ebn{0.0, 0.0, 0.0};
     if (TWO) Ebn = halo_load(eb, halo_mask(eb, moff_b, zb - 1), roff_b, zb - 1);
     u64 HA = halo_mask(ea, moff_a, zb), HB = TWO ? halo_mask(eb, moff_b, zb) : 0ull;  // masks of the loads step zb issues
     for (int z = zb; z < ze; ++z) {
       double F[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) F[k] = Fn[k];
-      const double Pp = Pn, Ea = Ean, Eb = Ebn;
+      double Pp = Pn;
+      if constexpr (PDOT) {
+        Pp = form(Tn);  // p of plane z + 1, from what step z - 1 requested
+        F[0] = C0keep;
+        C0keep = Tn.c0;
+        vtl_buf_store(a.pnew + (int64_t)(z + 1) * a.plane, pbytes, (z + 1 < ze && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
+      }
+      const double Ea = halo_value(ea, Ean), Eb = TWO ? halo_value(eb, Ebn) : 0.0;
       // masks: one step (the halo loads') and two steps (the own row's) ahead of their use
       const u64 M3 = MASK[mo_own + z + 3];
       const u64 HAn = halo_mask(ea, moff_a, z + 1);
       const u64 HBn = TWO ? halo_mask(eb, moff_b, z + 1) : 0ull;
       // next step's operands
       load_coefs(z + 1 < ze ? M1 : 0ull, z + 1);
-      Pn = ldp(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
+      if constexpr (PDOT) {
+        Tn = ld3(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
+      } else {
+        Pn = ldp(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
+      }
       Ean = halo_load(ea, HA, roff_a, z);
       if (TWO) Ebn = halo_load(eb, HB, roff_b, z);
       // publish this row
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < 15; ++k) s = fma(c[k], (k == 0 || c[k] != 0.0) ? v[k] : 0.0, s);
-      const bool out = (M0 & lanebit & (((1ull << SEG) - 1ull) << 1)) != 0ull;
+      const bool out = (M0 & lanebit & out_lanes) != 0ull;
       acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
       vtl_buf_store(Y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
       // roll: this plane becomes the plane below
@@ -362,6 +444,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
 struct VtlData {
   int ry = 4;
   bool dyn = false;
+  bool pdot = true;  // BEAT_VTL_PDOT=0: the three-kernel iteration (SpMV, residual update, direction update)
   VtlItem* d_items = nullptr;
   int* d_xcd_first = nullptr;  // 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
   u64* d_mask = nullptr;
@@ -371,7 +454,7 @@ struct VtlData {
 
 template <int RY>
 unsigned vtl_resident_blocks() {
-  auto kernel = vtl_spmv_kernel<RY, true>;
+  auto kernel = vtl_spmv_kernel<RY, true, true>;
   int dev = 0, cus = 256, per_cu = 1;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -413,6 +496,8 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
     // the whole workgroup waiting behind it once per tile, cost 560 against 375 us per launch: 12.85 against 11.24 ms/step
     const char* dy = std::getenv("BEAT_VTL_DYNAMIC");
     d->dyn = dy && dy[0] == '1';
+    const char* pd = std::getenv("BEAT_VTL_PDOT");
+    d->pdot = !(pd && pd[0] == '0');
   }
   int max_run = 16;
   if (const char* e = std::getenv("BEAT_VTL_RUN")) max_run = std::max(1, std::atoi(e));
@@ -546,8 +631,27 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
 
 bool beat_vtl_available(const beat_pde* pde) { return pde->var && pde->vtl != nullptr && ((VtlData*)pde->vtl)->nitems > 0; }
 
+static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first);
+
 // whole-slab q = A p and the sum p.q
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
+  return vtl_launch(pde, dev_p, dev_q, dev_st, nullptr, nullptr, 0);
+}
+
+// the solver's iteration in one pass: p_new = D^-1 r + beta p_old (beta from dev_st; first: p_new = D^-1 r) formed while
+// loading and stored, q = A p_new, the sum p_new.q.  Single-slab operators only (both faces physical).
+int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q, int first) {
+  BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "beat_vtl_pdot is the single-slab path");
+  BEAT_REQUIRE(dev_p_old != dev_p_new, "the direction update is out of place");
+  return vtl_launch(pde, dev_p_old, dev_q, dev_st, dev_r, dev_p_new, first);
+}
+
+bool beat_vtl_pdot_available(const beat_pde* pde) {
+  return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && pde->g.z_lo_phys && pde->g.z_hi_phys;
+}
+
+static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first) {
+  const bool pdot = dev_r != nullptr;
   VtlData* d = (VtlData*)pde->vtl;
   const Geom& f = pde->g;
   VtlArgs a{};
@@ -570,11 +674,20 @@ int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double*
   a.items = d->d_items;
   a.xcd_first = d->d_xcd_first;
   a.next = d->d_xcd_first + 9;
+  a.r = dev_r;
+  a.pnew = dev_p_new;
+  a.first = first;
   auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
-  if (d->ry == 8)
-    d->dyn ? launch(vtl_spmv_kernel<8, true>, 8) : launch(vtl_spmv_kernel<8, false>, 8);
-  else
-    d->dyn ? launch(vtl_spmv_kernel<4, true>, 4) : launch(vtl_spmv_kernel<4, false>, 4);
+  if (pdot) {
+    if (d->ry == 8)
+      d->dyn ? launch(vtl_spmv_kernel<8, true, true>, 8) : launch(vtl_spmv_kernel<8, false, true>, 8);
+    else
+      d->dyn ? launch(vtl_spmv_kernel<4, true, true>, 4) : launch(vtl_spmv_kernel<4, false, true>, 4);
+  } else if (d->ry == 8) {
+    d->dyn ? launch(vtl_spmv_kernel<8, true, false>, 8) : launch(vtl_spmv_kernel<8, false, false>, 8);
+  } else {
+    d->dyn ? launch(vtl_spmv_kernel<4, true, false>, 4) : launch(vtl_spmv_kernel<4, false, false>, 4);
+  }
   BEAT_LAUNCH_CHECK();
   return beat_pde_launch_reduce(pde, d->nitems, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
 }

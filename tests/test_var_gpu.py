@@ -352,7 +352,8 @@ def test_workgroup_tile_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, c
     the same iterations to the same solution.  Grids with one and several x segments of 62 nodes, row blocks that end
     inside the box, runs of planes longer and shorter than a tile run (BEAT_VTL_RUN=5 cuts them every 5 planes); tiles dealt
     round-robin (the default) and taken from the per-XCD counters (BEAT_VTL_DYNAMIC=1: p.q is summed per tile in list order
-    either way, so even the sum is the same bits)."""
+    either way, so even the sum is the same bits); and the solver's iteration with the direction update fused into the tile
+    pass (beat_vtl_pdot, the default) against the three-kernel iteration, bit for bit."""
     from beat import _stencil
     from beat._engine import HipOps
 
@@ -371,9 +372,12 @@ def test_workgroup_tile_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, c
                 ("tile8", {"BEAT_VTL": "1", "BEAT_VTL_RY": "8", "BEAT_VTL_RUN": "32", "BEAT_VTL_DYNAMIC": "0"}),
                 ("tile4short", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "5", "BEAT_VTL_DYNAMIC": "0"}),
                 ("tile8counter", {"BEAT_VTL": "1", "BEAT_VTL_RY": "8", "BEAT_VTL_RUN": "16", "BEAT_VTL_DYNAMIC": "1"}),
+                ("tile8three", {"BEAT_VTL": "1", "BEAT_VTL_RY": "8", "BEAT_VTL_RUN": "32", "BEAT_VTL_DYNAMIC": "0", "BEAT_VTL_PDOT": "0"}),
+                ("tile4three", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "32", "BEAT_VTL_DYNAMIC": "0", "BEAT_VTL_PDOT": "0"}),
                 ("tile4counter", {"BEAT_VTL": "1", "BEAT_VTL_RY": "4", "BEAT_VTL_RUN": "7", "BEAT_VTL_DYNAMIC": "1"}))
     monkeypatch.setenv("BEAT_VRR", "0")
     for key, env in variants:
+        monkeypatch.setenv("BEAT_VTL_PDOT", "1")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ops = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
@@ -399,6 +403,13 @@ def test_workgroup_tile_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, c
         assert np.isclose(pq1, pq0, rtol=1e-12), key
         assert abs(it1 - it0) <= 1, key
         np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-9 * np.abs(x0).max(), err_msg=key)
+    # the solver's fused pass -- p = D^-1 r + beta p_old formed while loading, stored, q = A p in the same pass (the default
+    # of every tile variant above) -- against the three-kernel iteration over the same tiles (BEAT_VTL_PDOT=0): the same
+    # expressions on the same values over the same tiles (same runs of planes: p.q is summed per tile), so the whole solve is
+    # the same bits
+    for fused, three in (("tile8", "tile8three"), ("tile4", "tile4three")):
+        assert out[fused][3] == out[three][3] > 3, (out[fused][3], out[three][3])
+        np.testing.assert_array_equal(out[fused][2], out[three][2], err_msg=fused)
 
 
 def test_workgroup_tile_spmv_on_a_slab_with_live_ghost_planes(hip_ctx, monkeypatch):
