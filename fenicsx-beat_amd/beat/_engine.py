@@ -777,14 +777,25 @@ class LibComm:
     def allreduce_sum(self, tensor) -> None:
         _hip.check(self.ctx.lib.beat_comm_allreduce_sum(self.handle, C.c_void_p(tensor.data_ptr()), int(tensor.numel())))
 
-    def close(self) -> None:
+    def close(self, collective: bool | None = None) -> None:
+        """Destroy the communicator.  For the ipc transport this is COLLECTIVE by default when the ranks are processes of a
+        torch.distributed group: a rank frees its mailbox only after every rank has drained its streams -- a neighbour's
+        last receive kernel still stores its `freed` count into this mailbox, and its all-reduce stores may target it too
+        (beat_comm_destroy itself synchronises this rank's streams only).  ``collective=False``: local teardown (the
+        finaliser; a rank leaving alone after a failure)."""
         if self.handle:
+            if collective is None:
+                collective = (self.transport == "ipc" and self.slab.world > 1 and self.dist is not None
+                              and getattr(self.dist, "is_initialized", lambda: False)())
+            if collective:
+                self.ctx.synchronize()
+                self.dist.barrier(group=self.group)
             self.ctx.lib.beat_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):  # pragma: no cover
         try:
-            self.close()
+            self.close(collective=False)
         except Exception:
             pass
 

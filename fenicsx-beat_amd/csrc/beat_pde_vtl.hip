@@ -149,7 +149,6 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     asm volatile("" : "+s"(ka));
     const VtlArgs& a = *(const VtlArgs*)ka;
     const double* __restrict__ X = a.x;
-    double* __restrict__ Y = a.y;
     const double* __restrict__ A = a.rows;
     const u64* __restrict__ MASK = a.mask;
     const VtlItem item = a.items[it];  // wave-uniform
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     // c0 (D^-1 = 1 / c0, rounded as var_form_A_kernel rounds the stored 1/diag; p = fma(beta, p_old, D^-1 r): the very
     // expression of var_pupdate_oop_kernel, so the same bits) -- wherever the SpMV needs it: the own row, the rows above and
     // below, the halo lanes.  Redundant arithmetic on the halo, no second pass over r, p_old and 1/diag (32 B/node).
-    const double* __restrict__ Rr = PDOT ? a.r : nullptr;
     const double beta = PDOT ? a.st[BETA] : 0.0;
     const bool first = PDOT && a.first != 0;
     struct Trio {
@@ -190,6 +188,9 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     };
     auto ld3 = [&](u64 mk, int z, unsigned ro) -> Trio {
       const unsigned off = lane_off(mk, ro);
+      KArgPtr kr = ka;
+      asm volatile("" : "+s"(kr));
+      const double* Rr = ((const VtlArgs*)kr)->r;
       Trio t;
       t.r = vtl_buf_load(Rr + (int64_t)z * a.plane, pbytes, off);
       t.q = vtl_buf_load(X + (int64_t)z * a.plane, pbytes, first ? VTL_OOB : off);
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       Trio t{0.0, 0.0, 0.0};
       if constexpr (PDOT) {
         // a p entry is three loads (r, p_old, c0), a coefficient entry one: the two others run with every lane out of range
-        const double* base = is_p ? Rr : A + slot * ld;
+        KArgPtr kr = ka;
+        asm volatile("" : "+s"(kr));
+        const double* base = is_p ? ((const VtlArgs*)kr)->r : A + slot * ld;
         const unsigned off = lane_off(m, ro), offp = is_p ? off : VTL_OOB;
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, off);
         t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, first ? VTL_OOB : offp);
@@ -321,6 +324,11 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     if (TWO) Ebn = halo_load(eb, halo_mask(eb, moff_b, zb - 1), roff_b, zb - 1);
     u64 HA = halo_mask(ea, moff_a, zb), HB = TWO ? halo_mask(eb, moff_b, zb) : 0ull;  // masks of the loads step zb issues
     for (int z = zb; z < ze; ++z) {
+      // (what a plane uses once -- the output pointers -- is read from the kernel arguments where it is used, every plane: held
+      // in SGPRs across the march it was spilled to VGPR lanes)
+      KArgPtr kz = ka;
+      asm volatile("" : "+s"(kz));
+      const VtlArgs& az = *(const VtlArgs*)kz;
       double F[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) F[k] = Fn[k];
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
         Pp = form(Tn);  // p of plane z + 1, from what step z - 1 requested
         F[0] = C0keep;
         C0keep = Tn.c0;
-        vtl_buf_store(a.pnew + (int64_t)(z + 1) * a.plane, pbytes, (z + 1 < ze && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
+        vtl_buf_store(az.pnew + (int64_t)(z + 1) * a.plane, pbytes, (z + 1 < ze && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
       }
       const double Ea = halo_value(ea, Ean), Eb = TWO ? halo_value(eb, Ebn) : 0.0;
       // masks: one step (the halo loads') and two steps (the own row's) ahead of their use
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       for (int k = 0; k < 15; ++k) s = fma(c[k], (k == 0 || c[k] != 0.0) ? v[k] : 0.0, s);
       const bool out = (M0 & lanebit & out_lanes) != 0ull;
       acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
-      vtl_buf_store(Y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
+      vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
       // roll: this plane becomes the plane below
       Pm = P0;
       P0 = Pp;
@@ -454,7 +462,7 @@ struct VtlData {
 
 template <int RY>
 unsigned vtl_resident_blocks() {
-  auto kernel = vtl_spmv_kernel<RY, true, true>;
+  auto kernel = vtl_spmv_kernel<RY, false, RY == 8>;
   int dev = 0, cus = 256, per_cu = 1;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -647,7 +655,8 @@ int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const doub
 }
 
 bool beat_vtl_pdot_available(const beat_pde* pde) {
-  return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && pde->g.z_lo_phys && pde->g.z_hi_phys;
+  // (tiles of 8 rows only: with 4 rows a wave carries two halo entries and the fused pass does not fit 128 VGPRs)
+  return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && ((VtlData*)pde->vtl)->ry == 8 && pde->g.z_lo_phys && pde->g.z_hi_phys;
 }
 
 static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first) {
@@ -678,11 +687,8 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   a.pnew = dev_p_new;
   a.first = first;
   auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
-  if (pdot) {
-    if (d->ry == 8)
-      d->dyn ? launch(vtl_spmv_kernel<8, true, true>, 8) : launch(vtl_spmv_kernel<8, false, true>, 8);
-    else
-      d->dyn ? launch(vtl_spmv_kernel<4, true, true>, 4) : launch(vtl_spmv_kernel<4, false, true>, 4);
+  if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
+    launch(vtl_spmv_kernel<8, false, true>, 8);
   } else if (d->ry == 8) {
     d->dyn ? launch(vtl_spmv_kernel<8, true, false>, 8) : launch(vtl_spmv_kernel<8, false, false>, 8);
   } else {
