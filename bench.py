@@ -699,7 +699,7 @@ def main():
     if rank == 0:
         n_total = n * n * nz_glob
         # HBM bytes and VALU counters per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-        # very command (tools/measure_round3.sh -> profiles/r03_<tag>_pmc.json); only quoted when this run has the
+        # very command (tools/measure_round.sh -> profiles/r0N_<tag>_pmc.json); only quoted when this run has the
         # configuration the counters were collected on
         traffic, valu, pmc_source = None, None, None
         for tfile in sorted((ROOT / "profiles").glob("r0*_pmc.json"), reverse=True):  # the newest round's file that fits

@@ -66,17 +66,26 @@ struct MarkedArgs {
   double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
 };
 
+// Per-node parameters of which only a few ROWS vary (a smooth gradient in one conductance: src/beat/odesolver.py:67-79 hands
+// ``fun`` the whole (P, N) array, demos/pace_train.py:133-167 builds such arrays): the varying rows alone live on the
+// device, the other parameters come from the uniform vector -- 8 B per varying row and node instead of 8 NP (TP06: 424).
+constexpr int BEAT_MAX_SPARSE_ROWS = 4;
+struct SparseRows {
+  int idx[BEAT_MAX_SPARSE_ROWS];  // parameter index of row j of ppn
+  int count;                      // 0: ppn holds all NP rows
+};
+
 template <class Model>
 struct OdeTableEntry {
   double p[Model::NP];
   typename Model::Derived d;
 };
 
-template <class Model, bool PER_NODE, bool PEND, bool MARKED = false>
+template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARSE = false>
 __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
-    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk) {
+    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk, SparseRows sp) {
   __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
@@ -205,8 +214,23 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
     }
     if (PER_NODE) {
       double pl[Model::NP];
+      if (SPARSE) {
+        // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
+        // the entry it lands in is found by comparison: no dynamic indexing of the register array)
 #pragma unroll
-      for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = p_uni[k];
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+          if (j < sp.count) {
+            const double vj = ppn[(int64_t)j * pld + i];
+#pragma unroll
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == sp.idx[j] ? vj : pl[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      }
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
     } else {
@@ -218,8 +242,23 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
     const NodeIO io{states, ldl, i, nullptr, -1};
     if (PER_NODE) {
       double pl[Model::NP];
+      if (SPARSE) {
+        // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
+        // the entry it lands in is found by comparison: no dynamic indexing of the register array)
 #pragma unroll
-      for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = p_uni[k];
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+          if (j < sp.count) {
+            const double vj = ppn[(int64_t)j * pld + i];
+#pragma unroll
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == sp.idx[j] ? vj : pl[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      }
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
     } else {
@@ -392,7 +431,8 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
-                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
+                      int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr},
+                      SparseRows sp = SparseRows{{0, 0, 0, 0}, 0}) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
   // (with num_params == NP and neither a vector nor rows nor classes every parameter would silently be 1.0 -- what the
@@ -428,15 +468,24 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   const dim3 g3(grid), b3(BEAT_BLOCK);
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
-                     dt, v_index, v_copy, pend, mk)
+                     dt, v_index, v_copy, pend, mk, sp)
   if (mk.markers != nullptr) {
     BEAT_REQUIRE(ppn == nullptr && mk.table != nullptr, "parameter classes come with a table, not with per-node rows");
     if (have_pend)
       BEAT_KERNEL((ode_step_kernel<Model, false, true, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
-                  v_index, v_copy, pend, mk);
+                  v_index, v_copy, pend, mk, sp);
     else
       BEAT_KERNEL((ode_step_kernel<Model, false, false, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
-                  v_index, v_copy, pend, mk);
+                  v_index, v_copy, pend, mk, sp);
+  } else if (ppn != nullptr && sp.count > 0) {
+    BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
+    BEAT_REQUIRE(host_params != nullptr, "sparse rows come with the uniform parameter vector");
+    if (have_pend)
+      BEAT_KERNEL((ode_step_kernel<Model, true, true, false, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
+                  v_index, v_copy, pend, mk, sp);
+    else
+      BEAT_KERNEL((ode_step_kernel<Model, true, false, false, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
+                  v_index, v_copy, pend, mk, sp);
   } else if (ppn != nullptr) {
     BEAT_REQUIRE(pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
     if (have_pend)
@@ -473,7 +522,8 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
 static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                              const double* host_params, int num_params, const double* dev_params_per_node,
                              int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
-                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
+                             const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr},
+                             SparseRows sp = SparseRows{{0, 0, 0, 0}, 0}) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
@@ -481,7 +531,7 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
   if (n == 0) return BEAT_OK;
 #define BEAT_STEP(M)                                                                                             \
   return launch_ode<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, \
-                       v_index, dev_v_copy, pend, mk)
+                       v_index, dev_v_copy, pend, mk, sp)
   switch (model_id) {
     case BEAT_MODEL_SIMPLE_ODE: BEAT_STEP(SimpleOde);
     case BEAT_MODEL_FHN_DEMO: BEAT_STEP(FhnDemo);
@@ -519,6 +569,32 @@ extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_st
                            t, dt, v_index, dev_v_copy, pend);
 }
 
+
+// Per-node parameters given as the uniform vector plus the rows that vary (see SparseRows): host_row_params[j] is the
+// parameter index of row j of dev_rows ((num_rows, rows_ld), num_rows <= 4).  With pde / pending as in
+// beat_ode_step_pending (pde == nullptr: a plain step).  The arithmetic is the per-node kernel's -- every parameter per
+// lane, Derived per lane -- only the (P - num_rows) rows that do not vary are not read from memory.
+extern "C" int beat_ode_step_rows(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                                  const double* host_params, int num_params, const int* host_row_params, int num_rows,
+                                  const double* dev_rows, int64_t rows_ld, double t, double dt, int v_index, double* dev_v_copy,
+                                  beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending) {
+  BEAT_REQUIRE(host_params != nullptr && host_row_params != nullptr && dev_rows != nullptr, "null argument");
+  BEAT_REQUIRE(num_rows >= 1 && num_rows <= BEAT_MAX_SPARSE_ROWS, "1..%d varying rows, got %d", BEAT_MAX_SPARSE_ROWS, num_rows);
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
+  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  SparseRows sp{{0, 0, 0, 0}, num_rows};
+  for (int j = 0; j < num_rows; ++j) {
+    BEAT_REQUIRE(host_row_params[j] >= 0 && host_row_params[j] < num_params, "row %d names parameter %d of %d", j, host_row_params[j], num_params);
+    sp.idx[j] = host_row_params[j];
+  }
+  PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
+  if (pde != nullptr && pde->guess_pending) {
+    pend.gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
+  return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_rows, rows_ld, t, dt, v_index, dev_v_copy,
+                           pend, MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}, sp);
+}
 
 template <class Model>
 static int fill_table(const double* host_params, int num_params, int classes, std::vector<double>& out) {

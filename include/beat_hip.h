@@ -108,6 +108,17 @@ int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64
                           int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
                           beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
 
+/* Per-node parameters of which only a few rows vary -- a smooth gradient in one or two parameters over otherwise uniform
+ * tissue; the reference hands ``fun`` the whole (P, N) array, src/beat/odesolver.py:67-79, demos/pace_train.py:133-167 --:
+ * host_params = the (P,) vector of the parameters that do not vary, dev_rows = (num_rows <= 4, rows_ld) = the rows that do,
+ * host_row_params[j] = the parameter index of row j.  Same values as beat_ode_step with all P rows on the device (the
+ * kernel builds the node's parameter set from both and runs the per-node step); 8 num_rows bytes per node are read
+ * instead of 8 P.  pde / dev_ring0 / field_stride / pending as in beat_ode_step_pending (pde = NULL: a plain step). */
+int beat_ode_step_rows(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
+                       const double* host_params, int num_params, const int* host_row_params, int num_rows,
+                       const double* dev_rows, int64_t rows_ld, double t, double dt, int v_index, double* dev_v_copy,
+                       beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
+
 /* Cell types / parameter classes in ONE launch (src/beat/odesolver.py:306-310 loops over the markers and calls `fun`
  * once per marker; demos/biv_endocardial.py:187-282: endo / mid / epi): one (S, n) state array, a byte per node that
  * names the node's class (0 .. classes-1; 255: the node belongs to none and is not advanced -- its potential still

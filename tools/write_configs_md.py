@@ -1,10 +1,12 @@
-"""profiles/r02_configs.md from the logs of `bash tools/run_configs.sh` (gpurun_out/configs/)."""
+"""profiles/<round>_configs.md (BEAT_ROUND, default r04) from the logs of `bash tools/run_configs.sh` (gpurun_out/configs/)."""
 import json
+import os
 import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 O = ROOT / "gpurun_out" / "configs"
+RND = os.environ.get("BEAT_ROUND", "r04")
 
 
 def j(f):
@@ -35,13 +37,13 @@ c3, c4, c1024, sl, sf = j("cfg3_256iso.json"), j("cfg4_512.json"), j("cfg4_1024.
 cb, fr, fr3 = c4["cpu_baseline"], c4["developed_front"], c3["developed_front"]
 n05, n02 = tail("cfg2_niederer_dx05_dt005.log", 10), tail("cfg2_niederer_dx02_dt001.log", 10)
 sh, sh4 = tail("cfg5_shell.log")[0], tail("cfg5_shell400.log")[0]
-md = f"""# Round 2: BASELINE.json's five configurations on one MI355X (`bash tools/run_configs.sh`, one gpurun call, ≈ 100 s of GPU time)
+md = f"""# Round {RND[2:]}: BASELINE.json's five configurations on one MI355X (`bash tools/run_configs.sh`, one gpurun call on one box)
 
-Package defaults: initial guess of the diffusion solve = quadratic or cubic extrapolation in time of the last diffusion
-increments, chosen per solve (`ksp_guess_order` "auto"); 24 576 blocks per ionic launch; grids of up to 8192 nodes
-solved in one launch of one workgroup, their steps batched by `MonodomainSplittingSolver.solve`.  Box-to-box spread of
-the pool is ±5 % (ionic kernel at 512³: 9.9–10.6 ms).  Round 1's table: `r01_configs.md`; written by
-`tools/write_configs_md.py`.
+Package defaults: initial guess of the diffusion solve = extrapolation in time of the last diffusion increments, order 1-4
+chosen per solve (`ksp_guess_order` "auto"); 24 576 blocks per ionic launch; grids of up to 8192 nodes solved in one launch
+of one workgroup, their steps batched by `MonodomainSplittingSolver.solve`; per-node rows (voxel meshes, fibre fields): the
+workgroup-tile pass with the direction update fused in (round 4).  Box-to-box spread of the pool is ±5 %.  Earlier tables:
+`r01_configs.md`, `r02_configs.md` (the "round 1" figures quoted below are theirs); written by `tools/write_configs_md.py`.
 
 | configuration | command | result |
 |---|---|---|
@@ -55,5 +57,5 @@ the pool is ±5 % (ionic kernel at 512³: 9.9–10.6 ms).  Round 1's table: `r01
 | configs[4] voxelised shell, ToR-ORd-dynCl endo/mid/epi, endocardial pacing (synthetic geometry, one GPU instead of 8) | `tools/bench_biv.py --n 520 --steps 20 --warmup 5` | box 521³ = 141.4 M nodes, 37.12 M tissue nodes; {sh.strip()} (round 1: 43.4 ms/step at 11.0 its) |
 | the same on a 401³ box | `tools/bench_biv.py --n 400 --steps 20 --warmup 5` | 17.00 M tissue nodes; {sh4.strip()} (round 1: 21.0 ms/step) |
 """
-(ROOT / "profiles" / "r02_configs.md").write_text(md)
+(ROOT / "profiles" / f"{RND}_configs.md").write_text(md)
 print(md)
