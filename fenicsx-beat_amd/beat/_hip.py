@@ -128,6 +128,7 @@ UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 2048
 IPC_MAX_RANKS = 16
 COMM_SERIAL = 1
+MAX_SPARSE_ROWS = 4  # BEAT_MAX_SPARSE_ROWS of csrc/beat_ode.hip
 TRANSPORT_NAMES = {0: "callbacks", 1: "rccl", 2: "rccl-serial", 3: "ipc"}
 E_NOT_CONVERGED = -3
 

@@ -106,6 +106,7 @@ class _DeviceODE:
         self._ppn_host = None  # what the device copy was uploaded from (None: the per-node route's cache is not current)
         self._dp_key = None    # (id, version) of the DeviceParameters handle the cached route was derived from
         self._per_node_args = None
+        self._sparse = None    # (uniform vector, indices of the varying rows, their (K, N) device rows) or None
         self.classes = None    # (marker bytes on the device, class table, number of classes): see set_classes
         self.explicit_classes = False  # the owner set the classes itself (DolfinMultiODESolver); else they follow the parameters
         self.node_map = None   # (int32 node of the PDE grid per entry, the field holding the potential): compact layout
@@ -169,14 +170,27 @@ class _DeviceODE:
         return inv.to(torch.uint8), t[:, first].T.contiguous().cpu().numpy()
 
     def _per_node_or_classes(self, tensor, num_rows):
-        """(host params, P, device rows, ld) for per-node parameters held in ``tensor``: the class route if they allow it."""
+        """(host params, P, device rows, ld) for per-node parameters held in ``tensor``: the class route if they allow it,
+        else -- when at most four ROWS vary over the nodes (a smooth gradient in a conductance or two) -- those rows alone
+        next to the uniform vector (``self._sparse``: beat_ode_step_rows reads 8 B per varying row and node instead of 8 P),
+        else all P rows."""
         per_node = (None, num_rows, C.c_void_p(tensor.data_ptr()), self.n)
+        self._sparse = None
         found = self._classify(tensor)
         if found is not None:
             self.set_classes(found[0], list(found[1]))
             self._per_node_args = per_node  # for the caller the class kernel does not serve (a mirror of another row than V)
             return None, num_rows, None, 0
         self.classes = None
+        import os
+
+        if os.environ.get("BEAT_PARAM_SPARSE", "1") != "0" and tensor.shape[1] == self.n:
+            varying = (tensor != tensor[:, :1]).any(dim=1)
+            idx = varying.nonzero().flatten().cpu().numpy().astype(np.int32)
+            if 1 <= len(idx) <= _hip.MAX_SPARSE_ROWS:
+                rows = tensor[varying].contiguous()  # (K, N): the only parameter data a step reads from memory
+                uniform = np.ascontiguousarray(tensor[:, 0].cpu().numpy(), dtype=np.float64)
+                self._sparse = (uniform, np.ascontiguousarray(idx), rows)
         return per_node
 
     def _forget_routes(self) -> None:
@@ -184,6 +198,7 @@ class _DeviceODE:
         again -- a classified (P, N) array, then a vector, then the same array must classify again (the vector branch
         cleared the classes the cached arguments rely on)."""
         self.classes = None
+        self._sparse = None
         self._ppn_host = None
         self._dp_key = None
 
@@ -249,6 +264,14 @@ class _DeviceODE:
                         self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, C.c_void_p(table.data_ptr()),
                         ncls, C.c_void_p(mk.data_ptr()), float(t0), float(dt), int(v_index), None if v_copy is None else v_copy.ptr,
                         nmap, vfield,
+                        pending_ops.handle if pend is not None else None, pending_ops.ring[0].ptr if pend is not None else None,
+                        pending_ops.fld if pend is not None else 0, int(pend[2]) if pend is not None else 0))
+                elif self._sparse is not None and ppn is not None and not self.explicit_classes:
+                    uni, idx, rows = self._sparse
+                    _hip.check(self.ctx.lib.beat_ode_step_rows(
+                        self.ctx.handle, self.model.model_id, self.states.ptr, self.n, self.states.ld, uni.ctypes.data_as(C.c_void_p),
+                        len(uni), idx.ctypes.data_as(C.c_void_p), len(idx), C.c_void_p(rows.data_ptr()), self.n, float(t0), float(dt),
+                        int(v_index), None if v_copy is None else v_copy.ptr,
                         pending_ops.handle if pend is not None else None, pending_ops.ring[0].ptr if pend is not None else None,
                         pending_ops.fld if pend is not None else 0, int(pend[2]) if pend is not None else 0))
                 elif pend is not None:

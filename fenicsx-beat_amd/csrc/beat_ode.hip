@@ -217,14 +217,23 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       if (SPARSE) {
         // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
         // the entry it lands in is found by comparison: no dynamic indexing of the register array)
+        // (read with VECTOR loads -- one address for the whole wave, a broadcast from one or two cache lines: as scalar
+        // loads the NP uniform values were all held in SGPRs until the selects below had consumed them, 500 (TP06) to 1300
+        // (Land) SGPRs spilled to VGPR lanes)
+        const double* pv = p_uni;
+        asm volatile("" : "+v"(pv));
 #pragma unroll
-        for (int k = 0; k < Model::NP; ++k) pl[k] = p_uni[k];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
           if (j < sp.count) {
             const double vj = ppn[(int64_t)j * pld + i];
+            // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
+            // hoisted out of the tile loop, held in SGPR pairs and spilled)
+            int ij = sp.idx[j];
+            asm volatile("" : "+s"(ij));
 #pragma unroll
-            for (int k = 0; k < Model::NP; ++k) pl[k] = k == sp.idx[j] ? vj : pl[k];
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == ij ? vj : pl[k];
           }
         }
       } else {
@@ -245,14 +254,23 @@ __global__ __launch_bounds__(BEAT_BLOCK, PER_NODE ? Model::WAVES_PER_NODE : Mode
       if (SPARSE) {
         // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
         // the entry it lands in is found by comparison: no dynamic indexing of the register array)
+        // (read with VECTOR loads -- one address for the whole wave, a broadcast from one or two cache lines: as scalar
+        // loads the NP uniform values were all held in SGPRs until the selects below had consumed them, 500 (TP06) to 1300
+        // (Land) SGPRs spilled to VGPR lanes)
+        const double* pv = p_uni;
+        asm volatile("" : "+v"(pv));
 #pragma unroll
-        for (int k = 0; k < Model::NP; ++k) pl[k] = p_uni[k];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
           if (j < sp.count) {
             const double vj = ppn[(int64_t)j * pld + i];
+            // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
+            // hoisted out of the tile loop, held in SGPR pairs and spilled)
+            int ij = sp.idx[j];
+            asm volatile("" : "+s"(ij));
 #pragma unroll
-            for (int k = 0; k < Model::NP; ++k) pl[k] = k == sp.idx[j] ? vj : pl[k];
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == ij ? vj : pl[k];
           }
         }
       } else {

@@ -890,8 +890,9 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     S0 = np.repeat(tp06.init_state_values()[:, None], n, axis=1)
     S0[tp06.state_index("V")] = rng.uniform(-90.0, 30.0, n)
 
-    def run(parameters, steps=6, classes_env="1"):
+    def run(parameters, steps=6, classes_env="1", sparse_env="1"):
         os.environ["BEAT_PARAM_CLASSES"] = classes_env
+        os.environ["BEAT_PARAM_SPARSE"] = sparse_env
         try:
             ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=g.Function(V), fun=tp06.generalized_rush_larsen,
                                                  init_states=S0, parameters=parameters, num_states=19, v_index=tp06.state_index("V"))
@@ -900,13 +901,14 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
             return ode, np.asarray(ode.values).copy()
         finally:
             os.environ.pop("BEAT_PARAM_CLASSES", None)
+            os.environ.pop("BEAT_PARAM_SPARSE", None)
 
     ode_c, out_c = run(P)
     assert ode_c._dev.classes is not None and ode_c._dev.classes[2] == 2
     ode_h, out_h = run(DeviceParameters(P))
     assert ode_h._dev.classes is not None and ode_h._dev.classes[2] == 2
-    ode_n, out_n = run(P, classes_env="0")
-    assert ode_n._dev.classes is None
+    ode_n, out_n = run(P, classes_env="0", sparse_env="0")
+    assert ode_n._dev.classes is None and ode_n._dev._sparse is None
     np.testing.assert_array_equal(out_c, out_h)
     np.testing.assert_allclose(out_c, out_n, rtol=1e-13, atol=1e-300)
     ref = S0.copy()
@@ -922,14 +924,74 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     err = np.abs(np.asarray(ode_c.values) - ref) / np.maximum(np.abs(ref), 1e-3)
     assert err.max() < 1e-10
     # a smooth field has as many distinct columns as nodes: per-node kernel
-    Pg = P.copy()
+    Pg = np.repeat(P0[:, None], n, axis=1)
     Pg[tp06.parameter_index("g_Na")] *= np.linspace(0.8, 1.2, n)
+    # ... but only ONE row of it varies: that row alone is kept on the device next to the uniform vector (round 4:
+    # beat_ode_step_rows -- 8 B per node of parameter traffic instead of 424), same arithmetic as with all 53 rows
+    Pg[tp06.parameter_index("g_CaL")] *= 1.0 + 0.2 * np.sin(3.0 * xs)
     ode_g, out_g = run(Pg)
-    assert ode_g._dev.classes is None
+    assert ode_g._dev.classes is None and ode_g._dev._sparse is not None
+    assert sorted(ode_g._dev._sparse[1].tolist()) == sorted([tp06.parameter_index("g_Na"), tp06.parameter_index("g_CaL")])
+    ode_d, out_d = run(Pg, sparse_env="0")
+    assert ode_d._dev._sparse is None
+    np.testing.assert_array_equal(out_g, out_d)
+    ode_h2, out_h2 = run(DeviceParameters(Pg))
+    assert ode_h2._dev._sparse is not None
+    np.testing.assert_array_equal(out_h2, out_d)
     ref = S0.copy()
     for i in range(6):
         ref = ionic.tp06_generalized_rush_larsen(ref, 0.02 * i, 0.02, Pg)
     assert (np.abs(out_g - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
+    # an edit of the live array that makes a fifth row vary: back to all rows
+    for k, name in enumerate(("g_Kr", "g_Ks", "g_to")):
+        Pg[tp06.parameter_index(name)] *= 1.0 + 0.01 * (k + 1) * np.cos(xs)
+    ode_g.step(0.12, 0.02)
+    assert ode_g._dev._sparse is None and ode_g._dev.classes is None
+    ref = ionic.tp06_generalized_rush_larsen(ref, 0.12, 0.02, Pg)
+    assert (np.abs(np.asarray(ode_g.values) - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
+
+def test_split_step_with_a_smooth_per_node_parameter_runs_on_sparse_rows():
+    """A smooth gradient in one conductance over a slab, through the public API and the fused split step (the ionic kernel
+    applies the previous solve's pending update): the sparse-rows route (one parameter row on the device) against all 53
+    rows (BEAT_PARAM_SPARSE=0), bit for bit after 12 steps, for TP06 and for ToR-ORd-dynCl (the per-node route itself is held against
+    the oracle by the tests above).  Reference: parameters per node, src/beat/odesolver.py:67-79, demos/pace_train.py:133-167."""
+    import os
+
+    import beat
+    from beat import grid as g
+    from beat.models import torord, tp06
+
+    def run(model, vname, pname, sparse):
+        os.environ["BEAT_PARAM_SPARSE"] = sparse
+        try:
+            mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([2.0, 1.0, 0.6])], [20, 10, 6])
+            V = g.functionspace(mesh, ("P", 1))
+            n = V.dofmap.index_map.size_local
+            xs = mesh.node_coordinates(pad3=True)
+            P0 = model.init_parameter_values()
+            P = np.repeat(P0[:, None], n, axis=1)
+            P[model.parameter_index(pname)] *= 1.0 - 0.2 * xs[:, 0] - 0.1 * xs[:, 1] - 0.07 * xs[:, 2]  # distinct at every node
+            time = g.Constant(mesh, 0.0)
+            pde = beat.MonodomainModel(time=time, mesh=mesh, M=np.diag([1e-3, 3e-4, 3e-4]), C_m=0.01,
+                                       params={"petsc_options": {"ksp_rtol": 1e-10}})
+            S0 = np.repeat(model.init_state_values()[:, None], n, axis=1)
+            S0[model.state_index(vname)] += 60.0 * np.exp(-((xs - np.array([0.4, 0.5, 0.3])) ** 2).sum(axis=1) / 0.05)
+            ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, fun=model.generalized_rush_larsen, init_states=S0,
+                                                 parameters=P, num_states=S0.shape[0], v_index=model.state_index(vname))
+            solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+            for k in range(12):
+                solver.step((0.02 * k, 0.02 * (k + 1)))
+            return np.asarray(ode.values).copy(), ode._dev._sparse is not None, (mesh, P, S0)
+        finally:
+            os.environ.pop("BEAT_PARAM_SPARSE", None)
+
+    for model, vname, pname in ((tp06, "V", "g_CaL"), (torord, "v", "GKr_b")):
+        a, sparse_a, info = run(model, vname, pname, "1")
+        b, sparse_b, _ = run(model, vname, pname, "0")
+        assert sparse_a and not sparse_b
+        np.testing.assert_array_equal(a, b)
+        assert np.isfinite(a).all() and a[model.state_index(vname)].max() > -80.0  # (the bump is still there)
+
 
 
 def test_parameter_route_follows_the_parameters_through_every_change_of_kind():

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """TP06 ionic step at 256^3 with (i) uniform parameters, (ii) the reference's pace_train heterogeneity -- a (P, N) array in
 which g_Kr and g_Ks are zero in half of the domain (demos/pace_train.py:133-167), recognised as two parameter classes --,
-(iii) the same array forced through the per-node kernel (BEAT_PARAM_CLASSES=0), (iv) a smooth per-node field (per-node
-kernel).  HIP events around the kernel, median of --reps launches.
+(iii) the same array forced through the per-node kernel (BEAT_PARAM_CLASSES=0), (iv) a smooth per-node field in ONE parameter: the varying row alone on the device
+(beat_ode_step_rows) and, for comparison, all 53 rows (BEAT_PARAM_SPARSE=0).  HIP events around the kernel, median of --reps launches.
     python tools/bench_param_classes.py [--n 256]"""
 import argparse
 import os
@@ -49,6 +49,7 @@ def main():
 
     def run(label, params, env=None):
         os.environ.pop("BEAT_PARAM_CLASSES", None)
+        os.environ.pop("BEAT_PARAM_SPARSE", None)
         if env:
             os.environ.update(env)
         dev = _DeviceODE(ctx, tp06.generalized_rush_larsen, 19, N, n * n, params, NullMonitor())
@@ -64,7 +65,8 @@ def main():
             b.record()
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
-        route = f"{dev.classes[2]} classes" if dev.classes is not None else ("per-node rows" if getattr(params, "ndim", 1) == 2 else "uniform")
+        route = (f"{dev.classes[2]} classes" if dev.classes is not None else f"{len(dev._sparse[1])} varying row(s) + uniform vector"
+                 if dev._sparse is not None else ("all per-node rows" if getattr(params, "ndim", 1) == 2 else "uniform"))
         print(f"{label:52s} {ms:7.3f} ms   ({route})", flush=True)
         del dev
         torch.cuda.empty_cache()
@@ -75,8 +77,10 @@ def main():
     c = run("g_Kr = g_Ks = 0 in half of the domain (P, N)", blk)
     p = run("  the same through the per-node kernel", blk, {"BEAT_PARAM_CLASSES": "0"})
     del blk
-    g = run("smooth g_CaL gradient (P, N)", per_node("smooth"))
-    print(f"classes / uniform = {c / u:.3f}; per-node / uniform = {p / u:.3f}, {g / u:.3f}")
+    sm = per_node("smooth")
+    g = run("smooth g_CaL gradient (P, N): sparse rows", sm)
+    gd = run("  the same with all 53 rows on the device", sm, {"BEAT_PARAM_SPARSE": "0"})
+    print(f"classes / uniform = {c / u:.3f}; per-node / uniform = {p / u:.3f}; smooth field: sparse rows {g / u:.3f}, all rows {gd / u:.3f}")
 
 
 if __name__ == "__main__":
