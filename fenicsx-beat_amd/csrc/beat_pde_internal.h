@@ -152,6 +152,8 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& host_ti
 void beat_vtl_destroy(beat_pde* pde);
 bool beat_vtl_available(const beat_pde* pde);
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
+bool beat_vtl_parts_available(const beat_pde* pde);
+int beat_vtl_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 bool beat_vtl_pdot_available(const beat_pde* pde);
 int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q, int first);
 

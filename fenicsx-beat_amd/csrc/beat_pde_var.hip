@@ -991,6 +991,7 @@ int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double*
 
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part) {
   if (beat_vrr_available(pde)) return beat_vrr_spmv_dot(pde, dev_p, dev_q, dev_st, part);
+  if (beat_vtl_parts_available(pde)) return beat_vtl_spmv_dot_part(pde, dev_p, dev_q, dev_st, part);
   const Geom& f = pde->g;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);  // planes that need no ghost data
   VarArgs a{};

@@ -454,8 +454,11 @@ struct VtlData {
   bool dyn = false;
   bool pdot = true;  // BEAT_VTL_PDOT=0: the three-kernel iteration (SpMV, residual update, direction update)
   VtlItem* d_items = nullptr;
-  int* d_xcd_first = nullptr;  // 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
+  int* d_xcd_first = nullptr;  // per list 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
   u64* d_mask = nullptr;
+  // tile lists, back to back in d_items: [0] the whole slab, [1] the planes that need no ghost data, [2] the one or two that do
+  // (decomposed grids; empty on a slab with two physical faces)
+  int list_base[3] = {0, 0, 0}, list_count[3] = {0, 0, 0};
   int nitems = 0, nsegx = 0, nzp = 0;
   unsigned resident = 0;
 };
@@ -539,84 +542,115 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
       }
     }
   const u64 out_lanes = ((1ull << SEG) - 1ull) << 1;  // lanes 1..62
-  std::vector<VtlItem> items;
   std::vector<char> act((size_t)f.nz);
-  // (one partial sum of p.q per tile: longer runs if there would be more tiles than partial slots)
-  for (;; max_run *= 2) {
-  items.clear();
-  for (int rb = 0; rb < nrb; ++rb)
-    for (int seg = 0; seg < nsegx; ++seg) {
-      bool any = false;
-      for (int z = 0; z < f.nz; ++z) {
-        u64 m = 0ull;
-        for (int y = rb * RY; y < std::min(f.ny, rb * RY + RY); ++y) m |= mask[((size_t)(y + 1) * nsegx + seg) * nzp + 1 + z];
-        act[(size_t)z] = (m & out_lanes) != 0ull;
-        any |= act[(size_t)z] != 0;
-      }
-      if (!any) continue;
-      if (aligned) {
-        // every tile of a z block covers the block's tissue range as a whole (BEAT_VTL_ALIGN=2: the whole block): neighbouring
-        // tiles then march through the same planes at about the same time, and the lines they share -- the halo rows, the
-        // 128-byte lines a row segment shares with the segments left and right of it -- are fetched once per XCD
-        for (int b0 = 0; b0 < f.nz; b0 += max_run) {
-          const int b1 = std::min(f.nz, b0 + max_run);
-          int lo = b1, hi = b0;
-          for (int z = b0; z < b1; ++z)
-            if (act[(size_t)z]) {
-              lo = std::min(lo, z);
-              hi = std::max(hi, z + 1);
-            }
-          if (lo >= hi) continue;
-          items.push_back(aligned == 2 ? VtlItem{seg, rb, b0, b1} : VtlItem{seg, rb, lo, hi});
+  // the tiles of the planes [z_lo, z_hi), in (z block, row block, x segment) order; false if there are more than partial slots
+  auto build = [&](int z_lo, int z_hi, int run, std::vector<VtlItem>& items) -> bool {
+    items.clear();
+    if (z_hi <= z_lo) return true;
+    for (int rb = 0; rb < nrb; ++rb)
+      for (int seg = 0; seg < nsegx; ++seg) {
+        bool any = false;
+        for (int z = z_lo; z < z_hi; ++z) {
+          u64 m = 0ull;
+          for (int y = rb * RY; y < std::min(f.ny, rb * RY + RY); ++y) m |= mask[((size_t)(y + 1) * nsegx + seg) * nzp + 1 + z];
+          act[(size_t)z] = (m & out_lanes) != 0ull;
+          any |= act[(size_t)z] != 0;
         }
-        continue;
-      }
-      int z = 0;
-      while (z < f.nz) {
-        if (!act[(size_t)z]) {
-          ++z;
+        if (!any) continue;
+        if (aligned) {
+          // every tile of a z block covers the block's tissue range as a whole (BEAT_VTL_ALIGN=2: the whole block): measured,
+          // within +-2 % of tiles trimmed to their own tissue
+          for (int b0 = (z_lo / run) * run; b0 < z_hi; b0 += run) {
+            const int c0 = std::max(b0, z_lo), c1 = std::min(z_hi, b0 + run);
+            int lo = c1, hi = c0;
+            for (int z = c0; z < c1; ++z)
+              if (act[(size_t)z]) {
+                lo = std::min(lo, z);
+                hi = std::max(hi, z + 1);
+              }
+            if (lo >= hi) continue;
+            items.push_back(aligned == 2 ? VtlItem{seg, rb, c0, c1} : VtlItem{seg, rb, lo, hi});
+          }
           continue;
         }
-        // a run never crosses a multiple of max_run: tiles of one z block are neighbours in the list
-        const int stop = std::min(f.nz, (z / max_run + 1) * max_run);
-        int e = z + 1, last = z + 1;  // grow the run over gaps of up to two planes
-        while (e < stop && (act[(size_t)e] || e - last < 2)) {
-          if (act[(size_t)e]) last = e + 1;
-          ++e;
+        int z = z_lo;
+        while (z < z_hi) {
+          if (!act[(size_t)z]) {
+            ++z;
+            continue;
+          }
+          // a run never crosses a multiple of `run`: tiles of one z block are neighbours in the list
+          const int stop = std::min(z_hi, (z / run + 1) * run);
+          int e = z + 1, last = z + 1;  // grow the run over gaps of up to two planes
+          while (e < stop && (act[(size_t)e] || e - last < 2)) {
+            if (act[(size_t)e]) last = e + 1;
+            ++e;
+          }
+          items.push_back(VtlItem{seg, rb, z, last});
+          z = last;
         }
-        items.push_back(VtlItem{seg, rb, z, last});
-        z = last;
       }
+    std::stable_sort(items.begin(), items.end(), [&](const VtlItem& p, const VtlItem& q) {
+      const int zp = p.zb / run, zq = q.zb / run;
+      if (zp != zq) return zp < zq;
+      if (p.rb != q.rb) return p.rb < q.rb;
+      return p.seg < q.seg;
+    });
+    return (int64_t)items.size() <= BEAT_MAX_PARTIALS;
+  };
+  // eight contiguous parts of equal weight (planes + a prologue's worth per tile); indices into the concatenated array
+  auto parts = [&](const std::vector<VtlItem>& items, int base, int (&first)[9]) {
+    std::vector<int64_t> cum(items.size() + 1, 0);
+    for (size_t k = 0; k < items.size(); ++k) cum[k + 1] = cum[k] + (items[k].ze - items[k].zb) + 2;
+    first[0] = 0;
+    for (int x = 1; x < 8; ++x) {
+      const int64_t want = cum.back() * x / 8;
+      first[x] = (int)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+      first[x] = std::max(first[x - 1], std::min(first[x], (int)items.size()));
     }
-  if ((int64_t)items.size() <= BEAT_MAX_PARTIALS || max_run >= f.nz) break;
+    first[8] = (int)items.size();
+    for (int x = 0; x < 9; ++x) first[x] += base;
+  };
+  std::vector<VtlItem> items, part_items[2];
+  // (one partial sum of p.q per tile: longer runs if there would be more tiles than partial slots)
+  bool fits = false;
+  for (; !(fits = build(0, f.nz, max_run, items)) && max_run < f.nz; max_run *= 2) {
   }
-  if ((int64_t)items.size() > BEAT_MAX_PARTIALS) {  // (a plane of more than 16384 tiles: the segment-list kernel)
+  if (!fits) {  // (a plane of more than 16384 tiles: the segment-list kernel)
     delete d;
     return BEAT_OK;
   }
-  std::stable_sort(items.begin(), items.end(), [&](const VtlItem& p, const VtlItem& q) {
-    const int zp = p.zb / max_run, zq = q.zb / max_run;
-    if (zp != zq) return zp < zq;
-    if (p.rb != q.rb) return p.rb < q.rb;
-    return p.seg < q.seg;
-  });
-  // eight contiguous parts of equal weight (planes + a prologue's worth per tile)
-  std::vector<int64_t> cum(items.size() + 1, 0);
-  for (size_t k = 0; k < items.size(); ++k) cum[k + 1] = cum[k] + (items[k].ze - items[k].zb) + 2;
-  int first[9];
-  first[0] = 0;
-  for (int x = 1; x < 8; ++x) {
-    const int64_t want = cum.back() * x / 8;
-    first[x] = (int)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
-    first[x] = std::max(first[x - 1], std::min(first[x], (int)items.size()));
+  if (!(f.z_lo_phys && f.z_hi_phys)) {
+    // a decomposed grid: the planes that need no ghost plane of p (their launch overlaps the exchange), then the one or two
+    // slab-boundary planes -- the same split as beat_var_spmv_dot_part's
+    const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
+    std::vector<VtlItem> b_lo, b_hi;
+    bool ok = build(lo, std::max(lo, hi), max_run, part_items[0]);
+    if (!f.z_lo_phys) ok = build(0, 1, max_run, b_lo) && ok;
+    if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) ok = build(f.nz - 1, f.nz, max_run, b_hi) && ok;
+    part_items[1] = b_lo;
+    part_items[1].insert(part_items[1].end(), b_hi.begin(), b_hi.end());
+    if (!ok || (int64_t)part_items[0].size() + (int64_t)part_items[1].size() > BEAT_MAX_PARTIALS) {
+      part_items[0].clear();  // (the split launches keep the segment-list kernel)
+      part_items[1].clear();
+    }
   }
-  first[8] = (int)items.size();
-  d->nitems = (int)items.size();
+  int first[3][9];
+  d->list_base[0] = 0;
+  d->list_count[0] = (int)items.size();
+  parts(items, 0, first[0]);
+  for (int k = 0; k < 2; ++k) {
+    d->list_base[k + 1] = (int)items.size();
+    d->list_count[k + 1] = (int)part_items[k].size();
+    parts(part_items[k], d->list_base[k + 1], first[k + 1]);
+    items.insert(items.end(), part_items[k].begin(), part_items[k].end());
+  }
+  d->nitems = d->list_count[0];
   pde->vtl = d;
   hipError_t e = hipMalloc(&d->d_items, sizeof(VtlItem) * std::max<size_t>(1, items.size()));
   if (e == hipSuccess && !items.empty()) e = hipMemcpy(d->d_items, items.data(), sizeof(VtlItem) * items.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&d->d_xcd_first, 2 * sizeof(first));
-  if (e == hipSuccess) e = hipMemset(d->d_xcd_first, 0, 2 * sizeof(first));
+  if (e == hipSuccess) e = hipMalloc(&d->d_xcd_first, sizeof(first) + 9 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(d->d_xcd_first, 0, sizeof(first) + 9 * sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(d->d_xcd_first, first, sizeof(first), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&d->d_mask, sizeof(u64) * mask.size());
   if (e == hipSuccess) e = hipMemcpy(d->d_mask, mask.data(), sizeof(u64) * mask.size(), hipMemcpyHostToDevice);
@@ -628,18 +662,17 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
   d->resident = RY == 8 ? vtl_resident_blocks<8>() : vtl_resident_blocks<4>();
   if (std::getenv("BEAT_VTL_VERBOSE")) {
     long planes = 0;
-    for (const VtlItem& it : items) planes += it.ze - it.zb;
-    std::fprintf(stderr, "vtl: RY %d, %d x %d columns, %d tiles, %.1f planes per tile, %u resident blocks, parts %d %d %d %d %d %d %d %d\n", RY,
-                 nsegx, nrb, d->nitems, d->nitems ? (double)planes / d->nitems : 0.0, d->resident, first[1] - first[0],
-                 first[2] - first[1], first[3] - first[2], first[4] - first[3], first[5] - first[4], first[6] - first[5],
-                 first[7] - first[6], first[8] - first[7]);
+    for (int k = 0; k < d->nitems; ++k) planes += items[(size_t)k].ze - items[(size_t)k].zb;
+    std::fprintf(stderr, "vtl: RY %d, %d x %d columns, %d tiles (+ %d / %d for the split launches), %.1f planes per tile, %u resident blocks\n", RY,
+                 nsegx, nrb, d->nitems, d->list_count[1], d->list_count[2], d->nitems ? (double)planes / d->nitems : 0.0, d->resident);
   }
   return BEAT_OK;
 }
 
 bool beat_vtl_available(const beat_pde* pde) { return pde->var && pde->vtl != nullptr && ((VtlData*)pde->vtl)->nitems > 0; }
 
-static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first);
+static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
+                      int list = 0, int part_off = 0, bool reduce = true, int reduce_count = 0);
 
 // whole-slab q = A p and the sum p.q
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
@@ -659,7 +692,8 @@ bool beat_vtl_pdot_available(const beat_pde* pde) {
   return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && ((VtlData*)pde->vtl)->ry == 8 && pde->g.z_lo_phys && pde->g.z_hi_phys;
 }
 
-static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first) {
+static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
+                      int list, int part_off, bool reduce, int reduce_count) {
   const bool pdot = dev_r != nullptr;
   VtlData* d = (VtlData*)pde->vtl;
   const Geom& f = pde->g;
@@ -672,17 +706,21 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   a.nsegx = d->nsegx;
   a.nzp = d->nzp;
   a.partials = pde->ctx->d_partials;
-  a.part_off = 0;
+  const int count = d->list_count[list];
+  if (count == 0) {  // (a split launch without tiles: only the reduction over what the other part wrote)
+    return reduce ? beat_pde_launch_reduce(pde, reduce_count, 1, dev_st + PQ, dev_st) : BEAT_OK;
+  }
+  a.part_off = part_off - d->list_base[list];  // the kernel indexes its partial by the tile's position in the whole array
   a.st = dev_st;
   // blocks in eights (one per XCD), at most the resident number, at least one tile per block on average
-  const unsigned grid = std::max(8u, std::min(d->resident, (unsigned)((d->nitems + 7) & ~7)));
+  const unsigned grid = std::max(8u, std::min(d->resident, (unsigned)((count + 7) & ~7)));
   a.x = dev_p;
   a.y = dev_q;
   a.rows = pde->v_A;
   a.mask = d->d_mask;
   a.items = d->d_items;
-  a.xcd_first = d->d_xcd_first;
-  a.next = d->d_xcd_first + 9;
+  a.xcd_first = d->d_xcd_first + 9 * list;
+  a.next = d->d_xcd_first + 27;
   a.r = dev_r;
   a.pnew = dev_p_new;
   a.first = first;
@@ -695,5 +733,20 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
     d->dyn ? launch(vtl_spmv_kernel<4, true, false>, 4) : launch(vtl_spmv_kernel<4, false, false>, 4);
   }
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, d->nitems, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
+  if (!reduce) return BEAT_OK;
+  return beat_pde_launch_reduce(pde, reduce_count ? reduce_count : count, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
+}
+
+// the split launches of a decomposed grid: part 0 = the planes that need no ghost plane of p (no reduction), part 1 = the
+// slab-boundary planes + the sum over both parts' tiles
+bool beat_vtl_parts_available(const beat_pde* pde) {
+  if (!(pde->var && pde->vtl != nullptr)) return false;
+  const VtlData* d = (const VtlData*)pde->vtl;
+  return d->list_count[1] + d->list_count[2] > 0;
+}
+
+int beat_vtl_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part) {
+  const VtlData* d = (const VtlData*)pde->vtl;
+  if (part == 0) return vtl_launch(pde, dev_p, dev_q, dev_st, nullptr, nullptr, 0, 1, 0, false, 0);
+  return vtl_launch(pde, dev_p, dev_q, dev_st, nullptr, nullptr, 0, 2, d->list_count[1], true, d->list_count[1] + d->list_count[2]);
 }

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="voxels per axis of the bounding box")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dense", action="store_true", help="every voxel active (a box with a fibre field): per-node rows without a mask")
+    ap.add_argument("--slab", action="store_true", help="both z faces belong to neighbouring ranks: time the SpMV of the decomposed solve "
+                    "(the planes that need no ghost data, then the two slab-boundary planes + the reduction)")
     args = ap.parse_args()
     import torch
 
@@ -40,7 +42,8 @@ def main():
     ctx = Context(0)
     HipOps.from_voxels(ctx, 3, (8, 8, 8), (h, h, h), np.eye(3), None, (9, 9, 9), 0, True, True)  # warm-up
     tic = time.perf_counter()
-    ops = HipOps.from_voxels(ctx, 3, (n, n, n), (h, h, h), M, mask.ravel(), (nn, nn, nn), 0, True, True)
+    phys = not args.slab
+    ops = HipOps.from_voxels(ctx, 3, (n, n, n), (h, h, h), M, mask.ravel(), (nn, nn, nn), 0, phys, phys)
     ctx.synchronize()
     t_asm = time.perf_counter() - tic
     active_nodes = int((ops._mass_dev[0] > 0).sum())
@@ -78,6 +81,13 @@ def main():
     timeit("apply A (per-node rows)", lambda: ops.apply(0, v, y), 136)
     ops.st.zero_()
     timeit("spmv_dot (+reduce)", lambda: ops.spmv_dot(), 136)
+    if args.slab:
+        def two_parts():
+            ops.spmv_interior(ops.p)
+            ops.spmv_boundary(ops.p)
+
+        timeit("spmv in two parts (+reduce)", two_parts, 136)
+        return
     timeit("rhs (A and K rows, +reduce)", lambda: ops.rhs(v, [], [], v), 264)
     x = ops.new_field()
     res = None
