@@ -18,9 +18,16 @@
 //     below, the four slots of the row below) are six more loads per plane, dealt to the waves;
 //   * x-neighbours by DPP wave shifts; lanes on nodes outside the tissue issue no loads (per-row 64-bit masks, a table
 //     laid out along z and read with scalar loads two steps ahead), so lines without tissue are never fetched.
-// Per plane and tile: 9 RY + 6 wave loads for 62 RY nodes (RY = 4: 10.5 per 62 nodes instead of 23 per 64).  The values
+// Per plane and tile: 9 RY + 6 wave loads for 62 RY nodes (RY = 8: 9.75 per 62 nodes instead of 23 per 64).  The values
 // of q are those of var_spmv_kernel bit for bit (same coefficients, the same 15 fused multiply-adds in slot order);
-// the block partials of p.q are summed in another order.
+// p.q is summed per TILE and the tiles in list order (the same bits whoever computed what).
+// Inside the solver the same pass also FORMS the search direction (PDOT = true, beat_vtl_pdot): it reads r and the previous
+// direction instead of p, builds p = D^-1 r + beta p_old wherever the product needs it (own row, rows above and below, halo
+// lanes; D^-1 = 1 / the row's own centre coefficient), stores it and computes q = A p -- var_pupdate_oop_kernel's pass over
+// r, p_old and 1/diag is gone from the iteration.  Three tile lists per operator: the whole slab, and for decomposed
+// grids the planes that need no ghost plane of p and the one or two that do (beat_vtl_spmv_dot_part).
+// Measured (profiles/r04_shell400.md, r04_var_resources.md): SpMV 529-543 -> 403-427 us on an 18.6 M-node shell, 121 -> 105
+// B/node from beyond the L2; the fused pass 475 us against 375 + 125; 119-125 VGPRs, no scratch, no spilled SGPR.
 //
 // Replaces, like beat_pde_var.hip, PETSc's MatMult inside KSP.solve (src/beat/base_model.py:236) for operators assembled
 // from per-cell conductivity tensors (src/beat/conductivities.py:101-118, demos/biv_endocardial.py:187-282).
