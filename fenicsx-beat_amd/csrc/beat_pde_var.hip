@@ -238,6 +238,9 @@ __device__ __forceinline__ int var_edge_offset(int lane, const int (&doff)[15]) 
 __device__ __forceinline__ void var_row_coefficients(const double* __restrict__ T, int64_t ld, int64_t i, bool active,
                                                      int64_t safe, const int (&doff)[15], double (&c)[15]) {
   const int64_t ii = active ? i : safe;
+  // (the row stride opaque per segment: the 15 products k ld of each operator are loop invariants otherwise, hoisted into
+  // SGPR pairs the kernel does not have -- 111 spilled SGPRs in var_rhs_kernel)
+  asm volatile("" : "+s"(ld));
 #pragma unroll
   for (int k = 0; k < 15; ++k) {
     int64_t src = (int64_t)k * ld + ii;
@@ -343,14 +346,20 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_spmv_kernel(VarArgs a) {
 // same bits) with the rows of v_ -- and of the guess increment e -- loaded once and shifted across the wave like the
 // SpMV's: T1 = A, T2 = K;  r0 = dt (stim - K v_),  b = A v_ + r0,  r = r0 - A e,  z = D^-1 r,  partials of b.b, r.z, r.r.
 // The 2 x 15 gathers per node of the plain kernel made it cost three SpMVs (1.82 against 0.58 ms on a 401^3 shell).
-__global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a) {
+__global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a_) {
   __shared__ double red[4];
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  const int64_t nwork = a.seg ? a.nseg : (a.i_hi - a.i_lo + VAR_SEG - 1) / VAR_SEG;
+  const int64_t nwork = a_.seg ? a_.nseg : (a_.i_hi - a_.i_lo + VAR_SEG - 1) / VAR_SEG;
   const int wave = var_wave(), lane = threadIdx.x % VAR_SEG;
-  const int edge_off = var_edge_offset(lane, a.doff);
-  const VarWalk walk = var_walk(a, nwork, wave);
+  const int edge_off = var_edge_offset(lane, a_.doff);
+  const VarWalk walk = var_walk(a_, nwork, wave);
   for (int64_t w = walk.w; w < walk.end; w += walk.stride) {
+    // the arguments through a pointer the optimiser cannot see through, per segment: the 15 offsets, the operator and
+    // stimulus pointers are read where a segment needs them instead of being held in SGPRs across the loop (67 spilled)
+    typedef const __attribute__((address_space(4))) char* KArgPtr;
+    KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const VarArgs& a = *(const VarArgs*)ka;
     const int64_t seg0 = a.seg ? (int64_t)a.seg[w] * VAR_SEG : a.i_lo + w * VAR_SEG;  // wave-uniform
     const int64_t i = seg0 + lane;
     const bool active = i >= a.i_lo && i < a.i_hi && (!a.seg || ((a.segmask[w] >> lane) & 1ull));
@@ -393,9 +402,9 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_rhs_kernel(VarArgs a) {
   const double s1 = beat_block_sum(acc1, red);
   const double s2 = beat_block_sum(acc2, red);
   if (threadIdx.x == 0) {
-    a.partials[a.part_off + blockIdx.x] = s0;
-    a.partials[BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s1;
-    a.partials[2 * BEAT_MAX_PARTIALS + a.part_off + blockIdx.x] = s2;
+    a_.partials[a_.part_off + blockIdx.x] = s0;
+    a_.partials[BEAT_MAX_PARTIALS + a_.part_off + blockIdx.x] = s1;
+    a_.partials[2 * BEAT_MAX_PARTIALS + a_.part_off + blockIdx.x] = s2;
   }
 }
 
