@@ -1239,8 +1239,12 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
     BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
     beat_guess_begin(pde);
-    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
-                      pde->guess.use_e ? pde->guess.e : nullptr);
+    if (beat_vtl_rhs_available(pde))  // two tile passes (K v_, then A on v_ and e) instead of the gather kernel; q is free until iteration 0
+      rc = beat_vtl_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, q, st,
+                        pde->guess.use_e ? pde->guess.e : nullptr);
+    else
+      rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
+                        pde->guess.use_e ? pde->guess.e : nullptr);
   } else {
     rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
   }

@@ -155,6 +155,9 @@ int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double*
 bool beat_vtl_parts_available(const beat_pde* pde);
 int beat_vtl_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 bool beat_vtl_pdot_available(const beat_pde* pde);
+bool beat_vtl_rhs_available(const beat_pde* pde);
+int beat_vtl_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                 double* dev_x, double* dev_r, double* dev_p, double* dev_t, double* dev_red, const double* dev_e);
 int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q, int first);
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)

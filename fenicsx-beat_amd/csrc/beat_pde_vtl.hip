@@ -68,6 +68,15 @@ struct VtlArgs {
   const double* r;
   double* pnew;
   int first;               // iteration 0: p = D^-1 r (beta = 0, p_old not read)
+  // RHS (mode 2, the right-hand side of a step in residual form, what var_rhs_kernel computes): x = v_, r = the guess
+  // increment e (or nullptr), t = K v_ (from a plain tile pass over the stiffness rows), y = the residual r0 - A e with
+  // r0 = dt (stim - K v_), pnew = D^-1 r; per-tile partials of b.b (b = A v_ + r0), r.z and r.r
+  const double* t;
+  double dt;
+  const double* w[BEAT_MAX_STIM];
+  double amp[BEAT_MAX_STIM];
+  int nstim;
+  int ignore_stop;         // launches outside the iteration (the latch of the previous solve is still set)
 };
 
 __device__ __forceinline__ double vtl_from_left(double v) {
@@ -101,17 +110,20 @@ __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsi
 
 // forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
 // 13 +x+y+z; the backward slot k+1 pairs with the forward slot k.  F[] below holds them in that order.
-template <int RY, bool DYN, bool PDOT>
-__global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
+template <int RY, bool DYN, int MODE>
+__global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(VtlArgs a_) {
+  constexpr bool PDOT = MODE == 1, RHS = MODE == 2;
+  constexpr int NPE = RHS ? 4 : 2;  // halo entries that are rows of a vector: p below / above (RHS: v_ below / above, e below / above)
   // one LDS array: p of plane z+1 for rows y0-1 .. y0+RY of the tile (two buffers), slots 3, 7, 9, 13 of plane z for rows
   // y0-1 .. y0+RY-2 (two buffers), and a row per wave that absorbs the stores of a wave without a (second) halo load
   constexpr int P_PAR = (RY + 2) * 64, C_PAR = RY * 4 * 64;
-  constexpr int P_BASE = 0, C_BASE = 2 * P_PAR, DUMMY = C_BASE + 2 * C_PAR;
-  constexpr bool TWO = RY < 6;  // six halo loads per plane: two per wave when a tile has fewer than six rows
-  __shared__ double lds[DUMMY + RY * 64];
-  __shared__ double red[RY];
+  constexpr int P_BASE = 0, C_BASE = 2 * P_PAR, DUMMY = C_BASE + 2 * C_PAR, P2_BASE = DUMMY + RY * 64;  // (P2: the second vector of RHS)
+  constexpr bool TWO = RY < NPE + 4;  // NPE + 4 halo loads per plane: two per wave when a tile has fewer rows than that
+  static_assert(!RHS || !TWO, "the right-hand side pass is built for tiles of 8 rows");
+  __shared__ double lds[P2_BASE + (RHS ? 2 * P_PAR : 0)];
+  __shared__ double red[3 * RY];
   __shared__ int next_item;
-  if (a_.st[STOP] != 0.0) return;
+  if (a_.st[STOP] != 0.0 && !a_.ignore_stop) return;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const u64 lanebit = 1ull << lane;
@@ -218,21 +230,21 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
     // needs is re-derived from its number where it is used (a handful of scalar instructions per plane): kept as
     // pointers, the descriptors cost the SGPRs the kernel does not have
     const int ea = w, eb = w + RY;
-    auto halo_row = [&](int e) -> int { return e == 1 ? y0 + RY : y0 - 1; };
+    auto halo_row = [&](int e) -> int { return (e < NPE && (e & 1)) ? y0 + RY : y0 - 1; };
     const unsigned roff_a = (unsigned)(min(max(halo_row(ea), 0), a.ny - 1) * a.nx + cx);
     const unsigned roff_b = (unsigned)(min(max(halo_row(eb), 0), a.ny - 1) * a.nx + cx);
     const int moff_a = ((min(max(halo_row(ea), -1), a.ny) + 1) * a.nsegx + item.seg) * a.nzp + 1;
     const int moff_b = ((min(max(halo_row(eb), -1), a.ny) + 1) * a.nsegx + item.seg) * a.nzp + 1;
-    auto halo_plane = [&](int e, int z) -> int { return z + (e < 2 ? 2 : 1); };  // what step z loads (step z+1 publishes)
+    auto halo_plane = [&](int e, int z) -> int { return z + (e < NPE ? 2 : 1); };  // what step z loads (step z+1 publishes)
     auto halo_mask = [&](int e, int moff, int z) -> u64 { return MASK[moff + halo_plane(e, z)]; };
     auto halo_load = [&](int e, u64 mk, unsigned ro, int z) -> Trio {
-      const bool is_p = e < 2;
+      const bool is_p = e < NPE;
       const int zz = halo_plane(e, z);
-      const bool want = e < 6 && zz <= (is_p ? ze : ze - 1);
+      const bool want = e < NPE + 4 && zz <= (is_p ? ze : ze - 1);
       const u64 m = want ? mk : 0ull;
       int64_t ld = a.ld;
       asm volatile("" : "+s"(ld));
-      const int slot = (0xD973 >> (4 * ((e - 2) & 3))) & 15;  // 3, 7, 9, 13
+      const int slot = (0xD973 >> (4 * ((e - NPE) & 3))) & 15;  // 3, 7, 9, 13
       Trio t{0.0, 0.0, 0.0};
       if constexpr (PDOT) {
         // a p entry is three loads (r, p_old, c0), a coefficient entry one: the two others run with every lane out of range
@@ -243,6 +255,13 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, off);
         t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, first ? VTL_OOB : offp);
         t.c0 = vtl_buf_load(A + (int64_t)zz * a.plane, pbytes, offp);
+      } else if constexpr (RHS) {
+        KArgPtr kr = ka;
+        asm volatile("" : "+s"(kr));
+        const double* E = ((const VtlArgs*)kr)->r;  // the guess increment, or nullptr: nothing loaded, 0
+        const bool is_e = is_p && (e & 2) != 0;
+        const double* base = is_p ? (is_e ? E : X) : A + slot * ld;
+        t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, (is_e && E == nullptr) ? VTL_OOB : lane_off(m, ro));
       } else {
         const double* base = is_p ? X : A + slot * ld;
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, lane_off(m, ro));
@@ -257,16 +276,21 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       }
     };
     auto halo_lds = [&](int e, int z) -> int {  // where step z publishes it
-      const int par = (e < 2 ? z + 1 : z) & 1;
-      const int p_at = P_BASE + par * P_PAR + (e & 1) * (RY + 1) * 64, c_at = C_BASE + par * C_PAR + (e - 2) * 64;
-      const int at = e < 2 ? p_at : c_at;
-      return e >= 6 ? DUMMY + w * 64 : at;
+      const int par = (e < NPE ? z + 1 : z) & 1;
+      const int p_at = ((e & 2) ? P2_BASE : P_BASE) + par * P_PAR + (e & 1) * (RY + 1) * 64, c_at = C_BASE + par * C_PAR + (e - NPE) * 64;
+      const int at = e < NPE ? p_at : c_at;
+      return e >= NPE + 4 ? DUMMY + w * 64 : at;
     };
 
     // ---- prologue: the planes below the run, straight from memory ------------------------------------------------------
     u64 M0 = MASK[mo_own + zb], M1 = MASK[mo_own + zb + 1], M2 = MASK[mo_own + zb + 2];
     double Pm, P0, U0, D0, Dm, K5, K9, K11, K13;
     double C0keep = 0.0;  // PDOT: the centre coefficient of the plane after this one's p was formed from, until it is F[0]
+    double Em = 0.0, E0 = 0.0, EU0 = 0.0, ED0 = 0.0, EDm = 0.0, acc1 = 0.0, acc2 = 0.0;  // RHS: the second vector's window; partials
+    const double* __restrict__ Ev = RHS ? a.r : nullptr;
+    auto lde = [&](u64 mk, int z, unsigned ro) -> double {
+      return vtl_buf_load(Ev + (int64_t)z * a.plane, pbytes, Ev != nullptr ? lane_off(mk, ro) : VTL_OOB);
+    };
     const u64 out_lanes = ((1ull << SEG) - 1ull) << 1;
     bool direct = zb == 0;
     {
@@ -288,6 +312,13 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       U0 = ldpv(MASK[mo_up + zb], zb, roff_up);
       D0 = ldpv(MASK[mo_dn + zb], zb, roff_dn);
       Dm = ldpv(md, zb - 1, roff_dn);
+      if constexpr (RHS) {
+        Em = lde(mo, zb - 1, roff);
+        E0 = lde(M0, zb, roff);
+        EU0 = lde(MASK[mo_up + zb], zb, roff_up);
+        ED0 = lde(MASK[mo_dn + zb], zb, roff_dn);
+        EDm = lde(md, zb - 1, roff_dn);
+      }
       // coefficients of the plane below towards this one: slots 5 / 11 of the own row, 9 / 13 of the row below.  Plane 0
       // of a slab has no stored plane below it: its own backward slots 6, 10, 12, 14 are used as they are (what
       // var_spmv_kernel does; zero on a physical face)
@@ -319,12 +350,16 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       }
     };
     load_coefs(M0, zb);
-    double Pn = 0.0;
+    double Pn = 0.0, En = 0.0, Kvn = 0.0;
     Trio Tn{0.0, 0.0, 0.0};
     if constexpr (PDOT) {
       Tn = ld3(M1, zb + 1, roff);
     } else {
       Pn = ldp(M1, zb + 1, roff);
+    }
+    if constexpr (RHS) {
+      En = lde(M1, zb + 1, roff);
+      Kvn = vtl_buf_load(a.t + (int64_t)zb * a.plane, pbytes, lane_off(M0, roff));  // K v_ of this plane
     }
     Trio Ean = halo_load(ea, halo_mask(ea, moff_a, zb - 1), roff_a, zb - 1);
     Trio Ebn{0.0, 0.0, 0.0};
@@ -347,6 +382,7 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
         vtl_buf_store(az.pnew + (int64_t)(z + 1) * a.plane, pbytes, (z + 1 < ze && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
       }
       const double Ea = halo_value(ea, Ean), Eb = TWO ? halo_value(eb, Ebn) : 0.0;
+      const double Ep = En, Kv = Kvn;
       // masks: one step (the halo loads') and two steps (the own row's) ahead of their use
       const u64 M3 = MASK[mo_own + z + 3];
       const u64 HAn = halo_mask(ea, moff_a, z + 1);
@@ -358,10 +394,15 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       } else {
         Pn = ldp(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
       }
+      if constexpr (RHS) {
+        En = lde(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
+        Kvn = vtl_buf_load(az.t + (int64_t)(z + 1) * a.plane, pbytes, lane_off(z + 1 < ze ? M1 : 0ull, roff));
+      }
       Ean = halo_load(ea, HA, roff_a, z);
       if (TWO) Ebn = halo_load(eb, HB, roff_b, z);
       // publish this row
       lds[P_BASE + ((z + 1) & 1) * P_PAR + (w + 1) * 64 + lane] = Pp;
+      if constexpr (RHS) lds[P2_BASE + ((z + 1) & 1) * P_PAR + (w + 1) * 64 + lane] = Ep;
       {
         double* __restrict__ cw = lds + (w + 1 < RY ? C_BASE + (z & 1) * C_PAR + (w + 1) * 4 * 64 : DUMMY + w * 64) + lane;
         const int cs = w + 1 < RY ? 64 : 0;
@@ -375,6 +416,12 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       __syncthreads();
       const double* __restrict__ pr = lds + P_BASE + ((z + 1) & 1) * P_PAR + w * 64 + lane;
       const double Dn = pr[0], Un = pr[128];
+      double EDn = 0.0, EUn = 0.0;
+      if constexpr (RHS) {
+        const double* __restrict__ pe = lds + P2_BASE + ((z + 1) & 1) * P_PAR + w * 64 + lane;
+        EDn = pe[0];
+        EUn = pe[128];
+      }
       const double* __restrict__ cr = lds + C_BASE + (z & 1) * C_PAR + w * 4 * 64 + lane;
       const double H3 = cr[0], H7 = cr[64], H9 = cr[128], H13 = cr[192];
       double c[15], v[15];
@@ -414,8 +461,51 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
 #pragma unroll
       for (int k = 0; k < 15; ++k) s = fma(c[k], (k == 0 || c[k] != 0.0) ? v[k] : 0.0, s);
       const bool out = (M0 & lanebit & out_lanes) != 0ull;
-      acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
-      vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
+      if constexpr (RHS) {
+        // s = A v_; the same coefficients on the window of the guess increment: se = A e
+        double ve[15];
+        ve[0] = E0;
+        ve[1] = vtl_from_right(E0);
+        ve[2] = vtl_from_left(E0);
+        ve[3] = EU0;
+        ve[4] = ED0;
+        ve[5] = Ep;
+        ve[6] = Em;
+        ve[7] = vtl_from_right(EU0);
+        ve[8] = vtl_from_left(ED0);
+        ve[9] = EUn;
+        ve[10] = EDm;
+        ve[11] = vtl_from_right(Ep);
+        ve[12] = vtl_from_left(Em);
+        ve[13] = vtl_from_right(EUn);
+        ve[14] = vtl_from_left(EDm);
+        double se = 0.0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) se = fma(c[k], (k == 0 || c[k] != 0.0) ? ve[k] : 0.0, se);
+        // r0 = dt (stim - K v_), b = A v_ + r0, r = r0 - A e, z = D^-1 r: var_rhs_kernel's expressions (same bits)
+        double stim = 0.0;
+        for (int k = 0; k < az.nstim; ++k)
+          stim = fma(az.amp[k], vtl_buf_load(az.w[k] + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB), stim);
+        const double r0 = az.dt * (stim - Kv);
+        const double b = s + r0;
+        const double rr = r0 - se;
+        const double zz = (1.0 / F[0]) * rr;
+        if (out) {
+          acc = fma(b, b, acc);
+          acc1 = fma(rr, zz, acc1);
+          acc2 = fma(rr, rr, acc2);
+        }
+        vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, rr);
+        vtl_buf_store(az.pnew + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, zz);
+        Em = E0;
+        E0 = Ep;
+        EU0 = EUn;
+        EDm = ED0;
+        ED0 = EDn;
+      } else {
+        acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
+        vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
+      }
       // roll: this plane becomes the plane below
       Pm = P0;
       P0 = Pp;
@@ -433,15 +523,26 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {
       HA = HAn;
       HB = HBn;
     }
-    // the tile's share of p.q, summed in wave order
+    // the tile's share of p.q (RHS: of b.b, r.z, r.r), summed in wave order
     acc = beat_wave_sum(acc);
     if (lane == 0) red[w] = acc;
+    if constexpr (RHS) {
+      acc1 = beat_wave_sum(acc1);
+      acc2 = beat_wave_sum(acc2);
+      if (lane == 0) {
+        red[RY + w] = acc1;
+        red[2 * RY + w] = acc2;
+      }
+    }
     __syncthreads();
     if (w == 0) {
-      double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < RY; ++k) t += red[k];
-      if (lane == 0) a.partials[a.part_off + it] = t;
+      for (int q = 0; q < (RHS ? 3 : 1); ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < RY; ++k) t += red[q * RY + k];
+        if (lane == 0) a.partials[q * BEAT_MAX_PARTIALS + a.part_off + it] = t;
+      }
     }
   }
   // the last workgroup to leave rewinds the counters for the next launch
@@ -460,6 +561,7 @@ struct VtlData {
   int ry = 4;
   bool dyn = false;
   bool pdot = true;  // BEAT_VTL_PDOT=0: the three-kernel iteration (SpMV, residual update, direction update)
+  bool rhs = false;  // BEAT_VTL_RHS=1: the right-hand side in two tile passes instead of var_rhs_kernel's gathers
   VtlItem* d_items = nullptr;
   int* d_xcd_first = nullptr;  // per list 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
   u64* d_mask = nullptr;
@@ -472,7 +574,7 @@ struct VtlData {
 
 template <int RY>
 unsigned vtl_resident_blocks() {
-  auto kernel = vtl_spmv_kernel<RY, false, RY == 8>;
+  auto kernel = vtl_spmv_kernel<RY, false, RY == 8 ? 1 : 0>;
   int dev = 0, cus = 256, per_cu = 1;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -516,6 +618,11 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
     d->dyn = dy && dy[0] == '1';
     const char* pd = std::getenv("BEAT_VTL_PDOT");
     d->pdot = !(pd && pd[0] == '0');
+    // the right-hand side in two tile passes (beat_vtl_rhs) is opt-in, BEAT_VTL_RHS=1: correct (same bits as var_rhs_kernel),
+    // but the pass with two vector windows needs 166 VGPRs -- one workgroup of 8 waves per CU -- and a whole extra product
+    // for K v_: 10.62 -> 10.55 ms per shell step (tools/bench_biv.py --n 400, A B A B on one box), not worth a default
+    const char* rh = std::getenv("BEAT_VTL_RHS");
+    d->rhs = rh && rh[0] == '1';
   }
   int max_run = 16;
   if (const char* e = std::getenv("BEAT_VTL_RUN")) max_run = std::max(1, std::atoi(e));
@@ -678,8 +785,20 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
 
 bool beat_vtl_available(const beat_pde* pde) { return pde->var && pde->vtl != nullptr && ((VtlData*)pde->vtl)->nitems > 0; }
 
+// what the two passes of the right-hand side add to a launch: other coefficient rows (pass 1: K), or mode 2 with its operands
+struct VtlRhs {
+  const double* rows;  // coefficient rows of this pass (nullptr: A)
+  int mode;            // 0: plain product with `rows`; 2: the right-hand side pass
+  const double* e;     // guess increment or nullptr
+  const double* t;     // K v_
+  double dt;
+  const double* w[BEAT_MAX_STIM];
+  double amp[BEAT_MAX_STIM];
+  int nstim;
+  double* red_out;     // b.b, r.z, r.r
+};
 static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
-                      int list = 0, int part_off = 0, bool reduce = true, int reduce_count = 0);
+                      int list = 0, int part_off = 0, bool reduce = true, int reduce_count = 0, const VtlRhs* rhs = nullptr);
 
 // whole-slab q = A p and the sum p.q
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st) {
@@ -700,8 +819,9 @@ bool beat_vtl_pdot_available(const beat_pde* pde) {
 }
 
 static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
-                      int list, int part_off, bool reduce, int reduce_count) {
-  const bool pdot = dev_r != nullptr;
+                      int list, int part_off, bool reduce, int reduce_count, const VtlRhs* rhs) {
+  const bool rhs2 = rhs != nullptr && rhs->mode == 2;
+  const bool pdot = dev_r != nullptr && !rhs2;
   VtlData* d = (VtlData*)pde->vtl;
   const Geom& f = pde->g;
   VtlArgs a{};
@@ -723,25 +843,72 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   const unsigned grid = std::max(8u, std::min(d->resident, (unsigned)((count + 7) & ~7)));
   a.x = dev_p;
   a.y = dev_q;
-  a.rows = pde->v_A;
+  a.rows = (rhs != nullptr && rhs->rows != nullptr) ? rhs->rows : pde->v_A;
+  a.ignore_stop = rhs != nullptr;
+  if (rhs2) {
+    a.t = rhs->t;
+    a.dt = rhs->dt;
+    a.nstim = rhs->nstim;
+    for (int k = 0; k < rhs->nstim; ++k) {
+      a.w[k] = rhs->w[k];
+      a.amp[k] = rhs->amp[k];
+    }
+  }
   a.mask = d->d_mask;
   a.items = d->d_items;
   a.xcd_first = d->d_xcd_first + 9 * list;
   a.next = d->d_xcd_first + 27;
-  a.r = dev_r;
+  a.r = rhs2 ? rhs->e : dev_r;
   a.pnew = dev_p_new;
   a.first = first;
   auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
-  if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
-    launch(vtl_spmv_kernel<8, false, true>, 8);
+  if (rhs2) {
+    launch(vtl_spmv_kernel<8, false, 2>, 8);
+  } else if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
+    launch(vtl_spmv_kernel<8, false, 1>, 8);
   } else if (d->ry == 8) {
-    d->dyn ? launch(vtl_spmv_kernel<8, true, false>, 8) : launch(vtl_spmv_kernel<8, false, false>, 8);
+    d->dyn ? launch(vtl_spmv_kernel<8, true, 0>, 8) : launch(vtl_spmv_kernel<8, false, 0>, 8);
   } else {
-    d->dyn ? launch(vtl_spmv_kernel<4, true, false>, 4) : launch(vtl_spmv_kernel<4, false, false>, 4);
+    d->dyn ? launch(vtl_spmv_kernel<4, true, 0>, 4) : launch(vtl_spmv_kernel<4, false, 0>, 4);
   }
   BEAT_LAUNCH_CHECK();
   if (!reduce) return BEAT_OK;
+  if (rhs2) return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr);
   return beat_pde_launch_reduce(pde, reduce_count ? reduce_count : count, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
+}
+
+// The right-hand side of a step on the tiles (what beat_var_rhs computes with gathers, 340 B/node from beyond the L2 on the
+// 401^3 shell against 168 algorithmic): pass 1, the plain tile product over the STIFFNESS rows, t = K v_; pass 2, the tile
+// pass over A with TWO vector windows (v_ and the guess increment e), r0 = dt (stim - t), b = A v_ + r0, r = r0 - A e,
+// z = D^-1 r, per-tile partials of b.b, r.z, r.r.  var_rhs_kernel's expressions in its order: the same bits.  Single slabs,
+// tiles of 8 rows.  dev_t: a work field (the solver's q, free until the first iteration).
+bool beat_vtl_rhs_available(const beat_pde* pde) {
+  if (!(beat_vtl_available(pde) && pde->g.z_lo_phys && pde->g.z_hi_phys)) return false;
+  const VtlData* d = (const VtlData*)pde->vtl;
+  return d->ry == 8 && d->rhs;
+}
+
+int beat_vtl_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                 double* dev_x, double* dev_r, double* dev_p, double* dev_t, double* dev_red, const double* dev_e) {
+  if (dev_x != dev_v_prev)  // nodes outside the tissue keep their value: copy everything first (as beat_var_rhs does)
+    BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice, pde->ctx->stream));
+  VtlRhs one{};
+  one.rows = pde->v_stiff;
+  one.mode = 0;
+  if (int rc = vtl_launch(pde, dev_v_prev, dev_t, pde->d_st, nullptr, nullptr, 0, 0, 0, false, 0, &one)) return rc;
+  VtlRhs two{};
+  two.mode = 2;
+  two.e = dev_e;
+  two.t = dev_t;
+  two.dt = pde->dt;
+  two.red_out = dev_red;
+  for (int k = 0; k < n_stim; ++k) {
+    if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
+    two.w[two.nstim] = host_dev_stim_w[k];
+    two.amp[two.nstim] = host_stim_amp[k];
+    ++two.nstim;
+  }
+  return vtl_launch(pde, dev_v_prev, dev_r, pde->d_st, nullptr, dev_p, 0, 0, 0, true, 0, &two);
 }
 
 // the split launches of a decomposed grid: part 0 = the planes that need no ghost plane of p (no reduction), part 1 = the

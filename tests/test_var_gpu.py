@@ -412,6 +412,64 @@ def test_workgroup_tile_spmv_equals_the_stored_row_kernel_bit_for_bit(hip_ctx, c
         np.testing.assert_array_equal(out[fused][2], out[three][2], err_msg=fused)
 
 
+@pytest.mark.parametrize("cells,L", [((70, 20, 40), (7.0, 2.0, 4.0)), ((22, 17, 13), (2.2, 1.7, 1.3))])
+def test_right_hand_side_on_the_tiles_equals_the_gather_kernel(hip_ctx, cells, L, monkeypatch):
+    """The right-hand side of a step in two tile passes (csrc/beat_pde_vtl.hip: t = K v_ with the plain tile product over the
+    stiffness rows, then the pass over A with the windows of v_ AND of the guess increment: r0 = dt (stim - t), b = A v_ + r0,
+    r = r0 - A e, z = D^-1 r) against var_rhs_kernel (BEAT_VTL_RHS=0) on masked grids with per-cell tensors and a stimulus
+    weight field: after a solve cut off before its first iteration the residual r and the first direction D^-1 r are
+    identical bit for bit on every tissue node, ||b||^2, r.z and r.r equal to the rounding of their summation order; three
+    consecutive solves -- the second and third start from the extrapolated guess, so A e is in the residual -- take the
+    same iterations to the same solutions (1e-12)."""
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    ctx = hip_ctx
+    h = tuple(l / c for l, c in zip(L, cells))
+    active, M = _shell_case(cells, L, 13)
+    nn = tuple(c + 1 for c in cells)
+    mf, kf = _stencil.stencil_fields(3, cells, h, M, active)
+    rng = np.random.default_rng(9)
+    n = int(np.prod(nn))
+    tissue = mf[0] != 0.0
+    v0 = np.where(tissue, -80.0 + 30.0 * rng.random(n), 0.0)
+    wst = np.where(tissue, rng.random(n) * 1e-3, 0.0)
+    out = {}
+    monkeypatch.setenv("BEAT_VRR", "0")
+    monkeypatch.setenv("BEAT_VTL", "1")
+    for key in ("0", "1"):
+        monkeypatch.setenv("BEAT_VTL_RHS", key)
+        ops = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
+        ops.set_guess_order(2)
+        ops.set_timestep(0.01, 0.5, 0.05)
+        fv, fx, fw = ops.new_field(), ops.new_field(), ops.new_field()
+        fv.set(v0)
+        fw.set(wst)
+        try:
+            ops.solve_single(fv, [fw], [0.7], fx, 1e-30, 1e-300, 0)  # the right-hand side alone
+        except Exception:  # noqa: BLE001 -- "did not converge in 0 iterations"
+            pass
+        ctx.synchronize()
+        st0 = ops.st.cpu().numpy().copy()
+        r0, p0 = ops.r.numpy().copy(), ops.ring[0].numpy().copy()
+        ops.guess_reset()
+        sols, its = [], []
+        for k in range(3):
+            fv.set(v0 * (1.0 + 0.01 * k))
+            res = ops.solve_single(fv, [fw], [0.7 + 0.1 * k], fx, 1e-11, 1e-50, 300)
+            sols.append(fx.numpy().copy())
+            its.append(res.iterations)
+        out[key] = (r0, p0, st0, sols, its)
+    a, b = out["0"], out["1"]
+    assert np.abs(a[0][tissue]).max() > 0.0
+    np.testing.assert_array_equal(b[0][tissue], a[0][tissue])
+    np.testing.assert_array_equal(b[1][tissue], a[1][tissue])
+    np.testing.assert_allclose(b[2][:3], a[2][:3], rtol=1e-12)  # BB, RZ, RR
+    assert a[4] == b[4] and a[4][1] < a[4][0]  # (the guess helps: fewer iterations in the second solve)
+    for xa, xb in zip(a[3], b[3]):
+        np.testing.assert_allclose(xb, xa, rtol=0, atol=1e-12 * np.abs(xa).max())
+
+
 def test_workgroup_tile_spmv_on_a_slab_with_live_ghost_planes(hip_ctx, monkeypatch):
     """The tile kernel on slab rows cut out of a larger masked grid, ghost planes holding the neighbouring slabs' p: plane 0
     takes its own stored backward coefficients (the plane below belongs to another rank), the last plane its forward ones;
