@@ -10,7 +10,9 @@ admit six GPU processes; the target shape is 8 ranks, the all-reduce is written 
         undivided solve (constant and per-node rows), iteration counts and values
 
 Run by tests/test_distributed_gpu.py with GPU_MAX_HW_QUEUES raised: spinning kernels of 2 x world streams must not be
-multiplexed onto four hardware queues.  Also the timing source of profiles/r04_dist_ranks.md (mode "time")."""
+multiplexed onto four hardware queues.  (Mode "time" reports the library's event timing per operation; with threads it measures
+the interpreter lock -- 117 us per all-reduce with 8 threads --, which is why profiles/r04_dist_ranks.md is made with processes,
+tools/dist_ranks.py.)"""
 import ctypes as C
 import json
 import sys
