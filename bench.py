@@ -232,8 +232,20 @@ _T0 = time.perf_counter()
 
 
 def _free_port() -> int:
+    """A port for a rendezvous on this host, from BELOW the kernel's ephemeral range (32768-60999): a port handed out by
+    bind(0) can be taken by any process's outgoing connection between this probe and the launcher's own bind -- seen once as
+    EADDRINUSE from torchrun's TCPStore in the GPU suite -- while nothing but another listener takes one of these."""
+    import random
     import socket
 
+    for _ in range(64):
+        port = random.randint(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
@@ -281,7 +293,11 @@ def launch_ranks(args, argv) -> int:
     if os.environ.get("BEAT_DIST_SERIAL", "0") != "1" and os.environ.get("BEAT_BENCH_NO_RETRY", "0") != "1":
         attempts.append({"BEAT_DIST_SERIAL": "1"})
     history = []
-    for k, extra in enumerate(attempts):
+    k = -1
+    port_retries = 0
+    while k + 1 < len(attempts):
+        k += 1
+        extra = attempts[k]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
                "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *argv]
         env = dict(os.environ, **extra)
@@ -297,6 +313,8 @@ def launch_ranks(args, argv) -> int:
                 state["last"] = time.monotonic()
                 state["seen"] = True
                 if relay:
+                    if "EADDRINUSE" in line or "address already in use" in line:
+                        state["port_taken"] = True
                     sys.stderr.write(line)
                     sys.stderr.flush()
                 else:
@@ -340,6 +358,12 @@ def launch_ranks(args, argv) -> int:
             return 0
         print(f"[bench launcher] attempt {k + 1} failed: rc {rc}" + (", watchdog" if timed_out else "")
               + (f", {len(lines)} stdout lines" if len(lines) != 1 else ""), file=sys.stderr, flush=True)
+        if state.get("port_taken") and not timed_out and port_retries < 3:
+            # the rendezvous port was taken between the probe and the launcher's bind: the same attempt again on another
+            # port (this is not what the serial fallback is for)
+            port_retries += 1
+            history[-1]["port_taken"] = True
+            k -= 1
     return history[-1]["rc"] or 1
 
 

@@ -17,6 +17,20 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _free_port():
+    """A port for a rendezvous on this host, from BELOW the kernel's ephemeral range (32768-60999): a port handed out by
+    bind(0) can be taken by any process's outgoing connection between this probe and the launcher's own bind -- seen once as
+    EADDRINUSE from torchrun's TCPStore in the GPU suite -- while nothing but another listener takes one of these."""
+    import random
+    import socket
+
+    for _ in range(64):
+        port = random.randint(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
