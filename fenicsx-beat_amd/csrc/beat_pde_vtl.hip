@@ -574,7 +574,7 @@ struct VtlData {
 
 template <int RY>
 unsigned vtl_resident_blocks() {
-  auto kernel = vtl_spmv_kernel<RY, false, RY >= 8 ? 1 : 0>;
+  auto kernel = vtl_spmv_kernel<RY, false, RY == 8 ? 1 : 0>;
   int dev = 0, cus = 256, per_cu = 1;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -609,7 +609,9 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
     // eight rows per tile halve the share of the halo rows; four keep thin slabs busy.  Measured on the 401^3 shell, one box,
     // alternating (tools/vtl_ab.sh, rocprofv3 kernel times): 8 rows, runs of 16 planes, dynamic: 403 us; 8 / 32: 414-428;
     // 4 / 32 dealt statically: 423-429, dynamic: 447; 4 / 16: 409-420; 4 / 64: 466 -- the segment-list kernel: 535
-    d->ry = e ? (std::atoi(e) == 16 ? 16 : std::atoi(e) == 8 ? 8 : 4) : (f.ny >= 16 ? 8 : 4);
+    // (16 rows per tile -- 1024-thread workgroups, half the halo share again -- were built and measured too: 11.65 against 11.30 ms
+    // per shell step, A B A B on one box: sixteen waves at one barrier per plane; not kept)
+    d->ry = e ? (std::atoi(e) == 8 ? 8 : 4) : (f.ny >= 16 ? 8 : 4);
     // tiles dealt round-robin to an XCD's workgroups (default) or taken from a counter per XCD (BEAT_VTL_DYNAMIC=1).  The
     // counter balances better on paper and measured the same on the SpMV alone (tools/bench_voxel.py: 403 against 409 us),
     // but inside the shell's split step (tools/bench_biv.py --n 400, same box, alternating) the round trip of the atomic, with
@@ -773,7 +775,7 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
     beat_set_error("beat_vtl_setup: %s", hipGetErrorString(e));
     return BEAT_EHIP;
   }
-  d->resident = RY == 16 ? vtl_resident_blocks<16>() : RY == 8 ? vtl_resident_blocks<8>() : vtl_resident_blocks<4>();
+  d->resident = RY == 8 ? vtl_resident_blocks<8>() : vtl_resident_blocks<4>();
   if (std::getenv("BEAT_VTL_VERBOSE")) {
     long planes = 0;
     for (int k = 0; k < d->nitems; ++k) planes += items[(size_t)k].ze - items[(size_t)k].zb;
@@ -815,7 +817,7 @@ int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const doub
 
 bool beat_vtl_pdot_available(const beat_pde* pde) {
   // (tiles of 8 rows only: with 4 rows a wave carries two halo entries and the fused pass does not fit 128 VGPRs)
-  return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && ((VtlData*)pde->vtl)->ry >= 8 && pde->g.z_lo_phys && pde->g.z_hi_phys;
+  return beat_vtl_available(pde) && ((VtlData*)pde->vtl)->pdot && ((VtlData*)pde->vtl)->ry == 8 && pde->g.z_lo_phys && pde->g.z_hi_phys;
 }
 
 static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
@@ -865,9 +867,7 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   if (rhs2) {
     launch(vtl_spmv_kernel<8, false, 2>, 8);
   } else if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
-    d->ry == 16 ? launch(vtl_spmv_kernel<16, false, 1>, 16) : launch(vtl_spmv_kernel<8, false, 1>, 8);
-  } else if (d->ry == 16) {  // (experiment: BEAT_VTL_RY=16)
-    launch(vtl_spmv_kernel<16, false, 0>, 16);
+    launch(vtl_spmv_kernel<8, false, 1>, 8);
   } else if (d->ry == 8) {
     d->dyn ? launch(vtl_spmv_kernel<8, true, 0>, 8) : launch(vtl_spmv_kernel<8, false, 0>, 8);
   } else {
