@@ -169,8 +169,8 @@ class HipOps:
         self.handle = handle
         self.mass_tab, self.stiff_tab = mt, kt
         nfields = max(4, int(self.lib.beat_pde_work_fields(handle)))  # see beat_pde_solve
-        self.work = ctx.zeros(nfields * (self.n + 2 * self.plane))
-        fld = self.n + 2 * self.plane
+        fld = int(self.lib.beat_pde_field_stride(handle))  # a field with its ghost planes (+ padding against channel aliasing)
+        self.work = ctx.zeros(nfields * fld)
         from ._device import Field
 
         # same layout as beat_pde_solve: r, q, z, ring[...]; p is ring[0] for the in-place recurrences

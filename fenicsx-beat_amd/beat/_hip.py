@@ -106,6 +106,7 @@ SIGNATURES = {
     "beat_pde_cg_first_z": (_int, [_vp, _vp, _vp, _vp]),
     "beat_pde_cg_next_z": (_int, [_vp, _vp, _vp, _vp]),
     "beat_pde_work_fields": (_int, [_vp]),
+    "beat_pde_field_stride": (_i64, [_vp]),
     "beat_pde_solve": (
         _int,
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],

@@ -816,7 +816,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   BEAT_REQUIRE(pde->pc_ncoef == 1, "the in-library decomposed solve is Jacobi-PCG (polynomial preconditioner: stage functions)");
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
   beat_ctx* ctx = pde->ctx;
-  const int64_t n = pde->n, plane = pde->g.plane, fld = n + 2 * plane;
+  const int64_t n = pde->n, plane = pde->g.plane, fld = beat_pde_field_stride(pde);
   double* r = dev_work + plane;
   double* q = r + fld;
   double* ring = q + 2 * fld;  // [r, q, z, ring...]: z is unused by the Jacobi path

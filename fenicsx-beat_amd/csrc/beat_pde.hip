@@ -935,6 +935,23 @@ extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev
   return BEAT_OK;
 }
 
+// Distance (doubles) between consecutive fields of the work area and of the guess's history: a field with its two ghost planes,
+// plus -- when that is a multiple of 4 KiB, as for 512^3 + 2 x 512^2 doubles -- 33 x 256 B of padding: otherwise node i of r, q,
+// every ring slot and every increment kept for the guess lies on the same memory channels, and the kernels that stream several
+// of them at once (PDOT: r, p_old, p_new; the ionic kernel's pending update: up to 6 ring slots + 4 guess fields next to
+// the 19 state rows) queue there.  The state rows have had their own padding since round 3 (StateArray, 17 x 256 B: a
+// different residue, so that a work field does not fall onto a state row either).  BEAT_FIELD_SKEW=<doubles> overrides.
+extern "C" int64_t beat_pde_field_stride(const beat_pde* pde) {
+  if (pde == nullptr) return 0;
+  const int64_t fld = pde->n + 2 * pde->g.plane;
+  static const int64_t forced = [] {
+    const char* e = std::getenv("BEAT_FIELD_SKEW");
+    return e ? (int64_t)std::max(0, std::atoi(e)) / 32 * 32 : (int64_t)-1;
+  }();
+  if (forced >= 0) return fld + forced;
+  return fld + (((fld * 8) % 4096 == 0 && pde->n >= 65536) ? 33 * 32 : 0);
+}
+
 extern "C" int beat_pde_work_fields(beat_pde* pde) {
   return pde ? 3 + PRING : BEAT_EINVAL;  // r, q, z + the ring of search directions
 }
@@ -1022,7 +1039,7 @@ extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   // fields: the max(order - 1, 1) increments kept + the guess (1024^3: 8.6 GB each -- only what the order needs)
   const int need = order > 0 ? std::max(1, order - 1) + 1 : 0;
   if (need > pde->hist_fields) {
-    const int64_t fld = pde->n + 2 * pde->g.plane;
+    const int64_t fld = beat_pde_field_stride(pde);
     BEAT_HIP_CHECK(hipStreamSynchronize(pde->ctx->stream));
     (void)hipFree(pde->d_hist_alloc);
     pde->d_hist_alloc = nullptr;
@@ -1214,7 +1231,7 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
     BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
     return beat_small_solve(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, rtol, atol, max_it, info);
   }
-  const int64_t fld = pde->n + 2 * pde->g.plane;
+  const int64_t fld = beat_pde_field_stride(pde);
   double* r = dev_work + pde->g.plane;
   double* q = r + fld;
   double* z = q + fld;     // only touched by the polynomial preconditioner

@@ -68,8 +68,12 @@ def main():
     check(lib.beat_malloc(ctx, 8 * (plane + S * ld + plane), C.byref(raw)))
     states = vp(raw.value + 8 * plane)
     nwork = lib.beat_pde_work_fields(pde)
+    lib.beat_pde_field_stride.restype = i64
+    lib.beat_pde_field_stride.argtypes = [vp]
+    fld = lib.beat_pde_field_stride(pde)  # a field with its ghost planes (+ padding on big grids)
+    assert fld >= n + 2 * plane
     work = vp()
-    check(lib.beat_malloc(ctx, 8 * nwork * (n + 2 * plane), C.byref(work)))
+    check(lib.beat_malloc(ctx, 8 * nwork * fld, C.byref(work)))
 
     vi = ionic.tp06_state_index("V")
     S0 = np.repeat(ionic.tp06_init_state_values()[:, None], n, axis=1)

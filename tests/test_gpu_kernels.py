@@ -318,7 +318,7 @@ def test_pde_solve_matches_direct_solve(hip_ctx, cells, L, Mk):
     fv, fx, fw = Field(ctx, n, plane), Field(ctx, n, plane), Field(ctx, n, plane)
     fv.set(v_prev)
     fw.set(w)
-    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * (n + 2 * plane))
+    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * ctx.lib.beat_pde_field_stride(handle))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([fw.ptr.value]), _dbl_array([amp]), 1, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-12, 1e-50, 500, C.byref(info)))
@@ -342,7 +342,7 @@ def test_pde_solve_zero_rhs_and_latch(hip_ctx):
     _hip.check(ctx.lib.beat_pde_set_timestep(handle, 1.0, 0.5, 0.4))
     n, plane = 11, 11
     fv, fx = Field(ctx, n, plane), Field(ctx, n, plane)
-    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * (n + 2 * plane))
+    work = ctx.zeros(ctx.lib.beat_pde_work_fields(handle) * ctx.lib.beat_pde_field_stride(handle))
     info = _hip.KspInfo()
     _hip.check(ctx.lib.beat_pde_solve(handle, fv.ptr, _ptr_array([]), _dbl_array([]), 0, fx.ptr,
                                       C.c_void_p(work.data_ptr()), 1e-10, 1e-50, 100, C.byref(info)))
