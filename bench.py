@@ -902,6 +902,33 @@ def main():
                 give_up(f"{label} raised on rank {rank}: {exc!r}")
             finally:
                 timer.cancel()
+        # The same steps on the headline's transport with ONE all-reduce per PCG iteration instead of two (PETSc's
+        # -ksp_cg_single_reduction; csrc/beat_pde_rr.hip, beat_rr_udot_part): reported beside the transports, never adopted --
+        # `value` stays the classic iteration's.  What it buys depends on what a reduction costs between real GPUs, which is
+        # what this line is for.
+        single = None
+        if os.environ.get("BEAT_BENCH_SINGLE", "1") == "1" and hasattr(ops, "set_single_reduction"):
+            timer = threading.Timer(deadline, give_up)
+            timer.daemon = True
+            timer.start()
+            try:
+                progress("single-reduction iteration")
+                before = int(ctx.lib.beat_comm_merged_solves(libcomm.handle))
+                ops.set_single_reduction(True)
+                sr = timed_run(t_alt, 2, args.steps)
+                t_alt = sr["t"]
+                single = {"ms_per_step": sr["wall"] / args.steps * 1e3, "pcg_iterations_per_step": float(np.mean(sr["iters"])),
+                          "ode_ms": sr["ode_ms"], "pde_ms": sr["pde_ms"], "transport": main_name,
+                          "solves_on_the_single_reduction_iteration": int(ctx.lib.beat_comm_merged_solves(libcomm.handle)) - before,
+                          "allreduces_per_solve": "k + 2 (classic: 2 k + 1)"}
+                ops.flush_pending()
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                ops.set_single_reduction(None)
+                give_up(f"the single-reduction iteration raised on rank {rank}: {exc!r}")
+            finally:
+                ops.set_single_reduction(None)
+                timer.cancel()
         # If an alternative beat the transport the headline was measured on by more than 3 % -- in the regime both were timed
         # in: the alternatives continue from the state of the last timed region -- the headline regime is measured again on
         # it (state re-initialised, same warm-up, same K steps, same barriers) and THAT becomes `value`: the line reports
@@ -967,6 +994,9 @@ def main():
         if rank == 0:
             out["transports"] = transports
             out["config"]["transport_choice"] = choice
+            if single is not None:
+                single["reference_ms_per_step"] = ref_ms
+                out["single_reduction"] = single
     if rank == 0:
         print(json.dumps(out), file=result_stream, flush=True)
     if world > 1 or force_dist:

@@ -393,6 +393,11 @@ class HipOps:
         _hip.check(self.lib.beat_pde_set_guess_order(self.handle, int(order)))
         self.guess_order = int(order)
 
+    def set_single_reduction(self, on) -> None:
+        """PETSc's ``-ksp_cg_single_reduction`` for the slab-decomposed solve: True one all-reduce per PCG iteration, False two,
+        None what BEAT_DIST_MERGED says (beat_pde_set_single_reduction)."""
+        _hip.check(self.lib.beat_pde_set_single_reduction(self.handle, -1 if on is None else int(bool(on))))
+
     def set_small(self, enable: bool) -> None:
         """Grids of a few thousand nodes are solved in one launch of one workgroup (beat_pde_small.hip); False keeps
         this operator on the multi-launch kernels (tests of those kernels on small grids, deferral semantics)."""

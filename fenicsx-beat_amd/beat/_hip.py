@@ -96,6 +96,7 @@ SIGNATURES = {
     "beat_split_steps": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl,
                                 _int, _vp, _vp, _int, _vp, _vp]),
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
+    "beat_pde_set_single_reduction": (_int, [_vp, _int]),
     "beat_pde_guess_reset": (_int, [_vp]),
     "beat_pde_guess_pending": (_int, [_vp]),
     "beat_pde_guess_history": (_int, [_vp, _vp, _vp, _vp]),
@@ -143,6 +144,7 @@ SIGNATURES.update({
     "beat_comm_ipc_connect_all": (_int, [_vp, _vp, _int]),
     "beat_comm_ipc_connect_local": (_int, [_vp, _vp, _int]),
     "beat_comm_info": (_int, [_vp, C.POINTER(_int)]),
+    "beat_comm_merged_solves": (_i64, [_vp]),
     "beat_comm_profile": (_int, [_vp, _int]),
     "beat_comm_profile_read": (_int, [_vp, C.POINTER(_dbl)]),
     "beat_comm_create_callbacks": (_int, [_vp, _int, _int, _int, _int, HALO_FN, ALLREDUCE_FN, _vp, C.POINTER(_vp)]),

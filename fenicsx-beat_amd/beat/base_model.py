@@ -156,6 +156,11 @@ class BaseModel:
             except BeatHipError as exc:  # e.g. no memory for the history fields on a grid that fills the GPU
                 logger.warning("initial guess from previous steps disabled (%s): solves start from x0 = v_", exc)
                 self._ops.set_guess_order(0)
+        # petsc_options["ksp_cg_single_reduction"] (PETSc's KSPCGUseSingleReduction): one all-reduce per PCG iteration on a
+        # decomposed grid instead of two; unset: what BEAT_DIST_MERGED says
+        single = (self.parameters.get("petsc_options") or {}).get("ksp_cg_single_reduction")
+        if single is not None and hasattr(self._ops, "set_single_reduction"):
+            self._ops.set_single_reduction(str(single).lower() not in ("0", "false", "no", ""))
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
         self.ksp = None  # KSP-like record of the last solve

@@ -289,6 +289,7 @@ struct beat_comm {
   uint64_t ipc_seq = 0;
   long long ipc_ticks = 30LL * 100000000LL;
   bool ipc_local = false;  // connected with beat_comm_ipc_connect_local: the other mailboxes are this process's own
+  long long merged_solves = 0;  // solves that ran the single-reduction iteration (BEAT_DIST_MERGED=1)
   // profiling (beat_comm_profile)
   bool profiling = false;
   std::vector<ProfSpan> spans;
@@ -601,6 +602,8 @@ extern "C" int beat_comm_info(beat_comm* c, int* host_out) {
   return BEAT_OK;
 }
 
+extern "C" int64_t beat_comm_merged_solves(const beat_comm* c) { return c ? (int64_t)c->merged_solves : 0; }
+
 extern "C" int beat_comm_profile(beat_comm* c, int enable) {
   BEAT_REQUIRE(c != nullptr, "null argument");
   if (enable) {
@@ -867,15 +870,41 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if ((rc = allreduce_sum(comm, st + BB, 3))) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
-  int chunk = beat_pde_first_chunk(pde);
+  // beat_pde_set_single_reduction / BEAT_DIST_MERGED=1 (constant coefficients): ONE all-reduce per iteration
+  // (beat_pde_rr.hip, beat_rr_udot_part); the environment is read per solve.  The pass that finds r_k converged is one more than the k updates: the first chunk and the limit count it.
+  const char* merged_env = std::getenv("BEAT_DIST_MERGED");
+  const bool merged = rr && (pde->single_reduction >= 0 ? pde->single_reduction == 1 : (merged_env != nullptr && merged_env[0] == '1'));
+  comm->merged_solves += merged ? 1 : 0;
+  const int limit = max_it + (merged ? 1 : 0);
+  int chunk = beat_pde_first_chunk(pde) + (merged ? 1 : 0);
   double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
   if (rr && (rc = halo_start(comm, rbuf[0], n, plane))) return rc;  // ghost planes of r_0
   while (true) {
-    chunk = std::min(chunk, max_it - launched);
+    chunk = std::min(chunk, limit - launched);
     for (int it = 0; it < chunk; ++it) {
       const int i = launched + it, slot = i % PRING;
       double* p_cur = ring + (int64_t)slot * fld;
       double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
+      if (merged) {
+        // u_i . A u_i, r_i . u_i, r_i . r_i in one pass over r_i (interior planes while its ghost planes travel, then the
+        // boundary planes), ONE all-reduce, the scalar step (stopping test, beta_i, alpha_i), then p_i = u_i + beta_i p_{i-1}
+        // and r_{i+1} = r_i - alpha_i A p_i in one pass without a dot product; the ghost planes of r_{i+1} travel behind it
+        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        double* r_cur = rbuf[i & 1];
+        double* r_new = rbuf[(i + 1) & 1];
+        if ((rc = beat_rr_udot_part(pde, st, r_cur, 0))) return rc;
+        if ((rc = halo_wait(comm))) return rc;
+        if ((rc = beat_rr_udot_part(pde, st, r_cur, 1))) return rc;
+        if ((rc = allreduce_sum(comm, st + PQ, 3))) return rc;
+        if ((rc = beat_rr_merged_next(pde, st, slot))) return rc;
+        if ((rc = beat_rr_prupd(pde, st, r_cur, p_old, p_cur, r_new))) return rc;
+        if ((rc = halo_start(comm, r_new, n, plane))) return rc;
+        if (slot == PRING - 1) {
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+            return rc;
+        }
+        continue;
+      }
       if (rr) {
         // p_i = D^-1 r_i + beta p_{i-1} and p_i . A p_i: the planes that need no ghost data while the ghost planes of
         // r_i travel, then the boundary planes, which also keep p_i on the ghost planes (no exchange of p)
@@ -913,7 +942,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
     BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if ((rc = ipc_check(comm))) return rc;
-    if (h[STOP] != 0.0 || launched >= max_it) break;
+    if (h[STOP] != 0.0 || launched >= limit) break;
     chunk = 2;
   }
   if (rr) {  // the exchange started after the last residual update has no consumer: drain it before anything else

@@ -621,9 +621,9 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   std::memcpy(p->h_stiff, host_stiff_tab, sizeof(p->h_stiff));
   BEAT_HIP_CHECK(hipSetDevice(ctx->device));
   BEAT_HIP_CHECK(hipMalloc(&p->d_tabs, sizeof(double) * (4 * 27 * TABW + 32)));
-  BEAT_HIP_CHECK(hipMalloc(&p->d_st, sizeof(double) * 16));
+  BEAT_HIP_CHECK(hipMalloc(&p->d_st, sizeof(double) * BEAT_ST_DOUBLES));
   BEAT_HIP_CHECK(hipMalloc(&p->d_alphas, sizeof(double) * PRING));
-  BEAT_HIP_CHECK(hipMemsetAsync(p->d_st, 0, sizeof(double) * 16, ctx->stream));
+  BEAT_HIP_CHECK(hipMemsetAsync(p->d_st, 0, sizeof(double) * BEAT_ST_DOUBLES, ctx->stream));
   const int rc = upload_tables(p);  // Mass / K usable before the first set_timestep
   if (rc) return rc;
   *out = p;
@@ -1023,6 +1023,12 @@ extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {
 }
 
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
+extern "C" int beat_pde_set_single_reduction(beat_pde* pde, int on) {
+  BEAT_REQUIRE(pde != nullptr && on >= -1 && on <= 1, "bad argument");
+  pde->single_reduction = on;
+  return BEAT_OK;
+}
+
 extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
   BEAT_REQUIRE(order >= -1 && order <= BEAT_GUESS_MAX_ORDER, "guess order must be -1 (adaptive) or 0..%d, got %d",

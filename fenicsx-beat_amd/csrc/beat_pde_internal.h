@@ -11,7 +11,10 @@
 namespace beat_pde_detail {
 
 // slots of the PCG scalar state `st` (device, caller-owned, >= 16 doubles)
-enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD, RR0 };  // RR0: r.r of the initial guess
+enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, ATOL, MAXIT, NUPD, RR0, ALPHA };  // RR0: r.r of the initial guess
+// ALPHA: the step length of the single-reduction iteration (beat_rr_merged_next), device side only: the host reads the first
+// 16 entries.  The operator's own scalar state (beat_pde::d_st) has BEAT_ST_DOUBLES entries.
+constexpr int BEAT_ST_DOUBLES = 32;
 constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
 constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
@@ -50,6 +53,7 @@ struct beat_pde {
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
   int ghost_lo_tz = 1, ghost_hi_tz = 1;
   // initial guess from the previous solves' increments (0: x0 = v_; m: + the degree-(m-1) extrapolation of the last m), see GuessTerms
+  int single_reduction = -1;               // decomposed solve: 1 one all-reduce per iteration, 0 two, -1 as BEAT_DIST_MERGED says
   int guess_order = 0;                     // as configured: 0..4, or -1 = choose between 3 and 4 per solve (below)
   // adaptive choice (guess_order = -1).  No order is right everywhere: each recorded increment carries an rtol-sized
   // error, which an extrapolation of order m amplifies by the sum of its |coefficients| (1, 3, 7, 15) -- where the
@@ -179,3 +183,8 @@ int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const 
 int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot,
                  bool roll = true);
 int beat_rr_next(beat_pde* pde, double* dev_st);
+// the single-reduction (Chronopoulos-Gear) iteration of a decomposed solve: see beat_pde_rr.hip
+int beat_rr_udot_part(beat_pde* pde, double* dev_st, const double* dev_r, int part);
+int beat_rr_merged_next(beat_pde* pde, double* dev_st, int slot);
+int beat_rr_prupd(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
+                  double* dev_r_new);

@@ -13,6 +13,7 @@
 // i.e. 24 + 24 B/node per iteration instead of 16 (SpMV) + 24 (r update) + 24 (p update) = 64, and the right-hand
 // side writes r only (16 B instead of 24; the first K_A forms p_0 = D^-1 r itself).  Values are those of the
 // classic three-kernel loop up to the order in which the block partial sums are added.
+// A decomposed solve may ask for the single-reduction form instead (K_U / K_P: beat_rr_udot_part below).
 //
 // Replaces, like beat_pde.hip, dolfinx assemble_vector + PETSc KSP.solve of src/beat/base_model.py:196-236.
 #include "beat_pde_internal.h"
@@ -44,13 +45,14 @@ struct RGeom {
   int ghost_lo_tz, ghost_hi_tz;    // z node type (0 low face, 1 interior, 2 high face) of the ghost planes -1 / nz
 };
 
-enum { RR_PDOT = 0, RR_RUPD = 1, RR_RHS = 2 };
+// RR_UDOT / RR_PRUPD: the single-reduction iteration of a decomposed solve (BEAT_DIST_MERGED, see beat_rr_udot_part)
+enum { RR_PDOT = 0, RR_RUPD = 1, RR_RHS = 2, RR_UDOT = 3, RR_PRUPD = 4 };
 
 struct RArgs {
-  const double* x;      // PDOT: r | RUPD: p | RHS: v_
-  const double* x2;     // PDOT: p_old | RUPD: r
-  double* y;            // PDOT: p_new | RUPD: r_new (another buffer than r) | RHS: r
-  double* y2;           // RHS: x (copy of v_) or nullptr
+  const double* x;      // PDOT, UDOT, PRUPD: r | RUPD: p | RHS: v_
+  const double* x2;     // PDOT, PRUPD: p_old | RUPD: r
+  double* y;            // PDOT, PRUPD: p_new | RUPD: r_new (another buffer than r) | RHS: r
+  double* y2;           // RHS: x (copy of v_) or nullptr | PRUPD: r_new (another buffer than r)
   const double* tab;    // A table (PDOT, RUPD) | Mass table (RHS)
   const double* tab2;   // RHS: K table
   const double* dinv;   // 1/diag(A) per node type
@@ -103,6 +105,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
                                                         double* __restrict__ Y2) {
   constexpr int NR = RY + 2;
   constexpr int NE = GUESS ? NR : 1;  // rows of the second register window (the guess increment e)
+  constexpr bool FORM = MODE == RR_PDOT || MODE == RR_UDOT || MODE == RR_PRUPD;  // the staged value is formed from r
+  constexpr bool OLD = MODE == RR_PDOT || MODE == RR_PRUPD;                      // ... with beta p_old, and stored
+  constexpr bool RAW = MODE == RR_UDOT || MODE == RR_PRUPD;                      // r itself of the owned rows is kept too
+  constexpr int NW = RAW ? RY : 1;
   static_assert(!GUESS || MODE == RR_RHS, "the initial guess enters the right-hand side only");
   __shared__ double red[4];
   // boundary rows of the coefficient tables and 1/diag per node type, staged in LDS: the lanes on a face of the box
@@ -148,7 +154,8 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     off[r] = min(max(gy, 0), g.ny - 1) * g.nx + cx;
   }
   double beta = 0.0, alpha = 0.0;
-  if (MODE == RR_PDOT) beta = a.st[BETA];
+  if (OLD) beta = a.st[BETA];
+  if (MODE == RR_PRUPD) alpha = a.st[ALPHA];
   if (MODE == RR_RUPD) {
     alpha = a.st[RZ] / a.st[PQ];
     if (blockIdx.x == 0 && threadIdx.x == 0) a.alphas[a.slot] = alpha;
@@ -162,6 +169,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
   double rvn[PD][RY];
+  double Rw0[NW], Rwp[NW];  // RAW: r of the owned rows on the planes z and z+1
+#pragma unroll
+  for (int j = 0; j < NW; ++j) Rw0[j] = Rwp[j] = 0.0;
   // GUESS: the same window of e (fetched with the plane of v_, staged with it)
   double Em[NE], E0[NE], Ep[NE], re1[PD][NE];
 #pragma unroll
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         double c = ra[u][r];
-        if (MODE == RR_PDOT) {
+        if (RAW && r >= 1 && r <= RY) Rwp[RAW ? r - 1 : 0] = c;
+        if (FORM) {
           const int type = txy[r] + tz9;
           const double di = s_dinv[type];  // (a select against the kernel argument a.dinv_i trips an LDS-pointer cast bug in hipcc 7.2)
           // p_new = D^-1 r + beta p_old (same expression as cg_pupdate_oop_kernel; p_old unread while beta = 0)
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           constexpr int q = GUESS ? 1 : 0;
           Ep[r * q] = (zok && row_in[r]) ? c + re1[u][r * q] : 0.0;  // x0 = v_ + e
         }
-        if (MODE == RR_PDOT) {
+        if (OLD) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
             Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx] = c;
         }
@@ -230,11 +241,11 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
       if (kf >= zb - 1 && kf <= ze) {
         const int cz = min(max(kf, -1), g.nz);
         const double* __restrict__ bx = X + (int64_t)cz * g.plane;
-        const double* __restrict__ bx2 = (MODE == RR_PDOT && have_old) ? X2 + (int64_t)cz * g.plane : bx;
+        const double* __restrict__ bx2 = (OLD && have_old) ? X2 + (int64_t)cz * g.plane : bx;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           ra[u][r] = bx[off[r]];
-          if (MODE == RR_PDOT) rb2[u][r] = bx2[off[r]];
+          if (OLD) rb2[u][r] = bx2[off[r]];
         }
         if (GUESS) {
           const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
@@ -364,6 +375,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           }
           if (MODE == RR_PDOT) {
             acc0 = fma(v[0], s, acc0);  // p . (A p)
+          } else if (MODE == RR_UDOT) {  // u = D^-1 r:  u . (A u),  r . u,  r . r
+            const double ri = Rw0[RAW ? j : 0];
+            acc0 = fma(v[0], s, acc0);
+            acc1 = fma(ri, v[0], acc1);
+            acc2 = fma(ri, ri, acc2);
+          } else if (MODE == RR_PRUPD) {  // r_new = r - alpha (A p_new)
+            Y2[gi] = fma(-alpha, s, Rw0[RAW ? j : 0]);
           } else {                      // r -= alpha (A p)
             const double ri = fma(-alpha, s, rv[j]);
             Y[gi] = ri;
@@ -386,6 +404,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
         E0[r] = Ep[r];
       }
     }
+    if (RAW) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) Rw0[j] = Rwp[j];
+    }
     }  // z < ze
   }
   }
@@ -400,6 +422,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
       a.partials[g.part_off + blockIdx.x] = s0;
       a.partials[BEAT_MAX_PARTIALS + g.part_off + blockIdx.x] = s1;
     }
+  } else if (MODE == RR_PRUPD) {
   } else {
     const double s0 = beat_block_sum(acc0, red);
     const double s1 = beat_block_sum(acc1, red);
@@ -427,6 +450,36 @@ __global__ void rr_next_kernel(double* st) {
     st[STOP] = 1.0;
     st[REASON] = -3.0;
   }
+}
+
+// The scalar step of the single-reduction iteration (Chronopoulos & Gear 1989), after the ONE all-reduce of
+//   st[PQ] = u . A u,  st[RZN] = r . u,  st[RRN] = r . r      (u = D^-1 r, r = r_i):
+// the stopping test on r_i, then  beta_i = (r_i.u_i) / (r_{i-1}.u_{i-1}),  alpha_i = (r.u) / (u.Au - beta_i (r.u) / alpha_{i-1})
+// -- the value p_i . A p_i has in exact arithmetic, without forming p_i first.  Counts the update that follows.
+__global__ void rr_merged_next_kernel(double* st, double* alphas, int slot) {
+  if (st[STOP] != 0.0) return;
+  const double g = st[RZN], d = st[PQ], rr = st[RRN];
+  st[RR] = rr;
+  const double tr = st[RTOL] * st[RTOL] * st[BB];
+  if (rr <= st[TOL2]) {
+    st[STOP] = 1.0;
+    st[REASON] = rr <= tr ? 2.0 : 3.0;
+    return;
+  }
+  if (st[ITERS] >= st[MAXIT]) {
+    st[STOP] = 1.0;
+    st[REASON] = -3.0;
+    return;
+  }
+  const bool first = st[ITERS] == 0.0;
+  const double beta = first ? 0.0 : g / st[RZ];
+  const double alpha = first ? g / d : g / (d - beta * g / st[ALPHA]);
+  st[BETA] = beta;
+  st[ALPHA] = alpha;
+  st[RZ] = g;
+  alphas[slot] = alpha;
+  st[NUPD] += 1.0;
+  st[ITERS] += 1.0;
 }
 
 // Rows per wave and blocks per launch: on big slabs (>= 64 M nodes) 4 rows and ~4096 blocks are best (the 6-of-4 row
@@ -669,6 +722,78 @@ int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev
   const int rc = beat_pde_launch_reduce(pde, grid_blocks(g), 2, dev_st + RZN, dev_st, dev_st + NUPD);
   if (rc || !roll) return rc;
   return beat_rr_next(pde, dev_st);
+}
+
+// ---- single-reduction iteration (decomposed solve, BEAT_DIST_MERGED=1) --------------------------------------------
+// Iteration i of the classic loop needs two all-reduces that depend on each other (p.Ap, then r.z / r.r of the updated
+// residual).  In Chronopoulos & Gear's form both come from ONE pass over r_i:
+//   K_U (udot):   u = D^-1 r_i formed while loading;  partials  u . A u,  r . u,  r . r     -- reads r, writes nothing
+//   [one all-reduce of three values; scalar step: stopping test, beta_i, alpha_i]
+//   K_P (prupd):  p_i = u + beta_i p_{i-1} formed while loading, stored;  r_{i+1} = r_i - alpha_i A p_i   -- no dot product
+// With the operator re-applied from registers neither w = A u nor s = A p is ever stored (the textbook form keeps both and
+// updates s by recurrence): 8 + 32 B/node per iteration against 24 + 24, two stencil passes as before, and k + 1 reductions
+// per solve of k iterations (the pass that finds r_k converged) against 2 k.
+// Part 0 / 1 as beat_rr_pdot_part; part 1 reduces the block partials into dev_st[PQ..RRN] (local sums).
+int beat_rr_udot_part(beat_pde* pde, double* dev_st, const double* dev_r, int part) {
+  static_assert(RZN == PQ + 1 && RRN == PQ + 2, "the three sums travel as one all-reduce of dev_st[PQ..RRN]");
+  const Geom& f = pde->g;
+  RArgs a{};
+  a.x = dev_r;
+  a.x2 = dev_r;
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.ci = interior_row(pde->h_A);
+  a.dinv_i = pde->h_dinv[13];
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0);
+  if (part == 0) {
+    launch_rr<RR_UDOT>(pde, gi, a);
+    BEAT_LAUNCH_CHECK();
+    return BEAT_OK;
+  }
+  int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
+  if (!f.z_lo_phys) {
+    const RGeom gb = make_geom(pde, 0, 1, off);
+    launch_rr<RR_UDOT>(pde, gb, a);
+    off += grid_blocks(gb);
+  }
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) {
+    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off);
+    launch_rr<RR_UDOT>(pde, gb, a);
+    off += grid_blocks(gb);
+  }
+  BEAT_LAUNCH_CHECK();
+  BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
+  return beat_pde_launch_reduce(pde, off, 3, dev_st + PQ, dev_st);
+}
+
+int beat_rr_merged_next(beat_pde* pde, double* dev_st, int slot) {
+  BEAT_KERNEL(rr_merged_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, dev_st, pde->d_alphas, slot);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
+// p_new = D^-1 r + st[BETA] p_old on the slab and on the ghost planes next to it (as beat_rr_pdot_part: no exchange of p),
+// r_new = r - st[ALPHA] A p_new (out of place).  The ghost planes of r (and of p_old) must be current.
+int beat_rr_prupd(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
+                  double* dev_r_new) {
+  const RGeom g = make_geom(pde);
+  RArgs a{};
+  a.x = dev_r;
+  a.x2 = dev_p_old;
+  a.y = dev_p_new;
+  a.y2 = dev_r_new;
+  a.tab = pde->d_tab(0);
+  a.dinv = pde->d_dinv();
+  a.ci = interior_row(pde->h_A);
+  a.dinv_i = pde->h_dinv[13];
+  a.partials = pde->ctx->d_partials;
+  a.st = dev_st;
+  launch_rr<RR_PRUPD>(pde, g, a);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
 }
 
 int beat_rr_next(beat_pde* pde, double* dev_st) {

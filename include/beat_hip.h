@@ -339,6 +339,12 @@ int64_t beat_pde_field_stride(const beat_pde* pde);
  * overwritten between steps; a stale history costs iterations, not accuracy).  Memory: max(m - 1, 1) + 1 more fields,
  * allocated when the order is set.  Default order: 0 (the Python layer's BaseModel asks for -1). */
 int beat_pde_set_guess_order(beat_pde* pde, int order);
+/* PETSc's -ksp_cg_single_reduction (KSPCGUseSingleReduction) for beat_pde_solve_dist: on = 1 runs the PCG iteration with
+ * ONE all-reduce of three values (u.Au, r.u, r.r with u = D^-1 r; step lengths by Chronopoulos & Gear's recurrence)
+ * instead of two dependent ones; 0 the classic iteration; -1 (default) as the environment says (BEAT_DIST_MERGED=1).
+ * Constant-coefficient operators only (per-node rows keep the classic iteration); beat_pde_solve on one rank is not
+ * affected.  Same stopping test, iteration counts within one, k + 2 instead of 2 k + 1 all-reduces per solve of k iterations. */
+int beat_pde_set_single_reduction(beat_pde* pde, int on);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);
 /* the last recorded increment, the guess increment prepared for the next solve, and the number of solves on record
@@ -461,6 +467,10 @@ int beat_comm_destroy(beat_comm* comm);
 #define BEAT_TRANSPORT_RCCL_SERIAL 2
 #define BEAT_TRANSPORT_IPC 3
 int beat_comm_info(beat_comm* comm, int* host_out);
+/* Number of beat_pde_solve_dist calls on this communicator that ran the single-reduction iteration (environment
+ * BEAT_DIST_MERGED=1, constant-coefficient operators: one all-reduce of three values per PCG iteration instead of two
+ * dependent ones -- what PETSc offers as -ksp_type pipecg / groppcg next to the cg of src/beat/base_model.py:199-206). */
+int64_t beat_comm_merged_solves(const beat_comm* comm);
 /* Event timing of the communication inside the decomposed solve (RCCL and ipc transports): enable = 1 drops what
  * was collected and starts, 0 stops.  beat_comm_profile_read synchronises and fills host_out[6] = {ms the ghost-plane
  * transfers took on their stream, their number, ms the all-reduces took on the compute stream (waiting for the

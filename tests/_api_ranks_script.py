@@ -32,7 +32,10 @@ tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
 I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1, mesh_unit="mm",
                                        amplitude=50_000.0)
 M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
-pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01, dx=I_s.dZ, params={"petsc_options": {"ksp_rtol": 1e-10}})
+petsc_options = {"ksp_rtol": 1e-10}
+if os.environ.get("BEAT_TEST_SINGLE_REDUCTION") == "1":  # PETSc's -ksp_cg_single_reduction, honoured on decomposed grids
+    petsc_options["ksp_cg_single_reduction"] = True
+pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01, dx=I_s.dZ, params={"petsc_options": petsc_options})
 ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(g.functionspace(mesh, ("P", 1))), v_pde=pde.state,
                                      fun=tp06.generalized_rush_larsen, init_states=tp06.init_state_values(),
                                      parameters=tp06.init_parameter_values(stim_amplitude=0.0), num_states=19,
@@ -61,7 +64,9 @@ roundtrip_ok = bool(np.array_equal(np.asarray(back.x.array), v))
 full = ode.full_values if hasattr(ode, "full_values") else None
 np.savez(out_dir / f"rank{comm.rank}.npz", v=v, probes=np.array(probes), z0=mesh.slab.z0, z1=mesh.slab.z1,
          states=np.asarray(ode.values), its=pde.ksp.getIterationNumber(), nodes=mesh.num_nodes, leads=leads,
-         roundtrip_ok=roundtrip_ok)
+         roundtrip_ok=roundtrip_ok,
+         merged_solves=(int(pde._ops.lib.beat_comm_merged_solves(pde._diffusion.libcomm.handle))
+                        if getattr(pde._diffusion, "libcomm", None) is not None else 0))
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
