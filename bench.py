@@ -251,6 +251,72 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+class ClockSampler:
+    """Shader clock, package power and temperatures of this rank's GPU while a timed region runs, read from the amdgpu hwmon
+    files in sysfs (no tool is started, nothing touches the GPU): the ionic kernel runs at the package power limit, so the
+    clock it is given decides the headline to a few percent -- the line says what it was.  Best effort: `summary()` is None
+    when the files cannot be found or read."""
+
+    def __init__(self, device_index: int):
+        import glob
+
+        self.dir = None
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}."
+            for card in glob.glob("/sys/class/drm/card[0-9]*"):
+                if "-" in os.path.basename(card):
+                    continue
+                if os.path.basename(os.path.realpath(card + "/device")).startswith(want):
+                    hw = glob.glob(card + "/device/hwmon/hwmon*")
+                    if hw:
+                        self.dir = hw[0]
+                    break
+        except Exception:  # noqa: BLE001
+            self.dir = None
+        self.samples, self._stop, self._thread = [], None, None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self._read("freq1_input") / 1e6, self._read("power1_input") / 1e6,
+                                     self._read("temp2_input") / 1e3, self._read("temp3_input") / 1e3))
+            except Exception:  # noqa: BLE001
+                return
+            self._stop.wait(0.02)
+
+    def start(self):
+        import threading
+
+        if self.dir is None:
+            return
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2.0)
+            self._thread = None
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.array(self.samples)
+        return {"sclk_mhz": {"mean": float(a[:, 0].mean()), "min": float(a[:, 0].min()), "max": float(a[:, 0].max())},
+                "power_w": {"mean": float(a[:, 1].mean()), "max": float(a[:, 1].max())},
+                "junction_c": float(a[:, 2].max()), "hbm_c": float(a[:, 3].max()), "samples": int(len(a)),
+                "source": "amdgpu hwmon (freq1_input, power1_input, temp2_input, temp3_input), polled every 20 ms over the timed steps"}
+
+
 def ordering_of(comm_info) -> str:
     """``config.ordering`` of an N > 1 line: "overlapped" = ghost planes on a side stream behind the interior stencil (the
     design of DESIGN section 5: transports rccl and ipc), "serial" = every communication operation on the compute stream
@@ -547,6 +613,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    clocks = ClockSampler(ctx.device.index if ctx.device.index is not None else 0)
+
     def timed_run(t, warmup, steps):
         """`warmup` untimed steps, then exactly `steps` timed ones bracketed by barriers; returns the statistics."""
         ev_ode = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -592,6 +660,7 @@ def main():
             step(t)
             t += DT
         barrier()
+        clocks.start()
         tic = time.perf_counter()
         for i in range(steps):
             step(t, i)
@@ -599,11 +668,13 @@ def main():
         ops.flush_pending()  # the potential is complete when the timed region ends
         barrier()
         wall = time.perf_counter() - tic
+        clocks.stop()
         if world > 1:
             w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w.item())
         return dict(t=t, wall=wall, iters=iters, pend_counts=pend_counts, guess_fields=guess_fields, guess_orders=guess_orders,
+                    clocks=clocks.summary(),
                     ode_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_ode])),
                     pde_ms=float(np.mean([ev_ode[i][1].elapsed_time(ev_pde_end[i]) for i in range(steps)])))
 
@@ -658,6 +729,7 @@ def main():
             "frac_of_8TBs_per_gpu": (16.0 * len(ic) + 16.0 + 88.0 * kf) * n * n * nz_glob * args.steps / fr["wall"] / 1e9 / world / HBM_PEAK_GBS,
             "v_min": fmin,
             "v_max": fmax,
+            "clocks": fr["clocks"],
         }
 
     # N > 1: what each rank did, and what the communication inside the solve costs.  Profiled on a few EXTRA steps after
@@ -781,6 +853,7 @@ def main():
                 "v_min": vmin,
                 "v_max": vmax,
                 "finite": finite,
+                "clocks": run["clocks"],  # rank 0's GPU over the timed steps (ClockSampler)
             },
             "roofline": {
                 "bound": "hbm",

@@ -935,21 +935,20 @@ extern "C" int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev
   return BEAT_OK;
 }
 
-// Distance (doubles) between consecutive fields of the work area and of the guess's history: a field with its two ghost planes,
-// plus -- when that is a multiple of 4 KiB, as for 512^3 + 2 x 512^2 doubles -- 33 x 256 B of padding: otherwise node i of r, q,
-// every ring slot and every increment kept for the guess lies on the same memory channels, and the kernels that stream several
-// of them at once (PDOT: r, p_old, p_new; the ionic kernel's pending update: up to 6 ring slots + 4 guess fields next to
-// the 19 state rows) queue there.  The state rows have had their own padding since round 3 (StateArray, 17 x 256 B: a
-// different residue, so that a work field does not fall onto a state row either).  BEAT_FIELD_SKEW=<doubles> overrides.
+// Distance (doubles) between consecutive fields of the work area and of the guess's history: a field with its two ghost planes.
+// BEAT_FIELD_SKEW=<doubles> adds a padding (rounded down to 256 B) -- an experiment of round 4: at 512^3 the fields lie a
+// multiple of 4 KiB apart like the state rows did before round 3's StateArray padding, and the kernels that stream several of
+// them at once might queue on the same memory channels.  Two A/B runs looked like 1 % for 33 x 256 B; a third with eight
+// alternating runs on one box showed none (13.67-13.89 ms/step with, 13.60-13.79 without), so the default is no padding.
+// Callers size and address the work area through this function either way.
 extern "C" int64_t beat_pde_field_stride(const beat_pde* pde) {
   if (pde == nullptr) return 0;
   const int64_t fld = pde->n + 2 * pde->g.plane;
   static const int64_t forced = [] {
     const char* e = std::getenv("BEAT_FIELD_SKEW");
-    return e ? (int64_t)std::max(0, std::atoi(e)) / 32 * 32 : (int64_t)-1;
+    return e ? (int64_t)std::max(0, std::atoi(e)) / 32 * 32 : (int64_t)0;
   }();
-  if (forced >= 0) return fld + forced;
-  return fld + (((fld * 8) % 4096 == 0 && pde->n >= 65536) ? 33 * 32 : 0);
+  return fld + forced;
 }
 
 extern "C" int beat_pde_work_fields(beat_pde* pde) {

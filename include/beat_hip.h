@@ -308,9 +308,9 @@ int beat_pde_cg_next_z(beat_pde* pde, double* dev_st, const double* dev_z, doubl
  * its own ghost planes: size fields * beat_pde_field_stride(pde) doubles. Synchronises. */
 int beat_pde_work_fields(beat_pde* pde);
 /* Distance in doubles between consecutive fields of dev_work (and the `field_stride` of the deferred-update calls when the
- * ring lives there): n_local + 2*nx*ny, plus padding when that is a multiple of 4 KiB (fields that far apart put node i of
- * all of them on the same memory channels).  The PETSc Vecs of the reference (src/beat/base_model.py:107-124) carry no such
- * layout; it is this library's. */
+ * ring lives there): n_local + 2*nx*ny, plus BEAT_FIELD_SKEW doubles of padding if that environment variable is set
+ * (an experiment against memory-channel aliasing of fields a multiple of 4 KiB apart; measured: no effect, default none).
+ * The PETSc Vecs of the reference (src/beat/base_model.py:107-124) carry no such layout; it is this library's. */
 int64_t beat_pde_field_stride(const beat_pde* pde);
 /* beat_pde_solve with the option to leave the last, partially filled ring cycle of search directions unapplied:
  * with defer_flush != 0, host_pending[0] = first iteration of that cycle (ring_base for beat_pde_x_flush) and

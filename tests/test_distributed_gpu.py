@@ -560,6 +560,8 @@ def test_bench_with_four_ranks_sharing_one_gpu(tmp_path):
     assert r["config"]["ordering"] in ("serial", "overlapped") and r["config"]["comm"]["world"] == 4
     ipc = r["transports"]["ipc"]
     assert "error" not in ipc and ipc["comm"]["transport"] == "ipc" and ipc["comm"]["allreduce"] == "ipc" and ipc["ms_per_step"] > 0
+    clocks = r["config"]["clocks"]  # hwmon samples over the timed steps (None where sysfs is not readable)
+    assert clocks is None or (clocks["samples"] >= 1 and clocks["sclk_mhz"]["mean"] > 100 and clocks["power_w"]["mean"] > 10)
     # the same steps with one all-reduce per PCG iteration (never adopted: reported beside the transports)
     one = r["single_reduction"]
     assert one["solves_on_the_single_reduction_iteration"] >= 4 and one["ms_per_step"] > 0
