@@ -456,3 +456,73 @@ def test_voxel_shell_torord_pipeline_at_full_size(hip_ctx):
         assert np.isfinite(lo) and np.isfinite(hi)
     print(f"configs[4] full size: {nt / 1e6:.1f} M tissue nodes, peak {peaks[19]:.1f} mV at stimulus end, {peaks[-1]:.1f} mV "
           f"2.2 ms later, min {min(lows):.1f} mV, PCG {np.mean(its):.1f} its/step")
+
+
+def test_decomposed_solves_on_the_slab_of_eight_ranks_meet_the_stopping_test(hip_ctx):
+    """The slab ONE of 8 ranks owns at 512^3 (512 x 512 x 64 planes, live neighbours on both faces: a communicator whose
+    peers are the rank itself over the mailbox transport makes it periodic in z) through beat_pde_solve_dist, with the classic
+    two-reduction iteration and with the single-reduction one (beat_pde_set_single_reduction): both solutions satisfy the
+    periodic system -- b - A x recomputed with beat_pde_apply after an exchange of the ghost planes -- to the stopping
+    tolerance, agree with each other, take the same number of iterations (within one), and the single-reduction solve called
+    the all-reduce about half as often."""
+    import torch
+
+    from beat import _stencil
+    from beat._engine import DiffusionSolver, HipOps, LibComm
+
+    ctx = hip_ctx
+    nz = 64
+    plane = N * N
+    f0 = np.array([np.cos(np.pi / 6), np.sin(np.pi / 6), 0.0])
+    M = 9.5301e-4 * np.outer(f0, f0) + 1.2576e-4 * (np.eye(3) - np.outer(f0, f0))
+    ops = HipOps(ctx, (N, N, nz), False, False, *_stencil.stencil_tables(3, (H, H, H), M))
+    ops.set_timestep(0.01, 0.5, 0.01)
+
+    class Interior:
+        rank, world, lo_phys, hi_phys, z0, z1 = 0, 1, False, False, 0, nz
+
+    Interior.nz = nz
+    comm = LibComm(ctx, Interior(), transport="ipc", peers=(0, 0), plane_doubles=plane)
+    try:
+        solver = DiffusionSolver(ops, Interior(), force_distributed=True, libcomm=comm)
+        n = plane * nz
+        idx = torch.arange(n, device=ctx.device, dtype=torch.float64)
+        xs, ys, zs = idx % N, torch.div(idx, N, rounding_mode="floor") % N, torch.div(idx, plane, rounding_mode="floor")
+        gen = torch.Generator(device=ctx.device)
+        gen.manual_seed(23)
+        v0 = -85.0 + 100.0 * torch.exp(-(((xs - 200.0) ** 2 + (ys - 256.0) ** 2 + (zs - 20.0) ** 2) * H * H) / 0.18)
+        v0 += torch.rand(n, generator=gen, device=ctx.device, dtype=torch.float64) - 0.5
+        del idx, xs, ys, zs
+        v, b, ax = (ops.new_field() for _ in range(3))
+        v.data.copy_(v0)
+        del v0
+        comm.exchange_halo(v)
+        ops.apply(1, v, b)
+        bnorm = float(torch.linalg.vector_norm(b.data))
+        rtol = 1e-8
+        sols, its, calls = [], [], []
+        for single in (False, True):
+            ops.set_single_reduction(single)
+            x = ops.new_field()
+            res = solver.solve(v, [], [], x, rtol, 1e-50, 200)  # sizes the next solve's first batch
+            comm.profile(True)
+            res = solver.solve(v, [], [], x, rtol, 1e-50, 200)
+            prof = comm.profile_read()
+            comm.profile(False)
+            assert res.converged_reason > 0 and 3 <= res.iterations <= 30
+            assert np.isclose(res.rhs_norm, bnorm, rtol=1e-12)
+            comm.exchange_halo(x)
+            ops.apply(0, x, ax)
+            ctx.synchronize()
+            assert float(torch.linalg.vector_norm(b.data - ax.data)) <= 1.05 * rtol * bnorm
+            sols.append(x)
+            its.append(res.iterations)
+            calls.append(prof["allreduce_count"])
+        ops.set_single_reduction(None)
+        assert abs(its[0] - its[1]) <= 1
+        assert calls[0] == 1 + 2 * (its[0] + 1) and calls[1] == 1 + (its[1] + 2)
+        scale = float(torch.linalg.vector_norm(sols[0].data, ord=float("inf")))
+        assert float(torch.linalg.vector_norm(sols[0].data - sols[1].data, ord=float("inf"))) <= 1e-7 * scale
+        assert int(ctx.lib.beat_comm_merged_solves(comm.handle)) == 2
+    finally:
+        comm.close()
