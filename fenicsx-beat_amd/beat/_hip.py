@@ -64,6 +64,7 @@ SIGNATURES = {
     "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
     "beat_ode_step_pending": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
     "beat_ode_step_rows": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
+    "beat_ode_jit_stats": (_int, [C.POINTER(C.c_longlong)]),
     "beat_ode_class_table_doubles": (_int, [_int, C.POINTER(_int)]),
     "beat_ode_class_table_fill": (_int, [_vp, _int, _vp, _int, _int, _vp]),
     "beat_ode_step_classes": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int]),

@@ -1,0 +1,111 @@
+// Sparse per-node parameter rows with the varying indices as COMPILE-TIME constants: the instance of ode_step_kernel for one
+// (model, index set) is written as a three-line translation unit, compiled by hipcc for gfx950 at first use (~1.5 s for TP06),
+// kept as a code object in a cache directory and loaded with hipModuleLoadData.  Why: with a run-time index every parameter of a
+// node has to live in a VGPR (the step's p[k] cannot tell at compile time which k varies): 238 VGPRs, 2 waves, 1.20 x the
+// uniform kernel for ONE varying conductance.  With the index known, p[k] folds to "the row's value" for that k and to a scalar
+// load for every other k, and the derived constants the parameter does not enter stay the host's: 135 VGPRs, 3 waves, the
+// uniform kernel's speed.  Reference: (P, N) parameter arrays handed to ``fun``, src/beat/odesolver.py:67-79,
+// demos/pace_train.py:133-167.
+//
+// Where no instance can be had -- no hipcc on the machine, no kernel sources beside the library, BEAT_JIT=0, a compile that
+// fails -- beat_ode_jit_launch returns BEAT_JIT_UNAVAILABLE and the caller launches the run-time-index kernel: a HIP kernel
+// either way, never a host path.
+#pragma once
+#include "beat_ode_kernel.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+constexpr int BEAT_JIT_UNAVAILABLE = 1000;
+
+// beat_ode_jit.hip
+bool beat_jit_enabled();
+// the kernel of `key` on ctx's device: from memory, from the cache directory, or compiled from `source` now; nullptr: unavailable
+hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source);
+
+template <class Model, class = void>
+struct BeatJitAccessor : std::false_type {};
+template <class Model>
+struct BeatJitAccessor<Model, std::void_t<decltype(Model::ACCESSOR_PARAMS)>> : std::true_type {};
+
+// the model's type as the generated source spells it
+template <class Model>
+struct BeatJitName {
+  static const char* get() { return nullptr; }
+};
+template <>
+struct BeatJitName<Tp06Grl1> {
+  static const char* get() { return "Tp06Grl1"; }
+};
+template <>
+struct BeatJitName<TorordDynClGrl1> {
+  static const char* get() { return "TorordDynClGrl1"; }
+};
+template <>
+struct BeatJitName<TorordLandGrl1> {
+  static const char* get() { return "TorordLandGrl1"; }
+};
+
+// Which derived constants does parameter `idx` enter?  Found numerically: the host evaluates Model::derive with the parameter
+// replaced by a spread of other values -- scaled, shifted, negated, and the small integers a cell-type or switch parameter takes
+// -- and every entry whose bits change is taken per lane.  (An entry that depends on the parameter only beyond a threshold none
+// of these values crosses would be missed; the models here have no such entry -- their branches in derive() are on cell type
+// and on flags in {0, 1, 2, 3}.)
+template <class Model>
+void beat_jit_derived_mask(const double* p, const SparseRows& sp, unsigned long long dm[2]) {
+  using D = typename Model::Derived;
+  constexpr int ND = (int)(sizeof(D) / sizeof(double));
+  static_assert(sizeof(D) % sizeof(double) == 0 && ND <= 128, "Derived: up to 128 doubles");
+  dm[0] = dm[1] = 0;
+  double q[Model::NP];
+  for (int k = 0; k < Model::NP; ++k) q[k] = p[k];
+  const D base = Model::derive((const double*)q);
+  for (int j = 0; j < sp.count; ++j) {
+    const int k = sp.idx[j];
+    const double x = p[k];
+    const double variants[] = {x * 1.5 + 0.25, x * 0.5 - 0.125, x + 1.0, x + 2.0, x - 1.0, -x - 0.5, 0.0, 1.0, 2.0, 3.0, x * 7.0, x * 0.01};
+    for (double v : variants) {
+      q[k] = v;
+      const D d = Model::derive((const double*)q);
+      for (int e = 0; e < ND; ++e)
+        if (std::memcmp((const char*)&d + 8 * e, (const char*)&base + 8 * e, 8) != 0) dm[e >> 6] |= 1ull << (e & 63);
+    }
+    q[k] = x;
+  }
+}
+
+template <class Model>
+int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
+                        typename Model::Derived drv, const double* ppn, int64_t pld, double t, double dt, int v_index, double* v_copy,
+                        PendingV pend, MarkedArgs mk, SparseRows sp) {
+  if constexpr (!BeatJitAccessor<Model>::value) {
+    return BEAT_JIT_UNAVAILABLE;
+  } else {
+    if (BeatJitName<Model>::get() == nullptr || sp.count < 1 || sp.count > BEAT_MAX_SPARSE_ROWS || !beat_jit_enabled())
+      return BEAT_JIT_UNAVAILABLE;
+    unsigned long long dm[2];
+    beat_jit_derived_mask<Model>(prm.p, sp, dm);
+    int ct[4] = {-1, -1, -1, -1};
+    for (int j = 0; j < sp.count; ++j) ct[j] = sp.idx[j];
+    char key[256], inst[512];
+    std::snprintf(key, sizeof key, "%s_p%d_i%d_%d_%d_%d_m%llx_%llx", BeatJitName<Model>::get(), have_pend ? 1 : 0, ct[0], ct[1], ct[2],
+                  ct[3], dm[0], dm[1]);
+    std::snprintf(inst, sizeof inst, "ode_step_kernel<%s, true, %s, false, true, %d, %d, %d, %d, 0x%llxull, 0x%llxull>",
+                  BeatJitName<Model>::get(), have_pend ? "true" : "false", ct[0], ct[1], ct[2], ct[3], dm[0], dm[1]);
+    std::string src = "// written by libbeat_hip (beat_ode_jit.h): one instance of the ionic step kernel, varying parameter indices compile-time\n"
+                      "#include \"beat_ode_kernel.h\"\n"
+                      "template __global__ void ";
+    src += inst;
+    src += "(\n    double*, int64_t, int64_t, ParamPack<";
+    src += BeatJitName<Model>::get();
+    src += "::NP>, typename ";
+    src += BeatJitName<Model>::get();
+    src += "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
+    hipFunction_t f = beat_jit_get(ctx, key, src);
+    if (f == nullptr) return BEAT_JIT_UNAVAILABLE;
+    void* args[] = {&states, &n, &ld, &prm, &drv, &ppn, &pld, &t, &dt, &v_index, &v_copy, &pend, &mk, &sp};
+    BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid.x, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+    return BEAT_OK;
+  }
+}

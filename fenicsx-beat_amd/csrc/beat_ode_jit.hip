@@ -1,0 +1,268 @@
+// Run-time compilation of ONE instance of the ionic step kernel (see beat_ode_jit.h): source written to the cache directory,
+// hipcc --genco for gfx950 as a child process, the code object kept on disk under a name that hashes the instance AND the kernel
+// sources it was built from, loaded with hipModuleLoadData.  Nothing here runs on the host in place of a kernel: when an
+// instance cannot be had the caller launches the run-time-index kernel of the library.
+#include "beat_ode_jit.h"
+
+#include <dirent.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <vector>
+
+extern char** environ;
+
+namespace {
+#define BEAT_STR2(x) #x
+#define BEAT_STR(x) BEAT_STR2(x)
+// the flags of the library's own build of beat_ode.hip (csrc/Makefile: CXXFLAGS + FLAGS_beat_ode), device side only
+const char* const kFlags[] = {"--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                              "-DBEAT_ODE_WAVES=" BEAT_STR(BEAT_ODE_WAVES), "-DBEAT_ODE_WAVES_PER_NODE=" BEAT_STR(BEAT_ODE_WAVES_PER_NODE),
+                              "-mllvm", "-disable-machine-licm", "-w"};
+
+struct JitState {
+  std::mutex m;
+  bool init = false, usable = false, verbose = false;
+  std::string srcdir, cachedir, hipcc, srchash, why;
+  std::map<std::string, hipFunction_t> fn;  // key@device
+  std::set<std::string> failed;
+  std::vector<hipModule_t> modules;
+  long long loaded = 0, compiled = 0, disk_hits = 0, failures = 0;
+};
+JitState& state() {
+  static JitState s;
+  return s;
+}
+
+unsigned long long fnv(const std::string& s, unsigned long long h = 1469598103934665603ull) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+bool is_file(const std::string& p) {
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+bool make_dirs(const std::string& p) {
+  std::string cur;
+  for (size_t i = 0; i <= p.size(); ++i) {
+    if (i == p.size() || p[i] == '/') {
+      if (!cur.empty() && ::mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return false;
+    }
+    if (i < p.size()) cur += p[i];
+  }
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && ::access(p.c_str(), W_OK) == 0;
+}
+
+std::string read_file(const std::string& p) {
+  std::ifstream f(p, std::ios::binary);
+  std::ostringstream o;
+  o << f.rdbuf();
+  return o.str();
+}
+
+void init_locked(JitState& s) {
+  s.init = true;
+  s.verbose = std::getenv("BEAT_JIT_VERBOSE") != nullptr;
+  // the kernel sources: BEAT_JIT_SRC, or csrc/ beside the package the library was loaded from (<pkg>/beat/lib/libbeat_hip.so)
+  if (const char* d = std::getenv("BEAT_JIT_SRC")) {
+    s.srcdir = d;
+  } else {
+    Dl_info info;
+    if (dladdr((const void*)&beat_jit_enabled, &info) && info.dli_fname) {
+      std::string lib = info.dli_fname;
+      char real[4096];
+      if (::realpath(lib.c_str(), real)) lib = real;
+      const size_t cut = lib.rfind("/beat/lib/");
+      if (cut != std::string::npos) s.srcdir = lib.substr(0, cut) + "/csrc";
+    }
+  }
+  if (s.srcdir.empty() || !is_file(s.srcdir + "/beat_ode_kernel.h") || !is_file(s.srcdir + "/../../include/beat_hip.h")) {
+    s.why = "kernel sources not found (BEAT_JIT_SRC, or csrc/ and include/ beside the package)";
+    return;
+  }
+  if (const char* h = std::getenv("BEAT_HIPCC")) s.hipcc = h;
+  else if (::access("/opt/rocm/bin/hipcc", X_OK) == 0) s.hipcc = "/opt/rocm/bin/hipcc";
+  else s.hipcc = "hipcc";  // looked up on PATH by posix_spawnp
+  std::vector<std::string> cands;
+  if (const char* c = std::getenv("BEAT_JIT_CACHE")) cands.push_back(c);
+  if (const char* x = std::getenv("XDG_CACHE_HOME")) cands.push_back(std::string(x) + "/beat_hip");
+  if (const char* h = std::getenv("HOME")) cands.push_back(std::string(h) + "/.cache/beat_hip");
+  cands.push_back("/tmp/beat_hip_" + std::to_string((long long)::getuid()));
+  for (const std::string& c : cands) {
+    if (make_dirs(c)) {
+      s.cachedir = c;
+      break;
+    }
+  }
+  if (s.cachedir.empty()) {
+    s.why = "no writable cache directory (BEAT_JIT_CACHE)";
+    return;
+  }
+  // what a cached code object was built from: every header of csrc/ and the flags
+  std::vector<std::string> names;
+  if (DIR* d = ::opendir(s.srcdir.c_str())) {
+    while (dirent* de = ::readdir(d)) {
+      const std::string n = de->d_name;
+      if (n.size() > 2 && n.compare(n.size() - 2, 2, ".h") == 0) names.push_back(n);
+    }
+    ::closedir(d);
+  }
+  std::sort(names.begin(), names.end());
+  unsigned long long h = fnv("beat-jit-1");
+  for (const std::string& n : names) h = fnv(read_file(s.srcdir + "/" + n), fnv(n, h));
+  for (const char* f : kFlags) h = fnv(f, h);
+  char buf[32];
+  std::snprintf(buf, sizeof buf, "%016llx", h);
+  s.srchash = buf;
+  s.usable = true;
+}
+
+// hipcc as a child process, output to `log`; true when it exited with 0
+bool run_hipcc(const JitState& s, const std::string& src, const std::string& out, const std::string& log) {
+  std::vector<std::string> a{s.hipcc};
+  for (const char* f : kFlags) a.push_back(f);
+  a.push_back("-I" + s.srcdir);
+  a.push_back(src);
+  a.push_back("-o");
+  a.push_back(out);
+  std::vector<char*> argv;
+  for (std::string& x : a) argv.push_back(&x[0]);
+  argv.push_back(nullptr);
+  posix_spawn_file_actions_t fa;
+  posix_spawn_file_actions_init(&fa);
+  posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  posix_spawn_file_actions_adddup2(&fa, 1, 2);
+  pid_t pid = 0;
+  const int rc = posix_spawnp(&pid, s.hipcc.c_str(), &fa, nullptr, argv.data(), environ);
+  posix_spawn_file_actions_destroy(&fa);
+  if (rc != 0) return false;
+  int status = 0;
+  while (::waitpid(pid, &status, 0) < 0) {
+    if (errno != EINTR) return false;
+  }
+  return WIFEXITED(status) && WEXITSTATUS(status) == 0;
+}
+
+// the kernel's symbol in a code object (an offload bundle or a bare ELF): the NUL-terminated string that starts with _Z, names
+// ode_step_kernel and carries no suffix (.kd, .private_seg_size ... are the descriptor and its metadata)
+std::string kernel_symbol(const std::string& blob) {
+  size_t pos = 0;
+  while ((pos = blob.find("ode_step_kernel", pos)) != std::string::npos) {
+    size_t b = pos;
+    while (b > 0 && blob[b - 1] != '\0' && (pos - b) < 8) --b;
+    size_t e = pos;
+    while (e < blob.size() && blob[e] != '\0') ++e;
+    const std::string name = blob.substr(b, e - b);
+    if (name.size() > 2 && name[0] == '_' && name[1] == 'Z' && name.find('.') == std::string::npos &&
+        std::all_of(name.begin(), name.end(), [](unsigned char c) { return c > 32 && c < 127; }))
+      return name;
+    pos = e;
+  }
+  return "";
+}
+
+void fail_locked(JitState& s, const std::string& full_key, const std::string& msg) {
+  s.failed.insert(full_key);
+  s.failures += 1;
+  s.why = msg;
+  std::fprintf(stderr, "[libbeat_hip] run-time compilation unavailable for %s: %s -- using the run-time-index kernel\n", full_key.c_str(),
+               msg.c_str());
+}
+}  // namespace
+
+bool beat_jit_enabled() {
+  const char* e = std::getenv("BEAT_JIT");  // read per call: a caller may switch routes between steps (tests, A/B runs)
+  if (e && e[0] == '0') return false;
+  JitState& s = state();
+  std::lock_guard<std::mutex> lock(s.m);
+  if (!s.init) init_locked(s);
+  return s.usable;
+}
+
+hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source) {
+  JitState& s = state();
+  std::lock_guard<std::mutex> lock(s.m);
+  if (!s.init) init_locked(s);
+  if (!s.usable) return nullptr;
+  const std::string full = key + "@" + std::to_string(ctx->device);
+  auto it = s.fn.find(full);
+  if (it != s.fn.end()) return it->second;
+  if (s.failed.count(full)) return nullptr;
+  char hx[32];
+  std::snprintf(hx, sizeof hx, "%016llx", fnv(key, fnv(s.srchash)));
+  const std::string base = s.cachedir + "/beatjit_" + hx;
+  const std::string obj = base + ".hsaco";
+  if (is_file(obj)) {
+    s.disk_hits += 1;
+  } else {
+    const std::string tag = "." + std::to_string((long long)::getpid());
+    const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp", log = base + ".log";
+    {
+      std::ofstream f(src);
+      f << "// " << key << "\n" << source;
+    }
+    if (s.verbose) std::fprintf(stderr, "[libbeat_hip] compiling %s -> %s\n", key.c_str(), obj.c_str());
+    const bool ok = run_hipcc(s, src, tmp, log);
+    ::unlink(src.c_str());
+    if (!ok || !is_file(tmp)) {
+      ::unlink(tmp.c_str());
+      fail_locked(s, full, "hipcc failed (" + s.hipcc + ", log " + log + ")");
+      return nullptr;
+    }
+    s.compiled += 1;
+    if (::rename(tmp.c_str(), obj.c_str()) != 0) {  // (another process may have put the same object there: either will do)
+      ::unlink(tmp.c_str());
+      if (!is_file(obj)) {
+        fail_locked(s, full, "cannot write " + obj);
+        return nullptr;
+      }
+    }
+  }
+  const std::string blob = read_file(obj);
+  const std::string sym = kernel_symbol(blob);
+  hipModule_t mod = nullptr;
+  hipFunction_t f = nullptr;
+  if (sym.empty() || hipSetDevice(ctx->device) != hipSuccess || hipModuleLoadData(&mod, blob.data()) != hipSuccess ||
+      hipModuleGetFunction(&f, mod, sym.c_str()) != hipSuccess || f == nullptr) {
+    (void)hipGetLastError();
+    if (mod) (void)hipModuleUnload(mod);
+    ::unlink(obj.c_str());  // a stale or truncated object: compiled again next time
+    fail_locked(s, full, "the code object " + obj + " did not load");
+    return nullptr;
+  }
+  s.modules.push_back(mod);
+  s.fn[full] = f;
+  s.loaded += 1;
+  return f;
+}
+
+// out[4]: kernels loaded in this process, hipcc runs, code objects taken from the cache directory, failures.  Returns 1 when
+// run-time compilation is usable here (sources, compiler and cache directory found), 0 otherwise.
+extern "C" int beat_ode_jit_stats(long long* host_out) {
+  JitState& s = state();
+  std::lock_guard<std::mutex> lock(s.m);
+  if (!s.init) init_locked(s);
+  if (host_out) {
+    host_out[0] = s.loaded;
+    host_out[1] = s.compiled;
+    host_out[2] = s.disk_hits;
+    host_out[3] = s.failures;
+  }
+  return s.usable ? 1 : 0;
+}

@@ -1,0 +1,365 @@
+// The ionic step kernel (template) and its argument structures, in a header so that two translation units can instantiate it:
+// beat_ode.hip (every instance the library ships) and the unit beat_ode_jit.hip writes and compiles at run time for ONE instance
+// whose varying parameter indices are compile-time constants (sparse per-node parameter rows, see MixedParams below).
+// Replaces  states[:] = fun(states=, t=, parameters=, dt=)  (src/beat/odesolver.py:67-79).
+#pragma once
+#include "beat_pde_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+#include "ionic_models.h"
+
+#ifndef BEAT_ODE_PROBE
+#define BEAT_ODE_PROBE 0  // 1 / 2: probe builds of the plain step kernel (memory only / arithmetic only), tools/ode_probe.sh
+#endif
+#include "torord_dyncl.h"
+
+
+template <int NP>
+struct ParamPack {
+  double p[NP];
+};
+
+// Search directions of the last diffusion solve whose contribution alpha_j p_j has not been added to the
+// potential row yet (deferred-x PCG, beat_pde_solve_ex with defer_flush): the ionic kernel reads the row anyway,
+// has HBM bandwidth to spare (it is fp64-issue bound) and adds them on the fly, which saves the separate
+// x += sum alpha_j p_j pass (8 (k+2) B/node).
+struct PendingV {
+  const double* ring;    // p_0 (device), p_j = ring + j * fld
+  int64_t fld;
+  const double* alphas;  // device, step lengths alpha_j
+  int count;             // 0: no search direction pending
+  // the solve started from an extrapolated guess (beat_pde_set_guess_order): v += inc, inc = e + sum alpha_j p_j,
+  // inc is recorded as the step's diffusion increment and the next guess prepared (gt.d == nullptr: no guess)
+  beat_pde_detail::GuessTerms gt;
+};
+
+// Layout of ode_step_kernel's kernel-argument segment up to the uniform parameters (all members 8-byte aligned): the
+// tile loop re-reads them through an opaque copy of the segment pointer (see the kernel).
+template <class Model>
+struct OdeStepKernArgHead {
+  double* states;
+  int64_t n, ld;
+  ParamPack<Model::NP> prm;
+  typename Model::Derived drv;
+  const double* ppn;
+  int64_t pld;
+  double t, dt;
+  int v_index;
+  double* v_copy;
+  PendingV pend;  // (MarkedArgs follows)
+};
+
+// Cell types / parameter classes in ONE launch (MARKED): a byte per node selects one of up to BEAT_MAX_CLASSES
+// parameter sets (uniform parameters + their Derived constants, a table in device memory laid out as TableEntry);
+// 255 = the node belongs to no class and is not advanced.  A wavefront whose nodes all carry the same marker -- the rule
+// when the classes are layers or regions -- reads its set with scalar loads exactly as the uniform kernel reads the
+// kernel-argument segment; a wavefront that straddles a boundary runs the step once per class present, lanes masked.
+// Replaces one launch per marker + scatter / gather of the potential (src/beat/odesolver.py:306-310 loops the markers).
+struct MarkedArgs {
+  const unsigned char* markers;  // (n) or nullptr
+  const double* table;           // classes x (NP + sizeof(Derived) / 8) doubles
+  int stride;                    // doubles per table entry
+  const int* vmap;               // (n) node of the PDE grid each entry of the state array belongs to, or nullptr (identity)
+  double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
+};
+
+// Per-node parameters of which only a few ROWS vary (a smooth gradient in one conductance: src/beat/odesolver.py:67-79 hands
+// ``fun`` the whole (P, N) array, demos/pace_train.py:133-167 builds such arrays): the varying rows alone live on the
+// device, the other parameters come from the uniform vector -- 8 B per varying row and node instead of 8 NP (TP06: 424).
+constexpr int BEAT_MAX_SPARSE_ROWS = 4;
+struct SparseRows {
+  int idx[BEAT_MAX_SPARSE_ROWS];  // parameter index of row j of ppn
+  int count;                      // 0: ppn holds all NP rows
+};
+
+template <class Model>
+struct OdeTableEntry {
+  double p[Model::NP];
+  typename Model::Derived d;
+};
+
+// Up to four varying rows whose parameter indices K0..K3 are known at COMPILE time (the instance is written and compiled at
+// first use, beat_ode_jit.hip): every use p[k] of the model's code folds to a row's value (k == Kj) or to the uniform vector,
+// read with scalar loads -- everything that does not vary stays on the scalar unit, as in the uniform kernel.  -1: unused.
+template <int K0, int K1, int K2, int K3>
+struct MixedParams {
+  const double* u;
+  double v0, v1, v2, v3;
+  __device__ __forceinline__ double operator[](int k) const {
+    return k == K0 ? v0 : k == K1 ? v1 : k == K2 ? v2 : k == K3 ? v3 : u[k];
+  }
+};
+// The derived constants (Model::Derived: doubles only): those a varying parameter enters -- bit j of DM0 (entries 0..63) / DM1
+// (64..127), found on the host by perturbing the parameter -- from the per-lane evaluation, the others from the uniform set
+// the host computed (scalar loads); the per-lane evaluation of an entry that is not taken is dead code and disappears.
+template <class D, unsigned long long DM0, unsigned long long DM1>
+__device__ __forceinline__ D mix_derived(const D& du, const D& dl) {
+  D d;
+  constexpr int ND = (int)(sizeof(D) / sizeof(double));
+  static_assert(sizeof(D) % sizeof(double) == 0 && ND <= 128, "Derived: up to 128 doubles");
+  const double* a = (const double*)&du;
+  const double* b = (const double*)&dl;
+  double* o = (double*)&d;
+#pragma unroll
+  for (int j = 0; j < ND; ++j) o[j] = (((j < 64 ? DM0 : DM1) >> (j & 63)) & 1ull) ? b[j] : a[j];
+  return d;
+}
+
+template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARSE = false, int CT0 = -1, int CT1 = -1, int CT2 = -1,
+          int CT3 = -1, unsigned long long DM0 = 0, unsigned long long DM1 = 0>
+__global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
+    double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
+    typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
+    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk, SparseRows sp) {
+  __shared__ double etab[BEAT_EXP_TAB];
+  __shared__ LogEntry ltab[128];
+  static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
+  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
+  __syncthreads();
+  const FastMath fm{etab, ltab};
+  // (Round 3, measured and removed: starting the three blocks that share a CU a third of a tile apart -- s_sleep by
+  // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
+  // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
+  // the first round.)
+  // a block walks over several tiles of 256 nodes (stride gridDim.x) and pays its launch and the table set-up once:
+  // at 512^3, 24 576 blocks of ~21 tiles each measured 10.5-10.6 ms against 10.9-11.3 for one block per tile on the
+  // same box (768 blocks, i.e. exactly the resident number: 11.5; 3 072: 10.7; 196 608: 10.9)
+  for (int64_t tile = blockIdx.x; tile * BEAT_BLOCK < n; tile += gridDim.x) {
+  const int64_t i = tile * BEAT_BLOCK + threadIdx.x;
+  if (i >= n) break;
+  // The row stride, opaque per tile: the base address of each of the NS state rows (states + k ld) is uniform and
+  // loop-invariant, so the compiler forms all of them ahead of the tile loop, runs out of SGPRs and parks them in VGPR
+  // lanes -- one v_readlane per half address per tile on the VALU this kernel is bound by (144 of 4756 VALU
+  // instructions per ToR-ORd node, 58 of 1928 per TP06 node).  Recomputed where used they cost SALU cycles only.
+  int64_t ldl = ld;
+  asm volatile("" : "+s"(ldl));
+  // the kernel-argument segment through a pointer the optimiser cannot see through (see below, at the uniform parameters);
+  // the pending-update arguments are read through it too: kept in SGPRs across the tile loop they were spilled as well
+  typedef const __attribute__((address_space(4))) char* KArgPtr;
+  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const PendingV& pendl = *(const PendingV*)(ka + offsetof(OdeStepKernArgHead<Model>, pend));
+  if (MARKED) {
+    const int m_lane = mk.markers[i];
+    // where the node's potential lives: row V_INDEX of the state array, or -- when the array holds only the nodes that
+    // carry a cell model (a voxelised wall inside its box) -- the PDE's field at node vmap[i]: the kernel then reads the
+    // potential there (pending update included) and writes the new one to both, which is the scatter and the gather of
+    // the potential the per-marker route spends two launches per marker on
+    const int64_t jn = mk.vmap != nullptr ? (int64_t)mk.vmap[i] : i;
+    double* const vptr = mk.vmap != nullptr ? mk.vfield + jn : states + (int64_t)Model::V_INDEX * ld + i;
+    struct NodeIOWithV {
+      double* __restrict__ base;
+      int64_t ld, i;
+      double* vout;  // the field entry that mirrors the potential (or nullptr)
+      double v;
+      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : base[(int64_t)k * ld + i]; }
+      __device__ __forceinline__ void store(int k, double x) const {
+        base[(int64_t)k * ld + i] = x;
+        if (k == Model::V_INDEX && vout != nullptr) *vout = x;
+      }
+    };
+    // 254: a padding entry (the compact layout keeps each class in its own run of whole tiles, so that a wavefront
+    // meets one class): nothing is read or written for it
+    double v_now = m_lane != 254 ? *vptr : 0.0;
+    if (PEND && m_lane != 254) {
+      // the potential with the pending update applied (and the guess's bookkeeping done) once, ahead of the passes --
+      // same expressions and order as NodeIOPending::load / x_flush_kernel: the pending values die here instead of
+      // staying live through every pass (-30 VGPRs, no scratch)
+      double pp[BEAT_MAX_PENDING], pa[BEAT_MAX_PENDING];
+#pragma unroll
+      for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
+        pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + jn) : 0.0;
+        pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
+      }
+      if (pendl.gt.d != nullptr) {
+        const beat_pde_detail::GuessTerms& gt = pendl.gt;
+        const double ge = beat_pde_detail::beat_guess_needs_e(gt) ? __builtin_nontemporal_load(gt.e + jn) : 0.0;
+        const double gd = beat_pde_detail::beat_guess_needs_d(gt) ? __builtin_nontemporal_load(gt.d + jn) : 0.0;
+        const double gp0 = beat_pde_detail::beat_guess_needs_dp(gt, 0) ? __builtin_nontemporal_load(gt.dp[0] + jn) : 0.0;
+        const double gp1 = beat_pde_detail::beat_guess_needs_dp(gt, 1) ? __builtin_nontemporal_load(gt.dp[1] + jn) : 0.0;
+        double inc = gt.accumulate ? 0.0 : ge;
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+          if (j < pendl.count) inc = fma(pa[j], pp[j], inc);
+        beat_pde_detail::beat_guess_record(gt, gt.d + jn, gt.e + jn, inc, gd, gp0, gp1, ge);
+        v_now += inc;
+      } else {
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
+          if (j < pendl.count) v_now = fma(pa[j], pp[j], v_now);
+      }
+    }
+    unsigned long long todo = __ballot(m_lane < 254);
+    while (todo) {
+      const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);  // wave-uniform
+      // the class's entry through a constant-address-space pointer the optimiser cannot see through: scalar loads where
+      // the values are used, as for the kernel-argument segment of the uniform kernel (the table is not written here)
+      typedef const __attribute__((address_space(4))) char* TabPtr;
+      TabPtr tb = (TabPtr)(uintptr_t)(mk.table + (int64_t)m * mk.stride);
+      asm volatile("" : "+s"(tb));
+      const double* p_c = (const double*)(tb + offsetof(OdeTableEntry<Model>, p));
+      const typename Model::Derived& d_c = *(const typename Model::Derived*)(tb + offsetof(OdeTableEntry<Model>, d));
+      // (node index and potential are made opaque per pass: otherwise the address of every state row and everything
+      // that depends on the potential alone is hoisted out of this loop and kept in registers, +38 VGPRs and scratch)
+      asm volatile("" : "+s"(ldl));
+      NodeIOWithV iol{states, ldl, i, mk.vmap != nullptr ? vptr : (v_copy != nullptr ? v_copy + i : nullptr), v_now};
+      asm volatile("" : "+v"(iol.i), "+v"(iol.v));
+      if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
+      todo &= ~__ballot(m_lane == m);
+    }
+    // a node outside every class still takes part in the diffusion: its potential gets the pending update
+    if (PEND && m_lane == 255) {
+      *vptr = v_now;
+      if (mk.vmap != nullptr) states[(int64_t)Model::V_INDEX * ld + i] = v_now;
+    }
+    continue;
+  }
+  // The ~90 uniform doubles (parameters, per-launch derived constants) are scalar loads from the kernel-argument
+  // segment.  Left to itself the compiler hoists all of them out of the tile loop, runs out of SGPRs and parks them in
+  // VGPR lanes: 640 v_readlane / v_writelane per node on the VALU that is this kernel's bottleneck.  Reading them
+  // through a pointer the optimiser cannot see through keeps the loads where they are used (SALU, scalar cache).
+  const double* p_uni = (const double*)(ka + offsetof(OdeStepKernArgHead<Model>, prm));
+  const typename Model::Derived& d_uni =
+      *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
+  if (PEND) {
+    // all loads issued together (they overlap with the state loads that follow)
+    NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, pendl.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+#pragma unroll
+    for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
+      io.pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + i) : 0.0;
+      io.pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
+    }
+    if (pendl.gt.d != nullptr) {
+      io.gt = pendl.gt;
+      io.ge = beat_pde_detail::beat_guess_needs_e(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.e + i) : 0.0;
+      io.gd = beat_pde_detail::beat_guess_needs_d(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.d + i) : 0.0;
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 0) ? __builtin_nontemporal_load(pendl.gt.dp[0] + i) : 0.0;
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 1) ? __builtin_nontemporal_load(pendl.gt.dp[1] + i) : 0.0;
+    }
+    if constexpr (PER_NODE && SPARSE && CT0 >= 0) {
+      // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
+      const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
+                                               CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
+      const typename Model::Derived dlane = Model::derive(mp);
+      const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
+      Model::step(io, mp, dm, fm, t, dt);
+    } else if (PER_NODE) {
+      double pl[Model::NP];
+      if (SPARSE) {
+        // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
+        // the entry it lands in is found by comparison: no dynamic indexing of the register array)
+        // (read with VECTOR loads -- one address for the whole wave, a broadcast from one or two cache lines: as scalar
+        // loads the NP uniform values were all held in SGPRs until the selects below had consumed them, 500 (TP06) to 1300
+        // (Land) SGPRs spilled to VGPR lanes)
+        const double* pv = p_uni;
+        asm volatile("" : "+v"(pv));
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+          if (j < sp.count) {
+            const double vj = ppn[(int64_t)j * pld + i];
+            // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
+            // hoisted out of the tile loop, held in SGPR pairs and spilled)
+            int ij = sp.idx[j];
+            asm volatile("" : "+s"(ij));
+#pragma unroll
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == ij ? vj : pl[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      }
+      const typename Model::Derived dl = Model::derive(pl);
+      Model::step(io, pl, dl, fm, t, dt);
+    } else {
+      Model::step(io, p_uni, d_uni, fm, t, dt);
+    }
+  } else {
+    // (the mirror of row v_index -- any row here, unlike in the pending-update form -- is written after the step from
+    // the row itself: a store-time test "k == v_index" for each of the NS rows is NS uniform conditions kept, and spilled)
+    const NodeIO io{states, ldl, i, nullptr, -1};
+    if constexpr (PER_NODE && SPARSE && CT0 >= 0) {
+      // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
+      const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
+                                               CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
+      const typename Model::Derived dlane = Model::derive(mp);
+      const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
+      Model::step(io, mp, dm, fm, t, dt);
+    } else if (PER_NODE) {
+      double pl[Model::NP];
+      if (SPARSE) {
+        // the uniform vector, then the few rows that vary written over their entries (the index of a row is wave-uniform,
+        // the entry it lands in is found by comparison: no dynamic indexing of the register array)
+        // (read with VECTOR loads -- one address for the whole wave, a broadcast from one or two cache lines: as scalar
+        // loads the NP uniform values were all held in SGPRs until the selects below had consumed them, 500 (TP06) to 1300
+        // (Land) SGPRs spilled to VGPR lanes)
+        const double* pv = p_uni;
+        asm volatile("" : "+v"(pv));
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
+#pragma unroll
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+          if (j < sp.count) {
+            const double vj = ppn[(int64_t)j * pld + i];
+            // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
+            // hoisted out of the tile loop, held in SGPR pairs and spilled)
+            int ij = sp.idx[j];
+            asm volatile("" : "+s"(ij));
+#pragma unroll
+            for (int k = 0; k < Model::NP; ++k) pl[k] = k == ij ? vj : pl[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+      }
+      const typename Model::Derived dl = Model::derive(pl);
+      Model::step(io, pl, dl, fm, t, dt);
+    } else {
+#if BEAT_ODE_PROBE == 1
+      // probe build (never shipped: -DBEAT_ODE_PROBE=1): the kernel's memory traffic alone -- every state read and
+      // written back, same grid and tile loop
+      double tmp[Model::NS];
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tmp[k] = io.load(k);
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) io.store(k, tmp[k] * 1.0000000001);
+#elif BEAT_ODE_PROBE == 3
+      // probe build (-DBEAT_ODE_PROBE=3): the traffic of probe 1 with the array addressed tile-major -- the NS rows of a
+      // tile's 256 nodes next to each other (NS * 2 KB contiguous per tile) instead of NS streams ld apart
+      double tmp[Model::NS];
+      double* tb = states + tile * (int64_t)(Model::NS * BEAT_BLOCK) + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tmp[k] = tb[k * BEAT_BLOCK];
+#pragma unroll
+      for (int k = 0; k < Model::NS; ++k) tb[k * BEAT_BLOCK] = tmp[k] * 1.0000000001;
+#elif BEAT_ODE_PROBE == 2
+      // probe build (-DBEAT_ODE_PROBE=2): the kernel's arithmetic alone -- states of the block's first tile (cache hits),
+      // stores behind a condition that never holds
+      struct ProbeIO {
+        double* __restrict__ base;
+        int64_t ld, i, j;
+        __device__ __forceinline__ double load(int k) const { return base[(int64_t)k * ld + j]; }
+        __device__ __forceinline__ void store(int k, double v) const {
+          if (v == 1.2345e300) base[(int64_t)k * ld + i] = v;
+        }
+      };
+      const ProbeIO pio{states, ldl, i, (int64_t)threadIdx.x};
+      Model::step(pio, p_uni, d_uni, fm, t, dt);
+#else
+      Model::step(io, p_uni, d_uni, fm, t, dt);
+#endif
+    }
+    if (v_copy != nullptr) v_copy[i] = states[(int64_t)v_index * ldl + i];
+  }
+  }
+}
+

@@ -474,6 +474,7 @@ struct FhnReadme {
 #endif
 struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53, V_INDEX = 17;
+  static constexpr bool ACCESSOR_PARAMS = true;  // derive / step take any p indexable by parameter number (beat_ode_jit.hip)
   static constexpr bool REGISTER_LOOP = true;
   static constexpr int WAVES = BEAT_ODE_WAVES;
   static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
@@ -490,7 +491,9 @@ struct Tp06Grl1 {
     double RTF, FRT, halfRTF, sqrtKo, gK1s, gKrs, KoPk, cCaL, NaK_B, Nao3, A2c, kNaCaQ, gm1,
         cVF, c1, c2, c3, c4, c5, Kup2, BKc, BKsr, BKss, dsr;
   };
-  __host__ __device__ static Derived derive(const double* p) {
+  // P: anything indexable by parameter number (const double*, a per-lane array, MixedParams of beat_ode.hip)
+  template <class P>
+  __host__ __device__ static Derived derive(const P& p) {
     Derived q;
     q.RTF = p[R] * p[T] / p[F];
     q.FRT = p[F] / (p[R] * p[T]);
@@ -566,8 +569,8 @@ struct Tp06Grl1 {
   // 3-4 resident waves per SIMD need.
 #define BEAT_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-  template <class IO>
-  __device__ static __forceinline__ void step(const IO& io, const double* p, const Derived& q, const FastMath& fm,
+  template <class IO, class P>
+  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived& q, const FastMath& fm,
                                               double t, double dt) {
     const double v = io.load(V);
     // exp(c) constants, c written out in the comment

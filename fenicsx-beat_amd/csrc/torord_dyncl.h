@@ -220,6 +220,7 @@ BEAT_DV Du<A> cube(const Du<A>& a) {
 template <bool LAND>
 struct TorordGrl1T {
   static constexpr int NS = LAND ? 52 : 45, NP = LAND ? 140 : 112, V_INDEX = LAND ? 41 : 42;  // V_INDEX: membrane potential
+  static constexpr bool ACCESSOR_PARAMS = true;  // derive / step take any p indexable by parameter number (beat_ode_jit.hip)
   // ode_run_kernel keeps the states of hand-written models in registers across steps (the generated kernel of round 1
   // spilled so heavily that this miscompiled and had to go through memory)
   static constexpr bool REGISTER_LOOP = true;
@@ -279,7 +280,9 @@ struct TorordGrl1T {
     double e_er, e_sd;  // exp((EKshift + 70)/20), exp(-(vShift + 6)/20)
     double gate_bound, ito_bound;  // upper bounds of the rates of the gates whose time constant has a floor (see gate_b)
   };
-  BEAT_HD static Derived derive(const double* p) {
+  // P: anything indexable by parameter number (const double*, a per-lane array, MixedParams of beat_ode_kernel.h)
+  template <class P>
+  BEAT_HD static Derived derive(const P& p) {
     Derived q;
     const double RTF = p[R_] * p[T_] / p[F_];
     q.FRT = p[F_] / (p[R_] * p[T_]);
@@ -487,8 +490,8 @@ struct TorordGrl1T {
     return grl1(y, f, J, fm.exp(fmin(fmax(z, -746.0), 710.0)) - 1.0, dt);
   }
 
-  template <class IO, class FM>
-  BEAT_DV static void step(const IO& io_, const double* p, const Derived& q, const FM& fm, double t, double dt) {
+  template <class IO, class FM, class P>
+  BEAT_DV static void step(const IO& io_, const P& p, const Derived& q, const FM& fm, double t, double dt) {
     using namespace torord_detail;
     const Rows<IO> io{io_};
     // directions of the dual numbers, per block: 0 = v always; 1, 2 = the block's ion concentrations

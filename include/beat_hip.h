@@ -118,6 +118,12 @@ int beat_ode_step_rows(beat_ctx* ctx, int model_id, double* dev_states, int64_t 
                        const double* host_params, int num_params, const int* host_row_params, int num_rows,
                        const double* dev_rows, int64_t rows_ld, double t, double dt, int v_index, double* dev_v_copy,
                        beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
+/* Run-time compilation behind beat_ode_step_rows: the kernel instance whose varying parameter indices are compile-time
+ * constants is written, compiled by hipcc for gfx950 and cached at first use (csrc/beat_ode_jit.h; environment: BEAT_JIT=0 off,
+ * BEAT_JIT_CACHE directory, BEAT_JIT_SRC kernel sources, BEAT_HIPCC compiler, BEAT_JIT_VERBOSE).  host_out[4] = kernels loaded
+ * in this process, hipcc runs, code objects taken from the cache directory, failures; returns 1 where it is usable (sources,
+ * compiler, cache directory found), 0 where beat_ode_step_rows runs its run-time-index kernel instead. */
+int beat_ode_jit_stats(long long* host_out);
 
 /* Cell types / parameter classes in ONE launch (src/beat/odesolver.py:306-310 loops over the markers and calls `fun`
  * once per marker; demos/biv_endocardial.py:187-282: endo / mid / epi): one (S, n) state array, a byte per node that

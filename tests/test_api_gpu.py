@@ -890,9 +890,10 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     S0 = np.repeat(tp06.init_state_values()[:, None], n, axis=1)
     S0[tp06.state_index("V")] = rng.uniform(-90.0, 30.0, n)
 
-    def run(parameters, steps=6, classes_env="1", sparse_env="1"):
+    def run(parameters, steps=6, classes_env="1", sparse_env="1", jit_env="1"):
         os.environ["BEAT_PARAM_CLASSES"] = classes_env
         os.environ["BEAT_PARAM_SPARSE"] = sparse_env
+        os.environ["BEAT_JIT"] = jit_env  # "0": the run-time-index kernel (same arithmetic as the all-rows kernel, bit for bit)
         try:
             ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=g.Function(V), fun=tp06.generalized_rush_larsen,
                                                  init_states=S0, parameters=parameters, num_states=19, v_index=tp06.state_index("V"))
@@ -902,6 +903,7 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
         finally:
             os.environ.pop("BEAT_PARAM_CLASSES", None)
             os.environ.pop("BEAT_PARAM_SPARSE", None)
+            os.environ.pop("BEAT_JIT", None)
 
     ode_c, out_c = run(P)
     assert ode_c._dev.classes is not None and ode_c._dev.classes[2] == 2
@@ -929,15 +931,20 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     # ... but only ONE row of it varies: that row alone is kept on the device next to the uniform vector (round 4:
     # beat_ode_step_rows -- 8 B per node of parameter traffic instead of 424), same arithmetic as with all 53 rows
     Pg[tp06.parameter_index("g_CaL")] *= 1.0 + 0.2 * np.sin(3.0 * xs)
-    ode_g, out_g = run(Pg)
+    ode_g, out_g = run(Pg, jit_env="0")
     assert ode_g._dev.classes is None and ode_g._dev._sparse is not None
     assert sorted(ode_g._dev._sparse[1].tolist()) == sorted([tp06.parameter_index("g_Na"), tp06.parameter_index("g_CaL")])
     ode_d, out_d = run(Pg, sparse_env="0")
     assert ode_d._dev._sparse is None
     np.testing.assert_array_equal(out_g, out_d)
-    ode_h2, out_h2 = run(DeviceParameters(Pg))
+    ode_h2, out_h2 = run(DeviceParameters(Pg), jit_env="0")
     assert ode_h2._dev._sparse is not None
     np.testing.assert_array_equal(out_h2, out_d)
+    # the default route: the instance compiled for these two indices (csrc/beat_ode_jit.h) -- the constants the two
+    # conductances do not enter come from the host there: last-bit differences
+    ode_j, out_j = run(Pg)
+    assert ode_j._dev._sparse is not None
+    np.testing.assert_allclose(out_j, out_d, rtol=1e-12, atol=1e-300)
     ref = S0.copy()
     for i in range(6):
         ref = ionic.tp06_generalized_rush_larsen(ref, 0.02 * i, 0.02, Pg)
@@ -963,6 +970,7 @@ def test_split_step_with_a_smooth_per_node_parameter_runs_on_sparse_rows():
 
     def run(model, vname, pname, sparse):
         os.environ["BEAT_PARAM_SPARSE"] = sparse
+        os.environ["BEAT_JIT"] = "0"  # the run-time-index kernel: same arithmetic as the all-rows kernel (the compiled instance: next test)
         try:
             mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([2.0, 1.0, 0.6])], [20, 10, 6])
             V = g.functionspace(mesh, ("P", 1))
@@ -984,6 +992,7 @@ def test_split_step_with_a_smooth_per_node_parameter_runs_on_sparse_rows():
             return np.asarray(ode.values).copy(), ode._dev._sparse is not None, (mesh, P, S0)
         finally:
             os.environ.pop("BEAT_PARAM_SPARSE", None)
+            os.environ.pop("BEAT_JIT", None)
 
     for model, vname, pname in ((tp06, "V", "g_CaL"), (torord, "v", "GKr_b")):
         a, sparse_a, info = run(model, vname, pname, "1")
@@ -992,6 +1001,75 @@ def test_split_step_with_a_smooth_per_node_parameter_runs_on_sparse_rows():
         np.testing.assert_array_equal(a, b)
         assert np.isfinite(a).all() and a[model.state_index(vname)].max() > -80.0  # (the bump is still there)
 
+
+
+def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
+    """The kernel instance with the varying parameter indices as compile-time constants, written and compiled by hipcc at first
+    use (csrc/beat_ode_jit.h): through the public API's fused split step against the all-rows kernel -- same values to 1e-12 (the
+    derived constants the varying parameter does not enter are the host's there and the device's here: last-bit differences) --
+    for one smooth conductance (TP06, ToR-ORd), for two varying rows at once, and for a DISCRETE parameter pushed through the
+    sparse route with the class analysis off (the cell type of ToR-ORd: derive() branches on it, so the numerically found
+    dependency mask has to catch every constant it switches).  The library's counters say the instances were compiled and
+    loaded, and a second solver with the same index set compiles nothing.  Reference: src/beat/odesolver.py:67-79."""
+    import ctypes as C
+    import os
+
+    import beat
+    from beat import _hip
+    from beat import grid as g
+    from beat.models import torord, tp06
+
+    lib = _hip.load()
+    stats = (C.c_longlong * 4)()
+    assert lib.beat_ode_jit_stats(stats) == 1, "hipcc / kernel sources / cache directory not found on a GPU box"
+
+    def run(model, vname, fields, route):
+        env = {"rows": {"BEAT_PARAM_SPARSE": "0"}, "jit": {}}[route]
+        env = dict(env, BEAT_PARAM_CLASSES="0")
+        os.environ.update(env)
+        try:
+            mesh = g.create_box(g.COMM_WORLD, [np.zeros(3), np.array([2.0, 1.0, 0.6])], [20, 10, 6])
+            V = g.functionspace(mesh, ("P", 1))
+            n = V.dofmap.index_map.size_local
+            xs = mesh.node_coordinates(pad3=True)
+            P = np.repeat(model.init_parameter_values()[:, None], n, axis=1)
+            for pname, field in fields.items():
+                P[model.parameter_index(pname)] = field(P[model.parameter_index(pname)], xs)
+            time = g.Constant(mesh, 0.0)
+            pde = beat.MonodomainModel(time=time, mesh=mesh, M=np.diag([1e-3, 3e-4, 3e-4]), C_m=0.01,
+                                       params={"petsc_options": {"ksp_rtol": 1e-10}})
+            S0 = np.repeat(model.init_state_values()[:, None], n, axis=1)
+            S0[model.state_index(vname)] += 60.0 * np.exp(-((xs - np.array([0.4, 0.5, 0.3])) ** 2).sum(axis=1) / 0.05)
+            ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(V), v_pde=pde.state, fun=model.generalized_rush_larsen, init_states=S0,
+                                                 parameters=P, num_states=S0.shape[0], v_index=model.state_index(vname))
+            solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+            for k in range(12):
+                solver.step((0.02 * k, 0.02 * (k + 1)))
+            return np.asarray(ode.values).copy(), ode._dev._sparse is not None
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    smooth = lambda p, xs: p * (1.0 - 0.2 * xs[:, 0] - 0.1 * xs[:, 1] - 0.07 * xs[:, 2])  # noqa: E731
+    other = lambda p, xs: p * (0.7 + 0.25 * np.sin(3.0 * xs[:, 0]) * np.cos(2.0 * xs[:, 1]))  # noqa: E731
+    layers = lambda p, xs: np.floor(3.0 * xs[:, 2] / 0.6001)  # noqa: E731  -- 0, 1, 2 through the wall
+    cases = [(tp06, "V", {"g_CaL": smooth}), (torord, "v", {"GKr_b": smooth}), (tp06, "V", {"g_CaL": smooth, "g_Kr": other}),
+             (torord, "v", {"celltype": layers, "GKs_b": other})]
+    loaded_before = stats[0]
+    for model, vname, fields in cases:
+        a, sparse_a = run(model, vname, fields, "jit")
+        b, sparse_b = run(model, vname, fields, "rows")
+        assert sparse_a and not sparse_b
+        scale = np.maximum(np.abs(b), 1e-9 * np.abs(b).max(axis=1, keepdims=True) + 1e-300)
+        assert (np.abs(a - b) / scale).max() < 1e-10, (sorted(fields), (np.abs(a - b) / scale).max())
+        assert np.isfinite(a).all()
+    assert lib.beat_ode_jit_stats(stats) == 1
+    loaded, compiled, from_disk, failures = (int(v) for v in stats)
+    # every case steps the plain kernel once (the first ionic step has no pending update) and the pending-update form after
+    assert failures == 0 and loaded - loaded_before >= len(cases) and compiled + from_disk >= loaded - loaded_before
+    run(tp06, "V", {"g_CaL": smooth}, "jit")
+    lib.beat_ode_jit_stats(stats)
+    assert int(stats[0]) == loaded and int(stats[3]) == 0  # same index set: nothing new compiled or loaded
 
 
 def test_parameter_route_follows_the_parameters_through_every_change_of_kind():
