@@ -246,9 +246,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
       // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
       const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
                                                CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
-      const typename Model::Derived dlane = Model::derive(mp);
-      const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
-      Model::step(io, mp, dm, fm, t, dt);
+      if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
+        Model::step(io, mp, d_uni, fm, t, dt);
+      } else {
+        const typename Model::Derived dlane = Model::derive(mp);
+        const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
+        Model::step(io, mp, dm, fm, t, dt);
+      }
     } else if (PER_NODE) {
       double pl[Model::NP];
       if (SPARSE) {
@@ -290,9 +294,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
       // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
       const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
                                                CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
-      const typename Model::Derived dlane = Model::derive(mp);
-      const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
-      Model::step(io, mp, dm, fm, t, dt);
+      if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
+        Model::step(io, mp, d_uni, fm, t, dt);
+      } else {
+        const typename Model::Derived dlane = Model::derive(mp);
+        const typename Model::Derived dm = mix_derived<typename Model::Derived, DM0, DM1>(d_uni, dlane);
+        Model::step(io, mp, dm, fm, t, dt);
+      }
     } else if (PER_NODE) {
       double pl[Model::NP];
       if (SPARSE) {
