@@ -23,6 +23,8 @@ constexpr int BEAT_JIT_UNAVAILABLE = 1000;
 bool beat_jit_enabled();
 // the kernel of `key` on ctx's device: from memory, from the cache directory, or compiled from `source` now; nullptr: unavailable
 hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source);
+// the same from memory only (every step but the first); *known = false when the key has not been asked for yet
+hipFunction_t beat_jit_lookup(beat_ctx* ctx, const std::string& key, bool* known);
 
 template <class Model, class = void>
 struct BeatJitAccessor : std::false_type {};
@@ -91,18 +93,23 @@ int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states
     char key[256], inst[512];
     std::snprintf(key, sizeof key, "%s_p%d_i%d_%d_%d_%d_m%llx_%llx", BeatJitName<Model>::get(), have_pend ? 1 : 0, ct[0], ct[1], ct[2],
                   ct[3], dm[0], dm[1]);
-    std::snprintf(inst, sizeof inst, "ode_step_kernel<%s, true, %s, false, true, %d, %d, %d, %d, 0x%llxull, 0x%llxull>",
-                  BeatJitName<Model>::get(), have_pend ? "true" : "false", ct[0], ct[1], ct[2], ct[3], dm[0], dm[1]);
-    std::string src = "// written by libbeat_hip (beat_ode_jit.h): one instance of the ionic step kernel, varying parameter indices compile-time\n"
-                      "#include \"beat_ode_kernel.h\"\n"
-                      "template __global__ void ";
-    src += inst;
-    src += "(\n    double*, int64_t, int64_t, ParamPack<";
-    src += BeatJitName<Model>::get();
-    src += "::NP>, typename ";
-    src += BeatJitName<Model>::get();
-    src += "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
-    hipFunction_t f = beat_jit_get(ctx, key, src);
+    bool known = false;
+    hipFunction_t f = beat_jit_lookup(ctx, key, &known);
+    if (known && f == nullptr) return BEAT_JIT_UNAVAILABLE;
+    if (!known) {
+      std::snprintf(inst, sizeof inst, "ode_step_kernel<%s, true, %s, false, true, %d, %d, %d, %d, 0x%llxull, 0x%llxull>",
+                    BeatJitName<Model>::get(), have_pend ? "true" : "false", ct[0], ct[1], ct[2], ct[3], dm[0], dm[1]);
+      std::string src = "// written by libbeat_hip (beat_ode_jit.h): one instance of the ionic step kernel, varying parameter indices compile-time\n"
+                        "#include \"beat_ode_kernel.h\"\n"
+                        "template __global__ void ";
+      src += inst;
+      src += "(\n    double*, int64_t, int64_t, ParamPack<";
+      src += BeatJitName<Model>::get();
+      src += "::NP>, typename ";
+      src += BeatJitName<Model>::get();
+      src += "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
+      f = beat_jit_get(ctx, key, src);
+    }
     if (f == nullptr) return BEAT_JIT_UNAVAILABLE;
     void* args[] = {&states, &n, &ld, &prm, &drv, &ppn, &pld, &t, &dt, &v_index, &v_copy, &pend, &mk, &sp};
     BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid.x, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));

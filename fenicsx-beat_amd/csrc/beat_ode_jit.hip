@@ -195,6 +195,15 @@ bool beat_jit_enabled() {
   return s.usable;
 }
 
+hipFunction_t beat_jit_lookup(beat_ctx* ctx, const std::string& key, bool* known) {
+  JitState& s = state();
+  std::lock_guard<std::mutex> lock(s.m);
+  const std::string full = key + "@" + std::to_string(ctx->device);
+  auto it = s.fn.find(full);
+  *known = it != s.fn.end() || s.failed.count(full) != 0;
+  return it != s.fn.end() ? it->second : nullptr;
+}
+
 hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source) {
   JitState& s = state();
   std::lock_guard<std::mutex> lock(s.m);
