@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 
 constexpr int BEAT_JIT_UNAVAILABLE = 1000;
@@ -50,10 +51,11 @@ struct BeatJitName<TorordLandGrl1> {
 };
 
 // Which derived constants does parameter `idx` enter?  Found numerically: the host evaluates Model::derive with the parameter
-// replaced by a spread of other values -- scaled, shifted, negated, and the small integers a cell-type or switch parameter takes
-// -- and every entry whose bits change is taken per lane.  (An entry that depends on the parameter only beyond a threshold none
-// of these values crosses would be missed; the models here have no such entry -- their branches in derive() are on cell type
-// and on flags in {0, 1, 2, 3}.)
+// replaced by NaN -- which reaches every constant it enters through arithmetic -- and by a spread of other values -- scaled,
+// shifted, negated, and the small integers a cell-type or switch parameter takes -- for the constants it enters through a
+// comparison; every entry whose bits change is taken per lane.  (An entry that depends on the parameter ONLY through a
+// comparison with a threshold none of these values crosses would be missed; the models here have no such entry -- their
+// branches in derive() are on cell type and on flags in {0, 1, 2, 3}.)
 template <class Model>
 void beat_jit_derived_mask(const double* p, const SparseRows& sp, unsigned long long dm[2]) {
   using D = typename Model::Derived;
@@ -66,7 +68,10 @@ void beat_jit_derived_mask(const double* p, const SparseRows& sp, unsigned long 
   for (int j = 0; j < sp.count; ++j) {
     const int k = sp.idx[j];
     const double x = p[k];
-    const double variants[] = {x * 1.5 + 0.25, x * 0.5 - 0.125, x + 1.0, x + 2.0, x - 1.0, -x - 0.5, 0.0, 1.0, 2.0, 3.0, x * 7.0, x * 0.01};
+    // (NaN reaches every constant the parameter enters ARITHMETICALLY, whatever its value; the finite values are for the
+    // constants it enters through a comparison)
+    const double variants[] = {std::numeric_limits<double>::quiet_NaN(), std::numeric_limits<double>::infinity(),
+                               x * 1.5 + 0.25, x * 0.5 - 0.125, x + 1.0, x + 2.0, x - 1.0, -x - 0.5, 0.0, 1.0, 2.0, 3.0, x * 7.0, x * 0.01};
     for (double v : variants) {
       q[k] = v;
       const D d = Model::derive((const double*)q);
