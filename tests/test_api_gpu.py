@@ -1072,6 +1072,25 @@ def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
     assert int(stats[0]) == loaded and int(stats[3]) == 0  # same index set: nothing new compiled or loaded
 
 
+def test_sparse_rows_without_a_compiler_run_on_the_run_time_index_kernel(tmp_path):
+    """BEAT_HIPCC pointing nowhere (a machine with the library but no hipcc): the step on sparse rows runs on the shipped
+    run-time-index kernel -- the all-rows kernel's bits --, the failure is counted (beat_ode_jit_stats) and reported once on stderr;
+    nothing falls back to the host (tests/_jit_fallback_script.py, its own process: the compiler is looked up once per process)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, BEAT_HIPCC=str(tmp_path / "no-such-hipcc"), BEAT_JIT_CACHE=str(tmp_path / "cache"))
+    env.pop("BEAT_JIT", None)
+    run = subprocess.run([sys.executable, str(root / "tests" / "_jit_fallback_script.py")], capture_output=True, text=True, timeout=300,
+                         cwd=root, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert "jit-fallback ok" in run.stdout
+    assert run.stderr.count("run-time compilation unavailable") == 1 and "using the run-time-index kernel" in run.stderr
+
+
 def test_parameter_route_follows_the_parameters_through_every_change_of_kind():
     """(round-3 review) The route a step takes -- uniform vector, per-node rows, parameter classes -- is re-derived whenever
     the KIND of ``parameters`` changes: a classified (P, N) array, then a vector, then the SAME array again must classify
