@@ -879,6 +879,33 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   int chunk = beat_pde_first_chunk(pde) + (merged ? 1 : 0);
   double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
   if (rr && (rc = halo_start(comm, rbuf[0], n, plane))) return rc;  // ghost planes of r_0
+  // per-node rows: the fused tile pass (direction formed while loading, csrc/beat_pde_vtl.hip) on the slab -- like the
+  // register-row path it exchanges r, forms the direction on the ghost planes itself and never exchanges p.  It needs the
+  // centre coefficients of the neighbours' boundary planes: one exchange per operator, through the work field q (free until the
+  // first iteration).
+  // Whether the pass is to be had is a property of the rank's slab (tiles of 8 rows, a tile list), and all ranks must walk the
+  // same sequence of exchanges and reductions: they agree once per operator (a sum over the ranks of "I can").
+  const bool var_dist = !rr && pde->var && !(pde->g.z_lo_phys && pde->g.z_hi_phys);
+  if (var_dist && !pde->v_gc0_valid) {
+    h[0] = beat_vtl_pdot_dist_available(pde) ? 1.0 : 0.0;
+    BEAT_HIP_CHECK(hipMemcpyAsync(ctx->d_small, h, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = allreduce_sum(comm, ctx->d_small, 1))) return rc;
+    BEAT_HIP_CHECK(hipMemcpyAsync(h, ctx->d_small, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    pde->v_pdot_dist = h[0] == (double)comm->world;
+    if (pde->v_pdot_dist) {
+      BEAT_HIP_CHECK(hipMemcpyAsync(q, pde->v_A, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));  // slot 0 of the rows
+      if ((rc = halo_start(comm, q, n, plane))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      BEAT_HIP_CHECK(hipMemcpyAsync(pde->v_gc0, q - plane, sizeof(double) * (size_t)plane, hipMemcpyDeviceToDevice, ctx->stream));
+      BEAT_HIP_CHECK(hipMemcpyAsync(pde->v_gc0 + plane, q + n, sizeof(double) * (size_t)plane, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    pde->v_gc0_valid = true;
+  }
+  const bool vpdot = var_dist && pde->v_pdot_dist;
+  if (vpdot) {
+    if ((rc = halo_start(comm, r, n, plane))) return rc;  // ghost planes of r_0
+  }
   while (true) {
     chunk = std::min(chunk, limit - launched);
     for (int it = 0; it < chunk; ++it) {
@@ -925,6 +952,25 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         if ((rc = beat_rr_next(pde, st))) return rc;
         continue;
       }
+      if (vpdot) {
+        // p_i = D^-1 r_i + beta p_{i-1}, q = A p_i and p_i . q in one pass over the coefficient rows: the tiles that need no ghost
+        // plane while the ghost planes of r_i travel, then the boundary tiles (which keep p_i on the ghost planes); the residual
+        // update in place, its ghost planes travelling behind the second reduction and the next pass's first part
+        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 0))) return rc;
+        if ((rc = halo_wait(comm))) return rc;
+        if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 1))) return rc;
+        if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
+        if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
+        if ((rc = halo_start(comm, r, n, plane))) return rc;
+        if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
+        if (slot == PRING - 1) {
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+            return rc;
+        }
+        if ((rc = beat_rr_next(pde, st))) return rc;  // the scalar roll (beta, iteration count, latch)
+        continue;
+      }
       if ((rc = halo_start(comm, p_cur, n, plane))) return rc;                  // ghost planes of p travel ...
       if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 0))) return rc;       // ... while the interior is computed
       if ((rc = halo_wait(comm))) return rc;
@@ -945,7 +991,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
     if (h[STOP] != 0.0 || launched >= limit) break;
     chunk = 2;
   }
-  if (rr) {  // the exchange started after the last residual update has no consumer: drain it before anything else
+  if (rr || vpdot) {  // the exchange started after the last residual update has no consumer: drain it before anything else
     if ((rc = halo_wait(comm))) return rc;  // touches those ghost planes
   }
   const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;

@@ -648,6 +648,7 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->d_hist_alloc);
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
+  (void)hipFree(pde->v_gc0);
   (void)hipFree(pde->v_seg);
   (void)hipFree(pde->v_segmask);
   (void)hipFree(pde->v_seg_tiled);
@@ -1022,6 +1023,8 @@ extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {
 }
 
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
+extern "C" int beat_pde_fused_dist_pass(const beat_pde* pde) { return (pde != nullptr && pde->v_gc0_valid && pde->v_pdot_dist) ? 1 : 0; }
+
 extern "C" int beat_pde_set_single_reduction(beat_pde* pde, int on) {
   BEAT_REQUIRE(pde != nullptr && on >= -1 && on <= 1, "bad argument");
   pde->single_reduction = on;

@@ -89,6 +89,12 @@ struct beat_pde {
   const double* v_stiff = nullptr;
   double* v_A = nullptr;
   double* v_dinv = nullptr;
+  // a slab with live neighbours: the centre coefficients of the neighbours' boundary planes ([0, plane): below, [plane, 2 plane):
+  // above), exchanged by beat_pde_solve_dist when v_gc0_valid is false (the operator changed) -- what the fused tile pass needs to
+  // form the search direction on the ghost planes (beat_vtl_pdot_part)
+  double* v_gc0 = nullptr;
+  bool v_gc0_valid = false;
+  bool v_pdot_dist = false;  // all ranks of the decomposition can run the fused tile pass (agreed when v_gc0 is refreshed)
   int64_t v_ld = 0;
   int* v_seg = nullptr;        // device: indices of the 64-node segments that hold tissue nodes (ascending)
   std::vector<int> h_seg;      // host copy (sub-ranges are located by binary search)
@@ -157,6 +163,9 @@ void beat_vtl_destroy(beat_pde* pde);
 bool beat_vtl_available(const beat_pde* pde);
 int beat_vtl_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 bool beat_vtl_parts_available(const beat_pde* pde);
+bool beat_vtl_pdot_dist_available(const beat_pde* pde);
+int beat_vtl_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q,
+                       int first, int part);
 int beat_vtl_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 bool beat_vtl_pdot_available(const beat_pde* pde);
 bool beat_vtl_rhs_available(const beat_pde* pde);

@@ -754,6 +754,7 @@ static unsigned var_vec_grid(const beat_pde* pde) {
 }
 
 int beat_var_form_A(beat_pde* pde) {
+  pde->v_gc0_valid = false;  // the neighbours' centre coefficients change with theta dt as well
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   BEAT_KERNEL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
                      pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, pde->v_A, pde->v_dinv);
@@ -775,7 +776,8 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
   p->v_stiff = dev_stiff;
   p->v_ld = ld;
   if (hipMalloc(&p->v_A, sizeof(double) * 15 * (size_t)ld) != hipSuccess ||
-      hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess) {
+      hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess ||
+      (!(z_lo_phys && z_hi_phys) && hipMalloc(&p->v_gc0, sizeof(double) * 2 * (size_t)(n[0] * n[1])) != hipSuccess)) {
     beat_pde_destroy(p);
     beat_set_error("out of device memory for the %lld-node coefficient rows", (long long)ld);
     return BEAT_EHIP;

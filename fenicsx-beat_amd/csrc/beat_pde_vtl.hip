@@ -67,7 +67,12 @@ struct VtlArgs {
   // p = D^-1 r + beta p_old, D^-1 = 1 / the row's own centre coefficient -- and stored to pnew
   const double* r;
   double* pnew;
-  int first;               // iteration 0: p = D^-1 r (beta = 0, p_old not read)
+  int first;               // bit 0: iteration 0, p = D^-1 r (beta = 0, p_old not read); bit 1: keep the direction on the lower ghost plane
+  // PDOT on a slab with live neighbours (beat_vtl_pdot_part): the centre coefficients of the NEIGHBOURS' boundary planes (one
+  // plane each, exchanged once per operator) -- the direction is formed on the ghost planes too, from the exchanged r, the
+  // previous direction kept there and these, and stored there, so that p itself is never exchanged.  nullptr: a physical face.
+  const double* gc0_lo;
+  const double* gc0_hi;
   // RHS (mode 2, the right-hand side of a step in residual form, what var_rhs_kernel computes): x = v_, r = the guess
   // increment e (or nullptr), t = K v_ (from a plain tile pass over the stiffness rows), y = the residual r0 - A e with
   // r0 = dt (stim - K v_), pnew = D^-1 r; per-tile partials of b.b (b = A v_ + r0), r.z and r.r
@@ -111,8 +116,9 @@ __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsi
 // forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
 // 13 +x+y+z; the backward slot k+1 pairs with the forward slot k.  F[] below holds them in that order.
 template <int RY, bool DYN, int MODE>
-__global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(VtlArgs a_) {
-  constexpr bool PDOT = MODE == 1, RHS = MODE == 2;
+__global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(VtlArgs a_) {  // MODE: 0 q = A p | 1 PDOT | 2 RHS | 3 PDOT, live neighbours
+  constexpr bool PDOT = MODE == 1 || MODE == 3, RHS = MODE == 2;
+  constexpr bool GHOST = MODE == 3;  // PDOT on a slab with live neighbours: the direction is formed and kept on the ghost planes too
   constexpr int NPE = RHS ? 4 : 2;  // halo entries that are rows of a vector: p below / above (RHS: v_ below / above, e below / above)
   // one LDS array: p of plane z+1 for rows y0-1 .. y0+RY of the tile (two buffers), slots 3, 7, 9, 13 of plane z for rows
   // y0-1 .. y0+RY-2 (two buffers), and a row per wave that absorbs the stores of a wave without a (second) halo load
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
     // expression of var_pupdate_oop_kernel, so the same bits) -- wherever the SpMV needs it: the own row, the rows above and
     // below, the halo lanes.  Redundant arithmetic on the halo, no second pass over r, p_old and 1/diag (32 B/node).
     const double beta = PDOT ? a.st[BETA] : 0.0;
-    const bool first = PDOT && a.first != 0;
+    const bool first = PDOT && (a.first & 1) != 0;
     struct Trio {
       double r, q, c0;
     };
@@ -205,6 +211,17 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       const double pv = first ? zz : fma(beta, t.q, zz);
       return t.c0 != 0.0 ? pv : 0.0;  // (a lane that loaded nothing: c0 = 0)
     };
+    // centre coefficients of plane z: slot 0 of the rows, or the neighbour's plane on a ghost plane
+    auto c0_of = [&](int z) -> const double* {
+      if constexpr (GHOST) {
+        KArgPtr kg = ka;
+        asm volatile("" : "+s"(kg));
+        const VtlArgs& ag = *(const VtlArgs*)kg;
+        return z < 0 ? ag.gc0_lo : (z >= a.nz ? ag.gc0_hi : A + (int64_t)z * a.plane);
+      } else {
+        return A + (int64_t)z * a.plane;
+      }
+    };
     auto ld3 = [&](u64 mk, int z, unsigned ro) -> Trio {
       const unsigned off = lane_off(mk, ro);
       KArgPtr kr = ka;
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       Trio t;
       t.r = vtl_buf_load(Rr + (int64_t)z * a.plane, pbytes, off);
       t.q = vtl_buf_load(X + (int64_t)z * a.plane, pbytes, first ? VTL_OOB : off);
-      t.c0 = vtl_buf_load(A + (int64_t)z * a.plane, pbytes, off);
+      t.c0 = vtl_buf_load(c0_of(z), pbytes, off);
       return t;
     };
     // (a ghost plane of a physical face: its mask is empty, nothing is loaded, p = 0; the decomposed solve does not come here)
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
         const unsigned off = lane_off(m, ro), offp = is_p ? off : VTL_OOB;
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, off);
         t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, first ? VTL_OOB : offp);
-        t.c0 = vtl_buf_load(A + (int64_t)zz * a.plane, pbytes, offp);
+        t.c0 = vtl_buf_load(c0_of(zz), pbytes, offp);
       } else if constexpr (RHS) {
         KArgPtr kr = ka;
         asm volatile("" : "+s"(kr));
@@ -301,11 +318,20 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       const u64 mo = MASK[mo_own + zb - 1], md = MASK[mo_dn + zb - 1];
       Pm = ldpv(mo, zb - 1, roff);
       if constexpr (PDOT) {
+
         const Trio t0 = ld3(M0, zb, roff);
         P0 = form(t0);
         C0keep = t0.c0;
-        // this tile's first plane of the new direction (the later ones are stored as they are formed, one plane ahead)
-        vtl_buf_store(a.pnew + (int64_t)zb * a.plane, pbytes, (M0 & lanebit & out_lanes) ? roff * 8u : VTL_OOB, P0);
+        // this tile's first plane of the new direction (the later ones are stored as they are formed, one plane ahead) and -- on
+        // plane 0 of a slab with a live lower neighbour, bit 1 of `first` -- the direction on the ghost plane below it, kept for
+        // the next iteration: the two planes as ONE buffer (a second descriptor costs the SGPRs the kernel does not have)
+        if constexpr (GHOST) {
+          double* const two = a.pnew + (int64_t)(zb - 1) * a.plane;
+          vtl_buf_store(two, 2u * pbytes, (zb == 0 && (a.first & 2) && (mo & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pm);
+          vtl_buf_store(two, 2u * pbytes, (M0 & lanebit & out_lanes) ? pbytes + roff * 8u : VTL_OOB, P0);
+        } else {
+          vtl_buf_store(a.pnew + (int64_t)zb * a.plane, pbytes, (M0 & lanebit & out_lanes) ? roff * 8u : VTL_OOB, P0);
+        }
       } else {
         P0 = ldp(M0, zb, roff);
       }
@@ -379,7 +405,9 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
         Pp = form(Tn);  // p of plane z + 1, from what step z - 1 requested
         F[0] = C0keep;
         C0keep = Tn.c0;
-        vtl_buf_store(az.pnew + (int64_t)(z + 1) * a.plane, pbytes, (z + 1 < ze && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
+        // (the plane above a slab with a live upper neighbour: the direction on the ghost plane, kept for the next iteration)
+        const bool keep = z + 1 < ze || (GHOST && z + 1 == a.nz && az.gc0_hi != nullptr);
+        vtl_buf_store(az.pnew + (int64_t)(z + 1) * a.plane, pbytes, (keep && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
       }
       const double Ea = halo_value(ea, Ean), Eb = TWO ? halo_value(eb, Ebn) : 0.0;
       const double Ep = En, Kv = Kvn;
@@ -862,12 +890,17 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   a.next = d->d_xcd_first + 27;
   a.r = rhs2 ? rhs->e : dev_r;
   a.pnew = dev_p_new;
-  a.first = first;
+  a.first = first ? 1 : 0;
+  if (pdot && pde->v_gc0 != nullptr) {  // a slab with live neighbours: the direction is formed and kept on the ghost planes too
+    a.gc0_lo = f.z_lo_phys ? nullptr : pde->v_gc0;
+    a.gc0_hi = f.z_hi_phys ? nullptr : pde->v_gc0 + f.plane;
+    if (a.gc0_lo != nullptr) a.first |= 2;
+  }
   auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
   if (rhs2) {
     launch(vtl_spmv_kernel<8, false, 2>, 8);
   } else if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
-    launch(vtl_spmv_kernel<8, false, 1>, 8);
+    (a.gc0_lo != nullptr || a.gc0_hi != nullptr) ? launch(vtl_spmv_kernel<8, false, 3>, 8) : launch(vtl_spmv_kernel<8, false, 1>, 8);
   } else if (d->ry == 8) {
     d->dyn ? launch(vtl_spmv_kernel<8, true, 0>, 8) : launch(vtl_spmv_kernel<8, false, 0>, 8);
   } else {
@@ -911,6 +944,28 @@ int beat_vtl_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
     ++two.nstim;
   }
   return vtl_launch(pde, dev_v_prev, dev_r, pde->d_st, nullptr, dev_p, 0, 0, 0, true, 0, &two);
+}
+
+// The fused pass on a slab with live neighbours, in the two parts of the split launches: part 0 = the planes whose stencil
+// needs no ghost plane (enqueue it while the ghost planes of r travel), part 1 = the one or two slab-boundary planes -- which also
+// form and keep the direction on the ghost planes next to them, from the exchanged r, the direction kept there by the previous
+// iteration and the neighbours' centre coefficients (beat_pde::v_gc0) -- and the sum over both parts' tiles.  p is never exchanged.
+bool beat_vtl_pdot_dist_available(const beat_pde* pde) {
+  if (!(beat_vtl_available(pde) && beat_vtl_parts_available(pde)) || (pde->g.z_lo_phys && pde->g.z_hi_phys)) return false;
+  const VtlData* d = (const VtlData*)pde->vtl;
+  static const bool on = [] {  // BEAT_VTL_PDOT_DIST=0: the three-kernel iteration with an exchange of p (A/B runs)
+    const char* e = std::getenv("BEAT_VTL_PDOT_DIST");
+    return !(e && e[0] == '0');
+  }();
+  return on && d->pdot && d->ry == 8 && pde->v_gc0 != nullptr;
+}
+
+int beat_vtl_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q,
+                       int first, int part) {
+  BEAT_REQUIRE(dev_p_old != dev_p_new, "the direction update is out of place");
+  const VtlData* d = (const VtlData*)pde->vtl;
+  if (part == 0) return vtl_launch(pde, dev_p_old, dev_q, dev_st, dev_r, dev_p_new, first, 1, 0, false, 0);
+  return vtl_launch(pde, dev_p_old, dev_q, dev_st, dev_r, dev_p_new, first, 2, d->list_count[1], true, d->list_count[1] + d->list_count[2]);
 }
 
 // the split launches of a decomposed grid: part 0 = the planes that need no ghost plane of p (no reduction), part 1 = the

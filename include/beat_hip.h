@@ -351,6 +351,11 @@ int beat_pde_set_guess_order(beat_pde* pde, int order);
  * Constant-coefficient operators only (per-node rows keep the classic iteration); beat_pde_solve on one rank is not
  * affected.  Same stopping test, iteration counts within one, k + 2 instead of 2 k + 1 all-reduces per solve of k iterations. */
 int beat_pde_set_single_reduction(beat_pde* pde, int on);
+/* 1 when the decomposed solves of this per-node-row operator run the fused tile pass (direction formed while loading, on the
+ * ghost planes too: r is exchanged, p never) -- every rank of the decomposition has to be able to (tiles of 8 rows, a tile list;
+ * agreed by a sum over the ranks when the operator changes; BEAT_VTL_PDOT_DIST=0 switches it off) -- 0 for the three-kernel
+ * iteration with an exchange of p, and before the first decomposed solve. */
+int beat_pde_fused_dist_pass(const beat_pde* pde);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);
 /* the last recorded increment, the guess increment prepared for the next solve, and the number of solves on record

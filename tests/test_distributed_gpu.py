@@ -222,8 +222,9 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, 
         ops.flush_pending()
         ctx.synchronize()
         out[key] = (fx.numpy().copy(), res, fx2.numpy().copy(), res2)
+        fused[key] = bool(ctx.lib.beat_pde_fused_dist_pass(ops.handle))
 
-    out = {}
+    out, fused = {}, {}
     solve(hip_ctx, Slab(nz), None, out, "whole")
     tw = _ThreadWorld(world)
     errors = []
@@ -249,6 +250,14 @@ def test_slabs_in_threads_match_single_slab_solve(hip_ctx, per_node, world, nz, 
     assert all(out[r][1].converged_reason > 0 for r in range(world))
     np.testing.assert_allclose(x_parts, x_whole, rtol=0, atol=1e-9 * np.abs(x_whole).max())
     np.testing.assert_array_equal(x_defer, x_parts)
+    # per-node rows through the library loop: the fused tile pass on every rank or on none (the ranks agree: a slab without a tissue
+    # node has no tile list) -- on all of them where every slab holds tissue (19+ planes over 2-8 ranks around a sphere of radius 15)
+    agreed = {fused[r] for r in range(world)}
+    assert len(agreed) == 1 and not fused["whole"]
+    if per_node and loop == "lib" and nz >= 19:
+        assert agreed == {True}
+    if not per_node or loop == "stage":
+        assert agreed == {False}
 
 
 @pytest.mark.parametrize("rtol", [1e-8, 1e-12])
@@ -942,10 +951,9 @@ def test_library_loop_with_rccl_self_neighbours_matches_stage_loop(hip_ctx, per_
         (xs, rs, xs2, _), (xl, rl, xl2, rl2) = out["stage"], out["lib"]
         assert rl.converged_reason > 0 and 3 < rl.iterations < 60 and rl.iterations == rl2.iterations
         assert abs(rl.iterations - rs.iterations) <= 1
-        if per_node:  # same kernels in the same order
-            np.testing.assert_array_equal(xl, xs)
-        else:         # the library loop runs the register-row kernels (ghost planes of r travel, p is formed on them)
-            np.testing.assert_allclose(xl, xs, rtol=0, atol=1e-9 * np.abs(xs).max())
+        # the library loop runs the fused passes -- register-row kernels on constant coefficients, the tile pass on per-node rows
+        # (round 4) --: ghost planes of r travel, p is formed on them; the stage loop the classic iteration with an exchange of p
+        np.testing.assert_allclose(xl, xs, rtol=0, atol=1e-9 * np.abs(xs).max())
         np.testing.assert_array_equal(xl2, xl)
         np.testing.assert_array_equal(xs2, xs)
         # the periodic operator really couples the two faces: the solution differs from the Neumann-faced one

@@ -87,6 +87,25 @@ def main():
             ops.spmv_boundary(ops.p)
 
         timeit("spmv in two parts (+reduce)", two_parts, 136)
+        # the decomposed solve itself: the rank is its own neighbour on both faces (mailbox transport), so the slab is periodic in z;
+        # BEAT_VTL_PDOT_DIST=0 runs the three-kernel iteration with an exchange of p, the default the fused tile pass
+        from beat._engine import DiffusionSolver, LibComm
+
+        class Interior:
+            rank, world, lo_phys, hi_phys, z0, z1, nz = 0, 1, False, False, 0, nn, nn
+
+        comm = LibComm(ctx, Interior(), transport="ipc", peers=(0, 0), plane_doubles=nn * nn)
+        solver = DiffusionSolver(ops, Interior(), force_distributed=True, libcomm=comm)
+        x = ops.new_field()
+        res = None
+
+        def solve_dist():
+            nonlocal res
+            res = solver.solve(v, [], [], x, rtol=1e-8, atol=1e-50, max_it=500)
+
+        timeit("decomposed theta-step solve rtol 1e-8", solve_dist, 0)
+        print("iterations", res.iterations, "reason", res.converged_reason, "fused tile pass:", bool(ctx.lib.beat_pde_fused_dist_pass(ops.handle)))
+        comm.close()
         return
     timeit("rhs (A and K rows, +reduce)", lambda: ops.rhs(v, [], [], v), 264)
     x = ops.new_field()
