@@ -7,6 +7,7 @@
 #include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -152,9 +153,21 @@ bool run_hipcc(const JitState& s, const std::string& src, const std::string& out
   const int rc = posix_spawnp(&pid, s.hipcc.c_str(), &fa, nullptr, argv.data(), environ);
   posix_spawn_file_actions_destroy(&fa);
   if (rc != 0) return false;
+  // a compile takes seconds; one that has not finished after BEAT_JIT_TIMEOUT_S (default 300) is killed: a step must not hang on it
+  const char* te = std::getenv("BEAT_JIT_TIMEOUT_S");
+  const double limit = te ? std::max(1.0, std::atof(te)) : 300.0;
   int status = 0;
-  while (::waitpid(pid, &status, 0) < 0) {
-    if (errno != EINTR) return false;
+  for (double waited = 0.0;; waited += 0.02) {
+    const pid_t w = ::waitpid(pid, &status, WNOHANG);
+    if (w == pid) break;
+    if (w < 0 && errno != EINTR) return false;
+    if (waited > limit) {
+      ::kill(pid, SIGKILL);
+      while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+      }
+      return false;
+    }
+    ::usleep(20000);
   }
   return WIFEXITED(status) && WEXITSTATUS(status) == 0;
 }

@@ -120,7 +120,7 @@ int beat_ode_step_rows(beat_ctx* ctx, int model_id, double* dev_states, int64_t 
                        beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending);
 /* Run-time compilation behind beat_ode_step_rows: the kernel instance whose varying parameter indices are compile-time
  * constants is written, compiled by hipcc for gfx950 and cached at first use (csrc/beat_ode_jit.h; environment: BEAT_JIT=0 off,
- * BEAT_JIT_CACHE directory, BEAT_JIT_SRC kernel sources, BEAT_HIPCC compiler, BEAT_JIT_VERBOSE).  host_out[4] = kernels loaded
+ * BEAT_JIT_CACHE directory, BEAT_JIT_SRC kernel sources, BEAT_HIPCC compiler, BEAT_JIT_TIMEOUT_S, BEAT_JIT_VERBOSE).  host_out[4] = kernels loaded
  * in this process, hipcc runs, code objects taken from the cache directory, failures; returns 1 where it is usable (sources,
  * compiler, cache directory found), 0 where beat_ode_step_rows runs its run-time-index kernel instead. */
 int beat_ode_jit_stats(long long* host_out);
