@@ -34,7 +34,7 @@ const char* const kFlags[] = {"--genco", "--offload-arch=gfx950", "-O3", "-std=c
 struct JitState {
   std::mutex m;
   bool init = false, usable = false, verbose = false;
-  std::string srcdir, cachedir, hipcc, srchash, why;
+  std::string srcdir, cachedir, hipcc, srchash, why, extra;
   std::map<std::string, hipFunction_t> fn;  // key@device
   std::set<std::string> failed;
   std::vector<hipModule_t> modules;
@@ -128,6 +128,10 @@ void init_locked(JitState& s) {
   unsigned long long h = fnv("beat-jit-1");
   for (const std::string& n : names) h = fnv(read_file(s.srcdir + "/" + n), fnv(n, h));
   for (const char* f : kFlags) h = fnv(f, h);
+  if (const char* x = std::getenv("BEAT_JIT_EXTRA_FLAGS")) {  // experiments with the compiler (tools/jit_flags_ab.sh): part of the cache key
+    s.extra = x;
+    h = fnv(s.extra, h);
+  }
   char buf[32];
   std::snprintf(buf, sizeof buf, "%016llx", h);
   s.srchash = buf;
@@ -138,6 +142,10 @@ void init_locked(JitState& s) {
 bool run_hipcc(const JitState& s, const std::string& src, const std::string& out, const std::string& log) {
   std::vector<std::string> a{s.hipcc};
   for (const char* f : kFlags) a.push_back(f);
+  {
+    std::istringstream extra(s.extra);
+    for (std::string f; extra >> f;) a.push_back(f);
+  }
   a.push_back("-I" + s.srcdir);
   a.push_back(src);
   a.push_back("-o");
