@@ -1091,6 +1091,31 @@ def test_sparse_rows_without_a_compiler_run_on_the_run_time_index_kernel(tmp_pat
     assert run.stderr.count("run-time compilation unavailable") == 1 and "using the run-time-index kernel" in run.stderr
 
 
+def test_three_processes_compile_the_same_instance_into_one_cache_directory(tmp_path):
+    """What the ranks of a decomposed run do at their first step with per-node parameters: three processes, one empty cache directory,
+    the same kernel instance wanted by all at once (tests/_jit_race_script.py).  Each compiles under a name of its own and renames the
+    object into place -- or finds the one another process put there -- and every one ends with a loaded instance, no failure, and the
+    all-rows kernel's values; the directory holds one code object afterwards and no leftovers."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    cache = tmp_path / "cache"
+    env = dict(os.environ, BEAT_JIT_CACHE=str(cache))
+    for k in ("BEAT_JIT", "BEAT_PARAM_SPARSE", "BEAT_PARAM_CLASSES"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, str(root / "tests" / "_jit_race_script.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=root, env=env) for _ in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-1500:] + se[-3000:]
+        assert "jit-race ok" in so
+    files = sorted(f.name for f in cache.iterdir())
+    assert sum(f.endswith(".hsaco") for f in files) == 1 and not any(f.endswith((".tmp", ".hip")) for f in files), files
+
+
 def test_parameter_route_follows_the_parameters_through_every_change_of_kind():
     """(round-3 review) The route a step takes -- uniform vector, per-node rows, parameter classes -- is re-derived whenever
     the KIND of ``parameters`` changes: a classified (P, N) array, then a vector, then the SAME array again must classify
