@@ -1017,7 +1017,7 @@ def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
     import beat
     from beat import _hip
     from beat import grid as g
-    from beat.models import torord, tp06
+    from beat.models import torord, torord_land, tp06
 
     lib = _hip.load()
     stats = (C.c_longlong * 4)()
@@ -1054,7 +1054,7 @@ def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
     other = lambda p, xs: p * (0.7 + 0.25 * np.sin(3.0 * xs[:, 0]) * np.cos(2.0 * xs[:, 1]))  # noqa: E731
     layers = lambda p, xs: np.floor(3.0 * xs[:, 2] / 0.6001)  # noqa: E731  -- 0, 1, 2 through the wall
     cases = [(tp06, "V", {"g_CaL": smooth}), (torord, "v", {"GKr_b": smooth}), (tp06, "V", {"g_CaL": smooth, "g_Kr": other}),
-             (torord, "v", {"celltype": layers, "GKs_b": other})]
+             (torord, "v", {"celltype": layers, "GKs_b": other}), (torord_land, "v", {"Tref": smooth, "GKr_b": other})]
     loaded_before = stats[0]
     for model, vname, fields in cases:
         a, sparse_a = run(model, vname, fields, "jit")
