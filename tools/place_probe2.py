@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--trials", type=int, default=6)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--vary", default="all", choices=["all", "ops", "states"], help="which of the two is released and allocated again between "
+                    "trials: the operator with its work / guess fields, the state array, or both")
     args = ap.parse_args()
     import torch
 
@@ -41,14 +43,26 @@ def main():
     slab = Slab(n, 0, 1)
     mass_tab, stiff_tab = _stencil.stencil_tables(3, (bench.H,) * 3, bench.conductivity())
     dummy_gib = [0, 1, 3, 0, 7, 2, 5, 0]
+    ops = states = solver = None
     for trial in range(args.trials):
         gib = dummy_gib[trial % len(dummy_gib)]
         dummy = torch.empty(gib * (1 << 27) + 4096 * trial, dtype=torch.float64, device=ctx.device) if gib else None
-        ops = HipOps(ctx, (n, n, n), True, True, mass_tab, stiff_tab)
-        ops.set_guess_order(-1)
-        ops.set_timestep(bench.C_M, bench.THETA, bench.DT)
-        solver = DiffusionSolver(ops, slab)
-        states = StateArray(ctx, len(ic), plane * n, plane)
+        if ops is None or args.vary in ("all", "ops"):
+            del solver, ops
+            gc.collect()
+            torch.cuda.empty_cache()
+            ops = HipOps(ctx, (n, n, n), True, True, mass_tab, stiff_tab)
+            ops.set_guess_order(-1)
+            ops.set_timestep(bench.C_M, bench.THETA, bench.DT)
+            solver = DiffusionSolver(ops, slab)
+        else:
+            ops.flush_pending()
+            ops.guess_reset()
+        if states is None or args.vary in ("all", "states"):
+            del states
+            gc.collect()
+            torch.cuda.empty_cache()
+            states = StateArray(ctx, len(ic), plane * n, plane)
         bench.init_states(ctx, states, ic, v_index, n, slab, 1234, n)
         v_field = states.row_field(v_index)
         t = 0.0
@@ -73,7 +87,7 @@ def main():
         torch.cuda.synchronize()
         print(f"trial {trial}: dummy {gib} GiB  states @ {states.ptr.value:#x}  work @ {ops.ring[0].ptr.value:#x}  "
               f"ode {np.mean(ode):.3f} ms (min {np.min(ode):.3f} max {np.max(ode):.3f})  pde {np.mean(pde):.3f} ms", flush=True)
-        del v_field, solver, ops, states, dummy
+        del v_field, dummy
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
