@@ -624,7 +624,13 @@ def main():
         guess_fields, guess_orders = [], []
         iters, pend_counts = [], []  # pend: search directions the timed ionic launches applied for the previous solve
 
+        gap_us = float(os.environ.get("BEAT_BENCH_GAP_US", "0"))  # experiment: extra host time between two steps (GPU idle)
+
         def step(t, i=None):
+            if gap_us > 0.0:
+                until = time.perf_counter() + gap_us * 1e-6
+                while time.perf_counter() < until:
+                    pass
             # the previous solve left its last x += sum alpha_j p_j to this step's ionic kernel (deferred-x PCG)
             pend = ops.pending
             if i is not None:

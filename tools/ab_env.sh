@@ -8,6 +8,6 @@ for i in $(seq 1 $REPS); do
     env $NAME=$v python3 bench.py --no-front --cpu-sample 0 "$@" 2>/dev/null | python3 -c "
 import sys, json
 r = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$NAME=$v', round(r['ms_per_step'], 3), 'ode', round(r['config']['ode_ms'], 3), 'pde', round(r['config']['pde_ms'], 3), 'k', r['config']['pcg_iterations_per_step'], 'sclk', (r['config'].get('clocks') or {}).get('sclk_mhz'), 'W', (r['config'].get('clocks') or {}).get('power_w'), 'Tj', (r['config'].get('clocks') or {}).get('junction_c'), flush=True)"
+print('$NAME=$v', round(r['ms_per_step'], 3), 'ode', round(r['config']['ode_ms'], 3), 'pde', round(r['config']['pde_ms'], 3), 'host', round(r['ms_per_step'] - r['config']['ode_ms'] - r['config']['pde_ms'], 3), 'k', r['config']['pcg_iterations_per_step'], 'sclk', (r['config'].get('clocks') or {}).get('sclk_mhz'), 'W', (r['config'].get('clocks') or {}).get('power_w'), 'Tj', (r['config'].get('clocks') or {}).get('junction_c'), flush=True)"
   done
 done
