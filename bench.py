@@ -738,6 +738,43 @@ def main():
             "clocks": fr["clocks"],
         }
 
+    # The headline regime once more through MonodomainSplittingSolver.solve -- the reference's own driver loop
+    # (src/beat/monodomain_solver.py:53-66) -- which hands the steps of a one-rank grid to the library's loop (beat_split_steps_big):
+    # same kernels and values as the step() calls above, without Python between the steps (the device idles 0.15-0.18 ms per step
+    # there, and the ionic kernel that follows an idle gap runs slower: DESIGN.md 7).  State re-initialised, same warm-up, same K steps.
+    batched = None
+    if world == 1 and use_api and finite and not force_dist and os.environ.get("BEAT_BENCH_BATCHED", "1") == "1":
+        saved = (api_solver.monitor, pde.monitor, ode._dev.monitor)
+        api_solver.monitor = pde.monitor = ode._dev.monitor = beat.telemetry.NullMonitor()
+        try:
+            if api_solver._can_batch(None):
+                progress("the same steps through MonodomainSplittingSolver.solve")
+                ops.flush_pending()
+                init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
+                ops.guess_reset()
+                api_solver.solve((0.0, args.warmup * DT), DT)
+                api_solver.batch_ode_ms = [] if os.environ.get("BEAT_BENCH_BATCHED_EVENTS", "1") == "1" else None
+                barrier()
+                clocks.start()
+                tic = time.perf_counter()
+                api_solver.solve((args.warmup * DT, (args.warmup + args.steps) * DT), DT)
+                ops.flush_pending()
+                barrier()
+                wall_b = time.perf_counter() - tic
+                clocks.stop()
+                bmin, bmax = v_field.minmax()
+                if (api_solver.batch_ode_ms is None or len(api_solver.batch_ode_ms) == args.steps) and np.isfinite(bmin) and np.isfinite(bmax):
+                    batched = {"what": f"MonodomainSplittingSolver.solve over the same {args.steps} steps after the same {args.warmup} warm-up steps "
+                                       "(state re-initialised): the library's own step loop, no Python between the steps",
+                               "value": n * n * nz_glob * args.steps / wall_b, "unit": "node-updates/s", "ms_per_step": wall_b / args.steps * 1e3,
+                               "pcg_iterations_last_step": int(pde.ksp.iterations),
+                               "ode_ms": float(np.mean(api_solver.batch_ode_ms)) if api_solver.batch_ode_ms else None,
+                               "v_min": bmin, "v_max": bmax, "clocks": clocks.summary()}
+                    progress(f"batched: {batched['ms_per_step']:.3f} ms/step")
+                api_solver.batch_ode_ms = None
+        finally:
+            api_solver.monitor, pde.monitor, ode._dev.monitor = saved
+
     # N > 1: what each rank did, and what the communication inside the solve costs.  Profiled on a few EXTRA steps after
     # the timed regions (timing events around every exchange and all-reduce are not free): ms per step the ghost-plane
     # transfers took on their stream, the all-reduces on the compute stream (waiting for the slowest rank included), and
@@ -901,6 +938,7 @@ def main():
             },
         }
         out["developed_front"] = front
+        out["batched_solve"] = batched
         if ranks_info is not None:
             out["ranks"] = ranks_info
             out["config"]["comm"] = comm_info

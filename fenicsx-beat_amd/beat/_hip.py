@@ -96,6 +96,8 @@ SIGNATURES = {
     "beat_pde_small_grid_solve_active": (_int, [_vp]),
     "beat_split_steps": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl,
                                 _int, _vp, _vp, _int, _vp, _vp]),
+    "beat_split_steps_big": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _int, _int,
+                             C.POINTER(KspInfo), C.POINTER(_int), C.POINTER(C.c_float)]),
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
     "beat_pde_set_single_reduction": (_int, [_vp, _int]),
     "beat_pde_fused_dist_pass": (_int, [_vp]),

@@ -10,6 +10,7 @@ copies per step (steps 2-4, 6, 7 of the reference sequence), none of the traffic
 from __future__ import annotations
 
 import logging
+import os
 from dataclasses import dataclass, field
 from typing import Protocol
 
@@ -78,8 +79,15 @@ class MonodomainSplittingSolver:
             return False
         ode, pde = self.ode, self.pde
         ops = getattr(pde, "_ops", None)
-        if ops is None or not hasattr(ops, "small_active") or not ops.small_active():
+        if ops is None or not hasattr(ops, "small_active"):
             return False
+        if not ops.small_active():
+            # a grid of any size on one rank: the step loop inside the library (beat_split_steps_big); no probe rows there
+            # (the potential is complete only after the next ionic launch or a flush)
+            diff = getattr(pde, "_diffusion", None)
+            one_rank = diff is not None and getattr(diff, "dist", None) is None and getattr(diff, "libcomm", None) is None
+            if not (one_rank and recorder is None and hasattr(ops, "work") and os.environ.get("BEAT_BATCH_BIG", "1") != "0"):
+                return False
         if not all(type(m) is NullMonitor for m in (self.monitor, pde.monitor, getattr(ode._dev, "monitor", NullMonitor()))):
             return False  # someone wants per-step timings / KSP records
         if any(getattr(s, "general", None) is not None or hasattr(s, "cellfun") for s in pde._stimuli):
@@ -108,6 +116,9 @@ class MonodomainSplittingSolver:
         hp, npar, _, _ = dev._param_args()
         w_ptrs = (C.c_void_p * max(1, len(stims)))(*[s.field.ptr for s in stims])
         done = 0
+        if not ops.small_active():
+            self._batched_steps_big(steps, stims, w_ptrs, hp, npar, (rtol, atol, max_it))
+            done = len(steps)
         while done < len(steps):
             nb = min(len(steps) - done, _hip.MAX_BATCH)
             probe = (None, None, 0, None)
@@ -136,6 +147,60 @@ class MonodomainSplittingSolver:
             pde.ksp = KspResult(last.iterations, last.residual_norm, last.converged_reason, last.rhs_norm)
             pde._check_converged()
             done += nb
+        ode._pending_ops = ops
+        for f in (pde.state, pde.v_, ode.v_ode):
+            f.alias_to(row, sync=ops.flush_pending)
+        ode._aliases = [pde.state, pde.v_, ode.v_ode]
+
+    def _batched_steps_big(self, steps, stims, w_ptrs, hp, npar, tol) -> None:
+        """The steps of a grid too big for the one-launch solve, run by the library's own loop (beat_split_steps_big): per step the
+        ionic launch that applies what the previous solve deferred and the solve in place on the potential row -- what
+        ``_fused_step`` does, without Python between the steps.  ``self.batch_ode_ms`` (a list, if the caller sets one) collects
+        the duration of every ionic launch."""
+        import ctypes as C
+
+        from . import _hip
+        from ._engine import KspResult
+
+        ode, pde = self.ode, self.pde
+        ops, dev, row = pde._ops, ode._dev, ode._v_row
+        theta_pde = pde.parameters["theta"]
+        rtol, atol, max_it = tol
+        # what an earlier deferred solve left for the next ionic launch: applied by the first launch of the batch if it belongs to
+        # this row, flushed otherwise (ops.flush_pending was called by _batched_steps: nothing is pending here)
+        pending_in = 0
+        times = getattr(self, "batch_ode_ms", None)
+        done = 0
+        while done < len(steps):
+            nb = min(len(steps) - done, _hip.MAX_BATCH)
+            chunk = steps[done : done + nb]
+            t_start = np.ascontiguousarray([a for a, _ in chunk], dtype=np.float64)
+            dts = np.ascontiguousarray([self.theta * (b - a) for a, b in chunk], dtype=np.float64)
+            amps = np.zeros((nb, max(1, len(stims))))
+            for k, (a, b) in enumerate(chunk):  # the stimulus expressions are evaluated at t0 + theta dt, as step() does
+                pde.time.value = a + theta_pde * (b - a)
+                for j, s in enumerate(stims):
+                    amps[k, j] = s.amplitude()
+            infos = (_hip.KspInfo * nb)()
+            pend = (C.c_int * 2)()
+            ode_ms = (C.c_float * nb)() if times is not None else None
+            ops.st_ptr_for_flush = None
+            rc = dev.ctx.lib.beat_split_steps_big(
+                dev.ctx.handle, dev.model.model_id, dev.states.ptr, dev.n, dev.states.ld, hp, npar, int(ode.v_index), ops.handle,
+                C.c_void_p(ops.work.data_ptr()), nb, t_start.ctypes.data_as(C.c_void_p), dts.ctypes.data_as(C.c_void_p), w_ptrs,
+                amps.ctypes.data_as(C.c_void_p), len(stims), rtol, atol, max_it, pending_in, infos, pend, ode_ms)
+            _hip.check(rc, allow_not_converged=True)
+            if times is not None:
+                times.extend(float(v) for v in ode_ms)
+            pending_in = int(pend[1])
+            ops.pending = (row, int(pend[0]), int(pend[1])) if (pend[1] > 0 or dev.ctx.lib.beat_pde_guess_pending(ops.handle)) else None
+            bad = [i for i in range(nb) if infos[i].converged_reason < 0]
+            last = infos[bad[0]] if bad else infos[nb - 1]
+            pde.ksp = KspResult(last.iterations, last.residual_norm, last.converged_reason, last.rhs_norm)
+            pde._check_converged()
+            done += nb
+            if done < len(steps):
+                ops.pending = None  # the next batch's first ionic launch applies it (pending_in)
         ode._pending_ops = ops
         for f in (pde.state, pde.v_, ode.v_ode):
             f.alias_to(row, sync=ops.flush_pending)

@@ -382,6 +382,69 @@ extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_st
 }
 
 
+// Many split steps of a BIG grid in one call (theta = 1): what a caller's loop of beat_ode_step_pending + beat_pde_solve_ex(defer_flush)
+// does, without the caller between the steps.  The host is on the critical path of a step exactly once -- the convergence check of
+// the solve, after which the next ionic kernel is launched -- and the device idles for as long as that takes; through the Python
+// layers it takes 0.15-0.18 ms per step at 512^3 (1 % of the step) and the ionic kernel that follows an idle gap runs slower on top
+// (DESIGN.md 7).  Here it is a wake-up and a launch.  Same kernels, same arguments, same values as the per-step calls.
+// pending_in: search directions of an earlier deferred solve still to be applied to the potential row (0: none; the guess
+// increment, if one is due, is known to the operator); host_pending[2]: what the LAST solve of the batch left pending, as
+// beat_pde_solve_ex reports it.  host_ode_ms (or NULL): per step, the duration of the ionic launch (HIP events).
+extern "C" int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld, const double* host_params,
+                                    int num_params, int v_index, beat_pde* pde, double* dev_work, int n_steps, const double* host_t0,
+                                    const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                                    double rtol, double atol, int max_it, int pending_in, beat_ksp_info* host_info, int* host_pending,
+                                    float* host_ode_ms) {
+  BEAT_REQUIRE(ctx != nullptr && pde != nullptr && dev_states != nullptr && dev_work != nullptr && host_pending != nullptr &&
+               ((host_t0 != nullptr && host_dt != nullptr) || n_steps == 0), "null argument");
+  BEAT_REQUIRE(pde->ctx == ctx, "operator and states belong to different contexts");
+  BEAT_REQUIRE(n_steps >= 0 && n_steps <= BEAT_MAX_BATCH, "at most %d steps per call, got %d", BEAT_MAX_BATCH, n_steps);
+  BEAT_REQUIRE(pde->n == n, "the operator has %lld nodes, the state array %lld", (long long)pde->n, (long long)n);
+  BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "a slab with live neighbours is stepped through beat_pde_solve_dist");
+  BEAT_REQUIRE(n_stim == 0 || (host_dev_stim_w != nullptr && host_stim_amp != nullptr), "null stimulus arrays");
+  BEAT_REQUIRE(pending_in >= 0 && pending_in <= beat_pde_ring_size(), "pending_in out of range");
+  host_pending[0] = 0;
+  host_pending[1] = pending_in;
+  if (n_steps == 0) return BEAT_OK;
+  const int64_t fld = beat_pde_field_stride(pde);
+  double* v_row = dev_states + (int64_t)v_index * ld;
+  const double* ring0 = dev_work + pde->g.plane + 3 * fld;  // [r, q, z, ring...], each field behind its lower ghost plane
+  std::vector<hipEvent_t> ev;
+  if (host_ode_ms != nullptr) {
+    ev.resize((size_t)2 * n_steps, nullptr);
+    for (hipEvent_t& e : ev) BEAT_HIP_CHECK(hipEventCreate(&e));
+  }
+  int rc = BEAT_OK, worst = BEAT_OK;
+  int count = pending_in;
+  for (int s = 0; s < n_steps && rc == BEAT_OK; ++s) {
+    if (host_ode_ms) BEAT_HIP_CHECK(hipEventRecord(ev[(size_t)2 * s], ctx->stream));
+    rc = beat_ode_step_pending(ctx, model_id, dev_states, n, ld, host_params, num_params, nullptr, 0, host_t0[s], host_dt[s], v_index, nullptr,
+                               pde, ring0, fld, count);
+    if (host_ode_ms) BEAT_HIP_CHECK(hipEventRecord(ev[(size_t)2 * s + 1], ctx->stream));
+    if (rc) break;
+    beat_ksp_info info{};
+    rc = beat_pde_solve_ex(pde, v_row, host_dev_stim_w, host_stim_amp ? host_stim_amp + (size_t)s * n_stim : nullptr, n_stim, v_row, dev_work,
+                           rtol, atol, max_it, 1, &info, host_pending);
+    if (host_info) host_info[s] = info;
+    if (rc == BEAT_ENOTCONV) {  // (the later steps run on its last iterate, as the reference's loop would without ksp_error_if_not_converged)
+      if (worst == BEAT_OK) worst = BEAT_ENOTCONV;
+      rc = BEAT_OK;
+    }
+    count = host_pending[1];
+  }
+  if (host_ode_ms != nullptr) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int s = 0; s < n_steps; ++s) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[(size_t)2 * s], ev[(size_t)2 * s + 1]) != hipSuccess) ms = -1.f;
+      host_ode_ms[s] = ms;
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    (void)hipGetLastError();
+  }
+  return rc ? rc : worst;
+}
+
 // Many split steps of a SMALL grid in one call (theta = 1: ionic step of dt, then the diffusion step of dt in place on
 // the potential row; src/beat/monodomain_solver.py:33-79 run n_steps times): per step one ionic launch, the
 // one-workgroup solve (beat_pde_small.hip) and, optionally, a probe record -- nothing else, in particular no host

@@ -396,6 +396,19 @@ int beat_split_steps(beat_ctx* ctx, int model_id, double* dev_states, int64_t n,
                      const double* host_t0, const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
                      double rtol, double atol, int max_it, const int64_t* host_probe_idx, const double* host_probe_w,
                      int n_probe, double* dev_probe_out, beat_ksp_info* host_info);
+/* The same for a grid of any size on one rank (theta = 1): per step one beat_ode_step_pending (applying what the previous solve
+ * deferred) and one beat_pde_solve_ex(defer_flush = 1) in place on the potential row -- the loop a caller would write
+ * (src/beat/monodomain_solver.py:53-66 calling :33-79), run inside the library so that nothing but the wake-up of the convergence
+ * check and a launch lies between two steps (through Python: 0.15-0.18 ms per step of a 512^3 grid with the device idle).
+ * dev_work: as for beat_pde_solve; pending_in: search directions of an earlier deferred solve still to be applied to the row
+ * (host_pending[1] of that solve, 0 for none); host_pending[2]: what the last solve of the batch left pending (apply it with
+ * the next ionic launch or beat_pde_x_flush); host_info[n_steps]; host_ode_ms[n_steps] or NULL: duration of every ionic launch.
+ * Returns BEAT_ENOTCONV if a solve ran out of iterations (the later steps have run on its last iterate). */
+int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld, const double* host_params,
+                         int num_params, int v_index, beat_pde* pde, double* dev_work, int n_steps, const double* host_t0,
+                         const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                         double rtol, double atol, int max_it, int pending_in, beat_ksp_info* host_info, int* host_pending,
+                         float* host_ode_ms);
 
 int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                       const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,

@@ -1403,6 +1403,68 @@ def test_batched_solve_equals_the_step_loop(order):
     assert not build(beat.telemetry.PerformanceMonitor())._can_batch(None)
 
 
+@pytest.mark.parametrize("order", [2, "auto"])
+def test_batched_solve_of_a_big_grid_equals_the_step_loop(order, monkeypatch):
+    """A grid too big for the one-launch solve (28 611 nodes): MonodomainSplittingSolver.solve hands its steps to the library's own
+    loop (beat_split_steps_big: per step the ionic launch that applies what the previous solve deferred, and the solve in place)
+    -- what step() does without Python between the steps.  Same kernels, same arguments: the states after 40 steps, a second call
+    that continues, the potential seen through pde.state (the deferred update applied on access) and the last KSP record are
+    those of the step() loop BIT FOR BIT, with a fixed guess order and with the adaptive one (chosen per solve in both); the
+    durations of the ionic launches are handed out on request; BEAT_BATCH_BIG=0, a probe recorder or a monitor keep the step loop."""
+    import beat
+    from beat import grid as g
+    from beat.models import tp06
+
+    def build(monitor=None):
+        geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=8.0, Ly=4.0, Lz=2.0, dx=0.2)
+        mesh = geo.mesh
+        time = g.Constant(mesh, 0.0)
+        cond = beat.conductivities.default_conductivities("Niederer")
+        cells = g.locate_entities(mesh, 3, lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+        tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+        I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                               mesh_unit="mm", amplitude=50_000.0, duration=1.0)
+        M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+        C_m = (1.0 * beat.units.ureg("uF/cm**2")).to("uF/mm**2").magnitude
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=C_m, dx=I_s.dZ,
+                                   params={"petsc_options": {"ksp_type": "cg", "ksp_rtol": 1e-10, "ksp_guess_order": order}})
+        ode = beat.odesolver.DolfinODESolver(
+            v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+            init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+            num_states=19, v_index=tp06.state_index("V"))
+        kw = {} if monitor is None else {"monitor": monitor}
+        return beat.MonodomainSplittingSolver(pde=pde, ode=ode, **kw)
+
+    dt, nsteps = 0.05, 40  # the stimulus switches off at t = 1 ms, inside the run
+    a = build()
+    assert a.pde.state.x.array.size > 8192 and not a.pde._ops.small_active() and a._can_batch(None)
+    a.batch_ode_ms = []
+    a.solve((0.0, nsteps * dt), dt)
+    assert len(a.batch_ode_ms) == nsteps and all(ms > 0.0 for ms in a.batch_ode_ms)
+    b = build()
+    t0 = 0.0
+    for i in range(nsteps):
+        b.step((t0, t0 + dt))
+        t0 = t0 + dt
+    assert b.ode.values[17].max() > 0.0
+    np.testing.assert_array_equal(np.asarray(a.pde.state.x.array), np.asarray(b.pde.state.x.array))  # (applies the deferred update)
+    np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    assert a.pde.ksp.iterations == b.pde.ksp.iterations and a.pde.ksp.converged_reason > 0
+    a.solve((t0, t0 + 7 * dt), dt)  # continues: the update the last solve deferred is applied by the batch's first ionic launch
+    for i in range(7):
+        b.step((t0, t0 + dt))
+        t0 = t0 + dt
+    np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    b.step((t0, t0 + dt))  # and a step() after a batch
+    a.step((t0, t0 + dt))
+    np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    pts = np.array([[0.0, 0.0, 0.0], [2.0, 1.0, 0.5]])
+    assert not a._can_batch(g.ProbeRecorder(a.pde.state, pts, capacity=8))
+    assert not build(beat.telemetry.PerformanceMonitor())._can_batch(None)
+    monkeypatch.setenv("BEAT_BATCH_BIG", "0")
+    assert not a._can_batch(None)
+
+
 def test_split_steps_entry_refuses_what_it_does_not_cover(hip_ctx):
     """beat_split_steps is for grids the one-launch solve takes: a larger grid, an operator switched to the multi-launch
     kernels or more steps than BEAT_MAX_BATCH are refused with an error text (and MonodomainSplittingSolver.solve
