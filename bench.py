@@ -772,6 +772,8 @@ def main():
                                "v_min": bmin, "v_max": bmax, "clocks": clocks.summary()}
                     progress(f"batched: {batched['ms_per_step']:.3f} ms/step")
                 api_solver.batch_ode_ms = None
+        except Exception as exc:  # noqa: BLE001 -- the headline is measured: an extra that fails must not cost the line
+            batched = {"error": repr(exc)}
         finally:
             api_solver.monitor, pde.monitor, ode._dev.monitor = saved
 
