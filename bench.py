@@ -751,7 +751,7 @@ def main():
                 progress("the same steps through MonodomainSplittingSolver.solve")
                 ops.flush_pending()
                 init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
-                ops.guess_reset()
+                ops.set_guess_order(args.guess_order)  # history AND the adaptive order's scores as at the start of the headline run
                 api_solver.solve((0.0, args.warmup * DT), DT)
                 api_solver.batch_ode_ms = [] if os.environ.get("BEAT_BENCH_BATCHED_EVENTS", "1") == "1" else None
                 barrier()
