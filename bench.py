@@ -1068,7 +1068,7 @@ def main():
                 solver.libcomm = alt
                 ops.flush_pending()
                 init_states(ctx, states, ic, v_index, n, slab, 1234, nz_glob)
-                ops.guess_reset()
+                ops.set_guess_order(args.guess_order)  # history and the adaptive order's scores as at the start of the first headline run
                 solver.exchange_halo(v_field)
                 hr = timed_run(0.0, args.warmup, args.steps)
                 hmin, hmax = v_field.minmax()
