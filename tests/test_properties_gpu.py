@@ -526,3 +526,62 @@ def test_decomposed_solves_on_the_slab_of_eight_ranks_meet_the_stopping_test(hip
         assert int(ctx.lib.beat_comm_merged_solves(comm.handle)) == 2
     finally:
         comm.close()
+
+
+def test_sparse_parameter_rows_at_256_cubed_on_the_compiled_instance(hip_ctx):
+    """A smooth gradient in one conductance over 256^3 nodes (a resident DeviceParameters handle: (53, 16.7 M) doubles on the device),
+    four TP06 steps: the route that keeps ONE row and runs the kernel instance compiled for its index (csrc/beat_ode_jit.h) against
+    the route that reads all 53 rows -- same values to 1e-12 at every node, every gate in [0, 1], everything finite -- and the
+    library's counters say an instance was compiled (or found in the cache) and loaded."""
+    import os
+
+    import torch
+
+    from beat.models import tp06
+    from beat.models._base import DeviceParameters
+    from beat.odesolver import _DeviceODE
+    from beat.telemetry import NullMonitor
+
+    ctx = hip_ctx
+    n1 = 256
+    n = n1**3
+    P0 = tp06.init_parameter_values(stim_amplitude=0.0)
+    ic = tp06.init_state_values()
+    vi = tp06.state_index("V")
+    x = (torch.arange(n, device=ctx.device) % n1).to(torch.float64) / n1
+    t = torch.from_numpy(P0).to(ctx.device)[:, None].repeat(1, n)
+    t[tp06.parameter_index("g_CaL")] *= 1.0 - 0.5 * x
+    dp = DeviceParameters.__new__(DeviceParameters)
+    dp.ctx, dp.version, dp._dev = ctx, 1, t
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(5)
+    v0 = -85.0 + 110.0 * torch.rand(n, generator=gen, device=ctx.device, dtype=torch.float64)
+    stats = (C.c_longlong * 4)()
+    assert ctx.lib.beat_ode_jit_stats(stats) == 1
+    loaded_before = int(stats[0])
+    out = {}
+    for route, env in (("compiled", {}), ("rows", {"BEAT_PARAM_SPARSE": "0"})):
+        os.environ.update(env)
+        try:
+            dev = _DeviceODE(ctx, tp06.generalized_rush_larsen, 19, n, n1 * n1, dp, NullMonitor())
+            for k in range(19):
+                dev.states.rows[k].fill_(float(ic[k]))
+            dev.states.rows[vi].copy_(v0)
+            for s in range(4):
+                dev.step(0.01 * s, 0.01, v_index=vi)
+            ctx.synchronize()
+            assert (dev._sparse is not None) == (route == "compiled")
+            out[route] = torch.stack([r.clone() for r in dev.states.rows])
+            del dev
+            torch.cuda.empty_cache()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a, b = out["compiled"], out["rows"]
+    assert bool(torch.isfinite(a).all())
+    scale = torch.clamp(b.abs(), min=1e-9)
+    assert float(((a - b).abs() / scale).max()) < 1e-11
+    gates = [tp06.state_index(nm) for nm in ("Xr1", "Xr2", "Xs", "m", "h", "j", "d", "f", "f2", "fCass", "s", "r")]
+    assert float(a[gates].min()) >= 0.0 and float(a[gates].max()) <= 1.0
+    ctx.lib.beat_ode_jit_stats(stats)
+    assert int(stats[0]) > loaded_before and int(stats[3]) == 0
