@@ -531,8 +531,8 @@ def test_decomposed_solves_on_the_slab_of_eight_ranks_meet_the_stopping_test(hip
 def test_sparse_parameter_rows_at_256_cubed_on_the_compiled_instance(hip_ctx):
     """A smooth gradient in one conductance over 256^3 nodes (a resident DeviceParameters handle: (53, 16.7 M) doubles on the device),
     four TP06 steps: the route that keeps ONE row and runs the kernel instance compiled for its index (csrc/beat_ode_jit.h) against
-    the route that reads all 53 rows -- same values to 1e-12 at every node, every gate in [0, 1], everything finite -- and the
-    library's counters say an instance was compiled (or found in the cache) and loaded."""
+    the route that reads all 53 rows -- same values to 1e-11 at every node, every gate in [0, 1], everything finite -- and the
+    library's counters say an instance is loaded and nothing failed."""
     import os
 
     import torch
@@ -584,4 +584,5 @@ def test_sparse_parameter_rows_at_256_cubed_on_the_compiled_instance(hip_ctx):
     gates = [tp06.state_index(nm) for nm in ("Xr1", "Xr2", "Xs", "m", "h", "j", "d", "f", "f2", "fCass", "s", "r")]
     assert float(a[gates].min()) >= 0.0 and float(a[gates].max()) <= 1.0
     ctx.lib.beat_ode_jit_stats(stats)
-    assert int(stats[0]) > loaded_before and int(stats[3]) == 0
+    # (an earlier test of the same process may have loaded this very instance already: the count need not grow)
+    assert int(stats[0]) >= max(1, loaded_before) and int(stats[3]) == 0
