@@ -422,6 +422,18 @@ def launch_ranks(args, argv) -> int:
             except ValueError:
                 print(lines[0], end="", flush=True)
             return 0
+        if rc != 0 and not timed_out and len(lines) == 1:
+            # ranks that measured and then left non-zero because the decomposed run differs from the undivided one
+            # (`multi_rank_parity.ok` false): a result, not a hang -- relay the line, keep the exit code, no second attempt
+            try:
+                out = json.loads(lines[0])
+            except ValueError:
+                out = None
+            if isinstance(out, dict) and out.get("multi_rank_parity", {}).get("ok") is False:
+                out.setdefault("config", {})["launch"] = {"by": "bench.py --gpus N (self-launched ranks)", "attempts": history}
+                print(json.dumps(out), flush=True)
+                print("[bench launcher] multi-rank parity FAILED (see multi_rank_parity in the line)", file=sys.stderr, flush=True)
+                return rc
         print(f"[bench launcher] attempt {k + 1} failed: rc {rc}" + (", watchdog" if timed_out else "")
               + (f", {len(lines)} stdout lines" if len(lines) != 1 else ""), file=sys.stderr, flush=True)
         if state.get("port_taken") and not timed_out and port_retries < 3:
@@ -524,6 +536,45 @@ def main():
     from beat import _stencil
     from beat._device import Context, StateArray
     from beat._engine import DiffusionSolver, HipOps, Slab
+
+    # N > 1: correctness before speed.  Two small problems (a TP06 slab with constant coefficients, a voxel shell with per-node
+    # rows and two parameter classes) run DECOMPOSED on the N ranks and UNDIVIDED on rank 0 through the public API, 25 split
+    # steps each, on the transport the headline is about to be measured on; the alternatives get the same check before they are
+    # timed (below).  `multi_rank_parity` in the line; a difference above bench_parity.TOLERANCE makes every rank exit non-zero
+    # after the line is printed.  (The reference's parallel CI runs its ACCURACY tests under mpirun -n 2,
+    # .github/workflows/main-mpi.yml:33.)
+    parity, parity_hook = None, None
+    if world > 1 and os.environ.get("BEAT_BENCH_PARITY", "1") == "1":
+        import bench_parity
+
+        class parity_hook:  # noqa: N801 -- installs a transport on the case's own operator, names it, removes it afterwards
+            def __init__(self, name=None, serial=False):
+                self.name, self.serial, self.label, self.alt = name, serial, None, None
+
+            def __call__(self, pde_):
+                from beat._engine import LibComm
+
+                d = pde_._diffusion
+                if self.name is not None:
+                    self.alt = LibComm(pde_._ctx, pde_._mesh.slab, dist, None, self.name, serial=self.serial, plane_doubles=pde_._ops.plane)
+                    self.default, d.libcomm = d.libcomm, self.alt
+                lc = d.libcomm
+                self.label = lc.info()["transport"] if lc is not None else "stage-driven"
+
+            def done(self, pde_):
+                if self.alt is not None:
+                    pde_._ops.flush_pending()
+                    torch.cuda.synchronize()
+                    pde_._diffusion.libcomm = self.default
+                    self.alt.close()
+                    self.alt = None
+
+        tic = time.perf_counter()
+        hk = parity_hook()
+        verdicts = bench_parity.run_cases(dist, rank, world, hook=hk)
+        parity = {hk.label: dict(verdicts, seconds=time.perf_counter() - tic)}
+        progress("multi-rank parity on " + hk.label + ": " + ", ".join(
+            f"{c} {v.get('max_rel_diff', float('nan')):.1e}" for c, v in verdicts.items()) + f" ({time.perf_counter() - tic:.1f} s)")
 
     n = args.n
     nz_glob = args.nz or n
@@ -822,20 +873,40 @@ def main():
             ranks_info = [mine]
         progress("per-rank figures gathered")
 
-    # What a trivial in-place kernel reaches on the very array the ionic kernel walks (every state read once and written
-    # back once: x *= 1.0, bit-preserving), measured here, after the timed regions: the practical ceiling next to which
-    # the 8 TB/s of "roofline.peak" should be read (on this pool: write-only 6.7, read-only 6.1, in-place 5.6, copy 4.8 TB/s;
-    # tools/bw_probe.py)
-    stream_ms = None
+    # What a kernel that only moves bytes reaches on the very array the ionic kernel walks, measured here after the timed regions
+    # with the LIBRARY's own loads and stores (beat_stream_probe, csrc/beat_probe.hip; round 4 used torch's x.mul_(1.0), which
+    # is 1.2 TB/s below what the memory system gives -- profiles/r05_streaming.md): (i) in place over the flat array, every value
+    # read once and written back, the best of three variants (one workgroup per chunk with non-temporal / plain accesses; a
+    # grid-stride loop with four accesses in flight); (ii) the ionic kernel's own access pattern -- all S rows of the (S, ld)
+    # array read at one node index, then written back: S row streams per wavefront.  The second is the ceiling the kernel can be
+    # held against; `roofline.peak` stays the 8 TB/s of the data sheet.
+    stream = None
     flat = states.buf[states.base: states.base + states.S * states.ld]  # the rows with their ghost-plane padding, contiguous
     if finite:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
-        for a, b in evs:
-            a.record()
-            flat.mul_(1.0)
-            b.record()
-        torch.cuda.synchronize()
-        stream_ms = sorted(a.elapsed_time(b) for a, b in evs[1:])[2]
+        def probe_ms(fn, reps=5):
+            fn()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in evs:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            return sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]
+
+        nflat = flat.numel() & ~1
+        fptr = C.c_void_p(flat.data_ptr())
+        variants = {"1 WG per chunk, nt loads + stores": (3, 1, 0), "1 WG per chunk, plain": (0, 1, 0),
+                    "16384 WGs, 4 in flight, nt loads + stores": (3, 4, 16384)}
+        rates = {}
+        for name, (pol, unroll, blocks) in variants.items():
+            ms = probe_ms(lambda: _hip.check(lib.beat_stream_probe(ctx.handle, fptr, nflat, 0, pol, unroll, blocks, 0, 0)))
+            rates[name] = 16.0 * nflat / (ms * 1e-3) / 1e9
+        rows_rate = None
+        if states.S in (1, 4, 8, 19, 45) and n_local % 2 == 0 and states.ld % 2 == 0:
+            ms = probe_ms(lambda: _hip.check(lib.beat_stream_probe(ctx.handle, states.ptr, n_local, 4, 3, 1, 0, states.S, states.ld)))
+            rows_rate = 16.0 * states.S * n_local / (ms * 1e-3) / 1e9
+        torch_ms = probe_ms(lambda: flat.mul_(1.0))
+        stream = {"rates": rates, "rows_rate": rows_rate, "torch_mul_rate": 16.0 * flat.numel() / (torch_ms * 1e-3) / 1e9}
 
     if rank == 0:
         n_total = n * n * nz_glob
@@ -925,11 +996,17 @@ def main():
                     "effective_clock_GHz": valu["gui_cycles_per_xcd"] / (valu["avg_us"] * 1e-6) / 1e9,
                     "source": f"{pmc_source} (rocprofv3 SQ/GRBM pass of this command, committed; kernel time measured live)",
                 },
-                "inplace_stream": None if stream_ms is None else {
-                    "what": "x *= 1.0 over the same state array (torch), 16 B per value, median of 5 launches after the timed region",
-                    "rate": 16.0 * flat.numel() / (stream_ms * 1e-3) / 1e9,
+                "inplace_stream": None if stream is None else {
+                    "what": "beat_stream_probe (the library's own global_load/store_dwordx4 kernels) in place over the same state array, "
+                            "16 B per value, median of 5 launches after the timed region; rate = the best variant",
+                    "rate": max(stream["rates"].values()),
+                    "variants": stream["rates"],
                     "unit": "GB/s",
-                    "kernel_frac_of_it": achieved / (16.0 * flat.numel() / (stream_ms * 1e-3) / 1e9),
+                    "kernel_frac_of_it": achieved / max(stream["rates"].values()),
+                    "rows_pattern": None if stream["rows_rate"] is None else {
+                        "what": f"all {S} rows of the (S, ld) array read at one node index, then written back (non-temporal): the ionic kernel's access pattern",
+                        "rate": stream["rows_rate"], "kernel_frac_of_it": achieved / stream["rows_rate"]},
+                    "torch_mul_rate": stream["torch_mul_rate"],  # x.mul_(1.0): the yardstick of rounds 2-4
                 },
                 "whole_step": {
                     "bytes_per_node_update": 16.0 * S + 16.0 + 88.0 * k_avg,
@@ -985,6 +1062,9 @@ def main():
                 line["transports"] = {main_name: dict(transports[main_name]),
                                       "error": reason or f"an alternative transport made no progress for {deadline:.0f} s; abandoned"}
                 line["alt_failed"] = True
+                if parity is not None:  # what was checked before the alternative that did not return
+                    line["multi_rank_parity"] = dict(dict(parity), tolerance=bench_parity.TOLERANCE, incomplete=True,
+                                                     ok=all(v.get("ok", False) for t in list(parity.values()) for v in t.values() if isinstance(v, dict)))
                 print(json.dumps(line), file=result_stream, flush=True)
             print(f"[bench rank {rank}] alternative transports abandoned" + (f": {reason}" if reason else " at the deadline"),
                   file=sys.stderr, flush=True)
@@ -1003,6 +1083,10 @@ def main():
                 progress(f"alternative transport {label}")
                 if os.environ.get("BEAT_BENCH_TEST_ALT_RAISE") == str(rank):  # tests: an alternative that fails on one rank only
                     raise RuntimeError("simulated failure inside an alternative transport (BEAT_BENCH_TEST_ALT_RAISE)")
+                if parity is not None:  # the same correctness check on this transport, before it is timed
+                    hk = parity_hook(name, serial)
+                    verdicts = bench_parity.run_cases(dist, rank, world, hook=hk)
+                    parity[label] = verdicts
                 alt = LibComm(ctx, slab, dist, None, name, serial=serial, plane_doubles=plane)
                 solver.libcomm = alt
                 ar = timed_run(t_alt, 2, args.steps)
@@ -1116,11 +1200,18 @@ def main():
             if single is not None:
                 single["reference_ms_per_step"] = ref_ms
                 out["single_reduction"] = single
+    parity_failed = parity is not None and any(not v.get("ok", False) for t in parity.values() for v in t.values() if isinstance(v, dict))
     if rank == 0:
+        if parity is not None:
+            out["multi_rank_parity"] = dict(parity, tolerance=bench_parity.TOLERANCE, ok=not parity_failed,
+                                            what="decomposed on the N ranks against undivided on rank 0, public API, 25 split steps: "
+                                                 "max |v_N - v_1| / max |v_1| per case and transport")
         print(json.dumps(out), file=result_stream, flush=True)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:  # (the verdicts are broadcast: every rank sees the same)
+        raise SystemExit(f"multi-rank parity failed: {json.dumps(parity)}")
     if not finite:
         raise SystemExit("non-finite membrane potential after the timed steps")  # every rank sees the same verdict
 

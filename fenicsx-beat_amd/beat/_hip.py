@@ -71,6 +71,7 @@ SIGNATURES = {
     "beat_ode_run": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _i64, _int, _int, _vp, _int, _vp]),
     "beat_copy": (_int, [_vp, _vp, _vp, _i64]),
     "beat_fill": (_int, [_vp, _vp, _dbl, _i64]),
+    "beat_stream_probe": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _i64]),
     "beat_gather": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "beat_scatter": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "beat_interp2": (_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
@@ -97,7 +98,7 @@ SIGNATURES = {
     "beat_split_steps": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl,
                                 _int, _vp, _vp, _int, _vp, _vp]),
     "beat_split_steps_big": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _int, _int,
-                             C.POINTER(KspInfo), C.POINTER(_int), C.POINTER(C.c_float)]),
+                             C.POINTER(KspInfo), C.POINTER(_int), C.POINTER(C.c_float)]),  # host_pending: int[3]
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
     "beat_pde_set_single_reduction": (_int, [_vp, _int]),
     "beat_pde_fused_dist_pass": (_int, [_vp]),

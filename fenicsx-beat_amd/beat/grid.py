@@ -129,6 +129,18 @@ class Comm:
 COMM_WORLD = Comm()
 
 
+class _SelfComm(Comm):
+    """``MPI.COMM_SELF``: this process alone, whatever launcher started it -- a mesh on it is never decomposed (the undivided
+    reference run of bench.py's multi-rank parity block lives on it, on rank 0, beside the decomposed run on COMM_WORLD)."""
+
+    @staticmethod
+    def _dist():
+        return None
+
+
+COMM_SELF = _SelfComm()
+
+
 # ------------------------------------------------------------------------------------------------
 # tiny expression language (the subset of UFL used to describe stimuli and exact solutions)
 # ------------------------------------------------------------------------------------------------

@@ -171,40 +171,56 @@ class MonodomainSplittingSolver:
         pending_in = 0
         times = getattr(self, "batch_ode_ms", None)
         done = 0
-        while done < len(steps):
-            nb = min(len(steps) - done, _hip.MAX_BATCH)
-            chunk = steps[done : done + nb]
-            t_start = np.ascontiguousarray([a for a, _ in chunk], dtype=np.float64)
-            dts = np.ascontiguousarray([self.theta * (b - a) for a, b in chunk], dtype=np.float64)
-            amps = np.zeros((nb, max(1, len(stims))))
-            for k, (a, b) in enumerate(chunk):  # the stimulus expressions are evaluated at t0 + theta dt, as step() does
-                pde.time.value = a + theta_pde * (b - a)
-                for j, s in enumerate(stims):
-                    amps[k, j] = s.amplitude()
-            infos = (_hip.KspInfo * nb)()
-            pend = (C.c_int * 2)()
-            ode_ms = (C.c_float * nb)() if times is not None else None
-            ops.st_ptr_for_flush = None
-            rc = dev.ctx.lib.beat_split_steps_big(
-                dev.ctx.handle, dev.model.model_id, dev.states.ptr, dev.n, dev.states.ld, hp, npar, int(ode.v_index), ops.handle,
-                C.c_void_p(ops.work.data_ptr()), nb, t_start.ctypes.data_as(C.c_void_p), dts.ctypes.data_as(C.c_void_p), w_ptrs,
-                amps.ctypes.data_as(C.c_void_p), len(stims), rtol, atol, max_it, pending_in, infos, pend, ode_ms)
-            _hip.check(rc, allow_not_converged=True)
-            if times is not None:
-                times.extend(float(v) for v in ode_ms)
-            pending_in = int(pend[1])
-            ops.pending = (row, int(pend[0]), int(pend[1])) if (pend[1] > 0 or dev.ctx.lib.beat_pde_guess_pending(ops.handle)) else None
-            bad = [i for i in range(nb) if infos[i].converged_reason < 0]
-            last = infos[bad[0]] if bad else infos[nb - 1]
-            pde.ksp = KspResult(last.iterations, last.residual_norm, last.converged_reason, last.rhs_norm)
-            pde._check_converged()
-            done += nb
-            if done < len(steps):
-                ops.pending = None  # the next batch's first ionic launch applies it (pending_in)
-        ode._pending_ops = ops
-        for f in (pde.state, pde.v_, ode.v_ode):
-            f.alias_to(row, sync=ops.flush_pending)
-        ode._aliases = [pde.state, pde.v_, ode.v_ode]
+        # a call into the library cannot be interrupted: its length is kept near one second of steps (the first call makes 16 and
+        # times them; 14 ms per step at 512^3, ten times that at 1024^3), and it returns early at a solve that ran out of iterations
+        import time as _time
+
+        cap = min(16, _hip.MAX_BATCH)
+        try:
+            while done < len(steps):
+                nb = min(len(steps) - done, cap)
+                chunk = steps[done : done + nb]
+                t_start = np.ascontiguousarray([a for a, _ in chunk], dtype=np.float64)
+                dts = np.ascontiguousarray([self.theta * (b - a) for a, b in chunk], dtype=np.float64)
+                amps = np.zeros((nb, max(1, len(stims))))
+                for k, (a, b) in enumerate(chunk):  # the stimulus expressions are evaluated at t0 + theta dt, as step() does
+                    pde.time.value = a + theta_pde * (b - a)
+                    for j, s in enumerate(stims):
+                        amps[k, j] = s.amplitude()
+                infos = (_hip.KspInfo * nb)()
+                pend = (C.c_int * 3)()
+                ode_ms = (C.c_float * nb)() if times is not None else None
+                ops.st_ptr_for_flush = None
+                tic = _time.perf_counter()
+                rc = dev.ctx.lib.beat_split_steps_big(
+                    dev.ctx.handle, dev.model.model_id, dev.states.ptr, dev.n, dev.states.ld, hp, npar, int(ode.v_index), ops.handle,
+                    C.c_void_p(ops.work.data_ptr()), nb, t_start.ctypes.data_as(C.c_void_p), dts.ctypes.data_as(C.c_void_p), w_ptrs,
+                    amps.ctypes.data_as(C.c_void_p), len(stims), rtol, atol, max_it, pending_in, infos, pend, ode_ms)
+                ran = int(pend[2])  # steps done: all of them, or up to and including a solve that did not converge
+                per_step = (_time.perf_counter() - tic) / max(1, ran)
+                cap = int(min(_hip.MAX_BATCH, max(1, 1.0 / max(per_step, 1e-6))))
+                pending_in = int(pend[1])
+                ops.pending = (row, int(pend[0]), int(pend[1])) if (pend[1] > 0 or dev.ctx.lib.beat_pde_guess_pending(ops.handle)) else None
+                if times is not None:
+                    times.extend(float(v) for v in ode_ms[:ran])
+                if ran > 0:
+                    last = infos[ran - 1]
+                    pde.ksp = KspResult(last.iterations, last.residual_norm, last.converged_reason, last.rhs_norm)
+                    pde.time.value = chunk[ran - 1][0] + theta_pde * (chunk[ran - 1][1] - chunk[ran - 1][0])
+                _hip.check(rc, allow_not_converged=True)
+                # (with ksp_error_if_not_converged this raises HERE, with the state as the failing step left it; without, the
+                # reference's loop goes on from that iterate and so does the next call)
+                pde._check_converged()
+                done += max(ran, 0)
+                if ran == 0:
+                    raise _hip.BeatHipError("beat_split_steps_big made no progress")
+                if done < len(steps):
+                    ops.pending = None  # the next batch's first ionic launch applies it (pending_in)
+        finally:  # (also when ksp_error_if_not_converged raised: the row, its aliases and what is pending stay consistent)
+            ode._pending_ops = ops
+            for f in (pde.state, pde.v_, ode.v_ode):
+                f.alias_to(row, sync=ops.flush_pending)
+            ode._aliases = [pde.state, pde.v_, ode.v_ode]
 
     # ---------------------------------------------------------------------------------------
     def _can_fuse(self) -> bool:

@@ -1,4 +1,4 @@
-from beat.grid import COMM_WORLD, Comm  # noqa: F401
+from beat.grid import COMM_SELF, COMM_WORLD, Comm  # noqa: F401
 
 SUM = "sum"
 MAX = "max"

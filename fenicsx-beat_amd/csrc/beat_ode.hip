@@ -388,8 +388,9 @@ extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_st
 // layers it takes 0.15-0.18 ms per step at 512^3 (1 % of the step) and the ionic kernel that follows an idle gap runs slower on top
 // (DESIGN.md 7).  Here it is a wake-up and a launch.  Same kernels, same arguments, same values as the per-step calls.
 // pending_in: search directions of an earlier deferred solve still to be applied to the potential row (0: none; the guess
-// increment, if one is due, is known to the operator); host_pending[2]: what the LAST solve of the batch left pending, as
-// beat_pde_solve_ex reports it.  host_ode_ms (or NULL): per step, the duration of the ionic launch (HIP events).
+// increment, if one is due, is known to the operator); host_pending[3]: what the LAST solve that ran left pending, as
+// beat_pde_solve_ex reports it, and the number of steps done -- a solve that runs out of iterations ends the batch there.
+// host_ode_ms (or NULL): per step, the duration of the ionic launch (HIP events).
 extern "C" int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld, const double* host_params,
                                     int num_params, int v_index, beat_pde* pde, double* dev_work, int n_steps, const double* host_t0,
                                     const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
@@ -405,17 +406,29 @@ extern "C" int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_sta
   BEAT_REQUIRE(pending_in >= 0 && pending_in <= beat_pde_ring_size(), "pending_in out of range");
   host_pending[0] = 0;
   host_pending[1] = pending_in;
+  host_pending[2] = 0;
   if (n_steps == 0) return BEAT_OK;
   const int64_t fld = beat_pde_field_stride(pde);
   double* v_row = dev_states + (int64_t)v_index * ld;
   const double* ring0 = dev_work + pde->g.plane + 3 * fld;  // [r, q, z, ring...], each field behind its lower ghost plane
-  std::vector<hipEvent_t> ev;
+  // (timing events of the ionic launches: destroyed on every way out of this function)
+  struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() {
+      for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+      (void)hipGetLastError();
+    }
+  } evs;
+  std::vector<hipEvent_t>& ev = evs.ev;
   if (host_ode_ms != nullptr) {
     ev.resize((size_t)2 * n_steps, nullptr);
     for (hipEvent_t& e : ev) BEAT_HIP_CHECK(hipEventCreate(&e));
+    for (int s = 0; s < n_steps; ++s) host_ode_ms[s] = -1.f;
   }
-  int rc = BEAT_OK, worst = BEAT_OK;
+  int rc = BEAT_OK;
   int count = pending_in;
+  int done = 0;
   for (int s = 0; s < n_steps && rc == BEAT_OK; ++s) {
     if (host_ode_ms) BEAT_HIP_CHECK(hipEventRecord(ev[(size_t)2 * s], ctx->stream));
     rc = beat_ode_step_pending(ctx, model_id, dev_states, n, ld, host_params, num_params, nullptr, 0, host_t0[s], host_dt[s], v_index, nullptr,
@@ -426,23 +439,22 @@ extern "C" int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_sta
     rc = beat_pde_solve_ex(pde, v_row, host_dev_stim_w, host_stim_amp ? host_stim_amp + (size_t)s * n_stim : nullptr, n_stim, v_row, dev_work,
                            rtol, atol, max_it, 1, &info, host_pending);
     if (host_info) host_info[s] = info;
-    if (rc == BEAT_ENOTCONV) {  // (the later steps run on its last iterate, as the reference's loop would without ksp_error_if_not_converged)
-      if (worst == BEAT_OK) worst = BEAT_ENOTCONV;
-      rc = BEAT_OK;
-    }
     count = host_pending[1];
+    done = s + 1;
+    // a solve that ran out of iterations ENDS the batch (round 5; it used to run on, up to BEAT_MAX_BATCH steps on the bad
+    // iterate): the caller sees the state of the failing step, decides (ksp_error_if_not_converged raises there; the
+    // reference's loop without it goes on) and calls again for the rest
   }
+  host_pending[2] = done;
   if (host_ode_ms != nullptr) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = 0; s < done; ++s) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ev[(size_t)2 * s], ev[(size_t)2 * s + 1]) != hipSuccess) ms = -1.f;
       host_ode_ms[s] = ms;
     }
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    (void)hipGetLastError();
   }
-  return rc ? rc : worst;
+  return rc;
 }
 
 // Many split steps of a SMALL grid in one call (theta = 1: ionic step of dt, then the diffusion step of dt in place on

@@ -13,10 +13,13 @@
 #pragma once
 #include "beat_ode_kernel.h"
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <vector>
 
 constexpr int BEAT_JIT_UNAVAILABLE = 1000;
 
@@ -26,6 +29,8 @@ bool beat_jit_enabled();
 hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source);
 // the same from memory only (every step but the first); *known = false when the key has not been asked for yet
 hipFunction_t beat_jit_lookup(beat_ctx* ctx, const std::string& key, bool* known);
+// an instance that loaded but failed its check against the run-time-index kernel: not used again in this process, reported once
+void beat_jit_reject(beat_ctx* ctx, const std::string& key, const std::string& why);
 
 template <class Model, class = void>
 struct BeatJitAccessor : std::false_type {};
@@ -55,7 +60,8 @@ struct BeatJitName<TorordLandGrl1> {
 // shifted, negated, and the small integers a cell-type or switch parameter takes -- for the constants it enters through a
 // comparison; every entry whose bits change is taken per lane.  (An entry that depends on the parameter ONLY through a
 // comparison with a threshold none of these values crosses would be missed; the models here have no such entry -- their
-// branches in derive() are on cell type and on flags in {0, 1, 2, 3}.)
+// branches in derive() are on cell type and on flags in {0, 1, 2, 3}.  What would catch such a miss: every instance is checked
+// once per process against the run-time-index kernel, beat_jit_self_check below.)
 template <class Model>
 void beat_jit_derived_mask(const double* p, const SparseRows& sp, unsigned long long dm[2]) {
   using D = typename Model::Derived;
@@ -82,6 +88,65 @@ void beat_jit_derived_mask(const double* p, const SparseRows& sp, unsigned long 
   }
 }
 
+// One step of the first nodes on two scratch copies: the instance `f` and the run-time-index kernel; BEAT_OK when they agree to
+// 1e-9 of each value (+ 1e-12 of its row's scale: the two differ in where the derived constants are rounded, 1e-12 measured),
+// BEAT_JIT_UNAVAILABLE (and the instance rejected) when they do not.  Synchronises; runs once per instance and process.
+template <class Model>
+int beat_jit_self_check(beat_ctx* ctx, hipFunction_t f, const std::string& key, const double* states, int64_t n, int64_t ld,
+                        ParamPack<Model::NP> prm, typename Model::Derived drv, const double* ppn, int64_t pld, double t, double dt,
+                        int v_index, SparseRows sp) {
+  if (const char* e = std::getenv("BEAT_JIT_SELF_CHECK"))
+    if (e[0] == '0') return BEAT_OK;
+  int64_t nc = std::min<int64_t>(n, 1024);
+  double* scratch = nullptr;
+  const size_t bytes = sizeof(double) * 2 * Model::NS * (size_t)nc;
+  BEAT_HIP_CHECK(hipMalloc(&scratch, bytes));
+  struct Free {
+    double* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{scratch};
+  double* sa = scratch;
+  double* sb = scratch + (size_t)Model::NS * nc;
+  for (int k = 0; k < Model::NS; ++k) {
+    BEAT_HIP_CHECK(hipMemcpyAsync(sa + (size_t)k * nc, states + (int64_t)k * ld, sizeof(double) * nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BEAT_HIP_CHECK(hipMemcpyAsync(sb + (size_t)k * nc, states + (int64_t)k * ld, sizeof(double) * nc, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  PendingV none{nullptr, 0, nullptr, 0, {}};
+  MarkedArgs mk{nullptr, nullptr, 0, nullptr, nullptr};
+  double* vc = nullptr;
+  int64_t ldc = nc;
+  const unsigned grid = (unsigned)((nc + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  void* args[] = {&sa, &nc, &ldc, &prm, &drv, &ppn, &pld, &t, &dt, &v_index, &vc, &none, &mk, &sp};
+  BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+  BEAT_KERNEL((ode_step_kernel<Model, true, false, false, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, sb, nc, ldc, prm, drv, ppn, pld,
+              t, dt, v_index, vc, none, mk, sp);
+  BEAT_LAUNCH_CHECK();
+  std::vector<double> h((size_t)2 * Model::NS * nc);
+  BEAT_HIP_CHECK(hipMemcpyAsync(h.data(), scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const double* a = h.data();
+  const double* b = h.data() + (size_t)Model::NS * nc;
+  for (int k = 0; k < Model::NS; ++k) {
+    double scale = 0.0;
+    for (int64_t i = 0; i < nc; ++i) {
+      const double v = std::fabs(b[(size_t)k * nc + i]);
+      if (v == v && v > scale && v < 1e300) scale = v;
+    }
+    for (int64_t i = 0; i < nc; ++i) {
+      const double x = a[(size_t)k * nc + i], y = b[(size_t)k * nc + i];
+      if (x != x && y != y) continue;  // both NaN (a caller's garbage in, the same garbage out)
+      if (!(std::fabs(x - y) <= 1e-9 * std::fabs(y) + 1e-12 * scale)) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "self-check against the run-time-index kernel failed (state %d, node %lld: %.17g against %.17g)", k,
+                      (long long)i, x, y);
+        beat_jit_reject(ctx, key, msg);
+        return BEAT_JIT_UNAVAILABLE;
+      }
+    }
+  }
+  return BEAT_OK;
+}
+
 template <class Model>
 int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
                         typename Model::Derived drv, const double* ppn, int64_t pld, double t, double dt, int v_index, double* v_copy,
@@ -91,8 +156,29 @@ int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states
   } else {
     if (BeatJitName<Model>::get() == nullptr || sp.count < 1 || sp.count > BEAT_MAX_SPARSE_ROWS || !beat_jit_enabled())
       return BEAT_JIT_UNAVAILABLE;
+    // (the mask costs 14 K + 1 evaluations of derive() on the host: kept for as long as the uniform vector and the indices stay
+    // what they were -- every step of a run but the first)
     unsigned long long dm[2];
-    beat_jit_derived_mask<Model>(prm.p, sp, dm);
+    {
+      struct MaskCache {
+        bool valid = false;
+        double p[Model::NP];
+        SparseRows sp;
+        unsigned long long dm[2];
+      };
+      static thread_local MaskCache mc;
+      if (mc.valid && std::memcmp(mc.p, prm.p, sizeof mc.p) == 0 && std::memcmp(&mc.sp, &sp, sizeof sp) == 0) {
+        dm[0] = mc.dm[0];
+        dm[1] = mc.dm[1];
+      } else {
+        beat_jit_derived_mask<Model>(prm.p, sp, dm);
+        std::memcpy(mc.p, prm.p, sizeof mc.p);
+        mc.sp = sp;
+        mc.dm[0] = dm[0];
+        mc.dm[1] = dm[1];
+        mc.valid = true;
+      }
+    }
     int ct[4] = {-1, -1, -1, -1};
     for (int j = 0; j < sp.count; ++j) ct[j] = sp.idx[j];
     char key[256], inst[512];
@@ -114,6 +200,15 @@ int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states
       src += BeatJitName<Model>::get();
       src += "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
       f = beat_jit_get(ctx, key, src);
+      // First use of an instance in this process: it is run beside the run-time-index kernel (every parameter and every derived
+      // constant per lane: nothing to get wrong) on a scratch copy of the first nodes, and must agree.  The derived-constant mask
+      // is found by perturbation (above); an entry it misses would make the instance use the uniform vector's constant for every
+      // node -- silently wrong physics.  A mismatch rejects the instance; the run-time-index kernel runs instead.
+      if (f != nullptr) {
+        const int rc = beat_jit_self_check<Model>(ctx, f, key, states, n, ld, prm, drv, ppn, pld, t, dt, v_index, sp);
+        if (rc == BEAT_JIT_UNAVAILABLE) return BEAT_JIT_UNAVAILABLE;
+        if (rc != BEAT_OK) return rc;
+      }
     }
     if (f == nullptr) return BEAT_JIT_UNAVAILABLE;
     void* args[] = {&states, &n, &ld, &prm, &drv, &ppn, &pld, &t, &dt, &v_index, &v_copy, &pend, &mk, &sp};

@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -27,7 +28,10 @@ namespace {
 #define BEAT_STR2(x) #x
 #define BEAT_STR(x) BEAT_STR2(x)
 // the flags of the library's own build of beat_ode.hip (csrc/Makefile: CXXFLAGS + FLAGS_beat_ode), device side only
-const char* const kFlags[] = {"--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+#ifndef BEAT_ARCH
+#define BEAT_ARCH gfx950  // csrc/Makefile passes -DBEAT_ARCH=$(ARCH): an instance is compiled for the architecture the library was
+#endif
+const char* const kFlags[] = {"--genco", "--offload-arch=" BEAT_STR(BEAT_ARCH), "-O3", "-std=c++17", "-ffp-contract=off",
                               "-DBEAT_ODE_WAVES=" BEAT_STR(BEAT_ODE_WAVES), "-DBEAT_ODE_WAVES_PER_NODE=" BEAT_STR(BEAT_ODE_WAVES_PER_NODE),
                               "-mllvm", "-disable-machine-licm", "-w"};
 
@@ -45,29 +49,36 @@ JitState& state() {
   return s;
 }
 
-unsigned long long fnv(const std::string& s, unsigned long long h = 1469598103934665603ull) {
-  for (unsigned char c : s) {
-    h ^= c;
-    h *= 1099511628211ull;
-  }
-  return h;
-}
+}  // namespace
+#include "beat_jit_hash.h"  // fnv, beat_jit_source_hash: shared with the build-time tool that writes beat_build_hash.h
+#if __has_include("beat_build_hash.h")
+#include "beat_build_hash.h"  // BEAT_BUILD_SRC_HASH (csrc/Makefile)
+#endif
+namespace {
+using beat_jit_hash::fnv;
+using beat_jit_hash::beat_jit_source_hash;
 
 bool is_file(const std::string& p) {
   struct stat st;
   return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
 }
 
+// The cache directory holds code objects this process will LOAD AND RUN: it has to be this user's own and closed to everybody
+// else (a directory another local user created in /tmp under the predictable name could hold planted objects).
+// Created with mode 0700; an existing one is accepted only if lstat says: a directory (not a link), owned by us, no group /
+// other write permission.
 bool make_dirs(const std::string& p) {
   std::string cur;
   for (size_t i = 0; i <= p.size(); ++i) {
     if (i == p.size() || p[i] == '/') {
-      if (!cur.empty() && ::mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return false;
+      if (!cur.empty() && ::mkdir(cur.c_str(), i == p.size() ? 0700 : 0755) != 0 && errno != EEXIST) return false;
     }
     if (i < p.size()) cur += p[i];
   }
   struct stat st;
-  return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && ::access(p.c_str(), W_OK) == 0;
+  if (::lstat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  if (st.st_uid != ::getuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) return false;
+  return ::access(p.c_str(), W_OK) == 0;
 }
 
 std::string read_file(const std::string& p) {
@@ -115,19 +126,31 @@ void init_locked(JitState& s) {
     s.why = "no writable cache directory (BEAT_JIT_CACHE)";
     return;
   }
-  // what a cached code object was built from: every header of csrc/ and the flags
-  std::vector<std::string> names;
-  if (DIR* d = ::opendir(s.srcdir.c_str())) {
-    while (dirent* de = ::readdir(d)) {
-      const std::string n = de->d_name;
-      if (n.size() > 2 && n.compare(n.size() - 2, 2, ".h") == 0) names.push_back(n);
-    }
-    ::closedir(d);
+  // what a cached code object was built from: every header of csrc/, include/beat_hip.h, the flags, the compiler
+  // The sources an instance would be compiled from must be the sources THIS library was compiled from (an edited header without a
+  // rebuilt library, another BEAT_ODE_WAVES or ARCH: the instance's kernel-argument layout or architecture would differ from what
+  // the host code passes -- silently).  csrc/Makefile stores the hash of its headers and flags in the library (beat_build_hash.h,
+  // written by tools/jit_hash.cpp with the function below); a mismatch switches run-time compilation off.
+  const unsigned long long hsrc = beat_jit_source_hash(s.srcdir);
+#ifdef BEAT_BUILD_SRC_HASH
+  if (hsrc != BEAT_BUILD_SRC_HASH && std::getenv("BEAT_JIT_ANY_SOURCES") == nullptr) {
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "the kernel sources in %s (hash %016llx) are not the ones this library was built from (%016llx): rebuild",
+                  s.srcdir.c_str(), hsrc, (unsigned long long)BEAT_BUILD_SRC_HASH);
+    s.why = msg;
+    return;
   }
-  std::sort(names.begin(), names.end());
-  unsigned long long h = fnv("beat-jit-1");
-  for (const std::string& n : names) h = fnv(read_file(s.srcdir + "/" + n), fnv(n, h));
+#endif
+  unsigned long long h = fnv("beat-jit-2", hsrc);
   for (const char* f : kFlags) h = fnv(f, h);
+  {  // the compiler: another hipcc (another ROCm) gets its own objects -- path, size and modification time of the resolved binary
+    std::string cc = s.hipcc;
+    char real[4096];
+    if (cc.find('/') != std::string::npos && ::realpath(cc.c_str(), real)) cc = real;
+    struct stat st;
+    h = fnv(cc, h);
+    if (::stat(cc.c_str(), &st) == 0) h = fnv(std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime), h);
+  }
   if (const char* x = std::getenv("BEAT_JIT_EXTRA_FLAGS")) {  // experiments with the compiler (tools/jit_flags_ab.sh): part of the cache key
     s.extra = x;
     h = fnv(s.extra, h);
@@ -153,12 +176,27 @@ bool run_hipcc(const JitState& s, const std::string& src, const std::string& out
   std::vector<char*> argv;
   for (std::string& x : a) argv.push_back(&x[0]);
   argv.push_back(nullptr);
+  // The child gets the parent's environment MINUS whatever makes a tool library load into it: under rocprofv3 (LD_PRELOAD,
+  // ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB ...) the preloaded tool initialises the GPU inside hipcc, which then exec's clang and lld --
+  // the exec of a process that has touched the GPU, which this pool forbids.  The compiler needs none of them.
+  std::vector<std::string> envs;
+  for (char** e = environ; e != nullptr && *e != nullptr; ++e) {
+    static const char* const drop[] = {"LD_PRELOAD=", "LD_AUDIT=", "ROCP", "ROCPROF", "ROCTRACER", "ROCTX", "HSA_TOOLS", "RPD_", "OMNITRACE",
+                                       "ROCM_SYSTEMS", "AMD_LOG_LEVEL=", "HIP_TRACE", "HSA_ENABLE_DEBUG"};
+    bool skip = false;
+    for (const char* d : drop) skip = skip || std::strncmp(*e, d, std::strlen(d)) == 0;
+    if (!skip) envs.push_back(*e);
+  }
+  std::vector<char*> envp;
+  for (std::string& x : envs) envp.push_back(&x[0]);
+  envp.push_back(nullptr);
   posix_spawn_file_actions_t fa;
   posix_spawn_file_actions_init(&fa);
-  posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  ::unlink(log.c_str());  // (a link somebody left under the log's name is removed, not followed)
+  posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
   posix_spawn_file_actions_adddup2(&fa, 1, 2);
   pid_t pid = 0;
-  const int rc = posix_spawnp(&pid, s.hipcc.c_str(), &fa, nullptr, argv.data(), environ);
+  const int rc = posix_spawnp(&pid, s.hipcc.c_str(), &fa, nullptr, argv.data(), envp.data());
   posix_spawn_file_actions_destroy(&fa);
   if (rc != 0) return false;
   // a compile takes seconds; one that has not finished after BEAT_JIT_TIMEOUT_S (default 300) is killed: a step must not hang on it
@@ -225,6 +263,14 @@ hipFunction_t beat_jit_lookup(beat_ctx* ctx, const std::string& key, bool* known
   return it != s.fn.end() ? it->second : nullptr;
 }
 
+void beat_jit_reject(beat_ctx* ctx, const std::string& key, const std::string& why) {
+  JitState& s = state();
+  std::lock_guard<std::mutex> lock(s.m);
+  const std::string full = key + "@" + std::to_string(ctx->device);
+  s.fn.erase(full);
+  fail_locked(s, full, why);
+}
+
 hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::string& source) {
   JitState& s = state();
   std::lock_guard<std::mutex> lock(s.m);
@@ -242,7 +288,7 @@ hipFunction_t beat_jit_get(beat_ctx* ctx, const std::string& key, const std::str
     s.disk_hits += 1;
   } else {
     const std::string tag = "." + std::to_string((long long)::getpid());
-    const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp", log = base + ".log";
+    const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp", log = base + tag + ".log";
     {
       std::ofstream f(src);
       f << "// " << key << "\n" << source;

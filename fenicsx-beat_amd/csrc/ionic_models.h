@@ -313,14 +313,36 @@ struct FastMath {
 __device__ __forceinline__ double beat_guard(double v) { return fabs(v) < 1.0e-4 ? copysign(1.0e-4, v) : v; }
 
 // Access to the state-major array for one node (row k at base + k*ld).
+// Cache policy of the state rows' loads and stores (-DBEAT_ODE_NT: bit 0 non-temporal loads, bit 1 non-temporal stores; default
+// 0 = plain).  Round 5 measured it because the library's own streaming probe reaches its best in-place rate with both
+// (csrc/beat_probe.hip, profiles/r05_streaming.md: 6.5 against 6.0 TB/s for ONE stream per wave; 5.85 against 5.73 for 19 row
+// streams, the pattern of this kernel); the result for the kernels themselves is in profiles/r05_streaming.md.
+#ifndef BEAT_ODE_NT
+#define BEAT_ODE_NT 0
+#endif
+__device__ __forceinline__ double beat_row_load(const double* p) {
+#if BEAT_ODE_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void beat_row_store(double* p, double v) {
+#if BEAT_ODE_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 struct NodeIO {
   double* __restrict__ base;
   int64_t ld, i;
   double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown), may be null
   int v_index;
-  __device__ __forceinline__ double load(int k) const { return base[(int64_t)k * ld + i]; }
+  __device__ __forceinline__ double load(int k) const { return beat_row_load(base + (int64_t)k * ld + i); }
   __device__ __forceinline__ void store(int k, double v) const {
-    base[(int64_t)k * ld + i] = v;
+    beat_row_store(base + (int64_t)k * ld + i, v);
     if (v_copy != nullptr && k == v_index) v_copy[i] = v;
   }
 };
@@ -340,7 +362,7 @@ struct NodeIOPending {
   double ge, gd, gp0, gp1;          // what the fields e, d, dp[0], dp[1] held at this node (when gt.d != nullptr; read up front)
   beat_pde_detail::GuessTerms gt;   // where the step's diffusion increment is recorded and the next guess prepared
   __device__ __forceinline__ double load(int k) const {
-    double x = base[(int64_t)k * ld + i];
+    double x = beat_row_load(base + (int64_t)k * ld + i);
     if (k == VIDX) {
       if (gt.d != nullptr) {  // same expressions and order as x_flush_kernel's guess branch
         double inc = gt.accumulate ? 0.0 : ge;
@@ -359,7 +381,7 @@ struct NodeIOPending {
     return x;
   }
   __device__ __forceinline__ void store(int k, double v) const {
-    base[(int64_t)k * ld + i] = v;
+    beat_row_store(base + (int64_t)k * ld + i, v);
     if (k == VIDX && v_copy != nullptr) v_copy[i] = v;
   }
 };

@@ -163,6 +163,18 @@ int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int
  * utils.py:52-54, monodomain_model.py:59-60) */
 int beat_copy(beat_ctx* ctx, double* dev_dst, const double* dev_src, int64_t n);
 int beat_fill(beat_ctx* ctx, double* dev_dst, double value, int64_t n);
+/* Streaming probe: ONE launch of a kernel that only moves bytes over dev[0, n) (n even, 16-byte aligned), so that the achieved
+ * rate of the hot kernels can be set against what the memory system gives THIS library's own loads and stores (bench.py's
+ * roofline.inplace_stream, tools/stream_probe.py).  The reference publishes no throughput (its demos print wall times,
+ * demos/external_operator_gotranx.py:187-256); this is measurement infrastructure, not part of the step.
+ *  mode  : 0 in place x = 1.0 * x (values unchanged), 1 read only, 2 write only (FILLS dev with 0), 3 copy first half -> second
+ *          half, 4 in place over `rows` rows of a (rows, ld) array with all loads of an index ahead of its stores (the ionic
+ *          kernels' access pattern; rows in {1, 4, 8, 19, 45}, n = row length, ld even)
+ *  policy: bit 0 non-temporal loads, bit 1 non-temporal stores, bit 2 raw-buffer instructions instead of global ones (modes 0-3)
+ *  unroll: 1, 2 or 4 independent 16-byte accesses in flight per lane (modes 0-3)
+ *  blocks: workgroups of 256 threads walking the array with a grid-stride loop; 0 = as many as the array has chunks */
+int beat_stream_probe(beat_ctx* ctx, double* dev, int64_t n, int mode, int policy, int unroll, int blocks, int rows,
+                      int64_t ld);
 /* dst[i] = src[idx[i]] (gather) / dst[idx[i]] = src[i] (scatter): marker-wise state transfer of
  * DolfinMultiODESolver (odesolver.py:280-292). */
 int beat_gather(beat_ctx* ctx, double* dev_dst, const double* dev_src, const int64_t* dev_idx, int64_t n);
@@ -401,9 +413,12 @@ int beat_split_steps(beat_ctx* ctx, int model_id, double* dev_states, int64_t n,
  * (src/beat/monodomain_solver.py:53-66 calling :33-79), run inside the library so that nothing but the wake-up of the convergence
  * check and a launch lies between two steps (through Python: 0.15-0.18 ms per step of a 512^3 grid with the device idle).
  * dev_work: as for beat_pde_solve; pending_in: search directions of an earlier deferred solve still to be applied to the row
- * (host_pending[1] of that solve, 0 for none); host_pending[2]: what the last solve of the batch left pending (apply it with
- * the next ionic launch or beat_pde_x_flush); host_info[n_steps]; host_ode_ms[n_steps] or NULL: duration of every ionic launch.
- * Returns BEAT_ENOTCONV if a solve ran out of iterations (the later steps have run on its last iterate). */
+ * (host_pending[1] of that solve, 0 for none); host_pending[3]: [0], [1] what the last solve that ran left pending (apply it with
+ * the next ionic launch or beat_pde_x_flush), [2] the number of steps done; host_info[n_steps]; host_ode_ms[n_steps] or NULL:
+ * duration of every ionic launch (-1 for steps not run).
+ * A solve that runs out of iterations ENDS the batch: BEAT_ENOTCONV is returned with host_pending[2] = the failing step + 1 and
+ * the state as that step left it -- the caller decides (PETSc's ksp_error_if_not_converged raises there; the reference's loop
+ * without it goes on, src/beat/base_model.py:236-239) and calls again for the remaining steps. */
 int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld, const double* host_params,
                          int num_params, int v_index, beat_pde* pde, double* dev_work, int n_steps, const double* host_t0,
                          const double* host_dt, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,

@@ -1466,6 +1466,62 @@ def test_batched_solve_of_a_big_grid_equals_the_step_loop(order, monkeypatch):
     assert not a._can_batch(None)
 
 
+def test_batched_solve_of_a_big_grid_stops_at_the_first_solve_that_does_not_converge():
+    """the library's step loop used to run on after a solve had hit ksp_max_it -- up to a thousand steps on the bad
+    iterate before Python saw it.  Now the batch ends AT that solve: with ``ksp_error_if_not_converged`` the exception comes with
+    the state the failing step left (equal to the step() loop's, bit for bit), without it ``solve`` goes on from that iterate as the
+    reference's loop does (src/beat/base_model.py:236-239 records and continues) and every step is still taken."""
+    import beat
+    from beat import grid as g
+    from beat.base_model import Status
+    from beat.models import tp06
+
+    def build(strict, max_it):
+        geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=8.0, Ly=4.0, Lz=2.0, dx=0.2)
+        mesh = geo.mesh
+        time = g.Constant(mesh, 0.0)
+        cond = beat.conductivities.default_conductivities("Niederer")
+        cells = g.locate_entities(mesh, 3, lambda x: np.logical_and(x[0] <= 1.0 + 1e-10, x[1] <= 1.0 + 1e-10))
+        tags = g.meshtags(mesh, 3, cells, np.full(len(cells), 1, dtype=np.int32))
+        I_s = beat.stimulation.define_stimulus(mesh=mesh, chi=cond["chi"], time=time, subdomain_data=tags, marker=1,
+                                               mesh_unit="mm", amplitude=50_000.0, start=0.2, duration=1.0)
+        M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, I_s=I_s, C_m=0.01, dx=I_s.dZ,
+                                   params={"petsc_options": {"ksp_rtol": 1e-10, "ksp_max_it": max_it, "ksp_guess_order": 0,
+                                                             "ksp_error_if_not_converged": strict}})
+        ode = beat.odesolver.DolfinODESolver(
+            v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+            init_states=tp06.init_state_values(), parameters=tp06.init_parameter_values(stim_amplitude=0.0),
+            num_states=19, v_index=tp06.state_index("V"))
+        return beat.MonodomainSplittingSolver(pde=pde, ode=ode)
+
+    dt = 0.05
+    # resting tissue: the solves need next to nothing until the stimulus starts at t = 0.2 (step 4), whose solve needs more
+    # than three iterations
+    a = build(True, 3)
+    assert a._can_batch(None)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        a.solve((0.0, 20 * dt), dt)
+    b = build(False, 3)
+    failed_at = None
+    for i in range(20):
+        b.step((i * dt, (i + 1) * dt))
+        if b.pde.ksp.converged_reason < 0:
+            failed_at = i
+            break
+    assert failed_at is not None and 2 <= failed_at <= 6
+    np.testing.assert_array_equal(np.asarray(a.pde.state.x.array), np.asarray(b.pde.state.x.array))
+    np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    assert a.pde.ksp.converged_reason < 0 and a.pde.ksp.iterations == 3
+    # without the option: all 20 steps are taken, the status says what happened, the values are the step() loop's
+    c = build(False, 3)
+    c.solve((0.0, 20 * dt), dt)
+    for i in range(failed_at + 1, 20):
+        b.step((i * dt, (i + 1) * dt))
+    assert c.pde.status == Status.NOT_CONVERGING
+    np.testing.assert_array_equal(c.ode.values, b.ode.values)
+
+
 def test_split_steps_entry_refuses_what_it_does_not_cover(hip_ctx):
     """beat_split_steps is for grids the one-launch solve takes: a larger grid, an operator switched to the multi-launch
     kernels or more steps than BEAT_MAX_BATCH are refused with an error text (and MonodomainSplittingSolver.solve

@@ -575,6 +575,42 @@ def test_bench_with_four_ranks_sharing_one_gpu(tmp_path):
     one = r["single_reduction"]
     assert one["solves_on_the_single_reduction_iteration"] >= 4 and one["ms_per_step"] > 0
     assert one["pcg_iterations_per_step"] > 0 and one["transport"] in r["transports"]  # (the one the first headline was measured on)
+    # correctness before speed (round 5): a TP06 slab and a voxel shell with per-node rows, decomposed on the four ranks against
+    # undivided on rank 0 through the public API, on the headline's transport and on every alternative that was timed
+    par = r["multi_rank_parity"]
+    assert par["ok"] and par["tolerance"] == 1e-9 and {"callbacks", "ipc"} <= set(par)
+    for transport in ("callbacks", "ipc"):
+        for case in ("slab", "shell"):
+            v = par[transport][case]
+            assert v["ok"] and v["finite"] and v["max_rel_diff"] <= 1e-9, (transport, case, v)
+            assert v["iterations_equal_across_ranks"] and abs(v["k"] - v["k_undivided"]) <= 1.0 and v["steps"] == 25, (transport, case, v)
+    assert par["callbacks"]["slab"]["nodes"] == 96 * 96 * 48 and par["callbacks"]["shell"]["nodes"] == 65 * 65 * 65
+    assert par["callbacks"]["seconds"] < 60.0  # (host-staged rehearsal transport; on RCCL / ipc the block takes a few seconds)
+
+
+def test_bench_exits_nonzero_when_the_decomposed_run_differs_from_the_undivided_one():
+    """``multi_rank_parity`` is a gate, not a decoration: with one rank's slab perturbed (BEAT_BENCH_TEST_PARITY_BREAK) the line is
+    still printed -- with ``ok: false`` and the difference -- and the job's exit code is non-zero, through the launcher too."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(BEAT_DIST_BACKEND="gloo", BEAT_BENCH_TEST_PARITY_BREAK="1", BEAT_BENCH_ALT="0")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--size", "48", "--steps", "2", "--warmup", "1", "--no-front"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert run.returncode != 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (run.stdout[-2000:], run.stderr[-3000:])
+    r = json.loads(lines[0])
+    par = r["multi_rank_parity"]
+    assert par["ok"] is False and r["value"] > 0
+    bad = [v for t in par.values() if isinstance(t, dict) for v in t.values() if isinstance(v, dict)]
+    assert bad and all(not v["ok"] and v["max_rel_diff"] > 1e-4 for v in bad)
+    assert "multi-rank parity FAILED" in run.stderr and len(r["config"]["launch"]["attempts"]) == 1
 
 
 @pytest.mark.parametrize("failing_rank", [0, 1])

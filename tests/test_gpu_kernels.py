@@ -384,6 +384,51 @@ def test_field_utilities(hip_ctx):
     np.testing.assert_allclose(out, [w[0] @ x[:4], x[5]], rtol=1e-15)
 
 
+def test_stream_probe_moves_the_bytes_it_claims(hip_ctx, small_grid_path):
+    """beat_stream_probe (csrc/beat_probe.hip; bench.py's roofline.inplace_stream) touches what each mode says and nothing
+    else: in place leaves every bit, copy reproduces the first half in the second, write only fills, read only and the row
+    pattern leave the array as it was -- for every cache policy, global and raw-buffer instructions, 1 / 2 / 4 accesses in
+    flight, looping and one-workgroup-per-chunk grids, and a length that is not a multiple of anything."""
+    if small_grid_path != "one-launch":
+        pytest.skip("independent of the solve path")
+    from beat import _hip
+    from beat._device import StateArray
+
+    ctx = hip_ctx
+    rng = np.random.default_rng(11)
+    n = 2 * 50_021
+    buf = ctx.from_numpy(rng.standard_normal(n))
+    ref = buf.cpu().numpy().copy()
+    ptr = C.c_void_p(buf.data_ptr())
+    for policy in range(8):
+        for unroll in (1, 2, 4):
+            for blocks in (0, 7):
+                _hip.check(ctx.lib.beat_stream_probe(ctx.handle, ptr, n, 0, policy, unroll, blocks, 0, 0))
+                if not (policy & 2):
+                    _hip.check(ctx.lib.beat_stream_probe(ctx.handle, ptr, n, 1, policy, unroll, blocks, 0, 0))
+                assert np.array_equal(buf.cpu().numpy(), ref), (policy, unroll, blocks)
+                cp = buf.clone()
+                _hip.check(ctx.lib.beat_stream_probe(ctx.handle, C.c_void_p(cp.data_ptr()), n, 3, policy, unroll, blocks, 0, 0))
+                out = cp.cpu().numpy()
+                half = n // 4 * 2  # 16-byte elements: (n / 2) / 2 of them are copied
+                assert np.array_equal(out[:half], ref[:half]) and np.array_equal(out[half:2 * half], ref[:half]), (policy, unroll, blocks)
+                assert np.array_equal(out[2 * half:], ref[2 * half:])
+                if not (policy & 1):
+                    _hip.check(ctx.lib.beat_stream_probe(ctx.handle, C.c_void_p(cp.data_ptr()), n, 2, policy, unroll, blocks, 0, 0))
+                    assert not cp.cpu().numpy().any()
+    sa = StateArray(ctx, 19, 10_002, 0)
+    vals = rng.standard_normal((19, 10_002))
+    sa.set(vals)
+    for policy in range(4):
+        for blocks in (0, 5):
+            _hip.check(ctx.lib.beat_stream_probe(ctx.handle, sa.ptr, sa.n, 4, policy, 1, blocks, 19, sa.ld))
+    assert np.array_equal(sa.numpy(), vals)
+    with pytest.raises(_hip.BeatHipError):
+        _hip.check(ctx.lib.beat_stream_probe(ctx.handle, ptr, n, 9, 0, 1, 0, 0, 0))
+    with pytest.raises(_hip.BeatHipError):
+        _hip.check(ctx.lib.beat_stream_probe(ctx.handle, sa.ptr, sa.n, 4, 0, 1, 0, 7, sa.ld))
+
+
 @pytest.mark.parametrize("lo_phys,hi_phys,nzl", [(0, 0, 5), (1, 0, 4), (0, 1, 3), (0, 0, 1), (0, 0, 2), (1, 1, 4)])
 def test_spmv_in_two_parts_equals_whole(hip_ctx, lo_phys, hi_phys, nzl):
     """beat_pde_spmv_dot_part: interior planes (part 0, ghost planes POISONED while it runs) + boundary

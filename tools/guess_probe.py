@@ -9,7 +9,10 @@
 
 Same stopping test as the library (||r|| <= rtol ||b||).  Runs the bench workload (bump, then developed front) on
 one GPU at a reduced size with a PCG written in torch over beat_pde_apply, so no kernel has to exist before the
-numbers say whether it is worth writing.  Usage: python tools/guess_probe.py [n] [steps]
+numbers say whether it is worth writing.  Usage: python tools/guess_probe.py [n] [steps] [dt] [h]
+(round 5: dt and h as arguments -- the slab at the shell's dt = 0.05 ms / h = 0.25 mm, tools/shell_guess_probe.py is the
+shell's counterpart -- and, beside the polynomial extrapolations, the A-norm optimal combination of the last 2 / 4 / 6
+increments: what the best linear guess from those increments would give)
 """
 import ctypes as C
 import sys
@@ -32,6 +35,11 @@ from beat._engine import HipOps, Slab  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    if len(sys.argv) > 3:
+        bench.DT = float(sys.argv[3])
+    if len(sys.argv) > 4:
+        bench.H = float(sys.argv[4])
+    print(f"slab {n}^3, TP06, dt = {bench.DT} ms, h = {bench.H} mm, D_l dt / h^2 = {bench.S_L / bench.C_M * bench.DT / bench.H ** 2:.3f}", flush=True)
     rtol = 1e-8
     ctx = Context(0)
     slab = Slab(n, 0, 1)
@@ -93,8 +101,19 @@ def main():
             p = z + (rzn / rz) * p
             rz = rzn
 
+    def optimal(b, v0, bb, D):
+        """x0 = v0 + the A-norm optimal combination of the increments D (Galerkin projection on their span)"""
+        rv = b - A(v0)
+        AD = [A(d) for d in D]
+        m = len(D)
+        G = torch.tensor([[float(D[a] @ AD[c]) for c in range(m)] for a in range(m)], dtype=torch.float64)
+        g = torch.tensor([float(D[a] @ rv) for a in range(m)], dtype=torch.float64)
+        c = torch.linalg.lstsq(G, g[:, None]).solution[:, 0]
+        return pcg(b, v0 + sum(float(c[j]) * D[j] for j in range(m)), bb)[1:]
+
     def run(label, nsteps):
-        d1 = d2 = d3 = d4 = d5 = None
+        d1 = d2 = d3 = d4 = d5 = d6 = None
+        v_last = None
         t = 0.0
         rows = []
         for i in range(nsteps):
@@ -114,16 +133,25 @@ def main():
                     continue
                 xg, kg, rg = pcg(b, g, bb)
                 ks.append(kg), rs.append(rg)
-            d5, d4, d3, d2, d1 = d4, d3, d2, d1, x - v0
+            for m, D in ((2, [d1, d2]), (4, [d1, d2, d3, d4]), (6, [d1, d2, d3, d4, d5, d6])):
+                if D[-1] is None:
+                    ks.append(-1), rs.append(float("nan"))
+                else:
+                    ko, ro = optimal(b, v0, bb, D)
+                    ks.append(ko), rs.append(ro)
+            d6, d5, d4, d3, d2, d1 = d5, d4, d3, d2, d1, x - v0
+            dv = float((v0 - v_last).abs().max()) if v_last is not None else float("nan")
+            v_last = v0
             v.data.copy_(x)
-            rows.append(ks)
+            rows.append(ks + [np.sqrt(r / bb) for r in rs])
             t += bench.DT
-            if i % 5 == 4 or i < 6:
-                print(f"{label} step {i:3d}: k(v)={ks[0]} k(v+d1)={ks[1]} k(v+2d1-d2)={ks[2]} k(quadratic)={ks[3]} k(cubic)={ks[4]} k(quartic)={ks[5]}  r0/b: "
+            if i % 5 == 4 or i < 8:
+                print(f"{label} step {i:3d} max|dv_|/step {dv:6.2f} mV: k(v)={ks[0]} poly1..5={ks[1:6]} optimal2/4/6={ks[6:9]}  r0/b: "
                       + " ".join(f"{np.sqrt(r / bb):.2e}" for r in rs), flush=True)
-        rows = np.array(rows[6:])
-        print(f"{label}: mean iterations after 5 steps: v {rows[:, 0].mean():.2f}, v+d1 {rows[:, 1].mean():.2f}, "
-              f"v+2d1-d2 {rows[:, 2].mean():.2f}, quadratic {rows[:, 3].mean():.2f}, cubic {rows[:, 4].mean():.2f}, quartic {rows[:, 5].mean():.2f}", flush=True)
+        rows = np.array(rows[8:], dtype=float)
+        names = ["v_", "poly1", "poly2", "poly3", "poly4", "poly5", "opt2", "opt4", "opt6"]
+        print(f"{label}: mean over steps >= 8 (k arithmetic, r0/b geometric): "
+              + ", ".join(f"{nm} {rows[:, j].mean():.2f} / {np.exp(np.log(rows[:, 9 + j]).mean()):.1e}" for j, nm in enumerate(names)), flush=True)
 
     bench.init_states(ctx, states, ic, v_index, n, slab, 1234, n)
     run("bump", steps)
