@@ -684,15 +684,25 @@ def main():
                     pass
             # the previous solve left its last x += sum alpha_j p_j to this step's ionic kernel (deferred-x PCG)
             pend = ops.pending
-            if i is not None:
+            lazy_open = getattr(ops, "open_x", None) is not None  # the previous solve is still open: this step's launch goes behind it
+            if i is not None and not lazy_open:
                 pend_counts.append(pend[2] if pend else 0)
                 gt = ops.guess_traffic()  # increments this launch reads / writes for the initial guess (only if it applies the update)
                 guess_fields.append(gt["reads"] + gt["writes"] if (pend and gt["pending"]) else 0)
                 guess_orders.append(gt["order"])
             if use_api:
+                # (the KSP record is NOT read here: MonodomainSplittingSolver.step leaves its solve open until the next step's
+                # ionic launch is queued behind it, and asking for pde.ksp would make the host wait -- the reference's demo
+                # loop does not look at the KSP either, demos/niederer_benchmark.py:270-289; every record is taken from the
+                # operator's log after the timed region)
                 mon.armed = i
                 api_solver.step((t, t + DT))
-                res = pde.ksp
+                res = None
+                if i is not None and lazy_open:  # what the launch behind the open solve applied (known once that solve is finished)
+                    gt = ops.guess_traffic()
+                    pend_counts.append(0)  # (set from the log below)
+                    guess_fields.append(gt["reads"] + gt["writes"] if gt["pending"] else 0)
+                    guess_orders.append(gt["order"])
                 if i is not None:
                     ev_ode[i] = mon.events.pop((i, "ode_step"))
                     ev_pde_end[i] = mon.events.pop((i, "pde_step"))[1]
@@ -708,15 +718,19 @@ def main():
                 res = solver.solve(v_field, [], [], v_field, rtol=args.rtol, atol=1e-50, max_it=500, defer_flush=not args.no_defer)
                 if i is not None:
                     ev_pde_end[i].record()
-            if res.converged_reason <= 0:
-                raise SystemExit(f"PCG did not converge: reason {res.converged_reason} after {res.iterations} iterations")
-            if i is not None:
-                iters.append(res.iterations)
+            if res is not None:
+                if res.converged_reason <= 0:
+                    raise SystemExit(f"PCG did not converge: reason {res.converged_reason} after {res.iterations} iterations")
+                if i is not None:
+                    iters.append(res.iterations)
 
         for _ in range(warmup):
             step(t)
             t += DT
         barrier()
+        if use_api:
+            ops.flush_pending()
+            ops.ksp_log = []
         clocks.start()
         tic = time.perf_counter()
         for i in range(steps):
@@ -726,6 +740,18 @@ def main():
         barrier()
         wall = time.perf_counter() - tic
         clocks.stop()
+        if use_api:  # every solve of the timed steps, from the operator's log (one record per finished solve)
+            log, ops.ksp_log = ops.ksp_log, None
+            if len(log) != steps:
+                raise SystemExit(f"{len(log)} KSP records for {steps} timed steps")
+            for rec in log:
+                if rec.converged_reason <= 0:
+                    raise SystemExit(f"PCG did not converge: reason {rec.converged_reason} after {rec.iterations} iterations")
+            iters.extend(rec.iterations for rec in log)
+            # what each timed ionic launch applied for the solve before it: the directions of that solve's last ring cycle
+            ring_len = len(ops.ring)
+            counts = [rec.iterations % ring_len for rec in log]
+            pend_counts[:] = [0] + counts[:-1]  # (the warm-up's last update was flushed before the timed region)
         if world > 1:
             w = torch.tensor([wall], dtype=torch.float64, device=ctx.device if backend == "nccl" else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)

@@ -184,6 +184,11 @@ class HipOps:
         self.st = ctx.zeros(_hip.ST_SIZE)
         self.pending = None            # (field, ring_base, count) of a deferred potential update
         self.st_ptr_for_flush = None   # scalar state the pending update belongs to (None: the handle's own)
+        # a solve that is enqueued and not yet looked at (solve_begin): the field it works on; its record arrives with solve_finish,
+        # which `on_finish` (the PDE model: its .ksp, its status) and `ksp_log` (a list, when a caller wants every record) receive
+        self.open_x = None
+        self.on_finish = None
+        self.ksp_log = None
         self.pc_degree = 1
         self._coeffs = (1.0, 0.5, 0.0)
         self.guess_order = 0  # x0 = v_ unless asked for (set_guess_order; BaseModel asks for "auto" by default)
@@ -255,6 +260,7 @@ class HipOps:
 
     # -- stages -----------------------------------------------------------------------------
     def set_timestep(self, C_m, theta, dt):
+        self.flush_pending()
         _hip.check(self.lib.beat_pde_set_timestep(self.handle, float(C_m), float(theta), float(dt)))
         self._coeffs = (float(C_m), float(theta), float(dt))
         self._update_preconditioner()
@@ -364,7 +370,55 @@ class HipOps:
                                               C.byref(info), pend), allow_not_converged=True)
         if pend[1] > 0 or self.lib.beat_pde_guess_pending(self.handle):  # (the guess increment alone may be due)
             self.pending = (x, int(pend[0]), int(pend[1]))
-        return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+        res = KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+        if self.ksp_log is not None:
+            self.ksp_log.append(res)
+        return res
+
+    # -- the solve in two halves (beat_pde_solve_begin / _end): see include/beat_hip.h ------------------------------------
+    def can_open(self) -> bool:
+        return bool(self.lib.beat_pde_solve_can_open(self.handle))
+
+    def solve_begin(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it) -> None:
+        """Enqueue the solve and return without waiting.  Until ``solve_finish`` -- which everything that needs the result or
+        the field calls: ``flush_pending``, the model's ``ksp``, the next ionic step -- the device works and the host is free."""
+        self.flush_pending()
+        self.st_ptr_for_flush = None
+        ptrs, amps, k = self._stim_args(stim_w, stim_amp)
+        _hip.check(self.lib.beat_pde_solve_begin(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr, C.c_void_p(self.work.data_ptr()),
+                                                 rtol, atol, max_it))
+        self.open_x = x
+
+    def _record(self, info) -> KspResult:
+        res = KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+        if self.ksp_log is not None:
+            self.ksp_log.append(res)
+        if self.on_finish is not None:
+            self.on_finish(res)
+        return res
+
+    def solve_finish(self):
+        """Wait for the open solve (more iterations are enqueued if it needs them), take its record; what it leaves pending
+        goes to ``self.pending`` as after ``solve_single(defer_flush=True)``.  None when no solve is open."""
+        if self.open_x is None:
+            return None
+        x, self.open_x = self.open_x, None
+        info = _hip.KspInfo()
+        pend = (C.c_int * 2)()
+        _hip.check(self.lib.beat_pde_solve_end(self.handle, C.byref(info), pend), allow_not_converged=True)
+        if pend[1] > 0 or self.lib.beat_pde_guess_pending(self.handle):
+            self.pending = (x, int(pend[0]), int(pend[1]))
+        return self._record(info)
+
+    def finished_behind(self):
+        """The open solve was finished inside the ionic call that was enqueued behind it (beat_ode_step_* with pending = -1):
+        collect its record; nothing is pending."""
+        self.open_x = None
+        self.pending = None
+        info = _hip.KspInfo()
+        pend = (C.c_int * 2)()
+        _hip.check(self.lib.beat_pde_solve_end(self.handle, C.byref(info), pend), allow_not_converged=True)  # (no solve open: the last record)
+        return self._record(info)
 
     def solve_dist(self, comm: "LibComm", v_prev, stim_w, stim_amp, x, rtol, atol, max_it, defer_flush: bool = False) -> KspResult:
         """The slab-decomposed solve as ONE C call (beat_pde_solve_dist): halo exchange and all-reduces are issued
@@ -419,7 +473,9 @@ class HipOps:
         _hip.check(self.lib.beat_pde_guess_reset(self.handle))
 
     def flush_pending(self) -> None:
-        """Apply a deferred update of the potential (no-op when nothing is pending)."""
+        """Apply a deferred update of the potential (no-op when nothing is pending).  A solve that is still open is finished first."""
+        if self.open_x is not None:
+            self.solve_finish()
         if self.pending is not None:
             x, ring_base, _ = self.pending
             self.pending = None

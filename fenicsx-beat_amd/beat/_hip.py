@@ -117,6 +117,10 @@ SIGNATURES = {
         _int,
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, C.POINTER(KspInfo)],
     ),
+    "beat_pde_solve_begin": (_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int]),
+    "beat_pde_solve_end": (_int, [_vp, C.POINTER(KspInfo), C.POINTER(_int)]),
+    "beat_pde_solve_is_open": (_int, [_vp]),
+    "beat_pde_solve_can_open": (_int, [_vp]),
     "beat_pde_solve_ex": (
         _int,
         [_vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, _int, C.POINTER(KspInfo), C.POINTER(_int)],
@@ -135,7 +139,8 @@ UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 2048
 IPC_MAX_RANKS = 16
 COMM_SERIAL = 1
-MAX_SPARSE_ROWS = 4  # BEAT_MAX_SPARSE_ROWS of csrc/beat_ode.hip
+MAX_SPARSE_ROWS = 16  # BEAT_MAX_SPARSE_ROWS of csrc/beat_ode_kernel.h: on an instance compiled for the rows (run-time compilation)
+MAX_SPARSE_ROWS_RT = 4  # BEAT_MAX_SPARSE_ROWS_RT: on the shipped kernel
 TRANSPORT_NAMES = {0: "callbacks", 1: "rccl", 2: "rccl-serial", 3: "ipc"}
 E_NOT_CONVERGED = -3
 

@@ -163,8 +163,21 @@ class BaseModel:
             self._ops.set_single_reduction(str(single).lower() not in ("0", "false", "no", ""))
         self._stimuli = [_CompiledStimulus(self, s) for s in self._I_s]
         self._update_matrices()
-        self.ksp = None  # KSP-like record of the last solve
+        self._ksp = None  # KSP-like record of the last solve (see the ``ksp`` property)
         self.status = Status.OK  # NOT_CONVERGING once a linear solve has run out of iterations
+
+    @property
+    def ksp(self):
+        """KSP-like record of the last solve (what telemetry.py:67-76 reads from PETSc's KSP).  A solve the fused step left
+        open is finished here."""
+        ops = getattr(self, "_ops", None)
+        if ops is not None and getattr(ops, "open_x", None) is not None:
+            ops.solve_finish()
+        return self._ksp
+
+    @ksp.setter
+    def ksp(self, value) -> None:
+        self._ksp = value
 
     @abc.abstractmethod
     def _setup_state_space(self) -> None: ...

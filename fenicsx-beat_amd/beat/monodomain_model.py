@@ -54,11 +54,39 @@ class MonodomainModel(BaseModel):
         self.ksp = self._diffusion.solve(self.v_.field, stim_w, stim_amp, x, rtol=rtol, atol=atol, max_it=max_it)
         self._state._touch()
 
-    def solve_in_place(self, field, stim_w, stim_amp, defer_flush: bool = False):
+    def can_solve_lazily(self) -> bool:
+        """May the fused step leave its solve open (enqueued, not waited for) until the next step's ionic launch is in the
+        queue behind it?  One rank, Jacobi, nobody who wants the KSP record step by step (a monitor; PETSc's
+        ``ksp_error_if_not_converged``, whose exception belongs to the failing step); BEAT_LAZY_KSP=0 switches it off."""
+        import os
+
+        from .telemetry import NullMonitor
+
+        d, ops = self._diffusion, self._ops
+        if os.environ.get("BEAT_LAZY_KSP", "1") == "0" or not hasattr(ops, "can_open"):
+            return False
+        if d.dist is not None or d.libcomm is not None or type(self.monitor) is not NullMonitor:
+            return False
+        if (self.parameters.get("petsc_options") or {}).get("ksp_error_if_not_converged"):
+            return False
+        return ops.can_open()
+
+    def solve_in_place(self, field, stim_w, stim_amp, defer_flush: bool = False, lazy: bool = False):
         """Fused-step entry: v_ and the unknown share ``field`` (the V row of the ODE state array).  With
-        ``defer_flush`` the last update of the potential may stay pending in ``self._ops`` (see HipOps.solve_single)."""
+        ``defer_flush`` the last update of the potential may stay pending in ``self._ops`` (see HipOps.solve_single).
+        ``lazy`` (with defer_flush, when ``can_solve_lazily``): the solve is enqueued and NOT waited for; ``self.ksp`` --
+        read when somebody asks, or when the next step has put its ionic kernel behind the solve -- finishes it."""
         rtol, atol, max_it = self._solver_tolerances()
+        if lazy and defer_flush:
+            ops = self._ops
+            ops.on_finish = self._solve_finished
+            ops.solve_begin(field, stim_w, stim_amp, field, rtol, atol, max_it)
+            return None
         self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it,
                                          defer_flush=defer_flush)
         self._check_converged()
         return self.ksp
+
+    def _solve_finished(self, res) -> None:
+        self._ksp = res
+        self._check_converged()

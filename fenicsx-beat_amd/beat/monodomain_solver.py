@@ -274,10 +274,14 @@ class MonodomainSplittingSolver:
                         if a != 0.0 and s.field is not None:
                             stim_w.append(s.field)
                             stim_amp.append(a)
+                    # (with nobody asking for the KSP record step by step the solve is left open: the next step's ionic launch
+                    # goes into the queue behind it before the host waits, and the device never idles in between)
+                    lazy = pde.can_solve_lazily()
                     with pde.monitor.track_time("pde_linear_solve"):
-                        pde.solve_in_place(row, stim_w, stim_amp, defer_flush=True)
+                        pde.solve_in_place(row, stim_w, stim_amp, defer_flush=True, lazy=lazy)
                     ode._pending_ops = pde._ops
-                    pde.monitor.record_ksp(pde.ksp)
+                    if not lazy:
+                        pde.monitor.record_ksp(pde.ksp)
                 pde.monitor.advance_step(t0, t1)
             if not np.isclose(self.theta, 1.0):
                 # corrective ionic step of length (1 - theta) dt from t0 + theta dt (monodomain_solver.py:98-113)

@@ -171,7 +171,8 @@ class _DeviceODE:
 
     def _per_node_or_classes(self, tensor, num_rows):
         """(host params, P, device rows, ld) for per-node parameters held in ``tensor``: the class route if they allow it,
-        else -- when at most four ROWS vary over the nodes (a smooth gradient in a conductance or two) -- those rows alone
+        else -- when at most sixteen ROWS vary over the nodes (smooth gradients in a few conductances; four without run-time
+        compilation) -- those rows alone
         next to the uniform vector (``self._sparse``: beat_ode_step_rows reads 8 B per varying row and node instead of 8 P),
         else all P rows."""
         per_node = (None, num_rows, C.c_void_p(tensor.data_ptr()), self.n)
@@ -187,7 +188,9 @@ class _DeviceODE:
         if os.environ.get("BEAT_PARAM_SPARSE", "1") != "0" and tensor.shape[1] == self.n:
             varying = (tensor != tensor[:, :1]).any(dim=1)
             idx = varying.nonzero().flatten().cpu().numpy().astype(np.int32)
-            if 1 <= len(idx) <= _hip.MAX_SPARSE_ROWS:
+            # (up to 16 varying rows on a kernel instance compiled for their indices, 4 where that cannot be had)
+            jit = os.environ.get("BEAT_JIT", "1") != "0" and self.ctx.lib.beat_ode_jit_stats(None) == 1
+            if 1 <= len(idx) <= (_hip.MAX_SPARSE_ROWS if jit else _hip.MAX_SPARSE_ROWS_RT):
                 rows = tensor[varying].contiguous()  # (K, N): the only parameter data a step reads from memory
                 uniform = np.ascontiguousarray(tensor[:, 0].cpu().numpy(), dtype=np.float64)
                 self._sparse = (uniform, np.ascontiguousarray(idx), rows)
@@ -244,7 +247,18 @@ class _DeviceODE:
             use_classes = False
             hp, npar, ppn, pld = self._per_node_args
         pend = None
-        if pending_ops is not None and pending_ops.pending is not None:
+        behind = False  # enqueue this launch BEHIND a solve that is still open (pending = -1: beat_ode_step_pending)
+        if pending_ops is not None and getattr(pending_ops, "open_x", None) is not None:
+            model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
+            long_ring = len(pending_ops.ring) > 6  # (only the class kernel takes more than six pending directions)
+            if (v_row is not None and int(v_index) == model_v and pending_ops.open_x.ptr.value == v_row.ptr.value
+                    and (self.node_map is None or self.node_map[1].ptr.value == v_row.ptr.value)
+                    and (use_classes or not long_ring)):
+                behind = True
+                pend = (v_row, 0, -1)
+            else:
+                pending_ops.solve_finish()
+        if not behind and pending_ops is not None and pending_ops.pending is not None:
             model_v = self.model.state_index(self.model.v_name) if self.model.v_name else -1
             if (v_row is not None and int(v_index) == model_v
                     and pending_ops.pending[0].ptr.value == v_row.ptr.value
@@ -287,6 +301,8 @@ class _DeviceODE:
                                                    self.states.ld, hp, npar, ppn, pld, float(t0), float(dt), int(v_index),
                                                    None if v_copy is None else v_copy.ptr)
                     )
+            if behind:  # the call has finished the solve it was enqueued behind: take its record
+                pending_ops.finished_behind()
             with self.monitor.track_time("ode_state_update"):
                 pass  # updated in place by the kernel
 

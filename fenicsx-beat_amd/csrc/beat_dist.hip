@@ -823,6 +823,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   double* r = dev_work + plane;
   double* q = r + fld;
   double* ring = q + 2 * fld;  // [r, q, z, ring...]: z is unused by the Jacobi path
+  const int PR = pde->ring;     // (6 on a decomposed grid; a one-rank communicator on a single slab of per-node rows: 12)
   double* st = pde->d_st;
   double* h = ctx->h_pinned;
   int rc;
@@ -909,14 +910,14 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   while (true) {
     chunk = std::min(chunk, limit - launched);
     for (int it = 0; it < chunk; ++it) {
-      const int i = launched + it, slot = i % PRING;
+      const int i = launched + it, slot = i % PR;
       double* p_cur = ring + (int64_t)slot * fld;
-      double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
+      double* p_next = ring + (int64_t)((i + 1) % PR) * fld;
       if (merged) {
         // u_i . A u_i, r_i . u_i, r_i . r_i in one pass over r_i (interior planes while its ghost planes travel, then the
         // boundary planes), ONE all-reduce, the scalar step (stopping test, beta_i, alpha_i), then p_i = u_i + beta_i p_{i-1}
         // and r_{i+1} = r_i - alpha_i A p_i in one pass without a dot product; the ghost planes of r_{i+1} travel behind it
-        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
         double* r_cur = rbuf[i & 1];
         double* r_new = rbuf[(i + 1) & 1];
         if ((rc = beat_rr_udot_part(pde, st, r_cur, 0))) return rc;
@@ -926,8 +927,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         if ((rc = beat_rr_merged_next(pde, st, slot))) return rc;
         if ((rc = beat_rr_prupd(pde, st, r_cur, p_old, p_cur, r_new))) return rc;
         if ((rc = halo_start(comm, r_new, n, plane))) return rc;
-        if (slot == PRING - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+        if (slot == PR - 1) {
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
             return rc;
         }
         continue;
@@ -935,7 +936,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
       if (rr) {
         // p_i = D^-1 r_i + beta p_{i-1} and p_i . A p_i: the planes that need no ghost data while the ghost planes of
         // r_i travel, then the boundary planes, which also keep p_i on the ghost planes (no exchange of p)
-        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
         double* r_cur = rbuf[i & 1];
         double* r_new = rbuf[(i + 1) & 1];
         if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 0))) return rc;
@@ -945,8 +946,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         if ((rc = beat_rr_rupd(pde, st, r_cur, r_new, p_cur, slot, false))) return rc;  // r_{i+1}, local r.z and r.r
         if ((rc = halo_start(comm, r_new, n, plane))) return rc;  // travels behind the reductions and the next part 0
         if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-        if (slot == PRING - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+        if (slot == PR - 1) {
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
             return rc;
         }
         if ((rc = beat_rr_next(pde, st))) return rc;
@@ -956,7 +957,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         // p_i = D^-1 r_i + beta p_{i-1}, q = A p_i and p_i . q in one pass over the coefficient rows: the tiles that need no ghost
         // plane while the ghost planes of r_i travel, then the boundary tiles (which keep p_i on the ghost planes); the residual
         // update in place, its ghost planes travelling behind the second reduction and the next pass's first part
-        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
+        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
         if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 0))) return rc;
         if ((rc = halo_wait(comm))) return rc;
         if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 1))) return rc;
@@ -964,8 +965,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
         if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
         if ((rc = halo_start(comm, r, n, plane))) return rc;
         if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-        if (slot == PRING - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+        if (slot == PR - 1) {
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
             return rc;
         }
         if ((rc = beat_rr_next(pde, st))) return rc;  // the scalar roll (beta, iteration count, latch)
@@ -978,8 +979,8 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
       if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
       if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
       if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-      if (slot == PRING - 1) {
-        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+      if (slot == PR - 1) {
+        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
           return rc;
       }
       if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
@@ -994,13 +995,14 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if (rr || vpdot) {  // the exchange started after the last residual update has no consumer: drain it before anything else
     if ((rc = halo_wait(comm))) return rc;  // touches those ghost planes
   }
-  const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
+  const int nupd = (int)h[NUPD], base = (nupd / PR) * PR;
   const GuessTerms last = beat_guess_terms(pde, base);
   beat_guess_observe(pde, (int)h[ITERS]);
   if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
     if (defer_flush) {
       host_pending[0] = base;
-      host_pending[1] = nupd % PRING;
+      host_pending[1] = nupd % PR;
+      pde->last_base = base;
     } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
       return rc;
     }

@@ -6,6 +6,8 @@
 #include "beat_ode_kernel.h"
 #include "beat_ode_jit.h"
 
+#include <functional>
+
 // Many steps inside one launch (single-cell pre-pacing, free-running ODE solves): the node's states stay
 // in registers; t restarts at 0 for every beat and advances as j*dt within it (numpy.arange semantics of
 // src/beat/single_cell.py:42-65).  Optionally records `ntrack` states every `save_freq` steps.
@@ -137,7 +139,7 @@ template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
                       int v_index, double* v_copy, const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr},
-                      SparseRows sp = SparseRows{{0, 0, 0, 0}, 0}) {
+                      SparseRows sp = SparseRows{{0}, 0}) {
   BEAT_REQUIRE(num_params == Model::NP || (host_params == nullptr && ppn == nullptr && Model::NP == 2) || mk.markers != nullptr,
                "model expects %d parameters, got %d", Model::NP, num_params);
   // (with num_params == NP and neither a vector nor rows nor classes every parameter would silently be 1.0 -- what the
@@ -147,7 +149,7 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < Model::NS), "v_index %d out of range", v_index);
   BEAT_REQUIRE(mk.markers == nullptr || v_copy == nullptr || v_index == Model::V_INDEX,
                "the class kernel mirrors the model's potential (row %d), not row %d", Model::V_INDEX, v_index);
-  const bool have_pend = pend.count > 0 || pend.gt.d != nullptr;
+  const bool have_pend = pend.count > 0 || pend.gt.d != nullptr || pend.dev_st != nullptr;
   BEAT_REQUIRE(!have_pend || v_index == Model::V_INDEX,
                "a pending update needs v_index = %d (the model's membrane potential), got %d", Model::V_INDEX, v_index);
   ParamPack<Model::NP> prm;
@@ -191,6 +193,9 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
       const int rc = beat_ode_jit_launch<Model>(ctx, g3, have_pend, states, n, ld, prm, drv, ppn, pld, t, dt, v_index, v_copy, pend, mk, sp);
       if (rc != BEAT_JIT_UNAVAILABLE) return rc;
     }
+    // (the shipped kernel finds a row's entry by comparison at run time: four rows; more need the compiled instance)
+    BEAT_REQUIRE(sp.count <= BEAT_MAX_SPARSE_ROWS_RT, "%d varying rows need run-time compilation, which is not available here "
+                 "(beat_ode_jit_stats; at most %d rows otherwise): pass all rows (beat_ode_step)", sp.count, BEAT_MAX_SPARSE_ROWS_RT);
     if (have_pend)
       BEAT_KERNEL((ode_step_kernel<Model, true, true, false, true>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, dt,
                   v_index, v_copy, pend, mk, sp);
@@ -234,7 +239,7 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
                              const double* host_params, int num_params, const double* dev_params_per_node,
                              int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
                              const PendingV& pend, MarkedArgs mk = MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr},
-                             SparseRows sp = SparseRows{{0, 0, 0, 0}, 0}) {
+                             SparseRows sp = SparseRows{{0}, 0}) {
   BEAT_REQUIRE(ctx != nullptr, "null context");
   BEAT_REQUIRE(dev_states != nullptr, "null states");
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
@@ -263,14 +268,76 @@ extern "C" int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, in
                            t, dt, v_index, dev_v_copy, PendingV{nullptr, 0, nullptr, 0, {}});
 }
 
+// More pending directions than the plain kernels' pending path takes (a per-node-row operator on a single slab keeps a ring of
+// 12, PRING_MAX; the class kernel takes them all, the uniform / per-node kernels 6 -- their pending values stay live through the
+// step): the update is applied by the flush pass instead and the launch proceeds without a pending update.
+static int flush_long_ring(beat_pde* pde, double* v_row, const double* dev_ring0, int64_t field_stride, int& pending) {
+  if (pending <= BEAT_MAX_PENDING) return BEAT_OK;
+  beat_pde_detail::GuessTerms gt{};
+  if (pde->guess_pending) {
+    gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
+  pending = 0;
+  return beat_pde_x_flush_terms(pde, nullptr, v_row, dev_ring0, field_stride, pde->last_base, 0, gt);
+}
+
+// pending = -1 (round 5): `pde` has an OPEN solve (beat_pde_solve_begin) whose result the host has not looked at.  The launch is
+// enqueued behind it at once, told to read what is pending from the solve's scalar state on the device and to do nothing if the
+// solve has not latched (PendingV::dev_st); only then does the host wait for the solve (beat_solve_end: its bookkeeping, more
+// iterations if the enqueued ones did not suffice).  The device goes from the solve's last kernel straight into the ionic kernel
+// instead of idling while the host wakes up, reads the latch and launches (0.15-0.2 ms of a 13.7 ms step at 512^3: what
+// MonodomainSplittingSolver.step cost over .solve).  If the solve did need more iterations the first launch was a no-op and the
+// step is launched again, with the host's own count.  Values: those of the two separate calls, bit for bit.
+static int step_behind_open_solve(beat_ctx* ctx, beat_pde* pde, const double* dev_ring0, int64_t field_stride, int64_t n, double* v_row,
+                                  const std::function<int(const PendingV&)>& launch) {
+  BEAT_REQUIRE(pde != nullptr && pde->open.on, "pending = -1 needs an operator with an open solve");
+  BEAT_REQUIRE(dev_ring0 != nullptr && field_stride >= n, "bad pending update");
+  BEAT_REQUIRE(pde->open.x == v_row, "the open solve does not work on this row");
+  PendingV behind{dev_ring0, field_stride, pde->d_alphas, 0, pde->guess, pde->d_st, pde->ring};
+  const bool plain_kernel_fits = pde->ring <= BEAT_MAX_PENDING;  // (a longer ring: only the class kernel takes it all)
+  (void)plain_kernel_fits;
+  if (int rc = launch(behind)) return rc;
+  beat_ksp_info info{};
+  int pend2[2] = {0, 0};
+  bool needed_more = false;
+  const int rc_solve = beat_solve_end(pde, 1, &info, pend2, &needed_more);
+  if (rc_solve != BEAT_OK && rc_solve != BEAT_ENOTCONV) return rc_solve;
+  pde->applied_behind = false;
+  if (!needed_more) {  // the launch behind the solve has applied the update: nothing is left to the caller
+    if (pde->guess_pending) {
+      pde->applied_terms = pde->guess_final;
+      pde->applied_behind = true;
+    }
+    pde->guess_pending = false;
+    return BEAT_OK;
+  }
+  // the first launch saw an unlatched solve and returned at once: again, with what the finished solve left
+  PendingV pend{dev_ring0, field_stride, pend2[1] ? pde->d_alphas : nullptr, pend2[1], {}, nullptr, 0};
+  if (pde->guess_pending) {
+    pend.gt = pde->guess_final;
+    pde->guess_pending = false;
+  }
+  return launch(pend);
+}
+
 extern "C" int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                                      const double* host_params, int num_params,
                                      const double* dev_params_per_node, int64_t params_ld, double t, double dt,
                                      int v_index, double* dev_v_copy, beat_pde* pde, const double* dev_ring0,
                                      int64_t field_stride, int pending) {
-  static_assert(BEAT_MAX_PENDING == beat_pde_detail::PRING, "pending directions = ring size");
-  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
+  static_assert(BEAT_MAX_PENDING == beat_pde_detail::PRING && BEAT_MAX_PENDING_CLASS == beat_pde_detail::PRING_MAX, "pending directions = ring size");
+  if (pending == -1) {
+    BEAT_REQUIRE(pde != nullptr && pde->ring <= BEAT_MAX_PENDING, "this kernel's pending path takes %d directions: finish the solve first", BEAT_MAX_PENDING);
+    return step_behind_open_solve(ctx, pde, dev_ring0, field_stride, n, dev_states + (int64_t)v_index * ld, [&](const PendingV& pv) {
+      return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, v_index,
+                               dev_v_copy, pv);
+    });
+  }
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING_CLASS, "pending count %d out of range", pending);
   BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  BEAT_REQUIRE(pde == nullptr || !pde->open.on, "the operator has an open solve: finish it (beat_pde_solve_end) or pass pending = -1");
+  if (int rc = flush_long_ring(pde, dev_states + (int64_t)v_index * ld, dev_ring0, field_stride, pending)) return rc;
   PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
   if (pde != nullptr && pde->guess_pending) {  // this launch is the application the deferring solve left open
     pend.gt = pde->guess_final;
@@ -291,13 +358,24 @@ extern "C" int beat_ode_step_rows(beat_ctx* ctx, int model_id, double* dev_state
                                   beat_pde* pde, const double* dev_ring0, int64_t field_stride, int pending) {
   BEAT_REQUIRE(host_params != nullptr && host_row_params != nullptr && dev_rows != nullptr, "null argument");
   BEAT_REQUIRE(num_rows >= 1 && num_rows <= BEAT_MAX_SPARSE_ROWS, "1..%d varying rows, got %d", BEAT_MAX_SPARSE_ROWS, num_rows);
-  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
-  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
-  SparseRows sp{{0, 0, 0, 0}, num_rows};
+  BEAT_REQUIRE(num_rows <= BEAT_MAX_SPARSE_ROWS_RT || beat_jit_enabled(), "%d varying rows need run-time compilation, which is not available "
+               "here (beat_ode_jit_stats; at most %d rows otherwise): pass all rows (beat_ode_step)", num_rows, BEAT_MAX_SPARSE_ROWS_RT);
+  SparseRows sp{{0}, num_rows};
   for (int j = 0; j < num_rows; ++j) {
     BEAT_REQUIRE(host_row_params[j] >= 0 && host_row_params[j] < num_params, "row %d names parameter %d of %d", j, host_row_params[j], num_params);
     sp.idx[j] = host_row_params[j];
   }
+  if (pending == -1) {  // behind an open solve (see beat_ode_step_pending)
+    BEAT_REQUIRE(pde != nullptr && pde->ring <= BEAT_MAX_PENDING, "this kernel's pending path takes %d directions: finish the solve first", BEAT_MAX_PENDING);
+    return step_behind_open_solve(ctx, pde, dev_ring0, field_stride, n, dev_states + (int64_t)v_index * ld, [&](const PendingV& pv) {
+      return ode_step_dispatch(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_rows, rows_ld, t, dt, v_index, dev_v_copy, pv,
+                               MarkedArgs{nullptr, nullptr, 0, nullptr, nullptr}, sp);
+    });
+  }
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING_CLASS, "pending count %d out of range", pending);
+  BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && field_stride >= n), "bad pending update");
+  BEAT_REQUIRE(pde == nullptr || !pde->open.on, "the operator has an open solve: finish it (beat_pde_solve_end) or pass pending = -1");
+  if (int rc = flush_long_ring(pde, dev_states + (int64_t)v_index * ld, dev_ring0, field_stride, pending)) return rc;
   PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
   if (pde != nullptr && pde->guess_pending) {
     pend.gt = pde->guess_final;
@@ -367,16 +445,24 @@ extern "C" int beat_ode_step_classes(beat_ctx* ctx, int model_id, double* dev_st
   BEAT_REQUIRE((dev_node_map == nullptr) == (dev_v_field == nullptr), "dev_node_map and dev_v_field come together");
   BEAT_REQUIRE(dev_node_map == nullptr || dev_v_copy == nullptr, "with a node map the field IS the mirror of the potential");
   BEAT_REQUIRE(classes >= 1 && classes <= BEAT_MAX_CLASSES, "1..%d parameter classes, got %d", BEAT_MAX_CLASSES, classes);
-  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING, "pending count %d out of range", pending);
+  int stride = 0;
+  if (int rc = beat_ode_class_table_doubles(model_id, &stride)) return rc;
+  if (pending == -1) {  // behind an open solve (see beat_ode_step_pending): the class kernel takes the long ring as well
+    double* v_row = dev_v_field != nullptr ? dev_v_field : dev_states + (int64_t)v_index * ld;
+    return step_behind_open_solve(ctx, pde, dev_ring0, field_stride, dev_node_map != nullptr ? 0 : n, v_row, [&](const PendingV& pv) {
+      return ode_step_dispatch(ctx, model_id, dev_states, n, ld, nullptr, 0, nullptr, 0, t, dt, v_index, dev_v_copy, pv,
+                               MarkedArgs{dev_markers, dev_table, stride, dev_node_map, dev_v_field});
+    });
+  }
+  BEAT_REQUIRE(pending >= 0 && pending <= BEAT_MAX_PENDING_CLASS, "pending count %d out of range", pending);
   BEAT_REQUIRE(pending == 0 || (pde != nullptr && dev_ring0 != nullptr && (field_stride >= n || dev_node_map != nullptr)),
                "bad pending update");
+  BEAT_REQUIRE(pde == nullptr || !pde->open.on, "the operator has an open solve: finish it (beat_pde_solve_end) or pass pending = -1");
   PendingV pend{dev_ring0, field_stride, pending ? pde->d_alphas : nullptr, pending, {}};
   if (pde != nullptr && pde->guess_pending) {
     pend.gt = pde->guess_final;
     pde->guess_pending = false;
   }
-  int stride = 0;
-  if (int rc = beat_ode_class_table_doubles(model_id, &stride)) return rc;
   return ode_step_dispatch(ctx, model_id, dev_states, n, ld, nullptr, 0, nullptr, 0, t, dt, v_index, dev_v_copy, pend,
                            MarkedArgs{dev_markers, dev_table, stride, dev_node_map, dev_v_field});
 }
@@ -403,7 +489,7 @@ extern "C" int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_sta
   BEAT_REQUIRE(pde->n == n, "the operator has %lld nodes, the state array %lld", (long long)pde->n, (long long)n);
   BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "a slab with live neighbours is stepped through beat_pde_solve_dist");
   BEAT_REQUIRE(n_stim == 0 || (host_dev_stim_w != nullptr && host_stim_amp != nullptr), "null stimulus arrays");
-  BEAT_REQUIRE(pending_in >= 0 && pending_in <= beat_pde_ring_size(), "pending_in out of range");
+  BEAT_REQUIRE(pending_in >= 0 && pending_in <= pde->ring, "pending_in out of range");
   host_pending[0] = 0;
   host_pending[1] = pending_in;
   host_pending[2] = 0;

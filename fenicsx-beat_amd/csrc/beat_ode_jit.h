@@ -1,4 +1,4 @@
-// Sparse per-node parameter rows with the varying indices as COMPILE-TIME constants: the instance of ode_step_kernel for one
+// Sparse per-node parameter rows (up to 16 of them) with the varying indices as COMPILE-TIME constants: the instance of ode_step_kernel for one
 // (model, index set) is written as a three-line translation unit, compiled by hipcc for gfx950 at first use (~1.5 s for TP06),
 // kept as a code object in a cache directory and loaded with hipModuleLoadData.  Why: with a run-time index every parameter of a
 // node has to live in a VGPR (the step's p[k] cannot tell at compile time which k varies): 238 VGPRs, 2 waves, 1.20 x the
@@ -97,6 +97,7 @@ int beat_jit_self_check(beat_ctx* ctx, hipFunction_t f, const std::string& key, 
                         int v_index, SparseRows sp) {
   if (const char* e = std::getenv("BEAT_JIT_SELF_CHECK"))
     if (e[0] == '0') return BEAT_OK;
+  const bool many = sp.count > BEAT_MAX_SPARSE_ROWS_RT;  // more rows than the run-time-index kernel takes: checked against the all-rows kernel
   int64_t nc = std::min<int64_t>(n, 1024);
   double* scratch = nullptr;
   const size_t bytes = sizeof(double) * 2 * Model::NS * (size_t)nc;
@@ -118,8 +119,33 @@ int beat_jit_self_check(beat_ctx* ctx, hipFunction_t f, const std::string& key, 
   const unsigned grid = (unsigned)((nc + BEAT_BLOCK - 1) / BEAT_BLOCK);
   void* args[] = {&sa, &nc, &ldc, &prm, &drv, &ppn, &pld, &t, &dt, &v_index, &vc, &none, &mk, &sp};
   BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
-  BEAT_KERNEL((ode_step_kernel<Model, true, false, false, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, sb, nc, ldc, prm, drv, ppn, pld,
-              t, dt, v_index, vc, none, mk, sp);
+  if (!many) {
+    BEAT_KERNEL((ode_step_kernel<Model, true, false, false, true>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, sb, nc, ldc, prm, drv, ppn, pld,
+                t, dt, v_index, vc, none, mk, sp);
+  } else {
+    // all NP rows for the first nodes: the uniform vector, the varying rows copied over their entries
+    std::vector<double> full((size_t)Model::NP * nc), rows((size_t)sp.count * nc);
+    for (int j = 0; j < sp.count; ++j)
+      BEAT_HIP_CHECK(hipMemcpyAsync(rows.data() + (size_t)j * nc, ppn + (int64_t)j * pld, sizeof(double) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < Model::NP; ++k)
+      for (int64_t i = 0; i < nc; ++i) full[(size_t)k * nc + i] = prm.p[k];
+    for (int j = 0; j < sp.count; ++j)
+      for (int64_t i = 0; i < nc; ++i) full[(size_t)sp.idx[j] * nc + i] = rows[(size_t)j * nc + i];
+    double* dfull = nullptr;
+    BEAT_HIP_CHECK(hipMalloc(&dfull, sizeof(double) * full.size()));
+    struct Free2 {
+      double* p;
+      ~Free2() { (void)hipFree(p); }
+    } g2{dfull};
+    BEAT_HIP_CHECK(hipMemcpyAsync(dfull, full.data(), sizeof(double) * full.size(), hipMemcpyHostToDevice, ctx->stream));
+    const double* cfull = dfull;
+    SparseRows none_sp{{0}, 0};
+    BEAT_KERNEL((ode_step_kernel<Model, true, false, false, false>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, sb, nc, ldc, prm, drv, cfull,
+                ldc, t, dt, v_index, vc, none, mk, none_sp);
+    BEAT_LAUNCH_CHECK();
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (dfull is freed when this block ends)
+  }
   BEAT_LAUNCH_CHECK();
   std::vector<double> h((size_t)2 * Model::NS * nc);
   BEAT_HIP_CHECK(hipMemcpyAsync(h.data(), scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -179,17 +205,18 @@ int beat_ode_jit_launch(beat_ctx* ctx, dim3 grid, bool have_pend, double* states
         mc.valid = true;
       }
     }
-    int ct[4] = {-1, -1, -1, -1};
-    for (int j = 0; j < sp.count; ++j) ct[j] = sp.idx[j];
-    char key[256], inst[512];
-    std::snprintf(key, sizeof key, "%s_p%d_i%d_%d_%d_%d_m%llx_%llx", BeatJitName<Model>::get(), have_pend ? 1 : 0, ct[0], ct[1], ct[2],
-                  ct[3], dm[0], dm[1]);
+    std::string pack;  // "12, 27, 3"
+    for (int j = 0; j < sp.count; ++j) pack += (j ? ", " : "") + std::to_string(sp.idx[j]);
+    char key[512], inst[768];
+    std::snprintf(key, sizeof key, "%s_p%d_i%s_m%llx_%llx", BeatJitName<Model>::get(), have_pend ? 1 : 0, pack.c_str(), dm[0], dm[1]);
+    for (char* c = key; *c; ++c)
+      if (*c == ',' || *c == ' ') *c = '_';
     bool known = false;
     hipFunction_t f = beat_jit_lookup(ctx, key, &known);
     if (known && f == nullptr) return BEAT_JIT_UNAVAILABLE;
     if (!known) {
-      std::snprintf(inst, sizeof inst, "ode_step_kernel<%s, true, %s, false, true, %d, %d, %d, %d, 0x%llxull, 0x%llxull>",
-                    BeatJitName<Model>::get(), have_pend ? "true" : "false", ct[0], ct[1], ct[2], ct[3], dm[0], dm[1]);
+      std::snprintf(inst, sizeof inst, "ode_step_kernel<%s, true, %s, false, true, IdxPack<%s>, 0x%llxull, 0x%llxull>",
+                    BeatJitName<Model>::get(), have_pend ? "true" : "false", pack.c_str(), dm[0], dm[1]);
       std::string src = "// written by libbeat_hip (beat_ode_jit.h): one instance of the ionic step kernel, varying parameter indices compile-time\n"
                         "#include \"beat_ode_kernel.h\"\n"
                         "template __global__ void ";

@@ -340,5 +340,6 @@ extern "C" int beat_ode_jit_stats(long long* host_out) {
     host_out[2] = s.disk_hits;
     host_out[3] = s.failures;
   }
+  if (!s.usable) beat_set_error("run-time compilation unavailable: %s", s.why.c_str());  // (beat_last_error says why)
   return s.usable ? 1 : 0;
 }

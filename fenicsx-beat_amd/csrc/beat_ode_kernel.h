@@ -36,7 +36,32 @@ struct PendingV {
   // the solve started from an extrapolated guess (beat_pde_set_guess_order): v += inc, inc = e + sum alpha_j p_j,
   // inc is recorded as the step's diffusion increment and the next guess prepared (gt.d == nullptr: no guess)
   beat_pde_detail::GuessTerms gt;
+  // The launch was enqueued BEHIND a solve the host has not looked at yet (beat_ode_step_pending with pending = -1, round 5): what
+  // is pending is read from that solve's scalar state on the device -- dev_st[NUPD] updates executed, `ring_len` directions per ring
+  // cycle: count = NUPD % ring, the guess terms accumulate when a full cycle was flushed inside the loop, nothing is due when the
+  // guess alone satisfied the stopping test and there is none -- and the kernel does NOTHING if the solve has not latched
+  // (dev_st[STOP] == 0: it needs more iterations than were enqueued; the host, which reads the same state right after, enqueues
+  // them and launches the step again).  nullptr: count and gt are the host's (every other caller).
+  const double* dev_st;
+  int ring_len;
 };
+
+// what a launch applies: the host's count and guess terms, or (PendingV::dev_st) the ones the open solve's device state says
+struct PendingNow {
+  int count;
+  beat_pde_detail::GuessTerms gt;
+};
+__device__ __forceinline__ PendingNow beat_pending_now(const PendingV& p) {
+  PendingNow o{p.count, p.gt};
+  if (p.dev_st != nullptr) {  // (wave-uniform: scalar loads)
+    const int nupd = (int)p.dev_st[beat_pde_detail::NUPD];
+    o.count = nupd % p.ring_len;
+    o.gt.accumulate = nupd >= p.ring_len ? 1 : 0;
+    const bool e_due = nupd == 0 && p.gt.use_e != 0;
+    if (o.count == 0 && !e_due) o.gt.d = nullptr;  // nothing to apply, nothing to record (beat_guess_end)
+  }
+  return o;
+}
 
 // Layout of ode_step_kernel's kernel-argument segment up to the uniform parameters (all members 8-byte aligned): the
 // tile loop re-reads them through an opaque copy of the segment pointer (see the kernel).
@@ -71,7 +96,8 @@ struct MarkedArgs {
 // Per-node parameters of which only a few ROWS vary (a smooth gradient in one conductance: src/beat/odesolver.py:67-79 hands
 // ``fun`` the whole (P, N) array, demos/pace_train.py:133-167 builds such arrays): the varying rows alone live on the
 // device, the other parameters come from the uniform vector -- 8 B per varying row and node instead of 8 NP (TP06: 424).
-constexpr int BEAT_MAX_SPARSE_ROWS = 4;
+constexpr int BEAT_MAX_SPARSE_ROWS = 16;     // on an instance compiled for the rows' indices (beat_ode_jit.h)
+constexpr int BEAT_MAX_SPARSE_ROWS_RT = 4;   // on the shipped kernel, which finds a row's entry by comparison at run time
 struct SparseRows {
   int idx[BEAT_MAX_SPARSE_ROWS];  // parameter index of row j of ppn
   int count;                      // 0: ppn holds all NP rows
@@ -83,15 +109,25 @@ struct OdeTableEntry {
   typename Model::Derived d;
 };
 
-// Up to four varying rows whose parameter indices K0..K3 are known at COMPILE time (the instance is written and compiled at
-// first use, beat_ode_jit.hip): every use p[k] of the model's code folds to a row's value (k == Kj) or to the uniform vector,
-// read with scalar loads -- everything that does not vary stays on the scalar unit, as in the uniform kernel.  -1: unused.
-template <int K0, int K1, int K2, int K3>
-struct MixedParams {
+// Varying rows whose parameter indices K... are known at COMPILE time (the instance is written and compiled at first use,
+// beat_ode_jit.hip; up to BEAT_MAX_SPARSE_ROWS of them since round 5, four before): every use p[k] of the model's code folds to a
+// row's value (k == Kj) or to the uniform vector, read with scalar loads -- everything that does not vary stays on the scalar
+// unit, as in the uniform kernel.  IdxPack<>: no compile-time indices (the shipped instances).
+template <int... K>
+struct IdxPack {
+  static constexpr int count = (int)sizeof...(K);
+};
+template <class CT>
+struct MixedParams;
+template <int... K>
+struct MixedParams<IdxPack<K...>> {
   const double* u;
-  double v0, v1, v2, v3;
+  double v[sizeof...(K) > 0 ? sizeof...(K) : 1];
   __device__ __forceinline__ double operator[](int k) const {
-    return k == K0 ? v0 : k == K1 ? v1 : k == K2 ? v2 : k == K3 ? v3 : u[k];
+    double r = u[k];  // (dead when k names a varying row: the load goes with it)
+    int j = 0;
+    ((r = (k == K ? v[j] : r), ++j), ...);
+    return r;
   }
 };
 // The derived constants (Model::Derived: doubles only): those a varying parameter enters -- bit j of DM0 (entries 0..63) / DM1
@@ -110,9 +146,9 @@ __device__ __forceinline__ D mix_derived(const D& du, const D& dl) {
   return d;
 }
 
-template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARSE = false, int CT0 = -1, int CT1 = -1, int CT2 = -1,
-          int CT3 = -1, unsigned long long DM0 = 0, unsigned long long DM1 = 0>
-__global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
+template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARSE = false, class CT = IdxPack<>,
+          unsigned long long DM0 = 0, unsigned long long DM1 = 0>
+__global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
     int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk, SparseRows sp) {
@@ -123,6 +159,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
   const FastMath fm{etab, ltab};
+  if (PEND && pend.dev_st != nullptr && pend.dev_st[beat_pde_detail::STOP] == 0.0) return;  // the solve ahead has not latched (see PendingV)
   // (Round 3, measured and removed: starting the three blocks that share a CU a third of a tile apart -- s_sleep by
   // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
   // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
@@ -171,28 +208,29 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
       // the potential with the pending update applied (and the guess's bookkeeping done) once, ahead of the passes --
       // same expressions and order as NodeIOPending::load / x_flush_kernel: the pending values die here instead of
       // staying live through every pass (-30 VGPRs, no scratch)
-      double pp[BEAT_MAX_PENDING], pa[BEAT_MAX_PENDING];
+      const PendingNow now = beat_pending_now(pendl);
+      double pp[BEAT_MAX_PENDING_CLASS], pa[BEAT_MAX_PENDING_CLASS];
 #pragma unroll
-      for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-        pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + jn) : 0.0;
-        pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
+      for (int j = 0; j < BEAT_MAX_PENDING_CLASS; ++j) {
+        pp[j] = j < now.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + jn) : 0.0;
+        pa[j] = j < now.count ? pendl.alphas[j] : 0.0;
       }
-      if (pendl.gt.d != nullptr) {
-        const beat_pde_detail::GuessTerms& gt = pendl.gt;
+      if (now.gt.d != nullptr) {
+        const beat_pde_detail::GuessTerms& gt = now.gt;
         const double ge = beat_pde_detail::beat_guess_needs_e(gt) ? __builtin_nontemporal_load(gt.e + jn) : 0.0;
         const double gd = beat_pde_detail::beat_guess_needs_d(gt) ? __builtin_nontemporal_load(gt.d + jn) : 0.0;
         const double gp0 = beat_pde_detail::beat_guess_needs_dp(gt, 0) ? __builtin_nontemporal_load(gt.dp[0] + jn) : 0.0;
         const double gp1 = beat_pde_detail::beat_guess_needs_dp(gt, 1) ? __builtin_nontemporal_load(gt.dp[1] + jn) : 0.0;
         double inc = gt.accumulate ? 0.0 : ge;
 #pragma unroll
-        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
-          if (j < pendl.count) inc = fma(pa[j], pp[j], inc);
+        for (int j = 0; j < BEAT_MAX_PENDING_CLASS; ++j)
+          if (j < now.count) inc = fma(pa[j], pp[j], inc);
         beat_pde_detail::beat_guess_record(gt, gt.d + jn, gt.e + jn, inc, gd, gp0, gp1, ge);
         v_now += inc;
       } else {
 #pragma unroll
-        for (int j = 0; j < BEAT_MAX_PENDING; ++j)
-          if (j < pendl.count) v_now = fma(pa[j], pp[j], v_now);
+        for (int j = 0; j < BEAT_MAX_PENDING_CLASS; ++j)
+          if (j < now.count) v_now = fma(pa[j], pp[j], v_now);
       }
     }
     unsigned long long todo = __ballot(m_lane < 254);
@@ -229,23 +267,26 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
       *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, pendl.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+    const PendingNow now = beat_pending_now(pendl);
+    NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-      io.pp[j] = j < pendl.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + i) : 0.0;
-      io.pa[j] = j < pendl.count ? pendl.alphas[j] : 0.0;
+      io.pp[j] = j < now.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + i) : 0.0;
+      io.pa[j] = j < now.count ? pendl.alphas[j] : 0.0;
     }
-    if (pendl.gt.d != nullptr) {
-      io.gt = pendl.gt;
-      io.ge = beat_pde_detail::beat_guess_needs_e(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.e + i) : 0.0;
-      io.gd = beat_pde_detail::beat_guess_needs_d(pendl.gt) ? __builtin_nontemporal_load(pendl.gt.d + i) : 0.0;
-      io.gp0 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 0) ? __builtin_nontemporal_load(pendl.gt.dp[0] + i) : 0.0;
-      io.gp1 = beat_pde_detail::beat_guess_needs_dp(pendl.gt, 1) ? __builtin_nontemporal_load(pendl.gt.dp[1] + i) : 0.0;
+    if (now.gt.d != nullptr) {
+      io.gt = now.gt;
+      io.ge = beat_pde_detail::beat_guess_needs_e(now.gt) ? __builtin_nontemporal_load(now.gt.e + i) : 0.0;
+      io.gd = beat_pde_detail::beat_guess_needs_d(now.gt) ? __builtin_nontemporal_load(now.gt.d + i) : 0.0;
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(now.gt, 0) ? __builtin_nontemporal_load(now.gt.dp[0] + i) : 0.0;
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(now.gt, 1) ? __builtin_nontemporal_load(now.gt.dp[1] + i) : 0.0;
     }
-    if constexpr (PER_NODE && SPARSE && CT0 >= 0) {
-      // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
-      const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
-                                               CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
+    if constexpr (PER_NODE && SPARSE && CT::count > 0) {
+      // (row j of ppn belongs to the j-th index of the pack: the launch checks sp.idx against the instance)
+      MixedParams<CT> mp;
+      mp.u = p_uni;
+#pragma unroll
+      for (int j = 0; j < CT::count; ++j) mp.v[j] = ppn[(int64_t)j * pld + i];
       if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
         Model::step(io, mp, d_uni, fm, t, dt);
       } else {
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
 #pragma unroll
         for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
 #pragma unroll
-        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS_RT; ++j) {
           if (j < sp.count) {
             const double vj = ppn[(int64_t)j * pld + i];
             // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
@@ -290,10 +331,12 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
     // (the mirror of row v_index -- any row here, unlike in the pending-update form -- is written after the step from
     // the row itself: a store-time test "k == v_index" for each of the NS rows is NS uniform conditions kept, and spilled)
     const NodeIO io{states, ldl, i, nullptr, -1};
-    if constexpr (PER_NODE && SPARSE && CT0 >= 0) {
-      // (row j of ppn belongs to index CTj: the launch checks sp.idx against the instance)
-      const MixedParams<CT0, CT1, CT2, CT3> mp{p_uni, ppn[i], CT1 >= 0 ? ppn[pld + i] : 0.0, CT2 >= 0 ? ppn[2 * pld + i] : 0.0,
-                                               CT3 >= 0 ? ppn[3 * pld + i] : 0.0};
+    if constexpr (PER_NODE && SPARSE && CT::count > 0) {
+      // (row j of ppn belongs to the j-th index of the pack: the launch checks sp.idx against the instance)
+      MixedParams<CT> mp;
+      mp.u = p_uni;
+#pragma unroll
+      for (int j = 0; j < CT::count; ++j) mp.v[j] = ppn[(int64_t)j * pld + i];
       if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
         Model::step(io, mp, d_uni, fm, t, dt);
       } else {
@@ -314,7 +357,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT0 < 0) ? Model::WAVES_PE
 #pragma unroll
         for (int k = 0; k < Model::NP; ++k) pl[k] = pv[k];
 #pragma unroll
-        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS; ++j) {
+        for (int j = 0; j < BEAT_MAX_SPARSE_ROWS_RT; ++j) {
           if (j < sp.count) {
             const double vj = ppn[(int64_t)j * pld + i];
             // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks

@@ -496,15 +496,15 @@ __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const do
                                                              double* __restrict__ x,
                                                              const double* __restrict__ ring, int64_t fld,
                                                              const double* __restrict__ alphas, int ring_base,
-                                                             int only_if_full, GuessTerms gt) {
+                                                             int only_if_full, GuessTerms gt, int R) {
   int nvalid = (int)st[NUPD] - ring_base;
-  nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
+  nvalid = nvalid < 0 ? 0 : (nvalid > R ? R : nvalid);
   // in-loop flushes are enqueued ahead of time: they must do nothing unless their ring cycle really
   // filled up (a partially filled last cycle is flushed once, after the host has seen the latch)
-  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.d == nullptr)) return;
-  double a[PRING];
+  if ((only_if_full && nvalid < R) || (nvalid == 0 && gt.d == nullptr)) return;
+  double a[PRING_MAX];
 #pragma unroll
-  for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
+  for (int j = 0; j < PRING_MAX; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
   if (gt.d != nullptr) {
     double* d = gt.d;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const do
       const double dp1 = beat_guess_needs_dp(gt, 1) ? gt.dp[1][i] : 0.0;
       double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
-      for (int j = 0; j < PRING; ++j)
+      for (int j = 0; j < PRING_MAX; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
       beat_guess_record(gt, d + i, e + i, inc, d_old, dp0, dp1, e_old);
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void x_flush_kernel(int64_t n, const do
   for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
     double xi = x[i];
 #pragma unroll
-    for (int j = 0; j < PRING; ++j)
+    for (int j = 0; j < PRING_MAX; ++j)
       if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
     x[i] = xi;
   }
@@ -622,7 +622,7 @@ extern "C" int beat_pde_create(beat_ctx* ctx, const int64_t n[3], int z_lo_phys,
   BEAT_HIP_CHECK(hipSetDevice(ctx->device));
   BEAT_HIP_CHECK(hipMalloc(&p->d_tabs, sizeof(double) * (4 * 27 * TABW + 32)));
   BEAT_HIP_CHECK(hipMalloc(&p->d_st, sizeof(double) * BEAT_ST_DOUBLES));
-  BEAT_HIP_CHECK(hipMalloc(&p->d_alphas, sizeof(double) * PRING));
+  BEAT_HIP_CHECK(hipMalloc(&p->d_alphas, sizeof(double) * PRING_MAX));
   BEAT_HIP_CHECK(hipMemsetAsync(p->d_st, 0, sizeof(double) * BEAT_ST_DOUBLES, ctx->stream));
   const int rc = upload_tables(p);  // Mass / K usable before the first set_timestep
   if (rc) return rc;
@@ -646,8 +646,11 @@ extern "C" int beat_pde_destroy(beat_pde* pde) {
   (void)hipFree(pde->d_alphas);
   (void)hipFree(pde->d_batch_st);
   (void)hipFree(pde->d_hist_alloc);
+  if (pde->h_st) (void)hipHostFree(pde->h_st);
+  if (pde->ev_st) (void)hipEventDestroy(pde->ev_st);
   (void)hipFree(pde->v_A);
   (void)hipFree(pde->v_dinv);
+  (void)hipFree(pde->v_B);
   (void)hipFree(pde->v_gc0);
   (void)hipFree(pde->v_seg);
   (void)hipFree(pde->v_segmask);
@@ -953,7 +956,7 @@ extern "C" int64_t beat_pde_field_stride(const beat_pde* pde) {
 }
 
 extern "C" int beat_pde_work_fields(beat_pde* pde) {
-  return pde ? 3 + PRING : BEAT_EINVAL;  // r, q, z + the ring of search directions
+  return pde ? 3 + pde->ring : BEAT_EINVAL;  // r, q, z + the ring of search directions
 }
 
 // ---- deferred-x stages for callers that drive the iteration themselves (slab-decomposed solve) ----------
@@ -963,7 +966,7 @@ extern "C" int beat_pde_ring_size(void) { return PRING; }
 // LOCAL r.D^-1 r, r.r -> dev_st[4..5]; counts the executed update in dev_st[14].
 extern "C" int beat_pde_cg_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
   BEAT_REQUIRE(pde != nullptr && dev_st && dev_r && dev_q, "null argument");
-  BEAT_REQUIRE(slot >= 0 && slot < PRING, "slot %d out of range", slot);
+  BEAT_REQUIRE(slot >= 0 && slot < pde->ring, "slot %d out of range", slot);
   if (pde->var) return beat_var_update_r(pde, dev_st, dev_r, dev_q, slot);
   BEAT_LAUNCH_VEC(pde, cg_update_r_kernel, dim3(pde->vec_grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->g,
                      (const double*)dev_st, dev_r, dev_q, pde->dinv_arg(), pde->h_dinv[13], pde->ctx->d_partials,
@@ -994,7 +997,7 @@ int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, c
   if (pde->var) return beat_var_flush(pde, dev_st, dev_x, dev_ring0, field_stride, ring_base, only_if_full, gt);
   const unsigned grid = (unsigned)std::min<int64_t>(2048, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   BEAT_KERNEL(x_flush_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, dev_st, dev_x,
-                     dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full, gt);
+                     dev_ring0, field_stride, (const double*)pde->d_alphas, ring_base, only_if_full, gt, pde->ring);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -1002,6 +1005,7 @@ int beat_pde_x_flush_terms(beat_pde* pde, const double* dev_st, double* dev_x, c
 extern "C" int beat_pde_x_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0,
                                 int64_t field_stride, int ring_base, int only_if_full) {
   BEAT_REQUIRE(pde != nullptr && dev_x && dev_ring0, "null argument");
+  BEAT_REQUIRE(!pde->open.on, "the operator has an open solve: finish it first (beat_pde_solve_end)");
   // the application a deferring solve left to its caller carries that solve's guess terms
   GuessTerms gt{};
   if (pde->guess_pending && !only_if_full) {
@@ -1070,6 +1074,7 @@ extern "C" int beat_pde_set_guess_order(beat_pde* pde, int order) {
 
 extern "C" int beat_pde_guess_reset(beat_pde* pde) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(!pde->open.on, "the operator has an open solve: finish it first (beat_pde_solve_end)");
   BEAT_REQUIRE(!pde->guess_pending, "a deferred update is pending");
   pde->hist_n = 0;
   pde->auto_e_order = 0;
@@ -1092,7 +1097,8 @@ extern "C" int beat_pde_guess_history(const beat_pde* pde, double** dev_d, doubl
 
 extern "C" int beat_pde_guess_traffic(const beat_pde* pde, int* host_out) {
   BEAT_REQUIRE(pde != nullptr && host_out != nullptr, "null argument");
-  const GuessTerms& g = pde->guess_pending ? pde->guess_final : pde->guess;
+  // (an update applied by a launch enqueued behind an open solve: its terms were kept when that solve was finished)
+  const GuessTerms& g = pde->guess_pending ? pde->guess_final : (pde->applied_behind ? pde->applied_terms : pde->guess);
   int reads = 0, writes = 0;
   if (g.d != nullptr) {
     reads += (g.accumulate || g.use_e) ? 1 : 0;          // e
@@ -1103,7 +1109,7 @@ extern "C" int beat_pde_guess_traffic(const beat_pde* pde, int* host_out) {
   host_out[0] = reads;
   host_out[1] = writes;
   host_out[2] = pde->guess_order < 0 ? pde->auto_cur : pde->guess_order;
-  host_out[3] = pde->guess_pending ? 1 : 0;
+  host_out[3] = pde->guess_pending ? 1 : (pde->applied_behind ? 2 : 0);  // 2: applied by the launch behind the open solve
   return BEAT_OK;
 }
 
@@ -1202,7 +1208,8 @@ void beat_guess_observe(beat_pde* pde, int iterations) {
 }
 
 bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
-  const bool partial = nupd % PRING != 0;
+  const int PR = pde->ring;
+  const bool partial = nupd % PR != 0;
   if (pde->guess.d == nullptr) return partial;
   const bool e_due = nupd == 0 && pde->guess.use_e;  // no ring cycle carried e to x yet
   if (nupd == 0 && !e_due) {  // x = v_ is the answer and nothing was recorded: the history ends here
@@ -1211,7 +1218,7 @@ bool beat_guess_end(beat_pde* pde, int nupd, bool deferred) {
   }
   const bool due = partial || e_due;
   if (due && deferred) {
-    pde->guess_final = beat_guess_terms(pde, (nupd / PRING) * PRING);
+    pde->guess_final = beat_guess_terms(pde, (nupd / PR) * PR);
     pde->guess_pending = true;
   }
   beat_guess_advance(pde);
@@ -1226,6 +1233,178 @@ extern "C" int beat_pde_solve(beat_pde* pde, const double* dev_v_prev,
                            0, info, nullptr);
 }
 
+bool beat_solve_lazy_available(const beat_pde* pde) {
+  // Jacobi on one slab, not the one-launch path of small grids: the two loops that keep every scalar on the device
+  return pde != nullptr && pde->g.z_lo_phys && pde->g.z_hi_phys && !beat_small_available(pde) && pde->pc_ncoef == 1 &&
+         (beat_rr_available(pde) || pde->var);
+}
+
+// `count` more iterations of the open solve, enqueued
+static int solve_enqueue_iterations(beat_pde* pde, int count) {
+  beat_pde::OpenSolve& o = pde->open;
+  const int64_t fld = beat_pde_field_stride(pde);
+  double* r = o.work + pde->g.plane;
+  double* q = r + fld;
+  double* ring = q + 2 * fld;
+  double* st = pde->d_st;
+  const int PR = pde->ring;
+  int rc;
+  for (int it = 0; it < count; ++it) {
+    const int i = o.launched + it, slot = i % PR;
+    double* p_cur = ring + (int64_t)slot * fld;
+    const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
+    if (o.kind == 0) {
+      // iteration i: p_i = D^-1 r + beta p_{i-1} and p_i . A p_i in one pass (ring slot i % PR), then r_new = r - alpha A p_i
+      // with A p_i recomputed (written to the other of the two residual buffers: the kernel then needs no store-before-load
+      // ordering), then the scalar roll
+      double* rbuf[2] = {r, q};
+      if ((rc = beat_rr_pdot(pde, st, rbuf[i & 1], p_old, p_cur))) return rc;
+      if ((rc = beat_rr_rupd(pde, st, rbuf[i & 1], rbuf[(i + 1) & 1], p_cur, slot))) return rc;
+      if (slot == PR - 1) {  // ring full: bring x up to date before slot 0 is overwritten
+        if ((rc = beat_pde_x_flush_terms(pde, st, o.x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR)))) return rc;
+      }
+    } else {
+      // per-node rows (round 4): the tile kernel forms p_i = D^-1 r + beta p_{i-1} while loading, stores it and q = A p_i in the
+      // same pass (beat_vtl_pdot); same expressions, same bits as the three-kernel iteration (BEAT_VTL_PDOT=0)
+      double* p_next = ring + (int64_t)((i + 1) % PR) * fld;
+      if (o.pdot) {
+        if ((rc = beat_vtl_pdot(pde, st, r, p_old, p_cur, q, i == 0))) return rc;
+      } else if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) {
+        return rc;
+      }
+      if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
+      if (slot == PR - 1) {
+        if ((rc = beat_pde_x_flush_terms(pde, st, o.x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR)))) return rc;
+      }
+      if (o.pdot) {  // the scalar roll alone: beta for the next pass, the latch, the iteration count
+        BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, st);
+        BEAT_LAUNCH_CHECK();
+      } else if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) {
+        return rc;
+      }
+    }
+  }
+  o.launched += count;
+  return BEAT_OK;
+}
+
+int beat_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                     double* dev_x, double* dev_work, double rtol, double atol, int max_it) {
+  BEAT_REQUIRE(pde != nullptr && dev_work != nullptr && dev_v_prev && dev_x, "null argument");
+  BEAT_REQUIRE(beat_solve_lazy_available(pde), "this operator's solves are not of the kind that can be left open");
+  BEAT_REQUIRE(!pde->open.on, "the previous solve has not been finished (beat_pde_solve_end)");
+  BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
+  BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
+  BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
+  BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
+  beat_ctx* ctx = pde->ctx;
+  if (pde->h_st == nullptr) {
+    BEAT_HIP_CHECK(hipHostMalloc((void**)&pde->h_st, sizeof(double) * 16, hipHostMallocDefault));
+    BEAT_HIP_CHECK(hipEventCreateWithFlags(&pde->ev_st, hipEventDisableTiming));
+  }
+  beat_pde::OpenSolve& o = pde->open;
+  o = beat_pde::OpenSolve{};
+  o.kind = beat_rr_available(pde) ? 0 : 1;
+  o.pdot = o.kind == 1 && beat_vtl_pdot_available(pde);
+  o.v_prev = dev_v_prev;
+  o.x = dev_x;
+  o.work = dev_work;
+  o.rtol = rtol;
+  o.atol = atol;
+  o.max_it = max_it;
+  const int64_t fld = beat_pde_field_stride(pde);
+  double* r = dev_work + pde->g.plane;
+  double* q = r + fld;
+  double* ring = q + 2 * fld;
+  double* st = pde->d_st;
+  int rc;
+  beat_guess_begin(pde);
+  if (o.kind == 0) {
+    rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
+  } else if (beat_vtl_rhs_available(pde)) {  // two tile passes (b = B v_ + dt stim, r = b - A (v_ + e)); q is free until iteration 0
+    rc = beat_vtl_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, q, st, pde->guess.use_e ? pde->guess.e : nullptr);
+  } else {  // the gather kernel: the guess increment e next to v_
+    rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, pde->guess.use_e ? pde->guess.e : nullptr);
+  }
+  if (rc) return rc;
+  if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
+  if ((rc = solve_enqueue_iterations(pde, std::min(beat_pde_first_chunk(pde), max_it)))) return rc;
+  BEAT_HIP_CHECK(hipMemcpyAsync(pde->h_st, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipEventRecord(pde->ev_st, ctx->stream));
+  o.on = true;
+  return BEAT_OK;
+}
+
+int beat_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* host_pending, bool* needed_more) {
+  BEAT_REQUIRE(pde != nullptr, "null pde");
+  if (host_pending) host_pending[0] = host_pending[1] = 0;
+  if (needed_more) *needed_more = false;
+  if (!pde->open.on) {  // nothing open: the record of the last solve that was finished
+    if (info) *info = pde->last_info;
+    return pde->last_rc;
+  }
+  BEAT_REQUIRE(!defer_flush || host_pending != nullptr, "defer_flush needs host_pending[2]");
+  beat_pde::OpenSolve& o = pde->open;
+  beat_ctx* ctx = pde->ctx;
+  double* h = pde->h_st;
+  double* st = pde->d_st;
+  const int64_t fld = beat_pde_field_stride(pde);
+  double* ring = o.work + pde->g.plane + 3 * fld;
+  const int PR = pde->ring;
+  int rc;
+  BEAT_HIP_CHECK(hipEventSynchronize(pde->ev_st));
+  while (!(h[STOP] != 0.0 || o.launched >= o.max_it)) {
+    if (needed_more) *needed_more = true;
+    if ((rc = solve_enqueue_iterations(pde, std::min(2, o.max_it - o.launched)))) {
+      o.on = false;
+      return rc;
+    }
+    BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  o.on = false;
+  pde->applied_behind = false;  // (step_behind_open_solve sets it again when its launch has applied this solve's update)
+  // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x) and / or the guess increment
+  const int nupd = (int)h[NUPD], base = (nupd / PR) * PR;
+  const GuessTerms last = beat_guess_terms(pde, base);
+  beat_guess_observe(pde, (int)h[ITERS]);
+  if (beat_guess_end(pde, nupd, defer_flush != 0)) {
+    if (defer_flush) {  // the caller adds these directions itself (beat_ode_step_pending / beat_pde_x_flush)
+      host_pending[0] = pde->last_base = base;
+      host_pending[1] = nupd % PR;
+    } else if ((rc = beat_pde_x_flush_terms(pde, st, o.x, ring, fld, base, 0, last))) {
+      return rc;
+    }
+  }
+  const int iters = (int)h[ITERS];
+  pde->last_iters = iters;
+  int reason = (int)h[REASON];
+  if (h[STOP] == 0.0) reason = -3;  // max_it == launched without the latch (max_it = 0)
+  pde->last_info.iterations = iters;
+  pde->last_info.converged_reason = reason;
+  pde->last_info.residual_norm = std::sqrt(h[RR]);
+  pde->last_info.rhs_norm = std::sqrt(h[BB]);
+  if (info) *info = pde->last_info;
+  pde->last_rc = BEAT_OK;
+  if (reason < 0) {
+    beat_set_error("PCG did not converge in %d iterations (||r|| = %.3e, ||b|| = %.3e)", iters, std::sqrt(h[RR]), std::sqrt(h[BB]));
+    pde->last_rc = BEAT_ENOTCONV;
+  }
+  return pde->last_rc;
+}
+
+extern "C" int beat_pde_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                                    const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
+                                    int max_it) {
+  return beat_solve_begin(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_work, rtol, atol, max_it);
+}
+extern "C" int beat_pde_solve_end(beat_pde* pde, beat_ksp_info* info, int* host_pending) {
+  BEAT_REQUIRE(host_pending != nullptr, "host_pending[2] expected");
+  return beat_solve_end(pde, 1, info, host_pending, nullptr);
+}
+extern "C" int beat_pde_solve_is_open(const beat_pde* pde) { return pde != nullptr && pde->open.on ? 1 : 0; }
+extern "C" int beat_pde_solve_can_open(const beat_pde* pde) { return beat_solve_lazy_available(pde) ? 1 : 0; }
+
 extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
                                  const double* const* host_dev_stim_w, const double* host_stim_amp,
                                  int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
@@ -1235,84 +1414,33 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
   BEAT_REQUIRE(pde != nullptr && dev_work != nullptr, "null argument");
   BEAT_REQUIRE(pde->g.z_lo_phys && pde->g.z_hi_phys, "beat_pde_solve is the single-slab path");
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
+  BEAT_REQUIRE(!pde->open.on, "the previous solve has not been finished (beat_pde_solve_end)");
   if (beat_small_available(pde)) {  // a few thousand nodes: the whole solve in one launch of one workgroup
     BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
     return beat_small_solve(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, rtol, atol, max_it, info);
+  }
+  if (beat_solve_lazy_available(pde)) {
+    // Jacobi with the register-row kernels (constant coefficients: the loop that never stores q = A p) or on per-node rows:
+    // enqueue, then wait -- the two halves a caller may also drive apart (beat_pde_solve_begin / _end)
+    if (int rc = beat_solve_begin(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_work, rtol, atol, max_it)) return rc;
+    return beat_solve_end(pde, defer_flush, info, host_pending, nullptr);
   }
   const int64_t fld = beat_pde_field_stride(pde);
   double* r = dev_work + pde->g.plane;
   double* q = r + fld;
   double* z = q + fld;     // only touched by the polynomial preconditioner
-  double* ring = z + fld;  // PRING search directions, ring[j] = ring + j*fld
+  double* ring = z + fld;  // pde->ring search directions, ring[j] = ring + j*fld
+  const int PR = pde->ring;
   double* st = pde->d_st;
   beat_ctx* ctx = pde->ctx;
   double* h = ctx->h_pinned;
   const int npass = pde->pc_ncoef - 1;
-  const bool rr = beat_rr_available(pde);  // constant coefficients + Jacobi: the loop that never stores q = A p
   int rc;
-  if (rr) {
-    BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
-    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
-    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
-    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
-    beat_guess_begin(pde);
-    rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
-  } else if (pde->var && npass == 0) {
-    // per-node rows, Jacobi: the right-hand side gathers the guess increment e next to v_
-    BEAT_REQUIRE(dev_v_prev && dev_x, "null argument");
-    BEAT_REQUIRE(pde->have_dt, "beat_pde_set_timestep has not been called");
-    BEAT_REQUIRE(n_stim >= 0 && n_stim <= BEAT_MAX_STIM, "at most %d stimuli", BEAT_MAX_STIM);
-    BEAT_REQUIRE(!pde->guess_pending, "the previous solve's deferred update has not been applied");
-    beat_guess_begin(pde);
-    if (beat_vtl_rhs_available(pde))  // two tile passes (K v_, then A on v_ and e) instead of the gather kernel; q is free until iteration 0
-      rc = beat_vtl_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, q, st,
-                        pde->guess.use_e ? pde->guess.e : nullptr);
-    else
-      rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st,
-                        pde->guess.use_e ? pde->guess.e : nullptr);
-  } else {
-    rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st);
-  }
-  if (rc) return rc;
+  if ((rc = beat_pde_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st))) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   int launched = 0;
   int chunk = beat_pde_first_chunk(pde);
-  if (rr) {
-    // iteration i: p_i = D^-1 r + beta p_{i-1} and p_i . A p_i in one pass (ring slot i % PRING), then
-    // r_new = r - alpha A p_i with A p_i recomputed (written to the other of the two residual buffers: the kernel
-    // then needs no store-before-load ordering), then the scalar roll
-    double* rbuf[2] = {r, q};
-    while (true) {
-      chunk = std::min(chunk, max_it - launched);
-      for (int it = 0; it < chunk; ++it) {
-        const int i = launched + it, slot = i % PRING;
-        double* p_cur = ring + (int64_t)slot * fld;
-        const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
-        if ((rc = beat_rr_pdot(pde, st, rbuf[i & 1], p_old, p_cur))) return rc;
-        if ((rc = beat_rr_rupd(pde, st, rbuf[i & 1], rbuf[(i + 1) & 1], p_cur, slot))) return rc;
-        if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
-            return rc;
-        }
-      }
-      launched += chunk;
-      BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
-      BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      if (h[STOP] != 0.0 || launched >= max_it) break;
-      chunk = 2;
-    }
-    const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
-    const GuessTerms last = beat_guess_terms(pde, base);
-    beat_guess_observe(pde, (int)h[ITERS]);
-    if (beat_guess_end(pde, nupd, defer_flush != 0)) {  // the last partial ring cycle and / or the guess increment
-      if (defer_flush) {
-        host_pending[0] = base;
-        host_pending[1] = nupd % PRING;
-      } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
-        return rc;
-      }
-    }
-  } else if (npass > 0) {
+  if (npass > 0) {
     // polynomial preconditioner: classic in-place recurrences with p = ring[0]
     double* p = ring;
     for (int j = 0; j < npass; ++j)
@@ -1334,34 +1462,20 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
       chunk = 2;
     }
   } else {
-    // Jacobi, deferred x: iteration i uses p_i = ring[i % PRING]
-    // per-node rows on one slab (round 4): the tile kernel forms p_i = D^-1 r + beta p_{i-1} while loading, stores it and
-    // q = A p_i in the same pass (beat_vtl_pdot) -- the direction update is no pass of its own any more (32 B/node and a
-    // launch per iteration); same expressions, same bits as the three-kernel iteration (BEAT_VTL_PDOT=0)
-    const bool pdot = pde->var && beat_vtl_pdot_available(pde);
+    // Jacobi on the LDS-tiled constant-coefficient kernels (BEAT_RR=0), deferred x: iteration i uses p_i = ring[i % PR]
     while (true) {
       chunk = std::min(chunk, max_it - launched);
       for (int it = 0; it < chunk; ++it) {
-        const int i = launched + it, slot = i % PRING;
+        const int i = launched + it, slot = i % PR;
         double* p_cur = ring + (int64_t)slot * fld;
-        double* p_next = ring + (int64_t)((i + 1) % PRING) * fld;
-        if (pdot) {
-          const double* p_old = ring + (int64_t)((i + PRING - 1) % PRING) * fld;
-          if ((rc = beat_vtl_pdot(pde, st, r, p_old, p_cur, q, i == 0))) return rc;
-        } else if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) {
-          return rc;
-        }
+        double* p_next = ring + (int64_t)((i + 1) % PR) * fld;
+        if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) return rc;
         if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
-        if (slot == PRING - 1) {  // ring full: bring x up to date before slot 0 is overwritten
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PRING, 1, beat_guess_terms(pde, i + 1 - PRING))))
+        if (slot == PR - 1) {  // ring full: bring x up to date before slot 0 is overwritten
+          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
             return rc;
         }
-        if (pdot) {  // the scalar roll alone: beta for the next pass, the latch, the iteration count
-          BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, st);
-          BEAT_LAUNCH_CHECK();
-        } else if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) {
-          return rc;
-        }
+        if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
       }
       launched += chunk;
       BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1369,15 +1483,14 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
       if (h[STOP] != 0.0 || launched >= max_it) break;
       chunk = 2;
     }
-    // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x) and / or the
-    // guess increment
-    const int nupd = (int)h[NUPD], base = (nupd / PRING) * PRING;
+    // directions of the last, partially filled ring cycle (stream-ordered before anything that reads x)
+    const int nupd = (int)h[NUPD], base = (nupd / PR) * PR;
     const GuessTerms last = beat_guess_terms(pde, base);
     beat_guess_observe(pde, (int)h[ITERS]);
     if (beat_guess_end(pde, nupd, defer_flush != 0)) {
       if (defer_flush) {  // the caller adds these directions itself (beat_ode_step_pending / beat_pde_x_flush)
-        host_pending[0] = base;
-        host_pending[1] = nupd % PRING;
+        host_pending[0] = pde->last_base = base;
+        host_pending[1] = nupd % PR;
       } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
         return rc;
       }
@@ -1387,16 +1500,16 @@ extern "C" int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev,
   pde->last_iters = iters;
   int reason = (int)h[REASON];
   if (h[STOP] == 0.0) reason = -3;  // max_it == launched without the latch (max_it = 0)
-  if (info) {
-    info->iterations = iters;
-    info->converged_reason = reason;
-    info->residual_norm = std::sqrt(h[RR]);
-    info->rhs_norm = std::sqrt(h[BB]);
-  }
+  pde->last_info.iterations = iters;
+  pde->last_info.converged_reason = reason;
+  pde->last_info.residual_norm = std::sqrt(h[RR]);
+  pde->last_info.rhs_norm = std::sqrt(h[BB]);
+  if (info) *info = pde->last_info;
+  pde->last_rc = BEAT_OK;
   if (reason < 0) {
     beat_set_error("PCG did not converge in %d iterations (||r|| = %.3e, ||b|| = %.3e)", iters,
                    std::sqrt(h[RR]), std::sqrt(h[BB]));
-    return BEAT_ENOTCONV;
+    pde->last_rc = BEAT_ENOTCONV;
   }
-  return BEAT_OK;
+  return pde->last_rc;
 }

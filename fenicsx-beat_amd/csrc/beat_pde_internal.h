@@ -15,7 +15,11 @@ enum St { BB = 0, RZ, RR, PQ, RZN, RRN, TOL2, BETA, STOP, ITERS, REASON, RTOL, A
 // ALPHA: the step length of the single-reduction iteration (beat_rr_merged_next), device side only: the host reads the first
 // 16 entries.  The operator's own scalar state (beat_pde::d_st) has BEAT_ST_DOUBLES entries.
 constexpr int BEAT_ST_DOUBLES = 32;
-constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date
+constexpr int PRING = 6;  // search directions kept by the deferred-x PCG before x must be brought up to date (default ring)
+// Per-node-row operators on a single slab keep PRING_MAX directions (beat_pde::ring): their solves take 9 - 12 iterations at the
+// reference's dt (profiles/r05_shell_guess.md), and with a ring of 6 every one of them paid an in-loop flush -- x and the guess's
+// fields read and written a second time, 48 B/node per step.  Kernels size their arrays by PRING_MAX and take the ring as an argument.
+constexpr int PRING_MAX = 12;
 constexpr int TABW = 16;  // padded row width of the device coefficient tables
 
 extern const int kOffsets[45];  // (dx, dy, dz) of the 15 stencil points
@@ -47,7 +51,28 @@ struct beat_pde {
   double* d_st = nullptr;  // 16 doubles, PCG scalar state of beat_pde_solve
   int last_iters = -1;
   unsigned vec_grid = 1;
-  double* d_alphas = nullptr;  // PRING step lengths of the deferred-x PCG
+  double* d_alphas = nullptr;  // PRING_MAX step lengths of the deferred-x PCG
+  // A solve that has been ENQUEUED and not yet looked at by the host (beat_pde_solve_begin / _end, round 5): right-hand side, the
+  // iterations the previous solve needed + 1 and the copy of the scalar state are in the stream, `ev_st` marks the copy.  The next
+  // ionic launch may be enqueued behind it before the host waits (PendingV::dev_st): the device does not idle while the host wakes up.
+  struct OpenSolve {
+    bool on = false;
+    int kind = 0;  // 0: register-row kernels (constant coefficients), 1: per-node rows
+    bool pdot = false;
+    const double* v_prev = nullptr;
+    double* x = nullptr;
+    double* work = nullptr;
+    double rtol = 0.0, atol = 0.0;
+    int max_it = 0, launched = 0;
+  } open;
+  double* h_st = nullptr;       // pinned copy of the scalar state of the open solve (16 doubles)
+  hipEvent_t ev_st = nullptr;   // recorded behind that copy
+  beat_ksp_info last_info{};    // of the last solve that was finished
+  bool applied_behind = false;  // its x update was applied by the launch enqueued behind it, with these terms (beat_pde_guess_traffic)
+  beat_pde_detail::GuessTerms applied_terms{};
+  int last_rc = 0;
+  int ring = beat_pde_detail::PRING;  // search directions kept before x is brought up to date (6; 12: per-node rows on a single slab)
+  int last_base = 0;                  // first iteration of the ring cycle the last deferring solve left pending
   double* d_batch_st = nullptr;  // scalar states of the solves of a beat_split_steps batch (BEAT_MAX_BATCH x 16)
   // z node type of the ghost planes (the neighbouring slabs' boundary planes): 1 unless that plane is a face of the
   // whole grid (a neighbour that owns a single plane); set with beat_pde_set_ghost_types
@@ -89,6 +114,7 @@ struct beat_pde {
   const double* v_stiff = nullptr;
   double* v_A = nullptr;
   double* v_dinv = nullptr;
+  double* v_B = nullptr;  // rows of B = C_m Mass - (1 - theta) dt K, formed beside A when the right-hand side runs on the tiles (beat_vtl_rhs)
   // a slab with live neighbours: the centre coefficients of the neighbours' boundary planes ([0, plane): below, [plane, 2 plane):
   // above), exchanged by beat_pde_solve_dist when v_gc0_valid is false (the operator changed) -- what the fused tile pass needs to
   // form the search direction on the ghost planes (beat_vtl_pdot_part)
@@ -169,9 +195,18 @@ int beat_vtl_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const
 int beat_vtl_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
 bool beat_vtl_pdot_available(const beat_pde* pde);
 bool beat_vtl_rhs_available(const beat_pde* pde);
+bool beat_vtl_rhs_wanted(const beat_pde* pde);
 int beat_vtl_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
                  double* dev_x, double* dev_r, double* dev_p, double* dev_t, double* dev_red, const double* dev_e);
 int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new, double* dev_q, int first);
+
+// the two halves of beat_pde_solve_ex for the Jacobi paths (beat_pde.hip): enqueue without waiting / wait, iterate on if needed, do
+// the host's bookkeeping.  beat_solve_end: *needed_more = the first look found the solve unlatched (a launch enqueued behind it
+// with PendingV::dev_st has done nothing); a solve that was never opened: the last finished solve's record
+bool beat_solve_lazy_available(const beat_pde* pde);
+int beat_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                     double* dev_x, double* dev_work, double rtol, double atol, int max_it);
+int beat_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* host_pending, bool* needed_more);
 
 // one-workgroup solve of small constant-coefficient grids (beat_pde_small.hip)
 bool beat_small_available(const beat_pde* pde);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 
 namespace {
@@ -70,6 +71,17 @@ struct RArgs {
   const double* e;
   const double* taba;
   Coef cia;
+};
+
+// the kernel-argument segment of rr_kernel as the hardware lays it out (every member naturally aligned): the right-hand-side
+// instances read their coefficient rows and scalars through an opaque pointer to it, per plane (see the kernel)
+struct RKernArgs {
+  RGeom g;
+  RArgs a;
+  const double* X;
+  const double* X2;
+  double* Y;
+  double* Y2;
 };
 
 // lane i <- lane i-1 (lane 0 <- 0) / lane i <- lane i+1 (lane 63 <- 0); all 64 lanes must be active
@@ -255,6 +267,15 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
       }
     }
     if (z >= zb) {
+    // RHS: the interior coefficient rows (B and A with a guess, Mass and K without: 2 x 15 doubles = 60 SGPRs), the scalars and
+    // the stimulus table are read from the kernel-argument segment through a pointer the optimiser cannot see through, HERE, once
+    // per plane -- as kernel parameters they are loop invariants, held in SGPRs from the top of the kernel on and, there being 106,
+    // spilled to VGPR lanes: 32 - 45 SGPRs, 49 v_readlane + 32 v_writelane in the 604 VALU instructions of <RHS, 2, 1, guess>
+    // (round 5; the recipe of beat_pde_vtl.hip).  Scalar loads from the constant cache, issued ahead of the stencil they feed.
+    typedef const __attribute__((address_space(4))) char* KArgPtr;
+    KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const RArgs& az = MODE == RR_RHS ? *(const RArgs*)(ka + offsetof(RKernArgs, a)) : a;
     // x-neighbours by lane shifts (every lane takes part)
     double L0[NR], R0[NR], Rp[NR], Lm[NR];
 #pragma unroll
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
         const int64_t gi = (int64_t)z * g.plane + (int64_t)(y0 + r) * g.nx + gx;
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 15; ++k) s = fma(a.ci.c[k], v[k], s);
+        for (int k = 0; k < 15; ++k) s = fma(az.ci.c[k], v[k], s);
         if (MODE == RR_RHS) {
           // without a guess: tab / tab2 = Mass / K, b = C_m Mass v - (1 - theta) dt K v + dt stim, r = dt (stim - K v);
           // with one: tab = B, the second window holds x0 = v + e, b = B v + dt stim, r = b - A x0 (the textbook form:
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           double s2 = 0.0;
           if (!GUESS) {
 #pragma unroll
-            for (int k = 0; k < 15; ++k) s2 = fma(a.ci2.c[k], v[k], s2);
+            for (int k = 0; k < 15; ++k) s2 = fma(az.ci2.c[k], v[k], s2);
           }
           double di = s_dinv[13];
           if (type != 13) {
@@ -327,9 +348,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
             di = s_dinv[type];
           }
           double stim = 0.0;
-          for (int k = 0; k < a.nstim; ++k) stim = fma(a.amp[k], a.w[k][gi], stim);
-          const double b = GUESS ? fma(a.dt, stim, s) : a.cm * s - a.omt_dt * s2 + a.dt * stim;
-          double rr = GUESS ? b : a.dt * (stim - s2);
+          for (int k = 0; k < az.nstim; ++k) stim = fma(az.amp[k], az.w[k][gi], stim);
+          const double b = GUESS ? fma(az.dt, stim, s) : az.cm * s - az.omt_dt * s2 + az.dt * stim;
+          double rr = GUESS ? b : az.dt * (stim - s2);
           if (GUESS) {  // - A x0
             constexpr int q = GUESS ? 1 : 0;  // (keeps the indices in range in the instantiations without a window)
             const int re_ = r * q, rp = (r + 1) * q, rm = (r - 1) * q;
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
               for (int k = 0; k < 15; ++k) se = fma(s_taba[type * TABW + k], ev[k], se);
             } else {
 #pragma unroll
-              for (int k = 0; k < 15; ++k) se = fma(a.cia.c[k], ev[k], se);
+              for (int k = 0; k < 15; ++k) se = fma(az.cia.c[k], ev[k], se);
             }
             rr -= se;
           }

@@ -458,13 +458,13 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
                                                                const double* __restrict__ st, double* __restrict__ x,
                                                                const double* __restrict__ ring, int64_t fld,
                                                                const double* __restrict__ alphas, int ring_base,
-                                                               int only_if_full, GuessTerms gt) {
+                                                               int only_if_full, GuessTerms gt, int R) {
   int nvalid = (int)st[NUPD] - ring_base;
-  nvalid = nvalid < 0 ? 0 : (nvalid > PRING ? PRING : nvalid);
-  if ((only_if_full && nvalid < PRING) || (nvalid == 0 && gt.d == nullptr)) return;
-  double a[PRING];
+  nvalid = nvalid < 0 ? 0 : (nvalid > R ? R : nvalid);
+  if ((only_if_full && nvalid < R) || (nvalid == 0 && gt.d == nullptr)) return;
+  double a[PRING_MAX];
 #pragma unroll
-  for (int j = 0; j < PRING; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
+  for (int j = 0; j < PRING_MAX; ++j) a[j] = (j < nvalid) ? alphas[j] : 0.0;
   for (int w = blockIdx.x * VAR_SEGS_PER_BLOCK + var_wave(); w < nseg; w += gridDim.x * VAR_SEGS_PER_BLOCK) {
     const int64_t i = (int64_t)seg[w] * VAR_SEG + threadIdx.x % VAR_SEG;
     if (i >= n || !((segmask[w] >> (threadIdx.x % VAR_SEG)) & 1ull)) continue;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
       const double dp1 = beat_guess_needs_dp(gt, 1) ? gt.dp[1][i] : 0.0;
       double inc = gt.accumulate ? 0.0 : e_old;
 #pragma unroll
-      for (int j = 0; j < PRING; ++j)
+      for (int j = 0; j < PRING_MAX; ++j)
         if (j < nvalid) inc = fma(a[j], ring[(int64_t)j * fld + i], inc);
       x[i] += inc;
       beat_guess_record(gt, gt.d + i, gt.e + i, inc, d_old, dp0, dp1, e_old);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_flush_kernel(const int* __rest
     }
     double xi = x[i];
 #pragma unroll
-    for (int j = 0; j < PRING; ++j)
+    for (int j = 0; j < PRING_MAX; ++j)
       if (j < nvalid) xi = fma(a[j], ring[(int64_t)j * fld + i], xi);
     x[i] = xi;
   }
@@ -502,10 +502,12 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_segment_flags_kernel(int64_t n
   }
 }
 
-// A = C_m Mass + theta dt K per node, 1/diag(A); rows without any element (inactive voxels) become identity
+// A = C_m Mass + theta dt K per node, 1/diag(A); rows without any element (inactive voxels) become identity.  B (or nullptr):
+// the rows of C_m Mass - (1 - theta) dt K, the operator of the right-hand side b = B v_ + dt stim (beat_vtl_rhs)
 __global__ __launch_bounds__(BEAT_BLOCK) void var_form_A_kernel(int64_t n, int64_t ld, const double* __restrict__ M,
-                                                                const double* __restrict__ K, double cm, double tdt,
-                                                                double* __restrict__ A, double* __restrict__ dinv) {
+                                                                const double* __restrict__ K, double cm, double tdt, double omt_dt,
+                                                                double* __restrict__ A, double* __restrict__ dinv,
+                                                                double* __restrict__ B) {
   const int64_t stride = (int64_t)gridDim.x * BEAT_BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x; i < n; i += stride) {
     double d = cm * M[i] + tdt * K[i];
@@ -513,10 +515,12 @@ __global__ __launch_bounds__(BEAT_BLOCK) void var_form_A_kernel(int64_t n, int64
     if (inactive) d = 1.0;
     A[i] = d;
     dinv[i] = 1.0 / d;
+    if (B != nullptr) B[i] = inactive ? 1.0 : cm * M[i] - omt_dt * K[i];
 #pragma unroll
     for (int k = 1; k < 15; ++k) {
       const int64_t j = (int64_t)k * ld + i;
       A[j] = inactive ? 0.0 : cm * M[j] + tdt * K[j];
+      if (B != nullptr) B[j] = inactive ? 0.0 : cm * M[j] - omt_dt * K[j];
     }
   }
 }
@@ -756,8 +760,16 @@ static unsigned var_vec_grid(const beat_pde* pde) {
 int beat_var_form_A(beat_pde* pde) {
   pde->v_gc0_valid = false;  // the neighbours' centre coefficients change with theta dt as well
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (pde->n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  if (pde->v_B == nullptr && beat_vtl_rhs_wanted(pde)) {
+    // the rows of B for the right-hand side on the tiles: 120 B/node more (401^3 box: 7.7 GB); without the memory the gather
+    // kernel keeps building the right-hand side from the rows of K
+    if (hipMalloc(&pde->v_B, sizeof(double) * 15 * (size_t)pde->v_ld) != hipSuccess) {
+      (void)hipGetLastError();
+      pde->v_B = nullptr;
+    }
+  }
   BEAT_KERNEL(var_form_A_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, pde->n, pde->v_ld,
-                     pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, pde->v_A, pde->v_dinv);
+                     pde->v_mass, pde->v_stiff, pde->C_m, pde->theta * pde->dt, (1.0 - pde->theta) * pde->dt, pde->v_A, pde->v_dinv, pde->v_B);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }
@@ -775,6 +787,11 @@ extern "C" int beat_pde_create_var(beat_ctx* ctx, const int64_t n[3], int z_lo_p
   p->v_mass = dev_mass;
   p->v_stiff = dev_stiff;
   p->v_ld = ld;
+  // a single slab keeps 12 search directions before x is brought up to date (see PRING_MAX; BEAT_VAR_RING=6: as the other paths)
+  if (z_lo_phys && z_hi_phys) {
+    const char* e = std::getenv("BEAT_VAR_RING");
+    p->ring = (e && std::atoi(e) == PRING) ? PRING : PRING_MAX;
+  }
   if (hipMalloc(&p->v_A, sizeof(double) * 15 * (size_t)ld) != hipSuccess ||
       hipMalloc(&p->v_dinv, sizeof(double) * (size_t)ld) != hipSuccess ||
       (!(z_lo_phys && z_hi_phys) && hipMalloc(&p->v_gc0, sizeof(double) * 2 * (size_t)(n[0] * n[1])) != hipSuccess)) {
@@ -1047,7 +1064,7 @@ int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const dou
                    int ring_base, int only_if_full, const GuessTerms& gt) {
   BEAT_KERNEL(var_flush_kernel, dim3(var_vec_grid(pde)), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
                      (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask, (int)pde->h_seg.size(), pde->n, dev_st, dev_x, dev_ring0, field_stride,
-                     (const double*)pde->d_alphas, ring_base, only_if_full, gt);
+                     (const double*)pde->d_alphas, ring_base, only_if_full, gt, pde->ring);
   BEAT_LAUNCH_CHECK();
   return BEAT_OK;
 }

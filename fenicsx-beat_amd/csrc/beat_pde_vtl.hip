@@ -73,9 +73,12 @@ struct VtlArgs {
   // previous direction kept there and these, and stored there, so that p itself is never exchanged.  nullptr: a physical face.
   const double* gc0_lo;
   const double* gc0_hi;
-  // RHS (mode 2, the right-hand side of a step in residual form, what var_rhs_kernel computes): x = v_, r = the guess
-  // increment e (or nullptr), t = K v_ (from a plain tile pass over the stiffness rows), y = the residual r0 - A e with
-  // r0 = dt (stim - K v_), pnew = D^-1 r; per-tile partials of b.b (b = A v_ + r0), r.z and r.r
+  // The right-hand side of a step in two single-window passes (round 5; the constant-coefficient kernels' formulation,
+  // beat_pde_rr.hip: b = B v_ + dt stim, r = b - A x0):
+  //   BV  (mode 2): rows = the rows of B, x = v_, y = b (stored), per-tile partials of b.b
+  //   RES (mode 4): rows = A, x = the guess increment e (or nullptr), r = v_ -- the window holds x0 = v_ + e, formed while loading
+  //                 as PDOT forms the direction --, t = b, y = the residual b - A x0, pnew = D^-1 r (or nullptr: not wanted),
+  //                 per-tile partials of r.z and r.r (slots 1 and 2)
   const double* t;
   double dt;
   const double* w[BEAT_MAX_STIM];
@@ -116,17 +119,18 @@ __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsi
 // forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
 // 13 +x+y+z; the backward slot k+1 pairs with the forward slot k.  F[] below holds them in that order.
 template <int RY, bool DYN, int MODE>
-__global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(VtlArgs a_) {  // MODE: 0 q = A p | 1 PDOT | 2 RHS | 3 PDOT, live neighbours
-  constexpr bool PDOT = MODE == 1 || MODE == 3, RHS = MODE == 2;
+__global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {  // MODE: 0 q = A p | 1 PDOT | 2 BV | 3 PDOT, live neighbours | 4 RES
+  constexpr bool PDOT = MODE == 1 || MODE == 3, BV = MODE == 2, RES = MODE == 4;
+  constexpr bool FORMED = PDOT || RES;  // the window's values are formed from several loads (PDOT: r, p_old, c0; RES: v_, e)
   constexpr bool GHOST = MODE == 3;  // PDOT on a slab with live neighbours: the direction is formed and kept on the ghost planes too
-  constexpr int NPE = RHS ? 4 : 2;  // halo entries that are rows of a vector: p below / above (RHS: v_ below / above, e below / above)
+  constexpr int NPE = 2;  // halo entries that are rows of a vector: p below / above
   // one LDS array: p of plane z+1 for rows y0-1 .. y0+RY of the tile (two buffers), slots 3, 7, 9, 13 of plane z for rows
   // y0-1 .. y0+RY-2 (two buffers), and a row per wave that absorbs the stores of a wave without a (second) halo load
   constexpr int P_PAR = (RY + 2) * 64, C_PAR = RY * 4 * 64;
-  constexpr int P_BASE = 0, C_BASE = 2 * P_PAR, DUMMY = C_BASE + 2 * C_PAR, P2_BASE = DUMMY + RY * 64;  // (P2: the second vector of RHS)
+  constexpr int P_BASE = 0, C_BASE = 2 * P_PAR, DUMMY = C_BASE + 2 * C_PAR;
   constexpr bool TWO = RY < NPE + 4;  // NPE + 4 halo loads per plane: two per wave when a tile has fewer rows than that
-  static_assert(!RHS || !TWO, "the right-hand side pass is built for tiles of 8 rows");
-  __shared__ double lds[P2_BASE + (RHS ? 2 * P_PAR : 0)];
+  static_assert(!(RES || BV) || !TWO, "the right-hand side passes are built for tiles of 8 rows");
+  __shared__ double lds[DUMMY + RY * 64];
   __shared__ double red[3 * RY];
   __shared__ int next_item;
   if (a_.st[STOP] != 0.0 && !a_.ignore_stop) return;
@@ -206,11 +210,17 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       double r, q, c0;
     };
     auto form = [&](const Trio& t) -> double {
-      const double di = 1.0 / t.c0;
-      const double zz = di * t.r;
-      const double pv = first ? zz : fma(beta, t.q, zz);
-      return t.c0 != 0.0 ? pv : 0.0;  // (a lane that loaded nothing: c0 = 0)
+      if constexpr (RES) {
+        return t.r + t.q;  // x0 = v_ + e (a lane that loaded nothing: 0 + 0; without a guess e is not read: + 0)
+      } else {
+        const double di = 1.0 / t.c0;
+        const double zz = di * t.r;
+        const double pv = first ? zz : fma(beta, t.q, zz);
+        return t.c0 != 0.0 ? pv : 0.0;  // (a lane that loaded nothing: c0 = 0)
+      }
     };
+    // RES: the second operand of a formed value is the guess increment; nullptr (no guess on record): never read
+    const bool no_second = RES ? X == nullptr : first;
     // centre coefficients of plane z: slot 0 of the rows, or the neighbour's plane on a ghost plane
     auto c0_of = [&](int z) -> const double* {
       if constexpr (GHOST) {
@@ -229,13 +239,13 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       const double* Rr = ((const VtlArgs*)kr)->r;
       Trio t;
       t.r = vtl_buf_load(Rr + (int64_t)z * a.plane, pbytes, off);
-      t.q = vtl_buf_load(X + (int64_t)z * a.plane, pbytes, first ? VTL_OOB : off);
-      t.c0 = vtl_buf_load(c0_of(z), pbytes, off);
+      t.q = vtl_buf_load(X + (int64_t)z * a.plane, pbytes, no_second ? VTL_OOB : off);
+      t.c0 = RES ? 0.0 : vtl_buf_load(c0_of(z), pbytes, off);
       return t;
     };
     // (a ghost plane of a physical face: its mask is empty, nothing is loaded, p = 0; the decomposed solve does not come here)
     auto ldpv = [&](u64 mk, int z, unsigned ro) -> double {  // p at (row ro, plane z), straight from memory
-      if constexpr (PDOT) {
+      if constexpr (FORMED) {
         return form(ld3(mk, z, ro));
       } else {
         return ldp(mk, z, ro);
@@ -263,22 +273,15 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       asm volatile("" : "+s"(ld));
       const int slot = (0xD973 >> (4 * ((e - NPE) & 3))) & 15;  // 3, 7, 9, 13
       Trio t{0.0, 0.0, 0.0};
-      if constexpr (PDOT) {
-        // a p entry is three loads (r, p_old, c0), a coefficient entry one: the two others run with every lane out of range
+      if constexpr (FORMED) {
+        // a p entry is three loads (r, p_old, c0; RES: v_, e), a coefficient entry one: the others run with every lane out of range
         KArgPtr kr = ka;
         asm volatile("" : "+s"(kr));
         const double* base = is_p ? ((const VtlArgs*)kr)->r : A + slot * ld;
         const unsigned off = lane_off(m, ro), offp = is_p ? off : VTL_OOB;
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, off);
-        t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, first ? VTL_OOB : offp);
-        t.c0 = vtl_buf_load(c0_of(zz), pbytes, offp);
-      } else if constexpr (RHS) {
-        KArgPtr kr = ka;
-        asm volatile("" : "+s"(kr));
-        const double* E = ((const VtlArgs*)kr)->r;  // the guess increment, or nullptr: nothing loaded, 0
-        const bool is_e = is_p && (e & 2) != 0;
-        const double* base = is_p ? (is_e ? E : X) : A + slot * ld;
-        t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, (is_e && E == nullptr) ? VTL_OOB : lane_off(m, ro));
+        t.q = vtl_buf_load(X + (int64_t)zz * a.plane, pbytes, no_second ? VTL_OOB : offp);
+        t.c0 = RES ? 0.0 : vtl_buf_load(c0_of(zz), pbytes, offp);
       } else {
         const double* base = is_p ? X : A + slot * ld;
         t.r = vtl_buf_load(base + (int64_t)zz * a.plane, pbytes, lane_off(m, ro));
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       return t;
     };
     auto halo_value = [&](int e, const Trio& t) -> double {  // what is published: p of the halo row, or the coefficient
-      if constexpr (PDOT) {
+      if constexpr (FORMED) {
         return e < 2 ? form(t) : t.r;
       } else {
         return t.r;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
     };
     auto halo_lds = [&](int e, int z) -> int {  // where step z publishes it
       const int par = (e < NPE ? z + 1 : z) & 1;
-      const int p_at = ((e & 2) ? P2_BASE : P_BASE) + par * P_PAR + (e & 1) * (RY + 1) * 64, c_at = C_BASE + par * C_PAR + (e - NPE) * 64;
+      const int p_at = P_BASE + par * P_PAR + (e & 1) * (RY + 1) * 64, c_at = C_BASE + par * C_PAR + (e - NPE) * 64;
       const int at = e < NPE ? p_at : c_at;
       return e >= NPE + 4 ? DUMMY + w * 64 : at;
     };
@@ -303,11 +306,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
     u64 M0 = MASK[mo_own + zb], M1 = MASK[mo_own + zb + 1], M2 = MASK[mo_own + zb + 2];
     double Pm, P0, U0, D0, Dm, K5, K9, K11, K13;
     double C0keep = 0.0;  // PDOT: the centre coefficient of the plane after this one's p was formed from, until it is F[0]
-    double Em = 0.0, E0 = 0.0, EU0 = 0.0, ED0 = 0.0, EDm = 0.0, acc1 = 0.0, acc2 = 0.0;  // RHS: the second vector's window; partials
-    const double* __restrict__ Ev = RHS ? a.r : nullptr;
-    auto lde = [&](u64 mk, int z, unsigned ro) -> double {
-      return vtl_buf_load(Ev + (int64_t)z * a.plane, pbytes, Ev != nullptr ? lane_off(mk, ro) : VTL_OOB);
-    };
+    double acc1 = 0.0, acc2 = 0.0;  // RES: the partials of r.z and r.r
     const u64 out_lanes = ((1ull << SEG) - 1ull) << 1;
     bool direct = zb == 0;
     {
@@ -317,7 +316,9 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       const unsigned roff_dn = (unsigned)(max(gy - 1, 0) * a.nx + cx);
       const u64 mo = MASK[mo_own + zb - 1], md = MASK[mo_dn + zb - 1];
       Pm = ldpv(mo, zb - 1, roff);
-      if constexpr (PDOT) {
+      if constexpr (RES) {
+        P0 = form(ld3(M0, zb, roff));
+      } else if constexpr (PDOT) {
 
         const Trio t0 = ld3(M0, zb, roff);
         P0 = form(t0);
@@ -338,13 +339,6 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       U0 = ldpv(MASK[mo_up + zb], zb, roff_up);
       D0 = ldpv(MASK[mo_dn + zb], zb, roff_dn);
       Dm = ldpv(md, zb - 1, roff_dn);
-      if constexpr (RHS) {
-        Em = lde(mo, zb - 1, roff);
-        E0 = lde(M0, zb, roff);
-        EU0 = lde(MASK[mo_up + zb], zb, roff_up);
-        ED0 = lde(MASK[mo_dn + zb], zb, roff_dn);
-        EDm = lde(md, zb - 1, roff_dn);
-      }
       // coefficients of the plane below towards this one: slots 5 / 11 of the own row, 9 / 13 of the row below.  Plane 0
       // of a slab has no stored plane below it: its own backward slots 6, 10, 12, 14 are used as they are (what
       // var_spmv_kernel does; zero on a physical face)
@@ -376,17 +370,14 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       }
     };
     load_coefs(M0, zb);
-    double Pn = 0.0, En = 0.0, Kvn = 0.0;
+    double Pn = 0.0, Bn = 0.0;
     Trio Tn{0.0, 0.0, 0.0};
-    if constexpr (PDOT) {
+    if constexpr (FORMED) {
       Tn = ld3(M1, zb + 1, roff);
     } else {
       Pn = ldp(M1, zb + 1, roff);
     }
-    if constexpr (RHS) {
-      En = lde(M1, zb + 1, roff);
-      Kvn = vtl_buf_load(a.t + (int64_t)zb * a.plane, pbytes, lane_off(M0, roff));  // K v_ of this plane
-    }
+    if constexpr (RES) Bn = vtl_buf_load(a.t + (int64_t)zb * a.plane, pbytes, lane_off(M0, roff));  // b of this plane
     Trio Ean = halo_load(ea, halo_mask(ea, moff_a, zb - 1), roff_a, zb - 1);
     Trio Ebn{0.0, 0.0, 0.0};
     if (TWO) Ebn = halo_load(eb, halo_mask(eb, moff_b, zb - 1), roff_b, zb - 1);
@@ -401,6 +392,7 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
 #pragma unroll
       for (int k = 0; k < 8; ++k) F[k] = Fn[k];
       double Pp = Pn;
+      if constexpr (RES) Pp = form(Tn);  // x0 of plane z + 1
       if constexpr (PDOT) {
         Pp = form(Tn);  // p of plane z + 1, from what step z - 1 requested
         F[0] = C0keep;
@@ -410,27 +402,23 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
         vtl_buf_store(az.pnew + (int64_t)(z + 1) * a.plane, pbytes, (keep && (M1 & lanebit & out_lanes)) ? roff * 8u : VTL_OOB, Pp);
       }
       const double Ea = halo_value(ea, Ean), Eb = TWO ? halo_value(eb, Ebn) : 0.0;
-      const double Ep = En, Kv = Kvn;
+      const double Bv = Bn;
       // masks: one step (the halo loads') and two steps (the own row's) ahead of their use
       const u64 M3 = MASK[mo_own + z + 3];
       const u64 HAn = halo_mask(ea, moff_a, z + 1);
       const u64 HBn = TWO ? halo_mask(eb, moff_b, z + 1) : 0ull;
       // next step's operands
       load_coefs(z + 1 < ze ? M1 : 0ull, z + 1);
-      if constexpr (PDOT) {
+      if constexpr (FORMED) {
         Tn = ld3(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
       } else {
         Pn = ldp(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
       }
-      if constexpr (RHS) {
-        En = lde(z + 2 <= ze ? M2 : 0ull, z + 2, roff);
-        Kvn = vtl_buf_load(az.t + (int64_t)(z + 1) * a.plane, pbytes, lane_off(z + 1 < ze ? M1 : 0ull, roff));
-      }
+      if constexpr (RES) Bn = vtl_buf_load(az.t + (int64_t)(z + 1) * a.plane, pbytes, lane_off(z + 1 < ze ? M1 : 0ull, roff));
       Ean = halo_load(ea, HA, roff_a, z);
       if (TWO) Ebn = halo_load(eb, HB, roff_b, z);
       // publish this row
       lds[P_BASE + ((z + 1) & 1) * P_PAR + (w + 1) * 64 + lane] = Pp;
-      if constexpr (RHS) lds[P2_BASE + ((z + 1) & 1) * P_PAR + (w + 1) * 64 + lane] = Ep;
       {
         double* __restrict__ cw = lds + (w + 1 < RY ? C_BASE + (z & 1) * C_PAR + (w + 1) * 4 * 64 : DUMMY + w * 64) + lane;
         const int cs = w + 1 < RY ? 64 : 0;
@@ -444,12 +432,6 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       __syncthreads();
       const double* __restrict__ pr = lds + P_BASE + ((z + 1) & 1) * P_PAR + w * 64 + lane;
       const double Dn = pr[0], Un = pr[128];
-      double EDn = 0.0, EUn = 0.0;
-      if constexpr (RHS) {
-        const double* __restrict__ pe = lds + P2_BASE + ((z + 1) & 1) * P_PAR + w * 64 + lane;
-        EDn = pe[0];
-        EUn = pe[128];
-      }
       const double* __restrict__ cr = lds + C_BASE + (z & 1) * C_PAR + w * 4 * 64 + lane;
       const double H3 = cr[0], H7 = cr[64], H9 = cr[128], H13 = cr[192];
       double c[15], v[15];
@@ -489,47 +471,24 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
 #pragma unroll
       for (int k = 0; k < 15; ++k) s = fma(c[k], (k == 0 || c[k] != 0.0) ? v[k] : 0.0, s);
       const bool out = (M0 & lanebit & out_lanes) != 0ull;
-      if constexpr (RHS) {
-        // s = A v_; the same coefficients on the window of the guess increment: se = A e
-        double ve[15];
-        ve[0] = E0;
-        ve[1] = vtl_from_right(E0);
-        ve[2] = vtl_from_left(E0);
-        ve[3] = EU0;
-        ve[4] = ED0;
-        ve[5] = Ep;
-        ve[6] = Em;
-        ve[7] = vtl_from_right(EU0);
-        ve[8] = vtl_from_left(ED0);
-        ve[9] = EUn;
-        ve[10] = EDm;
-        ve[11] = vtl_from_right(Ep);
-        ve[12] = vtl_from_left(Em);
-        ve[13] = vtl_from_right(EUn);
-        ve[14] = vtl_from_left(EDm);
-        double se = 0.0;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) se = fma(c[k], (k == 0 || c[k] != 0.0) ? ve[k] : 0.0, se);
-        // r0 = dt (stim - K v_), b = A v_ + r0, r = r0 - A e, z = D^-1 r: var_rhs_kernel's expressions (same bits)
+      if constexpr (BV) {
+        // b = B v_ + dt stim (rr_kernel's expression for the constant-coefficient grids), stored for the second pass
         double stim = 0.0;
         for (int k = 0; k < az.nstim; ++k)
           stim = fma(az.amp[k], vtl_buf_load(az.w[k] + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB), stim);
-        const double r0 = az.dt * (stim - Kv);
-        const double b = s + r0;
-        const double rr = r0 - se;
+        const double b = fma(az.dt, stim, s);
+        acc = fma(out ? b : 0.0, b, acc);
+        vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, b);
+      } else if constexpr (RES) {
+        // s = A x0: r = b - A x0 (the textbook form: its rounding error is ~1e-16 |b|, far below any threshold rtol |b|), z = D^-1 r
+        const double rr = Bv - s;
         const double zz = (1.0 / F[0]) * rr;
         if (out) {
-          acc = fma(b, b, acc);
           acc1 = fma(rr, zz, acc1);
           acc2 = fma(rr, rr, acc2);
         }
         vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, rr);
-        vtl_buf_store(az.pnew + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, zz);
-        Em = E0;
-        E0 = Ep;
-        EU0 = EUn;
-        EDm = ED0;
-        ED0 = EDn;
+        vtl_buf_store(az.pnew + (int64_t)z * a.plane, pbytes, (out && az.pnew != nullptr) ? roff * 8u : VTL_OOB, zz);
       } else {
         acc = fma(out ? P0 : 0.0, s, acc);  // (an inactive lane's P0 is 0 anyway; s is finite)
         vtl_buf_store(az.y + (int64_t)z * a.plane, pbytes, out ? roff * 8u : VTL_OOB, s);
@@ -551,21 +510,22 @@ __global__ __launch_bounds__(RY * 64, MODE == 2 ? 2 : 4) void vtl_spmv_kernel(Vt
       HA = HAn;
       HB = HBn;
     }
-    // the tile's share of p.q (RHS: of b.b, r.z, r.r), summed in wave order
-    acc = beat_wave_sum(acc);
-    if (lane == 0) red[w] = acc;
-    if constexpr (RHS) {
+    // the tile's share of p.q (BV: of b.b in slot 0; RES: of r.z and r.r in slots 1 and 2), summed in wave order
+    if constexpr (RES) {
       acc1 = beat_wave_sum(acc1);
       acc2 = beat_wave_sum(acc2);
       if (lane == 0) {
         red[RY + w] = acc1;
         red[2 * RY + w] = acc2;
       }
+    } else {
+      acc = beat_wave_sum(acc);
+      if (lane == 0) red[w] = acc;
     }
     __syncthreads();
     if (w == 0) {
 #pragma unroll
-      for (int q = 0; q < (RHS ? 3 : 1); ++q) {
+      for (int q = (RES ? 1 : 0); q < (RES ? 3 : 1); ++q) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < RY; ++k) t += red[q * RY + k];
@@ -589,7 +549,7 @@ struct VtlData {
   int ry = 4;
   bool dyn = false;
   bool pdot = true;  // BEAT_VTL_PDOT=0: the three-kernel iteration (SpMV, residual update, direction update)
-  bool rhs = false;  // BEAT_VTL_RHS=1: the right-hand side in two tile passes instead of var_rhs_kernel's gathers
+  bool rhs = true;   // the right-hand side in two tile passes (beat_vtl_rhs); BEAT_VTL_RHS=0: var_rhs_kernel's gathers
   VtlItem* d_items = nullptr;
   int* d_xcd_first = nullptr;  // per list 9 entries: the part of the list each XCD walks; then 9 counters (next tile per XCD, workgroups done)
   u64* d_mask = nullptr;
@@ -648,11 +608,11 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
     d->dyn = dy && dy[0] == '1';
     const char* pd = std::getenv("BEAT_VTL_PDOT");
     d->pdot = !(pd && pd[0] == '0');
-    // the right-hand side in two tile passes (beat_vtl_rhs) is opt-in, BEAT_VTL_RHS=1: correct (same bits as var_rhs_kernel),
-    // but the pass with two vector windows needs 166 VGPRs -- one workgroup of 8 waves per CU -- and a whole extra product
-    // for K v_: 10.62 -> 10.55 ms per shell step (tools/bench_biv.py --n 400, A B A B on one box), not worth a default
+    // the right-hand side in two single-window tile passes (beat_vtl_rhs, round 5) is the default on single slabs with tiles
+    // of 8 rows; BEAT_VTL_RHS=0 keeps var_rhs_kernel's gathers.  (Round 4's version -- K v_ in a first pass, then ONE pass over A
+    // with two vector windows, 166 VGPRs and one workgroup per CU -- measured 1.12 against 1.30 ms and stayed opt-in; it is gone.)
     const char* rh = std::getenv("BEAT_VTL_RHS");
-    d->rhs = rh && rh[0] == '1';
+    d->rhs = !(rh && rh[0] == '0');
   }
   int max_run = 16;
   if (const char* e = std::getenv("BEAT_VTL_RUN")) max_run = std::max(1, std::atoi(e));
@@ -815,12 +775,12 @@ int beat_vtl_setup(beat_pde* pde, const std::vector<unsigned long long>& flags) 
 
 bool beat_vtl_available(const beat_pde* pde) { return pde->var && pde->vtl != nullptr && ((VtlData*)pde->vtl)->nitems > 0; }
 
-// what the two passes of the right-hand side add to a launch: other coefficient rows (pass 1: K), or mode 2 with its operands
+// what the two passes of the right-hand side add to a launch
 struct VtlRhs {
   const double* rows;  // coefficient rows of this pass (nullptr: A)
-  int mode;            // 0: plain product with `rows`; 2: the right-hand side pass
-  const double* e;     // guess increment or nullptr
-  const double* t;     // K v_
+  int mode;            // 2: b = rows v_ + dt stim (rows = B); 4: r = b - A (v_ + e)
+  const double* e;     // mode 4: guess increment or nullptr
+  const double* t;     // mode 4: b
   double dt;
   const double* w[BEAT_MAX_STIM];
   double amp[BEAT_MAX_STIM];
@@ -850,8 +810,8 @@ bool beat_vtl_pdot_available(const beat_pde* pde) {
 
 static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, const double* dev_r, double* dev_p_new, int first,
                       int list, int part_off, bool reduce, int reduce_count, const VtlRhs* rhs) {
-  const bool rhs2 = rhs != nullptr && rhs->mode == 2;
-  const bool pdot = dev_r != nullptr && !rhs2;
+  const bool bv = rhs != nullptr && rhs->mode == 2, res = rhs != nullptr && rhs->mode == 4;
+  const bool pdot = dev_r != nullptr && !res;
   VtlData* d = (VtlData*)pde->vtl;
   const Geom& f = pde->g;
   VtlArgs a{};
@@ -875,8 +835,7 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   a.y = dev_q;
   a.rows = (rhs != nullptr && rhs->rows != nullptr) ? rhs->rows : pde->v_A;
   a.ignore_stop = rhs != nullptr;
-  if (rhs2) {
-    a.t = rhs->t;
+  if (bv) {
     a.dt = rhs->dt;
     a.nstim = rhs->nstim;
     for (int k = 0; k < rhs->nstim; ++k) {
@@ -884,11 +843,15 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
       a.amp[k] = rhs->amp[k];
     }
   }
+  if (res) {
+    a.t = rhs->t;
+    a.x = rhs->e;  // the second operand of the formed window (nullptr: no guess on record)
+  }
   a.mask = d->d_mask;
   a.items = d->d_items;
   a.xcd_first = d->d_xcd_first + 9 * list;
   a.next = d->d_xcd_first + 27;
-  a.r = rhs2 ? rhs->e : dev_r;
+  a.r = res ? dev_p : dev_r;  // (RES: the first operand of the formed window is v_, passed as dev_p)
   a.pnew = dev_p_new;
   a.first = first ? 1 : 0;
   if (pdot && pde->v_gc0 != nullptr) {  // a slab with live neighbours: the direction is formed and kept on the ghost planes too
@@ -897,8 +860,10 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
     if (a.gc0_lo != nullptr) a.first |= 2;
   }
   auto launch = [&](auto kernel, int ry) { BEAT_KERNEL(kernel, dim3(grid), dim3(ry * 64), 0, pde->ctx->stream, a); };
-  if (rhs2) {
+  if (bv) {
     launch(vtl_spmv_kernel<8, false, 2>, 8);
+  } else if (res) {
+    launch(vtl_spmv_kernel<8, false, 4>, 8);
   } else if (pdot) {  // (tiles dealt round-robin: the counter of BEAT_VTL_DYNAMIC serves the plain SpMV only)
     (a.gc0_lo != nullptr || a.gc0_hi != nullptr) ? launch(vtl_spmv_kernel<8, false, 3>, 8) : launch(vtl_spmv_kernel<8, false, 1>, 8);
   } else if (d->ry == 8) {
@@ -908,16 +873,27 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   }
   BEAT_LAUNCH_CHECK();
   if (!reduce) return BEAT_OK;
-  if (rhs2) return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr);
+  if (res) return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr);  // (b.b from the BV pass, r.z and r.r from this one)
   return beat_pde_launch_reduce(pde, reduce_count ? reduce_count : count, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
 }
 
-// The right-hand side of a step on the tiles (what beat_var_rhs computes with gathers, 340 B/node from beyond the L2 on the
-// 401^3 shell against 168 algorithmic): pass 1, the plain tile product over the STIFFNESS rows, t = K v_; pass 2, the tile
-// pass over A with TWO vector windows (v_ and the guess increment e), r0 = dt (stim - t), b = A v_ + r0, r = r0 - A e,
-// z = D^-1 r, per-tile partials of b.b, r.z, r.r.  var_rhs_kernel's expressions in its order: the same bits.  Single slabs,
-// tiles of 8 rows.  dev_t: a work field (the solver's q, free until the first iteration).
+// The right-hand side of a step on the tiles (what beat_var_rhs computes with gathers: 352 B/node from beyond the L2 on the 401^3
+// shell against 168 algorithmic, 1.30 ms, profiles/r04_shell400.md), in the formulation of the constant-coefficient kernels
+// (beat_pde_rr.hip):
+//   pass 1 (BV):  b = B v_ + dt sum_k amp_k w_k  -- the plain tile product over the rows of B = C_m Mass - (1 - theta) dt K, which
+//                 beat_var_form_A forms beside A (beat_pde::v_B) --, b stored in a work field, per-tile partials of b.b;
+//   pass 2 (RES): r = b - A x0 with x0 = v_ + e formed while loading (ONE vector window, as the iteration's fused pass forms its
+//                 direction), z = D^-1 r where the three-kernel iteration wants it; per-tile partials of r.z and r.r.
+// Two passes at the plain product's cost and register budget (4 waves per SIMD) instead of one pass with two windows at 166 VGPRs.
+// r differs from var_rhs_kernel's  dt (stim - K v_) - A e  by rounding (~1e-16 |b|: far below any threshold rtol |b|): the solves
+// are the same solves, not the same bits (tests/test_var_gpu.py).  Single slabs, tiles of 8 rows.  dev_t: a work field (the
+// solver's q, free until the first iteration).
 bool beat_vtl_rhs_available(const beat_pde* pde) {
+  if (!(beat_vtl_available(pde) && pde->g.z_lo_phys && pde->g.z_hi_phys)) return false;
+  const VtlData* d = (const VtlData*)pde->vtl;
+  return d->ry == 8 && d->rhs && pde->v_B != nullptr;
+}
+bool beat_vtl_rhs_wanted(const beat_pde* pde) {  // (before the rows of B exist: beat_var_form_A allocates them when this says so)
   if (!(beat_vtl_available(pde) && pde->g.z_lo_phys && pde->g.z_hi_phys)) return false;
   const VtlData* d = (const VtlData*)pde->vtl;
   return d->ry == 8 && d->rhs;
@@ -928,22 +904,24 @@ int beat_vtl_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
   if (dev_x != dev_v_prev)  // nodes outside the tissue keep their value: copy everything first (as beat_var_rhs does)
     BEAT_HIP_CHECK(hipMemcpyAsync(dev_x, dev_v_prev, sizeof(double) * (size_t)pde->n, hipMemcpyDeviceToDevice, pde->ctx->stream));
   VtlRhs one{};
-  one.rows = pde->v_stiff;
-  one.mode = 0;
-  if (int rc = vtl_launch(pde, dev_v_prev, dev_t, pde->d_st, nullptr, nullptr, 0, 0, 0, false, 0, &one)) return rc;
-  VtlRhs two{};
-  two.mode = 2;
-  two.e = dev_e;
-  two.t = dev_t;
-  two.dt = pde->dt;
-  two.red_out = dev_red;
+  one.rows = pde->v_B;
+  one.mode = 2;
+  one.dt = pde->dt;
   for (int k = 0; k < n_stim; ++k) {
     if (host_dev_stim_w[k] == nullptr || host_stim_amp[k] == 0.0) continue;
-    two.w[two.nstim] = host_dev_stim_w[k];
-    two.amp[two.nstim] = host_stim_amp[k];
-    ++two.nstim;
+    one.w[one.nstim] = host_dev_stim_w[k];
+    one.amp[one.nstim] = host_stim_amp[k];
+    ++one.nstim;
   }
-  return vtl_launch(pde, dev_v_prev, dev_r, pde->d_st, nullptr, dev_p, 0, 0, 0, true, 0, &two);
+  if (int rc = vtl_launch(pde, dev_v_prev, dev_t, pde->d_st, nullptr, nullptr, 0, 0, 0, false, 0, &one)) return rc;
+  VtlRhs two{};
+  two.mode = 4;
+  two.e = dev_e;
+  two.t = dev_t;
+  two.red_out = dev_red;
+  // (dev_p of vtl_launch carries v_ here; its dev_p_new is where z = D^-1 r goes: only the three-kernel iteration reads it --
+  // the fused pass forms its first direction from r itself)
+  return vtl_launch(pde, dev_v_prev, dev_r, pde->d_st, nullptr, beat_vtl_pdot_available(pde) ? nullptr : dev_p, 0, 0, 0, true, 0, &two);
 }
 
 // The fused pass on a slab with live neighbours, in the two parts of the split launches: part 0 = the planes whose stencil

@@ -351,7 +351,8 @@ struct NodeIO {
 // constant, Model::V_INDEX, so that every other load stays a plain load -- is read as
 // V + sum_j pa[j] pp[j], accumulated in the order x_flush_kernel uses (bit-identical to a flushed row); the store
 // writes the complete new value.
-constexpr int BEAT_MAX_PENDING = 6;  // = ring size of the deferred-x PCG
+constexpr int BEAT_MAX_PENDING = 6;  // = default ring size of the deferred-x PCG: what the plain kernels' pending path takes
+constexpr int BEAT_MAX_PENDING_CLASS = 12;  // the class kernel consumes the pending directions ahead of its passes: the long ring (PRING_MAX)
 template <int VIDX>
 struct NodeIOPending {
   double* __restrict__ base;

@@ -102,7 +102,8 @@ int beat_ode_step(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, in
  * (beat_pde_solve_ex with defer_flush, or a stage-driven solve that skipped the last beat_pde_x_flush):
  * row v_index is read as  V + sum_{j < pending} alpha_j p_j  with p_j = dev_ring0 + j*field_stride and the step
  * lengths kept by `pde`; the new value is stored complete.  Fuses the x += sum alpha_j p_j pass of the
- * deferred-x PCG into the next ionic kernel, which is fp64-issue bound and has HBM bandwidth to spare. */
+ * deferred-x PCG into the next ionic kernel, which is fp64-issue bound and has HBM bandwidth to spare.
+ * pending = -1: `pde` has an open solve (beat_pde_solve_begin): see there. */
 int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64_t n, int64_t ld,
                           const double* host_params, int num_params, const double* dev_params_per_node,
                           int64_t params_ld, double t, double dt, int v_index, double* dev_v_copy,
@@ -110,7 +111,8 @@ int beat_ode_step_pending(beat_ctx* ctx, int model_id, double* dev_states, int64
 
 /* Per-node parameters of which only a few rows vary -- a smooth gradient in one or two parameters over otherwise uniform
  * tissue; the reference hands ``fun`` the whole (P, N) array, src/beat/odesolver.py:67-79, demos/pace_train.py:133-167 --:
- * host_params = the (P,) vector of the parameters that do not vary, dev_rows = (num_rows <= 4, rows_ld) = the rows that do,
+ * host_params = the (P,) vector of the parameters that do not vary, dev_rows = (num_rows <= 16, rows_ld) = the rows that do
+ * (more than 4 only where run-time compilation is available, beat_ode_jit_stats: the shipped kernel takes four),
  * host_row_params[j] = the parameter index of row j.  Same values as beat_ode_step with all P rows on the device (the
  * kernel builds the node's parameter set from both and runs the per-node step); 8 num_rows bytes per node are read
  * instead of 8 P.  pde / dev_ring0 / field_stride / pending as in beat_ode_step_pending (pde = NULL: a plain step). */
@@ -287,6 +289,9 @@ int beat_pde_cg_next(beat_pde* pde, double* dev_st, const double* dev_r, double*
  * uses p_i = ring[i % size]; x is brought up to date by beat_pde_x_flush when the ring is full
  * (only_if_full = 1, enqueue it right after the update of iteration i with i % size == size-1, before
  * that slot is overwritten) and once more after the solve for the partially filled last cycle. */
+/* beat_pde_ring_size(): the default ring (6).  A per-node-row operator on a single slab keeps 12 directions (its solves take 9-12
+ * iterations at the reference's dt = 0.05 ms, demos/biv_endocardial.py:137; with 6 every solve paid an in-loop flush);
+ * beat_pde_work_fields(pde) - 3 is an operator's own ring, and the number of ring fields its dev_work holds. */
 int beat_pde_ring_size(void);
 /* alpha = st[1]/st[3] (remembered for slot); r -= alpha q; LOCAL r.D^-1 r, r.r -> dev_st[4..5]
  * -> all-reduce dev_st[4:6].  dev_st[14] counts the executed updates. */
@@ -376,7 +381,8 @@ int beat_pde_guess_history(const beat_pde* pde, double** dev_d, double** dev_e, 
 /* What the x update of the last solve (the pending one, if it was deferred to the next ionic kernel) moves for the
  * guess's bookkeeping: host_out[4] = {fields it reads (e, the increments its extrapolation uses), fields it writes
  * (d, e: 2, or 0 without a guess), the order in use (the adaptive policy's current one for order -1), 1 if that
- * update is still pending}.  8 bytes per node each: what bench.py charges the ionic kernel for. */
+ * update is still pending, 2 if it was applied by a launch enqueued behind the open solve (pending = -1)}.  8 bytes per node each:
+ * what bench.py charges the ionic kernel for. */
 int beat_pde_guess_traffic(const beat_pde* pde, int* host_out);
 
 /* Small grids (constant coefficients, Jacobi, undivided, <= 8192 nodes -- the reference's own CPU-sized cases, e.g.
@@ -425,6 +431,23 @@ int beat_split_steps_big(beat_ctx* ctx, int model_id, double* dev_states, int64_
                          double rtol, double atol, int max_it, int pending_in, beat_ksp_info* host_info, int* host_pending,
                          float* host_ode_ms);
 
+/* beat_pde_solve_ex(defer_flush = 1) in two halves (round 5): _begin enqueues the right-hand side, as many iterations as the
+ * previous solve needed + 1 and the copy of the solve's scalar state, and returns WITHOUT waiting; _end waits for that copy,
+ * enqueues more iterations if the solve has not latched (and waits again), does the host's bookkeeping and reports as
+ * beat_pde_solve_ex does (info, host_pending; BEAT_ENOTCONV).  Between the two the caller may enqueue the next ionic step behind
+ * the open solve -- beat_ode_step_pending / _rows / _classes with pending = -1: the kernel reads what is pending from the solve's
+ * state on the device and does nothing if the solve has not latched; the call then finishes the solve itself (as _end would) and
+ * repeats the launch if it has to -- so that the device never idles between the solve's last kernel and the ionic kernel while the
+ * host wakes up (MonodomainSplittingSolver.step against .solve: 13.71 against 13.46 ms per 512^3 step, BENCH_r04).  PETSc's KSPSolve
+ * (src/beat/base_model.py:236) returns when the solve is done; what the reference's caller does with the result -- nothing, unless a
+ * monitor is attached (base_model.py:239) -- can wait a step.  Jacobi on one slab only (beat_pde_solve_is_open says whether a
+ * solve is open; _end without one returns the last finished solve's record).  Every other entry point that takes the operator
+ * refuses while a solve is open. */
+int beat_pde_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                         const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol, int max_it);
+int beat_pde_solve_end(beat_pde* pde, beat_ksp_info* info, int* host_pending);
+int beat_pde_solve_is_open(const beat_pde* pde);
+int beat_pde_solve_can_open(const beat_pde* pde); /* 1: beat_pde_solve_begin takes this operator (Jacobi, one slab, not the one-launch path) */
 int beat_pde_solve_ex(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w,
                       const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol,
                       double atol, int max_it, int defer_flush, beat_ksp_info* info, int* host_pending);

@@ -780,7 +780,7 @@ def test_deferred_potential_update_is_bit_identical():
         deferred = 0
         for i in range(12):
             s.step((i * 0.05, (i + 1) * 0.05))
-            deferred += int(ops.pending is not None)
+            deferred += int(ops.pending is not None or ops.open_x is not None)  # (left pending, or the solve still open: round 5)
             if peek:
                 v = np.asarray(s.pde.state.x.array)
                 assert ops.pending is None
@@ -792,7 +792,7 @@ def test_deferred_potential_update_is_bit_identical():
             # every step) are not reads of the potential and must not cost a flush pass
             assert s.pde.state.x.array.size == s.ode.num_points == len(s.pde.v_.x.array)
             assert s.pde.state.x.array.shape == (s.ode.num_points,)
-            assert getattr(ops, "flushes", 0) == 0 and ops.pending is not None
+            assert getattr(ops, "flushes", 0) == 0 and (ops.pending is not None or ops.open_x is not None)
         runs[peek] = s.ode.values.copy()
         assert ops.pending is None
         np.testing.assert_array_equal(np.asarray(s.pde.v_.x.array), runs[peek][17])
@@ -949,12 +949,22 @@ def test_piecewise_constant_per_node_parameters_run_as_classes():
     for i in range(6):
         ref = ionic.tp06_generalized_rush_larsen(ref, 0.02 * i, 0.02, Pg)
     assert (np.abs(out_g - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
-    # an edit of the live array that makes a fifth row vary: back to all rows
+    # an edit of the live array that makes a fifth row vary: without run-time compilation (the shipped kernel takes four rows)
+    # back to all rows; with it (round 5: a compiled instance takes up to sixteen) the five rows stay the only ones on the device
     for k, name in enumerate(("g_Kr", "g_Ks", "g_to")):
         Pg[tp06.parameter_index(name)] *= 1.0 + 0.01 * (k + 1) * np.cos(xs)
-    ode_g.step(0.12, 0.02)
+    os.environ["BEAT_JIT"] = "0"
+    try:
+        ode_g.step(0.12, 0.02)
+    finally:
+        os.environ.pop("BEAT_JIT", None)
     assert ode_g._dev._sparse is None and ode_g._dev.classes is None
     ref = ionic.tp06_generalized_rush_larsen(ref, 0.12, 0.02, Pg)
+    assert (np.abs(np.asarray(ode_g.values) - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
+    Pg[tp06.parameter_index("g_to")] *= 1.0 + 1e-3 * np.sin(xs)  # (another edit: the route is looked at again)
+    ode_g.step(0.14, 0.02)
+    assert ode_g._dev._sparse is not None and len(ode_g._dev._sparse[1]) == 5 and ode_g._dev.classes is None
+    ref = ionic.tp06_generalized_rush_larsen(ref, 0.14, 0.02, Pg)
     assert (np.abs(np.asarray(ode_g.values) - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-10
 
 def test_split_step_with_a_smooth_per_node_parameter_runs_on_sparse_rows():
@@ -1021,7 +1031,7 @@ def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
 
     lib = _hip.load()
     stats = (C.c_longlong * 4)()
-    assert lib.beat_ode_jit_stats(stats) == 1, "hipcc / kernel sources / cache directory not found on a GPU box"
+    assert lib.beat_ode_jit_stats(stats) == 1, lib.beat_last_error().decode(errors="replace")  # (says what is missing)
 
     def run(model, vname, fields, route):
         env = {"rows": {"BEAT_PARAM_SPARSE": "0"}, "jit": {}}[route]
@@ -1053,8 +1063,12 @@ def test_sparse_rows_run_on_an_instance_compiled_for_their_indices():
     smooth = lambda p, xs: p * (1.0 - 0.2 * xs[:, 0] - 0.1 * xs[:, 1] - 0.07 * xs[:, 2])  # noqa: E731
     other = lambda p, xs: p * (0.7 + 0.25 * np.sin(3.0 * xs[:, 0]) * np.cos(2.0 * xs[:, 1]))  # noqa: E731
     layers = lambda p, xs: np.floor(3.0 * xs[:, 2] / 0.6001)  # noqa: E731  -- 0, 1, 2 through the wall
+    # eight smooth rows (round 5: the compiled instance takes up to 16 indices; the shipped run-time-index kernel four)
+    eight_tp06 = {nm: (smooth if k % 2 == 0 else other) for k, nm in enumerate(("g_CaL", "g_Kr", "g_Ks", "g_Na", "g_to", "g_K1", "g_bca", "g_pCa"))}
+    eight_tor = {nm: (smooth if k % 2 == 0 else other) for k, nm in enumerate(("GKr_b", "GKs_b", "GNa", "Gto_b", "GK1_b", "PCa_b", "GNaL_b", "Gncx_b"))}
     cases = [(tp06, "V", {"g_CaL": smooth}), (torord, "v", {"GKr_b": smooth}), (tp06, "V", {"g_CaL": smooth, "g_Kr": other}),
-             (torord, "v", {"celltype": layers, "GKs_b": other}), (torord_land, "v", {"Tref": smooth, "GKr_b": other})]
+             (torord, "v", {"celltype": layers, "GKs_b": other}), (torord_land, "v", {"Tref": smooth, "GKr_b": other}),
+             (tp06, "V", eight_tp06), (torord, "v", eight_tor)]
     loaded_before = stats[0]
     for model, vname, fields in cases:
         a, sparse_a = run(model, vname, fields, "jit")
@@ -1466,6 +1480,67 @@ def test_batched_solve_of_a_big_grid_equals_the_step_loop(order, monkeypatch):
     assert not a._can_batch(None)
 
 
+@pytest.mark.parametrize("case", ["slab", "shell"])
+def test_step_leaves_its_solve_open_and_the_next_ionic_launch_goes_behind_it(case, monkeypatch):
+    """Round 5: ``MonodomainSplittingSolver.step`` does not wait for its diffusion solve (beat_pde_solve_begin); the next step's
+    ionic launch is enqueued behind the open solve, reads what is pending from the solve's state on the device, does nothing if the
+    solve has not latched -- the host then enqueues the missing iterations and launches again (beat_ode_step_* with pending = -1).
+    Values, KSP records and status are those of the waiting step (BEAT_LAZY_KSP=0) BIT FOR BIT: on a TP06 slab whose iteration
+    counts jump by more than the one iteration enqueued on spec when the stimulated corner fires (the relaunch path) and on a
+    voxel shell with per-node rows, two parameter classes and the ring of 12 (the class kernel behind the solve);
+    ``pde.ksp`` and ``pde.state.x.array`` finish an open solve on access.  (The two cases are those of bench.py's multi-rank
+    parity block, bench_parity.py, on one rank, with this test's own step loop.)"""
+    import sys
+    from pathlib import Path
+
+    from beat import grid as g
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench_parity
+
+    nsteps = 30
+
+    def run(lazy, touch):
+        monkeypatch.setenv("BEAT_LAZY_KSP", "1" if lazy else "0")
+        out = {}
+
+        def loop(solver, pde, steps, dt):
+            extra, opens, t, log = [], 0, 0.0, []
+            pde._ops.ksp_log = log
+            for i in range(nsteps):
+                solver.step((t, t + dt))
+                opens += int(pde._ops.open_x is not None)
+                if touch and i == 11:
+                    extra.append(("ksp", pde.ksp.iterations))  # finishes the open solve
+                    assert pde._ops.open_x is None
+                if touch and i == 17:
+                    extra.append(("v", float(np.asarray(pde.state.x.array).max())))  # flushes (and finishes) on access
+                t += dt
+            v = np.asarray(pde.state.x.array, dtype=np.float64).copy()
+            out.update(v=v, opens=opens, its=[r.iterations for r in log], reasons=[r.converged_reason for r in log], extra=extra,
+                       last=pde.ksp.iterations, status=pde.status)
+            return v, out["its"]
+
+        monkeypatch.setattr(bench_parity, "_run", loop)
+        if case == "slab":
+            bench_parity.slab_case(g.COMM_SELF, 24, nxy=48)
+        else:
+            bench_parity.shell_case(g.COMM_SELF, 32, n_xy=48)
+        return out
+
+    a = run(False, False)
+    b = run(True, False)
+    c = run(True, True)
+    assert a["opens"] == 0 and b["opens"] == nsteps and c["opens"] == nsteps
+    assert len(a["its"]) == nsteps and a["its"] == b["its"] == c["its"] and all(r > 0 for r in b["reasons"])
+    # (the relaunch path is taken: the first solve needs more than the 8 iterations enqueued for a solve without a predecessor,
+    # or some solve needs two more than the one before it -- the speculative chunk is the previous count + 1)
+    assert a["its"][0] >= 9 or max(j - i for i, j in zip(a["its"][:-1], a["its"][1:])) >= 2
+    np.testing.assert_array_equal(b["v"], a["v"])
+    np.testing.assert_array_equal(c["v"], a["v"])
+    assert b["last"] == a["last"] and c["extra"][0] == ("ksp", a["its"][11]) and a["status"] == b["status"]
+
+
 def test_batched_solve_of_a_big_grid_stops_at_the_first_solve_that_does_not_converge():
     """the library's step loop used to run on after a solve had hit ksp_max_it -- up to a thousand steps on the bad
     iterate before Python saw it.  Now the batch ends AT that solve: with ``ksp_error_if_not_converged`` the exception comes with
@@ -1504,8 +1579,12 @@ def test_batched_solve_of_a_big_grid_stops_at_the_first_solve_that_does_not_conv
         a.solve((0.0, 20 * dt), dt)
     b = build(False, 3)
     failed_at = None
+    ivs, t0 = [], 0.0  # the intervals as solve() forms them (t1 = t0 + dt accumulated: i * dt differs in the last bit)
     for i in range(20):
-        b.step((i * dt, (i + 1) * dt))
+        ivs.append((t0, t0 + dt))
+        t0 = t0 + dt
+    for i in range(20):
+        b.step(ivs[i])
         if b.pde.ksp.converged_reason < 0:
             failed_at = i
             break
@@ -1517,7 +1596,7 @@ def test_batched_solve_of_a_big_grid_stops_at_the_first_solve_that_does_not_conv
     c = build(False, 3)
     c.solve((0.0, 20 * dt), dt)
     for i in range(failed_at + 1, 20):
-        b.step((i * dt, (i + 1) * dt))
+        b.step(ivs[i])
     assert c.pde.status == Status.NOT_CONVERGING
     np.testing.assert_array_equal(c.ode.values, b.ode.values)
 

@@ -28,9 +28,11 @@ def test_library_finds_sources_compiler_and_cache_directory(tmp_path, monkeypatc
 
 
 @pytest.mark.skipif(HIPCC is None, reason="no hipcc")
-@pytest.mark.parametrize("model,pend,idx,mask", [("Tp06Grl1", "true", (6, 2, -1, -1), (0xA0, 0)), ("TorordLandGrl1", "false", (100, -1, -1, -1), (0, 0))])
+@pytest.mark.parametrize("model,pend,idx,mask", [("Tp06Grl1", "true", (6, 2), (0xA0, 0)), ("TorordLandGrl1", "false", (100,), (0, 0)),
+                                                 ("Tp06Grl1", "true", (6, 2, 3, 4, 8, 1, 7, 18), (0xA0, 0))])
 def test_generated_unit_compiles_for_gfx950(tmp_path, model, pend, idx, mask):
-    inst = f"ode_step_kernel<{model}, true, {pend}, false, true, {idx[0]}, {idx[1]}, {idx[2]}, {idx[3]}, {mask[0]:#x}ull, {mask[1]:#x}ull>"
+    # (the indices of the varying rows as a pack: up to 16 of them since round 5)
+    inst = f"ode_step_kernel<{model}, true, {pend}, false, true, IdxPack<{', '.join(map(str, idx))}>, {mask[0]:#x}ull, {mask[1]:#x}ull>"
     src = tmp_path / "unit.hip"
     src.write_text('#include "beat_ode_kernel.h"\n'
                    f"template __global__ void {inst}(\n    double*, int64_t, int64_t, ParamPack<{model}::NP>, typename {model}::Derived, "

@@ -127,20 +127,27 @@ def main():
         solver.step((t, t + dt))
         t += dt
     torch.cuda.synchronize()
+    # (the KSP record of a step is taken from the operator's log: asking pde.ksp after every step would make the host wait for a
+    # solve that step() leaves open until the next ionic launch is queued behind it)
+    pde._ops.flush_pending()
+    pde._ops.ksp_log = log = []
     tic = time.perf_counter()
     tw = tic
     for i in range(args.steps):
         solver.step((t, t + dt))
-        its.append(pde.ksp.iterations)
         t += dt
         if args.trace and (i + 1) % args.trace == 0 and mesh.comm.rank == 0:
+            pde._ops.flush_pending()
+            its[:] = [r.iterations for r in log]
             torch.cuda.synchronize()
             now = time.perf_counter()
             print(f"  steps {i + 1 - args.trace:5d}-{i + 1:5d} (t = {t:7.2f} ms): {np.mean(its[-args.trace:]):5.2f} its/step, "
                   f"{(now - tw) / args.trace * 1e3:6.2f} ms/step", flush=True)
             tw = now
+    pde._ops.flush_pending()
     torch.cuda.synchronize()
     wall = time.perf_counter() - tic
+    its[:] = [r.iterations for r in log]
     vmin, vmax = pde.state.field.minmax()
     nt = int(tissue.sum())
     if args.save:

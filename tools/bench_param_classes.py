@@ -47,6 +47,11 @@ def main():
         if kind == "block":
             for name in blocked:
                 t[tp06.parameter_index(name)] = torch.where(x >= 0.5, torch.zeros_like(x), t[tp06.parameter_index(name)])
+        elif kind == "smooth8":  # eight smooth rows (round 5: compiled instances take up to 16 varying rows)
+            names8 = (("GKr_b", "GKs_b", "GNa", "Gto_b", "GK1_b", "PCa_b", "GNaL_b", "Gncx_b") if tor
+                      else ("g_CaL", "g_Kr", "g_Ks", "g_Na", "g_to", "g_K1", "g_bca", "g_pCa"))
+            for k, name in enumerate(names8):
+                t[tp06.parameter_index(name)] *= 1.0 - (0.1 + 0.04 * k) * x
         else:
             t[tp06.parameter_index(smooth_name)] *= 1.0 - 0.5 * x
         dp = DeviceParameters.__new__(DeviceParameters)
@@ -90,6 +95,12 @@ def main():
     g = run("  the same with the run-time-index kernel (BEAT_JIT=0)", sm, {"BEAT_JIT": "0"})
     gd = run(f"  the same with all {len(P0)} rows on the device", sm, {"BEAT_PARAM_SPARSE": "0"})
     print(f"classes / uniform = {c / u:.3f}; per-node / uniform = {p / u:.3f}; smooth field: compiled instance {gj / u:.3f}, run-time index {g / u:.3f}, all rows {gd / u:.3f}")
+    del sm
+    sm8 = per_node("smooth8")
+    run("eight smooth rows: compiling", sm8)
+    g8 = run("eight smooth rows (P, N): sparse rows, compiled instance", sm8)
+    g8d = run(f"  the same with all {len(P0)} rows on the device", sm8, {"BEAT_PARAM_SPARSE": "0"})
+    print(f"eight smooth rows: compiled instance {g8 / u:.3f} x the uniform kernel, all rows {g8d / u:.3f}")
 
 
 if __name__ == "__main__":
