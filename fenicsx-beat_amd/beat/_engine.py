@@ -433,7 +433,10 @@ class HipOps:
                                                 C.byref(info), pend), allow_not_converged=True)
         if pend[1] > 0 or self.lib.beat_pde_guess_pending(self.handle):
             self.pending = (x, int(pend[0]), int(pend[1]))
-        return KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+        res = KspResult(info.iterations, info.residual_norm, info.converged_reason, info.rhs_norm)
+        if self.ksp_log is not None:
+            self.ksp_log.append(res)
+        return res
 
     def set_guess_order(self, order: int) -> None:
         """0: every solve starts from x0 = v_; m = 1..4: from v_ plus the degree-(m-1) extrapolation in time of the last
@@ -1022,4 +1025,7 @@ class DiffusionSolver:
         reason = int(st[_hip.ST_REASON]) if st[_hip.ST_STOP] != 0.0 else -3
         # a solve that ran out of iterations is REPORTED (converged_reason < 0, as PETSc's KSP), not raised: the
         # caller decides (BaseModel.step -> Status.NOT_CONVERGING / ksp_error_if_not_converged)
-        return KspResult(its, float(np.sqrt(st[_hip.ST_RR])), reason, float(np.sqrt(st[_hip.ST_BB])))
+        res = KspResult(its, float(np.sqrt(st[_hip.ST_RR])), reason, float(np.sqrt(st[_hip.ST_BB])))
+        if getattr(ops, "ksp_log", None) is not None:
+            ops.ksp_log.append(res)
+        return res

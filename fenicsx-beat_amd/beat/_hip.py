@@ -61,6 +61,7 @@ SIGNATURES = {
     "beat_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "beat_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "beat_ode_model_info": (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
+    "beat_ode_model_register": (_int, [C.c_char_p, C.c_char_p, _int, _int, _int, C.POINTER(_int)]),
     "beat_ode_step": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp]),
     "beat_ode_step_pending": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),
     "beat_ode_step_rows": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _vp, _int, _vp, _i64, _dbl, _dbl, _int, _vp, _vp, _vp, _i64, _int]),

@@ -1,0 +1,270 @@
+"""A device cell model from a user's gotran ``.ode`` file: ``beat.models.from_ode(path)``.
+
+The reference takes ANY ``fun(states, t, parameters, dt)`` -- normally the function gotranx generates from an ``.ode`` file
+(demos/niederer_benchmark.py:82-99: ``gotranx.load_ode`` + ``gotranx.cli.gotran2py.get_code(..., scheme=[generalized_rush_larsen])``)
+-- and evaluates it with NumPy on the host (src/beat/odesolver.py:67-79).  The models this package ships (FHN, TP06, ToR-ORd) are
+hand-written kernels; a model it does not ship used to run as a Python callable on host arrays, with the whole state array making
+a round trip per step.  ``from_ode`` closes that: the file is parsed (``ast``: the format is Python syntax), every assignment is
+turned into a SymPy expression, the right-hand sides f_i and the TOTAL self-derivatives J_ii = d f_i / d y_i (intermediates
+resolved: the variant the reference's Niederer table pins) are put through common-subexpression elimination and printed
+as one C++ ``Model`` struct for ``csrc/beat_ode_kernel.h``; the library compiles it at first use (``beat_ode_model_register``,
+run-time ``hipcc --genco``, cached like the sparse-row instances) and every entry point that takes a model id takes this one:
+the fused split step, the pending update, the library's step loop.  Schemes: ``generalized_rush_larsen`` (gotranx's GRL1:
+y_i += f_i / J_ii (exp(J_ii dt) - 1) where |J_ii| > 1e-8, forward Euler elsewhere) and ``forward_euler``.
+
+The same expressions, lambdified for NumPy, are the handle's HOST evaluation (``numpy_step``): what the tests compare the kernel
+with, and what runs where no GPU / compiler is to be had.  Uniform parameters only (a (P,) vector); per-node parameters of a
+generated model raise.  SymPy is needed (it is what gotranx itself builds on).
+"""
+
+from __future__ import annotations
+
+import ast
+import hashlib
+from pathlib import Path
+
+import numpy as np
+
+from ._base import DeviceModel
+
+_SCHEMES = ("generalized_rush_larsen", "forward_euler")
+
+
+def _walk(text: str, where: str):
+    tree = ast.parse(text, filename=where)
+    for node in tree.body:
+        if isinstance(node, ast.Expr) and isinstance(node.value, ast.Call) and isinstance(node.value.func, ast.Name):
+            yield "call", node.value.func.id, node.value
+        elif isinstance(node, ast.Assign):
+            if len(node.targets) != 1 or not isinstance(node.targets[0], ast.Name):
+                raise ValueError(f"{where}:{node.lineno}: only plain assignments `name = expression` are understood")
+            yield "assign", node.targets[0].id, node.value
+        elif isinstance(node, ast.Expr):  # a docstring / bare constant
+            continue
+        else:
+            raise ValueError(f"{where}:{node.lineno}: statement not understood in an .ode file")
+
+
+def _number(node) -> float:
+    if isinstance(node, ast.Call):  # ScalarParam(value, unit=..., ...)
+        return float(ast.literal_eval(node.args[0]))
+    return float(ast.literal_eval(node))
+
+
+def _dependency_order(assignments):
+    """gotran files may use an intermediate before the line that defines it: order by dependencies (stable)."""
+    defined = {name for name, _ in assignments}
+    deps = {name: ({n.id for n in ast.walk(node) if isinstance(n, ast.Name)} & defined) - {name} for name, node in assignments}
+    out, done, pending = [], set(), list(assignments)
+    while pending:
+        rest = [(n, e) for n, e in pending if not deps[n] <= done]
+        ready = [(n, e) for n, e in pending if deps[n] <= done]
+        if not ready:
+            raise ValueError(f"cyclic definitions: {[n for n, _ in rest]}")
+        for n, e in ready:
+            out.append((n, e))
+            done.add(n)
+        pending = rest
+    return out
+
+
+class OdeFileModel(DeviceModel):
+    """A :class:`DeviceModel` generated from an ``.ode`` file (see the module docstring)."""
+
+    def __init__(self, path, scheme="generalized_rush_larsen", v_name=None, name=None):
+        import sympy
+
+        if scheme not in _SCHEMES:
+            raise ValueError(f"scheme must be one of {_SCHEMES}, got {scheme!r}")
+        self.path = Path(path)
+        self.scheme = scheme
+        text = self.path.read_text()
+        states, params, assigns = {}, {}, []
+        for kind, nm, node in _walk(text, str(self.path)):
+            if kind == "call" and nm in ("states", "parameters"):
+                target = states if nm == "states" else params
+                for kw in node.keywords:
+                    target[kw.arg] = _number(kw.value)
+            elif kind == "assign":
+                assigns.append((nm, node))
+            # (expressions(...), component(...), comment(...): grouping only)
+        if not states:
+            raise ValueError(f"{self.path}: no states(...) found")
+        assigns = _dependency_order(assigns)
+        if v_name is None:
+            v_name = next((s for s in states if s.lower() in ("v", "vm", "v_m")), None)
+        if v_name is not None and v_name not in states:
+            raise KeyError(f"{v_name!r} is not a state of {self.path.name}")
+        stem = "".join(c if c.isalnum() else "_" for c in (name or self.path.stem))
+        super().__init__(f"{stem}_{scheme}", -1, states, params, v_name)
+        # ---- symbolic right-hand sides and total self-derivatives
+        ysym = {s: sympy.Symbol(s, real=True) for s in states}
+        psym = {p: sympy.Symbol(p, real=True) for p in params}
+        tsym, dtsym = sympy.Symbol("time", real=True), sympy.Symbol("dt", real=True)
+
+        def cond(c):
+            return c
+
+        def piecewise(c, a, b):
+            return sympy.Piecewise((a, c), (b, True))
+
+        ns = {"exp": sympy.exp, "log": sympy.log, "sqrt": sympy.sqrt, "floor": sympy.floor, "abs": sympy.Abs, "Abs": sympy.Abs,
+              "pow": sympy.Pow, "sin": sympy.sin, "cos": sympy.cos, "tan": sympy.tan, "tanh": sympy.tanh, "sinh": sympy.sinh,
+              "cosh": sympy.cosh, "atan": sympy.atan, "asin": sympy.asin, "acos": sympy.acos,
+              "Conditional": piecewise, "Lt": sympy.Lt, "Le": sympy.Le, "Gt": sympy.Gt, "Ge": sympy.Ge, "Eq": sympy.Eq,
+              "And": sympy.And, "Or": sympy.Or, "Not": sympy.Not, "time": tsym, "t": tsym, "pi": sympy.pi}
+        ns.update(psym)
+        ns.update(ysym)
+        rhs = {}
+        for nm, node in assigns:
+            try:
+                expr = sympy.sympify(eval(compile(ast.Expression(node), str(self.path), "eval"), {"__builtins__": {}}, ns))
+            except Exception as exc:  # noqa: BLE001
+                raise ValueError(f"{self.path}: cannot turn `{nm} = ...` into an expression: {exc}") from exc
+            ns[nm] = expr
+            if nm.startswith("d") and nm.endswith("_dt") and nm[1:-3] in states:
+                rhs[nm[1:-3]] = expr
+        missing = [s for s in states if s not in rhs]
+        if missing:
+            raise ValueError(f"{self.path}: no d<state>_dt for {missing}")
+        names = list(states)
+        f = [rhs[s] for s in names]
+        J = [sympy.diff(rhs[s], ysym[s]) if scheme == "generalized_rush_larsen" else sympy.Integer(0) for s in names]
+        self._grl = [bool(j != 0) for j in J]
+        repl, red = sympy.cse(f + J, symbols=sympy.numbered_symbols("x_"), optimizations="basic")
+        self._sym = dict(y=[ysym[s] for s in names], p=[psym[p] for p in params], t=tsym, dt=dtsym, repl=repl,
+                         f=red[: len(names)], J=red[len(names):])
+        self._numpy_fn = None
+        self._registered = None
+        self.source = self._cxx(stem)
+        self.key = f"{self.cxx_name}"
+
+    # ------------------------------------------------------------------------------------------------ C++
+    def _cxx(self, stem: str) -> str:
+        import sympy
+        from sympy.printing.c import C99CodePrinter
+
+        class Printer(C99CodePrinter):
+            def _print_Pow(self, expr):  # small integer powers as products (pow() on fp64 is a long software routine)
+                b, e = expr.as_base_exp()
+                if e.is_Integer and 2 <= int(e) <= 4:
+                    pb = self.parenthesize(b, 1000)  # as an atom
+                    return "(" + "*".join([pb] * int(e)) + ")"
+                if e.is_Integer and -4 <= int(e) <= -1:
+                    pb = self.parenthesize(b, 1000)
+                    return "(1.0/(" + "*".join([pb] * (-int(e))) + "))"
+                return super()._print_Pow(expr)
+
+        pr = Printer({"contract": False})
+        y, p = self._sym["y"], self._sym["p"]
+        sub = {s: sympy.Symbol(f"y_{k}") for k, s in enumerate(y)}
+        sub.update({s: sympy.Symbol(f"p_{k}") for k, s in enumerate(p)})
+        sub[self._sym["t"]] = sympy.Symbol("t")
+        used = set()
+        lines = []
+        for lhs, e in self._sym["repl"]:
+            e2 = e.xreplace(sub)
+            used |= e2.free_symbols
+            lines.append(f"    const double {lhs} = {pr.doprint(e2)};")
+        ns_, np_ = len(y), len(p)
+        vi = self.state_index(self.v_name) if self.v_name else 0
+        body = []
+        for k in range(ns_):
+            fk, jk = self._sym["f"][k].xreplace(sub), self._sym["J"][k].xreplace(sub)
+            used |= fk.free_symbols | jk.free_symbols
+            if self._grl[k]:
+                body.append(f"    {{ const double f = {pr.doprint(fk)}; const double J = {pr.doprint(jk)};\n"
+                            f"      io.store({k}, y_{k} + (fabs(J) > 1e-8 ? f / J * (exp(J * dt) - 1.0) : f * dt)); }}")
+            else:
+                body.append(f"    io.store({k}, y_{k} + dt * ({pr.doprint(fk)}));")
+        loads = [f"    const double y_{k} = io.load({k});" for k in range(ns_)]
+        pl = [f"    const double p_{k} = p[{k}];" for k in range(np_) if sympy.Symbol(f"p_{k}") in used]
+        digest = hashlib.sha1(("\n".join(lines + body) + self.scheme).encode()).hexdigest()[:12]
+        self.cxx_name = f"Ode_{stem}_{digest}"
+        return (f"// generated by beat.models.from_ode from {self.path.name} ({self.scheme}): {ns_} states, {np_} parameters\n"
+                f"struct {self.cxx_name} {{\n"
+                f"  static constexpr int NS = {ns_}, NP = {max(np_, 1)}, V_INDEX = {vi};\n"
+                "  static constexpr bool REGISTER_LOOP = true;\n"
+                "  static constexpr int WAVES = 1, WAVES_PER_NODE = 1;\n"
+                "  struct Derived { double unused; };\n"
+                "  template <class P> __host__ __device__ static Derived derive(const P&) { return Derived{0.0}; }\n"
+                "  template <class IO, class P>\n"
+                "  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived&, const FastMath&, double t, double dt) {\n"
+                + "\n".join(loads + pl + lines + body) + "\n  }\n};\n")
+
+    # ------------------------------------------------------------------------------------------------ NumPy
+    def numpy_step(self, states, t, parameters, dt):
+        """One step on the HOST with NumPy: the same expressions as the kernel's (the reference's way of evaluating ``fun``)."""
+        import sympy
+
+        if self._numpy_fn is None:
+            s = self._sym
+            # (the common subexpressions found at construction are handed to lambdify as they are: local assignments in the generated function)
+            self._numpy_fn = sympy.lambdify(s["y"] + s["p"] + [s["t"]], [s["f"], s["J"]], "numpy", cse=lambda exprs: (s["repl"], exprs))
+        y = np.asarray(states, dtype=np.float64)
+        one_d = y.ndim == 1
+        y2 = y.reshape(y.shape[0], -1)
+        p = np.asarray(parameters, dtype=np.float64)
+        if p.ndim != 1:
+            raise NotImplementedError("a model generated from an .ode file takes uniform parameters (a (P,) vector)")
+        with np.errstate(all="ignore"):
+            f, J = self._numpy_fn(*[y2[k] for k in range(y2.shape[0])], *[p[k] for k in range(len(p))], float(t))
+        out = np.empty_like(y2)
+        for k in range(y2.shape[0]):
+            fk = np.broadcast_to(np.asarray(f[k], dtype=np.float64), y2[k].shape)
+            if self._grl[k]:
+                Jk = np.broadcast_to(np.asarray(J[k], dtype=np.float64), y2[k].shape)
+                with np.errstate(all="ignore"):
+                    out[k] = y2[k] + np.where(np.abs(Jk) > 1e-8, fk / np.where(Jk == 0, 1.0, Jk) * (np.exp(Jk * dt) - 1.0), fk * dt)
+            else:
+                out[k] = y2[k] + dt * fk
+        return out[:, 0].copy() if one_d else out
+
+    # ------------------------------------------------------------------------------------------------ device
+    def register(self) -> int:
+        """The library's id for this model (beat_ode_model_register: the source is handed over once per process; the kernel is
+        compiled when a step first needs it).  Raises BeatHipError where the library cannot compile at run time."""
+        import ctypes as C
+
+        from .. import _hip
+
+        if self._registered is None:
+            lib = _hip.load()
+            mid = C.c_int(-1)
+            _hip.check(lib.beat_ode_model_register(self.cxx_name.encode(), self.source.encode(), self.num_states,
+                                                   max(self.num_parameters, 1), self.state_index(self.v_name) if self.v_name else 0,
+                                                   C.byref(mid)))
+            self._registered = int(mid.value)
+            self.model_id = self._registered
+        return self._registered
+
+    def __call__(self, states=None, t=0.0, parameters=None, dt=None, **kwargs):
+        if dt is None:
+            raise TypeError("dt is required")
+        try:
+            import torch
+
+            on_gpu = torch.cuda.is_available()
+        except Exception:  # noqa: BLE001
+            on_gpu = False
+        if on_gpu:
+            self.register()
+            return super().__call__(states=states, t=t, parameters=parameters, dt=dt, **kwargs)
+        return self.numpy_step(states, t, parameters, dt)
+
+    def run(self, states, parameters, dt, nsteps, nbeats=1, t0=0.0, track_indices=None, save_freq=1):
+        """(The in-kernel time loop is built for the shipped models: a generated one steps launch by launch.)"""
+        y = np.asarray(states, dtype=np.float64)
+        rows = []
+        for _ in range(int(nbeats)):
+            for j in range(int(nsteps)):
+                if track_indices is not None and j % int(save_freq) == 0:
+                    rows.append(np.array([y[i] for i in track_indices]))
+                y = self(states=y, t=t0 + j * dt, parameters=parameters, dt=dt)
+        return y, (np.array(rows) if track_indices is not None else None)
+
+
+def from_ode(path, scheme: str = "generalized_rush_larsen", v_name: str | None = None, name: str | None = None) -> OdeFileModel:
+    """A device cell model from a gotran ``.ode`` file: pass the result as ``fun`` to ``DolfinODESolver`` (and use its
+    ``init_state_values`` / ``init_parameter_values`` / ``state_index`` / ``parameter_index`` as those of a gotranx module)."""
+    return OdeFileModel(path, scheme=scheme, v_name=v_name, name=name)

@@ -96,6 +96,8 @@ class _DeviceODE:
 
         if num_states != model.num_states:
             raise ValueError(f"{model.name} has {model.num_states} states, num_states={num_states}")
+        if hasattr(model, "register"):  # a model generated from an .ode file (beat.models.from_ode): its source goes to the library
+            model.register()
         self.ctx = ctx
         self.model = model
         self.n = n

@@ -135,6 +135,28 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 #undef BEAT_RUN
 }
 
+// blocks of an ionic launch over n nodes
+static unsigned ode_grid(int64_t n) {
+  unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  static const int grid_cap = [] {  // blocks per launch (BEAT_ODE_GRID; 0: one block per tile)
+    const char* e = std::getenv("BEAT_ODE_GRID");
+    return e ? std::atoi(e) : 24576;
+  }();
+  static const bool balance = [] {  // BEAT_ODE_BALANCE=0: plain cap (A/B runs)
+    const char* e = std::getenv("BEAT_ODE_BALANCE");
+    return !(e && e[0] == '0');
+  }();
+  if (grid_cap > 0 && grid > (unsigned)grid_cap) {
+    // a few tiles per block: give every block the same number (the last one aside).  With 2.67 tiles per block -- 256^3, or
+    // the slab one of 8 ranks owns at 512^3, on 24 576 blocks -- two thirds of the blocks are on a third tile while the
+    // others have finished: 1.36-1.47 ms against 1.25-1.32 with 3 tiles each (A B A B A B on one box, round 3).  With
+    // 21.3 tiles per block (512^3) the plain cap measures the same or better (9.80 against 9.83 ms) and stays.
+    const unsigned per_block = (grid + (unsigned)grid_cap - 1) / (unsigned)grid_cap;
+    grid = (balance && per_block <= 8) ? (grid + per_block - 1) / per_block : (unsigned)grid_cap;
+  }
+  return grid;
+}
+
 template <class Model>
 static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
                       int num_params, const double* ppn, int64_t pld, double t, double dt,
@@ -155,23 +177,7 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   ParamPack<Model::NP> prm;
   for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
   typename Model::Derived drv = Model::derive(prm.p);
-  unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
-  static const int grid_cap = [] {  // blocks per launch (BEAT_ODE_GRID; 0: one block per tile)
-    const char* e = std::getenv("BEAT_ODE_GRID");
-    return e ? std::atoi(e) : 24576;
-  }();
-  static const bool balance = [] {  // BEAT_ODE_BALANCE=0: plain cap (A/B runs)
-    const char* e = std::getenv("BEAT_ODE_BALANCE");
-    return !(e && e[0] == '0');
-  }();
-  if (grid_cap > 0 && grid > (unsigned)grid_cap) {
-    // a few tiles per block: give every block the same number (the last one aside).  With 2.67 tiles per block -- 256^3, or
-    // the slab one of 8 ranks owns at 512^3, on 24 576 blocks -- two thirds of the blocks are on a third tile while the
-    // others have finished: 1.36-1.47 ms against 1.25-1.32 with 3 tiles each (A B A B A B on one box, round 3).  With
-    // 21.3 tiles per block (512^3) the plain cap measures the same or better (9.80 against 9.83 ms) and stays.
-    const unsigned per_block = (grid + (unsigned)grid_cap - 1) / (unsigned)grid_cap;
-    grid = (balance && per_block <= 8) ? (grid + per_block - 1) / per_block : (unsigned)grid_cap;
-  }
+  const unsigned grid = ode_grid(n);
   const dim3 g3(grid), b3(BEAT_BLOCK);
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
@@ -228,7 +234,10 @@ extern "C" int beat_ode_model_info(int model_id, int* num_states, int* num_param
     case BEAT_MODEL_TP06_GRL1: ns = Tp06Grl1::NS; np = Tp06Grl1::NP; break;
     case BEAT_MODEL_TORORD_DYNCL_GRL1: ns = TorordDynClGrl1::NS; np = TorordDynClGrl1::NP; break;
     case BEAT_MODEL_TORORD_LAND_GRL1: ns = TorordLandGrl1::NS; np = TorordLandGrl1::NP; break;
-    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+    default:
+      if (beat_custom_model_info(model_id, &ns, &np, nullptr) == BEAT_OK) break;  // a model registered as source
+      beat_set_error("unknown model id %d", model_id);
+      return BEAT_EINVAL;
   }
   if (num_states) *num_states = ns;
   if (num_params) *num_params = np;
@@ -245,6 +254,11 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
   BEAT_REQUIRE((n + BEAT_BLOCK - 1) / BEAT_BLOCK < (int64_t)0x7fffffff, "n too large");
   if (n == 0) return BEAT_OK;
+  if (model_id >= BEAT_MODEL_CUSTOM_BASE) {  // a model registered as source (beat_ode_model_register): uniform parameters only
+    BEAT_REQUIRE(dev_params_per_node == nullptr && mk.markers == nullptr && sp.count == 0,
+                 "a model registered as source takes uniform parameters (no per-node rows, no classes)");
+    return beat_custom_step(ctx, model_id, ode_grid(n), dev_states, n, ld, host_params, num_params, t, dt, v_index, dev_v_copy, pend);
+  }
 #define BEAT_STEP(M)                                                                                             \
   return launch_ode<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, \
                        v_index, dev_v_copy, pend, mk, sp)

@@ -22,6 +22,11 @@
 #include <vector>
 
 constexpr int BEAT_JIT_UNAVAILABLE = 1000;
+constexpr int BEAT_MODEL_CUSTOM_BASE = 100;  // model ids of cell models registered as source (beat_ode_model_register)
+int beat_custom_model_info(int model_id, int* ns, int* np, int* v_index);
+struct PendingV;
+int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states, int64_t n, int64_t ld, const double* host_params,
+                     int num_params, double t, double dt, int v_index, double* v_copy, const PendingV& pend);
 
 // beat_ode_jit.hip
 bool beat_jit_enabled();

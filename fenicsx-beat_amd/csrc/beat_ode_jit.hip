@@ -343,3 +343,91 @@ extern "C" int beat_ode_jit_stats(long long* host_out) {
   if (!s.usable) beat_set_error("run-time compilation unavailable: %s", s.why.c_str());  // (beat_last_error says why)
   return s.usable ? 1 : 0;
 }
+
+// ---- cell models that are not shipped: registered as source, compiled at first use (beat.models.from_ode) -----------------------------
+namespace {
+struct CustomModel {
+  std::string name, source;
+  int ns, np, v_index;
+};
+std::vector<CustomModel>& customs() {
+  static std::vector<CustomModel> v;
+  return v;
+}
+std::mutex& customs_mutex() {
+  static std::mutex m;
+  return m;
+}
+}  // namespace
+
+extern "C" int beat_ode_model_register(const char* name, const char* source, int num_states, int num_params, int v_index, int* model_id_out) {
+  BEAT_REQUIRE(name != nullptr && source != nullptr && model_id_out != nullptr, "null argument");
+  BEAT_REQUIRE(num_states >= 1 && num_states <= 512 && num_params >= 1 && num_params <= 1024, "bad state / parameter count");
+  BEAT_REQUIRE(v_index >= 0 && v_index < num_states, "v_index %d out of range", v_index);
+  for (const char* c = name; *c; ++c)
+    BEAT_REQUIRE((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_', "model name: [A-Za-z0-9_]+");
+  BEAT_REQUIRE(std::string(source).find(std::string("struct ") + name) != std::string::npos, "the source does not define struct %s", name);
+  BEAT_REQUIRE(beat_jit_enabled(), "a model given as source needs run-time compilation, which is not available here (beat_ode_jit_stats)");
+  std::lock_guard<std::mutex> lock(customs_mutex());
+  std::vector<CustomModel>& v = customs();
+  for (size_t k = 0; k < v.size(); ++k)
+    if (v[k].name == name && v[k].source == source) {
+      *model_id_out = BEAT_MODEL_CUSTOM_BASE + (int)k;
+      return BEAT_OK;
+    }
+  v.push_back(CustomModel{name, source, num_states, num_params, v_index});
+  *model_id_out = BEAT_MODEL_CUSTOM_BASE + (int)v.size() - 1;
+  return BEAT_OK;
+}
+
+int beat_custom_model_info(int model_id, int* ns, int* np, int* v_index) {
+  std::lock_guard<std::mutex> lock(customs_mutex());
+  const int k = model_id - BEAT_MODEL_CUSTOM_BASE;
+  if (k < 0 || k >= (int)customs().size()) return BEAT_EINVAL;
+  if (ns) *ns = customs()[k].ns;
+  if (np) *np = customs()[k].np;
+  if (v_index) *v_index = customs()[k].v_index;
+  return BEAT_OK;
+}
+
+// One step of a registered model: uniform parameters, with or without a pending update.  The kernel is ode_step_kernel<Name, false, PEND>
+// of csrc/beat_ode_kernel.h, instantiated in a translation unit made of the registered source.
+int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states, int64_t n, int64_t ld, const double* host_params,
+                     int num_params, double t, double dt, int v_index, double* v_copy, const PendingV& pend_in) {
+  CustomModel m;
+  {
+    std::lock_guard<std::mutex> lock(customs_mutex());
+    const int k = model_id - BEAT_MODEL_CUSTOM_BASE;
+    BEAT_REQUIRE(k >= 0 && k < (int)customs().size(), "unknown model id %d", model_id);
+    m = customs()[k];
+  }
+  BEAT_REQUIRE(host_params != nullptr && num_params == m.np, "model %s expects %d uniform parameters (a host vector), got %d", m.name.c_str(),
+               m.np, num_params);
+  const bool have_pend = pend_in.count > 0 || pend_in.gt.d != nullptr || pend_in.dev_st != nullptr;
+  BEAT_REQUIRE(!have_pend || v_index == m.v_index, "a pending update needs v_index = %d (the model's membrane potential), got %d", m.v_index, v_index);
+  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < m.ns), "v_index %d out of range", v_index);
+  char hx[32];
+  std::snprintf(hx, sizeof hx, "%016llx", fnv(m.source));
+  const std::string key = "custom_" + m.name + "_p" + (have_pend ? "1" : "0") + "_" + hx;
+  bool known = false;
+  hipFunction_t f = beat_jit_lookup(ctx, key, &known);
+  if (!known) {
+    std::string src = "// written by libbeat_hip (beat_ode_model_register): a cell model given as source\n#include \"beat_ode_kernel.h\"\n";
+    src += m.source;
+    src += "\ntemplate __global__ void ode_step_kernel<" + m.name + ", false, " + (have_pend ? "true" : "false") + ">(\n    double*, int64_t, int64_t, ParamPack<" +
+           m.name + "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
+    f = beat_jit_get(ctx, key, src);
+  }
+  BEAT_REQUIRE(f != nullptr, "the kernel of model %s could not be compiled (see the log in the cache directory; BEAT_JIT_VERBOSE=1)", m.name.c_str());
+  std::vector<double> prm(host_params, host_params + m.np);
+  double drv = 0.0;
+  const double* ppn = nullptr;
+  int64_t pld = 0;
+  PendingV pend = pend_in;
+  MarkedArgs mk{nullptr, nullptr, 0, nullptr, nullptr};
+  SparseRows sp{{0}, 0};
+  void* args[] = {&states, &n, &ld, prm.data(), &drv, &ppn, &pld, &t, &dt, &v_index, &v_copy, &pend, &mk, &sp};
+  BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+  return BEAT_OK;
+}
+

@@ -103,9 +103,16 @@ __device__ __forceinline__ double vtl_from_right(double v) {
 // of the exec mask, and the compiler can count what is outstanding at every point of the march.
 typedef int vtl_v2i __attribute__((ext_vector_type(2)));
 constexpr unsigned VTL_OOB = 0x80000000u;
+// (-DBEAT_VTL_NT, an experiment of round 5: bit 0 = the coefficient loads non-temporal -- every coefficient is read once per pass
+// and should not push the vector rows the neighbouring tiles share out of the L2 --, bit 1 = the stores of p and q; measured in
+// profiles/r05_shell400.md; default 0)
+#ifndef BEAT_VTL_NT
+#define BEAT_VTL_NT 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ double vtl_buf_load(const double* base, unsigned bytes, unsigned off) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-  const vtl_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  const vtl_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX);
   return __hiloint2double(v.y, v.x);
 }
 __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsigned off, double val) {
@@ -113,7 +120,7 @@ __device__ __forceinline__ void vtl_buf_store(double* base, unsigned bytes, unsi
   vtl_v2i v;
   v.x = __double2loint(val);
   v.y = __double2hiint(val);
-  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, (BEAT_VTL_NT & 2) ? 2 : 0);
 }
 
 // forward slots of the 15-point stencil (beat_stencil_offsets): 0 centre, 1 +x, 3 +y, 5 +z, 7 +x+y, 9 +y+z, 11 +x+z,
@@ -359,14 +366,15 @@ __global__ __launch_bounds__(RY * 64, 4) void vtl_spmv_kernel(VtlArgs a_) {  // 
       int64_t ld = a.ld;
       asm volatile("" : "+s"(ld));
       const double* bc = A + (int64_t)z * a.plane;
-      Fn[0] = PDOT ? 0.0 : vtl_buf_load(bc, pbytes, off);  // (PDOT: the centre coefficient comes with r and p_old, a plane earlier)
+      constexpr int CNT = (BEAT_VTL_NT & 1) ? 2 : 0;
+      Fn[0] = PDOT ? 0.0 : vtl_buf_load<CNT>(bc, pbytes, off);  // (PDOT: the centre coefficient comes with r and p_old, a plane earlier)
       bc += ld;
-      Fn[1] = vtl_buf_load(bc, pbytes, off);
+      Fn[1] = vtl_buf_load<CNT>(bc, pbytes, off);
       ld += ld;
 #pragma unroll
       for (int k = 2; k < 8; ++k) {
         bc += ld;
-        Fn[k] = vtl_buf_load(bc, pbytes, off);
+        Fn[k] = vtl_buf_load<CNT>(bc, pbytes, off);
       }
     };
     load_coefs(M0, zb);
