@@ -23,12 +23,15 @@ Produced by `tools/measure_round.sh {tag}` on one gpurun box: the bench line (`{
 {d['value'] / 1e9:.2f} G node-updates/s, k = {d['config']['pcg_iterations_per_step']:.2f}"""
 if fr:
     head += f"; developed front {fr['ms_per_step']:.2f} ms/step, k = {fr['pcg_iterations_per_step']:.2f}"
+rp = st.get("rows_pattern") or {}
 head += f"""; ionic kernel
-{r['achieved'] / 1e3:.2f} TB/s of algorithmic bytes ({r['bytes_per_node']:.1f} B/node) = {r['frac']:.3f} of 8 TB/s = {st.get('kernel_frac_of_it', float('nan')):.2f} of the {st.get('rate', float('nan')) / 1e3:.2f} TB/s an
-in-place `x *= 1.0` over the same state array reached in that run), then the same command under `rocprofv3 --kernel-trace
+{r['achieved'] / 1e3:.2f} TB/s of algorithmic bytes ({r['bytes_per_node']:.1f} B/node) = {r['frac']:.3f} of 8 TB/s = {st.get('kernel_frac_of_it', float('nan')):.2f} of the {st.get('rate', float('nan')) / 1e3:.2f} TB/s the
+library's own in-place streaming probe reached over the same state array in that run, {rp.get('kernel_frac_of_it', float('nan')):.2f} of the
+{rp.get('rate', float('nan')) / 1e3:.2f} TB/s its own access pattern -- all state rows at one node index -- streams at without arithmetic; torch's
+`x.mul_(1.0)`: {st.get('torch_mul_rate', float('nan')) / 1e3:.2f}), then the same command under `rocprofv3 --kernel-trace
 --stats` (10 steps, `{RND}_{tag}_kernel_stats.csv`) and three PMC passes (FETCH_SIZE | WRITE_SIZE | SQ / GRBM counters; 4
-steps each), condensed by `tools/summarize_prof.py` (`{RND}_{tag}_pmc.json`).  `mul_` kernels in the tables are the in-place
-streaming probe.
+steps each), condensed by `tools/summarize_prof.py` (`{RND}_{tag}_pmc.json`).  `stream_kernel` / `rows_kernel` / `mul_` kernels in
+the tables are the streaming probes that close every bench run.
 
 Reading the tables: `rr_kernel<MODE, rows, prefetch, guess>`: MODE 0 = PDOT (p = D^-1 r + beta p, p.Ap), 1 = RUPD
 (r -= alpha A p), 2 = right-hand side (`true`: with the second register window for the guess increment);

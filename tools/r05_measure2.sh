@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5: the voxel shell under rocprofv3 (401^3), the shell at BASELINE configs[4]'s own size (521^3), then all five configurations
+set -o pipefail
+rm -rf gpurun_out/prof_shell
+bash tools/profile_shell.sh 400
+python3 tools/summarize_prof.py gpurun_out/prof_shell gpurun_out/prof_shell/summary.md "Round 5: voxel shell (401^3 box) under rocprofv3" --json gpurun_out/prof_shell/summary.json > /dev/null
+rm -f gpurun_out/prof_shell/*kernel_trace.csv gpurun_out/prof_shell/*agent_info.csv gpurun_out/prof_shell/*counter_collection.csv
+for i in 1 2; do timeout -k 10 300 python tools/bench_biv.py --size 400 --steps 20 2>&1 | tail -1; done | tee gpurun_out/r05_biv400_final.txt
+timeout -k 10 500 python tools/bench_biv.py --size 520 --steps 20 --warmup 5 2>&1 | grep -v amdgpu | tail -4 | tee gpurun_out/r05_biv520_final.txt
+rm -rf gpurun_out/configs
+bash tools/run_configs.sh > gpurun_out/configs_run.txt 2>&1; tail -30 gpurun_out/configs_run.txt
