@@ -142,6 +142,7 @@ IPC_MAX_RANKS = 16
 COMM_SERIAL = 1
 MAX_SPARSE_ROWS = 16  # BEAT_MAX_SPARSE_ROWS of csrc/beat_ode_kernel.h: on an instance compiled for the rows (run-time compilation)
 MAX_SPARSE_ROWS_RT = 4  # BEAT_MAX_SPARSE_ROWS_RT: on the shipped kernel
+CUSTOM_MODEL_BASE = 100  # BEAT_MODEL_CUSTOM_BASE: ids of models registered as source (beat_ode_model_register)
 TRANSPORT_NAMES = {0: "callbacks", 1: "rccl", 2: "rccl-serial", 3: "ipc"}
 E_NOT_CONVERGED = -3
 

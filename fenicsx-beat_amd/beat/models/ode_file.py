@@ -9,12 +9,14 @@ turned into a SymPy expression, the right-hand sides f_i and the TOTAL self-deri
 resolved: the variant the reference's Niederer table pins) are put through common-subexpression elimination and printed
 as one C++ ``Model`` struct for ``csrc/beat_ode_kernel.h``; the library compiles it at first use (``beat_ode_model_register``,
 run-time ``hipcc --genco``, cached like the sparse-row instances) and every entry point that takes a model id takes this one:
-the fused split step, the pending update, the library's step loop.  Schemes: ``generalized_rush_larsen`` (gotranx's GRL1:
+the fused split step, the pending update, the library's step loop, per-node parameter rows, parameter classes and cell types in
+one launch (``DolfinMultiODESolver``), the in-kernel time loop (``run`` / ``single_cell.get_steady_state``).  Schemes: ``generalized_rush_larsen`` (gotranx's GRL1:
 y_i += f_i / J_ii (exp(J_ii dt) - 1) where |J_ii| > 1e-8, forward Euler elsewhere) and ``forward_euler``.
 
 The same expressions, lambdified for NumPy, are the handle's HOST evaluation (``numpy_step``): what the tests compare the kernel
-with, and what runs where no GPU / compiler is to be had.  Uniform parameters only (a (P,) vector); per-node parameters of a
-generated model raise.  SymPy is needed (it is what gotranx itself builds on).
+with, and what runs where no GPU / compiler is to be had.  Parameters: a (P,) vector or per node (P, N); what a generated model
+does not get is the instance compiled for a FEW varying rows (beat_ode_step_rows: a (P, N) array of a generated model is read
+whole, or runs as classes when its columns are few).  SymPy is needed (it is what gotranx itself builds on).
 """
 
 from __future__ import annotations
@@ -204,9 +206,9 @@ class OdeFileModel(DeviceModel):
         y = np.asarray(states, dtype=np.float64)
         one_d = y.ndim == 1
         y2 = y.reshape(y.shape[0], -1)
-        p = np.asarray(parameters, dtype=np.float64)
-        if p.ndim != 1:
-            raise NotImplementedError("a model generated from an .ode file takes uniform parameters (a (P,) vector)")
+        p = np.asarray(parameters, dtype=np.float64)  # (P,) or per node (P, N)
+        if p.ndim == 2 and p.shape[1] != y2.shape[1]:
+            raise ValueError(f"per-node parameters must have shape ({len(p)}, {y2.shape[1]}), got {p.shape}")
         with np.errstate(all="ignore"):
             f, J = self._numpy_fn(*[y2[k] for k in range(y2.shape[0])], *[p[k] for k in range(len(p))], float(t))
         out = np.empty_like(y2)
@@ -253,15 +255,10 @@ class OdeFileModel(DeviceModel):
         return self.numpy_step(states, t, parameters, dt)
 
     def run(self, states, parameters, dt, nsteps, nbeats=1, t0=0.0, track_indices=None, save_freq=1):
-        """(The in-kernel time loop is built for the shipped models: a generated one steps launch by launch.)"""
-        y = np.asarray(states, dtype=np.float64)
-        rows = []
-        for _ in range(int(nbeats)):
-            for j in range(int(nsteps)):
-                if track_indices is not None and j % int(save_freq) == 0:
-                    rows.append(np.array([y[i] for i in track_indices]))
-                y = self(states=y, t=t0 + j * dt, parameters=parameters, dt=dt)
-        return y, (np.array(rows) if track_indices is not None else None)
+        """nbeats x nsteps steps inside ONE launch (beat_ode_run: ``ode_run_kernel`` instantiated for this model at first use), as
+        for the shipped models -- ``single_cell.get_steady_state`` with a generated model paces on the device."""
+        self.register()
+        return super().run(states, parameters, dt, nsteps, nbeats=nbeats, t0=t0, track_indices=track_indices, save_freq=save_freq)
 
 
 def from_ode(path, scheme: str = "generalized_rush_larsen", v_name: str | None = None, name: str | None = None) -> OdeFileModel:

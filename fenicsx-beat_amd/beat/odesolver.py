@@ -187,7 +187,8 @@ class _DeviceODE:
         self.classes = None
         import os
 
-        if os.environ.get("BEAT_PARAM_SPARSE", "1") != "0" and tensor.shape[1] == self.n:
+        # (a model registered as source has no compiled sparse-row instance: all its rows are read)
+        if os.environ.get("BEAT_PARAM_SPARSE", "1") != "0" and tensor.shape[1] == self.n and self.model.model_id < _hip.CUSTOM_MODEL_BASE:
             varying = (tensor != tensor[:, :1]).any(dim=1)
             idx = varying.nonzero().flatten().cpu().numpy().astype(np.int32)
             # (up to 16 varying rows on a kernel instance compiled for their indices, 4 where that cannot be had)
@@ -496,6 +497,10 @@ class DolfinMultiODESolver(BaseDolfinODESolver):
         ctx = self.v_ode._ctx
         self._ctx = ctx
         self.on_device = all(isinstance(f, DeviceModel) for f in self.fun.values())
+        if self.on_device:
+            for f in self.fun.values():  # models generated from .ode files get their ids now (markers sharing one are compared below)
+                if hasattr(f, "register"):
+                    f.register()
         self._initialize_full_values()
         self._aliases: list[grid.Function] = []
         self._pending_ops = None

@@ -8,80 +8,7 @@
 
 #include <functional>
 
-// Many steps inside one launch (single-cell pre-pacing, free-running ODE solves): the node's states stay
-// in registers; t restarts at 0 for every beat and advances as j*dt within it (numpy.arange semantics of
-// src/beat/single_cell.py:42-65).  Optionally records `ntrack` states every `save_freq` steps.
-struct TrackSpec {
-  int idx[8];
-  int n;
-};
-
-// (one wave per SIMD asked of the register allocator: the states of a node stay in registers through the time loop,
-// and these launches are a few hundred to a few thousand cells -- occupancy buys nothing, scratch traffic costs)
-template <class Model, bool PER_NODE>
-__global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
-    double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
-    const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
-    TrackSpec track, double* __restrict__ trace) {
-  __shared__ double etab[BEAT_EXP_TAB];
-  __shared__ LogEntry ltab[128];
-  static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
-  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
-  if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
-  __syncthreads();
-  const FastMath fm{etab, ltab};
-  const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  double y[Model::NS];
-#pragma unroll
-  for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];
-  double pl[PER_NODE ? Model::NP : 1];
-  typename Model::Derived dl = drv;
-  if (PER_NODE) {
-#pragma unroll
-    for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
-    dl = Model::derive((const double*)pl);
-  }
-  // Models keep the states in registers across steps (RegIO).  REGISTER_LOOP = false routes a model's step through
-  // global memory instead: needed by round 1's generated ToR-ORd step, whose heavy spilling produced wrong values
-  // through RegIO with ROCm 7.2; no model in the library uses it any more (the hand-organised ToR-ORd kernel has no
-  // spills), tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards every model.
-  const RegIO rio{y};
-  const NodeIO gio{states, ld, i, nullptr, -1};
-  int64_t row = 0;
-  for (int beat = 0; beat < nbeats; ++beat) {
-    for (int64_t j = 0; j < nsteps; ++j) {
-      if (track.n > 0 && j % save_freq == 0) {
-        for (int a = 0; a < track.n; ++a) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < Model::NS; ++k)
-            if (k == track.idx[a]) v = y[k];
-          trace[(row * track.n + a) * n + i] = v;
-        }
-        ++row;
-      }
-      const double t = t0 + (double)j * dt;
-      if (Model::REGISTER_LOOP) {
-        if (PER_NODE)
-          Model::step(rio, (const double*)pl, dl, fm, t, dt);
-        else
-          Model::step(rio, prm.p, dl, fm, t, dt);
-      } else {
-        if (PER_NODE)
-          Model::step(gio, (const double*)pl, dl, fm, t, dt);
-        else
-          Model::step(gio, prm.p, dl, fm, t, dt);
-#pragma unroll
-        for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];  // for the tracking above
-      }
-    }
-  }
-  if (Model::REGISTER_LOOP) {
-#pragma unroll
-    for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
-  }
-}
+// (ode_run_kernel -- many steps inside one launch -- lives in beat_ode_kernel.h: models registered as source instantiate it too)
 
 template <class Model>
 static int launch_ode_run(beat_ctx* ctx, double* states, int64_t n, int64_t ld, const double* host_params,
@@ -120,6 +47,9 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
   BEAT_REQUIRE(ctx != nullptr && dev_states != nullptr, "null argument");
   BEAT_REQUIRE(n >= 0 && ld >= n && nsteps >= 0 && nbeats >= 0, "bad shape");
   if (n == 0 || nsteps == 0 || nbeats == 0) return BEAT_OK;
+  if (model_id >= BEAT_MODEL_CUSTOM_BASE)  // a model registered as source (beat_ode_model_register)
+    return beat_custom_run(ctx, model_id, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t0, dt, nsteps, nbeats,
+                           save_freq, host_track_idx, ntrack, dev_trace);
 #define BEAT_RUN(M)                                                                                          \
   return launch_ode_run<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, \
                            t0, dt, nsteps, nbeats, save_freq, host_track_idx, ntrack, dev_trace)
@@ -254,10 +184,10 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
   BEAT_REQUIRE(n >= 0 && ld >= n, "bad shape n=%lld ld=%lld", (long long)n, (long long)ld);
   BEAT_REQUIRE((n + BEAT_BLOCK - 1) / BEAT_BLOCK < (int64_t)0x7fffffff, "n too large");
   if (n == 0) return BEAT_OK;
-  if (model_id >= BEAT_MODEL_CUSTOM_BASE) {  // a model registered as source (beat_ode_model_register): uniform parameters only
-    BEAT_REQUIRE(dev_params_per_node == nullptr && mk.markers == nullptr && sp.count == 0,
-                 "a model registered as source takes uniform parameters (no per-node rows, no classes)");
-    return beat_custom_step(ctx, model_id, ode_grid(n), dev_states, n, ld, host_params, num_params, t, dt, v_index, dev_v_copy, pend);
+  if (model_id >= BEAT_MODEL_CUSTOM_BASE) {  // a model registered as source (beat_ode_model_register)
+    BEAT_REQUIRE(sp.count == 0, "a model registered as source takes a uniform vector, all per-node rows or classes (no sparse rows)");
+    return beat_custom_step(ctx, model_id, ode_grid(n), dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt,
+                            v_index, dev_v_copy, pend, mk);
   }
 #define BEAT_STEP(M)                                                                                             \
   return launch_ode<M>(ctx, dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt, \
@@ -425,7 +355,15 @@ extern "C" int beat_ode_class_table_doubles(int model_id, int* doubles_per_class
     case BEAT_MODEL_TP06_GRL1: *doubles_per_class = table_doubles<Tp06Grl1>(); break;
     case BEAT_MODEL_TORORD_DYNCL_GRL1: *doubles_per_class = table_doubles<TorordDynClGrl1>(); break;
     case BEAT_MODEL_TORORD_LAND_GRL1: *doubles_per_class = table_doubles<TorordLandGrl1>(); break;
-    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+    default: {
+      int np = 0;  // a model registered as source: its parameters + the one double of its (empty) Derived
+      if (beat_custom_model_info(model_id, nullptr, &np, nullptr) == BEAT_OK) {
+        *doubles_per_class = np + 1;
+        break;
+      }
+      beat_set_error("unknown model id %d", model_id);
+      return BEAT_EINVAL;
+    }
   }
   return BEAT_OK;
 }
@@ -443,7 +381,18 @@ extern "C" int beat_ode_class_table_fill(beat_ctx* ctx, int model_id, const doub
     case BEAT_MODEL_TP06_GRL1: rc = fill_table<Tp06Grl1>(host_params, num_params, classes, tab); break;
     case BEAT_MODEL_TORORD_DYNCL_GRL1: rc = fill_table<TorordDynClGrl1>(host_params, num_params, classes, tab); break;
     case BEAT_MODEL_TORORD_LAND_GRL1: rc = fill_table<TorordLandGrl1>(host_params, num_params, classes, tab); break;
-    default: beat_set_error("unknown model id %d", model_id); return BEAT_EINVAL;
+    default: {
+      int np = 0;
+      if (beat_custom_model_info(model_id, nullptr, &np, nullptr) != BEAT_OK) {
+        beat_set_error("unknown model id %d", model_id);
+        return BEAT_EINVAL;
+      }
+      BEAT_REQUIRE(num_params == np, "model expects %d parameters, got %d", np, num_params);
+      tab.assign((size_t)(np + 1) * classes, 0.0);
+      for (int c = 0; c < classes; ++c)
+        for (int k = 0; k < np; ++k) tab[(size_t)c * (np + 1) + k] = host_params[(size_t)c * np + k];
+      rc = BEAT_OK;
+    }
   }
   if (rc) return rc;
   BEAT_HIP_CHECK(hipMemcpyAsync(dev_table, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

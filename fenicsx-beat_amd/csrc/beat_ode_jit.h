@@ -26,7 +26,11 @@ constexpr int BEAT_MODEL_CUSTOM_BASE = 100;  // model ids of cell models registe
 int beat_custom_model_info(int model_id, int* ns, int* np, int* v_index);
 struct PendingV;
 int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states, int64_t n, int64_t ld, const double* host_params,
-                     int num_params, double t, double dt, int v_index, double* v_copy, const PendingV& pend);
+                     int num_params, const double* ppn, int64_t pld, double t, double dt, int v_index, double* v_copy, const PendingV& pend,
+                     const MarkedArgs& mk);
+int beat_custom_run(beat_ctx* ctx, int model_id, double* states, int64_t n, int64_t ld, const double* host_params, int num_params,
+                    const double* ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq, const int* track_idx,
+                    int ntrack, double* trace);
 
 // beat_ode_jit.hip
 bool beat_jit_enabled();

@@ -219,10 +219,16 @@ bool run_hipcc(const JitState& s, const std::string& src, const std::string& out
 }
 
 // the kernel's symbol in a code object (an offload bundle or a bare ELF): the NUL-terminated string that starts with _Z, names
-// ode_step_kernel and carries no suffix (.kd, .private_seg_size ... are the descriptor and its metadata)
+// ode_step_kernel (or ode_run_kernel: a translation unit instantiates ONE kernel) and carries no suffix (.kd, .private_seg_size ...
+// are the descriptor and its metadata)
+std::string kernel_symbol(const std::string& blob, const char* stem);
 std::string kernel_symbol(const std::string& blob) {
+  const std::string s = kernel_symbol(blob, "ode_step_kernel");
+  return s.empty() ? kernel_symbol(blob, "ode_run_kernel") : s;
+}
+std::string kernel_symbol(const std::string& blob, const char* stem) {
   size_t pos = 0;
-  while ((pos = blob.find("ode_step_kernel", pos)) != std::string::npos) {
+  while ((pos = blob.find(stem, pos)) != std::string::npos) {
     size_t b = pos;
     while (b > 0 && blob[b - 1] != '\0' && (pos - b) < 8) --b;
     size_t e = pos;
@@ -390,44 +396,96 @@ int beat_custom_model_info(int model_id, int* ns, int* np, int* v_index) {
   return BEAT_OK;
 }
 
-// One step of a registered model: uniform parameters, with or without a pending update.  The kernel is ode_step_kernel<Name, false, PEND>
-// of csrc/beat_ode_kernel.h, instantiated in a translation unit made of the registered source.
-int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states, int64_t n, int64_t ld, const double* host_params,
-                     int num_params, double t, double dt, int v_index, double* v_copy, const PendingV& pend_in) {
-  CustomModel m;
-  {
-    std::lock_guard<std::mutex> lock(customs_mutex());
-    const int k = model_id - BEAT_MODEL_CUSTOM_BASE;
-    BEAT_REQUIRE(k >= 0 && k < (int)customs().size(), "unknown model id %d", model_id);
-    m = customs()[k];
-  }
-  BEAT_REQUIRE(host_params != nullptr && num_params == m.np, "model %s expects %d uniform parameters (a host vector), got %d", m.name.c_str(),
-               m.np, num_params);
-  const bool have_pend = pend_in.count > 0 || pend_in.gt.d != nullptr || pend_in.dev_st != nullptr;
-  BEAT_REQUIRE(!have_pend || v_index == m.v_index, "a pending update needs v_index = %d (the model's membrane potential), got %d", m.v_index, v_index);
-  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < m.ns), "v_index %d out of range", v_index);
+// A kernel of a registered model: the translation unit is the registered source behind beat_ode_kernel.h plus ONE explicit
+// instantiation; `what` names it in the cache key.
+namespace {
+int custom_model(int model_id, CustomModel& m) {
+  std::lock_guard<std::mutex> lock(customs_mutex());
+  const int k = model_id - BEAT_MODEL_CUSTOM_BASE;
+  BEAT_REQUIRE(k >= 0 && k < (int)customs().size(), "unknown model id %d", model_id);
+  m = customs()[k];
+  return BEAT_OK;
+}
+hipFunction_t custom_instance(beat_ctx* ctx, const CustomModel& m, const std::string& what, const std::string& instantiation) {
   char hx[32];
   std::snprintf(hx, sizeof hx, "%016llx", fnv(m.source));
-  const std::string key = "custom_" + m.name + "_p" + (have_pend ? "1" : "0") + "_" + hx;
+  const std::string key = "custom_" + m.name + "_" + what + "_" + hx;
   bool known = false;
   hipFunction_t f = beat_jit_lookup(ctx, key, &known);
   if (!known) {
     std::string src = "// written by libbeat_hip (beat_ode_model_register): a cell model given as source\n#include \"beat_ode_kernel.h\"\n";
     src += m.source;
-    src += "\ntemplate __global__ void ode_step_kernel<" + m.name + ", false, " + (have_pend ? "true" : "false") + ">(\n    double*, int64_t, int64_t, ParamPack<" +
-           m.name + "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);\n";
+    src += "\n" + instantiation + "\n";
     f = beat_jit_get(ctx, key, src);
   }
-  BEAT_REQUIRE(f != nullptr, "the kernel of model %s could not be compiled (see the log in the cache directory; BEAT_JIT_VERBOSE=1)", m.name.c_str());
-  std::vector<double> prm(host_params, host_params + m.np);
+  if (f == nullptr)
+    beat_set_error("the kernel of model %s could not be compiled (see the log in the cache directory; BEAT_JIT_VERBOSE=1)", m.name.c_str());
+  return f;
+}
+}  // namespace
+
+// One step of a registered model, every form the shipped models' step takes except the compiled sparse rows: uniform parameters,
+// all per-node rows, or parameter classes (markers + table, optionally the compact layout's node map), each with or without a pending
+// update.  The kernel is ode_step_kernel<Name, PER_NODE, PEND, MARKED> of csrc/beat_ode_kernel.h.
+int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states, int64_t n, int64_t ld, const double* host_params,
+                     int num_params, const double* ppn, int64_t pld, double t, double dt, int v_index, double* v_copy,
+                     const PendingV& pend_in, const MarkedArgs& mk_in) {
+  CustomModel m;
+  if (int rc = custom_model(model_id, m)) return rc;
+  const bool marked = mk_in.markers != nullptr, per_node = ppn != nullptr;
+  BEAT_REQUIRE(!(marked && per_node) && (!marked || mk_in.table != nullptr), "parameter classes come with a table, not with per-node rows");
+  BEAT_REQUIRE(marked || ((host_params != nullptr || per_node) && num_params == m.np),
+               "model %s expects %d parameters (a host vector, per-node rows or classes), got %d", m.name.c_str(), m.np, num_params);
+  BEAT_REQUIRE(!per_node || pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
+  const bool have_pend = pend_in.count > 0 || pend_in.gt.d != nullptr || pend_in.dev_st != nullptr;
+  BEAT_REQUIRE(!have_pend || v_index == m.v_index, "a pending update needs v_index = %d (the model's membrane potential), got %d", m.v_index, v_index);
+  BEAT_REQUIRE(v_copy == nullptr || (v_index >= 0 && v_index < m.ns), "v_index %d out of range", v_index);
+  BEAT_REQUIRE(!marked || v_copy == nullptr || v_index == m.v_index, "the class kernel mirrors the model's potential (row %d), not row %d",
+               m.v_index, v_index);
+  const char* tf[2] = {"false", "true"};
+  const std::string what = std::string("step_n") + (per_node ? "1" : "0") + "p" + (have_pend ? "1" : "0") + "m" + (marked ? "1" : "0");
+  hipFunction_t f = custom_instance(ctx, m, what,
+      "template __global__ void ode_step_kernel<" + m.name + ", " + tf[per_node] + ", " + tf[have_pend] + ", " + tf[marked] + ">(\n    double*, int64_t, int64_t, ParamPack<" +
+      m.name + "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);");
+  if (f == nullptr) return BEAT_EINVAL;
+  std::vector<double> prm(m.np, 1.0);
+  if (host_params != nullptr) prm.assign(host_params, host_params + m.np);
   double drv = 0.0;
-  const double* ppn = nullptr;
-  int64_t pld = 0;
   PendingV pend = pend_in;
-  MarkedArgs mk{nullptr, nullptr, 0, nullptr, nullptr};
+  MarkedArgs mk = mk_in;
   SparseRows sp{{0}, 0};
   void* args[] = {&states, &n, &ld, prm.data(), &drv, &ppn, &pld, &t, &dt, &v_index, &v_copy, &pend, &mk, &sp};
   BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
   return BEAT_OK;
 }
 
+// nbeats x nsteps steps of a registered model inside one launch (beat_ode_run): ode_run_kernel<Name, PER_NODE>.
+int beat_custom_run(beat_ctx* ctx, int model_id, double* states, int64_t n, int64_t ld, const double* host_params, int num_params,
+                    const double* ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq, const int* track_idx,
+                    int ntrack, double* trace) {
+  CustomModel m;
+  if (int rc = custom_model(model_id, m)) return rc;
+  const bool per_node = ppn != nullptr;
+  BEAT_REQUIRE((host_params != nullptr || per_node) && num_params == m.np, "model %s expects %d parameters (a host vector or per-node rows), got %d",
+               m.name.c_str(), m.np, num_params);
+  BEAT_REQUIRE(!per_node || pld >= n, "params_ld %lld < n %lld", (long long)pld, (long long)n);
+  BEAT_REQUIRE(ntrack >= 0 && ntrack <= 8, "at most 8 tracked states");
+  BEAT_REQUIRE(ntrack == 0 || (trace != nullptr && save_freq >= 1 && track_idx != nullptr), "tracking needs a trace buffer and save_freq >= 1");
+  TrackSpec tr{};
+  tr.n = ntrack;
+  for (int a = 0; a < ntrack; ++a) {
+    BEAT_REQUIRE(track_idx[a] >= 0 && track_idx[a] < m.ns, "tracked state %d out of range", track_idx[a]);
+    tr.idx[a] = track_idx[a];
+  }
+  hipFunction_t f = custom_instance(ctx, m, std::string("run_n") + (per_node ? "1" : "0"),
+      "template __global__ void ode_run_kernel<" + m.name + ", " + (per_node ? "true" : "false") + ">(\n    double*, int64_t, int64_t, ParamPack<" + m.name +
+      "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int64_t, int, int, TrackSpec, double*);");
+  if (f == nullptr) return BEAT_EINVAL;
+  std::vector<double> prm(m.np, 1.0);
+  if (host_params != nullptr) prm.assign(host_params, host_params + m.np);
+  double drv = 0.0;
+  const unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  void* args[] = {&states, &n, &ld, prm.data(), &drv, &ppn, &pld, &t0, &dt, &nsteps, &nbeats, &save_freq, &tr, &trace};
+  BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+  return BEAT_OK;
+}

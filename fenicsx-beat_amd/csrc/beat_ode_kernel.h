@@ -51,10 +51,35 @@ struct PendingNow {
   int count;
   beat_pde_detail::GuessTerms gt;
 };
-__device__ __forceinline__ PendingNow beat_pending_now(const PendingV& p) {
+// How a launch enqueued behind an open solve reads that solve's update count (BEAT_PENDING_READ, measured at 512^3 on one box,
+// profiles/r05_step_gap.md): 0 = per tile with a vector load through the generic pointer -- every pending load of the tile waits on
+// its round trip, and its s_waitcnt vmcnt(0) on the previous tile's stores as well: +0.10 ms on the ionic kernel of step() against the
+// library's loop, which knows the count on the host; 1 = once per launch, kept in an SGPR across the tile loop: the difference is
+// gone, but BOTH paths lose 0.1 - 0.4 ms to the changed register allocation; 2 = per tile with a SCALAR load (the state was written
+// by earlier kernels and is constant for this one; the constant cache is invalidated at kernel start): no vector-memory wait.
+#ifndef BEAT_PENDING_READ
+#define BEAT_PENDING_READ 2
+#endif
+__device__ __forceinline__ int beat_pending_read(const PendingV& p) {
+#if BEAT_PENDING_READ == 1
+  return p.dev_st != nullptr ? __builtin_amdgcn_readfirstlane((int)p.dev_st[beat_pde_detail::NUPD]) : -1;
+#else
+  return -1;
+#endif
+}
+__device__ __forceinline__ PendingNow beat_pending_now(const PendingV& p, int nupd) {
   PendingNow o{p.count, p.gt};
-  if (p.dev_st != nullptr) {  // (wave-uniform: scalar loads)
-    const int nupd = (int)p.dev_st[beat_pde_detail::NUPD];
+#if BEAT_PENDING_READ == 0
+  if (p.dev_st != nullptr) nupd = (int)p.dev_st[beat_pde_detail::NUPD];
+#elif BEAT_PENDING_READ == 2
+  if (p.dev_st != nullptr) {
+    typedef const __attribute__((address_space(4))) double* ConstD;
+    ConstD stc = (ConstD)(uintptr_t)p.dev_st;
+    asm volatile("" : "+s"(stc));
+    nupd = (int)stc[beat_pde_detail::NUPD];
+  }
+#endif
+  if (nupd >= 0) {
     o.count = nupd % p.ring_len;
     o.gt.accumulate = nupd >= p.ring_len ? 1 : 0;
     const bool e_due = nupd == 0 && p.gt.use_e != 0;
@@ -160,6 +185,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   __syncthreads();
   const FastMath fm{etab, ltab};
   if (PEND && pend.dev_st != nullptr && pend.dev_st[beat_pde_detail::STOP] == 0.0) return;  // the solve ahead has not latched (see PendingV)
+  const int nupd_dev = PEND ? beat_pending_read(pend) : -1;
   // (Round 3, measured and removed: starting the three blocks that share a CU a third of a tile apart -- s_sleep by
   // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
   // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       // the potential with the pending update applied (and the guess's bookkeeping done) once, ahead of the passes --
       // same expressions and order as NodeIOPending::load / x_flush_kernel: the pending values die here instead of
       // staying live through every pass (-30 VGPRs, no scratch)
-      const PendingNow now = beat_pending_now(pendl);
+      const PendingNow now = beat_pending_now(pendl, nupd_dev);
       double pp[BEAT_MAX_PENDING_CLASS], pa[BEAT_MAX_PENDING_CLASS];
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING_CLASS; ++j) {
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    const PendingNow now = beat_pending_now(pendl);
+    const PendingNow now = beat_pending_now(pendl, nupd_dev);
     NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
@@ -411,6 +437,81 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     }
     if (v_copy != nullptr) v_copy[i] = states[(int64_t)v_index * ldl + i];
   }
+  }
+}
+
+// Many steps inside one launch (single-cell pre-pacing, free-running ODE solves): the node's states stay
+// in registers; t restarts at 0 for every beat and advances as j*dt within it (numpy.arange semantics of
+// src/beat/single_cell.py:42-65).  Optionally records `ntrack` states every `save_freq` steps.
+struct TrackSpec {
+  int idx[8];
+  int n;
+};
+
+// (one wave per SIMD asked of the register allocator: the states of a node stay in registers through the time loop,
+// and these launches are a few hundred to a few thousand cells -- occupancy buys nothing, scratch traffic costs)
+template <class Model, bool PER_NODE>
+__global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
+    double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm, typename Model::Derived drv,
+    const double* __restrict__ ppn, int64_t pld, double t0, double dt, int64_t nsteps, int nbeats, int save_freq,
+    TrackSpec track, double* __restrict__ trace) {
+  __shared__ double etab[BEAT_EXP_TAB];
+  __shared__ LogEntry ltab[128];
+  static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
+  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
+  __syncthreads();
+  const FastMath fm{etab, ltab};
+  const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double y[Model::NS];
+#pragma unroll
+  for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];
+  double pl[PER_NODE ? Model::NP : 1];
+  typename Model::Derived dl = drv;
+  if (PER_NODE) {
+#pragma unroll
+    for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+    dl = Model::derive((const double*)pl);
+  }
+  // Models keep the states in registers across steps (RegIO).  REGISTER_LOOP = false routes a model's step through
+  // global memory instead: needed by round 1's generated ToR-ORd step, whose heavy spilling produced wrong values
+  // through RegIO with ROCm 7.2; no model in the library uses it any more (the hand-organised ToR-ORd kernel has no
+  // spills), tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards every model.
+  const RegIO rio{y};
+  const NodeIO gio{states, ld, i, nullptr, -1};
+  int64_t row = 0;
+  for (int beat = 0; beat < nbeats; ++beat) {
+    for (int64_t j = 0; j < nsteps; ++j) {
+      if (track.n > 0 && j % save_freq == 0) {
+        for (int a = 0; a < track.n; ++a) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < Model::NS; ++k)
+            if (k == track.idx[a]) v = y[k];
+          trace[(row * track.n + a) * n + i] = v;
+        }
+        ++row;
+      }
+      const double t = t0 + (double)j * dt;
+      if (Model::REGISTER_LOOP) {
+        if (PER_NODE)
+          Model::step(rio, (const double*)pl, dl, fm, t, dt);
+        else
+          Model::step(rio, prm.p, dl, fm, t, dt);
+      } else {
+        if (PER_NODE)
+          Model::step(gio, (const double*)pl, dl, fm, t, dt);
+        else
+          Model::step(gio, prm.p, dl, fm, t, dt);
+#pragma unroll
+        for (int k = 0; k < Model::NS; ++k) y[k] = states[(int64_t)k * ld + i];  // for the tracking above
+      }
+    }
+  }
+  if (Model::REGISTER_LOOP) {
+#pragma unroll
+    for (int k = 0; k < Model::NS; ++k) states[(int64_t)k * ld + i] = y[k];
   }
 }
 

@@ -641,6 +641,9 @@ extern "C" int beat_pde_set_ghost_types(beat_pde* pde, int ghost_lo_type, int gh
 
 extern "C" int beat_pde_destroy(beat_pde* pde) {
   if (pde == nullptr) return BEAT_OK;
+  // (an open solve -- beat_pde_solve_begin without its end -- has kernels and the copy of its scalar state in the queue: they read and
+  // write what is freed below)
+  if (pde->open.on && pde->ctx != nullptr) (void)hipStreamSynchronize(pde->ctx->stream);
   (void)hipFree(pde->d_tabs);
   (void)hipFree(pde->d_st);
   (void)hipFree(pde->d_alphas);
@@ -688,6 +691,7 @@ static int upload_tables(beat_pde* pde) {
 
 extern "C" int beat_pde_set_timestep(beat_pde* pde, double C_m, double theta, double dt) {
   BEAT_REQUIRE(pde != nullptr, "null pde");
+  BEAT_REQUIRE(!pde->open.on, "the operator has an open solve: finish it first (beat_pde_solve_end)");
   pde->C_m = C_m;
   pde->theta = theta;
   pde->dt = dt;

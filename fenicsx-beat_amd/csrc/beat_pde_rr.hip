@@ -44,6 +44,8 @@ struct RGeom {
   int z_lo, z_hi;                  // planes [z_lo, z_hi) computed by this launch (whole slab: 0, nz)
   int part_off;                    // first block-partial slot this launch writes
   int ghost_lo_tz, ghost_hi_tz;    // z node type (0 low face, 1 interior, 2 high face) of the ghost planes -1 / nz
+  int nrg;                         // > 0: the four waves of a block own four ADJACENT row blocks of one x segment (nrg groups of 4 row
+                                   // blocks per plane): the y-halo rows they share are fetched within one workgroup, in step (see make_geom)
 };
 
 // RR_UDOT / RR_PRUPD: the single-reduction iteration of a decomposed solve (BEAT_DIST_MERGED, see beat_rr_udot_part)
@@ -143,10 +145,16 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   const int lane = threadIdx.x & 63;
   const int blk = xcd_block(blockIdx.x, g.total_blocks);
   const int w = blk * 4 + (threadIdx.x >> 6);
-  const bool wave_ok = blk < g.total_blocks && w < g.total_waves;
-  const int seg = w % g.nsegx;
-  const int rb = (w / g.nsegx) % g.nrb;
-  const int chunk = w / (g.nsegx * g.nrb);
+  int seg = w % g.nsegx;
+  int rb = (w / g.nsegx) % g.nrb;
+  int chunk = w / (g.nsegx * g.nrb);
+  bool wave_ok = blk < g.total_blocks && w < g.total_waves;
+  if (g.nrg > 0) {
+    seg = blk % g.nsegx;
+    rb = ((blk / g.nsegx) % g.nrg) * 4 + (int)(threadIdx.x >> 6);
+    chunk = blk / (g.nsegx * g.nrg);
+    wave_ok = blk < g.total_blocks && rb < g.nrb;
+  }
   const int gx = seg * SEG - 1 + lane;
   const int y0 = rb * RY - 1;  // global row of register row 0
   const int zb = g.z_lo + chunk * g.zc;
@@ -533,7 +541,16 @@ int rr_prefetch() {  // planes fetched ahead of their use (BEAT_RR_PD = 1, 2 or 
 }
 
 // Decomposition of the planes [z_lo, z_hi) of the slab into waves; block partials are written from slot part_off on.
-RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows = 0) {
+// BEAT_RR_BY_ROWS: bit m set = launches of MODE m put the four waves of a block on four adjacent row blocks (RGeom::nrg)
+int rr_by_rows_mask() {
+  static const int mask = [] {
+    const char* e = std::getenv("BEAT_RR_BY_ROWS");
+    return e ? std::atoi(e) : 0;
+  }();
+  return mask;
+}
+
+RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows = 0, int mode = -1) {
   const Geom& f = pde->g;
   RGeom g{};
   const int64_t nodes = (int64_t)f.nx * f.ny * f.nz;
@@ -552,7 +569,8 @@ RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows 
   g.nsegx = (f.nx + SEG - 1) / SEG;
   g.nrb = (f.ny + RY - 1) / RY;
   const int nzr = std::max(0, z_hi - z_lo);
-  const int64_t per_layer = ((int64_t)g.nsegx * g.nrb + 3) / 4;  // blocks per z-chunk
+  g.nrg = (mode >= 0 && ((rr_by_rows_mask() >> mode) & 1)) ? (g.nrb + 3) / 4 : 0;
+  const int64_t per_layer = g.nrg > 0 ? (int64_t)g.nsegx * g.nrg : ((int64_t)g.nsegx * g.nrb + 3) / 4;  // blocks per z-chunk
   const int target = rr_target_blocks(nodes);  // 512^3: 1024 -> 12.3, 2048 -> 11.3, 4096 -> 11.0 ms per solve (early version)
   int nchunks = (int)std::max<int64_t>(1, (target + per_layer - 1) / per_layer);
   nchunks = std::max(1, std::min(nchunks, nzr));
@@ -564,6 +582,10 @@ RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows 
   }
   g.total_waves = g.nsegx * g.nrb * g.nchunks;
   g.total_blocks = (g.total_waves + 3) / 4;
+  if (g.nrg > 0) {
+    g.total_blocks = g.nsegx * g.nrg * g.nchunks;
+    g.total_waves = g.total_blocks * 4;
+  }
   return g;
 }
 
@@ -654,22 +676,22 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   };
   const Geom& f = pde->g;
   if (part < 0) {
-    const int nb = launch(make_geom(pde, 0, f.nz, 0, rows));
+    const int nb = launch(make_geom(pde, 0, f.nz, 0, rows, RR_RHS));
     BEAT_LAUNCH_CHECK();
     return beat_pde_launch_reduce(pde, nb, 3, dev_st, nullptr);
   }
   // in two parts on a decomposed grid (as beat_rr_pdot_part): the planes whose stencil needs no ghost plane of v_ / e
   // while those travel, then the one or two slab-boundary planes and the reduction over all block partials
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
-  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0, rows);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0, rows, RR_RHS);
   if (part == 0) {
     launch(gi);
     BEAT_LAUNCH_CHECK();
     return BEAT_OK;
   }
   int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
-  if (!f.z_lo_phys) off += launch(make_geom(pde, 0, 1, off, rows));
-  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch(make_geom(pde, f.nz - 1, f.nz, off, rows));
+  if (!f.z_lo_phys) off += launch(make_geom(pde, 0, 1, off, rows, RR_RHS));
+  if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) off += launch(make_geom(pde, f.nz - 1, f.nz, off, rows, RR_RHS));
   BEAT_LAUNCH_CHECK();
   BEAT_REQUIRE(off <= BEAT_MAX_PARTIALS, "too many block partials");
   return beat_pde_launch_reduce(pde, off, 3, dev_st, nullptr);
@@ -693,7 +715,7 @@ int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const 
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
-  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0, 0, RR_PDOT);
   if (part == 0) {
     launch_rr<RR_PDOT>(pde, gi, a);
     BEAT_LAUNCH_CHECK();
@@ -701,12 +723,12 @@ int beat_rr_pdot_part(beat_pde* pde, double* dev_st, const double* dev_r, const 
   }
   int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
   if (!f.z_lo_phys) {
-    const RGeom gb = make_geom(pde, 0, 1, off);
+    const RGeom gb = make_geom(pde, 0, 1, off, 0, RR_PDOT);
     launch_rr<RR_PDOT>(pde, gb, a);
     off += grid_blocks(gb);
   }
   if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) {
-    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off);
+    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off, 0, RR_PDOT);
     launch_rr<RR_PDOT>(pde, gb, a);
     off += grid_blocks(gb);
   }
@@ -725,7 +747,7 @@ int beat_rr_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const doubl
 // decomposed solve all-reduces dev_st[RZN..RRN] first and calls beat_rr_next itself.
 int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev_r_new, const double* dev_p, int slot,
                  bool roll) {
-  const RGeom g = make_geom(pde);
+  const RGeom g = make_geom(pde, 0, pde->g.nz, 0, 0, RR_RUPD);
   RArgs a{};
   a.x = dev_p;
   a.x2 = dev_r;

@@ -85,10 +85,11 @@ int beat_memcpy_d2h(beat_ctx* ctx, void* host_dst, const void* dev_src, size_t b
  *      src/beat/odesolver.py:67-79 ----------------------------------------------------------- */
 /* A cell model the library does not ship, given as SOURCE: a C++ struct `name` with the interface csrc/beat_ode_kernel.h expects of
  * a Model (NS, NP, V_INDEX, Derived, derive, step -- what beat.models.from_ode writes from a gotran .ode file: the reference takes any
- * gotranx-generated ``fun``, demos/niederer_benchmark.py:82-99, src/beat/odesolver.py:67-79).  Returns an id >= 100 that beat_ode_step,
- * beat_ode_step_pending, beat_split_steps[_big] and beat_ode_model_info accept like a built-in one; its kernel is compiled by hipcc
- * at the first step that needs it and cached (see beat_ode_jit_stats).  Uniform parameters only (host_params): per-node rows, classes
- * and beat_ode_run are for the shipped models.  Registering the same name and source again returns the same id. */
+ * gotranx-generated ``fun``, demos/niederer_benchmark.py:82-99, src/beat/odesolver.py:67-79).  Returns an id >= 100 that beat_ode_step
+ * (uniform vector or all per-node rows), beat_ode_step_pending, beat_ode_step_classes / beat_ode_class_table_*, beat_ode_run,
+ * beat_split_steps[_big] and beat_ode_model_info accept like a built-in one; each kernel instance is compiled by hipcc at the first
+ * call that needs it and cached (see beat_ode_jit_stats).  Not for it: beat_ode_step_rows (the instance compiled for a few varying
+ * rows).  Registering the same name and source again returns the same id. */
 int beat_ode_model_register(const char* name, const char* source, int num_states, int num_params, int v_index, int* model_id_out);
 /* Static description of a built-in (or registered) cell model. */
 int beat_ode_model_info(int model_id, int* num_states, int* num_params);

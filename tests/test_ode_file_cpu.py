@@ -66,19 +66,54 @@ def test_generated_model_compiles_for_gfx950(tmp_path):
 
     model = from_ode(SMALL)
     assert f"struct {model.cxx_name}" in model.source and "io.store(4," in model.source
-    for pend in ("false", "true"):
-        unit = tmp_path / f"unit_{pend}.hip"
+    # (uniform parameters without / with a pending update; all per-node rows + pending; parameter classes + pending: the
+    # instantiations csrc/beat_ode_jit.hip writes for a registered model -- and the in-kernel time loop, checked below)
+    for pend in ("false", "true", "true, per_node", "true, classes"):
+        flags = {"false": "false, false", "true": "false, true", "true, per_node": "true, true", "true, classes": "false, true, true"}[pend]
+        tag = pend.replace(", ", "_")
+        unit = tmp_path / f"unit_{tag}.hip"
         unit.write_text('#include "beat_ode_kernel.h"\n' + model.source +
-                        f"\ntemplate __global__ void ode_step_kernel<{model.cxx_name}, false, {pend}>(\n    double*, int64_t, int64_t, "
+                        f"\ntemplate __global__ void ode_step_kernel<{model.cxx_name}, {flags}>(\n    double*, int64_t, int64_t, "
                         f"ParamPack<{model.cxx_name}::NP>, typename {model.cxx_name}::Derived, const double*, int64_t, double, double, int, "
                         "double*, PendingV, MarkedArgs, SparseRows);\n")
-        out = tmp_path / f"unit_{pend}.hsaco"
+        out = tmp_path / f"unit_{tag}.hsaco"
         run = subprocess.run([HIPCC, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DBEAT_ODE_WAVES=3",
                               "-mllvm", "-disable-machine-licm", "-w", f"-I{CSRC}", str(unit), "-o", str(out)],
                              capture_output=True, text=True, timeout=600)
         assert run.returncode == 0, run.stderr[-3000:]
         names = {s for s in out.read_bytes().split(b"\0") if s.startswith(b"_Z") and b"ode_step_kernel" in s and b"." not in s}
         assert len(names) == 1, names
+    unit = tmp_path / "unit_run.hip"
+    unit.write_text('#include "beat_ode_kernel.h"\n' + model.source +
+                    f"\ntemplate __global__ void ode_run_kernel<{model.cxx_name}, true>(\n    double*, int64_t, int64_t, ParamPack<{model.cxx_name}::NP>, "
+                    f"typename {model.cxx_name}::Derived, const double*, int64_t, double, double, int64_t, int, int, TrackSpec, double*);\n")
+    out = tmp_path / "unit_run.hsaco"
+    run = subprocess.run([HIPCC, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DBEAT_ODE_WAVES=3",
+                          "-mllvm", "-disable-machine-licm", "-w", f"-I{CSRC}", str(unit), "-o", str(out)],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    names = {s for s in out.read_bytes().split(b"\0") if s.startswith(b"_Z") and b"ode_run_kernel" in s and b"." not in s}
+    assert len(names) == 1, names
+
+
+def test_generated_numpy_step_takes_per_node_parameters():
+    """(P, N) parameters through the NumPy twin = the (P,) evaluation column by column (the checker of the GPU suite's per-node
+    and class routes must itself be right)."""
+    from beat.models import from_ode
+
+    model = from_ode(SMALL)
+    rng = np.random.default_rng(2)
+    n = 40
+    y = np.repeat(model.init_state_values()[:, None], n, axis=1)
+    y[model.state_index("V")] = rng.uniform(-90.0, 40.0, n)
+    p = np.repeat(model.init_parameter_values(stim_amplitude=20.0)[:, None], n, axis=1)
+    p[model.parameter_index("g_in")] *= rng.uniform(0.5, 1.5, n)
+    p[model.parameter_index("E_out")] += rng.uniform(-5.0, 5.0, n)
+    whole = model.numpy_step(y, 0.7, p, 0.02)
+    for j in range(n):
+        np.testing.assert_allclose(whole[:, j], model.numpy_step(y[:, j], 0.7, p[:, j], 0.02), rtol=1e-14, atol=0.0)
+    with pytest.raises(ValueError):
+        model.numpy_step(y, 0.7, p[:, :5], 0.02)
 
 
 @pytest.mark.skipif(not REF_TP06.is_file(), reason="the reference's .ode files are only in the build container")
