@@ -103,6 +103,7 @@ SIGNATURES = {
     "beat_pde_set_guess_order": (_int, [_vp, _int]),
     "beat_pde_set_single_reduction": (_int, [_vp, _int]),
     "beat_pde_fused_dist_pass": (_int, [_vp]),
+    "beat_pde_tile_route": (_int, [_vp]),
     "beat_pde_guess_reset": (_int, [_vp]),
     "beat_pde_guess_pending": (_int, [_vp]),
     "beat_pde_guess_history": (_int, [_vp, _vp, _vp, _vp]),

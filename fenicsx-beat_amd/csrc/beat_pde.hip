@@ -1031,6 +1031,11 @@ extern "C" int beat_pde_set_small_grid_solve(beat_pde* pde, int enable) {
 }
 
 // ---- extrapolated initial guess --------------------------------------------------------------------------------
+extern "C" int beat_pde_tile_route(const beat_pde* pde) {
+  if (pde == nullptr || !pde->var) return 0;
+  return (beat_vtl_available(pde) ? 1 : 0) | (beat_vtl_pdot_available(pde) ? 2 : 0) | (beat_vtl_rhs_available(pde) ? 4 : 0) |
+         (pde->ring == beat_pde_detail::PRING_MAX ? 8 : 0);
+}
 extern "C" int beat_pde_fused_dist_pass(const beat_pde* pde) { return (pde != nullptr && pde->v_gc0_valid && pde->v_pdot_dist) ? 1 : 0; }
 
 extern "C" int beat_pde_set_single_reduction(beat_pde* pde, int on) {

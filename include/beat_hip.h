@@ -381,6 +381,10 @@ int beat_pde_set_single_reduction(beat_pde* pde, int on);
  * agreed by a sum over the ranks when the operator changes; BEAT_VTL_PDOT_DIST=0 switches it off) -- 0 for the three-kernel
  * iteration with an exchange of p, and before the first decomposed solve. */
 int beat_pde_fused_dist_pass(const beat_pde* pde);
+/* Which kernels a per-node-row operator on an undivided grid solves with (tests assert the route they mean to check): bit 0 the
+ * workgroup-tile product (beat_pde_spmv_dot and the solves), bit 1 its fused pass (direction formed while loading), bit 2 the
+ * right-hand side on the tiles, bit 3 the ring of 12 search directions.  0 for a constant-coefficient operator. */
+int beat_pde_tile_route(const beat_pde* pde);
 int beat_pde_guess_reset(beat_pde* pde);
 int beat_pde_guess_pending(const beat_pde* pde);
 /* the last recorded increment, the guess increment prepared for the next solve, and the number of solves on record

@@ -485,6 +485,62 @@ def test_right_hand_side_on_the_tiles_equals_the_gather_kernel(hip_ctx, cells, L
     np.testing.assert_array_equal(out["tiles"][0][tissue], out["tiles-3k"][0][tissue])
 
 
+def test_default_route_of_an_undivided_masked_grid_is_the_tile_kernels_and_equals_the_assembled_matrix(hip_ctx, monkeypatch):
+    """What ships BY DEFAULT for a per-node-row operator on an undivided grid -- asserted, not assumed (beat_pde_tile_route: tile
+    product, fused pass, right-hand side on the tiles, ring of 12) -- held DIRECTLY against the matrix the oracle assembles cell by
+    cell: q = A p of the tile product (beat_pde_spmv_dot) <= 1e-12 max|A p| on every tissue node, p.q with it; then one theta-step
+    of the default solve (tile right-hand side + fused passes) against SciPy's sparse LU of the same matrix <= 1e-9 max|v|.
+    The variants the other tests in this file compare bit for bit reach the oracle through this one."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    from beat import _stencil
+    from beat._engine import HipOps
+
+    for var in ("BEAT_VTL", "BEAT_VTL_RHS", "BEAT_VTL_PDOT", "BEAT_VTL_RY", "BEAT_VTL_RUN", "BEAT_VTL_DYNAMIC", "BEAT_VRR", "BEAT_VAR_RING",
+                "BEAT_VAR_TILE"):
+        monkeypatch.delenv(var, raising=False)
+    ctx = hip_ctx
+    cells, L = (70, 24, 19), (7.0, 2.4, 1.9)
+    h = tuple(l / c for l, c in zip(L, cells))
+    active, M = _shell_case(cells, L, 4)
+    mesh, Mass, K = _oracle_matrices(cells, L, active, M)
+    nn = [c + 1 for c in cells]
+    C_m, theta, dt = 0.01, 0.5, 0.05
+    touched = Mass.diagonal() > 0
+    A = (C_m * Mass + theta * dt * K + sp.diags(np.where(touched, 0.0, 1.0))).tocsc()
+    B = (C_m * Mass - (1 - theta) * dt * K).tocsr()
+    mf, kf = _stencil.stencil_fields(3, cells, h, M, active)
+    ops = HipOps(ctx, nn, True, True, mf, kf, per_node=True)
+    ops.set_timestep(C_m, theta, dt)
+    assert ctx.lib.beat_pde_tile_route(ops.handle) == 1 | 2 | 4 | 8
+    rng = np.random.default_rng(21)
+    x = np.where(touched, rng.standard_normal(mesh.num_nodes), 0.0)
+    p = ops.ring[0]
+    p.set(x)
+    p.ghost_lo.fill_(float("nan"))
+    p.ghost_hi.fill_(float("nan"))
+    ops.q.fill(float("nan"))
+    ops.st.zero_()
+    ops.spmv_dot()
+    ctx.synchronize()
+    ref = A @ x
+    q = ops.q.numpy()
+    assert np.abs(q[touched] - ref[touched]).max() <= 1e-12 * np.abs(ref).max()
+    assert np.isclose(float(ops.st[3]), float(x[touched] @ ref[touched]), rtol=1e-11)
+    # one theta-step through the default solve against sparse LU
+    v0 = np.where(touched, -80.0 + 30.0 * rng.random(mesh.num_nodes), 0.0)
+    v = ops.new_field()
+    v.set(v0)
+    info = ops.solve_single(v, [], [], v, rtol=1e-12, atol=1e-50, max_it=500)
+    ops.flush_pending()
+    ctx.synchronize()
+    exact = spla.splu(A).solve(B @ v0)
+    got = v.numpy()
+    assert info.converged_reason > 0 and info.iterations > 1
+    assert np.abs(got[touched] - exact[touched]).max() <= 1e-9 * np.abs(exact).max()
+
+
 def test_workgroup_tile_spmv_on_a_slab_with_live_ghost_planes(hip_ctx, monkeypatch):
     """The tile kernel on slab rows cut out of a larger masked grid, ghost planes holding the neighbouring slabs' p: plane 0
     takes its own stored backward coefficients (the plane below belongs to another rank), the last plane its forward ones;
