@@ -379,14 +379,19 @@ class HipOps:
     def can_open(self) -> bool:
         return bool(self.lib.beat_pde_solve_can_open(self.handle))
 
-    def solve_begin(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it) -> None:
+    def solve_begin(self, v_prev, stim_w, stim_amp, x, rtol, atol, max_it, comm: "LibComm | None" = None) -> None:
         """Enqueue the solve and return without waiting.  Until ``solve_finish`` -- which everything that needs the result or
-        the field calls: ``flush_pending``, the model's ``ksp``, the next ionic step -- the device works and the host is free."""
+        the field calls: ``flush_pending``, the model's ``ksp``, the next ionic step -- the device works and the host is free.
+        ``comm``: the slab-decomposed solve (beat_pde_solve_dist_begin), its exchanges and all-reduces enqueued with it."""
         self.flush_pending()
         self.st_ptr_for_flush = None
         ptrs, amps, k = self._stim_args(stim_w, stim_amp)
-        _hip.check(self.lib.beat_pde_solve_begin(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr, C.c_void_p(self.work.data_ptr()),
-                                                 rtol, atol, max_it))
+        if comm is not None:
+            _hip.check(self.lib.beat_pde_solve_dist_begin(self.handle, comm.handle, v_prev.ptr, ptrs, amps, k, x.ptr,
+                                                          C.c_void_p(self.work.data_ptr()), rtol, atol, max_it))
+        else:
+            _hip.check(self.lib.beat_pde_solve_begin(self.handle, v_prev.ptr, ptrs, amps, k, x.ptr, C.c_void_p(self.work.data_ptr()),
+                                                     rtol, atol, max_it))
         self.open_x = x
 
     def _record(self, info) -> KspResult:

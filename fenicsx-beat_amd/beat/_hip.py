@@ -168,6 +168,7 @@ SIGNATURES.update({
         _int,
         [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int, _int, C.POINTER(KspInfo), C.POINTER(_int)],
     ),
+    "beat_pde_solve_dist_begin": (_int, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_dbl), _int, _vp, _vp, _dbl, _dbl, _int]),
 })
 
 _lib = None

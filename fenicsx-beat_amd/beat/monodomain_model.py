@@ -56,8 +56,10 @@ class MonodomainModel(BaseModel):
 
     def can_solve_lazily(self) -> bool:
         """May the fused step leave its solve open (enqueued, not waited for) until the next step's ionic launch is in the
-        queue behind it?  One rank, Jacobi, nobody who wants the KSP record step by step (a monitor; PETSc's
-        ``ksp_error_if_not_converged``, whose exception belongs to the failing step); BEAT_LAZY_KSP=0 switches it off."""
+        queue behind it?  Jacobi on one rank, or on a decomposed grid whose solve the library runs itself (a LibComm: every rank
+        sees the same all-reduced scalars on the device, so every rank's launch behind the solve does the same); nobody who
+        wants the KSP record step by step (a monitor; PETSc's ``ksp_error_if_not_converged``, whose exception belongs to the
+        failing step); BEAT_LAZY_KSP=0 switches it off, BEAT_LAZY_KSP_DIST=0 on decomposed grids only."""
         import os
 
         from .telemetry import NullMonitor
@@ -65,9 +67,13 @@ class MonodomainModel(BaseModel):
         d, ops = self._diffusion, self._ops
         if os.environ.get("BEAT_LAZY_KSP", "1") == "0" or not hasattr(ops, "can_open"):
             return False
-        if d.dist is not None or d.libcomm is not None or type(self.monitor) is not NullMonitor:
+        if type(self.monitor) is not NullMonitor:
             return False
         if (self.parameters.get("petsc_options") or {}).get("ksp_error_if_not_converged"):
+            return False
+        if d.libcomm is not None:  # the in-library decomposed solve (Jacobi: the polynomial preconditioner is stage-driven)
+            return os.environ.get("BEAT_LAZY_KSP_DIST", "1") != "0" and ops.pc_num_passes == 0
+        if d.dist is not None:
             return False
         return ops.can_open()
 
@@ -80,7 +86,7 @@ class MonodomainModel(BaseModel):
         if lazy and defer_flush:
             ops = self._ops
             ops.on_finish = self._solve_finished
-            ops.solve_begin(field, stim_w, stim_amp, field, rtol, atol, max_it)
+            ops.solve_begin(field, stim_w, stim_amp, field, rtol, atol, max_it, comm=self._diffusion.libcomm)
             return None
         self.ksp = self._diffusion.solve(field, stim_w, stim_amp, field, rtol=rtol, atol=atol, max_it=max_it,
                                          defer_flush=defer_flush)

@@ -805,12 +805,109 @@ extern "C" int beat_comm_allreduce_sum(beat_comm* comm, double* dev_values, int 
   return allreduce_sum(comm, dev_values, count);
 }
 
-extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev,
-                                   const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
-                                   double* dev_x, double* dev_work, double rtol, double atol, int max_it,
-                                   int defer_flush, beat_ksp_info* info, int* host_pending) {
-  BEAT_REQUIRE(!defer_flush || host_pending != nullptr, "defer_flush needs host_pending[2]");
-  if (host_pending) host_pending[0] = host_pending[1] = 0;
+// ---- the decomposed solve in two halves (round 5: as beat_solve_begin / beat_solve_end of the single slab) ------------------------------
+// begin: ghost planes, right-hand side, the iterations the previous solve needed + 1 with their exchanges and all-reduces, and the
+// copy of the scalar state are in the streams when it returns; end: the host looks at the latch, enqueues more iterations if the
+// residual asks for them, and closes the solve.  Between the two a caller may enqueue the next ionic launch behind the solve
+// (beat_ode_step_pending with pending = -1): every rank sees the same all-reduced scalars, so every rank's launch does the same.
+namespace {
+// iterations [o.launched, o.launched + count) of the open decomposed solve
+int dist_enqueue_iterations(beat_pde* pde, int count) {
+  beat_pde::OpenSolve& o = pde->open;
+  beat_comm* comm = (beat_comm*)o.comm;
+  const int64_t n = pde->n, plane = pde->g.plane, fld = beat_pde_field_stride(pde);
+  double* r = o.work + plane;
+  double* q = r + fld;
+  double* ring = q + 2 * fld;  // [r, q, z, ring...]: z is unused by the Jacobi path
+  const int PR = pde->ring;     // (6 on a decomposed grid; a one-rank communicator on a single slab of per-node rows: 12)
+  double* st = pde->d_st;
+  double* dev_x = o.x;
+  double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
+  const bool rr = o.rr, merged = o.merged, vpdot = o.vpdot;
+  int rc;
+  for (int it = 0; it < count; ++it) {
+    const int i = o.launched + it, slot = i % PR;
+    double* p_cur = ring + (int64_t)slot * fld;
+    double* p_next = ring + (int64_t)((i + 1) % PR) * fld;
+    if (merged) {
+      // u_i . A u_i, r_i . u_i, r_i . r_i in one pass over r_i (interior planes while its ghost planes travel, then the
+      // boundary planes), ONE all-reduce, the scalar step (stopping test, beta_i, alpha_i), then p_i = u_i + beta_i p_{i-1}
+      // and r_{i+1} = r_i - alpha_i A p_i in one pass without a dot product; the ghost planes of r_{i+1} travel behind it
+      const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
+      double* r_cur = rbuf[i & 1];
+      double* r_new = rbuf[(i + 1) & 1];
+      if ((rc = beat_rr_udot_part(pde, st, r_cur, 0))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      if ((rc = beat_rr_udot_part(pde, st, r_cur, 1))) return rc;
+      if ((rc = allreduce_sum(comm, st + PQ, 3))) return rc;
+      if ((rc = beat_rr_merged_next(pde, st, slot))) return rc;
+      if ((rc = beat_rr_prupd(pde, st, r_cur, p_old, p_cur, r_new))) return rc;
+      if ((rc = halo_start(comm, r_new, n, plane))) return rc;
+      if (slot == PR - 1) {
+        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
+          return rc;
+      }
+      continue;
+    }
+    if (rr) {
+      // p_i = D^-1 r_i + beta p_{i-1} and p_i . A p_i: the planes that need no ghost data while the ghost planes of
+      // r_i travel, then the boundary planes, which also keep p_i on the ghost planes (no exchange of p)
+      const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
+      double* r_cur = rbuf[i & 1];
+      double* r_new = rbuf[(i + 1) & 1];
+      if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 0))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 1))) return rc;
+      if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
+      if ((rc = beat_rr_rupd(pde, st, r_cur, r_new, p_cur, slot, false))) return rc;  // r_{i+1}, local r.z and r.r
+      if ((rc = halo_start(comm, r_new, n, plane))) return rc;  // travels behind the reductions and the next part 0
+      if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
+      if (slot == PR - 1) {
+        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
+          return rc;
+      }
+      if ((rc = beat_rr_next(pde, st))) return rc;
+      continue;
+    }
+    if (vpdot) {
+      // p_i = D^-1 r_i + beta p_{i-1}, q = A p_i and p_i . q in one pass over the coefficient rows: the tiles that need no ghost
+      // plane while the ghost planes of r_i travel, then the boundary tiles (which keep p_i on the ghost planes); the residual
+      // update in place, its ghost planes travelling behind the second reduction and the next pass's first part
+      const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
+      if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 0))) return rc;
+      if ((rc = halo_wait(comm))) return rc;
+      if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 1))) return rc;
+      if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
+      if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
+      if ((rc = halo_start(comm, r, n, plane))) return rc;
+      if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
+      if (slot == PR - 1) {
+        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
+          return rc;
+      }
+      if ((rc = beat_rr_next(pde, st))) return rc;  // the scalar roll (beta, iteration count, latch)
+      continue;
+    }
+    if ((rc = halo_start(comm, p_cur, n, plane))) return rc;                  // ghost planes of p travel ...
+    if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 0))) return rc;       // ... while the interior is computed
+    if ((rc = halo_wait(comm))) return rc;
+    if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 1))) return rc;       // boundary planes + local p.q
+    if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
+    if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
+    if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
+    if (slot == PR - 1) {
+      if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
+        return rc;
+    }
+    if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
+  }
+  o.launched += count;
+  return BEAT_OK;
+}
+}  // namespace
+
+int beat_dist_solve_begin(beat_pde* pde, beat_comm* comm, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                          const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol, int max_it) {
   BEAT_REQUIRE(pde != nullptr && comm != nullptr && dev_v_prev && dev_x && dev_work, "null argument");
   BEAT_REQUIRE(pde->ctx == comm->ctx, "operator and communicator belong to different contexts");
   BEAT_REQUIRE((pde->g.z_lo_phys != 0) == (comm->peer_lo < 0) && (pde->g.z_hi_phys != 0) == (comm->peer_hi < 0),
@@ -818,12 +915,16 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
                pde->g.z_lo_phys, pde->g.z_hi_phys, comm->peer_lo, comm->peer_hi);
   BEAT_REQUIRE(pde->pc_ncoef == 1, "the in-library decomposed solve is Jacobi-PCG (polynomial preconditioner: stage functions)");
   BEAT_REQUIRE(max_it >= 0, "max_it must be >= 0");
+  BEAT_REQUIRE(!pde->open.on, "the previous solve has not been finished (beat_pde_solve_end)");
   beat_ctx* ctx = pde->ctx;
+  if (pde->h_st == nullptr) {
+    BEAT_HIP_CHECK(hipHostMalloc((void**)&pde->h_st, sizeof(double) * 16, hipHostMallocDefault));
+    BEAT_HIP_CHECK(hipEventCreateWithFlags(&pde->ev_st, hipEventDisableTiming));
+  }
   const int64_t n = pde->n, plane = pde->g.plane, fld = beat_pde_field_stride(pde);
   double* r = dev_work + plane;
   double* q = r + fld;
   double* ring = q + 2 * fld;  // [r, q, z, ring...]: z is unused by the Jacobi path
-  const int PR = pde->ring;     // (6 on a decomposed grid; a one-rank communicator on a single slab of per-node rows: 12)
   double* st = pde->d_st;
   double* h = ctx->h_pinned;
   int rc;
@@ -870,16 +971,12 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if (rc) return rc;
   if ((rc = allreduce_sum(comm, st + BB, 3))) return rc;
   if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
-  int launched = 0;
   // beat_pde_set_single_reduction / BEAT_DIST_MERGED=1 (constant coefficients): ONE all-reduce per iteration
   // (beat_pde_rr.hip, beat_rr_udot_part); the environment is read per solve.  The pass that finds r_k converged is one more than the k updates: the first chunk and the limit count it.
   const char* merged_env = std::getenv("BEAT_DIST_MERGED");
   const bool merged = rr && (pde->single_reduction >= 0 ? pde->single_reduction == 1 : (merged_env != nullptr && merged_env[0] == '1'));
   comm->merged_solves += merged ? 1 : 0;
-  const int limit = max_it + (merged ? 1 : 0);
-  int chunk = beat_pde_first_chunk(pde) + (merged ? 1 : 0);
-  double* rbuf[2] = {r, q};  // rr: the residual update writes out of place
-  if (rr && (rc = halo_start(comm, rbuf[0], n, plane))) return rc;  // ghost planes of r_0
+  if (rr && (rc = halo_start(comm, r, n, plane))) return rc;  // ghost planes of r_0
   // per-node rows: the fused tile pass (direction formed while loading, csrc/beat_pde_vtl.hip) on the slab -- like the
   // register-row path it exchanges r, forms the direction on the ghost planes itself and never exchanges p.  It needs the
   // centre coefficients of the neighbours' boundary planes: one exchange per operator, through the work field q (free until the
@@ -907,92 +1004,58 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   if (vpdot) {
     if ((rc = halo_start(comm, r, n, plane))) return rc;  // ghost planes of r_0
   }
-  while (true) {
-    chunk = std::min(chunk, limit - launched);
-    for (int it = 0; it < chunk; ++it) {
-      const int i = launched + it, slot = i % PR;
-      double* p_cur = ring + (int64_t)slot * fld;
-      double* p_next = ring + (int64_t)((i + 1) % PR) * fld;
-      if (merged) {
-        // u_i . A u_i, r_i . u_i, r_i . r_i in one pass over r_i (interior planes while its ghost planes travel, then the
-        // boundary planes), ONE all-reduce, the scalar step (stopping test, beta_i, alpha_i), then p_i = u_i + beta_i p_{i-1}
-        // and r_{i+1} = r_i - alpha_i A p_i in one pass without a dot product; the ghost planes of r_{i+1} travel behind it
-        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
-        double* r_cur = rbuf[i & 1];
-        double* r_new = rbuf[(i + 1) & 1];
-        if ((rc = beat_rr_udot_part(pde, st, r_cur, 0))) return rc;
-        if ((rc = halo_wait(comm))) return rc;
-        if ((rc = beat_rr_udot_part(pde, st, r_cur, 1))) return rc;
-        if ((rc = allreduce_sum(comm, st + PQ, 3))) return rc;
-        if ((rc = beat_rr_merged_next(pde, st, slot))) return rc;
-        if ((rc = beat_rr_prupd(pde, st, r_cur, p_old, p_cur, r_new))) return rc;
-        if ((rc = halo_start(comm, r_new, n, plane))) return rc;
-        if (slot == PR - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
-            return rc;
-        }
-        continue;
-      }
-      if (rr) {
-        // p_i = D^-1 r_i + beta p_{i-1} and p_i . A p_i: the planes that need no ghost data while the ghost planes of
-        // r_i travel, then the boundary planes, which also keep p_i on the ghost planes (no exchange of p)
-        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
-        double* r_cur = rbuf[i & 1];
-        double* r_new = rbuf[(i + 1) & 1];
-        if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 0))) return rc;
-        if ((rc = halo_wait(comm))) return rc;
-        if ((rc = beat_rr_pdot_part(pde, st, r_cur, p_old, p_cur, 1))) return rc;
-        if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
-        if ((rc = beat_rr_rupd(pde, st, r_cur, r_new, p_cur, slot, false))) return rc;  // r_{i+1}, local r.z and r.r
-        if ((rc = halo_start(comm, r_new, n, plane))) return rc;  // travels behind the reductions and the next part 0
-        if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-        if (slot == PR - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
-            return rc;
-        }
-        if ((rc = beat_rr_next(pde, st))) return rc;
-        continue;
-      }
-      if (vpdot) {
-        // p_i = D^-1 r_i + beta p_{i-1}, q = A p_i and p_i . q in one pass over the coefficient rows: the tiles that need no ghost
-        // plane while the ghost planes of r_i travel, then the boundary tiles (which keep p_i on the ghost planes); the residual
-        // update in place, its ghost planes travelling behind the second reduction and the next pass's first part
-        const double* p_old = ring + (int64_t)((i + PR - 1) % PR) * fld;
-        if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 0))) return rc;
-        if ((rc = halo_wait(comm))) return rc;
-        if ((rc = beat_vtl_pdot_part(pde, st, r, p_old, p_cur, q, i == 0, 1))) return rc;
-        if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
-        if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
-        if ((rc = halo_start(comm, r, n, plane))) return rc;
-        if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-        if (slot == PR - 1) {
-          if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
-            return rc;
-        }
-        if ((rc = beat_rr_next(pde, st))) return rc;  // the scalar roll (beta, iteration count, latch)
-        continue;
-      }
-      if ((rc = halo_start(comm, p_cur, n, plane))) return rc;                  // ghost planes of p travel ...
-      if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 0))) return rc;       // ... while the interior is computed
-      if ((rc = halo_wait(comm))) return rc;
-      if ((rc = beat_pde_spmv_dot_part(pde, p_cur, q, st, 1))) return rc;       // boundary planes + local p.q
-      if ((rc = allreduce_sum(comm, st + PQ, 1))) return rc;
-      if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
-      if ((rc = allreduce_sum(comm, st + RZN, 2))) return rc;
-      if (slot == PR - 1) {
-        if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR))))
-          return rc;
-      }
-      if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
+  beat_pde::OpenSolve& o = pde->open;
+  o = beat_pde::OpenSolve{};
+  o.comm = comm;
+  o.rr = rr;
+  o.merged = merged;
+  o.vpdot = vpdot;
+  o.v_prev = dev_v_prev;
+  o.x = dev_x;
+  o.work = dev_work;
+  o.rtol = rtol;
+  o.atol = atol;
+  o.max_it = max_it;
+  o.limit = max_it + (merged ? 1 : 0);
+  const int chunk = std::min(beat_pde_first_chunk(pde) + (merged ? 1 : 0), o.limit);
+  if ((rc = dist_enqueue_iterations(pde, chunk))) return rc;
+  BEAT_HIP_CHECK(hipMemcpyAsync(pde->h_st, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipEventRecord(pde->ev_st, ctx->stream));
+  o.on = true;
+  return BEAT_OK;
+}
+
+int beat_dist_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* host_pending, bool* needed_more) {
+  beat_pde::OpenSolve& o = pde->open;
+  beat_comm* comm = (beat_comm*)o.comm;
+  beat_ctx* ctx = pde->ctx;
+  double* h = pde->h_st;
+  double* st = pde->d_st;
+  const int64_t fld = beat_pde_field_stride(pde);
+  double* ring = o.work + pde->g.plane + 3 * fld;
+  const int PR = pde->ring;
+  int rc;
+  BEAT_HIP_CHECK(hipEventSynchronize(pde->ev_st));
+  if ((rc = ipc_check(comm))) {
+    o.on = false;
+    return rc;
+  }
+  while (!(h[STOP] != 0.0 || o.launched >= o.limit)) {
+    if (needed_more) *needed_more = true;
+    if ((rc = dist_enqueue_iterations(pde, std::min(2, o.limit - o.launched)))) {
+      o.on = false;
+      return rc;
     }
-    launched += chunk;
     BEAT_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
     BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if ((rc = ipc_check(comm))) return rc;
-    if (h[STOP] != 0.0 || launched >= limit) break;
-    chunk = 2;
+    if ((rc = ipc_check(comm))) {
+      o.on = false;
+      return rc;
+    }
   }
-  if (rr || vpdot) {  // the exchange started after the last residual update has no consumer: drain it before anything else
+  o.on = false;
+  pde->applied_behind = false;
+  if (o.rr || o.vpdot) {  // the exchange started after the last residual update has no consumer: drain it before anything else
     if ((rc = halo_wait(comm))) return rc;  // touches those ghost planes
   }
   const int nupd = (int)h[NUPD], base = (nupd / PR) * PR;
@@ -1003,7 +1066,7 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
       host_pending[0] = base;
       host_pending[1] = nupd % PR;
       pde->last_base = base;
-    } else if ((rc = beat_pde_x_flush_terms(pde, st, dev_x, ring, fld, base, 0, last))) {
+    } else if ((rc = beat_pde_x_flush_terms(pde, st, o.x, ring, fld, base, 0, last))) {
       return rc;
     }
   }
@@ -1011,16 +1074,32 @@ extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double*
   pde->last_iters = iters;
   int reason = (int)h[REASON];
   if (h[STOP] == 0.0) reason = -3;
-  if (info) {
-    info->iterations = iters;
-    info->converged_reason = reason;
-    info->residual_norm = std::sqrt(h[RR]);
-    info->rhs_norm = std::sqrt(h[BB]);
-  }
+  pde->last_info.iterations = iters;
+  pde->last_info.converged_reason = reason;
+  pde->last_info.residual_norm = std::sqrt(h[RR]);
+  pde->last_info.rhs_norm = std::sqrt(h[BB]);
+  if (info) *info = pde->last_info;
+  pde->last_rc = BEAT_OK;
   if (reason < 0) {
     beat_set_error("PCG did not converge in %d iterations (||r|| = %.3e, ||b|| = %.3e)", iters, std::sqrt(h[RR]),
                    std::sqrt(h[BB]));
-    return BEAT_ENOTCONV;
+    pde->last_rc = BEAT_ENOTCONV;
   }
-  return BEAT_OK;
+  return pde->last_rc;
+}
+
+extern "C" int beat_pde_solve_dist_begin(beat_pde* pde, beat_comm* comm, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                                         const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
+                                         int max_it) {
+  return beat_dist_solve_begin(pde, comm, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_work, rtol, atol, max_it);
+}
+
+extern "C" int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev,
+                                   const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
+                                   double* dev_x, double* dev_work, double rtol, double atol, int max_it,
+                                   int defer_flush, beat_ksp_info* info, int* host_pending) {
+  BEAT_REQUIRE(!defer_flush || host_pending != nullptr, "defer_flush needs host_pending[2]");
+  if (host_pending) host_pending[0] = host_pending[1] = 0;
+  if (int rc = beat_dist_solve_begin(pde, comm, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, dev_work, rtol, atol, max_it)) return rc;
+  return beat_dist_solve_end(pde, defer_flush, info, host_pending, nullptr);
 }

@@ -1353,6 +1353,7 @@ int beat_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* hos
     return pde->last_rc;
   }
   BEAT_REQUIRE(!defer_flush || host_pending != nullptr, "defer_flush needs host_pending[2]");
+  if (pde->open.comm != nullptr) return beat_dist_solve_end(pde, defer_flush, info, host_pending, needed_more);  // a decomposed solve
   beat_pde::OpenSolve& o = pde->open;
   beat_ctx* ctx = pde->ctx;
   double* h = pde->h_st;

@@ -64,6 +64,10 @@ struct beat_pde {
     double* work = nullptr;
     double rtol = 0.0, atol = 0.0;
     int max_it = 0, launched = 0;
+    // a decomposed solve (beat_dist.hip: beat_dist_solve_begin / _end): its communicator and which of its loops runs
+    void* comm = nullptr;
+    bool rr = false, merged = false, vpdot = false;
+    int limit = 0;
   } open;
   double* h_st = nullptr;       // pinned copy of the scalar state of the open solve (16 doubles)
   hipEvent_t ev_st = nullptr;   // recorded behind that copy
@@ -204,6 +208,10 @@ int beat_vtl_pdot(beat_pde* pde, double* dev_st, const double* dev_r, const doub
 // the host's bookkeeping.  beat_solve_end: *needed_more = the first look found the solve unlatched (a launch enqueued behind it
 // with PendingV::dev_st has done nothing); a solve that was never opened: the last finished solve's record
 bool beat_solve_lazy_available(const beat_pde* pde);
+struct beat_comm;
+int beat_dist_solve_begin(beat_pde* pde, beat_comm* comm, const double* dev_v_prev, const double* const* host_dev_stim_w,
+                          const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol, int max_it);
+int beat_dist_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* host_pending, bool* needed_more);
 int beat_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* const* host_dev_stim_w, const double* host_stim_amp, int n_stim,
                      double* dev_x, double* dev_work, double rtol, double atol, int max_it);
 int beat_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* host_pending, bool* needed_more);

@@ -42,9 +42,10 @@ ode = beat.odesolver.DolfinODESolver(v_ode=g.Function(g.functionspace(mesh, ("P"
                                      v_index=tp06.state_index("V"))
 solver = beat.MonodomainSplittingSolver(pde=pde, ode=ode)
 points = np.array([[0.0, 0.0, 0.0], [6.0, 3.0, 4.0], [3.0, 1.5, 2.0], [1.0, 1.0, 2.25], [5.5, 0.5, 3.9]])
-dt, t, probes = 0.05, 0.0, []
+dt, t, probes, opens = 0.05, 0.0, [], 0
 for step in range(60):
     solver.step((t, t + dt))
+    opens += int(getattr(pde._ops, "open_x", None) is not None)  # the step left its solve open (round 5: decomposed solves too)
     t += dt
     if step % 10 == 9:
         probes.append(g.evaluate_function(pde.state, points).ravel().copy())
@@ -64,7 +65,7 @@ roundtrip_ok = bool(np.array_equal(np.asarray(back.x.array), v))
 full = ode.full_values if hasattr(ode, "full_values") else None
 np.savez(out_dir / f"rank{comm.rank}.npz", v=v, probes=np.array(probes), z0=mesh.slab.z0, z1=mesh.slab.z1,
          states=np.asarray(ode.values), its=pde.ksp.getIterationNumber(), nodes=mesh.num_nodes, leads=leads,
-         roundtrip_ok=roundtrip_ok,
+         roundtrip_ok=roundtrip_ok, opens=opens,
          merged_solves=(int(pde._ops.lib.beat_comm_merged_solves(pde._diffusion.libcomm.handle))
                         if getattr(pde._diffusion, "libcomm", None) is not None else 0))
 if world > 1:

@@ -753,6 +753,39 @@ def test_public_api_on_several_ranks_matches_one_process(world, transport, tmp_p
         assert bool(p["roundtrip_ok"]) and abs(float(a["leads"][0])) > 0.0
 
 
+def test_open_decomposed_solve_equals_the_waiting_one_bit_for_bit(tmp_path):
+    """Round 5: on a decomposed grid too ``step()`` leaves its solve open (beat_pde_solve_dist_begin) and the next ionic launch
+    goes behind it on every rank -- the ranks see the same all-reduced scalars on the device as on the host, so they act alike.
+    Three processes over the mailbox transport, 60 TP06 steps through the public API (tests/_api_ranks_script.py, whose
+    stimulated corner fires: iteration counts jump, the relaunch path is taken): every step of the default run leaves its solve
+    open, none with BEAT_LAZY_KSP_DIST=0, and potentials, states, probes, ECG leads and the last iteration count are THE SAME
+    BITS.  (That either equals the one-process run is test_public_api_on_several_ranks_matches_one_process.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    script = str(root / "tests" / "_api_ranks_script.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BEAT_DIST_MERGED", "BEAT_LAZY_KSP", "BEAT_LAZY_KSP_DIST")}
+    world, out = 3, {}
+    for lazy in ("1", "0"):
+        d = tmp_path / f"lazy{lazy}"
+        d.mkdir()
+        run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, str(d)],
+                             capture_output=True, text=True, timeout=300, cwd=root,
+                             env=dict(env, BEAT_DIST_BACKEND="gloo", BEAT_DIST_TRANSPORT="ipc", BEAT_LAZY_KSP_DIST=lazy))
+        assert run.returncode == 0, run.stderr[-3000:]
+        out[lazy] = [np.load(d / f"rank{r}.npz") for r in range(world)]
+    for a, b in zip(out["1"], out["0"]):
+        assert int(a["opens"]) == 60 and int(b["opens"]) == 0
+        for key in ("v", "states", "probes", "leads"):
+            np.testing.assert_array_equal(a[key], b[key])
+        assert int(a["its"]) == int(b["its"])
+    assert max(float(p["v"].max()) for p in out["1"]) > 0.0  # the stimulated corner fired
+
+
 @pytest.mark.parametrize("odespace,dim,world,percell", [("CG_2", 3, 2, False), ("DG_1", 3, 2, False), ("CG_1", 2, 2, False), ("CG_2", 2, 3, False),
                                                         ("DG_1", 2, 2, False), ("CG_1", 2, 2, True), ("CG_2", 2, 3, True)])
 def test_p2_and_dg1_ode_spaces_and_nodal_fibres_on_two_ranks_match_one_process(odespace, dim, world, percell, tmp_path):
