@@ -573,7 +573,7 @@ int beat_pde_solve_dist(beat_pde* pde, beat_comm* comm, const double* dev_v_prev
  * streams when it returns; beat_pde_solve_end (or the next ionic step with pending = -1, enqueued behind the solve) finishes it.
  * Every rank sees the same all-reduced scalars -- on the device as on the host -- so every rank's launch behind the solve does
  * the same.  Between the ranks' steps the host was on the critical path once per step: a wake-up, the read of the latch and the
- * ionic launch, 0.11 - 0.15 ms of a 2.1 ms step on one rank's 512 x 512 x 64 share of the 512^3 grid (profiles/r05_slab64.md). */
+ * ionic launch, 75 us of a 1.9 ms step on one rank's 512 x 512 x 64 share of the 512^3 grid (profiles/r05_slab64.md). */
 int beat_pde_solve_dist_begin(beat_pde* pde, beat_comm* comm, const double* dev_v_prev, const double* const* host_dev_stim_w,
                               const double* host_stim_amp, int n_stim, double* dev_x, double* dev_work, double rtol, double atol,
                               int max_it);
