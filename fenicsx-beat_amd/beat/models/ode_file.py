@@ -49,6 +49,51 @@ def _walk(text: str, where: str):
             raise ValueError(f"{where}:{node.lineno}: statement not understood in an .ode file")
 
 
+_EXPR_NODES = (ast.Expression, ast.BinOp, ast.UnaryOp, ast.Call, ast.Name, ast.Constant, ast.Load, ast.Add, ast.Sub, ast.Mult, ast.Div,
+               ast.Pow, ast.USub, ast.UAdd, ast.Compare, ast.Lt, ast.LtE, ast.Gt, ast.GtE, ast.Eq, ast.NotEq, ast.BoolOp, ast.And, ast.Or,
+               ast.Not, ast.IfExp, ast.Mod)
+
+
+def _check_expression(node, where: str, known) -> None:
+    """The right-hand side of an assignment is evaluated (with SymPy objects for the names) to build the expression tree: only
+    arithmetic, comparisons and calls of the functions an .ode file may use pass -- no attribute access, subscripts, lambdas,
+    comprehensions or keyword tricks: an .ode file is data, and this is not the place where it gets to run code."""
+    for n in ast.walk(node):
+        if not isinstance(n, _EXPR_NODES):
+            raise ValueError(f"{where}:{getattr(n, 'lineno', '?')}: `{type(n).__name__}` is not understood in an expression of an .ode file")
+        if isinstance(n, ast.Call):
+            if not isinstance(n.func, ast.Name) or n.func.id not in known or n.keywords:
+                raise ValueError(f"{where}:{n.lineno}: call of an unknown function in an .ode file"
+                                 + (f": {n.func.id}" if isinstance(n.func, ast.Name) else ""))
+        if isinstance(n, ast.Constant) and not isinstance(n.value, (int, float)):
+            raise ValueError(f"{where}:{n.lineno}: only numbers are understood in an expression of an .ode file")
+
+
+class _ComparisonsAsNumbers(ast.NodeTransformer):
+    """gotran lets a comparison stand in arithmetic as 0 or 1 -- ``gammas*((zetas > 0)*zetas + (zetas < -1)*(-zetas - 1))`` in the
+    Land model, ``Gt(Zetas, 0)*Zetas`` in the reference's own file: a comparison (infix or Lt / Le / Gt / Ge / Eq / And / Or / Not)
+    that is an operand of an arithmetic operator becomes ``_indicator(comparison)``
+    (Piecewise((1, c), (0, True))); as an argument of Conditional / And / Or / Not it stays a condition."""
+
+    @staticmethod
+    def _wrap(node):
+        relation = isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in ("Lt", "Le", "Gt", "Ge", "Eq", "And", "Or", "Not")
+        if relation or isinstance(node, (ast.Compare, ast.BoolOp)):
+            return ast.copy_location(ast.Call(func=ast.Name(id="_indicator", ctx=ast.Load()), args=[node], keywords=[]), node)
+        return node
+
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        node.left, node.right = self._wrap(node.left), self._wrap(node.right)
+        return node
+
+    def visit_UnaryOp(self, node):
+        self.generic_visit(node)
+        if not isinstance(node.op, ast.Not):
+            node.operand = self._wrap(node.operand)
+        return node
+
+
 def _number(node) -> float:
     if isinstance(node, ast.Call):  # ScalarParam(value, unit=..., ...)
         return float(ast.literal_eval(node.args[0]))
@@ -118,11 +163,15 @@ class OdeFileModel(DeviceModel):
               "pow": sympy.Pow, "sin": sympy.sin, "cos": sympy.cos, "tan": sympy.tan, "tanh": sympy.tanh, "sinh": sympy.sinh,
               "cosh": sympy.cosh, "atan": sympy.atan, "asin": sympy.asin, "acos": sympy.acos,
               "Conditional": piecewise, "Lt": sympy.Lt, "Le": sympy.Le, "Gt": sympy.Gt, "Ge": sympy.Ge, "Eq": sympy.Eq,
-              "And": sympy.And, "Or": sympy.Or, "Not": sympy.Not, "time": tsym, "t": tsym, "pi": sympy.pi}
+              "And": sympy.And, "Or": sympy.Or, "Not": sympy.Not, "time": tsym, "t": tsym, "pi": sympy.pi,
+              "_indicator": lambda c: sympy.Piecewise((sympy.Integer(1), c), (sympy.Integer(0), True))}
         ns.update(psym)
         ns.update(ysym)
         rhs = {}
+        callables = {k for k, v in ns.items() if callable(v) and not isinstance(v, sympy.Basic)}
         for nm, node in assigns:
+            _check_expression(node, str(self.path), callables - {"_indicator"})
+            node = ast.fix_missing_locations(_ComparisonsAsNumbers().visit(node))
             try:
                 expr = sympy.sympify(eval(compile(ast.Expression(node), str(self.path), "eval"), {"__builtins__": {}}, ns))
             except Exception as exc:  # noqa: BLE001
@@ -147,6 +196,8 @@ class OdeFileModel(DeviceModel):
 
     # ------------------------------------------------------------------------------------------------ C++
     def _cxx(self, stem: str) -> str:
+        import os
+
         import sympy
         from sympy.printing.c import C99CodePrinter
 
@@ -161,6 +212,23 @@ class OdeFileModel(DeviceModel):
                     return "(1.0/(" + "*".join([pb] * (-int(e))) + "))"
                 return super()._print_Pow(expr)
 
+            def _print_Piecewise(self, expr):
+                # BRANCH-FREE: both arms evaluated, the result selected (v_cndmask).  As `c ? a : b` with the arms inline the
+                # compiler builds divergent branches; a heavily spilled kernel (the reference's ToR-ORd files generate 250 - 300 spilled
+                # SGPRs and 450 spilled VGPRs) then reloads registers it spilled under another lane mask -- wrong values on exactly the
+                # nodes that take the other arm, in the states behind that arm, different from run to run (ROCm 7.2; seen in round 1
+                # on the generated ToR-ORd kernel and reproduced in round 5: tools/diag_spill.py, profiles/r05_generated_spills.md).
+                # A lane computes both arms of a divergent branch anyway.
+                if os.environ.get("BEAT_ODE_BRANCHES") == "1":  # the form that was seen miscompiled (tests of the self checks)
+                    return super()._print_Piecewise(expr)
+                args = list(expr.args)
+                out = self._print(args[-1][0])
+                if args[-1][1] != True:  # noqa: E712 -- no default arm: what C's chained ?: would leave undefined
+                    out = f"beat_sel({self._print(args[-1][1])}, {out}, 0.0)"
+                for e, c in reversed(args[:-1]):
+                    out = f"beat_sel({self._print(c)}, {self._print(e)}, {out})"
+                return out
+
         # exp(): the library's table-driven evaluation (FastMath::exp of csrc/ionic_models.h, what the shipped models use: 13 VALU
         # instructions, <= 1 ulp, the 256-entry table in LDS) with the argument kept inside double range -- or libm's
         exp_name = "fexp" if self.fast_exp else "exp"
@@ -170,22 +238,55 @@ class OdeFileModel(DeviceModel):
         sub.update({s: sympy.Symbol(f"p_{k}") for k, s in enumerate(p)})
         sub[self._sym["t"]] = sympy.Symbol("t")
         used = set()
-        lines = []
-        for lhs, e in self._sym["repl"]:
-            e2 = e.xreplace(sub)
-            used |= e2.free_symbols
-            lines.append(f"    const double {lhs} = {pr.doprint(e2)};")
         ns_, np_ = len(y), len(p)
         vi = self.state_index(self.v_name) if self.v_name else 0
-        body = []
-        for k in range(ns_):
+        # Order: state by state, each one's common subexpressions right ahead of its update (depth first, those not yet emitted),
+        # then the update and its store -- a temporary is defined next to its first use and a state's result leaves the registers
+        # when it is final.  (All temporaries first and all updates last -- the order the elimination returns them in -- keeps every
+        # one of them and all NS results alive to the end: the 48-state test model needed 256 + 256 registers and 450 B of scratch
+        # per lane that way.)
+        temp = {lhs: e.xreplace(sub) for lhs, e in self._sym["repl"]}
+        emitted, lines = set(), []
+
+        def emit(expr):
+            stack = [(sym, False) for sym in sorted(expr.free_symbols, key=str, reverse=True) if sym in temp]
+            while stack:
+                sym, done = stack.pop()
+                if sym in emitted:
+                    continue
+                if done:
+                    emitted.add(sym)
+                    lines.append(f"    const double {sym} = {pr.doprint(temp[sym])};")
+                    continue
+                stack.append((sym, True))
+                for dep in sorted(temp[sym].free_symbols, key=str, reverse=True):
+                    if dep in temp and dep not in emitted:
+                        stack.append((dep, False))
+
+        order = list(range(ns_))
+        if os.environ.get("BEAT_ODE_V_LAST", "1") == "1" and self.v_name:  # the potential's equation sums every current: last, when the currents exist
+            order = [k for k in order if k != vi] + [vi]
+        if os.environ.get("BEAT_ODE_EMIT") == "global":  # every temporary first, in the elimination's order (tests: the heavily spilled form)
+            for lhs in temp:
+                emit(lhs)
+            order = list(range(ns_))
+        for k in order:
             fk, jk = self._sym["f"][k].xreplace(sub), self._sym["J"][k].xreplace(sub)
+            emit(fk)
+            emit(jk)
             used |= fk.free_symbols | jk.free_symbols
             if self._grl[k]:
-                body.append(f"    {{ const double f = {pr.doprint(fk)}; const double J = {pr.doprint(jk)};\n"
-                            f"      io.store({k}, y_{k} + (fabs(J) > 1e-8 ? f / J * ({exp_name}(J * dt) - 1.0) : f * dt)); }}")
+                if os.environ.get("BEAT_ODE_BRANCHES") == "1":  # (the former output: see _print_Piecewise)
+                    lines.append(f"    {{ const double f = {pr.doprint(fk)}; const double J = {pr.doprint(jk)};\n"
+                                 f"      io.store({k}, y_{k} + (fabs(J) > 1e-8 ? f / J * ({exp_name}(J * dt) - 1.0) : f * dt)); }}")
+                    continue
+                lines.append(f"    {{ const double f = {pr.doprint(fk)}; const double J = {pr.doprint(jk)};\n"
+                             f"      io.store({k}, y_{k} + beat_sel(fabs(J) > 1e-8, f / J * ({exp_name}(J * dt) - 1.0), f * dt)); }}")
             else:
-                body.append(f"    io.store({k}, y_{k} + dt * ({pr.doprint(fk)}));")
+                lines.append(f"    io.store({k}, y_{k} + dt * ({pr.doprint(fk)}));")
+        for e in emitted:
+            used |= temp[e].free_symbols
+        body = []
         loads = [f"    const double y_{k} = io.load({k});" for k in range(ns_)]
         pl = [f"    const double p_{k} = p[{k}];" for k in range(np_) if sympy.Symbol(f"p_{k}") in used]
         digest = hashlib.sha1(("\n".join(lines + body) + self.scheme).encode()).hexdigest()[:12]
@@ -200,6 +301,7 @@ class OdeFileModel(DeviceModel):
                 "  template <class IO, class P>\n"
                 "  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived&, const FastMath& fm, double t, double dt) {\n"
                 + ("    const auto fexp = [&fm](double x) { return fm.exp(fmin(fmax(x, -745.0), 709.0)); };\n" if self.fast_exp else "")
+                + "    const auto beat_sel = [](bool c, double a, double b) { return c ? a : b; };\n"
                 + "\n".join(loads + pl + lines + body) + "\n  }\n};\n")
 
     # ------------------------------------------------------------------------------------------------ NumPy
@@ -217,8 +319,12 @@ class OdeFileModel(DeviceModel):
         p = np.asarray(parameters, dtype=np.float64)  # (P,) or per node (P, N)
         if p.ndim == 2 and p.shape[1] != y2.shape[1]:
             raise ValueError(f"per-node parameters must have shape ({len(p)}, {y2.shape[1]}), got {p.shape}")
+        # (every argument an array of the nodes' shape: NumPy's and / or of a condition on parameters alone with one on a state
+        # would otherwise be a reduction over a ragged pair)
+        n = y2.shape[1]
+        pn = [np.broadcast_to(np.asarray(p[k], dtype=np.float64), (n,)) for k in range(len(p))]
         with np.errstate(all="ignore"):
-            f, J = self._numpy_fn(*[y2[k] for k in range(y2.shape[0])], *[p[k] for k in range(len(p))], float(t))
+            f, J = self._numpy_fn(*[y2[k] for k in range(y2.shape[0])], *pn, np.full(n, float(t)))
         out = np.empty_like(y2)
         for k in range(y2.shape[0]):
             fk = np.broadcast_to(np.asarray(f[k], dtype=np.float64), y2[k].shape)
@@ -246,7 +352,56 @@ class OdeFileModel(DeviceModel):
                                                    C.byref(mid)))
             self._registered = int(mid.value)
             self.model_id = self._registered
+            self._self_check()
         return self._registered
+
+    def _sample_states(self, n: int, seed: int = 0) -> np.ndarray:
+        """States to try a kernel on: the initial values, the potential spread over [-100, 60] mV, values in [0, 1] (gates) spread
+        over [0, 1], everything else within +-30 % of its initial value."""
+        rng = np.random.default_rng(seed)
+        y = np.repeat(self.init_state_values()[:, None], n, axis=1)
+        for k, name in enumerate(self.state_names):
+            y0 = y[k, 0]
+            if name == self.v_name:
+                y[k] = rng.uniform(-100.0, 60.0, n)
+            elif 0.0 <= y0 <= 1.0:
+                y[k] = rng.uniform(0.0, 1.0, n)
+            else:
+                y[k] = y0 * rng.uniform(0.7, 1.3, n)
+        y[:, 0] = self.init_state_values()
+        return y
+
+    def _self_check(self) -> None:
+        """The model's PLAIN kernel instance (uniform parameters, no pending update) against the NumPy evaluation of the same
+        expressions on 2048 sample states (to 1e-6 of each value), once per process: a big generated kernel is heavily spilled, and such a kernel has been
+        seen miscompiled (round 1; reproduced in round 5, tools/diag_spill.py) -- wrong values on part of the nodes, silently.
+        The other instances (per-node rows, pending update, classes) are held against this one by the library at their first
+        launch (csrc/beat_ode_jit.hip: custom_cross_check).  BEAT_JIT_SELF_CHECK=0 skips both."""
+        import os
+
+        if os.environ.get("BEAT_JIT_SELF_CHECK", "1") == "0" or getattr(self, "_verified", False):
+            return
+        y = self._sample_states(2048)
+        p = self.init_parameter_values()
+        worst = 0.0
+        for t, dt in ((0.0, 0.01), (0.37, 0.05)):
+            dev = DeviceModel.__call__(self, states=y, t=t, parameters=p, dt=dt)
+            with np.errstate(all="ignore"):
+                ref = self.numpy_step(y, t, p, dt)
+            ok = np.isfinite(ref)
+            err = np.abs(dev - ref)[ok] / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)[ok]
+            # (1e-6 of the value: a sample far from the model's physiological range may sit where exp(J dt) - 1 cancels, and the two
+            # exp()s differ in the last bit -- 3e-8 seen; a miscompiled kernel is wrong by O(1) on thousands of values)
+            if not np.isfinite(dev[ok]).all() or (err.size and err.max() > 1e-6):
+                bad = np.argwhere(~(np.abs(np.where(ok, dev - ref, 0.0)) <= 1e-6 * np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)))
+                k, i = (int(bad[0][0]), int(bad[0][1])) if len(bad) else (0, 0)
+                raise RuntimeError(
+                    f"{self.name}: the compiled kernel differs from the NumPy evaluation of the same expressions (state {self.state_names[k]}, "
+                    f"sample {i}: {dev[k, i]!r} against {ref[k, i]!r}; {len(bad)} of {ok.sum()} values) -- a miscompiled (heavily spilled) kernel; "
+                    "other compiler flags (BEAT_JIT_EXTRA_FLAGS) may help, BEAT_JIT_SELF_CHECK=0 skips this check")
+            worst = max(worst, float(err.max()) if err.size else 0.0)
+        self._verified = True
+        self.self_check_error = worst
 
     def __call__(self, states=None, t=0.0, parameters=None, dt=None, **kwargs):
         if dt is None:

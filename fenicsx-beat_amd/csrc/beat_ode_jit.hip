@@ -424,6 +424,122 @@ hipFunction_t custom_instance(beat_ctx* ctx, const CustomModel& m, const std::st
 }
 }  // namespace
 
+namespace {
+std::set<std::string>& custom_checked() {
+  static std::set<std::string> v;
+  return v;
+}
+
+// A variant instance of a registered model (per-node rows, pending update, classes) against the model's PLAIN instance, once per
+// instance and process: one step of the caller's first nodes on two scratch copies, the variant given what makes it compute the
+// plain step (every node the parameters of node 0 / class 0, nothing pending) -- same arithmetic, same values.  Why: the kernel of
+// a big generated model is heavily spilled (the reference's ToR-ORd files: ~400 SGPRs and ~500 VGPRs), and with ROCm 7.2 one of two
+// instances of such a kernel has been seen to reload registers under another lane mask than it spilled them under: wrong values on
+// the nodes that took the other arm of a branch, in ONE instance, the other one right (tools/diag_spill.py,
+// profiles/r05_generated_spills.md; the generator has emitted branch-free code since, which removes the trigger that was found).
+// The plain instance itself is held against the NumPy evaluation of the same expressions when the model is registered from
+// Python (beat/models/ode_file.py).  A variant that fails is rejected: the call fails, nothing falls back.
+int custom_cross_check(beat_ctx* ctx, const CustomModel& m, hipFunction_t f, const std::string& what, bool per_node, bool marked,
+                       const double* states, int64_t n, int64_t ld, const double* host_params, const double* ppn, int64_t pld,
+                       const MarkedArgs& mk_in, double t, double dt, int v_index) {
+  if (const char* e = std::getenv("BEAT_JIT_SELF_CHECK"))
+    if (e[0] == '0') return BEAT_OK;
+  const std::string key = m.name + "/" + what + "@" + std::to_string(ctx->device);
+  {
+    std::lock_guard<std::mutex> lock(customs_mutex());
+    if (custom_checked().count(key)) return BEAT_OK;
+  }
+  hipFunction_t f0 = custom_instance(ctx, m, "step_n0p0m0",
+      "template __global__ void ode_step_kernel<" + m.name + ", false, false, false>(\n    double*, int64_t, int64_t, ParamPack<" + m.name +
+      "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);");
+  if (f0 == nullptr) return BEAT_EINVAL;
+  int64_t nc = std::min<int64_t>(n, 1024);
+  if (nc < 1) return BEAT_OK;
+  // the parameters of node 0 / class 0
+  std::vector<double> p0(m.np, 1.0);
+  if (host_params != nullptr) {
+    p0.assign(host_params, host_params + m.np);
+  } else if (per_node) {
+    BEAT_HIP_CHECK(hipMemcpy2DAsync(p0.data(), sizeof(double), ppn, sizeof(double) * (size_t)pld, sizeof(double), (size_t)m.np,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } else if (marked) {
+    BEAT_HIP_CHECK(hipMemcpyAsync(p0.data(), mk_in.table, sizeof(double) * (size_t)m.np, hipMemcpyDeviceToHost, ctx->stream));
+    BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  const size_t ns = (size_t)m.ns, np = (size_t)m.np;
+  const size_t doubles = 2 * ns * (size_t)nc + np * (size_t)nc + (np + 1) + ((size_t)nc + 7) / 8;
+  double* scratch = nullptr;
+  BEAT_HIP_CHECK(hipMalloc(&scratch, sizeof(double) * doubles));
+  struct Free {
+    double* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{scratch};
+  double* sa = scratch;
+  double* sb = sa + ns * (size_t)nc;
+  double* rows = sb + ns * (size_t)nc;
+  double* table = rows + np * (size_t)nc;
+  unsigned char* marks = (unsigned char*)(table + np + 1);
+  for (size_t k = 0; k < ns; ++k) {
+    BEAT_HIP_CHECK(hipMemcpyAsync(sa + k * nc, states + (int64_t)k * ld, sizeof(double) * nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BEAT_HIP_CHECK(hipMemcpyAsync(sb + k * nc, states + (int64_t)k * ld, sizeof(double) * nc, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  std::vector<double> hrows(np * (size_t)nc), htab(np + 1, 0.0);
+  for (size_t k = 0; k < np; ++k) {
+    htab[k] = p0[k];
+    for (int64_t i = 0; i < nc; ++i) hrows[k * nc + i] = p0[k];
+  }
+  BEAT_HIP_CHECK(hipMemcpyAsync(rows, hrows.data(), sizeof(double) * hrows.size(), hipMemcpyHostToDevice, ctx->stream));
+  BEAT_HIP_CHECK(hipMemcpyAsync(table, htab.data(), sizeof(double) * htab.size(), hipMemcpyHostToDevice, ctx->stream));
+  BEAT_HIP_CHECK(hipMemsetAsync(marks, 0, (size_t)nc, ctx->stream));
+  PendingV none{nullptr, 0, nullptr, 0, {}, nullptr, 0};
+  MarkedArgs mk0{nullptr, nullptr, 0, nullptr, nullptr};
+  MarkedArgs mkv = marked ? MarkedArgs{marks, table, m.np + 1, nullptr, nullptr} : mk0;
+  SparseRows sp{{0}, 0};
+  double drv = 0.0;
+  double* vc = nullptr;
+  int64_t ldc = nc;
+  const double* ppn_v = per_node ? rows : nullptr;
+  const double* ppn_0 = nullptr;
+  int64_t pld_v = per_node ? nc : 0, pld_0 = 0;
+  const unsigned grid = (unsigned)((nc + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  {
+    void* args[] = {&sa, &nc, &ldc, p0.data(), &drv, &ppn_v, &pld_v, &t, &dt, &v_index, &vc, &none, &mkv, &sp};
+    BEAT_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+  }
+  {
+    void* args[] = {&sb, &nc, &ldc, p0.data(), &drv, &ppn_0, &pld_0, &t, &dt, &v_index, &vc, &none, &mk0, &sp};
+    BEAT_HIP_CHECK(hipModuleLaunchKernel(f0, grid, 1, 1, BEAT_BLOCK, 1, 1, 0, ctx->stream, args, nullptr));
+  }
+  std::vector<double> h(2 * ns * (size_t)nc);
+  BEAT_HIP_CHECK(hipMemcpyAsync(h.data(), scratch, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+  BEAT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const double* a = h.data();
+  const double* b = h.data() + ns * (size_t)nc;
+  for (size_t k = 0; k < ns; ++k) {
+    double scale = 0.0;
+    for (int64_t i = 0; i < nc; ++i) {
+      const double v = std::fabs(b[k * nc + i]);
+      if (v == v && v > scale && v < 1e300) scale = v;
+    }
+    for (int64_t i = 0; i < nc; ++i) {
+      const double x = a[k * nc + i], y = b[k * nc + i];
+      if (x != x && y != y) continue;  // both NaN (a caller's garbage in, the same garbage out)
+      if (!(std::fabs(x - y) <= 1e-10 * std::fabs(y) + 1e-13 * scale)) {
+        char msg[320];
+        std::snprintf(msg, sizeof msg, "instance %s of model %s differs from the model's plain instance (state %d, node %lld: %.17g against %.17g): "
+                      "miscompiled (heavily spilled) kernel; try other BEAT_JIT_EXTRA_FLAGS", what.c_str(), m.name.c_str(), (int)k, (long long)i, x, y);
+        beat_set_error("%s", msg);
+        return BEAT_EINVAL;
+      }
+    }
+  }
+  std::lock_guard<std::mutex> lock(customs_mutex());
+  custom_checked().insert(key);
+  return BEAT_OK;
+}
+}  // namespace
+
 // One step of a registered model, every form the shipped models' step takes except the compiled sparse rows: uniform parameters,
 // all per-node rows, or parameter classes (markers + table, optionally the compact layout's node map), each with or without a pending
 // update.  The kernel is ode_step_kernel<Name, PER_NODE, PEND, MARKED> of csrc/beat_ode_kernel.h.
@@ -448,6 +564,9 @@ int beat_custom_step(beat_ctx* ctx, int model_id, unsigned grid, double* states,
       "template __global__ void ode_step_kernel<" + m.name + ", " + tf[per_node] + ", " + tf[have_pend] + ", " + tf[marked] + ">(\n    double*, int64_t, int64_t, ParamPack<" +
       m.name + "::NP>, typename " + m.name + "::Derived, const double*, int64_t, double, double, int, double*, PendingV, MarkedArgs, SparseRows);");
   if (f == nullptr) return BEAT_EINVAL;
+  if (per_node || have_pend || marked) {
+    if (int rc = custom_cross_check(ctx, m, f, what, per_node, marked, states, n, ld, host_params, ppn, pld, mk_in, t, dt, v_index)) return rc;
+  }
   std::vector<double> prm(m.np, 1.0);
   if (host_params != nullptr) prm.assign(host_params, host_params + m.np);
   double drv = 0.0;

@@ -128,3 +128,54 @@ def test_generated_tp06_reproduces_the_committed_fixture():
     new = model.numpy_step(g["states"], float(g["t"]), g["parameter_defaults"], float(g["dt"]))
     ref = g["grl1_total"]
     assert (np.abs(new - ref) / np.maximum(np.abs(ref), 1e-9)).max() < 1e-10
+
+
+REF_TORORD = Path("/root/reference/odes/torord/ToRORd_dynCl_endo.ode")
+REF_LAND = Path("/root/reference/odes/torord/ToRORd_dynCl_endo_Land.ode")
+
+
+@pytest.mark.skipif(not REF_TORORD.is_file(), reason="the reference's .ode files are only in the build container")
+def test_generated_torord_reproduces_the_committed_fixtures():
+    """The reference's two ToR-ORd files (45 and 52 states; demos/biv_endocardial.py:124-173 generates its ``fun`` from the first)
+    through the generator: GRL1 steps of tests/golden/torord_spec.npz (48 states along an action potential, the three cell types)
+    and torord_land_spec.npz (six parameter sets) from the generated NumPy evaluation to 1e-11.  The Land file multiplies
+    comparisons into its arithmetic (``Gt(Zetas, 0)*Zetas``) and has conditions on parameters alone next to conditions on states:
+    both are what _ComparisonsAsNumbers and the broadcast parameters in numpy_step are for."""
+    from beat.models import from_ode
+
+    g = np.load(ROOT / "tests" / "golden" / "torord_spec.npz")
+    model = from_ode(REF_TORORD)
+    assert list(model.state_names) == list(g["state_names"]) and list(model.parameter_names) == list(g["parameter_names"])
+    for ct in (0, 1, 2):
+        p = g["parameter_defaults"].copy()
+        p[model.parameter_index("celltype")] = ct
+        new = model.numpy_step(g["states"], float(g["t"]), p, float(g["dt"]))
+        ref = g[f"grl1_celltype{ct}"]
+        assert (np.abs(new - ref) / np.maximum(np.abs(ref), 1e-9)).max() < 1e-11, ct
+    g = np.load(ROOT / "tests" / "golden" / "torord_land_spec.npz")
+    model = from_ode(REF_LAND)
+    assert list(model.state_names) == list(g["state_names"]) and list(model.parameter_names) == list(g["parameter_names"])
+    for k, p in enumerate(g["parameter_sets"]):
+        new = model.numpy_step(g["states"], float(g["t"]), p, float(g["dt"]))
+        ref = g["grl1"][k]
+        assert (np.abs(new - ref) / np.maximum(np.abs(ref), 1e-9)).max() < 1e-11, k
+
+
+def test_ode_expressions_are_data_not_code(tmp_path):
+    """An .ode file's right-hand sides are evaluated to build expression trees: only arithmetic, comparisons and calls of the
+    functions such a file may use get that far -- attribute access, subscripts, lambdas, unknown calls, keyword arguments and
+    strings are refused with the line they stand on."""
+    from beat.models import from_ode
+
+    text = SMALL.read_text()
+    for bad in ("x_bad = ().__class__", "x_bad = [1, 2][0]", "x_bad = (lambda: 1)()", "x_bad = open('/etc/passwd')",
+                "x_bad = exp(V, evaluate=False)", "x_bad = 'a'"):
+        f = tmp_path / "bad.ode"
+        f.write_text(text + "\n" + bad + "\n")
+        with pytest.raises(ValueError, match="bad.ode"):
+            from_ode(f)
+    # a comparison standing in arithmetic is a number (gotran): an infix one and a function-style one
+    f = tmp_path / "ind.ode"
+    f.write_text(text.replace("dn_dt =", "gate_on = (V > -60)*1.0 + Lt(V, -100)*2.0\ndn_dt = 0*gate_on +"))
+    m = from_ode(f)
+    assert m.num_states == 5 and np.isfinite(m.numpy_step(m.init_state_values(), 0.0, m.init_parameter_values(), 0.01)).all()

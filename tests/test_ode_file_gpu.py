@@ -12,6 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 SMALL = ROOT / "tests" / "data" / "small_cell.ode"
+BIG = ROOT / "tests" / "data" / "big_cell.ode"  # written by tests/data/make_big_cell.py
 
 
 def _states(model, n, seed):
@@ -223,3 +224,101 @@ def test_generated_model_in_the_fused_split_step_stays_on_the_device(hip_ctx):
     c.solve((0.0, nsteps * dt), dt)
     vc = np.asarray(c.ode.values)
     np.testing.assert_array_equal(vc, va)  # same kernels, same arguments as the step() loop
+
+
+@pytest.mark.parametrize("emit", ["by_state", "global"])
+def test_generated_kernel_of_a_big_model_with_spilled_registers(hip_ctx, emit, monkeypatch):
+    """A user's big model does to the generator what the reference's ToR-ORd files do (45 / 52 states: 256 VGPRs + 256 AGPRs and
+    1.8 KB of scratch per lane when generated): hundreds of temporaries alive at once, registers spilled.  tests/data/big_cell.ode
+    (48 states, synthetic) in the order the generator emits by default (state by state, the potential last: 215 VGPRs, nothing
+    spilled) and with every temporary ahead of every update (BEAT_ODE_EMIT=global: 256 + 256 registers, 450 B of scratch, 116
+    spilled VGPRs on gfx950) through the step kernel -- uniform and per-node parameters, 8000 random states -- and through the
+    in-kernel time loop, whose states live in registers across steps (round 1 saw a heavily spilled generated kernel go wrong
+    exactly there): against the NumPy evaluation of the same expressions."""
+    from beat.models import from_ode
+
+    if emit == "global":
+        monkeypatch.setenv("BEAT_ODE_EMIT", "global")
+    model = from_ode(BIG)
+    assert model.num_states == 48 and model.v_name == "V"
+    rng = np.random.default_rng(17)
+    n = 8000
+    y = np.repeat(model.init_state_values()[:, None], n, axis=1)
+    y[0] = rng.uniform(-95.0, 40.0, n)
+    for k, name in enumerate(model.state_names):
+        if name.startswith("x"):
+            y[k] = rng.uniform(0.0, 1.0, n)
+        elif name.startswith("c_"):
+            y[k] *= rng.uniform(0.7, 1.4, n)
+    p = model.init_parameter_values(stim_amplitude=30.0)
+    for t in (0.3, 1.4):
+        dev = model(states=y, t=t, parameters=p, dt=0.02)
+        ref = model.numpy_step(y, t, p, 0.02)
+        assert np.isfinite(dev).all()
+        assert (np.abs(dev - ref) / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)).max() < 1e-11, t
+    pn = np.repeat(p[:, None], n, axis=1)
+    pn[model.parameter_index("g_3")] *= rng.uniform(0.5, 1.5, n)
+    pn[model.parameter_index("k_5")] *= rng.uniform(0.5, 1.5, n)
+    dev = model(states=y, t=1.4, parameters=pn, dt=0.02)
+    ref = model.numpy_step(y, 1.4, pn, 0.02)
+    assert (np.abs(dev - ref) / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)).max() < 1e-11
+    # the in-kernel loop: 300 steps through the stimulus, V and one gate tracked
+    y0 = y[:, :256].copy()
+    track = [0, model.state_index("x4_1")]
+    out, tr = model.run(y0, p, 0.02, 300, nbeats=1, t0=0.0, track_indices=track, save_freq=25)
+    yy, rows = y0.copy(), []
+    for j in range(300):
+        if j % 25 == 0:
+            rows.append(yy[track].copy())
+        yy = model.numpy_step(yy, j * 0.02, p, 0.02)
+    rows = np.array(rows)
+    assert np.isfinite(out).all() and tr.shape == (12, 2, 256)
+    assert (np.abs(out - yy) / np.abs(yy).max(axis=1, keepdims=True)).max() < 1e-8
+    assert (np.abs(tr - rows) / np.abs(rows).max(axis=(0, 2), keepdims=True)).max() < 1e-8
+
+
+def test_self_checks_catch_a_miscompiled_generated_kernel(hip_ctx, monkeypatch):
+    """The generator's former output -- `c ? a : b` with the arms inline, every temporary ahead of every update -- makes hipcc
+    (ROCm 7.2) build a heavily spilled kernel with divergent branches, ONE instance of which reloads registers under another lane
+    mask than it spilled them under: at -O3 the per-node-rows instance is wrong on the nodes that take the other arm of a branch,
+    the plain one right; at -O1 the plain one is wrong (tools/diag_spill.py, profiles/r05_generated_spills.md).  Where that still
+    reproduces, the two self checks must refuse the instance LOUDLY: the library's cross-check of a variant instance against the
+    plain one (BeatHipError at the first launch) and the registration's check of the plain instance against the NumPy evaluation
+    (RuntimeError).  Where the compiler no longer does it, there is nothing to catch (skip)."""
+    from beat import _hip
+    from beat.models import from_ode
+
+    monkeypatch.setenv("BEAT_ODE_BRANCHES", "1")
+    monkeypatch.setenv("BEAT_ODE_EMIT", "global")
+
+    def sample(model, n=4096):
+        y = model._sample_states(n, seed=5)
+        p = model.init_parameter_values(stim_amplitude=30.0)
+        return y, p, np.repeat(p[:, None], n, axis=1)
+
+    def wrong(dev, ref, y):
+        return (np.abs(dev - ref) / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)).max() > 1e-8
+
+    # is the miscompilation still there?  (checks off; a distinct model name per stage: the library checks an instance once)
+    monkeypatch.setenv("BEAT_JIT_SELF_CHECK", "0")
+    probe = from_ode(BIG, name="big_probe")
+    y, p, pn = sample(probe)
+    per_node_wrong = wrong(probe(states=y, t=1.4, parameters=pn, dt=0.02), probe.numpy_step(y, 1.4, pn, 0.02), y)
+    monkeypatch.setenv("BEAT_JIT_EXTRA_FLAGS", "-O1")
+    probe1 = from_ode(BIG, name="big_probe_o1")
+    plain_wrong = wrong(probe1(states=y, t=1.4, parameters=p, dt=0.02), probe1.numpy_step(y, 1.4, p, 0.02), y)
+    monkeypatch.delenv("BEAT_JIT_EXTRA_FLAGS")
+    if not (per_node_wrong or plain_wrong):
+        pytest.skip("this compiler does not miscompile the branchy form")
+    monkeypatch.setenv("BEAT_JIT_SELF_CHECK", "1")
+    if per_node_wrong:
+        model = from_ode(BIG, name="big_checked")
+        model.register()  # the plain instance passes its check against NumPy
+        with pytest.raises(_hip.BeatHipError, match="differs from the model's plain instance"):
+            model(states=y, t=1.4, parameters=pn, dt=0.02)
+        np.testing.assert_allclose(model(states=y, t=1.4, parameters=p, dt=0.02), model.numpy_step(y, 1.4, p, 0.02), rtol=1e-9, atol=1e-12)
+    if plain_wrong:
+        monkeypatch.setenv("BEAT_JIT_EXTRA_FLAGS", "-O1")
+        model = from_ode(BIG, name="big_checked_o1")
+        with pytest.raises(RuntimeError, match="differs from the NumPy evaluation"):
+            model.register()
