@@ -106,8 +106,23 @@ class MonodomainSplittingSolver:
         ode, pde = self.ode, self.pde
         ops, dev, row = pde._ops, ode._dev, ode._v_row
         dt = steps[0][1] - steps[0][0]
-        ops.flush_pending()
-        if not abs(dt - float(pde._timestep)) < 1.0e-12:
+        # What an earlier step or solve() left for the next ionic launch (the x update of its last solve, deferred): the first launch
+        # of the library's loop applies it, as step() would have (pending_in) -- a call of solve() per output interval does not pay
+        # a pass over the potential per call (2 ms at 512^3).  Anything else that is pending (another row, another time step, the
+        # one-launch path) is flushed.
+        carry = 0
+        if getattr(ops, "open_x", None) is not None:
+            ops.solve_finish()
+        same_dt = abs(dt - float(pde._timestep)) < 1.0e-12
+        pend = getattr(ops, "pending", None)
+        if (same_dt and pend is not None and not ops.small_active() and pend[0].ptr.value == row.ptr.value
+                and ode._pending_ops is ops and os.environ.get("BEAT_BATCH_CARRY", "1") != "0"):
+            carry = int(pend[2])
+            ops.pending = None  # (the guess increment, if one is due, is known to the operator)
+        else:
+            ops.flush_pending()
+        self._last_carry = carry
+        if not same_dt:
             pde._timestep.value = dt
             pde._update_matrices()
         theta_pde = pde.parameters["theta"]
@@ -117,7 +132,7 @@ class MonodomainSplittingSolver:
         w_ptrs = (C.c_void_p * max(1, len(stims)))(*[s.field.ptr for s in stims])
         done = 0
         if not ops.small_active():
-            self._batched_steps_big(steps, stims, w_ptrs, hp, npar, (rtol, atol, max_it))
+            self._batched_steps_big(steps, stims, w_ptrs, hp, npar, (rtol, atol, max_it), pending_in=carry)
             done = len(steps)
         while done < len(steps):
             nb = min(len(steps) - done, _hip.MAX_BATCH)
@@ -152,7 +167,7 @@ class MonodomainSplittingSolver:
             f.alias_to(row, sync=ops.flush_pending)
         ode._aliases = [pde.state, pde.v_, ode.v_ode]
 
-    def _batched_steps_big(self, steps, stims, w_ptrs, hp, npar, tol) -> None:
+    def _batched_steps_big(self, steps, stims, w_ptrs, hp, npar, tol, pending_in: int = 0) -> None:
         """The steps of a grid too big for the one-launch solve, run by the library's own loop (beat_split_steps_big): per step the
         ionic launch that applies what the previous solve deferred and the solve in place on the potential row -- what
         ``_fused_step`` does, without Python between the steps.  ``self.batch_ode_ms`` (a list, if the caller sets one) collects
@@ -166,9 +181,8 @@ class MonodomainSplittingSolver:
         ops, dev, row = pde._ops, ode._dev, ode._v_row
         theta_pde = pde.parameters["theta"]
         rtol, atol, max_it = tol
-        # what an earlier deferred solve left for the next ionic launch: applied by the first launch of the batch if it belongs to
-        # this row, flushed otherwise (ops.flush_pending was called by _batched_steps: nothing is pending here)
-        pending_in = 0
+        # pending_in: what an earlier deferred solve left for the next ionic launch (directions of its last ring cycle): applied by
+        # the first launch of the batch (_batched_steps hands it over when it belongs to this row and flushes it otherwise)
         times = getattr(self, "batch_ode_ms", None)
         done = 0
         # a call into the library cannot be interrupted: its length is kept near one second of steps (the first call makes 16 and

@@ -56,9 +56,14 @@ struct PendingNow {
 // its round trip, and its s_waitcnt vmcnt(0) on the previous tile's stores as well: +0.10 ms on the ionic kernel of step() against the
 // library's loop, which knows the count on the host; 1 = once per launch, kept in an SGPR across the tile loop: the difference is
 // gone, but BOTH paths lose 0.1 - 0.4 ms to the changed register allocation; 2 = per tile with a SCALAR load (the state was written
-// by earlier kernels and is constant for this one; the constant cache is invalidated at kernel start): no vector-memory wait.
+// by earlier kernels and is constant for this one; the constant cache is invalidated at kernel start): no vector-memory wait;
+// 3 = thread 0 of a block reads latch and count once, ahead of the barrier that follows the table set-up, into LDS; every tile
+// takes the count from there (a volatile LDS read: nothing lives across the tile loop, no global round trip per tile).  3 is the
+// build: against 2, alternating on two boxes (13 runs each, profiles/r05_step_gap.md), the ionic kernel of step() AND of the library's
+// loop sat at 9.68 - 9.72 ms in every run, where build 2 ranged from 9.63 to 10.03 (the two modes of this kernel that rounds 3 and 4
+// chased): mean step 13.55 - 13.57 against 13.62 - 13.76 ms.
 #ifndef BEAT_PENDING_READ
-#define BEAT_PENDING_READ 2
+#define BEAT_PENDING_READ 3
 #endif
 __device__ __forceinline__ int beat_pending_read(const PendingV& p) {
 #if BEAT_PENDING_READ == 1
@@ -171,6 +176,11 @@ __device__ __forceinline__ D mix_derived(const D& du, const D& dl) {
   return d;
 }
 
+#if BEAT_PENDING_READ == 3
+#define BEAT_PENDING_TILE_COUNT __builtin_amdgcn_readfirstlane(*(volatile int*)&s_pend[1])
+#else
+#define BEAT_PENDING_TILE_COUNT nupd_dev
+#endif
 template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARSE = false, class CT = IdxPack<>,
           unsigned long long DM0 = 0, unsigned long long DM1 = 0>
 __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
@@ -182,10 +192,22 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
   etab[threadIdx.x] = kExp2Tab[threadIdx.x];
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
+#if BEAT_PENDING_READ == 3
+  __shared__ int s_pend[2];  // [0] the solve ahead has latched (or there is none), [1] its update count (-1: the host's count)
+  if (PEND && threadIdx.x == 0) {
+    s_pend[0] = pend.dev_st != nullptr ? (pend.dev_st[beat_pde_detail::STOP] != 0.0 ? 1 : 0) : 1;
+    s_pend[1] = pend.dev_st != nullptr ? (int)pend.dev_st[beat_pde_detail::NUPD] : -1;
+  }
+  __syncthreads();
+  const FastMath fm{etab, ltab};
+  if (PEND && s_pend[0] == 0) return;  // the solve ahead has not latched (see PendingV)
+#else
   __syncthreads();
   const FastMath fm{etab, ltab};
   if (PEND && pend.dev_st != nullptr && pend.dev_st[beat_pde_detail::STOP] == 0.0) return;  // the solve ahead has not latched (see PendingV)
+#endif
   const int nupd_dev = PEND ? beat_pending_read(pend) : -1;
+  (void)nupd_dev;
   // (Round 3, measured and removed: starting the three blocks that share a CU a third of a tile apart -- s_sleep by
   // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
   // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       // the potential with the pending update applied (and the guess's bookkeeping done) once, ahead of the passes --
       // same expressions and order as NodeIOPending::load / x_flush_kernel: the pending values die here instead of
       // staying live through every pass (-30 VGPRs, no scratch)
-      const PendingNow now = beat_pending_now(pendl, nupd_dev);
+      const PendingNow now = beat_pending_now(pendl, BEAT_PENDING_TILE_COUNT);
       double pp[BEAT_MAX_PENDING_CLASS], pa[BEAT_MAX_PENDING_CLASS];
 #pragma unroll
       for (int j = 0; j < BEAT_MAX_PENDING_CLASS; ++j) {
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    const PendingNow now = beat_pending_now(pendl, nupd_dev);
+    const PendingNow now = beat_pending_now(pendl, BEAT_PENDING_TILE_COUNT);
     NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {

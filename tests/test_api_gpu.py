@@ -1473,6 +1473,28 @@ def test_batched_solve_of_a_big_grid_equals_the_step_loop(order, monkeypatch):
     b.step((t0, t0 + dt))  # and a step() after a batch
     a.step((t0, t0 + dt))
     np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    # solve() after step() / solve() WITHOUT a read in between (a driver that calls solve() per output interval): what the last
+    # solve deferred -- here the solve step() left open -- is handed to the library loop's first ionic launch (pending_in), not
+    # flushed in a pass of its own; twice in a row; same bits as the step() loop
+    t0 = t0 + dt
+    ops = a.pde._ops
+    for span in (5, 3):
+        a.step((t0, t0 + dt))
+        b.step((t0, t0 + dt))
+        t0 = t0 + dt
+        assert ops.open_x is not None
+        flushes, real_flush = [], ops.flush_pending
+        ops.flush_pending = lambda: (flushes.append(1) if (ops.pending is not None or ops.open_x is not None) else None, real_flush())[1]  # (a call with nothing pending does nothing)
+        try:
+            a.solve((t0, t0 + span * dt), dt)
+            a.solve((t0 + span * dt, t0 + 2 * span * dt), dt)
+        finally:
+            del ops.flush_pending
+        assert not flushes
+        for i in range(2 * span):
+            b.step((t0, t0 + dt))
+            t0 = t0 + dt
+        np.testing.assert_array_equal(a.ode.values, b.ode.values)
     pts = np.array([[0.0, 0.0, 0.0], [2.0, 1.0, 0.5]])
     assert not a._can_batch(g.ProbeRecorder(a.pde.state, pts, capacity=8))
     assert not build(beat.telemetry.PerformanceMonitor())._can_batch(None)
