@@ -61,7 +61,7 @@ struct PendingNow {
 // takes the count from there (a volatile LDS read: nothing lives across the tile loop, no global round trip per tile).  3 is the
 // build: against 2, alternating on two boxes (13 runs each, profiles/r05_step_gap.md), the ionic kernel of step() AND of the library's
 // loop sat at 9.68 - 9.72 ms in every run, where build 2 ranged from 9.63 to 10.03 (the two modes of this kernel that rounds 3 and 4
-// chased): mean step 13.55 - 13.57 against 13.62 - 13.76 ms.
+// chased): mean step 13.55 - 13.57 against 13.62 - 13.76 ms.  (Not immune: 9.65 - 10.07 on a third box.)
 #ifndef BEAT_PENDING_READ
 #define BEAT_PENDING_READ 3
 #endif
