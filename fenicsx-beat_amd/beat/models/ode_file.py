@@ -32,6 +32,9 @@ import numpy as np
 from ._base import DeviceModel
 
 _SCHEMES = ("generalized_rush_larsen", "forward_euler")
+# gotranx's own names for the same two schemes (gotranx.schemes: what its code generator is asked for)
+_SCHEME_ALIASES = {"forward_generalized_rush_larsen": "generalized_rush_larsen", "forward_explicit_euler": "forward_euler",
+                   "explicit_euler": "forward_euler"}
 
 
 def _walk(text: str, where: str):
@@ -125,6 +128,7 @@ class OdeFileModel(DeviceModel):
 
         self.fast_exp = bool(fast_exp)
 
+        scheme = _SCHEME_ALIASES.get(scheme, scheme)
         if scheme not in _SCHEMES:
             raise ValueError(f"scheme must be one of {_SCHEMES}, got {scheme!r}")
         self.path = Path(path)

@@ -96,6 +96,15 @@ def test_generated_model_compiles_for_gfx950(tmp_path):
     assert len(names) == 1, names
 
 
+def test_gotranx_scheme_names_are_understood():
+    from beat.models import from_ode
+
+    assert from_ode(SMALL, scheme="forward_explicit_euler").scheme == "forward_euler"
+    assert from_ode(SMALL, scheme="forward_generalized_rush_larsen").scheme == "generalized_rush_larsen"
+    with pytest.raises(ValueError):
+        from_ode(SMALL, scheme="hybrid_rush_larsen")
+
+
 def test_generated_numpy_step_takes_per_node_parameters():
     """(P, N) parameters through the NumPy twin = the (P,) evaluation column by column (the checker of the GPU suite's per-node
     and class routes must itself be right)."""
