@@ -188,6 +188,14 @@ def load():
             f"HIP extension not built: {_LIB_PATH} is missing. Run `python -c 'import __graft_entry__ "
             "as g; g.build()'` (or `make -C fenicsx-beat_amd/csrc`). There is no CPU fallback."
         )
+    # PyTorch FIRST: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so); loaded after this library's (the system's
+    # copy) the process holds two runtimes, and the one that initialises second finds no device ("no ROCm-capable device is
+    # detected" from beat_ctx_create although torch.cuda.is_available() -- seen when a generated model was registered before
+    # anything had imported torch).  With torch's copy in the process this library's dependency resolves to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # (a host without PyTorch: bare-ctypes use of the library, tests/_ctypes_only_script.py does not come through here)
+        pass
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

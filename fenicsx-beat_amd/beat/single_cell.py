@@ -25,6 +25,8 @@ logger = logging.getLogger(__name__)
 def _identity_of(fun: Callable) -> bytes:
     """What distinguishes one step function from another in the cache key."""
     if isinstance(fun, DeviceModel):
+        if hasattr(fun, "cxx_name"):  # a model generated from an .ode file: its id is per process, its source digest is not
+            return f"device:{fun.name}:{fun.cxx_name}".encode()
         return f"device:{fun.name}:{fun.model_id}".encode()
     code = getattr(fun, "__code__", None)
     return code.co_code if code is not None else repr(fun).encode()

@@ -60,3 +60,21 @@ def test_pace_train_demo_with_the_reference_heterogeneity(capsys):
     near, far = report[0]
     assert 0.0 < near[0] < 3.0 and 10.0 < far[0] < 40.0
     assert np.isfinite(near[1]) and (np.isnan(far[1]) or far[1] > near[1] + 50.0)
+
+
+def test_ode_file_demo_runs_a_generated_model_on_a_slab(capsys):
+    """demos/ode_file_slab.py: a cell model straight from an .ode file (beat.models.from_ode) -- pre-paced as a single cell in one
+    launch (single_cell.get_steady_state -> beat_ode_run on the generated kernel), then on a slab through the fused split step: the
+    wave started in one corner reaches the opposite one.  (Run in a fresh process too: the library used to be loaded ahead of
+    PyTorch there -- two HIP runtimes in one process, "no ROCm-capable device" -- which no test that gets its context from the
+    fixture could see.)"""
+    import subprocess
+
+    t_act, v_far, solver = _demo("ode_file_slab").main(["--dx", "0.25", "--T", "30", "--beats", "2"])
+    out = capsys.readouterr().out
+    assert "5 states, 14 parameters" in out and "status OK" in out
+    assert t_act is not None and 10.0 < t_act < 30.0 and v_far.max() > 0.0
+    assert solver.ode.on_device and solver.ode._dev.model.model_id >= 100
+    fresh = subprocess.run([sys.executable, str(DEMOS / "ode_file_slab.py"), "--dx", "0.5", "--T", "5", "--beats", "1"],
+                           capture_output=True, text=True, timeout=300)
+    assert fresh.returncode == 0 and "status OK" in fresh.stdout, fresh.stderr[-2000:]
