@@ -98,6 +98,24 @@ __device__ __forceinline__ double from_right(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// BEAT_RR_BUF (round 5; 0 = the clamped global loads of rounds 2 - 4): the rows of a plane through a raw buffer over that plane -- a lane
+// that is to hold 0 (outside the box, a plane beyond a physical face) passes an offset beyond the buffer's end (or the plane gets no
+// records): the load returns 0 and fetches nothing, and neither the clamped address nor the select that zeroed the value afterwards
+// is needed.  1 = every mode, 2 = every mode but the right-hand side (the build).  Measured on one box, alternating
+// (profiles/r05_rr_resources.md): PDOT 776 - 779 -> 742 us (162 -> 156 VGPRs), RUPD 715 - 718 -> 719 (174 -> 162 VGPRs, 2 -> 3 waves per
+// SIMD: no effect), the right-hand side 951 - 985 -> 1002 - 1018 with them (hence 2); the diffusion part of the 512^3 step 3.65 - 3.68 ->
+// 3.62 ms, of the developed front's 5.56 - 5.58 -> 5.48 - 5.49.
+#ifndef BEAT_RR_BUF
+#define BEAT_RR_BUF 2
+#endif
+typedef int rr_v2i __attribute__((ext_vector_type(2)));
+[[maybe_unused]] constexpr unsigned RR_OOB = 0x80000000u;
+__device__ __forceinline__ double rr_buf_load(const double* base, unsigned bytes, unsigned off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  const rr_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  return __hiloint2double(v.y, v.x);
+}
+
 __device__ __forceinline__ int axis_type3(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
   if (i == 0 && lo_phys) return 0;
@@ -123,6 +141,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   constexpr bool OLD = MODE == RR_PDOT || MODE == RR_PRUPD;                      // ... with beta p_old, and stored
   constexpr bool RAW = MODE == RR_UDOT || MODE == RR_PRUPD;                      // r itself of the owned rows is kept too
   constexpr int NW = RAW ? RY : 1;
+  constexpr bool BUF = BEAT_RR_BUF == 1 || (BEAT_RR_BUF == 2 && MODE != RR_RHS);  // raw-buffer loads of the rows (see BEAT_RR_BUF)
   static_assert(!GUESS || MODE == RR_RHS, "the initial guess enters the right-hand side only");
   __shared__ double red[4];
   // boundary rows of the coefficient tables and 1/diag per node type, staged in LDS: the lanes on a face of the box
@@ -172,7 +191,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     row_in[r] = x_in && gy >= 0 && gy < g.ny;
     txy[r] = tx + 3 * axis_type3(gy, g.ny, 1, 1);
     off[r] = min(max(gy, 0), g.ny - 1) * g.nx + cx;
+    if constexpr (BUF) off[r] = row_in[r] ? (int)((unsigned)(gy * g.nx + gx) * 8u) : (int)RR_OOB;  // byte offset within the plane, or out of range
   }
+  [[maybe_unused]] const unsigned pbytes = (unsigned)(g.plane * 8);
   double beta = 0.0, alpha = 0.0;
   if (OLD) beta = a.st[BETA];
   if (MODE == RR_PRUPD) alpha = a.st[ALPHA];
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     if (z < ze) {
     const int k = z + 1;  // plane whose raw values (slot u) become the staged plane z+1 now
     if (k >= zb - 1 && k <= ze) {  // staged values of plane k; PDOT forms p_new here and stores the rows this wave owns
-      const bool zok = (k >= 0 || !g.z_lo_phys) && (k < g.nz || !g.z_hi_phys);
+      [[maybe_unused]] const bool zok = (k >= 0 || !g.z_lo_phys) && (k < g.nz || !g.z_hi_phys);
       // ghost planes (another rank's boundary planes): their z type comes with the geometry; PDOT keeps p_new there
       // too -- both neighbours form it from the same exchanged r and the same p_old, so it needs no exchange of its own
       const int tz9 = 9 * (k < 0 ? g.ghost_lo_tz : k >= g.nz ? g.ghost_hi_tz : axis_type3(k, g.nz, g.z_lo_phys, g.z_hi_phys));
@@ -234,11 +255,14 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           // p_new = D^-1 r + beta p_old (same expression as cg_pupdate_oop_kernel; p_old unread while beta = 0)
           c = have_old ? fma(beta, rb2[u][r], di * ra[u][r]) : di * ra[u][r];
         }
-        c = (zok && row_in[r]) ? c : 0.0;
+        if constexpr (!BUF) c = (zok && row_in[r]) ? c : 0.0;
         Cp[r] = c;
         if (GUESS) {
           constexpr int q = GUESS ? 1 : 0;
-          Ep[r * q] = (zok && row_in[r]) ? c + re1[u][r * q] : 0.0;  // x0 = v_ + e
+          if constexpr (BUF)
+            Ep[r * q] = c + re1[u][r * q];  // x0 = v_ + e (both 0 where nothing was loaded)
+          else
+            Ep[r * q] = (zok && row_in[r]) ? c + re1[u][r * q] : 0.0;  // x0 = v_ + e
         }
         if (OLD) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
@@ -253,7 +277,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
       if (z + PD >= zb && z + PD < ze) {
         const double* __restrict__ br = X2 + (int64_t)(z + PD) * g.plane;
 #pragma unroll
-        for (int j = 0; j < RY; ++j) rvn[u][j] = br[off[j + 1]];
+        for (int j = 0; j < RY; ++j) rvn[u][j] = BUF ? rr_buf_load(br, pbytes, (unsigned)off[j + 1]) : br[off[j + 1]];
       }
     }
     {
@@ -262,15 +286,30 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
         const int cz = min(max(kf, -1), g.nz);
         const double* __restrict__ bx = X + (int64_t)cz * g.plane;
         const double* __restrict__ bx2 = (OLD && have_old) ? X2 + (int64_t)cz * g.plane : bx;
+        if constexpr (BUF) {
+          // (a plane beyond a physical face holds nothing: no records, every load 0)
+          const unsigned pb = ((kf >= 0 || !g.z_lo_phys) && (kf < g.nz || !g.z_hi_phys)) ? pbytes : 0u;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          ra[u][r] = bx[off[r]];
-          if (OLD) rb2[u][r] = bx2[off[r]];
-        }
-        if (GUESS) {
-          const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
+          for (int r = 0; r < NR; ++r) {
+            ra[u][r] = rr_buf_load(bx, pb, (unsigned)off[r]);
+            if (OLD) rb2[u][r] = rr_buf_load(bx2, pb, (unsigned)off[r]);
+          }
+          if (GUESS) {
+            const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
 #pragma unroll
-          for (int r = 0; r < NR; ++r) re1[u][r < NE ? r : 0] = b1[off[r]];
+            for (int r = 0; r < NR; ++r) re1[u][r < NE ? r : 0] = rr_buf_load(b1, pb, (unsigned)off[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            ra[u][r] = bx[off[r]];
+            if (OLD) rb2[u][r] = bx2[off[r]];
+          }
+          if (GUESS) {
+            const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) re1[u][r < NE ? r : 0] = b1[off[r]];
+          }
         }
       }
     }
