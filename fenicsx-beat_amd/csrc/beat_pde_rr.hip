@@ -116,6 +116,31 @@ __device__ __forceinline__ double rr_buf_load(const double* base, unsigned bytes
   return __hiloint2double(v.y, v.x);
 }
 
+// BEAT_RR_ALIGN = 1 (round 5): in PDOT and RUPD a wave owns 64 x-nodes that start on a multiple of 64 (whole aligned 512-byte pieces of
+// a row) instead of 62 that start 8 bytes before a multiple of 496.  The access pattern alone -- six rows of a plane read, four written,
+// no arithmetic -- streams at 4.2 - 4.3 TB/s in the 62-node form and at 5.0 - 5.1 TB/s in the aligned form INCLUDING what it needs
+// instead of the two halo lanes (tools/march_probe.py, profiles/r05_march_probe.md): ONE more load per plane in which lanes 0 .. NR-1
+// fetch the element left of the segment in rows 0 .. NR-1 and lanes 8 .. 8+NR-1 the element right of it (every other lane passes an
+// out-of-range offset), kept in one register pair per plane of the window; the lane shifts put that element into lane 0 / lane 63
+// (v_readlane, then the shift keeps it where a lane has no source).  Needs the raw-buffer loads (BEAT_RR_BUF).
+#ifndef BEAT_RR_ALIGN
+#define BEAT_RR_ALIGN 1
+#endif
+// lane i <- lane i-1, lane 0 <- lane `src_lane` of `h` / lane i <- lane i+1, lane 63 <- lane `src_lane` of `h`: the lane without a
+// source keeps the shift's `old` operand, which is that element broadcast (v_readlane, v_mov, v_mov_dpp per half)
+__device__ __forceinline__ double from_left_h(double v, double h, int src_lane) {
+  const int lo = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__double2loint(h), src_lane), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__double2hiint(h), src_lane), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_right_h(double v, double h, int src_lane) {
+  const int lo = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__double2loint(h), src_lane), __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__double2hiint(h), src_lane), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// (the same condition on the host, where the geometry of a launch is made: make_geom)
+constexpr bool rr_aligned_mode(int mode) { return BEAT_RR_ALIGN == 1 && BEAT_RR_BUF != 0 && (mode == 0 || mode == 1); }
+
 __device__ __forceinline__ int axis_type3(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
   if (i == 0 && lo_phys) return 0;
@@ -142,6 +167,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   constexpr bool RAW = MODE == RR_UDOT || MODE == RR_PRUPD;                      // r itself of the owned rows is kept too
   constexpr int NW = RAW ? RY : 1;
   constexpr bool BUF = BEAT_RR_BUF == 1 || (BEAT_RR_BUF == 2 && MODE != RR_RHS);  // raw-buffer loads of the rows (see BEAT_RR_BUF)
+  constexpr bool ALIGNED = rr_aligned_mode(MODE);  // 64 aligned x-nodes per wave, the x-halo from one more load per plane (see BEAT_RR_ALIGN)
+  static_assert(!ALIGNED || BUF, "aligned segments come with the raw-buffer loads");
+  constexpr int SEGW = ALIGNED ? 64 : SEG;
   static_assert(!GUESS || MODE == RR_RHS, "the initial guess enters the right-hand side only");
   __shared__ double red[4];
   // boundary rows of the coefficient tables and 1/diag per node type, staged in LDS: the lanes on a face of the box
@@ -174,12 +202,12 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     chunk = blk / (g.nsegx * g.nrg);
     wave_ok = blk < g.total_blocks && rb < g.nrb;
   }
-  const int gx = seg * SEG - 1 + lane;
+  const int gx = seg * SEGW + (ALIGNED ? 0 : -1) + lane;
   const int y0 = rb * RY - 1;  // global row of register row 0
   const int zb = g.z_lo + chunk * g.zc;
   const int ze = wave_ok ? min(zb + g.zc, g.z_hi) : zb;
   const bool x_in = wave_ok && gx >= 0 && gx < g.nx;
-  const bool x_out = x_in && lane >= 1 && lane <= SEG;  // this lane produces outputs
+  const bool x_out = x_in && (ALIGNED || (lane >= 1 && lane <= SEG));  // this lane produces outputs
   const int tx = axis_type3(gx, g.nx, 1, 1);
   bool row_in[NR];
   int txy[NR];  // tx + 3 ty of the register rows
@@ -194,6 +222,18 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     if constexpr (BUF) off[r] = row_in[r] ? (int)((unsigned)(gy * g.nx + gx) * 8u) : (int)RR_OOB;  // byte offset within the plane, or out of range
   }
   [[maybe_unused]] const unsigned pbytes = (unsigned)(g.plane * 8);
+  // ALIGNED: what this lane fetches in the x-halo load of a plane (lanes 0 .. NR-1: left of the segment in rows 0 .. NR-1, lanes
+  // 8 .. 8+NR-1: right of it), and the node type of that element (PDOT forms p_new there as everywhere)
+  [[maybe_unused]] unsigned hoff = RR_OOB;
+  [[maybe_unused]] int htxy = 13 % 9;
+  if constexpr (ALIGNED) {
+    const int hr = lane < 8 ? lane : lane - 8;
+    const int hx = lane < 8 ? seg * SEGW - 1 : seg * SEGW + SEGW;
+    const int hy = y0 + hr;
+    const bool hv = wave_ok && (lane < NR || (lane >= 8 && lane < 8 + NR)) && hx >= 0 && hx < g.nx && hy >= 0 && hy < g.ny;
+    hoff = hv ? (unsigned)(hy * g.nx + hx) * 8u : RR_OOB;
+    htxy = axis_type3(min(max(hx, 0), g.nx - 1), g.nx, 1, 1) + 3 * axis_type3(min(max(hy, 0), g.ny - 1), g.ny, 1, 1);
+  }
   double beta = 0.0, alpha = 0.0;
   if (OLD) beta = a.st[BETA];
   if (MODE == RR_PRUPD) alpha = a.st[ALPHA];
@@ -210,6 +250,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
   double rvn[PD][RY];
+  [[maybe_unused]] double Hm = 0.0, H0 = 0.0, Hp = 0.0, rha[PD], rhb[PD];  // ALIGNED: the x-halo elements of the three planes, raw values in flight
+#pragma unroll
+  for (int u = 0; u < PD; ++u) rha[u] = rhb[u] = 0.0;
   double Rw0[NW], Rwp[NW];  // RAW: r of the owned rows on the planes z and z+1
 #pragma unroll
   for (int j = 0; j < NW; ++j) Rw0[j] = Rwp[j] = 0.0;
@@ -269,6 +312,14 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
             Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx] = c;
         }
       }
+      if constexpr (ALIGNED) {  // the x-halo elements of plane k, formed like the rows (a lane that fetched nothing holds 0)
+        double hc = rha[u];
+        if (FORM) {
+          const double di = s_dinv[htxy + tz9];
+          hc = have_old ? fma(beta, rhb[u], di * rha[u]) : di * rha[u];
+        }
+        Hp = hc;
+      }
     }
     double rv[RY];
     if (MODE == RR_RUPD) {  // residual values of the owned rows of plane z (fetched PD steps ago)
@@ -293,6 +344,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           for (int r = 0; r < NR; ++r) {
             ra[u][r] = rr_buf_load(bx, pb, (unsigned)off[r]);
             if (OLD) rb2[u][r] = rr_buf_load(bx2, pb, (unsigned)off[r]);
+          }
+          if constexpr (ALIGNED) {
+            rha[u] = rr_buf_load(bx, pb, hoff);
+            if (OLD) rhb[u] = rr_buf_load(bx2, pb, hoff);
           }
           if (GUESS) {
             const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
@@ -327,13 +382,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     double L0[NR], R0[NR], Rp[NR], Lm[NR];
 #pragma unroll
     for (int r = 0; r < NR - 1; ++r) {
-      L0[r] = from_left(C0[r]);
-      Lm[r] = from_left(Cm[r]);
+      L0[r] = ALIGNED ? from_left_h(C0[r], H0, r) : from_left(C0[r]);
+      Lm[r] = ALIGNED ? from_left_h(Cm[r], Hm, r) : from_left(Cm[r]);
     }
 #pragma unroll
     for (int r = 1; r < NR; ++r) {
-      R0[r] = from_right(C0[r]);
-      Rp[r] = from_right(Cp[r]);
+      R0[r] = ALIGNED ? from_right_h(C0[r], H0, 8 + r) : from_right(C0[r]);
+      Rp[r] = ALIGNED ? from_right_h(Cp[r], Hp, 8 + r) : from_right(Cp[r]);
     }
     double eL0[NE], eR0[NE], eRp[NE], eLm[NE];
     if (GUESS) {
@@ -464,6 +519,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     for (int r = 0; r < NR; ++r) {
       Cm[r] = C0[r];
       C0[r] = Cp[r];
+    }
+    if constexpr (ALIGNED) {
+      Hm = H0;
+      H0 = Hp;
     }
     if (GUESS) {
 #pragma unroll
@@ -605,7 +664,8 @@ RGeom make_geom(const beat_pde* pde, int z_lo, int z_hi, int part_off, int rows 
   g.part_off = part_off;
   g.ghost_lo_tz = pde->ghost_lo_tz;
   g.ghost_hi_tz = pde->ghost_hi_tz;
-  g.nsegx = (f.nx + SEG - 1) / SEG;
+  const int segw = (mode >= 0 && rr_aligned_mode(mode)) ? 64 : SEG;  // (x-nodes per wave: what the kernel instance of this mode assumes)
+  g.nsegx = (f.nx + segw - 1) / segw;
   g.nrb = (f.ny + RY - 1) / RY;
   const int nzr = std::max(0, z_hi - z_lo);
   g.nrg = (mode >= 0 && ((rr_by_rows_mask() >> mode) & 1)) ? (g.nrb + 3) / 4 : 0;

@@ -134,6 +134,86 @@ int launch_rows(beat_ctx* ctx, int policy, unsigned grid, v2d* x, int64_t n2, in
   return BEAT_OK;
 }
 
+// mode 5: the register-row kernels' ACCESS PATTERN without their arithmetic: a wave owns `segw` consecutive x-nodes of RY rows and
+// marches along z, loading RY + 2 rows of the source field per plane (one double per lane, the plane after next in flight while the
+// current one is summed) and storing RY rows of the destination.  segw = 62 with shift = -1 is what the kernels do (lanes 0 and 63
+// carry the x-halo: every wave's 512-byte row read starts 8 bytes before a multiple of 496); segw = 64 with shift = 0 reads and
+// writes whole aligned 512-byte pieces (and would need its x-halo from elsewhere).  What it answers: does the misaligned,
+// overlapping segment cost bandwidth by itself?
+template <int RY>
+__global__ __launch_bounds__(BEAT_BLOCK) void march_kernel(const double* __restrict__ src, double* __restrict__ dst, int nx, int ny, int nz,
+                                                           int segw, int shift, int zc, int total_waves, int halo) {
+  constexpr int NR = RY + 2;
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= total_waves) return;
+  const int nseg = (nx + segw - 1) / segw, nrb = (ny + RY - 1) / RY;
+  const int seg = w % nseg, rb = (w / nseg) % nrb, chunk = w / (nseg * nrb);
+  const int gx = seg * segw + shift + lane;
+  const int cx = min(max(gx, 0), nx - 1);
+  const bool out = gx >= 0 && gx < nx && lane + shift >= 0 && lane + shift < segw;
+  const int64_t plane = (int64_t)nx * ny;
+  int off[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) off[r] = min(max(rb * RY - 1 + r, 0), ny - 1) * nx + cx;
+  const int zb = chunk * zc, ze = min(zb + zc, nz);
+  double cur[NR], nxt[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) cur[r] = src[(int64_t)zb * plane + off[r]];
+  // halo = 1 (with aligned segments): ONE more load per plane in which lanes 0 .. NR-1 fetch the element left of the segment in rows
+  // 0 .. NR-1 and lanes 8 .. 8+NR-1 the element right of it; every other lane passes an out-of-range offset (fetches nothing)
+  const int hr = lane < 8 ? lane : lane - 8;
+  const bool hl = halo && ((lane < NR) || (lane >= 8 && lane < 8 + NR));
+  const int hx = lane < 8 ? seg * segw - 1 : seg * segw + segw;
+  const unsigned hoff = (hl && hx >= 0 && hx < nx) ? (unsigned)((min(max(rb * RY - 1 + hr, 0), ny - 1) * nx + hx) * 8) : 0x80000000u;
+  double hcur = 0.0, hsum = 0.0;
+  for (int z = zb; z < ze; ++z) {
+    const int zn = min(z + 1, nz - 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) nxt[r] = src[(int64_t)zn * plane + off[r]];
+    double hnxt = 0.0;
+    if (halo) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)zn * plane), 0, (int)(plane * 8), 0x00020000);
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      const v2i hv = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)hoff, 0, 0);
+      hnxt = __hiloint2double(hv.y, hv.x);
+    }
+    if (out) {
+#pragma unroll
+      for (int j = 0; j < RY; ++j) {
+        const int gy = rb * RY + j;
+        if (gy < ny) dst[(int64_t)z * plane + (int64_t)gy * nx + gx] = cur[j] + cur[j + 1] + cur[j + 2] + (lane == 0 ? hcur : 0.0);
+      }
+    }
+    hsum += hcur;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) cur[r] = nxt[r];
+    hcur = hnxt;
+  }
+  if (hsum == 1.2345e300) dst[0] = hsum;  // (keeps the halo loads alive)
+}
+
+int launch_march(beat_ctx* ctx, double* dev, int64_t n, int nx, int ry, int segw, int shift, int blocks, int halo) {
+  BEAT_REQUIRE(nx >= 64 && (segw == 62 || segw == 64) && (shift == 0 || shift == -1) && (ry == 2 || ry == 4), "bad march probe arguments");
+  const int64_t per_field = n / 2;
+  const int nz = (int)(per_field / ((int64_t)nx * nx));
+  BEAT_REQUIRE(nz >= 1 && (int64_t)nz * nx * nx == per_field, "the buffer holds two fields of nx x nx x nz doubles");
+  const int nseg = (nx + segw - 1) / segw, nrb = (nx + ry - 1) / ry;
+  const int64_t per_layer = ((int64_t)nseg * nrb + 3) / 4;
+  int nchunks = (int)std::max<int64_t>(1, ((blocks > 0 ? blocks : 4096) + per_layer - 1) / per_layer);
+  nchunks = std::min(nchunks, nz);
+  const int zc = (nz + nchunks - 1) / nchunks;
+  nchunks = (nz + zc - 1) / zc;
+  const int total_waves = nseg * nrb * nchunks;
+  const unsigned grid = (unsigned)((total_waves + 3) / 4);
+  if (ry == 4)
+    BEAT_KERNEL((march_kernel<4>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, (const double*)dev, dev + per_field, nx, nx, nz, segw, shift, zc, total_waves, halo);
+  else
+    BEAT_KERNEL((march_kernel<2>), dim3(grid), dim3(BEAT_BLOCK), 0, ctx->stream, (const double*)dev, dev + per_field, nx, nx, nz, segw, shift, zc, total_waves, halo);
+  BEAT_LAUNCH_CHECK();
+  return BEAT_OK;
+}
+
 }  // namespace
 
 extern "C" int beat_stream_probe(beat_ctx* ctx, double* dev, int64_t n, int mode, int policy, int unroll, int blocks,
@@ -143,6 +223,8 @@ extern "C" int beat_stream_probe(beat_ctx* ctx, double* dev, int64_t n, int mode
   BEAT_REQUIRE(blocks >= 0 && blocks <= (1 << 22), "blocks out of range");
   const int64_t n2 = n / 2;
   v2d* x = (v2d*)dev;
+  if (mode == 5)  // the register-row kernels' access pattern: rows = x-nodes per wave (62 | 64), unroll = rows per wave (2 | 4), ld = nx, policy bit 0 = the -1 lane shift, bit 1 = one more load per plane for the x-halo of an aligned segment
+    return launch_march(ctx, dev, n, (int)ld, unroll, rows, (policy & 1) ? -1 : 0, blocks, (policy & 2) ? 1 : 0);
   if (mode == 4) {
     BEAT_REQUIRE((ld & 1) == 0 && ld >= n, "even row stride >= n expected");
     const unsigned grid = blocks > 0 ? (unsigned)blocks : (unsigned)std::min<int64_t>((n2 + BEAT_BLOCK - 1) / BEAT_BLOCK, 1 << 22);
@@ -165,6 +247,6 @@ extern "C" int beat_stream_probe(beat_ctx* ctx, double* dev, int64_t n, int mode
     case 2: return launch_p<2>(ctx, policy, unroll, grid, x, n2, 0.0);  // (the caller owns the buffer's content)
     case 3: return launch_p<3>(ctx, policy, unroll, grid, x, n2 / 2, 1.0);  // first half -> second half
   }
-  beat_set_error("mode must be 0..4");
+  beat_set_error("mode must be 0..5");
   return BEAT_EINVAL;
 }
