@@ -116,7 +116,7 @@ __device__ __forceinline__ double rr_buf_load(const double* base, unsigned bytes
   return __hiloint2double(v.y, v.x);
 }
 
-// BEAT_RR_ALIGN = 1 (round 5): in PDOT and RUPD a wave owns 64 x-nodes that start on a multiple of 64 (whole aligned 512-byte pieces of
+// BEAT_RR_ALIGN = 1 (round 5): in PDOT and RUPD (and the two passes of the single-reduction iteration) a wave owns 64 x-nodes that start on a multiple of 64 (whole aligned 512-byte pieces of
 // a row) instead of 62 that start 8 bytes before a multiple of 496.  The access pattern alone -- six rows of a plane read, four written,
 // no arithmetic -- streams at 4.2 - 4.3 TB/s in the 62-node form and at 5.0 - 5.1 TB/s in the aligned form INCLUDING what it needs
 // instead of the two halo lanes (tools/march_probe.py, profiles/r05_march_probe.md): ONE more load per plane in which lanes 0 .. NR-1
@@ -139,7 +139,7 @@ __device__ __forceinline__ double from_right_h(double v, double h, int src_lane)
   return __hiloint2double(hi, lo);
 }
 // (the same condition on the host, where the geometry of a launch is made: make_geom)
-constexpr bool rr_aligned_mode(int mode) { return BEAT_RR_ALIGN == 1 && BEAT_RR_BUF != 0 && (mode == 0 || mode == 1); }
+constexpr bool rr_aligned_mode(int mode) { return BEAT_RR_ALIGN == 1 && BEAT_RR_BUF != 0 && (mode == 0 || mode == 1 || mode == 3 || mode == 4); }
 
 __device__ __forceinline__ int axis_type3(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -889,7 +889,7 @@ int beat_rr_udot_part(beat_pde* pde, double* dev_st, const double* dev_r, int pa
   a.partials = pde->ctx->d_partials;
   a.st = dev_st;
   const int lo = f.z_lo_phys ? 0 : 1, hi = f.nz - (f.z_hi_phys ? 0 : 1);
-  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0);
+  const RGeom gi = make_geom(pde, lo, std::max(lo, hi), 0, 0, RR_UDOT);
   if (part == 0) {
     launch_rr<RR_UDOT>(pde, gi, a);
     BEAT_LAUNCH_CHECK();
@@ -897,12 +897,12 @@ int beat_rr_udot_part(beat_pde* pde, double* dev_st, const double* dev_r, int pa
   }
   int off = gi.total_blocks > 0 ? grid_blocks(gi) : 0;
   if (!f.z_lo_phys) {
-    const RGeom gb = make_geom(pde, 0, 1, off);
+    const RGeom gb = make_geom(pde, 0, 1, off, 0, RR_UDOT);
     launch_rr<RR_UDOT>(pde, gb, a);
     off += grid_blocks(gb);
   }
   if (!f.z_hi_phys && (f.nz > 1 || f.z_lo_phys)) {
-    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off);
+    const RGeom gb = make_geom(pde, f.nz - 1, f.nz, off, 0, RR_UDOT);
     launch_rr<RR_UDOT>(pde, gb, a);
     off += grid_blocks(gb);
   }
@@ -921,7 +921,7 @@ int beat_rr_merged_next(beat_pde* pde, double* dev_st, int slot) {
 // r_new = r - st[ALPHA] A p_new (out of place).  The ghost planes of r (and of p_old) must be current.
 int beat_rr_prupd(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_old, double* dev_p_new,
                   double* dev_r_new) {
-  const RGeom g = make_geom(pde);
+  const RGeom g = make_geom(pde, 0, pde->g.nz, 0, 0, RR_PRUPD);
   RArgs a{};
   a.x = dev_r;
   a.x2 = dev_p_old;
