@@ -1,7 +1,8 @@
 // Constant-coefficient diffusion solve without a stored q = A p: "register-row" stencil kernels.
 //
-// The 15-point P1 stencil touches 7 rows of x (3 of the plane z, 2 of z+1, 2 of z-1).  A wave owns 62 consecutive
-// x-nodes (lanes 1..62; lanes 0 and 63 carry the x-halo) of RY = 4 consecutive rows and marches along z with the
+// The 15-point P1 stencil touches 7 rows of x (3 of the plane z, 2 of z+1, 2 of z-1).  A wave owns 64 consecutive x-nodes from
+// a multiple of 64 (the iteration's passes since round 5: the x-halo comes with one extra load per plane, see BEAT_RR_ALIGN; the
+// right-hand side keeps the original form: 62 nodes, lanes 0 and 63 carrying the x-halo) of RY = 4 consecutive rows and marches along z with the
 // 3 x 6 row values it needs held in registers: every row is loaded ONCE per wave (one coalesced 512 B request),
 // the x +- 1 neighbours come from the adjacent lanes by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1, no
 // LDS, no barriers), and the plane z+2 is in flight while plane z is computed.  The y-halo rows (6 rows loaded
@@ -26,7 +27,7 @@
 namespace {
 using namespace beat_pde_detail;
 
-constexpr int SEG = 62;  // x-nodes computed per wave and row (lanes 1..62)
+constexpr int SEG = 62;  // x-nodes computed per wave and row where lanes 0 and 63 carry the x-halo (the right-hand side; BEAT_RR_ALIGN=0)
 // rows computed per wave: template parameter RY (2 or 4; BEAT_RR_RY, default 4), NR = RY + 2 rows held per plane;
 // PD: planes fetched ahead of their use (BEAT_RR_PD)
 
