@@ -140,7 +140,12 @@ __device__ __forceinline__ double from_right_h(double v, double h, int src_lane)
   return __hiloint2double(hi, lo);
 }
 // (the same condition on the host, where the geometry of a launch is made: make_geom)
-constexpr bool rr_aligned_mode(int mode) { return BEAT_RR_ALIGN == 1 && BEAT_RR_BUF != 0 && (mode == 0 || mode == 1 || mode == 3 || mode == 4); }
+#ifndef BEAT_RR_ALIGN_RHS
+#define BEAT_RR_ALIGN_RHS 0  // 1: the right-hand side on aligned segments too (with raw-buffer loads and a halo element per window); measured, see profiles/r05_rr_resources.md
+#endif
+constexpr bool rr_aligned_mode(int mode) {
+  return BEAT_RR_ALIGN == 1 && BEAT_RR_BUF != 0 && (mode == 0 || mode == 1 || mode == 3 || mode == 4 || (mode == 2 && BEAT_RR_ALIGN_RHS == 1));
+}
 
 __device__ __forceinline__ int axis_type3(int i, int n, int lo_phys, int hi_phys) {
   if (n == 1 && lo_phys && hi_phys) return 1;  // collapsed axis: no coupling along it
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   constexpr bool OLD = MODE == RR_PDOT || MODE == RR_PRUPD;                      // ... with beta p_old, and stored
   constexpr bool RAW = MODE == RR_UDOT || MODE == RR_PRUPD;                      // r itself of the owned rows is kept too
   constexpr int NW = RAW ? RY : 1;
-  constexpr bool BUF = BEAT_RR_BUF == 1 || (BEAT_RR_BUF == 2 && MODE != RR_RHS);  // raw-buffer loads of the rows (see BEAT_RR_BUF)
+  constexpr bool BUF = BEAT_RR_BUF == 1 || (BEAT_RR_BUF == 2 && (MODE != RR_RHS || BEAT_RR_ALIGN_RHS == 1));  // raw-buffer loads of the rows (see BEAT_RR_BUF)
   constexpr bool ALIGNED = rr_aligned_mode(MODE);  // 64 aligned x-nodes per wave, the x-halo from one more load per plane (see BEAT_RR_ALIGN)
   static_assert(!ALIGNED || BUF, "aligned segments come with the raw-buffer loads");
   constexpr int SEGW = ALIGNED ? 64 : SEG;
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
   double Cm[NR], C0[NR], Cp[NR], ra[PD][NR], rb2[PD][NR];
   double rvn[PD][RY];
   [[maybe_unused]] double Hm = 0.0, H0 = 0.0, Hp = 0.0, rha[PD], rhb[PD];  // ALIGNED: the x-halo elements of the three planes, raw values in flight
+  [[maybe_unused]] double HEm = 0.0, HE0 = 0.0, HEp = 0.0;              // ... and of the second window (GUESS: x0 = v_ + e; rhb holds e's)
 #pragma unroll
   for (int u = 0; u < PD; ++u) rha[u] = rhb[u] = 0.0;
   double Rw0[NW], Rwp[NW];  // RAW: r of the owned rows on the planes z and z+1
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           hc = have_old ? fma(beta, rhb[u], di * rha[u]) : di * rha[u];
         }
         Hp = hc;
+        if (GUESS) HEp = hc + rhb[u];  // x0 = v_ + e on the halo elements
       }
     }
     double rv[RY];
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
           if constexpr (ALIGNED) {
             rha[u] = rr_buf_load(bx, pb, hoff);
             if (OLD) rhb[u] = rr_buf_load(bx2, pb, hoff);
+            if (GUESS) rhb[u] = rr_buf_load(X2 + (int64_t)cz * g.plane, pb, hoff);
           }
           if (GUESS) {
             const double* __restrict__ b1 = X2 + (int64_t)cz * g.plane;  // (e comes as X2: see the note on aliasing)
@@ -395,13 +403,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     if (GUESS) {
 #pragma unroll
       for (int r = 0; r < NE - 1; ++r) {
-        eL0[r] = from_left(E0[r]);
-        eLm[r] = from_left(Em[r]);
+        eL0[r] = ALIGNED ? from_left_h(E0[r], HE0, r) : from_left(E0[r]);
+        eLm[r] = ALIGNED ? from_left_h(Em[r], HEm, r) : from_left(Em[r]);
       }
 #pragma unroll
       for (int r = 1; r < NE; ++r) {
-        eR0[r] = from_right(E0[r]);
-        eRp[r] = from_right(Ep[r]);
+        eR0[r] = ALIGNED ? from_right_h(E0[r], HE0, 8 + r) : from_right(E0[r]);
+        eRp[r] = ALIGNED ? from_right_h(Ep[r], HEp, 8 + r) : from_right(Ep[r]);
       }
     }
     const int tz = axis_type3(z, g.nz, g.z_lo_phys, g.z_hi_phys);
@@ -524,6 +532,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
     if constexpr (ALIGNED) {
       Hm = H0;
       H0 = Hp;
+      if (GUESS) {
+        HEm = HE0;
+        HE0 = HEp;
+      }
     }
     if (GUESS) {
 #pragma unroll
