@@ -309,23 +309,24 @@ __global__ __launch_bounds__(BEAT_BLOCK) void stencil_kernel(Geom g, StencilArgs
 }
 
 // Sum `count` block partials of `nsum` quantities in a fixed order and store them at out[0..nsum).
-__global__ __launch_bounds__(BEAT_BLOCK) void reduce_partials_kernel(const double* __restrict__ partials,
-                                                                     int count, int nsum,
-                                                                     double* __restrict__ out,
-                                                                     const double* __restrict__ st,
-                                                                     double* __restrict__ counter) {
-  __shared__ double red[4];
-  if (st != nullptr && st[STOP] != 0.0) return;
-  if (counter != nullptr && threadIdx.x == 0) counter[0] += 1.0;  // one more executed residual update
-  for (int k = 0; k < nsum; ++k) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += BEAT_BLOCK) s += partials[(int64_t)k * BEAT_MAX_PARTIALS + i];
-    s = beat_block_sum(s, red);
-    if (threadIdx.x == 0) out[k] = s;
+// `then` (round 5: one launch instead of two behind a residual update / a right-hand side on a single slab; the same arithmetic in the
+// same order as the kernels it replaces): 1 = the scalar roll of the iteration (pcg_next_kernel: beta, iteration count, latch) on the
+// state `roll_st` the sums were just written into; 2 = the start of a solve (pcg_begin_kernel) with rtol / atol / max_it.
+__device__ __forceinline__ void beat_pcg_roll(double* st) {
+  st[BETA] = st[RZN] / st[RZ];
+  st[RZ] = st[RZN];
+  st[RR] = st[RRN];
+  st[ITERS] += 1.0;
+  const double tr = st[RTOL] * st[RTOL] * st[BB];
+  if (st[RR] <= st[TOL2]) {
+    st[STOP] = 1.0;
+    st[REASON] = st[RR] <= tr ? 2.0 : 3.0;
+  } else if (st[ITERS] >= st[MAXIT]) {
+    st[STOP] = 1.0;
+    st[REASON] = -3.0;
   }
 }
-
-__global__ void pcg_begin_kernel(double* st, double rtol, double atol, double max_it) {
+__device__ __forceinline__ void beat_pcg_begin(double* st, double rtol, double atol, double max_it) {
   const double bb = st[BB], rr = st[RR];
   const double tr = rtol * rtol * bb, ta = atol * atol;
   const double tol2 = tr > ta ? tr : ta;
@@ -341,21 +342,29 @@ __global__ void pcg_begin_kernel(double* st, double rtol, double atol, double ma
   st[STOP] = done ? 1.0 : 0.0;
   st[REASON] = done ? (rr <= tr ? 2.0 : 3.0) : 0.0;
 }
+__global__ __launch_bounds__(BEAT_BLOCK) void reduce_partials_kernel(const double* __restrict__ partials, int count, int nsum, double* out,
+                                                                     const double* st, double* counter, int then, double* roll_st,
+                                                                     double rtol, double atol, double max_it) {
+  __shared__ double red[4];
+  if (st != nullptr && st[STOP] != 0.0) return;
+  if (counter != nullptr && threadIdx.x == 0) counter[0] += 1.0;  // one more executed residual update
+  for (int k = 0; k < nsum; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += BEAT_BLOCK) s += partials[(int64_t)k * BEAT_MAX_PARTIALS + i];
+    s = beat_block_sum(s, red);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+  if (then != 0 && threadIdx.x == 0) {  // (the thread that wrote the sums: its own stores are ahead of these loads)
+    if (then == 1) beat_pcg_roll(roll_st);
+    else beat_pcg_begin(roll_st, rtol, atol, max_it);
+  }
+}
+
+__global__ void pcg_begin_kernel(double* st, double rtol, double atol, double max_it) { beat_pcg_begin(st, rtol, atol, max_it); }
 
 __global__ void pcg_next_kernel(double* st) {
   if (st[STOP] != 0.0) return;
-  st[BETA] = st[RZN] / st[RZ];
-  st[RZ] = st[RZN];
-  st[RR] = st[RRN];
-  st[ITERS] += 1.0;
-  const double tr = st[RTOL] * st[RTOL] * st[BB];
-  if (st[RR] <= st[TOL2]) {
-    st[STOP] = 1.0;
-    st[REASON] = st[RR] <= tr ? 2.0 : 3.0;
-  } else if (st[ITERS] >= st[MAXIT]) {
-    st[STOP] = 1.0;
-    st[REASON] = -3.0;
-  }
+  beat_pcg_roll(st);
 }
 
 // x += alpha p ; r -= alpha q ; partial sums of r.z (z = D^-1 r) and r.r.  Row-per-wave so the node
@@ -752,10 +761,20 @@ extern "C" int beat_pde_apply(beat_pde* pde, int which, const double* dev_x, dou
   return BEAT_OK;
 }
 
-int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter) {
-  BEAT_KERNEL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream,
-                     (const double*)pde->ctx->d_partials, count, nsum, out, st, counter);
+int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter, int then, double* roll_st,
+                           double rtol, double atol, int max_it) {
+  static const bool fuse = [] {  // BEAT_PCG_FUSE=0: the scalar step in a launch of its own, as before round 5 (A/B runs)
+    const char* e = std::getenv("BEAT_PCG_FUSE");
+    return !(e && e[0] == '0');
+  }();
+  BEAT_KERNEL(reduce_partials_kernel, dim3(1), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const double*)pde->ctx->d_partials, count, nsum, out, st,
+              counter, fuse ? then : 0, roll_st, rtol, atol, (double)max_it);
   BEAT_LAUNCH_CHECK();
+  if (then != 0 && !fuse) {
+    if (then == 1) BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, roll_st);
+    else BEAT_KERNEL(pcg_begin_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, roll_st, rtol, atol, (double)max_it);
+    BEAT_LAUNCH_CHECK();
+  }
   return BEAT_OK;
 }
 
@@ -1281,16 +1300,13 @@ static int solve_enqueue_iterations(beat_pde* pde, int count) {
       } else if ((rc = beat_pde_spmv_dot(pde, p_cur, q, st))) {
         return rc;
       }
-      if ((rc = beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
+      // (with the fused pass the scalar roll -- beta for the next pass, the latch, the iteration count -- runs in the launch that sums
+      // the residual update's partials; the x update, when the ring is full, reads the update count only and may follow it)
+      if ((rc = o.pdot ? beat_var_update_r(pde, st, r, q, slot, true) : beat_pde_cg_update_r(pde, st, r, q, slot))) return rc;
       if (slot == PR - 1) {
         if ((rc = beat_pde_x_flush_terms(pde, st, o.x, ring, fld, i + 1 - PR, 1, beat_guess_terms(pde, i + 1 - PR)))) return rc;
       }
-      if (o.pdot) {  // the scalar roll alone: beta for the next pass, the latch, the iteration count
-        BEAT_KERNEL(pcg_next_kernel, dim3(1), dim3(1), 0, pde->ctx->stream, st);
-        BEAT_LAUNCH_CHECK();
-      } else if ((rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) {
-        return rc;
-      }
+      if (!o.pdot && (rc = beat_pde_cg_next_oop(pde, st, r, p_cur, p_next))) return rc;
     }
   }
   o.launched += count;
@@ -1328,6 +1344,7 @@ int beat_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* cons
   double* st = pde->d_st;
   int rc;
   beat_guess_begin(pde);
+  pde->fuse_begin = beat_pde::FuseBegin{true, false, rtol, atol, max_it};
   if (o.kind == 0) {
     rc = beat_rr_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, st);
   } else if (beat_vtl_rhs_available(pde)) {  // two tile passes (b = B v_ + dt stim, r = b - A (v_ + e)); q is free until iteration 0
@@ -1335,8 +1352,10 @@ int beat_solve_begin(beat_pde* pde, const double* dev_v_prev, const double* cons
   } else {  // the gather kernel: the guess increment e next to v_
     rc = beat_var_rhs(pde, dev_v_prev, host_dev_stim_w, host_stim_amp, n_stim, dev_x, r, ring, st, pde->guess.use_e ? pde->guess.e : nullptr);
   }
+  const bool begun = pde->fuse_begin.done;  // (the right-hand side's reduction has run the start of the solve in its own launch)
+  pde->fuse_begin.on = false;
   if (rc) return rc;
-  if ((rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
+  if (!begun && (rc = beat_pde_cg_begin(pde, st, rtol, atol, max_it))) return rc;
   if ((rc = solve_enqueue_iterations(pde, std::min(beat_pde_first_chunk(pde), max_it)))) return rc;
   BEAT_HIP_CHECK(hipMemcpyAsync(pde->h_st, st, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
   BEAT_HIP_CHECK(hipEventRecord(pde->ev_st, ctx->stream));

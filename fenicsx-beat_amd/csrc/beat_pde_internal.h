@@ -69,6 +69,13 @@ struct beat_pde {
     bool rr = false, merged = false, vpdot = false;
     int limit = 0;
   } open;
+  // set by beat_solve_begin around its right-hand side: the start of the solve (pcg_begin_kernel's step) is to run in the launch that
+  // sums the right-hand side's partials; `done` says a right-hand side took it up
+  struct FuseBegin {
+    bool on = false, done = false;
+    double rtol = 0.0, atol = 0.0;
+    int max_it = 0;
+  } fuse_begin;
   double* h_st = nullptr;       // pinned copy of the scalar state of the open solve (16 doubles)
   hipEvent_t ev_st = nullptr;   // recorded behind that copy
   beat_ksp_info last_info{};    // of the last solve that was finished
@@ -148,7 +155,9 @@ inline int beat_pde_first_chunk(const beat_pde* pde) {
 }
 
 // fixed-order sum of `count` block partials of `nsum` quantities into out[0..nsum) (beat_pde.hip)
-int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter = nullptr);
+// then / roll_st / rtol / atol / max_it: the scalar step that follows the sums, in the same launch (1: the iteration's roll, 2: the start of a solve)
+int beat_pde_launch_reduce(beat_pde* pde, int count, int nsum, double* out, const double* st, double* counter = nullptr, int then = 0,
+                           double* roll_st = nullptr, double rtol = 0.0, double atol = 0.0, int max_it = 0);
 
 // per-node-coefficient variants of the stage operations (beat_pde_var.hip); same contracts as the beat_pde_*
 // entry points that dispatch to them
@@ -160,7 +169,7 @@ int beat_var_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* h
                  int part = -1);  // decomposed grids: 0 = the planes that need no ghost data, 1 = the boundary planes + the sums; -1: all
 int beat_var_spmv_dot(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st);
 int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, double* dev_st, int part);
-int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot);
+int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot, bool roll = false);
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next);
 int beat_var_flush(beat_pde* pde, const double* dev_st, double* dev_x, const double* dev_ring0, int64_t field_stride,
                    int ring_base, int only_if_full, const beat_pde_detail::GuessTerms& gt);

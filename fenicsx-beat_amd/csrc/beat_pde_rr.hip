@@ -790,6 +790,11 @@ int beat_rr_rhs(beat_pde* pde, const double* dev_v_prev, const double* const* ho
   if (part < 0) {
     const int nb = launch(make_geom(pde, 0, f.nz, 0, rows, RR_RHS));
     BEAT_LAUNCH_CHECK();
+    if (pde->fuse_begin.on) {  // a single-slab solve: its start in the same launch (beat_solve_begin)
+      pde->fuse_begin.done = true;
+      return beat_pde_launch_reduce(pde, nb, 3, dev_st, nullptr, nullptr, 2, dev_st, pde->fuse_begin.rtol, pde->fuse_begin.atol,
+                                    pde->fuse_begin.max_it);
+    }
     return beat_pde_launch_reduce(pde, nb, 3, dev_st, nullptr);
   }
   // in two parts on a decomposed grid (as beat_rr_pdot_part): the planes whose stencil needs no ghost plane of v_ / e
@@ -874,9 +879,8 @@ int beat_rr_rupd(beat_pde* pde, double* dev_st, const double* dev_r, double* dev
   a.slot = slot;
   launch_rr<RR_RUPD>(pde, g, a);
   BEAT_LAUNCH_CHECK();
-  const int rc = beat_pde_launch_reduce(pde, grid_blocks(g), 2, dev_st + RZN, dev_st, dev_st + NUPD);
-  if (rc || !roll) return rc;
-  return beat_rr_next(pde, dev_st);
+  // (with `roll` the scalar step -- beta, iteration count, latch: rr_next_kernel's -- runs in the reduction's launch)
+  return beat_pde_launch_reduce(pde, grid_blocks(g), 2, dev_st + RZN, dev_st, dev_st + NUPD, roll ? 1 : 0, dev_st);
 }
 
 // ---- single-reduction iteration (decomposed solve, BEAT_DIST_MERGED=1) --------------------------------------------

@@ -1043,13 +1043,13 @@ int beat_var_spmv_dot_part(beat_pde* pde, const double* dev_p, double* dev_q, do
   return beat_pde_launch_reduce(pde, off, 1, dev_st + PQ, dev_st);
 }
 
-int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot) {
+int beat_var_update_r(beat_pde* pde, double* dev_st, double* dev_r, const double* dev_q, int slot, bool roll) {
   const unsigned grid = var_vec_grid(pde);
   BEAT_KERNEL(var_update_r_kernel, dim3(grid), dim3(BEAT_BLOCK), 0, pde->ctx->stream, (const int*)pde->v_seg, (const unsigned long long*)pde->v_segmask,
                      (int)pde->h_seg.size(), pde->n, (const double*)dev_st, dev_r, dev_q, (const double*)pde->v_dinv,
                      pde->ctx->d_partials, pde->d_alphas, slot);
   BEAT_LAUNCH_CHECK();
-  return beat_pde_launch_reduce(pde, (int)grid, 2, dev_st + RZN, dev_st, dev_st + NUPD);
+  return beat_pde_launch_reduce(pde, (int)grid, 2, dev_st + RZN, dev_st, dev_st + NUPD, roll ? 1 : 0, dev_st);  // (roll: the scalar step in the same launch)
 }
 
 int beat_var_pupdate_oop(beat_pde* pde, double* dev_st, const double* dev_r, const double* dev_p_cur, double* dev_p_next) {

@@ -881,7 +881,14 @@ static int vtl_launch(beat_pde* pde, const double* dev_p, double* dev_q, double*
   }
   BEAT_LAUNCH_CHECK();
   if (!reduce) return BEAT_OK;
-  if (res) return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr);  // (b.b from the BV pass, r.z and r.r from this one)
+  if (res) {  // (b.b from the BV pass, r.z and r.r from this one; on a single-slab solve its start in the same launch)
+    if (pde->fuse_begin.on) {
+      pde->fuse_begin.done = true;
+      return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr, nullptr, 2, rhs->red_out, pde->fuse_begin.rtol, pde->fuse_begin.atol,
+                                    pde->fuse_begin.max_it);
+    }
+    return beat_pde_launch_reduce(pde, count, 3, rhs->red_out, nullptr);
+  }
   return beat_pde_launch_reduce(pde, reduce_count ? reduce_count : count, 1, dev_st + PQ, dev_st);  // one partial per tile, in list order
 }
 
