@@ -179,6 +179,19 @@ class BaseModel:
     def ksp(self, value) -> None:
         self._ksp = value
 
+    @property
+    def status(self) -> Status:
+        """``Status.NOT_CONVERGING`` once a linear solve has run out of iterations (base_model.py:23-30).  Like ``ksp``, reading it
+        finishes a solve the fused step left open: the record of the LAST step is in it too."""
+        ops = getattr(self, "_ops", None)
+        if ops is not None and getattr(ops, "open_x", None) is not None:
+            ops.solve_finish()
+        return self._status
+
+    @status.setter
+    def status(self, value: Status) -> None:
+        self._status = value
+
     @abc.abstractmethod
     def _setup_state_space(self) -> None: ...
 

@@ -194,7 +194,8 @@ class OdeFileModel(DeviceModel):
         self._sym = dict(y=[ysym[s] for s in names], p=[psym[p] for p in params], t=tsym, dt=dtsym, repl=repl,
                          f=red[: len(names)], J=red[len(names):])
         self._numpy_fn = None
-        self._registered = None
+        self._registered = None   # the library's id, once the compiled kernel has passed _self_check
+        self._library_id = None   # the id beat_ode_model_register gave (the source is handed over once per process)
         self.source = self._cxx(stem)
         self.key = f"{self.cxx_name}"
 
@@ -304,7 +305,9 @@ class OdeFileModel(DeviceModel):
                 "  template <class P> __host__ __device__ static Derived derive(const P&) { return Derived{0.0}; }\n"
                 "  template <class IO, class P>\n"
                 "  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived&, const FastMath& fm, double t, double dt) {\n"
-                + ("    const auto fexp = [&fm](double x) { return fm.exp(fmin(fmax(x, -745.0), 709.0)); };\n" if self.fast_exp else "")
+                + ("    // (FastMath::exp takes |x| < ~700; outside: what libm / NumPy give -- NaN stays NaN, overflow is inf, underflow 0)\n"
+                   "    const auto fexp = [&fm](double x) { const double e = fm.exp(fmin(fmax(x, -745.0), 709.0));\n"
+                   "                                        return x != x ? x : (x > 709.782712893384 ? HUGE_VAL : e); };\n" if self.fast_exp else "")
                 + "    const auto beat_sel = [](bool c, double a, double b) { return c ? a : b; };\n"
                 + "\n".join(loads + pl + lines + body) + "\n  }\n};\n")
 
@@ -349,14 +352,22 @@ class OdeFileModel(DeviceModel):
         from .. import _hip
 
         if self._registered is None:
-            lib = _hip.load()
-            mid = C.c_int(-1)
-            _hip.check(lib.beat_ode_model_register(self.cxx_name.encode(), self.source.encode(), self.num_states,
-                                                   max(self.num_parameters, 1), self.state_index(self.v_name) if self.v_name else 0,
-                                                   C.byref(mid)))
-            self._registered = int(mid.value)
-            self.model_id = self._registered
-            self._self_check()
+            if self._library_id is None:
+                lib = _hip.load()
+                mid = C.c_int(-1)
+                _hip.check(lib.beat_ode_model_register(self.cxx_name.encode(), self.source.encode(), self.num_states,
+                                                       max(self.num_parameters, 1), self.state_index(self.v_name) if self.v_name else 0,
+                                                       C.byref(mid)))
+                self._library_id = int(mid.value)
+            # the id is handed out only once the compiled kernel has passed its check: a caller that catches the check's error and
+            # asks again gets the check again, not the id of a kernel known to be wrong
+            self.model_id = self._library_id  # (the check itself steps the model through DeviceModel.__call__)
+            try:
+                self._self_check()
+            except BaseException:
+                self.model_id = -1
+                raise
+            self._registered = self._library_id
         return self._registered
 
     def _sample_states(self, n: int, seed: int = 0) -> np.ndarray:
@@ -393,7 +404,8 @@ class OdeFileModel(DeviceModel):
             with np.errstate(all="ignore"):
                 ref = self.numpy_step(y, t, p, dt)
             ok = np.isfinite(ref)
-            err = np.abs(dev - ref)[ok] / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)[ok]
+            with np.errstate(all="ignore"):  # (inf - inf where both sides overflow: masked by `ok`)
+                err = np.abs(dev - ref)[ok] / np.maximum(np.maximum(np.abs(ref), np.abs(y)), 1e-12)[ok]
             # (1e-6 of the value: a sample far from the model's physiological range may sit where exp(J dt) - 1 cancels, and the two
             # exp()s differ in the last bit -- 3e-8 seen; a miscompiled kernel is wrong by O(1) on thousands of values)
             if not np.isfinite(dev[ok]).all() or (err.size and err.max() > 1e-6):

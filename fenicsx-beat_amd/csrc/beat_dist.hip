@@ -1040,8 +1040,8 @@ int beat_dist_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int
     o.on = false;
     return rc;
   }
+  if (needed_more && h[STOP] == 0.0) *needed_more = true;  // unlatched at the first look: the launch behind the solve did nothing (beat_solve_end)
   while (!(h[STOP] != 0.0 || o.launched >= o.limit)) {
-    if (needed_more) *needed_more = true;
     if ((rc = dist_enqueue_iterations(pde, std::min(2, o.limit - o.launched)))) {
       o.on = false;
       return rc;

@@ -151,9 +151,15 @@ void init_locked(JitState& s) {
     h = fnv(cc, h);
     if (::stat(cc.c_str(), &st) == 0) h = fnv(std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime), h);
   }
+#ifdef BEAT_BUILD_EXTRA_FLAGS
+  // the EXTRA flags this library was built with (csrc/Makefile: variant libraries for A/B runs, -DBEAT_ODE_NT=3 ...): an instance
+  // compiled at run time is built with them too and cached under its own key
+  s.extra = BEAT_BUILD_EXTRA_FLAGS;
+  h = fnv(s.extra, h);
+#endif
   if (const char* x = std::getenv("BEAT_JIT_EXTRA_FLAGS")) {  // experiments with the compiler (tools/jit_flags_ab.sh): part of the cache key
-    s.extra = x;
-    h = fnv(s.extra, h);
+    s.extra += std::string(s.extra.empty() ? "" : " ") + x;
+    h = fnv(x, h);
   }
   char buf[32];
   std::snprintf(buf, sizeof buf, "%016llx", h);

@@ -1382,8 +1382,10 @@ int beat_solve_end(beat_pde* pde, int defer_flush, beat_ksp_info* info, int* hos
   const int PR = pde->ring;
   int rc;
   BEAT_HIP_CHECK(hipEventSynchronize(pde->ev_st));
+  // (a launch enqueued behind this solve saw the state the host sees at this first look: unlatched, it did nothing -- also when no
+  // further iteration may be enqueued (max_it = 0: pcg_begin does not latch and the loop below is skipped))
+  if (needed_more && h[STOP] == 0.0) *needed_more = true;
   while (!(h[STOP] != 0.0 || o.launched >= o.max_it)) {
-    if (needed_more) *needed_more = true;
     if ((rc = solve_enqueue_iterations(pde, std::min(2, o.max_it - o.launched)))) {
       o.on = false;
       return rc;

@@ -763,7 +763,19 @@ int beat_var_form_A(beat_pde* pde) {
   if (pde->v_B == nullptr && beat_vtl_rhs_wanted(pde)) {
     // the rows of B for the right-hand side on the tiles: 120 B/node more (401^3 box: 7.7 GB); without the memory the gather
     // kernel keeps building the right-hand side from the rows of K
-    if (hipMalloc(&pde->v_B, sizeof(double) * 15 * (size_t)pde->v_ld) != hipSuccess) {
+    // Only with room to spare: the rows of B nearly double the operator's memory, and what the caller allocates
+    // AFTER this point -- the cell model's state array (up to 52 rows: 416 B/node), the PCG's work fields (r, q, z + a ring of 12:
+    // 120 B/node), the guess history (32 B/node) -- must still fit, or a grid that ran with the gather kernel would fail later for
+    // the sake of 0.3 ms per step.  Taken when, after the 120 B/node of B, BEAT_VTL_RHS_RESERVE_B_PER_NODE (default 700) bytes per
+    // node + 1 GiB stay free; BEAT_VTL_RHS_RESERVE_B_PER_NODE=0 restores "whenever the allocation itself succeeds".
+    size_t free_b = 0, total_b = 0;
+    const char* rs = std::getenv("BEAT_VTL_RHS_RESERVE_B_PER_NODE");
+    const double reserve_per_node = rs != nullptr ? std::atof(rs) : 700.0;
+    const size_t rows_b = sizeof(double) * 15 * (size_t)pde->v_ld;
+    const size_t reserve_b = reserve_per_node > 0.0 ? (size_t)(reserve_per_node * (double)pde->v_ld) + ((size_t)1 << 30) : 0;
+    const bool roomy = reserve_b == 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= rows_b + reserve_b);
+    if (!roomy) (void)hipGetLastError();
+    if (!roomy || hipMalloc(&pde->v_B, rows_b) != hipSuccess) {
       (void)hipGetLastError();
       pde->v_B = nullptr;
     }

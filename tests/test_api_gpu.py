@@ -1563,6 +1563,62 @@ def test_step_leaves_its_solve_open_and_the_next_ionic_launch_goes_behind_it(cas
     assert b["last"] == a["last"] and c["extra"][0] == ("ksp", a["its"][11]) and a["status"] == b["status"]
 
 
+@pytest.mark.parametrize("max_it", [0, 2])
+def test_open_solve_that_may_not_iterate_still_takes_its_ionic_steps_and_reports_the_last_step(max_it, monkeypatch):
+    """ADVICE round 5, two findings on the open solve.  (1) ``ksp_max_it = 0``: pcg_begin does not latch and no iteration is
+    enqueued, so the ionic launch behind the solve saw an unlatched solve and did nothing -- and beat_solve_end, whose loop is
+    skipped with nothing left to enqueue, used to report "no more iterations were needed": every ionic step after the first was
+    silently dropped.  Now the first look at the latch decides, and the step is launched again with the host's count.  With
+    x0 = v_ (guess order 0) and no iteration the diffusion changes nothing, so n steps must equal n steps of the cell model alone,
+    bit for bit; with ``ksp_max_it = 2`` and an unreachable tolerance the values must be the waiting loop's.  (2) ``pde.status``
+    of the LAST step: it is a property that finishes the open solve, as ``pde.ksp`` is."""
+    import beat
+    from beat import grid as g
+    from beat.base_model import Status
+    from beat.models import tp06
+
+    def build(lazy):
+        monkeypatch.setenv("BEAT_LAZY_KSP", "1" if lazy else "0")
+        geo = beat.geometry.get_3D_slab_geometry(comm=g.COMM_WORLD, Lx=8.0, Ly=4.0, Lz=2.0, dx=0.2)  # 9 471 nodes: not the one-launch solve
+        mesh = geo.mesh
+        time = g.Constant(mesh, 0.0)
+        cond = beat.conductivities.default_conductivities("Niederer")
+        M = beat.conductivities.define_conductivity_tensor(f0=geo.f0, **cond)
+        pde = beat.MonodomainModel(time=time, mesh=mesh, M=M, C_m=0.01,
+                                   params={"petsc_options": {"ksp_rtol": 1e-14, "ksp_max_it": max_it, "ksp_guess_order": 0}})
+        ic = tp06.init_state_values()
+        init = np.repeat(ic[:, None], pde.state.x.array.shape[0], axis=1)
+        x = mesh.geometry.x
+        init[tp06.state_index("V")] += 60.0 * np.exp(-((x[:, 0] - 4.0) ** 2 + (x[:, 1] - 2.0) ** 2) / 2.0)  # something to diffuse
+        ode = beat.odesolver.DolfinODESolver(
+            v_ode=g.Function(g.functionspace(mesh, ("Lagrange", 1))), v_pde=pde.state, fun=tp06.generalized_rush_larsen,
+            init_states=init, parameters=tp06.init_parameter_values(stim_amplitude=0.0), num_states=19, v_index=tp06.state_index("V"))
+        return beat.MonodomainSplittingSolver(pde=pde, ode=ode), init
+
+    dt, nsteps = 0.05, 6
+    a, init = build(True)
+    opens = 0
+    for i in range(nsteps):
+        a.step((i * dt, (i + 1) * dt))
+        opens += int(a.pde._ops.open_x is not None)
+    assert opens == nsteps  # every solve was left open: the path under test
+    assert a.pde.status == Status.NOT_CONVERGING  # (read BEFORE anything else finishes the last solve)
+    assert a.pde._ops.open_x is None and a.pde.ksp.converged_reason < 0 and a.pde.ksp.iterations == max_it
+    b, _ = build(False)
+    for i in range(nsteps):
+        b.step((i * dt, (i + 1) * dt))
+    assert b.pde.status == Status.NOT_CONVERGING
+    np.testing.assert_array_equal(a.ode.values, b.ode.values)
+    if max_it == 0:  # no iteration from x0 = v_: the cell model alone
+        y = init.copy()
+        p = tp06.init_parameter_values(stim_amplitude=0.0)
+        for i in range(nsteps):
+            y = tp06.generalized_rush_larsen(states=y, t=i * dt, parameters=p, dt=dt)
+        # (the fused step and the model's __call__ are two instances of one kernel template; with the step's fma contraction they
+        # may differ in the last bit -- a dropped step differs by 1e-3)
+        np.testing.assert_allclose(a.ode.values, y, rtol=1e-11, atol=1e-300)
+
+
 def test_batched_solve_of_a_big_grid_stops_at_the_first_solve_that_does_not_converge():
     """the library's step loop used to run on after a solve had hit ksp_max_it -- up to a thousand steps on the bad
     iterate before Python saw it.  Now the batch ends AT that solve: with ``ksp_error_if_not_converged`` the exception comes with

@@ -322,3 +322,63 @@ def test_self_checks_catch_a_miscompiled_generated_kernel(hip_ctx, monkeypatch):
         model = from_ode(BIG, name="big_checked_o1")
         with pytest.raises(RuntimeError, match="differs from the NumPy evaluation"):
             model.register()
+        # a caller that catches the error and asks again gets the check again, not the id of the wrong kernel
+        assert model._registered is None and model.model_id == -1
+        with pytest.raises(RuntimeError, match="differs from the NumPy evaluation"):
+            model.register()
+
+
+def test_registration_hands_out_no_id_until_the_self_check_has_passed(hip_ctx, monkeypatch):
+    """``register()`` used to set the id before ``_self_check()`` ran, so a second call after a failed check returned
+    the id of a kernel known to be wrong.  With a check made to fail once: no id, the check runs again at the next call, and only
+    then is the model usable; the source went to the library once."""
+    from beat.models import from_ode
+    from beat.models.ode_file import OdeFileModel
+
+    model = from_ode(SMALL, name="small_retry")
+    calls = []
+    real = OdeFileModel._self_check
+
+    def flaky(self):
+        calls.append(self.model_id)
+        if len(calls) == 1:
+            raise RuntimeError("made to fail")
+        return real(self)
+
+    monkeypatch.setattr(OdeFileModel, "_self_check", flaky)
+    with pytest.raises(RuntimeError, match="made to fail"):
+        model.register()
+    assert model._registered is None and model.model_id == -1 and model._library_id is not None
+    first = model._library_id
+    mid = model.register()
+    assert mid == first == model.model_id and len(calls) == 2 and calls[0] == calls[1] == first
+    assert model.register() == mid and len(calls) == 2  # verified: not checked a third time
+    y = _states(model, 256, 1)
+    p = model.init_parameter_values()
+    np.testing.assert_allclose(model(states=y, t=0.0, parameters=p, dt=0.02), model.numpy_step(y, 0.0, p, 0.02), rtol=1e-10, atol=1e-300)
+
+
+def test_generated_exp_keeps_nan_and_overflow(hip_ctx, tmp_path):
+    """the generated step's ``exp`` clamps its argument into the range the table-driven routine takes
+    (fmin(fmax(x, -745), 709)) -- which turned a NaN argument into exp(-745) ~ 0 and an overflowing one into 8e307, where NumPy
+    (the reference's way of evaluating ``fun``) gives NaN and inf: a cell that has diverged must stay visibly diverged.  Forward
+    Euler on  dx/dt = exp(a x) - 1  with x in {finite, > 709.78, < -745, NaN, +inf, -inf}."""
+    from beat.models import from_ode
+
+    f = tmp_path / "expo.ode"
+    f.write_text('parameters("P", a = 1.0)\nstates("S", x = 0.5, y = 0.25)\nexpressions("S")\n'
+                 'dx_dt = exp(a*x) - 1\ndy_dt = -y*exp(-a*x)\n')
+    for scheme in ("forward_euler", "generalized_rush_larsen"):
+        model = from_ode(f, name=f"expo_{scheme}", scheme=scheme, v_name="x")
+        x = np.array([0.5, -3.0, 709.0, 709.9, 800.0, -744.0, -800.0, np.nan, np.inf, -np.inf, 1e-3, 30.0])
+        y = np.vstack([x, np.full_like(x, 0.25)])
+        p = model.init_parameter_values()
+        dev = model(states=y, t=0.0, parameters=p, dt=0.01)
+        with np.errstate(all="ignore"):
+            ref = model.numpy_step(y, 0.0, p, 0.01)
+        np.testing.assert_array_equal(np.isnan(dev), np.isnan(ref))
+        np.testing.assert_array_equal(np.isposinf(dev), np.isposinf(ref))
+        np.testing.assert_array_equal(np.isneginf(dev), np.isneginf(ref))
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(dev[ok], ref[ok], rtol=1e-10, atol=1e-300)
+        assert np.isnan(dev[0, 7]) and (scheme != "forward_euler" or np.isposinf(dev[0, 4]))
