@@ -93,6 +93,20 @@ __device__ __forceinline__ PendingNow beat_pending_now(const PendingV& p, int nu
   return o;
 }
 
+// Cell types / parameter classes in ONE launch (MARKED): a byte per node selects one of up to BEAT_MAX_CLASSES
+// parameter sets (uniform parameters + their Derived constants, a table in device memory laid out as TableEntry);
+// 255 = the node belongs to no class and is not advanced.  A wavefront whose nodes all carry the same marker -- the rule
+// when the classes are layers or regions -- reads its set with scalar loads exactly as the uniform kernel reads the
+// kernel-argument segment; a wavefront that straddles a boundary runs the step once per class present, lanes masked.
+// Replaces one launch per marker + scatter / gather of the potential (src/beat/odesolver.py:306-310 loops the markers).
+struct MarkedArgs {
+  const unsigned char* markers;  // (n) or nullptr
+  const double* table;           // classes x (NP + sizeof(Derived) / 8) doubles
+  int stride;                    // doubles per table entry
+  const int* vmap;               // (n) node of the PDE grid each entry of the state array belongs to, or nullptr (identity)
+  double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
+};
+
 // Layout of ode_step_kernel's kernel-argument segment up to the uniform parameters (all members 8-byte aligned): the
 // tile loop re-reads them through an opaque copy of the segment pointer (see the kernel).
 template <class Model>
@@ -106,21 +120,8 @@ struct OdeStepKernArgHead {
   double t, dt;
   int v_index;
   double* v_copy;
-  PendingV pend;  // (MarkedArgs follows)
-};
-
-// Cell types / parameter classes in ONE launch (MARKED): a byte per node selects one of up to BEAT_MAX_CLASSES
-// parameter sets (uniform parameters + their Derived constants, a table in device memory laid out as TableEntry);
-// 255 = the node belongs to no class and is not advanced.  A wavefront whose nodes all carry the same marker -- the rule
-// when the classes are layers or regions -- reads its set with scalar loads exactly as the uniform kernel reads the
-// kernel-argument segment; a wavefront that straddles a boundary runs the step once per class present, lanes masked.
-// Replaces one launch per marker + scatter / gather of the potential (src/beat/odesolver.py:306-310 loops the markers).
-struct MarkedArgs {
-  const unsigned char* markers;  // (n) or nullptr
-  const double* table;           // classes x (NP + sizeof(Derived) / 8) doubles
-  int stride;                    // doubles per table entry
-  const int* vmap;               // (n) node of the PDE grid each entry of the state array belongs to, or nullptr (identity)
-  double* vfield;                // the PDE's field the potential is read from / mirrored to when vmap is given
+  PendingV pend;
+  MarkedArgs mk;  // (SparseRows follows)
 };
 
 // Per-node parameters of which only a few ROWS vary (a smooth gradient in one conductance: src/beat/odesolver.py:67-79 hands
@@ -176,6 +177,27 @@ __device__ __forceinline__ D mix_derived(const D& du, const D& dl) {
   return d;
 }
 
+// An IO type with somewhere to park values (ionic_models.h: beat_stash / beat_unstash): slot j of this lane at lds[j * BEAT_BLOCK]
+// (consecutive lanes 8 bytes apart: no bank conflicts), a region no other lane touches -- no barrier
+template <class Base>
+struct StashIO : Base {
+  double* lds;
+  __device__ __forceinline__ void stash(int slot, double v) const { lds[slot * BEAT_BLOCK] = v; }
+  __device__ __forceinline__ double unstash(int slot) const { return lds[slot * BEAT_BLOCK]; }
+};
+template <class Model, class = void>
+struct beat_stash_slots : std::integral_constant<int, 0> {};
+template <class Model>
+struct beat_stash_slots<Model, std::void_t<decltype(Model::STASH_SLOTS)>> : std::integral_constant<int, Model::STASH_SLOTS> {};
+
+// 1: the kernel's scalar arguments are re-read through the opaque kernel-argument pointer in every tile (see the tile loop)
+#ifndef BEAT_KARGS_PER_TILE
+#define BEAT_KARGS_PER_TILE 1
+#endif
+// 1: the thread's index within the block is recomputed per tile (see the tile loop)
+#ifndef BEAT_TID_PER_TILE
+#define BEAT_TID_PER_TILE 1
+#endif
 #if BEAT_PENDING_READ == 3
 #define BEAT_PENDING_TILE_COUNT __builtin_amdgcn_readfirstlane(*(volatile int*)&s_pend[1])
 #else
@@ -186,12 +208,16 @@ template <class Model, bool PER_NODE, bool PEND, bool MARKED = false, bool SPARS
 __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::WAVES_PER_NODE : Model::WAVES) void ode_step_kernel(
     double* __restrict__ states, int64_t n, int64_t ld, ParamPack<Model::NP> prm,
     typename Model::Derived drv, const double* __restrict__ ppn, int64_t pld, double t, double dt,
-    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk, SparseRows sp) {
+    int v_index, double* __restrict__ v_copy, PendingV pend, MarkedArgs mk_arg, SparseRows sp) {
   __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
   etab[threadIdx.x] = kExp2Tab[threadIdx.x];
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
+  // values a step parks in LDS across the stretch that does not use them (StashIO): the uniform-parameter instances only
+  constexpr int NSTASH = (!PER_NODE && !MARKED) ? beat_stash_slots<Model>::value : 0;
+  __shared__ double stash_lds[NSTASH > 0 ? NSTASH * BEAT_BLOCK : 1];
+  __shared__ int cls_jn[MARKED ? BEAT_BLOCK : 1];  // class kernel: the mapped node of each lane (see NodeIOWithV)
 #if BEAT_PENDING_READ == 3
   __shared__ int s_pend[2];  // [0] the solve ahead has latched (or there is none), [1] its update count (-1: the host's count)
   if (PEND && threadIdx.x == 0) {
@@ -215,8 +241,41 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   // a block walks over several tiles of 256 nodes (stride gridDim.x) and pays its launch and the table set-up once:
   // at 512^3, 24 576 blocks of ~21 tiles each measured 10.5-10.6 ms against 10.9-11.3 for one block per tile on the
   // same box (768 blocks, i.e. exactly the resident number: 11.5; 3 072: 10.7; 196 608: 10.9)
-  for (int64_t tile = blockIdx.x; tile * BEAT_BLOCK < n; tile += gridDim.x) {
-  const int64_t i = tile * BEAT_BLOCK + threadIdx.x;
+  // (the wave's number in the block lives in an SGPR; the lane number is taken from mbcnt per tile, opaque: whatever is derived from
+  // threadIdx.x -- its 64-bit extension, its byte offset -- would otherwise be kept in VGPRs across the tile loop, three of the 128
+  // that four waves per SIMD have: see BEAT_TID_PER_TILE below)
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int64_t tile = blockIdx.x;; tile += gridDim.x) {
+  // the kernel-argument segment through a pointer the optimiser cannot see through (see below, at the uniform parameters);
+  // the pending-update arguments are read through it too: kept in SGPRs across the tile loop they were spilled as well
+  typedef const __attribute__((address_space(4))) char* KArgPtr;
+  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const PendingV& pendl = *(const PendingV*)(ka + offsetof(OdeStepKernArgHead<Model>, pend));
+#if BEAT_KARGS_PER_TILE
+  // (round 6) the scalar arguments as well, under their own names: as kernel parameters they are loaded once and stay in SGPRs
+  // across the tile loop -- with the class arguments the last spilled SGPRs of the class kernels, i.e. a VGPR of lanes to hold them
+  const OdeStepKernArgHead<Model>& hd = *(const OdeStepKernArgHead<Model>*)ka;
+  double* __restrict__ const states = hd.states;
+  const int64_t n = hd.n, ld = hd.ld;
+  const double* __restrict__ const ppn = hd.ppn;
+  const int64_t pld = hd.pld;
+  const double t = hd.t, dt = hd.dt;
+  const int v_index = hd.v_index;
+  double* __restrict__ const v_copy = hd.v_copy;
+  (void)ppn; (void)pld; (void)v_index; (void)v_copy;
+#endif
+  if (tile * BEAT_BLOCK >= n) break;
+#if BEAT_TID_PER_TILE
+  int lane_now = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane_now));
+  const int tid = (wave_in_block << 6) + lane_now;
+#else
+  const int tid = (int)threadIdx.x;
+#endif
+  const int64_t tile0 = tile * BEAT_BLOCK;  // the tile's first node: uniform
+  const unsigned lane_off = (unsigned)tid * 8u;  // the lane's node within the tile, in BYTES (see NodeIO)
+  const int64_t i = tile0 + tid;
   if (i >= n) break;
   // The row stride, opaque per tile: the base address of each of the NS state rows (states + k ld) is uniform and
   // loop-invariant, so the compiler forms all of them ahead of the tile loop, runs out of SGPRs and parks them in VGPR
@@ -224,13 +283,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   // instructions per ToR-ORd node, 58 of 1928 per TP06 node).  Recomputed where used they cost SALU cycles only.
   int64_t ldl = ld;
   asm volatile("" : "+s"(ldl));
-  // the kernel-argument segment through a pointer the optimiser cannot see through (see below, at the uniform parameters);
-  // the pending-update arguments are read through it too: kept in SGPRs across the tile loop they were spilled as well
-  typedef const __attribute__((address_space(4))) char* KArgPtr;
-  KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
-  const PendingV& pendl = *(const PendingV*)(ka + offsetof(OdeStepKernArgHead<Model>, pend));
   if (MARKED) {
+    // (the class arguments through the opaque kernel-argument pointer too, read where they are used: as kernel parameters they
+    // stayed in SGPRs across the tile loop and were spilled to VGPR lanes -- one more VGPR, the one the class kernel was over)
+    const MarkedArgs& mk = *(const MarkedArgs*)(ka + offsetof(OdeStepKernArgHead<Model>, mk));
     const int m_lane = mk.markers[i];
     // where the node's potential lives: row V_INDEX of the state array, or -- when the array holds only the nodes that
     // carry a cell model (a voxelised wall inside its box) -- the PDE's field at node vmap[i]: the kernel then reads the
@@ -238,15 +294,27 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     // the potential the per-marker route spends two launches per marker on
     const int64_t jn = mk.vmap != nullptr ? (int64_t)mk.vmap[i] : i;
     double* const vptr = mk.vmap != nullptr ? mk.vfield + jn : states + (int64_t)Model::V_INDEX * ld + i;
+    // (round 6) Nothing of this block stays in VGPRs across Model::step but the class byte: the mapped node's index waits in LDS
+    // for the one store that needs it (the potential's mirror), the unmapped mirror is addressed like the rows (uniform base +
+    // lane offset), and nodes outside every class are dealt with BEFORE the passes -- the pointer and the updated potential used to
+    // live through the whole step, 4 of the 7 VGPRs the class kernel lacked for a third wave per SIMD (175 against 168).
+    if (mk.vmap != nullptr) cls_jn[tid] = (int)jn;
     struct NodeIOWithV {
-      double* __restrict__ base;
-      int64_t ld, i;
-      double* vout;  // the field entry that mirrors the potential (or nullptr)
+      double* __restrict__ base;  // the tile's first node in row 0 (uniform)
+      int64_t ld;
+      unsigned i;    // the lane's BYTE offset within the tile (see NodeIO)
+      double* vbase;  // mirror of the potential: the PDE's field (mapped: entry *jn_slot) or v_copy at the tile (entry = lane), or nullptr
+      const int* jn_slot;  // LDS: the block's array (uniform; the lane's entry is found from `i`); nullptr: not mapped
       double v;
-      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : base[(int64_t)k * ld + i]; }
+      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : *beat_at(beat_row(base, k, ld), i); }
       __device__ __forceinline__ void store(int k, double x) const {
-        base[(int64_t)k * ld + i] = x;
-        if (k == Model::V_INDEX && vout != nullptr) *vout = x;
+        *beat_at(beat_row(base, k, ld), i) = x;
+        if (k == Model::V_INDEX && vbase != nullptr) {
+          if (jn_slot != nullptr)
+            vbase[*(const int*)((const char*)jn_slot + (i >> 1))] = x;  // entry tid = byte offset / 8
+          else
+            *beat_at(vbase, i) = x;
+        }
       }
     };
     // 254: a padding entry (the compact layout keeps each class in its own run of whole tiles, so that a wavefront
@@ -281,6 +349,11 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
           if (j < now.count) v_now = fma(pa[j], pp[j], v_now);
       }
     }
+    // a node outside every class still takes part in the diffusion: its potential gets the pending update
+    if (PEND && m_lane == 255) {
+      *vptr = v_now;
+      if (mk.vmap != nullptr) states[(int64_t)Model::V_INDEX * ld + i] = v_now;
+    }
     unsigned long long todo = __ballot(m_lane < 254);
     while (todo) {
       const int m = __builtin_amdgcn_readlane(m_lane, __ffsll((long long)todo) - 1);  // wave-uniform
@@ -294,15 +367,11 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       // (node index and potential are made opaque per pass: otherwise the address of every state row and everything
       // that depends on the potential alone is hoisted out of this loop and kept in registers, +38 VGPRs and scratch)
       asm volatile("" : "+s"(ldl));
-      NodeIOWithV iol{states, ldl, i, mk.vmap != nullptr ? vptr : (v_copy != nullptr ? v_copy + i : nullptr), v_now};
+      NodeIOWithV iol{states + tile0, ldl, lane_off, mk.vmap != nullptr ? mk.vfield : (v_copy != nullptr ? v_copy + tile0 : nullptr),
+                      mk.vmap != nullptr ? cls_jn : nullptr, v_now};
       asm volatile("" : "+v"(iol.i), "+v"(iol.v));
       if (m_lane == m) Model::step(iol, p_c, d_c, fm, t, dt);
       todo &= ~__ballot(m_lane == m);
-    }
-    // a node outside every class still takes part in the diffusion: its potential gets the pending update
-    if (PEND && m_lane == 255) {
-      *vptr = v_now;
-      if (mk.vmap != nullptr) states[(int64_t)Model::V_INDEX * ld + i] = v_now;
     }
     continue;
   }
@@ -315,26 +384,31 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       *(const typename Model::Derived*)(ka + offsetof(OdeStepKernArgHead<Model>, drv));
   if (PEND) {
     // all loads issued together (they overlap with the state loads that follow)
-    const PendingNow now = beat_pending_now(pendl, BEAT_PENDING_TILE_COUNT);
-    NodeIOPending<Model::V_INDEX> io{states, ldl, i, v_copy, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
+    // (every field addressed as its tile's first node -- uniform, SGPRs -- plus the lane's 32-bit offset: see NodeIO)
+    PendingNow now = beat_pending_now(pendl, BEAT_PENDING_TILE_COUNT);
+    NodeIOPending<Model::V_INDEX> io{states + tile0, ldl, lane_off, v_copy != nullptr ? v_copy + tile0 : nullptr, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-      io.pp[j] = j < now.count ? __builtin_nontemporal_load(pendl.ring + (int64_t)j * pendl.fld + i) : 0.0;
+      io.pp[j] = j < now.count ? __builtin_nontemporal_load(beat_at(pendl.ring + ((int64_t)j * pendl.fld + tile0), lane_off)) : 0.0;
       io.pa[j] = j < now.count ? pendl.alphas[j] : 0.0;
     }
     if (now.gt.d != nullptr) {
+      now.gt.d += tile0;
+      now.gt.e += tile0;
+      if (now.gt.dp[0] != nullptr) now.gt.dp[0] += tile0;
+      if (now.gt.dp[1] != nullptr) now.gt.dp[1] += tile0;
       io.gt = now.gt;
-      io.ge = beat_pde_detail::beat_guess_needs_e(now.gt) ? __builtin_nontemporal_load(now.gt.e + i) : 0.0;
-      io.gd = beat_pde_detail::beat_guess_needs_d(now.gt) ? __builtin_nontemporal_load(now.gt.d + i) : 0.0;
-      io.gp0 = beat_pde_detail::beat_guess_needs_dp(now.gt, 0) ? __builtin_nontemporal_load(now.gt.dp[0] + i) : 0.0;
-      io.gp1 = beat_pde_detail::beat_guess_needs_dp(now.gt, 1) ? __builtin_nontemporal_load(now.gt.dp[1] + i) : 0.0;
+      io.ge = beat_pde_detail::beat_guess_needs_e(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.e, lane_off)) : 0.0;
+      io.gd = beat_pde_detail::beat_guess_needs_d(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.d, lane_off)) : 0.0;
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(now.gt, 0) ? __builtin_nontemporal_load(beat_at(now.gt.dp[0], lane_off)) : 0.0;
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(now.gt, 1) ? __builtin_nontemporal_load(beat_at(now.gt.dp[1], lane_off)) : 0.0;
     }
     if constexpr (PER_NODE && SPARSE && CT::count > 0) {
       // (row j of ppn belongs to the j-th index of the pack: the launch checks sp.idx against the instance)
       MixedParams<CT> mp;
       mp.u = p_uni;
 #pragma unroll
-      for (int j = 0; j < CT::count; ++j) mp.v[j] = ppn[(int64_t)j * pld + i];
+      for (int j = 0; j < CT::count; ++j) mp.v[j] = *beat_at(beat_row(ppn + tile0, j, pld), lane_off);
       if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
         Model::step(io, mp, d_uni, fm, t, dt);
       } else {
@@ -357,7 +431,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_SPARSE_ROWS_RT; ++j) {
           if (j < sp.count) {
-            const double vj = ppn[(int64_t)j * pld + i];
+            const double vj = *beat_at(beat_row(ppn + tile0, j, pld), lane_off);
             // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
             // hoisted out of the tile loop, held in SGPR pairs and spilled)
             int ij = sp.idx[j];
@@ -368,23 +442,26 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = *beat_at(beat_row(ppn + tile0, k, pld), lane_off);
       }
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
+    } else if constexpr (NSTASH > 0) {
+      const StashIO<NodeIOPending<Model::V_INDEX>> sio{io, stash_lds + tid};
+      Model::step(sio, p_uni, d_uni, fm, t, dt);
     } else {
       Model::step(io, p_uni, d_uni, fm, t, dt);
     }
   } else {
     // (the mirror of row v_index -- any row here, unlike in the pending-update form -- is written after the step from
     // the row itself: a store-time test "k == v_index" for each of the NS rows is NS uniform conditions kept, and spilled)
-    const NodeIO io{states, ldl, i, nullptr, -1};
+    const NodeIO io{states + tile0, ldl, lane_off, nullptr, -1};
     if constexpr (PER_NODE && SPARSE && CT::count > 0) {
       // (row j of ppn belongs to the j-th index of the pack: the launch checks sp.idx against the instance)
       MixedParams<CT> mp;
       mp.u = p_uni;
 #pragma unroll
-      for (int j = 0; j < CT::count; ++j) mp.v[j] = ppn[(int64_t)j * pld + i];
+      for (int j = 0; j < CT::count; ++j) mp.v[j] = *beat_at(beat_row(ppn + tile0, j, pld), lane_off);
       if constexpr (DM0 == 0 && DM1 == 0) {  // the varying parameters enter no derived constant: the uniform set where it lies
         Model::step(io, mp, d_uni, fm, t, dt);
       } else {
@@ -407,7 +484,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_SPARSE_ROWS_RT; ++j) {
           if (j < sp.count) {
-            const double vj = ppn[(int64_t)j * pld + i];
+            const double vj = *beat_at(beat_row(ppn + tile0, j, pld), lane_off);
             // (the row's index opaque per tile: the NP comparisons with it are loop invariants otherwise -- 4 NP lane masks
             // hoisted out of the tile loop, held in SGPR pairs and spilled)
             int ij = sp.idx[j];
@@ -418,7 +495,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < Model::NP; ++k) pl[k] = ppn[(int64_t)k * pld + i];
+        for (int k = 0; k < Model::NP; ++k) pl[k] = *beat_at(beat_row(ppn + tile0, k, pld), lane_off);
       }
       const typename Model::Derived dl = Model::derive(pl);
       Model::step(io, pl, dl, fm, t, dt);
@@ -454,7 +531,12 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       const ProbeIO pio{states, ldl, i, (int64_t)threadIdx.x};
       Model::step(pio, p_uni, d_uni, fm, t, dt);
 #else
-      Model::step(io, p_uni, d_uni, fm, t, dt);
+      if constexpr (NSTASH > 0) {
+        const StashIO<NodeIO> sio{io, stash_lds + tid};
+        Model::step(sio, p_uni, d_uni, fm, t, dt);
+      } else {
+        Model::step(io, p_uni, d_uni, fm, t, dt);
+      }
 #endif
     }
     if (v_copy != nullptr) v_copy[i] = states[(int64_t)v_index * ldl + i];
@@ -501,7 +583,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
   // through RegIO with ROCm 7.2; no model in the library uses it any more (the hand-organised ToR-ORd kernel has no
   // spills), tests/test_golden_gpu.py::test_run_kernel_equals_repeated_steps guards every model.
   const RegIO rio{y};
-  const NodeIO gio{states, ld, i, nullptr, -1};
+  const NodeIO gio{states + (int64_t)blockIdx.x * BEAT_BLOCK, ld, threadIdx.x * 8u, nullptr, -1};
   int64_t row = 0;
   for (int beat = 0; beat < nbeats; ++beat) {
     for (int64_t j = 0; j < nsteps; ++j) {

@@ -13,6 +13,8 @@
 #pragma once
 
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
 #include "beat_common.h"
 
@@ -335,15 +337,50 @@ __device__ __forceinline__ void beat_row_store(double* p, double v) {
 #endif
 }
 
+// Addressing (round 6): `base` points at the first node of the wave's TILE in row 0 (wave-uniform: it lives in SGPRs, and so
+// does base + k ld for every row), `i` is the lane's node within the tile as an UNSIGNED 32-bit number: address = uniform 64-bit
+// base + zero-extended 32-bit lane offset, the form global_load / global_store take with the base in an SGPR pair and ONE offset
+// VGPR shared by every row.  With the node's 64-bit index in `i` (rounds 1 - 5) each row's address was a VGPR pair of its own
+// (v_lshl_add_u64 per row), kept from the row's load to its store: 38 of the TP06 step's 134 VGPRs, 90 of ToR-ORd's 227.
+// (the offset in BYTES, formed in 32-bit arithmetic: `base + zext(lane)` scales the 64-bit extension by 8, which the instruction
+// selector cannot prove to fit the 32-bit offset register)
+#ifndef BEAT_AT_OPAQUE
+#define BEAT_AT_OPAQUE 1
+#endif
+// base + k ld with the stride opaque per access (BEAT_ROW_OPAQUE): the row's base is then formed on the scalar unit where the access
+// is (s_mul + s_add, a handful of otherwise idle SALU cycles) instead of being kept in an SGPR pair from the row's load to its
+// store -- 19 (TP06) to 52 (ToR-ORd + Land) pairs of the ~100 SGPRs a wave has, spilled to VGPR lanes beyond that
+#ifndef BEAT_ROW_OPAQUE
+#define BEAT_ROW_OPAQUE 1
+#endif
+template <class T>
+__device__ __forceinline__ T* beat_row(T* base, int k, int64_t ld) {
+#if defined(__AMDGCN__) && BEAT_ROW_OPAQUE
+  asm volatile("" : "+s"(ld));
+#endif
+  return base + (int64_t)k * ld;
+}
+template <class T>
+__device__ __forceinline__ T* beat_at(T* uniform_base, unsigned byte_off) {
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type Byte;
+#if defined(__AMDGCN__) && BEAT_AT_OPAQUE
+  // (a copy of the offset the optimiser cannot see through, per access: otherwise ONE 64-bit extension of the offset is formed at
+  // the top of the tile, outside the blocks of the accesses, and instruction selection -- block by block -- no longer sees
+  // "uniform base + zext(32-bit offset)", the form that goes into the instruction's own address operands)
+  asm volatile("" : "+v"(byte_off));
+#endif
+  return (T*)((Byte*)uniform_base + byte_off);
+}
 struct NodeIO {
   double* __restrict__ base;
-  int64_t ld, i;
-  double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown), may be null
+  int64_t ld;
+  unsigned i;  // BYTE offset of the lane's node within the tile
+  double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown; offset like `base`), may be null
   int v_index;
-  __device__ __forceinline__ double load(int k) const { return beat_row_load(base + (int64_t)k * ld + i); }
+  __device__ __forceinline__ double load(int k) const { return beat_row_load(beat_at(beat_row(base, k, ld), i)); }
   __device__ __forceinline__ void store(int k, double v) const {
-    beat_row_store(base + (int64_t)k * ld + i, v);
-    if (v_copy != nullptr && k == v_index) v_copy[i] = v;
+    beat_row_store(beat_at(beat_row(base, k, ld), i), v);
+    if (v_copy != nullptr && k == v_index) *beat_at(v_copy, i) = v;
   }
 };
 
@@ -355,15 +392,16 @@ constexpr int BEAT_MAX_PENDING = 6;  // = default ring size of the deferred-x PC
 constexpr int BEAT_MAX_PENDING_CLASS = 12;  // the class kernel consumes the pending directions ahead of its passes: the long ring (PRING_MAX)
 template <int VIDX>
 struct NodeIOPending {
-  double* __restrict__ base;
-  int64_t ld, i;
+  double* __restrict__ base;  // (tile base and 32-bit lane offset: see NodeIO)
+  int64_t ld;
+  unsigned i;  // BYTE offset
   double* __restrict__ v_copy;
   int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
   double ge, gd, gp0, gp1;          // what the fields e, d, dp[0], dp[1] held at this node (when gt.d != nullptr; read up front)
   beat_pde_detail::GuessTerms gt;   // where the step's diffusion increment is recorded and the next guess prepared
   __device__ __forceinline__ double load(int k) const {
-    double x = beat_row_load(base + (int64_t)k * ld + i);
+    double x = beat_row_load(beat_at(beat_row(base, k, ld), i));
     if (k == VIDX) {
       if (gt.d != nullptr) {  // same expressions and order as x_flush_kernel's guess branch
         double inc = gt.accumulate ? 0.0 : ge;
@@ -372,7 +410,7 @@ struct NodeIOPending {
           if (j < npend) inc = fma(pa[j], pp[j], inc);
         // (recorded here, where the increment is formed: doing it with the potential's own store near the end of the
         // step keeps five more values alive through the step and measured no faster)
-        beat_pde_detail::beat_guess_record(gt, gt.d + i, gt.e + i, inc, gd, gp0, gp1, ge);
+        beat_pde_detail::beat_guess_record(gt, beat_at(gt.d, i), beat_at(gt.e, i), inc, gd, gp0, gp1, ge);
         return x + inc;
       }
 #pragma unroll
@@ -382,8 +420,8 @@ struct NodeIOPending {
     return x;
   }
   __device__ __forceinline__ void store(int k, double v) const {
-    beat_row_store(base + (int64_t)k * ld + i, v);
-    if (k == VIDX && v_copy != nullptr) v_copy[i] = v;
+    beat_row_store(beat_at(beat_row(base, k, ld), i), v);
+    if (k == VIDX && v_copy != nullptr) *beat_at(v_copy, i) = v;
   }
 };
 
@@ -394,6 +432,27 @@ struct RegIO {
   __device__ __forceinline__ double load(int k) const { return y[k]; }
   __device__ __forceinline__ void store(int k, double v) const { y[k] = v; }
 };
+
+// Parking a value in LDS across the part of a step that does not use it (an IO type that has somewhere to park it offers
+// stash / unstash: StashIO in beat_ode_kernel.h; every other IO type keeps the value where it is).  The TP06 step holds 19
+// loaded states, nine shared exponentials and five conductances while its twelve gate blocks run: at four waves per SIMD (128
+// VGPRs) the register allocator spilled 28 B per lane to scratch -- memory operations that also queue on the in-order vector-memory
+// counter behind the gate stores.  LDS reads and writes count on lgkmcnt and cost 64 B per node and value of LDS traffic.
+template <class IO, class = void>
+struct beat_has_stash : std::false_type {};
+template <class IO>
+struct beat_has_stash<IO, std::void_t<decltype(std::declval<const IO&>().stash(0, 0.0))>> : std::true_type {};
+template <class IO>
+__device__ __forceinline__ void beat_stash(const IO& io, int slot, double v) {
+  if constexpr (beat_has_stash<IO>::value) io.stash(slot, v);
+}
+template <class IO>
+__device__ __forceinline__ double beat_unstash(const IO& io, int slot, double kept) {
+  if constexpr (beat_has_stash<IO>::value)
+    return io.unstash(slot);
+  else
+    return kept;
+}
 
 // ------------------------------------------------------------------------------------------------
 // v' = -a s, s' = b v, forward Euler  (tests/test_odesolver.py:11-17)
@@ -499,8 +558,15 @@ struct Tp06Grl1 {
   static constexpr int NS = 19, NP = 53, V_INDEX = 17;
   static constexpr bool ACCESSOR_PARAMS = true;  // derive / step take any p indexable by parameter number (beat_ode_jit.hip)
   static constexpr bool REGISTER_LOOP = true;
-  static constexpr int WAVES = BEAT_ODE_WAVES;
+#ifndef BEAT_TP06_WAVES
+#define BEAT_TP06_WAVES BEAT_ODE_WAVES
+#endif
+#ifndef BEAT_TP06_STASH
+#define BEAT_TP06_STASH 0
+#endif
+  static constexpr int WAVES = BEAT_TP06_WAVES;
   static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
+  static constexpr int STASH_SLOTS = BEAT_TP06_STASH;  // values parked in LDS while the gate blocks run (beat_stash)
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
     P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,
@@ -631,8 +697,15 @@ struct Tp06Grl1 {
     // once per tile and wave) -- 12 more VGPRs through the gate section, which the three-wave budget has.  512^3, same
     // box, runs in pairs: 10.34-10.43 against 10.50-10.55 ms.  (Loading V after the gates, so that the two stores a
     // pending update makes at V's load precede no other load, added nothing to that: 10.34-10.39.)
-    const double vCai = io.load(Ca_i), vCaSR = io.load(Ca_SR), vCass = io.load(Ca_ss), vNai = io.load(Na_i),
-                 vKi = io.load(K_i), vR = io.load(R_prime);
+    const double vCai0 = io.load(Ca_i), vCaSR0 = io.load(Ca_SR), vCass0 = io.load(Ca_ss), vNai0 = io.load(Na_i),
+                 vKi0 = io.load(K_i), vR0 = io.load(R_prime);
+    // parked in LDS while the gate blocks run (see beat_stash): the ones needed last first
+    if (STASH_SLOTS >= 1) beat_stash(io, 0, vR0);
+    if (STASH_SLOTS >= 2) beat_stash(io, 1, vCaSR0);
+    if (STASH_SLOTS >= 3) beat_stash(io, 2, vKi0);
+    if (STASH_SLOTS >= 4) beat_stash(io, 3, vNai0);
+    if (STASH_SLOTS >= 5) beat_stash(io, 4, vCai0);
+    if (STASH_SLOTS >= 6) beat_stash(io, 5, vCass0);
 
     // ---- shared exponentials of V ----------------------------------------------------------------------
     const double E20 = fm.exp(0.05 * v), E7 = fm.exp(v * (1.0 / 7.0));
@@ -727,6 +800,7 @@ struct Tp06Grl1 {
     }
     BEAT_FENCE();
 
+    const double vCass = STASH_SLOTS >= 6 ? beat_unstash(io, 5, vCass0) : vCass0;
     {  // fCass (.ode:261-264): depends on Ca_ss only
       const double c2 = 1.0 + (vCass * 20.0) * (vCass * 20.0);                // 1 + (Ca_ss/0.05)^2
       double rc2, rt;
@@ -735,6 +809,9 @@ struct Tp06Grl1 {
     }
 
     // ---- reversal potentials ------------------------------------------------------------------------
+    const double vKi = STASH_SLOTS >= 3 ? beat_unstash(io, 2, vKi0) : vKi0;
+    const double vNai = STASH_SLOTS >= 4 ? beat_unstash(io, 3, vNai0) : vNai0;
+    const double vCai = STASH_SLOTS >= 5 ? beat_unstash(io, 4, vCai0) : vCai0;
     double rNai, rKi, rCai, rKs;
     rcp4(vNai, vKi, vCai, vKi + p[P_kna] * vNai, rNai, rKi, rCai, rKs);
     const double E_Na = q.RTF * fm.log(p[Na_o] * rNai);
@@ -850,6 +927,8 @@ struct Tp06Grl1 {
     BEAT_FENCE();
 
     // ---- calcium dynamics (.ode:298-316) -----------------------------------------------------------------------------
+    const double vR = STASH_SLOTS >= 1 ? beat_unstash(io, 0, vR0) : vR0;
+    const double vCaSR = STASH_SLOTS >= 2 ? beat_unstash(io, 1, vCaSR0) : vCaSR0;
     const double qup = q.Kup2 * rCai * rCai;
     double rup, rbc, rCaSR, rbsr, rbss;
     rcp3(1.0 + qup, vCai + p[K_buf_c], vCaSR, rup, rbc, rCaSR);
