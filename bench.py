@@ -990,6 +990,9 @@ def main():
                 "pcg_iterations_per_step": k_avg,
                 "guess_order": args.guess_order,
                 "guess_order_used": (float(np.mean(run["guess_orders"])) if run["guess_orders"] else None),
+                # where the state array lies decides how fast its rows stream: StateArray allocates a few candidates, times the
+                # library's streaming probe of the ionic kernels' pattern on each and keeps the best (beat/_device.py; GB/s)
+                "state_placement": getattr(states, "placement", None),
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
                 "v_min": vmin,

@@ -134,8 +134,65 @@ class StateArray:
             skew = 544 if (self.ld * 8) % 4096 == 0 and self.n >= 65536 else 0
         self.ld += int(skew) // 32 * 32
         self.base = self.plane  # leading ghost plane of row 0
-        self.buf = ctx.zeros(self.base + self.S * self.ld + 32)
+        self.placement = None  # what _place_buffer found (large arrays)
+        self.buf = self._place_buffer(self.base + self.S * self.ld + 32)
         self.rows = self.buf[self.base : self.base + self.S * self.ld].view(self.S, self.ld)[:, : self.n]
+
+    # Round 6: WHERE the driver puts a large state array decides how fast its rows stream.  The S row streams of the ionic kernels
+    # (every row read at one node index, written back) ran at 5.1 - 6.3 TB/s on 19-row arrays allocated one after another in ONE
+    # process (tools/place_probe3.py, profiles/r06_placement.md: the rate belongs to the allocation -- measured again later it is
+    # the same --, the first large allocation of a process was the slowest every time), and consecutive bench processes alternated
+    # between two levels of the 512^3 step ~0.4 ms apart that rounds 3 - 5 chased inside the kernel.  So a large array is allocated
+    # up to BEAT_STATE_PLACE (default 3; 0 / 1: off) times, each candidate is timed with the library's own streaming probe of that
+    # very pattern (beat_stream_probe mode 4: a few launches, ~10 ms each at 20 GB), the best one is kept and the others go back to
+    # the driver.  Only when the device has room for the candidates side by side; what was found is in ``self.placement``.
+    def _place_buffer(self, numel: int):
+        ctx = self.ctx
+        torch = ctx.torch
+        tries = int(os.environ.get("BEAT_STATE_PLACE", "3"))
+        nbytes = 8 * int(numel)
+        if tries <= 1 or nbytes < (1 << 30):
+            return ctx.zeros(numel)
+        rows = max(r for r in (1, 4, 8, 19, 45) if r <= self.S)  # (the probe's instances)
+        lib = ctx.lib
+
+        def rate(buf) -> float:
+            ptr = C.c_void_p(buf.data_ptr() + 8 * self.base)
+            times = []
+            for it in range(4):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(ctx.stream)
+                _hip.check(lib.beat_stream_probe(ctx.handle, ptr, self.n & ~1, 4, 3, 1, 0, rows, self.ld))
+                b.record(ctx.stream)
+                b.synchronize()
+                if it:  # (the first launch loads the kernel)
+                    times.append(a.elapsed_time(b))
+            return 2.0 * rows * (self.n & ~1) * 8 / (sorted(times)[len(times) // 2] * 1e6)  # GB/s (zeros x 1.0 stay zeros)
+
+        cands, rates = [], []
+        for _ in range(tries):
+            free_b, _total = torch.cuda.mem_get_info(ctx.device)
+            if cands and free_b < 2 * nbytes:  # keep room for what the caller allocates next
+                break
+            try:
+                buf = ctx.zeros(numel)
+            except RuntimeError:  # out of memory with the candidates held: what we have is what we choose from
+                if not cands:
+                    raise
+                break
+            cands.append(buf)
+            try:
+                rates.append(rate(buf))
+            except _hip.BeatHipError:  # a layout the probe does not take (odd plane: rows not 16-byte aligned): no selection
+                self.placement = None
+                return cands[0]
+        best = max(range(len(cands)), key=lambda j: rates[j])
+        buf = cands[best]
+        self.placement = {"candidates": [round(r, 1) for r in rates], "chosen": best, "rows_probed": rows, "unit": "GB/s"}
+        if len(cands) > 1:
+            del cands
+            torch.cuda.empty_cache()  # the losers go back to the driver, not into torch's cache (the next allocation would get one)
+        return buf
 
     @property
     def ptr(self) -> C.c_void_p:

@@ -68,9 +68,16 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 // blocks of an ionic launch over n nodes
 static unsigned ode_grid(int64_t n) {
   unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
+  // Round 6: ONE BLOCK PER TILE is the default.  Rounds 2 - 5 capped the launch at 24 576 blocks walking ~21 tiles each: at three
+  // waves per SIMD a block's set-up (4 KB of tables into LDS, a barrier) was worth amortising (10.5 - 10.6 against 10.9 - 11.3 ms at
+  // 512^3).  At four waves per SIMD (TP06, 118 VGPRs) / three (ToR-ORd) the other blocks of the CU cover it, and blocks handed out
+  // in order by the dispatcher keep the launch's accesses in one moving window of the state rows -- what the streaming probe shows
+  // for one workgroup per chunk (profiles/r05_streaming.md): TP06 512^3 in one process on the same memory 8.70 -> 8.49 - 8.54 ms
+  // (16 384 blocks: 8.75, 32 768: 8.65, 8 192: 8.98), class kernel 8.87 -> 8.57, ToR-ORd 256^3 2.49 -> 2.44; the 512^3 step 13.33 -
+  // 13.57 -> 13.04 - 13.27 ms, process by process (profiles/r06_ode_addressing.md).  BEAT_ODE_GRID=<blocks> caps the launch again.
   static const int grid_cap = [] {  // blocks per launch (BEAT_ODE_GRID; 0: one block per tile)
     const char* e = std::getenv("BEAT_ODE_GRID");
-    return e ? std::atoi(e) : 24576;
+    return e ? std::atoi(e) : 0;
   }();
   static const bool balance = [] {  // BEAT_ODE_BALANCE=0: plain cap (A/B runs)
     const char* e = std::getenv("BEAT_ODE_BALANCE");

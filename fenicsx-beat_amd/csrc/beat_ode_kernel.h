@@ -274,7 +274,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   const int tid = (int)threadIdx.x;
 #endif
   const int64_t tile0 = tile * BEAT_BLOCK;  // the tile's first node: uniform
-  const unsigned lane_off = (unsigned)tid * 8u;  // the lane's node within the tile, in BYTES (see NodeIO)
+  unsigned lane_off = (unsigned)tid * 8u;  // the lane's node within the tile, in BYTES (see NodeIO; not const: beat_at)
   const int64_t i = tile0 + tid;
   if (i >= n) break;
   // The row stride, opaque per tile: the base address of each of the NS state rows (states + k ld) is uniform and
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     struct NodeIOWithV {
       double* __restrict__ base;  // the tile's first node in row 0 (uniform)
       int64_t ld;
-      unsigned i;    // the lane's BYTE offset within the tile (see NodeIO)
+      mutable unsigned i;    // the lane's BYTE offset within the tile (see NodeIO)
       double* vbase;  // mirror of the potential: the PDE's field (mapped: entry *jn_slot) or v_copy at the tile (entry = lane), or nullptr
       const int* jn_slot;  // LDS: the block's array (uniform; the lane's entry is found from `i`); nullptr: not mapped
       double v;

@@ -319,18 +319,22 @@ __device__ __forceinline__ double beat_guard(double v) { return fabs(v) < 1.0e-4
 // 0 = plain).  Round 5 measured it because the library's own streaming probe reaches its best in-place rate with both
 // (csrc/beat_probe.hip, profiles/r05_streaming.md: 6.5 against 6.0 TB/s for ONE stream per wave; 5.85 against 5.73 for 19 row
 // streams, the pattern of this kernel); the result for the kernels themselves is in profiles/r05_streaming.md.
+// Round 6: 3 is the default.  With one block per tile and four waves per SIMD (beat_ode.hip: ode_grid) the kernel behaves as the
+// probe does: TP06 512^3 in one process on the same memory 8.60 - 8.64 -> 8.41 ms (loads only: 8.55 - 8.57, stores only: no change),
+// the 512^3 step 12.68 / 13.12 -> 12.41 / 12.80 ms on the two levels consecutive processes alternate between
+// (profiles/r06_ode_addressing.md); ToR-ORd: 2.465 -> 2.44 ms at 256^3, its class kernel (plain accesses) unchanged.
 #ifndef BEAT_ODE_NT
-#define BEAT_ODE_NT 0
+#define BEAT_ODE_NT 3
 #endif
 __device__ __forceinline__ double beat_row_load(const double* p) {
-#if BEAT_ODE_NT & 1
+#if (BEAT_ODE_NT & 1) && defined(__clang__)  // (the host harnesses build this header with g++: plain accesses there)
   return __builtin_nontemporal_load(p);
 #else
   return *p;
 #endif
 }
 __device__ __forceinline__ void beat_row_store(double* p, double v) {
-#if BEAT_ODE_NT & 2
+#if (BEAT_ODE_NT & 2) && defined(__clang__)
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
@@ -361,12 +365,13 @@ __device__ __forceinline__ T* beat_row(T* base, int k, int64_t ld) {
   return base + (int64_t)k * ld;
 }
 template <class T>
-__device__ __forceinline__ T* beat_at(T* uniform_base, unsigned byte_off) {
+__device__ __forceinline__ T* beat_at(T* uniform_base, unsigned& byte_off) {
   typedef typename std::conditional<std::is_const<T>::value, const char, char>::type Byte;
 #if defined(__AMDGCN__) && BEAT_AT_OPAQUE
-  // (a copy of the offset the optimiser cannot see through, per access: otherwise ONE 64-bit extension of the offset is formed at
-  // the top of the tile, outside the blocks of the accesses, and instruction selection -- block by block -- no longer sees
-  // "uniform base + zext(32-bit offset)", the form that goes into the instruction's own address operands)
+  // (the offset made opaque at every access, IN PLACE -- the caller's own variable, so that there is one value chain and no copy:
+  // otherwise ONE 64-bit extension of the offset is formed at the top of the tile, outside the blocks of the accesses, and
+  // instruction selection -- block by block -- no longer sees "uniform base + zext(32-bit offset)", the form that goes into the
+  // instruction's own address operands.  On a by-value copy the same statement cost a v_mov_b32 per access.)
   asm volatile("" : "+v"(byte_off));
 #endif
   return (T*)((Byte*)uniform_base + byte_off);
@@ -374,7 +379,7 @@ __device__ __forceinline__ T* beat_at(T* uniform_base, unsigned byte_off) {
 struct NodeIO {
   double* __restrict__ base;
   int64_t ld;
-  unsigned i;  // BYTE offset of the lane's node within the tile
+  mutable unsigned i;  // BYTE offset of the lane's node within the tile (mutable: beat_at makes it opaque in place)
   double* __restrict__ v_copy;  // optional mirror of row v_index (the PDE unknown; offset like `base`), may be null
   int v_index;
   __device__ __forceinline__ double load(int k) const { return beat_row_load(beat_at(beat_row(base, k, ld), i)); }
@@ -394,7 +399,7 @@ template <int VIDX>
 struct NodeIOPending {
   double* __restrict__ base;  // (tile base and 32-bit lane offset: see NodeIO)
   int64_t ld;
-  unsigned i;  // BYTE offset
+  mutable unsigned i;  // BYTE offset (see NodeIO)
   double* __restrict__ v_copy;
   int npend;
   double pa[BEAT_MAX_PENDING], pp[BEAT_MAX_PENDING];
@@ -656,7 +661,14 @@ struct Tp06Grl1 {
   // independent exp() chains; without fences everything is hoisted and one wave needs the whole
   // register file.  Each fenced block keeps a few chains in flight, which is all the latency hiding
   // 3-4 resident waves per SIMD need.
+#ifndef BEAT_TP06_FENCES
+#define BEAT_TP06_FENCES 1  // 0: none (experiments)
+#endif
+#if BEAT_TP06_FENCES
 #define BEAT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BEAT_FENCE()
+#endif
 
   template <class IO, class P>
   __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived& q, const FastMath& fm,

@@ -55,7 +55,20 @@ def main():
     ctx0 = Context.default()  # (torch's device and stream; the package's own library for StateArray)
     stream = torch.cuda.current_stream()
     builds = []
-    for path in args.libs:
+    import os
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="ab_ode_")
+    envs = {}
+    for spec in args.libs:
+        # lib.so@NAME=VALUE[,NAME=VALUE]: a private copy of the library whose first launch (which reads the library's environment
+        # switches into function-local statics, e.g. BEAT_ODE_GRID) runs with these variables set
+        path, _, env = spec.partition("@")
+        if env:
+            copy = Path(tmp) / (Path(path).stem + "_" + env.replace("=", "").replace(",", "_") + ".so")
+            shutil.copy(Path(path).resolve(), copy)
+            envs[copy.name] = dict(kv.split("=", 1) for kv in env.split(","))
+            path = str(copy)
         lib = C.CDLL(str(Path(path).resolve()), mode=C.RTLD_LOCAL)
         for name in ("beat_ctx_create", "beat_ode_step", "beat_ode_step_pending", "beat_last_error", "beat_ode_step_classes",
                      "beat_ode_class_table_doubles", "beat_ode_class_table_fill"):
@@ -109,9 +122,13 @@ def main():
                                                0.0, args.dt, vi, None, None, None, None, None, 0, 0)
             assert rc == 0, lib.beat_last_error()
 
-        for name, lib, h in builds:  # warm-up (module load, clocks)
+        for name, lib, h in builds:  # warm-up (module load, clocks; the library's environment switches are read here)
+            for k, v in envs.get(name, {}).items():
+                os.environ[k] = v
             for which in kinds:
                 launch(lib, h, which, name)
+            for k in envs.get(name, {}):
+                os.environ.pop(k, None)
         torch.cuda.synchronize()
         for rep in range(args.reps):
             for which in kinds:
