@@ -186,6 +186,10 @@ struct StashIO : Base {
   __device__ __forceinline__ double unstash(int slot) const { return lds[slot * BEAT_BLOCK]; }
 };
 template <class Model, class = void>
+struct beat_fm_pin_wanted : std::false_type {};
+template <class Model>
+struct beat_fm_pin_wanted<Model, std::void_t<decltype(Model::FM_PIN)>> : std::integral_constant<bool, Model::FM_PIN> {};
+template <class Model, class = void>
 struct beat_stash_slots : std::integral_constant<int, 0> {};
 template <class Model>
 struct beat_stash_slots<Model, std::void_t<decltype(Model::STASH_SLOTS)>> : std::integral_constant<int, Model::STASH_SLOTS> {};
@@ -198,6 +202,16 @@ struct beat_stash_slots<Model, std::void_t<decltype(Model::STASH_SLOTS)>> : std:
 #ifndef BEAT_TID_PER_TILE
 #define BEAT_TID_PER_TILE 1
 #endif
+// a double nobody has computed: the register's content (see the pending values of the tile loop)
+__device__ __forceinline__ double beat_any_value() {
+  double x;
+#ifdef __AMDGCN__
+  asm volatile("" : "=v"(x));
+#else
+  x = 0.0;
+#endif
+  return x;
+}
 #if BEAT_PENDING_READ == 3
 #define BEAT_PENDING_TILE_COUNT __builtin_amdgcn_readfirstlane(*(volatile int*)&s_pend[1])
 #else
@@ -225,11 +239,13 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     s_pend[1] = pend.dev_st != nullptr ? (int)pend.dev_st[beat_pde_detail::NUPD] : -1;
   }
   __syncthreads();
-  const FastMath fm{etab, ltab};
+  FastMath fm{etab, ltab};
+  if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   if (PEND && s_pend[0] == 0) return;  // the solve ahead has not latched (see PendingV)
 #else
   __syncthreads();
-  const FastMath fm{etab, ltab};
+  FastMath fm{etab, ltab};
+  if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   if (PEND && pend.dev_st != nullptr && pend.dev_st[beat_pde_detail::STOP] == 0.0) return;  // the solve ahead has not latched (see PendingV)
 #endif
   const int nupd_dev = PEND ? beat_pending_read(pend) : -1;
@@ -386,22 +402,26 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     // all loads issued together (they overlap with the state loads that follow)
     // (every field addressed as its tile's first node -- uniform, SGPRs -- plus the lane's 32-bit offset: see NodeIO)
     PendingNow now = beat_pending_now(pendl, BEAT_PENDING_TILE_COUNT);
+    // (round 6: the pending values are NOT zero-filled where nothing is pending -- every use is behind the same uniform condition as the
+    // load; `j < count ? load : 0.0` cost 16 register pairs of zeros per tile, 46 of the step's ~1700 VALU instructions.  The
+    // alternative value is "whatever the register holds": an asm statement without instructions that DEFINES the value.)
     NodeIOPending<Model::V_INDEX> io{states + tile0, ldl, lane_off, v_copy != nullptr ? v_copy + tile0 : nullptr, now.count, {}, {}, 0.0, 0.0, 0.0, 0.0, {}};
 #pragma unroll
     for (int j = 0; j < BEAT_MAX_PENDING; ++j) {
-      io.pp[j] = j < now.count ? __builtin_nontemporal_load(beat_at(pendl.ring + ((int64_t)j * pendl.fld + tile0), lane_off)) : 0.0;
+      io.pp[j] = j < now.count ? __builtin_nontemporal_load(beat_at(pendl.ring + ((int64_t)j * pendl.fld + tile0), lane_off)) : beat_any_value();
       io.pa[j] = j < now.count ? pendl.alphas[j] : 0.0;
     }
+    io.ge = io.gd = io.gp0 = io.gp1 = 0.0;
     if (now.gt.d != nullptr) {
       now.gt.d += tile0;
       now.gt.e += tile0;
       if (now.gt.dp[0] != nullptr) now.gt.dp[0] += tile0;
       if (now.gt.dp[1] != nullptr) now.gt.dp[1] += tile0;
       io.gt = now.gt;
-      io.ge = beat_pde_detail::beat_guess_needs_e(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.e, lane_off)) : 0.0;
-      io.gd = beat_pde_detail::beat_guess_needs_d(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.d, lane_off)) : 0.0;
-      io.gp0 = beat_pde_detail::beat_guess_needs_dp(now.gt, 0) ? __builtin_nontemporal_load(beat_at(now.gt.dp[0], lane_off)) : 0.0;
-      io.gp1 = beat_pde_detail::beat_guess_needs_dp(now.gt, 1) ? __builtin_nontemporal_load(beat_at(now.gt.dp[1], lane_off)) : 0.0;
+      io.ge = beat_pde_detail::beat_guess_needs_e(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.e, lane_off)) : beat_any_value();
+      io.gd = beat_pde_detail::beat_guess_needs_d(now.gt) ? __builtin_nontemporal_load(beat_at(now.gt.d, lane_off)) : beat_any_value();
+      io.gp0 = beat_pde_detail::beat_guess_needs_dp(now.gt, 0) ? __builtin_nontemporal_load(beat_at(now.gt.dp[0], lane_off)) : beat_any_value();
+      io.gp1 = beat_pde_detail::beat_guess_needs_dp(now.gt, 1) ? __builtin_nontemporal_load(beat_at(now.gt.dp[1], lane_off)) : beat_any_value();
     }
     if constexpr (PER_NODE && SPARSE && CT::count > 0) {
       // (row j of ppn belongs to the j-th index of the pack: the launch checks sp.idx against the instance)
@@ -565,7 +585,8 @@ __global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
   etab[threadIdx.x] = kExp2Tab[threadIdx.x];
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
-  const FastMath fm{etab, ltab};
+  FastMath fm{etab, ltab};
+  if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;
   double y[Model::NS];

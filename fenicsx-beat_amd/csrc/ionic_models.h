@@ -273,9 +273,16 @@ __device__ __forceinline__ double beat_sconst(double c) {
   return c;
 }
 
+#ifndef BEAT_FM_PIN
+#define BEAT_FM_PIN 1
+#endif
 struct FastMath {
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
   const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab
+  // 1.5 * 2^52, the rounding constant of exp(), in a VGPR pair for the whole step (the kernels make it opaque once, beat_fm_pin): an
+  // fma takes ONE scalar constant on gfx9, so `fma(x, 256/ln2, 1.5 * 2^52)` needs the second in VGPRs, and as a plain literal the
+  // register allocator re-materialised it (two v_mov_b32) at ten places of the TP06 step rather than keep two registers live
+  double magic = 6755399441055744.0;
   __device__ __forceinline__ double log(double x) const {
     const int hi = __double2hiint(x);
     const int e = ((hi >> 20) & 0x7ff) - 1023;
@@ -291,8 +298,8 @@ struct FastMath {
     return fma(ed, 0.693147180559663, t.logc + fma(ed, 2.8235290563031577e-13, p));
   }
   __device__ __forceinline__ double exp(double x) const {
-    const double kb = fma(x, 369.3299304675746, 6755399441055744.0);    // 256 / ln 2; 1.5 * 2^52: k in the low dword
-    const double k = kb - 6755399441055744.0;
+    const double kb = fma(x, 369.3299304675746, magic);    // 256 / ln 2; 1.5 * 2^52: k in the low dword
+    const double k = kb - magic;
     double r = fma(k, -0.002707606173999011, x);                        // ln2/256, high part (34 bits: exact product)
     r = fma(k, -6.327543041662719e-14, r);                              // low part
     const int ki = __double2loint(kb);
@@ -306,6 +313,12 @@ struct FastMath {
     return ldexp(fma(t, p, t), ki >> 8);
   }
 };
+
+__device__ __forceinline__ void beat_fm_pin(FastMath& fm) {
+#if defined(__AMDGCN__) && BEAT_FM_PIN
+  asm volatile("" : "+v"(fm.magic));
+#endif
+}
 
 // The generated models' Goldman-Hodgkin-Katz fluxes  v g / (exp(c v) - 1)  are 0/0 at v = 0 and their v-derivative
 // loses all accuracy next to it (relative error ~ ulp / (c v F/RT)^2; round-1 notes in DESIGN.md): the intermediates
@@ -409,7 +422,7 @@ struct NodeIOPending {
     double x = beat_row_load(beat_at(beat_row(base, k, ld), i));
     if (k == VIDX) {
       if (gt.d != nullptr) {  // same expressions and order as x_flush_kernel's guess branch
-        double inc = gt.accumulate ? 0.0 : ge;
+        double inc = (!gt.accumulate && gt.use_e) ? ge : 0.0;  // (ge is only loaded when it is due: beat_guess_needs_e)
 #pragma unroll
         for (int j = 0; j < BEAT_MAX_PENDING; ++j)
           if (j < npend) inc = fma(pa[j], pp[j], inc);
@@ -564,7 +577,7 @@ struct Tp06Grl1 {
   static constexpr bool ACCESSOR_PARAMS = true;  // derive / step take any p indexable by parameter number (beat_ode_jit.hip)
   static constexpr bool REGISTER_LOOP = true;
 #ifndef BEAT_TP06_WAVES
-#define BEAT_TP06_WAVES BEAT_ODE_WAVES
+#define BEAT_TP06_WAVES 4  // (round 6: 118 - 124 VGPRs in the uniform and the class kernels; the bound keeps it that way)
 #endif
 #ifndef BEAT_TP06_STASH
 #define BEAT_TP06_STASH 0
@@ -572,6 +585,7 @@ struct Tp06Grl1 {
   static constexpr int WAVES = BEAT_TP06_WAVES;
   static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   static constexpr int STASH_SLOTS = BEAT_TP06_STASH;  // values parked in LDS while the gate blocks run (beat_stash)
+  static constexpr bool FM_PIN = true;  // exp()'s rounding constant in a VGPR pair for the whole step (FastMath::magic): 118 -> 120 VGPRs, -18 VALU instructions
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
     P_kna, g_K1, g_Kr, g_Ks, g_Na, g_bna, g_CaL, g_bca, g_to, P_NaK, K_mk, K_mNa, K_NaCa, K_sat,
@@ -652,8 +666,48 @@ struct Tp06Grl1 {
     return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(beat_clamp_exp_arg(J * dt)) - 1.0) * rJ : fy * dt);
   }
   __device__ static __forceinline__ double guard(double J) { return (fabs(J) > 1e-8) ? J : 1.0; }
+  // The GRL1 increment f (exp(J dt) - 1) / J of a non-gate state as f dt phi(J dt), phi(z) = (exp(z) - 1) / z by its Taylor polynomial
+  // of degree 8 when |J dt| <= 1/16 (first omitted term z^9 / 10! < 5e-18; phi(0) = 1 is the |J| <= 1e-8 limit of the scheme), the
+  // scheme's literal expression otherwise -- the form the ToR-ORd kernel has had since round 3 (torord_dyncl.h: advance).  At dt = 0.01 -
+  // 0.05 ms nearly every node is inside the window for its seven non-gate states (the potential during an upstroke is not): 13
+  // instructions in place of exp() + reciprocal + selection (~26), and no cancellation in exp(z) - 1.  Round 6: the kernel is bound by
+  // fp64 issue once more (four waves per SIMD, 86 % VALU busy: profiles/r06_512.md).  BEAT_TP06_PHI=0: the literal expression always.
+#ifndef BEAT_TP06_PHI
+#define BEAT_TP06_PHI 1
+#endif
+  __device__ static __forceinline__ double phi_small(double z) {
+    double ph = z * beat_sconst(1.0 / 362880.0) + beat_sconst(1.0 / 40320.0);
+    ph = fma(z, ph, beat_sconst(1.0 / 5040.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 720.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 120.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 24.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 6.0));
+    ph = fma(z, ph, 0.5);
+    return fma(z, ph, 1.0);
+  }
+  __device__ static __forceinline__ double advance(const FastMath& fm, double y, double fy, double J, double dt) {
+    const double z = J * dt;
+    if (BEAT_TP06_PHI && fabs(z) <= 0.0625) return fma(fy * dt, phi_small(z), y);
+    return grl1(fm, y, fy, J, dt);
+  }
   // gate with f = (inf - y)/tau, J = -1/tau
+#ifndef BEAT_TP06_GATE_PHI
+#define BEAT_TP06_GATE_PHI 0  // 1: 1 - exp(z), z = -dt/tau, as -z phi7(z) when |z| <= 1/32 (per lane); measured, see profiles/r06_ode_addressing.md
+#endif
+  __device__ static __forceinline__ double phi7(double z) {  // (exp(z) - 1) / z, |z| <= 1/32: first omitted term z^8 / 9! < 3e-18
+    double ph = z * beat_sconst(1.0 / 40320.0) + beat_sconst(1.0 / 5040.0);
+    ph = fma(z, ph, beat_sconst(1.0 / 720.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 120.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 24.0));
+    ph = fma(z, ph, beat_sconst(1.0 / 6.0));
+    ph = fma(z, ph, 0.5);
+    return fma(z, ph, 1.0);
+  }
   __device__ static __forceinline__ double gate(const FastMath& fm, double y, double inf, double rtau, double dt) {
+#if BEAT_TP06_GATE_PHI
+    const double z = -dt * rtau;
+    if (z >= -0.03125) return fma(inf - y, -z * phi7(z), y);
+#endif
     return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rtau, -746.0)));
   }
 
@@ -930,11 +984,17 @@ struct Tp06Grl1 {
       // dE_K/dK_i = -RTF/K_i, dE_Ks/dK_i = -RTF/(K_i + P_kna Na_i); currents depend on K_i only through them
       const double J_Ki = -(sum_du * q.RTF * rKi + gKs * q.RTF * rKs) * q.cVF;
       const double J_Nai = -((gNa + p[g_bna]) * q.RTF * rNai + 3.0 * di_NaK_dNai + 3.0 * di_NaCa_dNai) * q.cVF;
+#if BEAT_TP06_PHI
+      io.store(V, advance(fm, v, -(I_tot + i_Stim), J_V, dt));
+      io.store(K_i, advance(fm, vKi, -(I_K + i_Stim - 2.0 * i_NaK) * q.cVF, J_Ki, dt));
+      io.store(Na_i, advance(fm, vNai, -(i_Na_tot + 3.0 * i_NaK + 3.0 * i_NaCa) * q.cVF, J_Nai, dt));
+#else
       double rJV, rJK, rJN;
       rcp3(guard(J_V), guard(J_Ki), guard(J_Nai), rJV, rJK, rJN);
       io.store(V, grl1r(fm, v, -(I_tot + i_Stim), J_V, rJV, dt));
       io.store(K_i, grl1r(fm, vKi, -(I_K + i_Stim - 2.0 * i_NaK) * q.cVF, J_Ki, rJK, dt));
       io.store(Na_i, grl1r(fm, vNai, -(i_Na_tot + 3.0 * i_NaK + 3.0 * i_NaCa) * q.cVF, J_Nai, rJN, dt));
+#endif
     }
     BEAT_FENCE();
 
@@ -957,7 +1017,7 @@ struct Tp06Grl1 {
       const double T_i = -(i_b_Ca + i_p_Ca - 2.0 * i_NaCa) * q.c1 + (i_leak - i_up) * q.c2 + i_xfer;
       const double dT_i = -(p[g_bca] * q.halfRTF * rCai + di_pCa_dCai - 2.0 * di_NaCa_dCai) * q.c1 +
                           (-p[V_leak] - di_up_dCai) * q.c2 - p[V_xfer];
-      io.store(Ca_i, grl1(fm, vCai, T_i * Fr_i, dT_i * Fr_i + T_i * (Fr_i * Fr_i * 2.0 * gci * rbc), dt));
+      io.store(Ca_i, advance(fm, vCai, T_i * Fr_i, dT_i * Fr_i + T_i * (Fr_i * Fr_i * 2.0 * gci * rbc), dt));
     }
     BEAT_FENCE();
     const double kcasr = p[max_sr] - q.dsr * rz;
@@ -973,17 +1033,17 @@ struct Tp06Grl1 {
     const double dO_dCass = 2.0 * vCass * k1 * vR * p[k3] * rO * rO;
     const double dsrss = vCaSR - vCass;
     const double i_rel = p[V_rel] * O * dsrss;
-    io.store(R_prime, grl1(fm, vR, -k2 * vCass * vR + p[k4] * (1.0 - vR), -vCass * k2 - p[k4], dt));
+    io.store(R_prime, advance(fm, vR, -k2 * vCass * vR + p[k4] * (1.0 - vR), -vCass * k2 - p[k4], dt));
     {  // Ca_SR
       const double T_sr = i_up - (i_rel + i_leak);
       const double dT_sr = -(p[V_rel] * (dO_dk1 * dk1 * dsrss + O) + p[V_leak]);
-      io.store(Ca_SR, grl1(fm, vCaSR, T_sr * Fr_sr, dT_sr * Fr_sr + T_sr * (Fr_sr * Fr_sr * 2.0 * gsr * rbsr), dt));
+      io.store(Ca_SR, advance(fm, vCaSR, T_sr * Fr_sr, dT_sr * Fr_sr + T_sr * (Fr_sr * Fr_sr * 2.0 * gsr * rbsr), dt));
     }
     BEAT_FENCE();
     {  // Ca_ss
       const double T_ss = -i_CaL * q.c3 + i_rel * q.c4 - i_xfer * q.c5;
       const double dT_ss = -di_CaL_dCass * q.c3 + p[V_rel] * (dO_dCass * dsrss - O) * q.c4 - p[V_xfer] * q.c5;
-      io.store(Ca_ss, grl1(fm, vCass, T_ss * Fr_ss, dT_ss * Fr_ss + T_ss * (Fr_ss * Fr_ss * 2.0 * gss * rbss), dt));
+      io.store(Ca_ss, advance(fm, vCass, T_ss * Fr_ss, dT_ss * Fr_ss + T_ss * (Fr_ss * Fr_ss * 2.0 * gss * rbss), dt));
     }
   }
 #undef BEAT_FENCE

@@ -214,8 +214,10 @@ BEAT_DV Du<A> cube(const Du<A>& a) {
 // (cross-bridges XS / XW, troponin-bound calcium CaTrpn, blocked tropomyosin TmB, distortions Zetas / Zetaw, dashpot Cd),
 // 28 more parameters, troponin buffering as a flux of the calcium equation instead of a term of Bcai; in that file cai
 // is declared with the mechanics states, so its row is 44 and the rows of cajsr .. xs2 are one lower (slot()).
+// (round 6: 3 -- with the rows addressed through SGPR bases the uniform and the class kernels need 164 - 168 VGPRs without scratch,
+// profiles/r06_ode_resources.md; as a launch bound it keeps a later change from silently falling back to two waves)
 #ifndef BEAT_TORORD_WAVES
-#define BEAT_TORORD_WAVES 2
+#define BEAT_TORORD_WAVES 3
 #endif
 template <bool LAND>
 struct TorordGrl1T {

@@ -90,7 +90,19 @@ def main():
         raws.append(p)
         base = C.c_void_p(p.value + 8 * plane)
         # (beat_malloc zero-fills; the probe multiplies by 1.0)
-        print(f"hipMalloc   {a}: ptr {p.value:#x}  rows pattern {probe(base, ld):7.0f} GB/s", flush=True)
+        rate = probe(base, ld)
+        # the kernel on this allocation: the states of the first torch array copied over
+        _hip.check(lib.beat_copy(ctx.handle, p, C.c_void_p(keep[0].buf.data_ptr()), plane + S * ld))
+        ts = []
+        for _ in range(args.reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _hip.check(lib.beat_ode_step(ctx.handle, _hip.MODEL_TP06_GRL1, base, N, ld, prm.ctypes.data_as(C.c_void_p), len(prm), None, 0, 0.0, 0.01, vi, None))
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts = sorted(ts[1:])
+        print(f"hipMalloc   {a}: ptr {p.value:#x}  rows pattern {rate:7.0f} GB/s   TP06 kernel {ts[len(ts) // 2]:6.3f} ms", flush=True)
     # the first ones again (has anything changed while the others were allocated?)
     for a in range(min(2, args.allocs)):
         sa = keep[a]
