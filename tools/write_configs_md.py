@@ -40,7 +40,8 @@ sh, sh4 = tail("cfg5_shell.log")[0], tail("cfg5_shell400.log")[0]
 md = f"""# Round {RND[2:]}: BASELINE.json's five configurations on one MI355X (`bash tools/run_configs.sh`, one gpurun call on one box)
 
 Package defaults: initial guess of the diffusion solve = extrapolation in time of the last diffusion increments, order 1-4
-chosen per solve (`ksp_guess_order` "auto"); 24 576 blocks per ionic launch; grids of up to 8192 nodes solved in one launch
+chosen per solve (`ksp_guess_order` "auto"); one block per 256-node tile in an ionic launch (round 6; 24 576 looping blocks before), the
+state array placed by the best of three allocations (round 6); grids of up to 8192 nodes solved in one launch
 of one workgroup, their steps batched by `MonodomainSplittingSolver.solve`; per-node rows (voxel meshes, fibre fields): the
 workgroup-tile pass with the direction update fused in (round 4).  Box-to-box spread of the pool is ±5 %.  Earlier tables:
 `r01_configs.md`, `r02_configs.md` (the "round 1" figures quoted below are theirs); written by `tools/write_configs_md.py`.
