@@ -1004,7 +1004,8 @@ def main():
                 "bound": "hbm",
                 # the yardstick above is the HBM roofline (the path is bandwidth-shaped); THIS kernel sits close to three
                 # ceilings at once
-                "limiter": "co-limited: fp64 VALU issue (see valu), the in-place streaming rate of HBM (see inplace_stream) and the package power limit (profiles/r02_power.md)",
+                "limiter": "fp64 VALU issue at the power-limited clock (see valu: four waves per SIMD since round 6, profiles/r06_ode_addressing.md; "
+                           "package power: profiles/r02_power.md), over the rate its own 19-row access pattern streams at (see inplace_stream.rows_pattern)",
                 "kernel": "ode_step_kernel<Tp06Grl1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
