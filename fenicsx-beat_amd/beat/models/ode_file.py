@@ -305,9 +305,9 @@ class OdeFileModel(DeviceModel):
                 "  template <class P> __host__ __device__ static Derived derive(const P&) { return Derived{0.0}; }\n"
                 "  template <class IO, class P>\n"
                 "  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived&, const FastMath& fm, double t, double dt) {\n"
-                + ("    // (FastMath::exp takes |x| < ~700; outside: what libm / NumPy give -- NaN stays NaN, overflow is inf, underflow 0)\n"
-                   "    const auto fexp = [&fm](double x) { const double e = fm.exp(fmin(fmax(x, -745.0), 709.0));\n"
-                   "                                        return x != x ? x : (x > 709.782712893384 ? HUGE_VAL : e); };\n" if self.fast_exp else "")
+                + ("    // (FastMath::exp takes [BEAT_EXP_LO, BEAT_EXP_HI]; outside: what libm / NumPy give -- NaN stays NaN, overflow is inf, below -708 it is 0 where libm still has subnormals)\n"
+                   "    const auto fexp = [&fm](double x) { const double e = fm.exp(beat_clamp_exp_arg(x));\n"
+                   "                                        return x != x ? x : (x < BEAT_EXP_LO ? 0.0 : beat_exp_overflow(x, e)); };\n" if self.fast_exp else "")
                 + "    const auto beat_sel = [](bool c, double a, double b) { return c ? a : b; };\n"
                 + "\n".join(loads + pl + lines + body) + "\n  }\n};\n")
 

@@ -185,6 +185,11 @@ struct StashIO : Base {
   __device__ __forceinline__ void stash(int slot, double v) const { lds[slot * BEAT_BLOCK] = v; }
   __device__ __forceinline__ double unstash(int slot) const { return lds[slot * BEAT_BLOCK]; }
 };
+// the FastMath flavour a model's step takes (Model::FM; FastMath = v_ldexp_f64 scaling unless the model says otherwise)
+template <class Model, class = void>
+struct beat_fm_type { using type = FastMath; };
+template <class Model>
+struct beat_fm_type<Model, std::void_t<typename Model::FM>> { using type = typename Model::FM; };
 template <class Model, class = void>
 struct beat_fm_pin_wanted : std::false_type {};
 template <class Model>
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
-  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  etab[threadIdx.x] = beat_exp_tab_entry<beat_fm_type<Model>::type::INT_SCALE>(kExp2Tab[threadIdx.x], (int)threadIdx.x);
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   // values a step parks in LDS across the stretch that does not use them (StashIO): the uniform-parameter instances only
   constexpr int NSTASH = (!PER_NODE && !MARKED) ? beat_stash_slots<Model>::value : 0;
@@ -239,12 +244,12 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
     s_pend[1] = pend.dev_st != nullptr ? (int)pend.dev_st[beat_pde_detail::NUPD] : -1;
   }
   __syncthreads();
-  FastMath fm{etab, ltab};
+  typename beat_fm_type<Model>::type fm{etab, ltab};
   if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   if (PEND && s_pend[0] == 0) return;  // the solve ahead has not latched (see PendingV)
 #else
   __syncthreads();
-  FastMath fm{etab, ltab};
+  typename beat_fm_type<Model>::type fm{etab, ltab};
   if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   if (PEND && pend.dev_st != nullptr && pend.dev_st[beat_pde_detail::STOP] == 0.0) return;  // the solve ahead has not latched (see PendingV)
 #endif
@@ -582,10 +587,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, 1) void ode_run_kernel(
   __shared__ double etab[BEAT_EXP_TAB];
   __shared__ LogEntry ltab[128];
   static_assert(BEAT_EXP_TAB == BEAT_BLOCK, "one table entry per thread");
-  etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  etab[threadIdx.x] = beat_exp_tab_entry<beat_fm_type<Model>::type::INT_SCALE>(kExp2Tab[threadIdx.x], (int)threadIdx.x);
   if (threadIdx.x < 128) ltab[threadIdx.x] = kLogTab[threadIdx.x];
   __syncthreads();
-  FastMath fm{etab, ltab};
+  typename beat_fm_type<Model>::type fm{etab, ltab};
   if constexpr (beat_fm_pin_wanted<Model>::value) beat_fm_pin(fm);  // (two VGPRs for the whole step: a model's choice)
   const int64_t i = (int64_t)blockIdx.x * BEAT_BLOCK + threadIdx.x;
   if (i >= n) return;

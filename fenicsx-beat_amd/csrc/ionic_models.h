@@ -24,12 +24,12 @@
 //   exp(x) = 2^m * 2^(j/256) * (1 + r + r^2/2 + r^3/6 + r^4/24)
 // 2^(j/256) comes from a 256-entry table staged in LDS (2 KB), the truncation error of the degree-4 polynomial
 // is < 4e-17, so the result is within ~1 ulp.  k is rounded with the 1.5 * 2^52 trick: one fma gives the rounded
-// value in the mantissa and k as a signed integer in the low dword (no v_rndne / v_cvt).  No overflow / NaN
-// handling: arguments in these models are bounded (|x| < 700); large negative arguments underflow to 0 through
-// v_ldexp_f64 -- as long as |x| < 5.8e6 (k must fit the low dword): arguments that are rate * dt products (gate updates,
-// exp(J dt)) can exceed that at unphysiological potentials and are clamped by their callers (beat_clamp_exp_arg).
-// 13 VALU instructions (16 with the 64-entry table and a degree-5 polynomial, ~27 for the library
-// routine) -- the ionic kernels are fp64-issue bound and the TP06 step evaluates 51 of them per node.
+// value in the mantissa and k as a signed integer in the low dword (no v_rndne / v_cvt).  No overflow / underflow / NaN
+// handling: arguments in these models are bounded (|x| < 700), and the result must be a normal number (BEAT_EXP_LO / _HI below:
+// round 6 scales by an integer add into the exponent field); arguments that are rate * dt products (gate updates, exp(J dt))
+// leave that range at unphysiological potentials and are clamped by their callers (beat_clamp_exp_arg).
+// 12 VALU instructions (13 with shift + v_ldexp_f64 until round 5, 16 with the 64-entry table and a degree-5 polynomial, ~27 for
+// the library routine) -- the ionic kernels are fp64-issue bound and the TP06 step evaluates 51 of them per node.
 // ------------------------------------------------------------------------------------------------
 constexpr int BEAT_EXP_TAB = 256;
 __device__ const double kExp2Tab[BEAT_EXP_TAB] = {
@@ -247,9 +247,26 @@ __device__ const LogEntry kLogTab[128] = {
 #define BEAT_ODE_WAVES_PER_NODE 2  // kernels whose parameters are per-node rows (TP06: 53 more doubles per lane)
 #endif
 
-// exp() argument of a rate * dt product, kept inside the range FastMath::exp handles (below -746 the result is 0,
-// above 710 it is inf: the clamp changes no finite value)
-__device__ __forceinline__ double beat_clamp_exp_arg(double x) { return fmin(fmax(x, -746.0), 710.0); }
+// The range FastMath::exp takes (round 6): on the device the factor 2^m goes into the table value's exponent field by an INTEGER add
+// (one instruction in place of the shift + v_ldexp_f64 pair), which neither underflows to 0 nor overflows to inf -- the result must be a
+// normal number: exp(-708) = 3.3e-308 (m = -1022) ... exp(709) = 8.2e307.  Callers whose argument is a rate * dt product clamp it into
+// that range: below -708 the clamp changes no RESULT (1 - 3e-308 = 1, 3e-308 - 1 = -1 in fp64: what the gate updates and the GRL1
+// increments do with it), above 709.78 the callers put the overflow back (beat_exp_overflow: the scheme's literal expression gives
+// inf there, and so does the oracle).
+constexpr double BEAT_EXP_LO = -708.0, BEAT_EXP_HI = 709.0;
+__device__ __forceinline__ double beat_clamp_exp_arg(double x) { return fmin(fmax(x, BEAT_EXP_LO), BEAT_EXP_HI); }
+// exp(x) for any x >= BEAT_EXP_LO given e = FastMath::exp(min(x, BEAT_EXP_HI)): inf where exp overflows (x > 709.78...)
+__device__ __forceinline__ double beat_exp_overflow(double x, double e) { return x > 709.782712893384 ? HUGE_VAL : e; }
+// The table entry as the device's exp() wants it: 2^(j/256) with j << 12 taken off its high word, so that adding the whole
+// k = 256 m + j, shifted by 12, leaves m in the exponent field (k << 12 = (m << 20) + (j << 12))
+template <bool INT_SCALE>
+__device__ __forceinline__ double beat_exp_tab_entry(double t, int j) {
+#ifdef __AMDGCN__
+  if constexpr (INT_SCALE) return __hiloint2double(__double2hiint(t) - (j << 12), __double2loint(t));
+#endif
+  (void)j;
+  return t;
+}
 
 // 1/x: hardware estimate (~26 bits) + one third-order step r (1 + e + e^2), e = 1 - x r
 __device__ __forceinline__ double beat_rcp(double x) {
@@ -276,7 +293,12 @@ __device__ __forceinline__ double beat_sconst(double c) {
 #ifndef BEAT_FM_PIN
 #define BEAT_FM_PIN 1
 #endif
-struct FastMath {
+// INT_SCALE (round 6, the TP06 step): exp() puts 2^m into the table value's exponent field by an integer add -- see exp() and
+// BEAT_EXP_LO / _HI; the table then holds adjusted entries (beat_exp_tab_entry).  false: v_ldexp_f64, any argument down to -5.8e6
+// underflows to 0 (ToR-ORd, the generated models, the forward-Euler models).
+template <bool INT_SCALE_>
+struct FastMathT {
+  static constexpr bool INT_SCALE = INT_SCALE_;
   const double* __restrict__ tab;  // LDS copy of kExp2Tab
   const LogEntry* __restrict__ ltab;  // LDS copy of kLogTab
   // 1.5 * 2^52, the rounding constant of exp(), in a VGPR pair for the whole step (the kernels make it opaque once, beat_fm_pin): an
@@ -310,11 +332,21 @@ struct FastMath {
     double p = fma(r, beat_sconst(1.0 / 6.0), 0.5);
     p = fma(r2, beat_sconst(1.0 / 24.0), p);
     p = fma(r2, p, r);
-    return ldexp(fma(t, p, t), ki >> 8);
+#ifdef __AMDGCN__
+    if constexpr (INT_SCALE) {
+      // 2^m 2^(j/256): k << 12 added to the (adjusted, beat_exp_tab_entry) table value's high word -- one v_lshl_add_u32; x in
+      // [BEAT_EXP_LO, BEAT_EXP_HI] (NaN stays NaN: r is NaN).  Bit for bit what ldexp gives there: scaling by 2^m commutes with the fma.
+      const double ts = __hiloint2double(__double2hiint(t) + (int)((unsigned)ki << 12), __double2loint(t));
+      return fma(ts, p, ts);
+    }
+#endif
+    return ldexp(fma(t, p, t), ki >> 8);  // (also the host harnesses' form: the plain table)
   }
 };
 
-__device__ __forceinline__ void beat_fm_pin(FastMath& fm) {
+using FastMath = FastMathT<false>;
+template <bool I>
+__device__ __forceinline__ void beat_fm_pin(FastMathT<I>& fm) {
 #if defined(__AMDGCN__) && BEAT_FM_PIN
   asm volatile("" : "+v"(fm.magic));
 #endif
@@ -585,6 +617,14 @@ struct Tp06Grl1 {
   static constexpr int WAVES = BEAT_TP06_WAVES;
   static constexpr int WAVES_PER_NODE = BEAT_ODE_WAVES_PER_NODE;  // per-node parameter rows: NP more values per lane
   static constexpr int STASH_SLOTS = BEAT_TP06_STASH;  // values parked in LDS while the gate blocks run (beat_stash)
+  // exp() with the factor 2^m added into the exponent field (FastMathT<true>: one instruction less per exp(), 51 per node; results in
+  // the normal range only, i.e. |V| < ~370 mV -- beyond it the Gaussian time constants' arguments leave [BEAT_EXP_LO, BEAT_EXP_HI])
+  // Measured (profiles/r06_ode_addressing.md): 1778 -> 1729 static VALU instructions, 8.10 -> 8.00 ms in one process, 12.20 -> 12.165 ms per
+  // 512^3 step -- 0.3 %, for a step that would return garbage instead of NaN beyond its range: OFF.
+#ifndef BEAT_TP06_EXP_INT
+#define BEAT_TP06_EXP_INT 0
+#endif
+  using FM = FastMathT<BEAT_TP06_EXP_INT != 0>;
   static constexpr bool FM_PIN = true;  // exp()'s rounding constant in a VGPR pair for the whole step (FastMath::magic): 118 -> 120 VGPRs, -18 VALU instructions
   enum S { Xr1, Xr2, Xs, m, h, j, d, f, f2, fCass, s, r, R_prime, Ca_i, Ca_SR, Ca_ss, Na_i, V, K_i };
   enum P {
@@ -657,13 +697,13 @@ struct Tp06Grl1 {
     ic = rcd * d;
     id = rcd * c;
   }
-  __device__ static __forceinline__ double grl1(const FastMath& fm, double y, double fy, double J, double dt) {
-    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(beat_clamp_exp_arg(J * dt)) - 1.0) * rcp(J) : fy * dt);
+  __device__ static __forceinline__ double grl1(const FM& fm, double y, double fy, double J, double dt) {
+    return y + ((fabs(J) > 1e-8) ? fy * (beat_exp_overflow(J * dt, fm.exp(beat_clamp_exp_arg(J * dt))) - 1.0) * rcp(J) : fy * dt);
   }
   // same with 1/J supplied by the caller (batched); rJ is only used where |J| > 1e-8
-  __device__ static __forceinline__ double grl1r(const FastMath& fm, double y, double fy, double J, double rJ,
+  __device__ static __forceinline__ double grl1r(const FM& fm, double y, double fy, double J, double rJ,
                                                  double dt) {
-    return y + ((fabs(J) > 1e-8) ? fy * (fm.exp(beat_clamp_exp_arg(J * dt)) - 1.0) * rJ : fy * dt);
+    return y + ((fabs(J) > 1e-8) ? fy * (beat_exp_overflow(J * dt, fm.exp(beat_clamp_exp_arg(J * dt))) - 1.0) * rJ : fy * dt);
   }
   __device__ static __forceinline__ double guard(double J) { return (fabs(J) > 1e-8) ? J : 1.0; }
   // The GRL1 increment f (exp(J dt) - 1) / J of a non-gate state as f dt phi(J dt), phi(z) = (exp(z) - 1) / z by its Taylor polynomial
@@ -685,7 +725,7 @@ struct Tp06Grl1 {
     ph = fma(z, ph, 0.5);
     return fma(z, ph, 1.0);
   }
-  __device__ static __forceinline__ double advance(const FastMath& fm, double y, double fy, double J, double dt) {
+  __device__ static __forceinline__ double advance(const FM& fm, double y, double fy, double J, double dt) {
     const double z = J * dt;
     if (BEAT_TP06_PHI && fabs(z) <= 0.0625) return fma(fy * dt, phi_small(z), y);
     return grl1(fm, y, fy, J, dt);
@@ -703,12 +743,12 @@ struct Tp06Grl1 {
     ph = fma(z, ph, 0.5);
     return fma(z, ph, 1.0);
   }
-  __device__ static __forceinline__ double gate(const FastMath& fm, double y, double inf, double rtau, double dt) {
+  __device__ static __forceinline__ double gate(const FM& fm, double y, double inf, double rtau, double dt) {
 #if BEAT_TP06_GATE_PHI
     const double z = -dt * rtau;
     if (z >= -0.03125) return fma(inf - y, -z * phi7(z), y);
 #endif
-    return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rtau, -746.0)));
+    return y + (inf - y) * (1.0 - fm.exp(fmax(-dt * rtau, BEAT_EXP_LO)));  // (-dt / tau <= 0)
   }
 
   // Fence for the instruction scheduler: the step is ~3000 straight-line instructions with ~50
@@ -725,7 +765,7 @@ struct Tp06Grl1 {
 #endif
 
   template <class IO, class P>
-  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived& q, const FastMath& fm,
+  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived& q, const FM& fm,
                                               double t, double dt) {
     const double v = io.load(V);
     // exp(c) constants, c written out in the comment

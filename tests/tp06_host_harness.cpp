@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   std::fclose(f);
   const bool per_node = got == P.size() && n > 1;
   if (!per_node && got < (size_t)Model::NP) return 3;
-  const FastMath fm{kExp2Tab, kLogTab};
+  const Model::FM fm{kExp2Tab, kLogTab};  // (on the host both flavours scale by ldexp and read the plain table)
   // optional: <nsteps> <steps_per_beat> -- the in-kernel time loop of beat_ode_run on the host: nsteps steps in all, t restarts
   // at the given t every steps_per_beat steps (src/beat/single_cell.py:86-156 paces a cell this way)
   const long nsteps = argc > 7 ? std::atol(argv[7]) : 1;
