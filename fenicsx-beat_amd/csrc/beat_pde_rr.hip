@@ -111,9 +111,23 @@ __device__ __forceinline__ double from_right(double v) {
 #endif
 typedef int rr_v2i __attribute__((ext_vector_type(2)));
 [[maybe_unused]] constexpr unsigned RR_OOB = 0x80000000u;
+// BEAT_RR_NT (round 6): bit 0 non-temporal row loads, bit 1 non-temporal stores of the pass's output field.  2 is the build: the
+// output field is written once and read by the NEXT launch (1 GB at 512^3: from HBM either way), and not keeping it in the L2 leaves
+// the L2 to the y-halo rows neighbouring waves re-read -- diffusion part of the 512^3 step 3.38 - 3.42 -> 3.31 - 3.36 ms, of the developed
+// front's 5.06 - 5.12 -> 4.93 - 5.01; non-temporal LOADS throw exactly those rows away: 3.84 - 3.88 / 6.12 - 6.16 (profiles/r06_ab_rr_nt.txt)
+#ifndef BEAT_RR_NT
+#define BEAT_RR_NT 2
+#endif
+__device__ __forceinline__ void rr_store(double* p, double v) {
+#if BEAT_RR_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ double rr_buf_load(const double* base, unsigned bytes, unsigned off) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-  const rr_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  const rr_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, (BEAT_RR_NT & 1) ? 2 : 0);
   return __hiloint2double(v.y, v.x);
 }
 
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
         }
         if (OLD) {
           if (own_plane && r >= 1 && r <= RY && x_out && row_in[r])
-            Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx] = c;
+            rr_store(&Y[(int64_t)k * g.plane + (int64_t)(y0 + r) * g.nx + gx], c);
         }
       }
       if constexpr (ALIGNED) {  // the x-halo elements of plane k, formed like the rows (a lane that fetched nothing holds 0)
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
             rr -= se;
           }
           const double zz = di * rr;
-          Y[gi] = rr;
+          rr_store(&Y[gi], rr);
           if (Y2 != nullptr) Y2[gi] = v[0];
           acc0 = fma(b, b, acc0);
           acc1 = fma(rr, zz, acc1);
@@ -513,10 +527,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) 
             acc1 = fma(ri, v[0], acc1);
             acc2 = fma(ri, ri, acc2);
           } else if (MODE == RR_PRUPD) {  // r_new = r - alpha (A p_new)
-            Y2[gi] = fma(-alpha, s, Rw0[RAW ? j : 0]);
+            rr_store(&Y2[gi], fma(-alpha, s, Rw0[RAW ? j : 0]));
           } else {                      // r -= alpha (A p)
             const double ri = fma(-alpha, s, rv[j]);
-            Y[gi] = ri;
+            rr_store(&Y[gi], ri);
             acc0 = fma(ri * di, ri, acc0);
             acc1 = fma(ri, ri, acc1);
           }
