@@ -207,6 +207,24 @@ struct beat_stash_slots<Model, std::void_t<decltype(Model::STASH_SLOTS)>> : std:
 #ifndef BEAT_TID_PER_TILE
 #define BEAT_TID_PER_TILE 1
 #endif
+// cache policy of the class kernel's state rows (BEAT_ODE_CLS_NT: 1 = as the uniform kernels' rows, BEAT_ODE_NT; 0 = plain)
+#ifndef BEAT_ODE_CLS_NT
+#define BEAT_ODE_CLS_NT 1  // (round 6: ToR-ORd classes 2.547 -> 2.522 ms at 256^3 in one process, shell 401^3 9.87 - 10.05 -> 9.81 - 9.96: profiles/r06_inproc_cls_nt.txt)
+#endif
+__device__ __forceinline__ double beat_cls_load(const double* p) {
+#if BEAT_ODE_CLS_NT
+  return beat_row_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void beat_cls_store(double* p, double v) {
+#if BEAT_ODE_CLS_NT
+  beat_row_store(p, v);
+#else
+  *p = v;
+#endif
+}
 // a double nobody has computed: the register's content (see the pending values of the tile loop)
 __device__ __forceinline__ double beat_any_value() {
   double x;
@@ -327,9 +345,9 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
       double* vbase;  // mirror of the potential: the PDE's field (mapped: entry *jn_slot) or v_copy at the tile (entry = lane), or nullptr
       const int* jn_slot;  // LDS: the block's array (uniform; the lane's entry is found from `i`); nullptr: not mapped
       double v;
-      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : *beat_at(beat_row(base, k, ld), i); }
+      __device__ __forceinline__ double load(int k) const { return k == Model::V_INDEX ? v : beat_cls_load(beat_at(beat_row(base, k, ld), i)); }
       __device__ __forceinline__ void store(int k, double x) const {
-        *beat_at(beat_row(base, k, ld), i) = x;
+        beat_cls_store(beat_at(beat_row(base, k, ld), i), x);
         if (k == Model::V_INDEX && vbase != nullptr) {
           if (jn_slot != nullptr)
             vbase[*(const int*)((const char*)jn_slot + (i >> 1))] = x;  // entry tid = byte offset / 8

@@ -124,6 +124,69 @@ def test_tp06_grl1_one_step_matches_oracle(hip_ctx):
         assert err[:, near].max() < 1e-8
 
 
+def test_tp06_grl1_increment_matches_oracle_on_both_sides_of_the_polynomial_window(hip_ctx):
+    """Round 6: the GRL1 increment of TP06's seven non-gate states is ``f dt phi(J dt)`` with phi by its Taylor polynomial when
+    |J dt| <= 1/16 and the scheme's literal ``f (exp(J dt) - 1) / J`` outside (csrc/ionic_models.h: advance).  Random physiological
+    states stepped with time steps from 0.001 to 1 ms put |J_V dt| from 1e-4 to beyond 10 -- both branches of every state and
+    lanes of one wavefront on either side; each dt against the NumPy oracle (the literal expression throughout) to 1e-11 of the
+    state scale, as the one-step test asks of dt = 0.01 / 0.05."""
+    from beat import _hip
+    from oracle import ionic
+
+    n = 8192
+    S = _random_tp06_states(n, 23)
+    P = ionic.tp06_init_parameter_values(stim_amplitude=0.0)
+    near = np.abs(S[17] - 15.0) < 0.05  # (the i_CaL singularity: see test_tp06_grl1_one_step_matches_oracle)
+    for dt in (0.001, 0.02, 0.1, 0.3, 1.0):
+        out = _ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, P, 1.0, dt)
+        ref = ionic.tp06_generalized_rush_larsen(S, 1.0, dt, P)
+        ok = np.isfinite(ref).all(axis=0) & ~near
+        scale = np.maximum(np.abs(ref), 1e-3)
+        err = (np.abs(out - ref) / scale)[:, ok]
+        assert np.isfinite(out[:, ok]).all() and err.max() < 1e-11, (dt, err.max())
+    # the window is really straddled: the potential's own J dt = -dt dI/dV lies on both sides at dt = 0.1
+    out1, out2 = (_ode_step(hip_ctx, _hip.MODEL_TP06_GRL1, S, P, 1.0, d)[17] for d in (0.1, 0.1 * (1 + 1e-9)))
+    assert np.isfinite(out1).all() and np.abs(out1 - out2).max() < 1e-6  # (continuous across the switch)
+
+
+def test_state_array_keeps_the_best_of_three_placements(hip_ctx, monkeypatch):
+    """Round 6: where the driver puts a large state array decides how fast its rows stream (profiles/r06_placement.md);
+    ``StateArray`` allocates up to BEAT_STATE_PLACE candidates, times the library's streaming probe of the ionic kernels' access
+    pattern on each and keeps the best.  With the size threshold lowered for the test (the product: 1 GB): the record names three
+    rates and the index of the largest, the array is zero-filled and of the layout an unplaced one has, a TP06 step on it equals the
+    step on an unplaced array bit for bit, and BEAT_STATE_PLACE=1 switches the choice off."""
+    from beat import _hip
+    from beat._device import StateArray
+    from oracle import ionic
+
+    n, S = 1 << 18, 19
+    monkeypatch.setenv("BEAT_STATE_PLACE_MIN_BYTES", str(1 << 20))
+    a = StateArray(hip_ctx, S, n, 4096)
+    rec = a.placement
+    assert rec is not None and len(rec["candidates"]) == 3 and rec["rows_probed"] == 19
+    assert rec["chosen"] == int(np.argmax(rec["candidates"])) and min(rec["candidates"]) > 0.0
+    assert float(a.buf.abs().max()) == 0.0
+    monkeypatch.setenv("BEAT_STATE_PLACE", "1")
+    b = StateArray(hip_ctx, S, n, 4096)
+    assert b.placement is None and (b.ld, b.base, tuple(b.rows.shape)) == (a.ld, a.base, tuple(a.rows.shape))
+    st = _random_tp06_states(n, 5)
+    P = np.ascontiguousarray(ionic.tp06_init_parameter_values(stim_amplitude=0.0))
+    outs = []
+    for sa in (a, b):
+        sa.set(st)
+        _hip.check(hip_ctx.lib.beat_ode_step(hip_ctx.handle, _hip.MODEL_TP06_GRL1, sa.ptr, n, sa.ld, P.ctypes.data_as(C.c_void_p), len(P),
+                                             None, 0, 1.0, 0.02, 17, None))
+        hip_ctx.synchronize()
+        outs.append(sa.numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    # a row count the probe has no instance for takes the largest it has; an odd plane (rows not 16-byte aligned) is not probed
+    monkeypatch.setenv("BEAT_STATE_PLACE", "2")
+    c = StateArray(hip_ctx, 7, n, 0)
+    assert c.placement is not None and c.placement["rows_probed"] == 4 and len(c.placement["candidates"]) == 2
+    d = StateArray(hip_ctx, 7, n + 1, 3)
+    assert float(d.buf.abs().max()) == 0.0  # (placed or not: a usable array either way)
+
+
 def test_tp06_many_steps_and_stimulus_window(hip_ctx):
     """2000 steps (20 ms at dt = 0.01) through an upstroke triggered by the model's own i_Stim:
     trajectories agree to 1e-7 relative (error growth through the stiff upstroke)."""
