@@ -305,9 +305,10 @@ class OdeFileModel(DeviceModel):
                 "  template <class P> __host__ __device__ static Derived derive(const P&) { return Derived{0.0}; }\n"
                 "  template <class IO, class P>\n"
                 "  __device__ static __forceinline__ void step(const IO& io, const P& p, const Derived&, const FastMath& fm, double t, double dt) {\n"
-                + ("    // (FastMath::exp takes [BEAT_EXP_LO, BEAT_EXP_HI]; outside: what libm / NumPy give -- NaN stays NaN, overflow is inf, below -708 it is 0 where libm still has subnormals)\n"
-                   "    const auto fexp = [&fm](double x) { const double e = fm.exp(beat_clamp_exp_arg(x));\n"
-                   "                                        return x != x ? x : (x < BEAT_EXP_LO ? 0.0 : beat_exp_overflow(x, e)); };\n" if self.fast_exp else "")
+                + ("    // (what libm / NumPy give everywhere: NaN stays NaN, overflow is inf, underflow goes through the subnormals to 0)\n"
+                   "    // (k = round(x 256 / ln 2) must fit 32 bits: the clamp; inside it v_ldexp_f64 underflows to 0 through the subnormals and\n"
+                   "    // overflows to inf as libm does; the clamp turns a NaN argument into a number, hence the select)\n"
+                   "    const auto fexp = [&fm](double x) { const double e = fm.exp(fmin(fmax(x, -1.0e6), 1.0e3)); return x != x ? x : e; };\n" if self.fast_exp else "")
                 + "    const auto beat_sel = [](bool c, double a, double b) { return c ? a : b; };\n"
                 + "\n".join(loads + pl + lines + body) + "\n  }\n};\n")
 

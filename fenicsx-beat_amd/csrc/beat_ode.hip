@@ -66,7 +66,10 @@ extern "C" int beat_ode_run(beat_ctx* ctx, int model_id, double* dev_states, int
 }
 
 // blocks of an ionic launch over n nodes
-static unsigned ode_grid(int64_t n) {
+// (num_states: a block's set-up -- 4 KB of tables into LDS, a barrier -- is 2 % of what a TP06 tile moves and 20 - 50 % of what a tile of
+// a 2- or 5-state model moves: models below BEAT_ODE_TILE_MIN_STATES (12) keep the capped, looping launch of rounds 2 - 5; the
+// generated 5-state test model 0.455 ms per step at 256^3 with a block per tile, 0.43 with 24 576 looping blocks)
+static unsigned ode_grid(int64_t n, int num_states) {
   unsigned grid = (unsigned)((n + BEAT_BLOCK - 1) / BEAT_BLOCK);
   // Round 6: ONE BLOCK PER TILE is the default.  Rounds 2 - 5 capped the launch at 24 576 blocks walking ~21 tiles each: at three
   // waves per SIMD a block's set-up (4 KB of tables into LDS, a barrier) was worth amortising (10.5 - 10.6 against 10.9 - 11.3 ms at
@@ -75,10 +78,15 @@ static unsigned ode_grid(int64_t n) {
   // for one workgroup per chunk (profiles/r05_streaming.md): TP06 512^3 in one process on the same memory 8.70 -> 8.49 - 8.54 ms
   // (16 384 blocks: 8.75, 32 768: 8.65, 8 192: 8.98), class kernel 8.87 -> 8.57, ToR-ORd 256^3 2.49 -> 2.44; the 512^3 step 13.33 -
   // 13.57 -> 13.04 - 13.27 ms, process by process (profiles/r06_ode_addressing.md).  BEAT_ODE_GRID=<blocks> caps the launch again.
-  static const int grid_cap = [] {  // blocks per launch (BEAT_ODE_GRID; 0: one block per tile)
+  static const int grid_cap_env = [] {  // blocks per launch (BEAT_ODE_GRID; 0: one block per tile; unset: by the model's size)
     const char* e = std::getenv("BEAT_ODE_GRID");
-    return e ? std::atoi(e) : 0;
+    return e ? std::atoi(e) : -1;
   }();
+  static const int tile_min_states = [] {
+    const char* e = std::getenv("BEAT_ODE_TILE_MIN_STATES");
+    return e ? std::atoi(e) : 12;
+  }();
+  const int grid_cap = grid_cap_env >= 0 ? grid_cap_env : (num_states >= tile_min_states ? 0 : 24576);
   static const bool balance = [] {  // BEAT_ODE_BALANCE=0: plain cap (A/B runs)
     const char* e = std::getenv("BEAT_ODE_BALANCE");
     return !(e && e[0] == '0');
@@ -114,7 +122,7 @@ static int launch_ode(beat_ctx* ctx, double* states, int64_t n, int64_t ld, cons
   ParamPack<Model::NP> prm;
   for (int k = 0; k < Model::NP; ++k) prm.p[k] = host_params ? host_params[k] : 1.0;
   typename Model::Derived drv = Model::derive(prm.p);
-  const unsigned grid = ode_grid(n);
+  const unsigned grid = ode_grid(n, Model::NS);
   const dim3 g3(grid), b3(BEAT_BLOCK);
 #define BEAT_LAUNCH_ODE(PN, PD)                                                                                 \
   BEAT_KERNEL((ode_step_kernel<Model, PN, PD>), g3, b3, 0, ctx->stream, states, n, ld, prm, drv, ppn, pld, t, \
@@ -193,7 +201,9 @@ static int ode_step_dispatch(beat_ctx* ctx, int model_id, double* dev_states, in
   if (n == 0) return BEAT_OK;
   if (model_id >= BEAT_MODEL_CUSTOM_BASE) {  // a model registered as source (beat_ode_model_register)
     BEAT_REQUIRE(sp.count == 0, "a model registered as source takes a uniform vector, all per-node rows or classes (no sparse rows)");
-    return beat_custom_step(ctx, model_id, ode_grid(n), dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt,
+    int cns = 0, cnp = 0, cvi = 0;
+    if (int rc = beat_custom_model_info(model_id, &cns, &cnp, &cvi)) return rc;
+    return beat_custom_step(ctx, model_id, ode_grid(n, cns), dev_states, n, ld, host_params, num_params, dev_params_per_node, params_ld, t, dt,
                             v_index, dev_v_copy, pend, mk);
   }
 #define BEAT_STEP(M)                                                                                             \
