@@ -277,9 +277,10 @@ __global__ __launch_bounds__(BEAT_BLOCK, (PER_NODE && CT::count == 0) ? Model::W
   // (blockIdx.x / 256) % 3 -- to de-phase their load bursts: 9.83 against 9.78 ms at 512^3, A B A B A B on one box.  The
   // 24 576 blocks of a launch replace each other on the CUs 32 times over; whatever phase they start in is gone after
   // the first round.)
-  // a block walks over several tiles of 256 nodes (stride gridDim.x) and pays its launch and the table set-up once:
-  // at 512^3, 24 576 blocks of ~21 tiles each measured 10.5-10.6 ms against 10.9-11.3 for one block per tile on the
-  // same box (768 blocks, i.e. exactly the resident number: 11.5; 3 072: 10.7; 196 608: 10.9)
+  // A block takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... -- since round 6 the launch has ONE BLOCK PER TILE for models of 12
+  // states and more (beat_ode.hip: ode_grid; at four / three waves per SIMD the other blocks of the CU cover a block's table
+  // set-up, and blocks dispatched in order keep the launch in one moving window of the rows); rounds 2 - 5 launched 24 576 blocks
+  // of ~21 tiles each (at three waves per SIMD: 10.5-10.6 ms against 10.9-11.3 for one block per tile), which small models keep.
   // (the wave's number in the block lives in an SGPR; the lane number is taken from mbcnt per tile, opaque: whatever is derived from
   // threadIdx.x -- its 64-bit extension, its byte offset -- would otherwise be kept in VGPRs across the tile loop, three of the 128
   // that four waves per SIMD have: see BEAT_TID_PER_TILE below)

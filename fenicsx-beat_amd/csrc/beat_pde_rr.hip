@@ -173,11 +173,18 @@ __device__ __forceinline__ int xcd_block(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
+// waves per SIMD asked of the register allocator: the right-hand side with a guess (two register windows) / the iteration's two passes
+#ifndef BEAT_RR_WAVES_RHS
+#define BEAT_RR_WAVES_RHS 3
+#endif
+#ifndef BEAT_RR_WAVES_IT
+#define BEAT_RR_WAVES_IT 1
+#endif
 // X / X2 / Y / Y2: the fields of RArgs::x, x2 (RHS with a guess: e), y, y2 as separate restrict-qualified kernel parameters -- the launch
 // passes distinct buffers (the residual update writes r out of place), and without the no-alias guarantee every
 // store would have to complete (s_waitcnt vmcnt(0)) before the next plane's loads may issue.
 template <int MODE, int RY, int PD, bool GUESS = false>
-__global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? 3 : 1) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
+__global__ __launch_bounds__(BEAT_BLOCK, (GUESS && RY == 2 && PD == 1) ? BEAT_RR_WAVES_RHS : ((MODE == RR_PDOT || MODE == RR_RUPD) && PD == 1 ? BEAT_RR_WAVES_IT : 1)) void rr_kernel(RGeom g, RArgs a, const double* __restrict__ X,
                                                         const double* __restrict__ X2, double* __restrict__ Y,
                                                         double* __restrict__ Y2) {
   constexpr int NR = RY + 2;
