@@ -993,6 +993,7 @@ def main():
                 # where the state array lies decides how fast its rows stream: StateArray allocates a few candidates, times the
                 # library's streaming probe of the ionic kernels' pattern on each and keeps the best (beat/_device.py; GB/s)
                 "state_placement": getattr(states, "placement", None),
+                "work_placement": getattr(ops, "work_placement", None),  # the PCG's work fields, placed the same way (beat/_engine.py)
                 "ode_ms": ode_ms,
                 "pde_ms": pde_ms,
                 "v_min": vmin,

@@ -170,7 +170,8 @@ class HipOps:
         self.mass_tab, self.stiff_tab = mt, kt
         nfields = max(4, int(self.lib.beat_pde_work_fields(handle)))  # see beat_pde_solve
         fld = int(self.lib.beat_pde_field_stride(handle))  # a field with its ghost planes (+ padding against channel aliasing)
-        self.work = ctx.zeros(nfields * fld)
+        self.work_placement = None
+        self.work = self._place_work(ctx, nfields, fld)
         from ._device import Field
 
         # same layout as beat_pde_solve: r, q, z, ring[...]; p is ring[0] for the in-place recurrences
@@ -401,6 +402,47 @@ class HipOps:
         if self.on_finish is not None:
             self.on_finish(res)
         return res
+
+    def _place_work(self, ctx, nfields: int, fld: int):
+        """The PCG's work fields (r, q, z, the ring): like the state array (``StateArray._place_buffer``, profiles/r06_placement.md) a
+        buffer of 1 GB or more is the best of BEAT_WORK_PLACE (default 3; 1: off) allocations by the library's streaming probe over
+        four of the fields -- the ring's directions are read by the ionic kernel as well (the pending update): ten bench processes,
+        alternating, 12.10 - 12.25 -> 12.03 - 12.11 ms per 512^3 step, developed front 14.19 - 14.49 -> 13.96 - 14.26
+        (profiles/r06_ab_work_place.txt)."""
+        import os
+
+        tries = int(os.environ.get("BEAT_WORK_PLACE", "3"))
+        numel = nfields * fld
+        if tries <= 1 or 8 * numel < int(os.environ.get("BEAT_STATE_PLACE_MIN_BYTES", str(1 << 30))) or (fld & 1) or (self.plane & 1):
+            return ctx.zeros(numel)
+        torch = ctx.torch
+
+        def rate(buf):
+            ptr = C.c_void_p(buf.data_ptr() + 8 * self.plane)
+            ts = []
+            for it in range(4):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(ctx.stream)
+                _hip.check(self.lib.beat_stream_probe(ctx.handle, ptr, self.n & ~1, 4, 3, 1, 0, 4, fld))
+                b.record(ctx.stream)
+                b.synchronize()
+                if it:
+                    ts.append(a.elapsed_time(b))
+            return 2.0 * 4 * (self.n & ~1) * 8 / (sorted(ts)[len(ts) // 2] * 1e6)
+
+        cands, rates = [], []
+        for _ in range(tries):
+            free_b, _t = torch.cuda.mem_get_info(ctx.device)
+            if cands and free_b < 2 * 8 * numel:
+                break
+            cands.append(ctx.zeros(numel))
+            rates.append(rate(cands[-1]))
+        best = max(range(len(cands)), key=lambda j: rates[j])
+        buf = cands[best]
+        self.work_placement = {"candidates": [round(r, 1) for r in rates], "chosen": best, "unit": "GB/s"}
+        del cands
+        torch.cuda.empty_cache()
+        return buf
 
     def solve_finish(self):
         """Wait for the open solve (more iterations are enqueued if it needs them), take its record; what it leaves pending
